@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the batched hot path on N MI355X (one process per GPU).
+
+A "step" = one pass of the hot path over one batch: every lane advanced by one fixed integrator
+step dt = 1e-3 s with the command held, `odeSolver = "runge_kutta_4"` (4 dynamics evaluations:
+FK + spring-damper contacts + motor law + ABA), then the extra terms and the sensor refresh
+(the unit of work of BASELINE.md section 3).  Workload = BASELINE.json configs[2]: ANYmal
+(nq 19, nv 18, 12 motors, 4 contact points), batch 65 536 per GPU (weak scaling), float64 like the
+reference, seeded synthetic states resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (`k_batch`) vs the HBM roof, from per-launch HIP-event timing on the
+                launch stream; `traffic` = PMC-measured HBM bytes per launch when profiles/ holds it
+  cpu_baseline  the CPU oracle ("port" of the reference's single-threaded algorithm) timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_scalars(model) -> int:
+    """Scalars that must cross HBM once per env-step (SURVEY.md 8d / BASELINE.md section 3):
+    reads q, v, a_prev, command; writes q, v, a; writes the sensor outputs."""
+    s = model.sensors
+    obs = 6 * len(s.get("ImuSensor", [])) + 6 * len(s.get("ForceSensor", [])) \
+        + 3 * len(s.get("ContactSensor", [])) + 2 * len(s.get("EncoderSensor", [])) \
+        + len(s.get("EffortSensor", []))
+    return (model.nq + 2 * model.nv + model.nmotors) + (model.nq + 2 * model.nv) + obs
+
+
+def cpu_baseline(model, states, dt: float, budget_s: float = 12.0):
+    """Oracle timed on the host: 1 thread (the reference's shape: one engine, one robot, one
+    thread), then all cores with independent slices (the SubprocVecEnv analogue without IPC)."""
+    from oracle.oracle_py import OracleEngine
+    from tests.helpers import alloc_soa, oracle_io
+
+    def make(B):
+        arr = alloc_soa(model, B)
+        for k in ("q", "v", "command"):
+            arr[k][:] = states[k][:, :B]
+        return arr
+
+    n_lanes, n_steps = 512, 4
+    arr = make(n_lanes)
+    e = OracleEngine(model)
+    io = oracle_io(arr)
+    e.batch_run("start", io)
+    e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < budget_s * 0.5:
+        for _ in range(n_steps):
+            e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1,
+                        command_changed=False)
+        done += n_lanes * n_steps
+    single = done / (time.perf_counter() - t0)
+
+    cores = os.cpu_count() or 1
+    per = 256
+    arrs = [make(per) for _ in range(cores)]
+    engines = [OracleEngine(model) for _ in range(cores)]
+    ios = [oracle_io(a) for a in arrs]
+    for eng, i in zip(engines, ios):
+        eng.batch_run("start", i)
+    counts = [0] * cores
+    stop_at = time.perf_counter() + budget_s * 0.5
+
+    def work(k):
+        while time.perf_counter() < stop_at:
+            engines[k].batch_run("step", ios[k], solver="runge_kutta_4", dt=dt, n_substeps=1,
+                                 command_changed=False)
+            counts[k] += per
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    multi = sum(counts) / (time.perf_counter() - t0)
+    return {
+        "value": single, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{n_lanes} lanes of the same seeded ANYmal batch stepped for ~{budget_s * 0.5:.0f} s "
+                  f"by oracle/liboracle.so (g++ -O3, float64, RK4 dt={dt})",
+        "all_cores": {"value": multi, "cores": cores,
+                      "sample": f"{cores} threads x {per} lanes, independent slices, "
+                                f"~{budget_s * 0.5:.0f} s"},
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="lanes per GPU")
+    ap.add_argument("--model", default="anymal")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--solver", default="runge_kutta_4")
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--gather-obs", action="store_true",
+                    help="all-gather the observation block over RCCL every step (config 4 topology)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.synthetic import sample_states
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    model = load_builtin(args.model)
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    B = args.batch
+    states = sample_states(model, B, seed=rank)
+    eng = BatchedEngine(model, B, dtype=dtype, device=device, extra_outputs=("contact_forces",))
+    eng.set_options({"stepper": {"odeSolver": args.solver, "dtMax": args.dt,
+                                 "controllerUpdatePeriod": args.dt, "sensorsUpdatePeriod": args.dt}})
+    eng.set_command(torch.from_numpy(states["command"]).to(dtype))
+    eng.start(torch.from_numpy(states["q"]).to(dtype), torch.from_numpy(states["v"]).to(dtype))
+
+    obs_rows = [eng.field(k) for k in ("imu", "force", "encoder", "effort") if eng._rows[k] > 0]
+    gather_out = None
+
+    def one_step() -> None:
+        eng.step(args.dt)
+        if args.gather_obs and world > 1:
+            from jiminy_amd.distributed import all_gather_observations
+            nonlocal gather_out
+            gather_out = all_gather_observations(obs_rows, gather_out)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_launch, kernel_ms = eng.timing_summary()
+    eng.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    status = eng.status.cpu().numpy()
+    ok_frac = float((status == 0).mean())
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        scal = algorithmic_scalars(model)
+        sz = 8 if args.dtype == "f64" else 4
+        alg_bytes_per_launch = scal * sz * B
+        avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                if pmc.get("batch") == B and pmc.get("model") == args.model and pmc.get("dtype") == args.dtype:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} nq{model.nq} nv{model.nv} {model.nmotors} motors "
+                                   f"{model.ncontacts} spring-damper contact points, "
+                                   f"{args.solver} dt={args.dt} command held, extra terms + sensors",
+                       "lanes_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"
+                                      + (" + obs all-gather" if args.gather_obs else ""),
+                       "lanes_ok_at_end": ok_frac},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "jm::k_batch", "launches_timed": n_launch,
+                         "avg_launch_ms": 1e3 * avg_launch_s,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.model == "anymal":
+            out["cpu_baseline"] = cpu_baseline(model, states, args.dt)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+/* jiminy_hip.h -- C ABI of the MI355X-native batched rigid-body dynamics library.
+ *
+ * This is the drop-in boundary for ONE hot path of duburcqa/jiminy: the per-step
+ * physics (ABA forward dynamics with rotor armature + spring-damper contact
+ * forces + SimpleMotor law + explicit Euler / RK4 step on the configuration
+ * manifold + the RNEA-style "extra terms" + noiseless sensors), batched one robot
+ * per wavefront lane on gfx950.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference tree, duburcqa/jiminy @ v1.8.12):
+ *
+ *   jm_model_create     Robot::pinocchioModel_ + motors/sensors/contact registries as seen
+ *                       by the engine (core/src/robot/model.cc, robot.cc; built on the Python
+ *                       side by jiminy_py/robot.py:518-860).  Binding replaced:
+ *                       python/jiminy_pywrap/src/robot.cc (Robot.initialize, attach_motor, ...)
+ *   jm_batch_create     Engine::add_robot + RobotState/StepperState allocation
+ *                       (core/include/jiminy/core/engine/engine.h:134-156, 216-250;
+ *                        python/jiminy_pywrap/src/engine.cc:600-606)
+ *   jm_batch_bind       the numpy views on Eigen buffers (`DEF_READONLY` on RobotState::q...,
+ *                       python/jiminy_pywrap/src/engine.cc:173-188): here the caller owns
+ *                       the memory and lends device pointers
+ *   jm_batch_set_options Engine::setOptions, hot-path subset (core/src/engine/engine.cc:2654-2795)
+ *   jm_batch_start      Engine::start (core/src/engine/engine.cc:952-1533)
+ *   jm_batch_stop       Engine::stop (core/src/engine/engine.cc:2419-2460)
+ *   jm_batch_step       Engine::step fixed-step branch (core/src/engine/engine.cc:1724-2417)
+ *                       = AbstractStepper::tryStep (core/src/stepper/abstract_stepper.cc:15-62)
+ *                       + computeAllExtraTerms (engine.cc:800-915) + computeSensorMeasurements
+ *   jm_batch_dynamics   Engine::computeRobotsDynamics (core/src/engine/engine.cc:3585-3708;
+ *                       python binding `compute_robots_dynamics`, pywrap engine.cc:634-638)
+ *   jm_batch_reset_lanes BaseJiminyEnv.reset state injection for a subset of the batch
+ *                       (python/gym_jiminy/common/gym_jiminy/common/envs/generic.py:521-760)
+ *   jm_last_error       JIMINY_THROW message text (core/include/jiminy/core/macros.h:82-86)
+ *
+ * Conventions: all batch arrays are structure-of-arrays `X[component][B]` (component-major,
+ * lane-contiguous) of the batch scalar type (float64 or float32), living in device memory
+ * owned by the caller.  Spatial vectors are [linear; angular], quaternions xyzw, free-flyer
+ * velocity is expressed in the body frame (engine.cc:3591-3592).
+ * All functions return 0 on success and a negative JM_E* code otherwise; they never throw.
+ * Numerical failures are per lane: see the `status` field.
+ */
+#ifndef JIMINY_HIP_H
+#define JIMINY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (mapped by the Python facade to the exception classes of
+ *      python/jiminy_pywrap/src/module.cc:96-103) */
+#define JM_OK 0
+#define JM_EINVAL (-1)      /* std::invalid_argument  -> ValueError   */
+#define JM_ERUNTIME (-2)    /* std::runtime_error     -> RuntimeError */
+#define JM_ECONTROLFLOW (-3)/* jiminy::bad_control_flow -> BadControlFlow */
+#define JM_ELOOKUP (-4)     /* jiminy::lookup_error   -> LookupError  */
+#define JM_ENOTIMPL (-5)    /* jiminy::not_implemented_error -> NotImplementedError */
+#define JM_ETOPOLOGY (-6)   /* model topology does not match the compiled-in specialisation */
+
+/* ---- joint type codes (core/include/jiminy/core/fwd.h:84-96 groups them as
+ *      LINEAR / ROTARY / ROTARY_UNBOUNDED / FREE; the axis variant is explicit here) */
+enum {
+    JM_JT_NONE = 0,
+    JM_JT_RX = 1, JM_JT_RY = 2, JM_JT_RZ = 3, JM_JT_RU = 4,
+    JM_JT_PX = 5, JM_JT_PY = 6, JM_JT_PZ = 7, JM_JT_PU = 8,
+    JM_JT_RUBX = 9, JM_JT_RUBY = 10, JM_JT_RUBZ = 11, JM_JT_RUBU = 12,
+    JM_JT_FREEFLYER = 13
+};
+
+/* ---- scalar type of a batch */
+enum { JM_F64 = 0, JM_F32 = 1 };
+
+/* ---- ODE solvers (core/include/jiminy/core/engine/engine.h:30-38 `odeSolver`) */
+enum { JM_SOLVER_EULER_EXPLICIT = 0, JM_SOLVER_RUNGE_KUTTA_4 = 1 };
+
+/* ---- motor flags */
+enum { JM_MOTOR_EFFORT_LIMIT = 1, JM_MOTOR_VELOCITY_LIMIT = 2, JM_MOTOR_FRICTION = 4 };
+
+/* number of doubles per motor in `motor_params`:
+ * reduction, effortLimit, velocityLimit, velocityEffortInvSlope,
+ * frictionViscousPositive, frictionViscousNegative, frictionDryPositive,
+ * frictionDryNegative, frictionDrySlope  (core/src/hardware/basic_motors.cc:83-143) */
+#define JM_MOTOR_NPARAMS 9
+
+/* ---- per-lane status bits written by the kernels */
+enum {
+    JM_LANE_OK = 0,
+    JM_LANE_NAN = 1,            /* NaN in q/v/a (engine.cc:1737-1747, abstract_stepper.cc:41-48) */
+    JM_LANE_OUT_OF_BOUNDS = 2,  /* a bounded joint left [lower, upper]: the reference would switch
+                                   to its constraint solver (engine.cc:3285-3298, 3722) */
+    JM_LANE_FORCE_OVERFLOW = 4  /* initial contact force > 1e5 N (engine.cc:1338-1345) */
+};
+
+/* ---- model description: plain arrays, all host memory, copied by jm_model_create.
+ * Joint 0 is the universe. Matrices are row-major 3x3. */
+typedef struct jm_model_desc {
+    int32_t njoints, nq, nv;
+    int32_t nmotors, ncontacts;
+    int32_t nimu, nforce, ncontact_sensors, nencoder, neffort;
+    const int32_t * parents;       /* [njoints] */
+    const int32_t * jtypes;        /* [njoints] JM_JT_* */
+    const int32_t * idx_q;         /* [njoints] */
+    const int32_t * idx_v;         /* [njoints] */
+    const double * axes;           /* [njoints*3] unit axis (unaligned joints) */
+    const double * placement_R;    /* [njoints*9] joint placement wrt parent joint */
+    const double * placement_p;    /* [njoints*3] */
+    const double * mass;           /* [njoints] */
+    const double * com;            /* [njoints*3] */
+    const double * inertia;        /* [njoints*9] rotational inertia about the COM */
+    const double * rotor_inertia;  /* [nv] armature on joint side */
+    const double * position_lower; /* [nq] */
+    const double * position_upper; /* [nq] */
+    const int32_t * motor_joint;   /* [nmotors] */
+    const int32_t * motor_flags;   /* [nmotors] JM_MOTOR_* */
+    const double * motor_params;   /* [nmotors*JM_MOTOR_NPARAMS] */
+    const int32_t * contact_joint; /* [ncontacts] parent joint of the contact frame */
+    const double * contact_R;      /* [ncontacts*9] frame placement in the joint frame */
+    const double * contact_p;      /* [ncontacts*3] */
+    const int32_t * imu_joint;     /* [nimu] */
+    const double * imu_R;          /* [nimu*9] */
+    const double * imu_p;          /* [nimu*3] */
+    const int32_t * force_joint;   /* [nforce] */
+    const double * force_R;        /* [nforce*9] */
+    const double * force_p;        /* [nforce*3] */
+    const int32_t * contact_sensor_contact; /* [ncontact_sensors] index into contacts */
+    const int32_t * encoder_joint;          /* [nencoder] */
+    const int32_t * encoder_joint_side;     /* [nencoder] 1 = joint side */
+    const double * encoder_reduction;       /* [nencoder] */
+    const int32_t * effort_motor;           /* [neffort] motor index */
+} jm_model_desc;
+
+/* ---- hot-path subset of the engine options, same names/defaults as the reference
+ * (core/include/jiminy/core/engine/engine.h:273-325) */
+typedef struct jm_options {
+    double gravity[6];                 /* world.gravity, default (0,0,-9.81,0,0,0) */
+    double contact_stiffness;          /* contacts.stiffness          1e6  */
+    double contact_damping;            /* contacts.damping            2e3  */
+    double contact_friction;           /* contacts.friction           1.0  */
+    double contact_transition_eps;     /* contacts.transitionEps      1e-3 */
+    double contact_transition_velocity;/* contacts.transitionVelocity 1e-2 */
+} jm_options;
+
+/* ---- bindable batch fields (jm_batch_bind).  Shapes are [rows][B]. */
+enum {
+    JM_F_Q = 0,            /* [nq]      in/out  RobotState::q            */
+    JM_F_V = 1,            /* [nv]      in/out  RobotState::v            */
+    JM_F_A = 2,            /* [nv]      in/out  RobotState::a            */
+    JM_F_COMMAND = 3,      /* [nmotors] in      RobotState::command      */
+    JM_F_U_MOTOR = 4,      /* [nmotors] out     RobotState::uMotor       */
+    JM_F_U = 5,            /* [nv]      out     RobotState::u            */
+    JM_F_F_EXTERNAL = 6,   /* [njoints*6] out   RobotState::fExternal (joint frame)   optional */
+    JM_F_CONTACT_FORCES = 7,/* [ncontacts*6] out Robot::contactForces_ (contact frame) optional */
+    JM_F_IMU = 8,          /* [nimu*6]   out  gyro(3), accel(3)  (basic_sensors.cc:142-164) */
+    JM_F_FORCE = 9,        /* [nforce*6] out  (basic_sensors.cc:368-387) */
+    JM_F_CONTACT = 10,     /* [ncontact_sensors*3] out (basic_sensors.cc:267-277) */
+    JM_F_ENCODER = 11,     /* [nencoder*2] out Q,V (basic_sensors.cc:509-539) */
+    JM_F_EFFORT = 12,      /* [neffort]  out  (basic_sensors.cc:604-618) */
+    JM_F_ENERGY = 13,      /* [2] out kinetic, potential (engine.cc:808-810)       optional */
+    JM_F_JOINT_FORCES = 14,/* [njoints*6] out data.f joint internal wrenches (engine.cc:878-887) optional */
+    JM_F_CENTROIDAL = 15,  /* [15] out com(3), hg(6), dhg(6) (engine.cc:889-904)    optional */
+    JM_F_STATUS = 16,      /* [1] int32 per lane, JM_LANE_* bits */
+    JM_F_WORKSPACE = 17,   /* scratch, jm_batch_workspace_rows() rows */
+    JM_F_COUNT = 18
+};
+
+typedef struct jm_model jm_model;
+typedef struct jm_batch jm_batch;
+
+/* Topology signature the library was specialised for (see DESIGN.md "model compilation"). */
+const char * jm_topology_signature(void);
+/* ABI version of this header. */
+int32_t jm_abi_version(void);
+
+int32_t jm_model_create(const jm_model_desc * desc, jm_model ** out);
+int32_t jm_model_destroy(jm_model * model);
+
+/* `device` is the HIP device ordinal the batch lives on. */
+int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtype,
+                        int32_t device, jm_batch ** out);
+int32_t jm_batch_destroy(jm_batch * batch);
+int32_t jm_batch_set_options(jm_batch * batch, const jm_options * options);
+/* Number of [B]-rows of scratch the caller must provide through JM_F_WORKSPACE. */
+int32_t jm_batch_workspace_rows(const jm_batch * batch);
+/* Lend a device pointer for one field; NULL unbinds an optional output. */
+int32_t jm_batch_bind(jm_batch * batch, int32_t field, void * device_ptr);
+
+/* Engine::start: from bound (q, v, command) compute a, extra terms and sensors;
+ * checks the initial contact forces. `stream` is a hipStream_t (NULL = default). */
+int32_t jm_batch_start(jm_batch * batch, void * stream);
+/* Engine::stop (core/src/engine/engine.cc:2419-2460): the model may be re-configured again. */
+int32_t jm_batch_stop(jm_batch * batch);
+/* Engine::step fixed-step branch: `n_substeps` integrator steps of `dt` with the command
+ * held. `command_changed` != 0 re-evaluates a(t+) with the current command before the
+ * first sub-step (engine.cc:2030-2042); `update_sensors` != 0 refreshes the sensor outputs
+ * at the end (engine.cc:2386-2410). */
+int32_t jm_batch_step(jm_batch * batch, int32_t solver, double dt, int32_t n_substeps,
+                      int32_t command_changed, int32_t update_sensors, void * stream);
+/* Engine::computeRobotsDynamics: a = f(q, v) with the bound command; q_in/v_in are device
+ * arrays [nq][B] / [nv][B]; a_out [nv][B]. Does not modify the bound state. */
+int32_t jm_batch_dynamics(jm_batch * batch, const void * q_in, const void * v_in,
+                          void * a_out, void * stream);
+/* Re-initialise the lanes whose mask byte is non-zero from (q_init, v_init) ([nq][B], [nv][B]):
+ * copies the state, zeroes a, then performs the `start` computation for those lanes only. */
+int32_t jm_batch_reset_lanes(jm_batch * batch, const uint8_t * lane_mask,
+                             const void * q_init, const void * v_init, void * stream);
+
+/* Per-launch kernel timing with HIP events recorded on the launch stream around every kernel
+ * launch of this batch (up to 2048 launches between two summaries).  `jm_batch_timing_summary`
+ * blocks until the recorded launches completed, returns their count and summed duration (ms)
+ * and restarts the recording. */
+int32_t jm_batch_enable_timing(jm_batch * batch, int32_t enable);
+int32_t jm_batch_timing_summary(jm_batch * batch, int32_t * n_launches, double * total_ms);
+
+/* Copy the message of the last error raised on the calling thread. */
+int32_t jm_last_error(char * buffer, size_t size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JIMINY_HIP_H */

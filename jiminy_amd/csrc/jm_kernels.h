@@ -1,0 +1,816 @@
+// jm_kernels.h -- the batched per-step physics, one robot per wavefront lane (gfx950).
+//
+// The code is specialised at compile time on the robot TOPOLOGY (`Tp`: parents, joint types,
+// index maps, which joints carry motors / contact points / sensors -- a generated header, see
+// jiminy_amd/codegen.py) and reads every numeric PARAMETER (placements, inertias, limits,
+// gains, contact options) from a small block in the constant address space, i.e. through the
+// scalar cache into SGPRs: parameters are lane-uniform, state is per lane.
+//
+// Reference functions restated here (paths relative to the reference tree):
+//   eval_dynamics    Engine::computeRobotsDynamics              core/src/engine/engine.cc:3585-3708
+//     FK             Engine::computeForwardKinematics           engine.cc:2957-3014
+//     contacts       computeContactDynamicsAtFrame / computeContactDynamics   engine.cc:3117-3238
+//                    convertForceGlobalFrameToJoint              core/src/utilities/pinocchio.cc:794-809
+//     motors         SimpleMotor::computeEffort                 core/src/hardware/basic_motors.cc:83-143
+//     ABA            pinocchio_overload::aba / AbaBackwardStep  core/include/jiminy/core/robot/pinocchio_overload_algorithms.h:126-489
+//   integrate_q      State::sum -> pinocchio::integrate         core/include/jiminy/core/stepper/lie_group.h:446-455
+//   lane_run (step)  AbstractStepper::tryStep + RK4 / Euler     core/src/stepper/abstract_stepper.cc:15-62,
+//                    abstract_runge_kutta_stepper.cc:24-77, euler_explicit_stepper.cc:5-21,
+//                    tableau core/include/jiminy/core/stepper/runge_kutta4_stepper.h:12-23
+//   extra_terms      computeExtraTerms                          engine.cc:800-905
+//   write_sensors    Imu/Contact/Force/Encoder/EffortSensor::set core/src/hardware/basic_sensors.cc:142-164,
+//                    267-277, 368-387, 509-539, 604-618
+#pragma once
+#include <type_traits>
+
+#include "jm_math.h"
+#include "../../include/jiminy_hip.h"
+
+namespace jm
+{
+template<int I, int N, class F> JM_DEV void static_for(F && f)
+{
+    if constexpr (I < N)
+    {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// I = N-1 ... LO
+template<int LO, int N, class F> JM_DEV void static_rfor(F && f)
+{
+    if constexpr (N > LO)
+    {
+        f(std::integral_constant<int, N - 1>{});
+        static_rfor<LO, N - 1>(f);
+    }
+}
+
+constexpr bool jt_is_rev(int t) { return (t >= JM_JT_RX && t <= JM_JT_RU) || (t >= JM_JT_RUBX && t <= JM_JT_RUBU); }
+constexpr bool jt_is_pri(int t) { return t >= JM_JT_PX && t <= JM_JT_PU; }
+constexpr bool jt_is_unb(int t) { return t >= JM_JT_RUBX && t <= JM_JT_RUBU; }
+constexpr bool jt_bounded(int t) { return t >= JM_JT_RX && t <= JM_JT_PU; }
+constexpr int jt_axis(int t)  // 0,1,2 aligned; -1 unaligned
+{
+    return (t == JM_JT_RX || t == JM_JT_PX || t == JM_JT_RUBX) ? 0
+         : (t == JM_JT_RY || t == JM_JT_PY || t == JM_JT_RUBY) ? 1
+         : (t == JM_JT_RZ || t == JM_JT_PZ || t == JM_JT_RUBZ) ? 2 : -1;
+}
+constexpr int c_max(int a, int b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------- parameter block layout
+// Host packing: jiminy_amd/csrc/jm_lib.cpp pack_params(); same offsets.
+template<class Tp> struct Layout
+{
+    static constexpr int JSTRIDE = 25;  // R9 p3 | mass c3 I6(xx xy xz yy yz zz) | axis3
+    static constexpr int JOINT = 0;
+    static constexpr int ROTOR = JOINT + Tp::NJ * JSTRIDE;
+    static constexpr int QLO = ROTOR + Tp::NV;
+    static constexpr int QHI = QLO + Tp::NQ;
+    static constexpr int MOTOR = QHI + Tp::NQ;  // NM * 9
+    static constexpr int CONTACT = MOTOR + Tp::NM * JM_MOTOR_NPARAMS;  // NC * 12
+    static constexpr int IMU = CONTACT + Tp::NC * 12;                  // NIMU * 12
+    static constexpr int FREL = IMU + Tp::NIMU * 12;                   // NFORCE * NC * 12
+    static constexpr int ENC = FREL + Tp::NFORCE * Tp::NC * 12;        // NENC
+    static constexpr int OPT = ENC + Tp::NENC;  // gravity6 k c mu eps vt
+    static constexpr int TOTAL = OPT + 11;
+};
+
+#ifdef JM_HOST_EMU
+template<class T> using CPtr = const T *;
+#else
+template<class T> using CPtr = const T __attribute__((address_space(4))) *;
+#endif
+
+template<class T> JM_DEV M3<T> ld_m3(CPtr<T> P, int o)
+{
+    return {P[o], P[o + 1], P[o + 2], P[o + 3], P[o + 4], P[o + 5], P[o + 6], P[o + 7], P[o + 8]};
+}
+template<class T> JM_DEV V3<T> ld_v3(CPtr<T> P, int o) { return {P[o], P[o + 1], P[o + 2]}; }
+template<class T> JM_DEV SE3<T> ld_se3(CPtr<T> P, int o) { return {ld_m3<T>(P, o), ld_v3<T>(P, o + 9)}; }
+template<class T> JM_DEV RBI<T> ld_rbi(CPtr<T> P, int o)
+{
+    return {P[o], ld_v3<T>(P, o + 1), S3<T>{P[o + 4], P[o + 5], P[o + 6], P[o + 7], P[o + 8], P[o + 9]}};
+}
+
+// ---------------------------------------------------------------- kernel arguments
+template<class T> struct BatchArgs
+{
+    const T * P;           // parameter block (device, Layout<Tp>::TOTAL scalars)
+    T * q; T * v; T * a;   // state, [rows][B]
+    const T * command;
+    T * u_motor; T * u;
+    T * f_external; T * contact_forces;
+    T * imu; T * force; T * contact; T * encoder; T * effort;
+    T * energy; T * joint_forces; T * centroidal;
+    int32_t * status;
+    T * ws;                // workspace rows (unused by the LDS variant, kept for large models)
+    const T * q_in; const T * v_in; T * a_out;                     // MODE_DYNAMICS
+    const unsigned char * mask; const T * q_init; const T * v_init;  // MODE_RESET
+    long long B;
+    int mode, solver, n_sub, command_changed, update_sensors;
+    T dt;
+};
+enum { MODE_STEP = 0, MODE_START = 1, MODE_DYNAMICS = 2, MODE_RESET = 3 };
+
+// ---------------------------------------------------------------- per-lane working set
+template<class T, class Tp> struct Work
+{
+    SE3<T> liMi[Tp::NJ];
+    SE3<T> oMi[Tp::NJ];
+    Sp<T> vel[Tp::NJ];
+    Sp<T> agf[Tp::NJ];
+    Sp<T> f[Tp::NJ];
+    Sp<T> fext[Tp::NJ];
+    Sp<T> cf[c_max(Tp::NC, 1)];  // contact forces, contact frame (Robot::contactForces_)
+    Sp<T> U[Tp::NJ];
+    T dinv[Tp::NJ];
+    T u[Tp::NV];
+    T ueff[Tp::NV];              // total effort vector (RobotState::u)
+    T umotor[c_max(Tp::NM, 1)];
+    T ddq[Tp::NV];
+    int status;
+};
+
+template<class T, class Tp, int J> JM_DEV V3<T> joint_axis(CPtr<T> P)
+{
+    constexpr int ax = jt_axis(Tp::jtype[J]);
+    if constexpr (ax == 0) return {T(1), T(0), T(0)};
+    else if constexpr (ax == 1) return {T(0), T(1), T(0)};
+    else if constexpr (ax == 2) return {T(0), T(0), T(1)};
+    else return ld_v3<T>(P, Layout<Tp>::JOINT + J * Layout<Tp>::JSTRIDE + 22);
+}
+
+// joint transform M_j(q) and joint velocity S qd
+template<class T, class Tp, int J>
+JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> & vj)
+{
+    constexpr int t = Tp::jtype[J];
+    constexpr int iq = Tp::idx_q[J], iv = Tp::idx_v[J];
+    if constexpr (t == JM_JT_FREEFLYER)
+    {
+        Mj.R = quat_to_matrix(q[iq + 3], q[iq + 4], q[iq + 5], q[iq + 6]);
+        Mj.p = {q[iq], q[iq + 1], q[iq + 2]};
+        vj = {{v[iv], v[iv + 1], v[iv + 2]}, {v[iv + 3], v[iv + 4], v[iv + 5]}};
+    }
+    else if constexpr (jt_is_rev(t))
+    {
+        T c, s;
+        if constexpr (jt_is_unb(t)) { c = q[iq]; s = q[iq + 1]; }
+        else sincos_(q[iq], &s, &c);
+        constexpr int ax = jt_axis(t);
+        const V3<T> n = joint_axis<T, Tp, J>(P);
+        if constexpr (ax >= 0) Mj.R = rot_axis<T>(ax, c, s);
+        else Mj.R = rot_rodrigues(n, c, s);
+        Mj.p = zero3<T>();
+        vj = {zero3<T>(), v[iv] * n};
+    }
+    else
+    {
+        const V3<T> n = joint_axis<T, Tp, J>(P);
+        Mj.R = ident3<T>();
+        Mj.p = q[iq] * n;
+        vj = {v[iv] * n, zero3<T>()};
+    }
+}
+template<class T, class Tp, int J> JM_DEV Sp<T> joint_S_times(CPtr<T> P, const T * x)
+{
+    constexpr int t = Tp::jtype[J];
+    constexpr int iv = Tp::idx_v[J];
+    if constexpr (t == JM_JT_FREEFLYER)
+        return {{x[iv], x[iv + 1], x[iv + 2]}, {x[iv + 3], x[iv + 4], x[iv + 5]}};
+    else if constexpr (jt_is_rev(t))
+        return {zero3<T>(), x[iv] * joint_axis<T, Tp, J>(P)};
+    else
+        return {x[iv] * joint_axis<T, Tp, J>(P), zero3<T>()};
+}
+// S^T f for 1-dof joints
+template<class T, class Tp, int J> JM_DEV T joint_St_dot(CPtr<T> P, Sp<T> f)
+{
+    constexpr int t = Tp::jtype[J];
+    constexpr int ax = jt_axis(t);
+    const V3<T> w = jt_is_rev(t) ? f.a : f.l;
+    if constexpr (ax >= 0) return comp(w, ax);
+    else return dot(joint_axis<T, Tp, J>(P), w);
+}
+
+// Engine::computeContactDynamics (engine.cc:3197-3238), flat ground n = z
+template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> vW)
+{
+    using L = Layout<Tp>;
+    const T k = P[L::OPT + 6], c = P[L::OPT + 7], mu = P[L::OPT + 8], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    const T vDepth = vW.z;
+    const T fN = -fmin_(k * depth + c * vDepth, T(0));
+    const V3<T> vT = {vW.x, vW.y, vW.z - vDepth};
+    const T ratio = fmin_(sqrt_(dot(vT, vT)) / vt, T(1));
+    const T fT = mu * ratio * fN;
+    V3<T> f = {-fT * vT.x, -fT * vT.y, fN - fT * vT.z};
+    if (eps > Eps<T>::eps)
+    {
+        const T blend = tanh_(T(2) * (-depth / eps));
+        f = blend * f;
+    }
+    return f;
+}
+
+// symmetric 6x6 solve (Ia + diag(rot)) x = b through Cholesky (calc_aba free-flyer,
+// pinocchio_overload_algorithms.h:357-378; the explicit inverse of the reference is replaced by
+// one factorisation + one solve: x = Dinv (u - Ia a_gf))
+template<class T> JM_DEV void chol6_solve(T (&A)[6][6], T (&b)[6])
+{
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+        T s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
+        const T d = sqrt_(s);
+        const T dinv = T(1) / d;
+        A[j][j] = dinv;  // store inverse diagonal
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i)
+        {
+            T t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
+            A[i][j] = t * dinv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+    {
+        T s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= A[i][k] * b[k];
+        b[i] = s * A[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+    {
+        T s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= A[k][i] * b[k];
+        b[i] = s * A[i][i];
+    }
+}
+
+// ---------------------------------------------------------------- a = f(q, v) with held command
+template<class T, class Tp>
+JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Work<T, Tp> & w)
+{
+    using L = Layout<Tp>;
+    constexpr int NJ = Tp::NJ;
+    // ---- forward kinematics (+ ABA pass 1 velocity part)
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        SE3<T> Mj;
+        Sp<T> vj;
+        joint_calc<T, Tp, j>(P, q, v, Mj, vj);
+        const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+        w.liMi[j] = plc * Mj;
+        if constexpr (p > 0)
+        {
+            w.oMi[j] = w.oMi[p] * w.liMi[j];
+            w.vel[j] = vj + actinv_motion(w.liMi[j], w.vel[p]);
+        }
+        else
+        {
+            w.oMi[j] = w.liMi[j];
+            w.vel[j] = vj;
+        }
+        w.agf[j] = cross_mm(w.vel[j], vj);  // c_j = 0 for every supported joint
+        w.fext[j] = zero6<T>();
+        if constexpr (jt_bounded(Tp::jtype[j]))
+        {
+            constexpr int iq = Tp::idx_q[j];
+            if (P[L::QHI + iq] < q[iq] || q[iq] < P[L::QLO + iq]) w.status |= JM_LANE_OUT_OF_BOUNDS;
+        }
+    });
+    // ---- spring-damper contact forces (engine.cc:3394-3425)
+    static_for<0, Tp::NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int j = Tp::contact_joint[c];
+        const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);
+        const T depth = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, fr.p);
+        Sp<T> fl = zero6<T>();
+        if (depth < T(0))
+        {
+            // world velocity of the contact point: oMi.R (v_lin + w x p_frame)
+            const V3<T> vj = w.vel[j].l + cross(w.vel[j].a, fr.p);
+            const V3<T> vW = w.oMi[j].R * vj;
+            const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
+            fl.l = tmul(w.oMi[j].R, fW);
+            fl.a = cross(fr.p, fl.l);
+        }
+        w.fext[j] = w.fext[j] + fl;
+        w.cf[c] = actinv_force(fr, fl);
+    });
+    // ---- motors (basic_motors.cc:83-143) and total effort
+    static_for<0, Tp::NV>([&](auto ic) { w.ueff[decltype(ic)::value] = T(0); });
+    static_for<0, Tp::NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int j = Tp::motor_joint[m];
+        constexpr int iv = Tp::idx_v[j];
+        constexpr int fl = Tp::motor_flags[m];
+        constexpr int o = L::MOTOR + JM_MOTOR_NPARAMS * m;
+        const T red = P[o], elim = P[o + 1], vlim = P[o + 2], islope = P[o + 3];
+        const T vjnt = v[iv];
+        const T vmot = red * vjnt;
+        T um = cmd[m];
+        if constexpr ((fl & JM_MOTOR_EFFORT_LIMIT) != 0)
+        {
+            T emin = -elim, emax = elim;
+            if constexpr ((fl & JM_MOTOR_VELOCITY_LIMIT) != 0)
+            {
+                const T vdelta = elim * islope;
+                if (vdelta > T(0))
+                {
+                    const T vthr = fmax_(vlim - vdelta, T(0));
+                    const T inv = T(1) / (vlim - vthr);
+                    emin *= clamp_((vlim + vmot) * inv, T(0), T(1));
+                    emax *= clamp_((vlim - vmot) * inv, T(0), T(1));
+                }
+            }
+            um = clamp_(um, emin, emax);
+        }
+        T ut = red * um;
+        if constexpr ((fl & JM_MOTOR_FRICTION) != 0)
+        {
+            const T fds = P[o + 8];
+            if (vjnt > T(0)) ut += P[o + 4] * vjnt + P[o + 6] * tanh_(fds * vjnt);
+            else ut += P[o + 5] * vjnt + P[o + 7] * tanh_(fds * vjnt);
+        }
+        w.umotor[m] = um;
+        w.ueff[iv] += ut;
+    });
+    static_for<0, Tp::NV>([&](auto ic) { w.u[decltype(ic)::value] = w.ueff[decltype(ic)::value]; });
+    // ---- ABA pass 1 (force part): f = v x* (I v) - fext
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+        const Sp<T> h = rbi_mul(Y, w.vel[j]);
+        w.f[j] = cross_mf(w.vel[j], h) - w.fext[j];
+    });
+    // ---- ABA pass 2 (AbaBackwardStep), leaves -> root
+    AI<T> Yacc[NJ];
+    static_rfor<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        constexpr int t = Tp::jtype[j];
+        constexpr int iv = Tp::idx_v[j];
+        AI<T> Ia;
+        if constexpr (Tp::nchildren[j] > 0) Ia = Yacc[j];
+        else Ia = ai_from_rbi(ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+        if constexpr (t == JM_JT_FREEFLYER)
+        {
+            static_assert(t != JM_JT_FREEFLYER || p == 0, "free-flyer joints are only supported at the root");
+            // u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf   (solved in pass 3 order right here)
+            const SE3<T> & M = w.liMi[j];
+            const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+            const Sp<T> a0 = {-g, -gw};
+            w.agf[j] = w.agf[j] + actinv_motion(M, a0);
+            const Sp<T> Ya = ai_mul(Ia, w.agf[j]);
+            T b[6] = {w.u[iv] - w.f[j].l.x - Ya.l.x, w.u[iv + 1] - w.f[j].l.y - Ya.l.y, w.u[iv + 2] - w.f[j].l.z - Ya.l.z,
+                      w.u[iv + 3] - w.f[j].a.x - Ya.a.x, w.u[iv + 4] - w.f[j].a.y - Ya.a.y, w.u[iv + 5] - w.f[j].a.z - Ya.a.z};
+            T A[6][6];
+            A[0][0] = Ia.A.xx; A[1][0] = Ia.A.xy; A[2][0] = Ia.A.xz; A[1][1] = Ia.A.yy; A[2][1] = Ia.A.yz; A[2][2] = Ia.A.zz;
+            // lower-left block = B^T : A[3+i][k] = B[k][i]
+            A[3][0] = Ia.B.m00; A[3][1] = Ia.B.m10; A[3][2] = Ia.B.m20;
+            A[4][0] = Ia.B.m01; A[4][1] = Ia.B.m11; A[4][2] = Ia.B.m21;
+            A[5][0] = Ia.B.m02; A[5][1] = Ia.B.m12; A[5][2] = Ia.B.m22;
+            A[3][3] = Ia.D.xx; A[4][3] = Ia.D.xy; A[5][3] = Ia.D.xz; A[4][4] = Ia.D.yy; A[5][4] = Ia.D.yz; A[5][5] = Ia.D.zz;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) A[k][k] += P[L::ROTOR + iv + k];
+            chol6_solve(A, b);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w.ddq[iv + k] = b[k];
+            w.agf[j] = w.agf[j] + Sp<T>{{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
+        }
+        else
+        {
+            const V3<T> n = joint_axis<T, Tp, j>(P);
+            const T uj = w.u[iv] - joint_St_dot<T, Tp, j>(P, w.f[j]);
+            w.u[iv] = uj;
+            Sp<T> U;
+            if constexpr (jt_is_rev(t)) U = {Ia.B * n, Ia.D * n};
+            else U = {Ia.A * n, tmul(Ia.B, n)};
+            const T D = joint_St_dot<T, Tp, j>(P, U) + P[L::ROTOR + iv];
+            const T dinv = T(1) / D;
+            w.U[j] = U;
+            w.dinv[j] = dinv;
+            if constexpr (p > 0)
+            {
+                ai_rank1_sub(Ia, U, dinv);
+                const Sp<T> Ya = ai_mul(Ia, w.agf[j]);
+                const T ud = uj * dinv;
+                const Sp<T> pa = {w.f[j].l + Ya.l + ud * U.l, w.f[j].a + Ya.a + ud * U.a};
+                const AI<T> Tr = ai_transform(w.liMi[j], Ia);
+                if constexpr (Tp::first_child[p] == j)
+                    Yacc[p] = ai_from_rbi(ld_rbi<T>(P, L::JOINT + p * L::JSTRIDE + 12)) + Tr;
+                else
+                    Yacc[p] = Yacc[p] + Tr;
+                w.f[p] = w.f[p] + act_force(w.liMi[j], pa);
+            }
+        }
+    });
+    // ---- ABA pass 3 (AbaForwardStep2), root -> leaves
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        constexpr int t = Tp::jtype[j];
+        constexpr int iv = Tp::idx_v[j];
+        if constexpr (t != JM_JT_FREEFLYER)
+        {
+            Sp<T> ap;
+            if constexpr (p > 0) ap = w.agf[p];
+            else
+            {
+                const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+                ap = {-g, -gw};
+            }
+            const Sp<T> ag = w.agf[j] + actinv_motion(w.liMi[j], ap);
+            const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
+            const T dd = w.dinv[j] * (w.u[iv] - Ua);
+            w.ddq[iv] = dd;
+            const V3<T> n = joint_axis<T, Tp, j>(P);
+            if constexpr (jt_is_rev(t)) w.agf[j] = {ag.l, ag.a + dd * n};
+            else w.agf[j] = {ag.l + dd * n, ag.a};
+        }
+    });
+    static_for<0, Tp::NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (w.ddq[i] != w.ddq[i]) w.status |= JM_LANE_NAN;
+    });
+}
+
+// ---------------------------------------------------------------- q (+) dv on the manifold
+template<class T, class Tp> JM_DEV void integrate_q(CPtr<T> P, const T * q, const T * d, T * qo)
+{
+    static_for<1, Tp::NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int t = Tp::jtype[j];
+        constexpr int iq = Tp::idx_q[j], iv = Tp::idx_v[j];
+        if constexpr (t == JM_JT_FREEFLYER)
+        {
+            SE3<T> M0;
+            M0.R = quat_to_matrix(q[iq + 3], q[iq + 4], q[iq + 5], q[iq + 6]);
+            M0.p = {q[iq], q[iq + 1], q[iq + 2]};
+            const Sp<T> nu = {{d[iv], d[iv + 1], d[iv + 2]}, {d[iv + 3], d[iv + 4], d[iv + 5]}};
+            const SE3<T> M1 = M0 * exp6(nu);
+            T x, y, z, ww;
+            matrix_to_quat(M1.R, x, y, z, ww);
+            const T dp = x * q[iq + 3] + y * q[iq + 4] + z * q[iq + 5] + ww * q[iq + 6];
+            const T sg = dp < T(0) ? T(-1) : T(1);
+            const T n2 = x * x + y * y + z * z + ww * ww;
+            const T al = sg * (T(3) - n2) * T(0.5);
+            qo[iq] = M1.p.x; qo[iq + 1] = M1.p.y; qo[iq + 2] = M1.p.z;
+            qo[iq + 3] = x * al; qo[iq + 4] = y * al; qo[iq + 5] = z * al; qo[iq + 6] = ww * al;
+        }
+        else if constexpr (jt_is_unb(t))
+        {
+            T sw, cw;
+            sincos_(d[iv], &sw, &cw);
+            const T c = cw * q[iq] - sw * q[iq + 1], s = sw * q[iq] + cw * q[iq + 1];
+            const T k = (T(3) - (c * c + s * s)) * T(0.5);
+            qo[iq] = c * k; qo[iq + 1] = s * k;
+        }
+        else
+            qo[iq] = q[iq] + d[iv];
+    });
+    (void)P;
+}
+
+// ---------------------------------------------------------------- extra terms + sensors
+// Uses the kinematic data (liMi, oMi, vel, fext, cf, umotor) left in `w` by the last dynamics
+// evaluation, which is at the new state (engine.cc:2143-2151).
+template<class T, class Tp>
+JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long lane, const T * q, const T * v,
+                                    const T * acc, Work<T, Tp> & w, bool sensors)
+{
+    using L = Layout<Tp>;
+    constexpr int NJ = Tp::NJ;
+    const long long B = A.B;
+    const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+    // true spatial accelerations (ForwardKinematicsAccelerationStep, engine.cc:858-868)
+    Sp<T> da[NJ], dagf[NJ];
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        const Sp<T> vj = joint_S_times<T, Tp, j>(P, v);
+        const Sp<T> aj = cross_mm(w.vel[j], vj) + joint_S_times<T, Tp, j>(P, acc);
+        if constexpr (p > 0)
+        {
+            da[j] = aj + actinv_motion(w.liMi[j], da[p]);
+            dagf[j] = aj + actinv_motion(w.liMi[j], dagf[p]);
+        }
+        else
+        {
+            da[j] = aj;  // data.a[0] = 0
+            dagf[j] = aj + actinv_motion(w.liMi[j], Sp<T>{-g, -gw});
+        }
+    });
+    if (A.energy)
+    {
+        T kin = T(0), pot = T(0), rot = T(0);
+        static_for<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+            kin += rbi_vtiv(Y, w.vel[j]);
+            const V3<T> cg = w.oMi[j].p + w.oMi[j].R * Y.c;
+            pot -= Y.m * dot(cg, g);
+        });
+        static_for<0, Tp::NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            rot += P[L::ROTOR + i] * v[i] * v[i];
+        });
+        A.energy[lane] = T(0.5) * kin + T(0.5) * rot;
+        A.energy[B + lane] = pot;
+    }
+    if (A.joint_forces || A.centroidal)
+    {
+        // RNEA-like sweeps (engine.cc:870-887)
+        Sp<T> h[NJ], fB[NJ], fj[NJ];
+        static_for<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+            h[j] = rbi_mul(Y, w.vel[j]);
+            const Sp<T> vxh = cross_mf(w.vel[j], h[j]);
+            fB[j] = rbi_mul(Y, da[j]) + vxh;
+            fj[j] = vxh + rbi_mul(Y, dagf[j]) - w.fext[j];
+        });
+        Sp<T> h0 = zero6<T>(), fB0 = zero6<T>();
+        static_rfor<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int p = Tp::parent[j];
+            if constexpr (p > 0)
+            {
+                fB[p] = fB[p] + act_force(w.liMi[j], fB[j]);
+                h[p] = h[p] + act_force(w.liMi[j], h[j]);
+                fj[p] = fj[p] + act_force(w.liMi[j], fj[j]);
+            }
+            else
+            {
+                fB0 = fB0 + act_force(w.liMi[j], fB[j]);
+                h0 = h0 + act_force(w.liMi[j], h[j]);
+            }
+        });
+        if (A.joint_forces)
+        {
+            static_for<0, 6>([&](auto kc) { A.joint_forces[decltype(kc)::value * B + lane] = T(0); });
+            static_for<1, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                T * o = A.joint_forces + (long long)(6 * j) * B + lane;
+                o[0] = fj[j].l.x; o[B] = fj[j].l.y; o[2 * B] = fj[j].l.z;
+                o[3 * B] = fj[j].a.x; o[4 * B] = fj[j].a.y; o[5 * B] = fj[j].a.z;
+            });
+        }
+        if (A.centroidal)
+        {
+            // subtree inertia of joint 1 (engine.cc:817-832) -> com (engine.cc:889-904)
+            T ms[NJ];
+            V3<T> mc[NJ];  // mass * com of each subtree, in the joint frame
+            static_for<1, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+                ms[j] = Y.m;
+                mc[j] = Y.m * Y.c;
+            });
+            static_rfor<2, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int p = Tp::parent[j];
+                if constexpr (p > 0)
+                {
+                    mc[p] = mc[p] + w.liMi[j].R * mc[j] + ms[j] * w.liMi[j].p;
+                    ms[p] = ms[p] + ms[j];
+                }
+            });
+            const V3<T> c1 = (T(1) / ms[1]) * mc[1];
+            const V3<T> com0 = w.liMi[1].R * c1 + w.liMi[1].p;
+            Sp<T> hg = h0, dhg = fB0;
+            hg.a = hg.a + cross(hg.l, com0);
+            dhg.a = dhg.a + cross(dhg.l, com0);
+            T * o = A.centroidal + lane;
+            o[0] = com0.x; o[B] = com0.y; o[2 * B] = com0.z;
+            o[3 * B] = hg.l.x; o[4 * B] = hg.l.y; o[5 * B] = hg.l.z; o[6 * B] = hg.a.x; o[7 * B] = hg.a.y; o[8 * B] = hg.a.z;
+            o[9 * B] = dhg.l.x; o[10 * B] = dhg.l.y; o[11 * B] = dhg.l.z; o[12 * B] = dhg.a.x; o[13 * B] = dhg.a.y; o[14 * B] = dhg.a.z;
+        }
+    }
+    if (A.f_external)
+    {
+        static_for<0, 6>([&](auto kc) { A.f_external[decltype(kc)::value * B + lane] = T(0); });
+        static_for<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            T * o = A.f_external + (long long)(6 * j) * B + lane;
+            o[0] = w.fext[j].l.x; o[B] = w.fext[j].l.y; o[2 * B] = w.fext[j].l.z;
+            o[3 * B] = w.fext[j].a.x; o[4 * B] = w.fext[j].a.y; o[5 * B] = w.fext[j].a.z;
+        });
+    }
+    if (A.contact_forces)
+        static_for<0, Tp::NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            T * o = A.contact_forces + (long long)(6 * c) * B + lane;
+            o[0] = w.cf[c].l.x; o[B] = w.cf[c].l.y; o[2 * B] = w.cf[c].l.z;
+            o[3 * B] = w.cf[c].a.x; o[4 * B] = w.cf[c].a.y; o[5 * B] = w.cf[c].a.z;
+        });
+    if (A.u_motor)
+        static_for<0, Tp::NM>([&](auto mc) { A.u_motor[decltype(mc)::value * B + lane] = w.umotor[decltype(mc)::value]; });
+    if (A.u)
+        static_for<0, Tp::NV>([&](auto ic) { A.u[decltype(ic)::value * B + lane] = w.ueff[decltype(ic)::value]; });
+    if (!sensors) return;
+    // ---- sensors (basic_sensors.cc)
+    if (A.imu)
+        static_for<0, Tp::NIMU>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int j = Tp::imu_joint[s];
+            const SE3<T> fr = ld_se3<T>(P, L::IMU + 12 * s);
+            const Sp<T> vf = actinv_motion(fr, w.vel[j]);
+            Sp<T> af = actinv_motion(fr, da[j]);
+            af.l = af.l + cross(vf.a, vf.l);
+            const V3<T> gl = tmul(fr.R, tmul(w.oMi[j].R, g));  // (oMi.R fr.R)^T g
+            const V3<T> acc3 = af.l - gl;
+            T * o = A.imu + (long long)(6 * s) * B + lane;
+            o[0] = vf.a.x; o[B] = vf.a.y; o[2 * B] = vf.a.z; o[3 * B] = acc3.x; o[4 * B] = acc3.y; o[5 * B] = acc3.z;
+        });
+    if (A.contact)
+        static_for<0, Tp::NCS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int c = Tp::cs_contact[s];
+            T * o = A.contact + (long long)(3 * s) * B + lane;
+            o[0] = w.cf[c].l.x; o[B] = w.cf[c].l.y; o[2 * B] = w.cf[c].l.z;
+        });
+    if (A.force)
+        static_for<0, Tp::NFORCE>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            Sp<T> sum = zero6<T>();
+            static_for<0, Tp::NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (Tp::contact_joint[c] == Tp::force_joint[s])
+                {
+                    const SE3<T> rel = ld_se3<T>(P, L::FREL + 12 * (s * Tp::NC + c));
+                    sum = sum + act_force(rel, w.cf[c]);
+                }
+            });
+            T * o = A.force + (long long)(6 * s) * B + lane;
+            o[0] = sum.l.x; o[B] = sum.l.y; o[2 * B] = sum.l.z; o[3 * B] = sum.a.x; o[4 * B] = sum.a.y; o[5 * B] = sum.a.z;
+        });
+    if (A.encoder)
+        static_for<0, Tp::NENC>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int j = Tp::enc_joint[s];
+            constexpr int iq = Tp::idx_q[j], iv = Tp::idx_v[j];
+            T pos;
+            if constexpr (jt_is_unb(Tp::jtype[j])) pos = atan2_(q[iq + 1], q[iq]);
+            else pos = q[iq];
+            T vel = v[iv];
+            if constexpr (Tp::enc_side[s] == 0)
+            {
+                const T red = P[L::ENC + s];
+                pos *= red;
+                vel *= red;
+            }
+            A.encoder[(long long)(2 * s) * B + lane] = pos;
+            A.encoder[(long long)(2 * s + 1) * B + lane] = vel;
+        });
+    if (A.effort)
+        static_for<0, Tp::NEFF>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            A.effort[(long long)s * B + lane] = w.umotor[Tp::eff_motor[s]];
+        });
+}
+
+// ---------------------------------------------------------------- one lane, all modes
+// `sb` is the per-lane stage buffer (LDS on the GPU): element r at sb[r * SBS].
+// Rows: [0,NV) accumulated velocity increment, [NV,2NV) accumulated acceleration increment,
+//       [2NV,3NV) velocity of the previous stage.
+template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
+
+template<class T, class Tp, int SBS>
+JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
+{
+    using L = Layout<Tp>;
+    constexpr int NQ = Tp::NQ, NV = Tp::NV, NM = Tp::NM;
+    const long long B = A.B;
+    CPtr<T> P = (CPtr<T>)A.P;
+    Work<T, Tp> w;
+    w.status = 0;
+    T qs[NQ], vs[NV], as[NV], cmd[c_max(NM, 1)];
+    static_for<0, NM>([&](auto mc) { cmd[decltype(mc)::value] = A.command[decltype(mc)::value * B + lane]; });
+
+    if (A.mode == MODE_RESET)
+    {
+        if (!A.mask[lane]) return;
+        static_for<0, NQ>([&](auto ic) { A.q[decltype(ic)::value * B + lane] = A.q_init[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = A.v_init[decltype(ic)::value * B + lane]; });
+    }
+    if (A.mode != MODE_STEP)
+    {
+        // one evaluation at the given state
+        const T * qsrc = (A.mode == MODE_DYNAMICS) ? A.q_in : A.q;
+        const T * vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
+        static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
+        eval_dynamics<T, Tp>(P, qs, vs, cmd, w);
+        if (A.mode == MODE_DYNAMICS)
+        {
+            static_for<0, NV>([&](auto ic) { A.a_out[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
+            return;
+        }
+        // Engine::start: refuse huge initial contact forces (engine.cc:1310-1346)
+        T fmax2 = T(0);
+        static_for<0, Tp::NC>([&](auto cc) {
+            const Sp<T> & f = w.cf[decltype(cc)::value];
+            fmax2 = fmax_(fmax2, dot(f.l, f.l));
+        });
+        if (fmax2 > T(1e10)) w.status |= JM_LANE_FORCE_OVERFLOW;
+        static_for<0, NV>([&](auto ic) { A.a[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
+        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, w.ddq, w, true);
+        if (A.status) A.status[lane] = w.status;
+        return;
+    }
+
+    // ---- MODE_STEP: n_sub fixed steps of dt with the command held
+    const T dt = A.dt;
+    const bool rk4 = A.solver == JM_SOLVER_RUNGE_KUTTA_4;
+    const int evals_per_step = rk4 ? 4 : 1;
+    const int pre = A.command_changed ? 1 : 0;
+    const int n_evals = pre + A.n_sub * evals_per_step;
+    // NaN guard on the incoming state (engine.cc:1737-1747)
+    {
+        bool bad = false;
+        static_for<0, NQ>([&](auto ic) { const T x = A.q[decltype(ic)::value * B + lane]; bad |= (x != x); });
+        static_for<0, NV>([&](auto ic) { const T x = A.v[decltype(ic)::value * B + lane]; bad |= (x != x); });
+        static_for<0, NV>([&](auto ic) { const T x = A.a[decltype(ic)::value * B + lane]; bad |= (x != x); });
+        if (bad) w.status |= JM_LANE_NAN;
+    }
+#pragma nounroll
+    for (int e = 0; e < n_evals; ++e)
+    {
+        // stage index within the sub-step: -1 = a(t+) refresh, 0..2 = RK stages 1..3, 3 = final
+        const int k = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+        if (k == -1)
+        {
+            static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
+            static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = A.v[decltype(ic)::value * B + lane]; });
+        }
+        else
+        {
+            // previous stage derivative (kv, ka): for the first stage it is the state (v, a)
+            const bool first = rk4 ? (k == 0) : true;
+            T q0[NQ], incv[NV];
+            static_for<0, NQ>([&](auto ic) { q0[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
+            // weights: b of the previous stage for the accumulators, A(i, i-1) for the stage state
+            T bw, aw;
+            if (rk4)
+            {
+                // accumulate derivative k_k with its own weight b_k (b = 1/6, 1/3, 1/3, 1/6)
+                bw = (k == 0 || k == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0);
+                aw = (k == 2) ? dt : dt * T(0.5);
+            }
+            else { bw = dt; aw = dt; }
+            static_for<0, NV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const T v0 = A.v[i * B + lane];
+                const T kv = first ? v0 : sb[(2 * NV + i) * SBS];
+                const T ka = first ? A.a[i * B + lane] : as[i];
+                T accv, acca;
+                if (!rk4) { accv = bw * kv; acca = bw * ka; }
+                else
+                {
+                    accv = first ? bw * kv : sb[i * SBS] + bw * kv;
+                    acca = first ? bw * ka : sb[(NV + i) * SBS] + bw * ka;
+                    if (k != 3) { sb[i * SBS] = accv; sb[(NV + i) * SBS] = acca; }
+                }
+                if (k == 3) { incv[i] = accv; vs[i] = v0 + acca; }
+                else { incv[i] = aw * kv; vs[i] = v0 + aw * ka; sb[(2 * NV + i) * SBS] = vs[i]; }
+            });
+            integrate_q<T, Tp>(P, q0, incv, qs);
+            if (k == 3)
+            {
+                static_for<0, NQ>([&](auto ic) { A.q[decltype(ic)::value * B + lane] = qs[decltype(ic)::value]; });
+                static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = vs[decltype(ic)::value]; });
+            }
+        }
+        eval_dynamics<T, Tp>(P, qs, vs, cmd, w);
+        static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = w.ddq[decltype(ic)::value]; });
+        if (k == -1 || k == 3)
+            static_for<0, NV>([&](auto ic) { A.a[decltype(ic)::value * B + lane] = as[decltype(ic)::value]; });
+        if (e == n_evals - 1)
+        {
+            extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.update_sensors != 0);
+            if (A.status) A.status[lane] = w.status;
+        }
+    }
+}
+
+#ifndef JM_HOST_EMU
+template<class T, class Tp>
+__global__ void __launch_bounds__(64) k_batch(const BatchArgs<T> A)
+{
+    __shared__ T lds[stage_rows<Tp>() * 64];
+    const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= A.B) return;
+    lane_run<T, Tp, 64>(A, lane, lds + threadIdx.x);
+}
+#endif
+}  // namespace jm

@@ -1,0 +1,347 @@
+// jm_lib.cpp -- C ABI (include/jiminy_hip.h) of the per-topology HIP library, compiled with
+// `hipcc --offload-arch=gfx950 -x hip -DJM_TOPO_HEADER="topo_<hash>.h"` (jiminy_amd/codegen.py).
+//
+// The library owns only the model constants (host copy + one small device block per batch).
+// All batch state is borrowed from the caller as raw device pointers; nothing is allocated
+// inside start/step/dynamics (mirrors the reference's "no malloc during step" guarantee,
+// core/unit/engine_sanity_check.cc:118-121).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#ifndef JM_TOPO_HEADER
+#error "JM_TOPO_HEADER must name the generated topology header"
+#endif
+#include JM_TOPO_HEADER
+
+#include "jm_kernels.h"
+#include "jm_pack.h"
+
+#define JM_ABI_VERSION 1
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string & msg)
+{
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do                                                                                             \
+    {                                                                                              \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(JM_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+}  // namespace
+
+struct jm_model
+{
+    std::vector<double> params;  // Layout<Topo>, options tail = defaults
+};
+
+struct jm_batch
+{
+    const jm_model * model = nullptr;
+    long long B = 0;
+    int dtype = JM_F64;
+    int device = 0;
+    std::vector<double> params;
+    void * d_params = nullptr;
+    void * field[JM_F_COUNT] = {};
+    bool started = false;
+    // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // pairs (begin, end), ring of JM_TIMING_RING launches
+    size_t n_timed = 0;
+};
+#define JM_TIMING_RING 2048
+
+namespace
+{
+int32_t upload_params(jm_batch * b)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t n = b->params.size();
+    if (b->dtype == JM_F64)
+    {
+        HIP_TRY(hipMemcpy(b->d_params, b->params.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    else
+    {
+        std::vector<float> pf(n);
+        for (size_t i = 0; i < n; ++i) pf[i] = (float)b->params[i];
+        HIP_TRY(hipMemcpy(b->d_params, pf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return JM_OK;
+}
+
+template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
+{
+    jm::BatchArgs<T> A;
+    std::memset(&A, 0, sizeof(A));
+    A.P = (const T *)b->d_params;
+    A.q = (T *)b->field[JM_F_Q];
+    A.v = (T *)b->field[JM_F_V];
+    A.a = (T *)b->field[JM_F_A];
+    A.command = (const T *)b->field[JM_F_COMMAND];
+    A.u_motor = (T *)b->field[JM_F_U_MOTOR];
+    A.u = (T *)b->field[JM_F_U];
+    A.f_external = (T *)b->field[JM_F_F_EXTERNAL];
+    A.contact_forces = (T *)b->field[JM_F_CONTACT_FORCES];
+    A.imu = (T *)b->field[JM_F_IMU];
+    A.force = (T *)b->field[JM_F_FORCE];
+    A.contact = (T *)b->field[JM_F_CONTACT];
+    A.encoder = (T *)b->field[JM_F_ENCODER];
+    A.effort = (T *)b->field[JM_F_EFFORT];
+    A.energy = (T *)b->field[JM_F_ENERGY];
+    A.joint_forces = (T *)b->field[JM_F_JOINT_FORCES];
+    A.centroidal = (T *)b->field[JM_F_CENTROIDAL];
+    A.status = (int32_t *)b->field[JM_F_STATUS];
+    A.ws = (T *)b->field[JM_F_WORKSPACE];
+    A.B = b->B;
+    return A;
+}
+
+template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stream)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    const hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((b->B + 63) / 64);
+    const bool timed = b->timing && b->n_timed < JM_TIMING_RING;
+    if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
+    hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);
+    HIP_TRY(hipGetLastError());
+    if (timed)
+    {
+        HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed + 1], s));
+        ++b->n_timed;
+    }
+    return JM_OK;
+}
+
+int32_t check_bound(const jm_batch * b, bool need_command)
+{
+    if (!b->field[JM_F_Q] || !b->field[JM_F_V] || !b->field[JM_F_A])
+        return fail(JM_ECONTROLFLOW, "state fields q, v, a must be bound before this call");
+    if (need_command && Topo::NM > 0 && !b->field[JM_F_COMMAND])
+        return fail(JM_ECONTROLFLOW, "the command field must be bound before this call");
+    return JM_OK;
+}
+}  // namespace
+
+extern "C"
+{
+const char * jm_topology_signature(void) { return Topo::signature; }
+int32_t jm_abi_version(void) { return JM_ABI_VERSION; }
+
+int32_t jm_model_create(const jm_model_desc * desc, jm_model ** out)
+{
+    if (!desc || !out) return fail(JM_EINVAL, "jm_model_create: null argument");
+    std::string why;
+    if (!jm::check_topology<Topo>(*desc, why)) return fail(JM_ETOPOLOGY, why);
+    jm_model * m = new (std::nothrow) jm_model();
+    if (!m) return fail(JM_ERUNTIME, "out of host memory");
+    m->params = jm::pack_model<Topo>(*desc);
+    jm::pack_options<Topo>(m->params, jm::default_options());
+    *out = m;
+    return JM_OK;
+}
+int32_t jm_model_destroy(jm_model * model)
+{
+    delete model;
+    return JM_OK;
+}
+
+int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtype, int32_t device, jm_batch ** out)
+{
+    if (!model || !out) return fail(JM_EINVAL, "jm_batch_create: null argument");
+    if (batch_size <= 0) return fail(JM_EINVAL, "batch size must be positive");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "dtype must be JM_F64 or JM_F32");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(JM_EINVAL, "invalid HIP device ordinal");
+    jm_batch * b = new (std::nothrow) jm_batch();
+    if (!b) return fail(JM_ERUNTIME, "out of host memory");
+    b->model = model;
+    b->B = batch_size;
+    b->dtype = dtype;
+    b->device = device;
+    b->params = model->params;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&b->d_params, b->params.size() * sizeof(double));
+    if (e != hipSuccess)
+    {
+        delete b;
+        return fail(JM_ERUNTIME, std::string("jm_batch_create: ") + hipGetErrorString(e));
+    }
+    const int32_t rc = upload_params(b);
+    if (rc != JM_OK)
+    {
+        jm_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return JM_OK;
+}
+int32_t jm_batch_destroy(jm_batch * b)
+{
+    if (!b) return JM_OK;
+    (void)hipSetDevice(b->device);
+    if (b->d_params) (void)hipFree(b->d_params);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+    delete b;
+    return JM_OK;
+}
+int32_t jm_batch_set_options(jm_batch * b, const jm_options * o)
+{
+    if (!b || !o) return fail(JM_EINVAL, "jm_batch_set_options: null argument");
+    if (b->started)
+        return fail(JM_ECONTROLFLOW, "options cannot be changed while a simulation is running");  // engine.cc:2656-2662
+    if (!(o->contact_stiffness >= 0.0) || !(o->contact_damping >= 0.0) || !(o->contact_friction >= 0.0))
+        return fail(JM_EINVAL, "contact stiffness, damping and friction must be non-negative");
+    if (!(o->contact_transition_velocity > 0.0)) return fail(JM_EINVAL, "contacts.transitionVelocity must be positive");
+    if (o->contact_transition_eps < 0.0) return fail(JM_EINVAL, "contacts.transitionEps must be non-negative");  // engine.cc:2697-2702
+    jm::pack_options<Topo>(b->params, *o);
+    return upload_params(b);
+}
+int32_t jm_batch_workspace_rows(const jm_batch *) { return 0; }
+int32_t jm_batch_bind(jm_batch * b, int32_t field, void * ptr)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_bind: null batch");
+    if (field < 0 || field >= JM_F_COUNT) return fail(JM_ELOOKUP, "jm_batch_bind: unknown field id");
+    b->field[field] = ptr;
+    return JM_OK;
+}
+
+int32_t jm_batch_start(jm_batch * b, void * stream)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_start: null batch");
+    int32_t rc = check_bound(b, true);
+    if (rc != JM_OK) return rc;
+    if (b->dtype == JM_F64)
+    {
+        auto A = make_args<double>(b);
+        A.mode = jm::MODE_START;
+        rc = launch<double>(b, A, stream);
+    }
+    else
+    {
+        auto A = make_args<float>(b);
+        A.mode = jm::MODE_START;
+        rc = launch<float>(b, A, stream);
+    }
+    if (rc == JM_OK) b->started = true;
+    return rc;
+}
+
+int32_t jm_batch_stop(jm_batch * b)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_stop: null batch");
+    b->started = false;
+    return JM_OK;
+}
+
+int32_t jm_batch_step(jm_batch * b, int32_t solver, double dt, int32_t n_substeps, int32_t command_changed,
+                      int32_t update_sensors, void * stream)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_step: null batch");
+    if (!b->started)
+        return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before using step method.");  // engine.cc:1727-1731
+    if (solver != JM_SOLVER_EULER_EXPLICIT && solver != JM_SOLVER_RUNGE_KUTTA_4)
+        return fail(JM_ENOTIMPL, "only 'euler_explicit' and 'runge_kutta_4' are available on the batched path");
+    if (!(dt >= 1e-6) || !(dt <= 0.02 + 1e-12))
+        return fail(JM_EINVAL, "Step size out of bounds.");  // engine.cc:1750-1753, constants.h:18-20
+    if (n_substeps < 1) return fail(JM_EINVAL, "n_substeps must be >= 1");
+    int32_t rc = check_bound(b, true);
+    if (rc != JM_OK) return rc;
+    if (b->dtype == JM_F64)
+    {
+        auto A = make_args<double>(b);
+        A.mode = jm::MODE_STEP; A.solver = solver; A.dt = dt; A.n_sub = n_substeps;
+        A.command_changed = command_changed; A.update_sensors = update_sensors;
+        return launch<double>(b, A, stream);
+    }
+    auto A = make_args<float>(b);
+    A.mode = jm::MODE_STEP; A.solver = solver; A.dt = (float)dt; A.n_sub = n_substeps;
+    A.command_changed = command_changed; A.update_sensors = update_sensors;
+    return launch<float>(b, A, stream);
+}
+
+int32_t jm_batch_dynamics(jm_batch * b, const void * q_in, const void * v_in, void * a_out, void * stream)
+{
+    if (!b || !q_in || !v_in || !a_out) return fail(JM_EINVAL, "jm_batch_dynamics: null argument");
+    if (!b->started)
+        return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before calling this method.");  // engine.cc:3594-3599
+    if (Topo::NM > 0 && !b->field[JM_F_COMMAND]) return fail(JM_ECONTROLFLOW, "the command field must be bound");
+    if (b->dtype == JM_F64)
+    {
+        auto A = make_args<double>(b);
+        A.mode = jm::MODE_DYNAMICS; A.q_in = (const double *)q_in; A.v_in = (const double *)v_in; A.a_out = (double *)a_out;
+        return launch<double>(b, A, stream);
+    }
+    auto A = make_args<float>(b);
+    A.mode = jm::MODE_DYNAMICS; A.q_in = (const float *)q_in; A.v_in = (const float *)v_in; A.a_out = (float *)a_out;
+    return launch<float>(b, A, stream);
+}
+
+int32_t jm_batch_reset_lanes(jm_batch * b, const uint8_t * lane_mask, const void * q_init, const void * v_init, void * stream)
+{
+    if (!b || !lane_mask || !q_init || !v_init) return fail(JM_EINVAL, "jm_batch_reset_lanes: null argument");
+    if (!b->started) return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before resetting lanes.");
+    int32_t rc = check_bound(b, true);
+    if (rc != JM_OK) return rc;
+    if (b->dtype == JM_F64)
+    {
+        auto A = make_args<double>(b);
+        A.mode = jm::MODE_RESET; A.mask = lane_mask; A.q_init = (const double *)q_init; A.v_init = (const double *)v_init;
+        return launch<double>(b, A, stream);
+    }
+    auto A = make_args<float>(b);
+    A.mode = jm::MODE_RESET; A.mask = lane_mask; A.q_init = (const float *)q_init; A.v_init = (const float *)v_init;
+    return launch<float>(b, A, stream);
+}
+
+int32_t jm_batch_enable_timing(jm_batch * b, int32_t enable)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_enable_timing: null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    if (enable && b->ev.empty())
+    {
+        b->ev.resize(2 * JM_TIMING_RING, nullptr);
+        for (hipEvent_t & e : b->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    b->timing = enable != 0;
+    b->n_timed = 0;
+    return JM_OK;
+}
+int32_t jm_batch_timing_summary(jm_batch * b, int32_t * n_launches, double * total_ms)
+{
+    if (!b || !n_launches || !total_ms) return fail(JM_EINVAL, "jm_batch_timing_summary: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i < b->n_timed; ++i)
+    {
+        HIP_TRY(hipEventSynchronize(b->ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 * i], b->ev[2 * i + 1]));
+        sum += ms;
+    }
+    *n_launches = (int32_t)b->n_timed;
+    *total_ms = sum;
+    b->n_timed = 0;
+    return JM_OK;
+}
+
+int32_t jm_last_error(char * buffer, size_t size)
+{
+    if (!buffer || size == 0) return JM_EINVAL;
+    std::snprintf(buffer, size, "%s", g_last_error.c_str());
+    return JM_OK;
+}
+}  // extern "C"

@@ -1,0 +1,426 @@
+"""BatchedEngine: the `jiminy.Engine` surface for one robot model x B independent lanes.
+
+Mirrors, for the hot path only, the Python-visible API of the reference engine
+(python/jiminy_pywrap/src/engine.cc:587-786): `set_options/get_options`, `start`, `step`,
+`stop`, `reset`, `compute_robots_dynamics`, `robot_state`, `stepper_state`,
+`is_simulation_running`, plus `sensor_measurements` (the `SensorMeasurementTree` seen by
+controllers).  Every array has a trailing batch axis in storage (`[rows][B]`, lane contiguous) and
+is a `torch.Tensor` on the HIP device, so that learners consume it without a host round trip.
+
+All physics runs in the hand-written HIP kernels behind include/jiminy_hip.h; there is no CPU
+fallback: constructing an engine without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import BadControlFlow, HipLibrary, load_for
+from .model import CompiledModel
+
+# constants of reference core/include/jiminy/core/constants.h:18-20
+STEPPER_MIN_TIMESTEP = 1e-10
+SIMULATION_MIN_TIMESTEP = 1e-6
+SIMULATION_MAX_TIMESTEP = 0.02
+EPS = float(np.finfo(np.float64).eps)
+
+SOLVER_IDS = {"euler_explicit": _abi.JM_SOLVER_EULER_EXPLICIT,
+              "runge_kutta_4": _abi.JM_SOLVER_RUNGE_KUTTA_4}
+
+
+def default_options() -> Dict[str, Dict[str, Any]]:
+    """Hot-path subset of `Engine::getDefaultEngineOptions` (reference engine.h:260-481),
+    same names; defaults identical except where the batched path restricts the choice:
+    `odeSolver` (reference default "runge_kutta_dopri" is adaptive, per-lane step sizes are
+    outside the batched path) and `contacts.model` (reference default "constraint")."""
+    return {
+        "world": {"gravity": [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]},
+        "stepper": {"odeSolver": "runge_kutta_4", "dtMax": SIMULATION_MAX_TIMESTEP,
+                    "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
+        "contacts": {"model": "spring_damper", "stiffness": 1.0e6, "damping": 2.0e3,
+                     "friction": 1.0, "transitionEps": 1.0e-3, "transitionVelocity": 1.0e-2},
+    }
+
+
+def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
+              ) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
+    """Fixed-step schedule of one `Engine::step(step_size)` call.
+
+    Re-states the breakpoint logic of the reference's discrete branch (engine.cc:1755-1795 end
+    time with Kahan compensation; :1920-1940 controller breakpoints; :1985-2090 time to the next
+    breakpoint and sub-step size; :2386-2410 sensor breakpoints) for solvers whose step size is
+    not error-controlled.  Returns (launches, t_end, t_error) where each launch is
+    `(dt, n_substeps, command_changed, update_sensors)`.
+    """
+    st = options["stepper"]
+    dt_max = float(st["dtMax"])
+    ctrl = float(st["controllerUpdatePeriod"])
+    sens = float(st["sensorsUpdatePeriod"])
+    if step_size < EPS:
+        # default step size: controller period, else sensor period, else dtMax (engine.cc:1758-1778)
+        step_size = ctrl if ctrl > EPS else (sens if sens > EPS else dt_max)
+    if step_size < SIMULATION_MIN_TIMESTEP:
+        raise ValueError("Step size out of bounds.")
+    corrected = step_size - t_error
+    t_end = t + corrected
+    t_error = (t_end - t) - corrected
+    periods = [p for p in (ctrl, sens) if p > EPS]
+    update_period = min(periods) if periods else math.inf
+
+    def hit(period: float, time: float) -> bool:
+        if period < EPS:
+            return True
+        nxt = period - math.fmod(time, period)
+        return nxt < SIMULATION_MIN_TIMESTEP or period - nxt < STEPPER_MIN_TIMESTEP
+
+    launches: List[Tuple[float, int, bool, bool]] = []
+    while t_end - t >= STEPPER_MIN_TIMESTEP:
+        command_changed = hit(ctrl, t)
+        if math.isfinite(update_period):
+            nxt = update_period - math.fmod(t, update_period)
+            if nxt < SIMULATION_MIN_TIMESTEP:
+                nxt += update_period
+            dt_next = nxt
+            if t_end - t - STEPPER_MIN_TIMESTEP < dt_next:
+                dt_next = t_end - t
+        else:
+            dt_next = t_end - t
+        t_next = t + dt_next
+        # sub-steps of dtMax, last one shortened to land on the breakpoint (engine.cc:2063-2089)
+        n_full = int(math.floor((dt_next + STEPPER_MIN_TIMESTEP) / dt_max))
+        rem = dt_next - n_full * dt_max
+        groups: List[Tuple[float, int]] = []
+        if n_full > 0:
+            groups.append((dt_max, n_full))
+        if rem > STEPPER_MIN_TIMESTEP:
+            groups.append((rem, 1))
+        elif not groups:
+            groups.append((dt_next, 1))
+        t = t_next
+        update_sensors = hit(sens, t)
+        for i, (dt, n) in enumerate(groups):
+            launches.append((dt, n, command_changed and i == 0,
+                             update_sensors and i == len(groups) - 1))
+    return launches, t_end, t_error
+
+
+@dataclass
+class RobotState:
+    """≙ `struct RobotState` (reference engine.h:134-156), each tensor `[rows][B]`."""
+    q: torch.Tensor
+    v: torch.Tensor
+    a: torch.Tensor
+    command: torch.Tensor
+    u: torch.Tensor
+    u_motor: torch.Tensor
+    f_external: Optional[torch.Tensor]
+
+
+@dataclass
+class StepperState:
+    """≙ `struct StepperState` (reference engine.h:216-250); time is shared by all lanes."""
+    iter: int
+    iter_failed: int
+    t: float
+    t_prev: float
+    t_error: float
+    dt: float
+    q: torch.Tensor
+    v: torch.Tensor
+    a: torch.Tensor
+
+
+class BatchedEngine:
+    def __init__(self, model: CompiledModel, batch_size: int, dtype: torch.dtype = torch.float64,
+                 device: Optional[torch.device] = None,
+                 extra_outputs: Tuple[str, ...] = ("contact_forces",)) -> None:
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device available: the batched engine runs on the GPU only "
+                               "(there is no CPU fallback)")
+        self.model = model
+        self.batch_size = int(batch_size)
+        self.dtype = dtype
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the batched engine needs a HIP ('cuda') device")
+        self._lib: HipLibrary = load_for(model)
+        self._L = self._lib.L
+        self._desc, self._keep = _abi.make_model_desc(model)
+        self._model_h = C.c_void_p()
+        self._lib.check(self._L.jm_model_create(C.byref(self._desc), C.byref(self._model_h)))
+        self._batch_h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._lib.check(self._L.jm_batch_create(
+            self._model_h, self.batch_size,
+            _abi.JM_F64 if dtype == torch.float64 else _abi.JM_F32, dev_index,
+            C.byref(self._batch_h)))
+        self._options = default_options()
+        self._rows = _abi.field_rows(model)
+        B = self.batch_size
+        mandatory = ("q", "v", "a", "command", "u_motor", "u", "imu", "force", "contact",
+                     "encoder", "effort")
+        self._fields: Dict[str, torch.Tensor] = {}
+        for name in mandatory + tuple(extra_outputs):
+            self._alloc(name)
+        self._fields["status"] = torch.zeros((1, B), dtype=torch.int32, device=self.device)
+        self._bind("status")
+        self._running = False
+        self._t = 0.0
+        self._t_prev = 0.0
+        self._t_error = 0.0
+        self._dt = 0.0
+        self._iter = 0
+        self._command_dirty = True
+        self._apply_options()
+
+    # ------------------------------------------------------------------ memory
+    def _alloc(self, name: str) -> torch.Tensor:
+        rows = max(self._rows[name], 1)
+        t = torch.zeros((rows, self.batch_size), dtype=self.dtype, device=self.device)
+        self._fields[name] = t
+        if self._rows[name] > 0:
+            self._bind(name)
+        return t
+
+    def _bind(self, name: str) -> None:
+        t = self._fields[name]
+        self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES[name],
+                                              C.c_void_p(t.data_ptr())))
+
+    def enable_output(self, name: str) -> torch.Tensor:
+        """Allocate and bind one of the optional outputs
+        ('f_external', 'contact_forces', 'energy', 'joint_forces', 'centroidal')."""
+        if name not in ("f_external", "contact_forces", "energy", "joint_forces", "centroidal"):
+            raise LookupError(f"unknown optional output '{name}'")
+        if name not in self._fields:
+            self._alloc(name)
+        return self._fields[name]
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_batch_h", None) and self._batch_h.value:
+                self._L.jm_batch_destroy(self._batch_h)
+                self._batch_h = C.c_void_p()
+            if getattr(self, "_model_h", None) and self._model_h.value:
+                self._L.jm_model_destroy(self._model_h)
+                self._model_h = C.c_void_p()
+        except Exception:  # pragma: no cover
+            pass
+
+    # ------------------------------------------------------------------ options
+    def get_options(self) -> Dict[str, Dict[str, Any]]:
+        return {k: dict(v) for k, v in self._options.items()}
+
+    def set_options(self, options: Dict[str, Dict[str, Any]]) -> None:
+        """≙ `Engine::setOptions` (reference engine.cc:2654-2795), hot-path subset."""
+        if self._running:
+            raise BadControlFlow("Please stop the simulation before updating the options.")
+        new = self.get_options()
+        for section, values in options.items():
+            if section not in new:
+                continue  # sections outside the hot path (telemetry, constraints, ...) are ignored
+            for k, v in values.items():
+                if k in new[section]:
+                    new[section][k] = v
+        st, ct = new["stepper"], new["contacts"]
+        if st["odeSolver"] not in SOLVER_IDS:
+            raise NotImplementedError(
+                f"odeSolver '{st['odeSolver']}' is not available on the batched path "
+                f"(available: {sorted(SOLVER_IDS)})")
+        if ct["model"] != "spring_damper":
+            raise NotImplementedError(
+                "only contacts.model='spring_damper' is available on the batched path")
+        dt_max = float(st["dtMax"])
+        if not (SIMULATION_MIN_TIMESTEP - EPS <= dt_max <= SIMULATION_MAX_TIMESTEP + EPS):
+            raise ValueError("'dtMax' option is out of range.")  # engine.cc:2668-2673
+        cp, sp = float(st["controllerUpdatePeriod"]), float(st["sensorsUpdatePeriod"])
+        for p in (cp, sp):
+            if EPS < p < SIMULATION_MIN_TIMESTEP:
+                raise ValueError("Cannot simulate a discrete robot with update period smaller "
+                                 "than 1us.")  # engine.cc:2714-2722
+        if cp > EPS and sp > EPS:
+            big, small = max(cp, sp), min(cp, sp)
+            if abs(big / small - round(big / small)) > 1e-9:
+                raise ValueError("In discrete mode, the controller and sensor update periods "
+                                 "must be multiple of each other.")  # engine.cc:2724-2733
+        if len(new["world"]["gravity"]) != 6:
+            raise ValueError("The size of the gravity force vector must be 6.")
+        self._options = new
+        self._apply_options()
+
+    def _apply_options(self) -> None:
+        ct = self._options["contacts"]
+        o = _abi.make_options(gravity=self._options["world"]["gravity"],
+                              stiffness=ct["stiffness"], damping=ct["damping"],
+                              friction=ct["friction"], transition_eps=ct["transitionEps"],
+                              transition_velocity=ct["transitionVelocity"])
+        self._lib.check(self._L.jm_batch_set_options(self._batch_h, C.byref(o)))
+
+    # ------------------------------------------------------------------ state access
+    @property
+    def is_simulation_running(self) -> bool:
+        return self._running
+
+    @property
+    def robot_state(self) -> RobotState:
+        f = self._fields
+        return RobotState(f["q"], f["v"], f["a"], f["command"], f["u"], f["u_motor"],
+                          f.get("f_external"))
+
+    @property
+    def stepper_state(self) -> StepperState:
+        f = self._fields
+        return StepperState(self._iter, 0, self._t, self._t_prev, self._t_error, self._dt,
+                            f["q"], f["v"], f["a"])
+
+    @property
+    def status(self) -> torch.Tensor:
+        """Per-lane status bits (JM_LANE_*), int32 tensor of shape (B,)."""
+        return self._fields["status"][0]
+
+    @property
+    def command(self) -> torch.Tensor:
+        return self._fields["command"]
+
+    def set_command(self, command: torch.Tensor) -> None:
+        """Write the motor commands `[nmotors][B]` (≙ what `computeCommand` leaves in
+        `RobotState::command`, reference engine.cc:3240-3251)."""
+        self._fields["command"].copy_(command)
+        self._command_dirty = True
+
+    def mark_command_changed(self) -> None:
+        self._command_dirty = True
+
+    @property
+    def sensor_measurements(self) -> Dict[str, torch.Tensor]:
+        """`{SensorType: tensor (n_fields, n_sensors, B)}` (reference layout is
+        `(n_fields, n_sensors)`, gym_jiminy common/utils/spaces.py:107-152)."""
+        f, s = self._fields, self.model.sensors
+        B = self.batch_size
+        out: Dict[str, torch.Tensor] = {}
+        spec = (("ImuSensor", "imu", 6), ("ForceSensor", "force", 6), ("ContactSensor", "contact", 3),
+                ("EncoderSensor", "encoder", 2))
+        for stype, name, nf in spec:
+            n = len(s.get(stype, []))
+            if n:
+                out[stype] = f[name].view(n, nf, B).permute(1, 0, 2)
+        n = len(s.get("EffortSensor", []))
+        if n:
+            out["EffortSensor"] = f["effort"].view(1, n, B)
+        return out
+
+    def field(self, name: str) -> torch.Tensor:
+        return self._fields[name]
+
+    # ------------------------------------------------------------------ control flow
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _to_soa(self, x: Any, rows: int, what: str) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=self.dtype, device=self.device)
+        if t.dim() == 1:
+            t = t[:, None].expand(rows, self.batch_size)
+        if tuple(t.shape) != (rows, self.batch_size):
+            raise ValueError(f"{what} must have shape ({rows}, B) or ({rows},)")
+        return t
+
+    def reset(self) -> None:
+        """≙ `Engine::reset` (reference engine.cc:726-775): stop and clear the state."""
+        self.stop()
+        for name in ("q", "v", "a", "command", "u", "u_motor"):
+            self._fields[name].zero_()
+        self._fields["status"].zero_()
+
+    def start(self, q_init: Any, v_init: Any, a_init: Any = None) -> None:
+        """≙ `Engine::start(q, v, a)` (reference engine.cc:952-1533)."""
+        if self._running:
+            raise BadControlFlow("Simulation already running. Please stop it before starting a "
+                                 "new one.")  # engine.cc:960-965
+        m = self.model
+        q = self._to_soa(q_init, m.nq, "q_init")
+        v = self._to_soa(v_init, m.nv, "v_init")
+        self._fields["q"].copy_(q)
+        self._fields["v"].copy_(v)
+        if a_init is not None:
+            self._fields["a"].copy_(self._to_soa(a_init, m.nv, "a_init"))
+        else:
+            self._fields["a"].zero_()
+        self._t = self._t_prev = self._t_error = 0.0
+        self._dt = 0.0
+        self._iter = 0
+        self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
+        self._running = True
+        self._command_dirty = False
+
+    def stop(self) -> None:
+        """≙ `Engine::stop` (reference engine.cc:2419-2460)."""
+        if self._running:
+            self._lib.check(self._L.jm_batch_stop(self._batch_h))
+        self._running = False
+
+    def step(self, step_dt: float = -1.0) -> None:
+        """≙ `Engine::step(stepSize)` for fixed-step solvers (reference engine.cc:1724-2417)."""
+        if not self._running:
+            raise BadControlFlow("No simulation running. Please start one before using step "
+                                 "method.")
+        launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options)
+        solver = SOLVER_IDS[self._options["stepper"]["odeSolver"]]
+        stream = self._stream()
+        for dt, n, cmd_bp, sens in launches:
+            changed = cmd_bp and self._command_dirty
+            self._lib.check(self._L.jm_batch_step(self._batch_h, solver, dt, n, int(changed),
+                                                  int(sens), stream))
+            if changed:
+                self._command_dirty = False
+            self._iter += n
+            self._dt = dt
+        self._t_prev = self._t
+        self._t = t_end
+        self._t_error = t_err
+
+    def compute_robots_dynamics(self, t: float, q: Any, v: Any) -> torch.Tensor:
+        """≙ `Engine.compute_robots_dynamics(t, [q], [v]) -> [a]` (pywrap engine.cc:634-638)."""
+        if not self._running:
+            raise BadControlFlow("No simulation running. Please start one before calling this "
+                                 "method.")
+        m = self.model
+        qs = self._to_soa(q, m.nq, "q").contiguous()
+        vs = self._to_soa(v, m.nv, "v").contiguous()
+        a = torch.empty((m.nv, self.batch_size), dtype=self.dtype, device=self.device)
+        self._lib.check(self._L.jm_batch_dynamics(self._batch_h, C.c_void_p(qs.data_ptr()),
+                                                  C.c_void_p(vs.data_ptr()),
+                                                  C.c_void_p(a.data_ptr()), self._stream()))
+        return a
+
+    def reset_lanes(self, lane_mask: torch.Tensor, q_init: Any, v_init: Any) -> None:
+        """Re-initialise the masked lanes from (q_init, v_init) and recompute their
+        acceleration / sensors (per-lane `reset` + `start`)."""
+        m = self.model
+        mask = lane_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        if tuple(mask.shape) != (self.batch_size,):
+            raise ValueError("lane_mask must have shape (B,)")
+        q = self._to_soa(q_init, m.nq, "q_init").contiguous()
+        v = self._to_soa(v_init, m.nv, "v_init").contiguous()
+        self._lib.check(self._L.jm_batch_reset_lanes(
+            self._batch_h, C.c_void_p(mask.data_ptr()), C.c_void_p(q.data_ptr()),
+            C.c_void_p(v.data_ptr()), self._stream()))
+
+    # ------------------------------------------------------------------ measurement helpers
+    def enable_timing(self, enable: bool = True) -> None:
+        self._lib.check(self._L.jm_batch_enable_timing(self._batch_h, int(enable)))
+
+    def timing_summary(self) -> Tuple[int, float]:
+        """(number of kernel launches, summed kernel time in ms) since the last call; HIP events
+        recorded on the launch stream around each launch."""
+        n, ms = C.c_int32(), C.c_double()
+        self._lib.check(self._L.jm_batch_timing_summary(self._batch_h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)

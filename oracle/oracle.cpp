@@ -1,0 +1,1240 @@
+// oracle.cpp -- CPU restatement of the reference's per-step physics. TEST INFRASTRUCTURE ONLY.
+//
+// This file is the parity oracle and the "port" CPU baseline of the MI355X-native engine.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+// product path (jiminy_amd/, libjm_*.so) never does.
+//
+// It restates, in scalar float64 and in the reference's order of operations, the single
+// threaded algorithm of duburcqa/jiminy v1.8.12 (paths relative to the reference tree):
+//
+//   dynamics()        Engine::computeRobotsDynamics      core/src/engine/engine.cc:3585-3708
+//   forward_kin()     Engine::computeForwardKinematics   core/src/engine/engine.cc:2957-3014
+//   contact_*()       computeContactDynamicsAtFrame/computeContactDynamics  engine.cc:3117-3238,
+//                     computeCollisionForces engine.cc:3394-3425,
+//                     convertForceGlobalFrameToJoint core/src/utilities/pinocchio.cc:794-809
+//   motor_efforts()   SimpleMotor::computeEffort         core/src/hardware/basic_motors.cc:83-143
+//   aba()             pinocchio_overload::aba + AbaBackwardStep
+//                     core/include/jiminy/core/robot/pinocchio_overload_algorithms.h:126-489
+//   try_step_*()      AbstractStepper::tryStep, AbstractRungeKuttaStepper::tryStepImpl,
+//                     EulerExplicitStepper::tryStepImpl   core/src/stepper/*.cc,
+//                     RK4 tableau core/include/jiminy/core/stepper/runge_kutta4_stepper.h:12-23,
+//                     State::sum core/include/jiminy/core/stepper/lie_group.h:446-455
+//   extra_terms()     computeExtraTerms                  core/src/engine/engine.cc:800-905
+//   sensors()         ImuSensor/ContactSensor/ForceSensor/EncoderSensor/EffortSensor::set
+//                     core/src/hardware/basic_sensors.cc:142-164,267-277,368-387,509-539,604-618
+//   start()           Engine::start                      core/src/engine/engine.cc:952-1533
+//
+// The parts of the path that live in Pinocchio v2.7.0 (pinned by the reference in
+// build_tools/build_install_deps_unix.sh:219-229, NOT vendored under /root/reference) are
+// restated from the published algorithm: AbaForwardStep1/2, forwardKinematics, joint calc()
+// per type, SE3/Motion/Force/Inertia algebra, integrate() on SE(3) and SO(2), energies.
+//
+// PARITY PINNING: the reference core cannot be built or imported here (no Eigen/Boost/
+// Pinocchio/hpp-fcl) and holds no stored numeric vectors for this path.  The
+// oracle is pinned instead against the reference's own known-answer laws re-expressed in
+// tests/test_oracle_*.py (pendulum vs analytic/expm/scipy, armature, two-mass spring chain,
+// contact equilibrium, friction steady state, energy conservation, IMU closed form,
+// diff(v)/dt == a) and against an independently coded CRBA/RNEA (oracle/rbd_numpy.py).
+// For ANYmal/Atlas-sized floating-base models against the real binary: "parity unpinned".
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../include/jiminy_hip.h"
+
+namespace
+{
+constexpr double INF = std::numeric_limits<double>::infinity();
+constexpr double EPS = std::numeric_limits<double>::epsilon();
+
+// ------------------------------------------------------------------ small algebra
+struct V3
+{
+    double x = 0, y = 0, z = 0;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+
+struct M3
+{
+    double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    static M3 identity()
+    {
+        M3 r;
+        r.m[0][0] = r.m[1][1] = r.m[2][2] = 1.0;
+        return r;
+    }
+};
+inline V3 operator*(const M3 & A, V3 v)
+{
+    return {A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z,
+            A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+            A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z};
+}
+inline V3 tmul(const M3 & A, V3 v)  // A^T v
+{
+    return {A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z,
+            A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
+            A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z};
+}
+inline M3 operator*(const M3 & A, const M3 & B)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return r;
+}
+inline M3 transpose(const M3 & A)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = A.m[j][i];
+    return r;
+}
+inline M3 operator+(const M3 & A, const M3 & B)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = A.m[i][j] + B.m[i][j];
+    return r;
+}
+inline M3 skew(V3 v)
+{
+    M3 r;
+    r.m[0][1] = -v.z; r.m[0][2] = v.y;
+    r.m[1][0] = v.z;  r.m[1][2] = -v.x;
+    r.m[2][0] = -v.y; r.m[2][1] = v.x;
+    return r;
+}
+
+struct SE3
+{
+    M3 R = M3::identity();
+    V3 p;
+};
+inline SE3 operator*(const SE3 & A, const SE3 & B) { return {A.R * B.R, A.p + A.R * B.p}; }
+
+// Spatial motion / force, [linear; angular]
+struct Motion
+{
+    V3 lin, ang;
+};
+struct Force
+{
+    V3 lin, ang;
+};
+inline Motion operator+(Motion a, Motion b) { return {a.lin + b.lin, a.ang + b.ang}; }
+inline Force operator+(Force a, Force b) { return {a.lin + b.lin, a.ang + b.ang}; }
+inline Force operator-(Force a, Force b) { return {a.lin - b.lin, a.ang - b.ang}; }
+// SE3::act / actInv on motions and forces
+inline Motion act(const SE3 & M, Motion m)
+{
+    V3 Rw = M.R * m.ang;
+    return {M.R * m.lin + cross(M.p, Rw), Rw};
+}
+inline Motion actInv(const SE3 & M, Motion m)
+{
+    return {tmul(M.R, m.lin - cross(M.p, m.ang)), tmul(M.R, m.ang)};
+}
+inline Force act(const SE3 & M, Force f)
+{
+    V3 Rf = M.R * f.lin;
+    return {Rf, M.R * f.ang + cross(M.p, Rf)};
+}
+inline Force actInv(const SE3 & M, Force f)
+{
+    return {tmul(M.R, f.lin), tmul(M.R, f.ang - cross(M.p, f.lin))};
+}
+// Motion x Motion and Motion x* Force
+inline Motion crossm(Motion a, Motion b)
+{
+    return {cross(a.ang, b.lin) + cross(a.lin, b.ang), cross(a.ang, b.ang)};
+}
+inline Force crossf(Motion a, Force f)
+{
+    return {cross(a.ang, f.lin), cross(a.ang, f.ang) + cross(a.lin, f.lin)};
+}
+
+struct Inertia
+{
+    double mass = 0;
+    V3 c;
+    M3 I;  // about the COM
+};
+inline Force mul(const Inertia & Y, Motion v)  // Inertia::__mult__
+{
+    V3 l = Y.mass * (v.lin - cross(Y.c, v.ang));
+    return {l, Y.I * v.ang + cross(Y.c, l)};
+}
+inline Force vxiv(const Inertia & Y, Motion v)  // v x* (Y v)
+{
+    V3 mcxw = Y.mass * cross(Y.c, v.ang);
+    V3 mv_mcxw = Y.mass * v.lin - mcxw;
+    return {cross(v.ang, mv_mcxw),
+            cross(v.ang, cross(Y.c, mv_mcxw) + Y.I * v.ang) - cross(v.lin, mcxw)};
+}
+inline double vtiv(const Inertia & Y, Motion v)  // v^T Y v
+{
+    V3 cxw = cross(Y.c, v.ang);
+    V3 d = v.lin - cxw;
+    return Y.mass * dot(d, d) + dot(v.ang, Y.I * v.ang);
+}
+inline Inertia act(const SE3 & M, const Inertia & Y)
+{
+    return {Y.mass, M.R * Y.c + M.p, M.R * Y.I * transpose(M.R)};
+}
+inline Inertia add(const Inertia & A, const Inertia & B)  // Inertia::operator+=
+{
+    const double mab = A.mass + B.mass;
+    const double mab_inv = 1.0 / std::max(mab, EPS);
+    const V3 AB = A.c - B.c;
+    const M3 S = skew(AB);
+    const M3 S2 = S * S;
+    Inertia r;
+    const double alpha = A.mass * B.mass * mab_inv;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.I.m[i][j] = A.I.m[i][j] + B.I.m[i][j] - alpha * S2.m[i][j];
+    r.c = (A.mass * mab_inv) * A.c + (B.mass * mab_inv) * B.c;
+    r.mass = mab;
+    return r;
+}
+
+struct M6
+{
+    double m[6][6];
+    void zero() { std::memset(m, 0, sizeof(m)); }
+};
+inline M6 inertia_matrix(const Inertia & Y)  // Inertia::matrix()
+{
+    M6 r;
+    r.zero();
+    const M3 cx = skew(Y.c);
+    const M3 cx2 = cx * cx;
+    for (int i = 0; i < 3; ++i)
+    {
+        r.m[i][i] = Y.mass;
+        for (int j = 0; j < 3; ++j)
+        {
+            r.m[i][3 + j] = -Y.mass * cx.m[i][j];
+            r.m[3 + i][j] = Y.mass * cx.m[i][j];
+            r.m[3 + i][3 + j] = Y.I.m[i][j] - Y.mass * cx2.m[i][j];
+        }
+    }
+    return r;
+}
+// Congruence transform of a force<-motion map from the child frame to the parent frame:
+// X_f Ia X_f^T with X_f = [[R, 0], [p^ R, R]]  (internal::SE3actOn)
+inline M6 se3_act_on(const SE3 & M, const M6 & Ia)
+{
+    double X[6][6];
+    std::memset(X, 0, sizeof(X));
+    const M3 pR = skew(M.p) * M.R;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+        {
+            X[i][j] = M.R.m[i][j];
+            X[3 + i][3 + j] = M.R.m[i][j];
+            X[3 + i][j] = pR.m[i][j];
+        }
+    double T[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j)
+        {
+            double s = 0;
+            for (int k = 0; k < 6; ++k)
+                s += X[i][k] * Ia.m[k][j];
+            T[i][j] = s;
+        }
+    M6 r;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j)
+        {
+            double s = 0;
+            for (int k = 0; k < 6; ++k)
+                s += T[i][k] * X[j][k];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+inline void to6(Motion m, double * o)
+{
+    o[0] = m.lin.x; o[1] = m.lin.y; o[2] = m.lin.z; o[3] = m.ang.x; o[4] = m.ang.y; o[5] = m.ang.z;
+}
+inline void to6(Force m, double * o)
+{
+    o[0] = m.lin.x; o[1] = m.lin.y; o[2] = m.lin.z; o[3] = m.ang.x; o[4] = m.ang.y; o[5] = m.ang.z;
+}
+inline Motion motion6(const double * o) { return {{o[0], o[1], o[2]}, {o[3], o[4], o[5]}}; }
+inline Force force6(const double * o) { return {{o[0], o[1], o[2]}, {o[3], o[4], o[5]}}; }
+
+inline M3 m3_from(const double * r)
+{
+    M3 A;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A.m[i][j] = r[3 * i + j];
+    return A;
+}
+inline V3 v3_from(const double * r) { return {r[0], r[1], r[2]}; }
+
+inline M3 quat_to_matrix(double x, double y, double z, double w)  // Eigen toRotationMatrix
+{
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    M3 R;
+    R.m[0][0] = 1 - (tyy + tzz); R.m[0][1] = txy - twz;       R.m[0][2] = txz + twy;
+    R.m[1][0] = txy + twz;       R.m[1][1] = 1 - (txx + tzz); R.m[1][2] = tyz - twx;
+    R.m[2][0] = txz - twy;       R.m[2][1] = tyz + twx;       R.m[2][2] = 1 - (txx + tyy);
+    return R;
+}
+inline void matrix_to_quat(const M3 & R, double * q /* xyzw */)  // Eigen quaternion from matrix
+{
+    double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+    if (t > 0)
+    {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R.m[2][1] - R.m[1][2]) * t;
+        q[1] = (R.m[0][2] - R.m[2][0]) * t;
+        q[2] = (R.m[1][0] - R.m[0][1]) * t;
+    }
+    else
+    {
+        int i = 0;
+        if (R.m[1][1] > R.m[0][0]) i = 1;
+        if (R.m[2][2] > R.m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R.m[i][i] - R.m[j][j] - R.m[k][k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R.m[k][j] - R.m[j][k]) * t;
+        q[j] = (R.m[j][i] + R.m[i][j]) * t;
+        q[k] = (R.m[k][i] + R.m[i][k]) * t;
+    }
+}
+inline M3 rot_axis_angle(V3 a, double c, double s)  // Rodrigues
+{
+    const double oc = 1 - c;
+    M3 R;
+    R.m[0][0] = c + oc * a.x * a.x;         R.m[0][1] = oc * a.x * a.y - s * a.z;   R.m[0][2] = oc * a.x * a.z + s * a.y;
+    R.m[1][0] = oc * a.y * a.x + s * a.z;   R.m[1][1] = c + oc * a.y * a.y;         R.m[1][2] = oc * a.y * a.z - s * a.x;
+    R.m[2][0] = oc * a.z * a.x - s * a.y;   R.m[2][1] = oc * a.z * a.y + s * a.x;   R.m[2][2] = c + oc * a.z * a.z;
+    return R;
+}
+// exp6 of a twist [v; w] (upstream explog.hpp), Taylor expansion below eps^(1/4)
+inline SE3 exp6(Motion nu)
+{
+    const V3 v = nu.lin, w = nu.ang;
+    const double t2 = dot(w, w);
+    const double t = std::sqrt(t2);
+    const double prec = std::pow(EPS, 0.25);
+    double alpha_wxv, alpha_v, alpha_w, diag;
+    if (t < prec)
+    {
+        alpha_wxv = 0.5 - t2 / 24;
+        alpha_v = 1 - t2 / 6;
+        alpha_w = 1.0 / 6 - t2 / 120;
+        diag = 1 - t2 / 2;
+    }
+    else
+    {
+        const double st = std::sin(t), ct = std::cos(t);
+        const double inv_t2 = 1.0 / t2;
+        alpha_wxv = (1 - ct) * inv_t2;
+        alpha_v = st / t;
+        alpha_w = (1 - alpha_v) * inv_t2;
+        diag = ct;
+    }
+    SE3 M;
+    M.p = alpha_v * v + (alpha_w * dot(w, v)) * w + alpha_wxv * cross(w, v);
+    const double ww[3] = {w.x, w.y, w.z};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            M.R.m[i][j] = alpha_wxv * ww[i] * ww[j];
+    M.R.m[0][1] -= alpha_v * w.z; M.R.m[1][0] += alpha_v * w.z;
+    M.R.m[0][2] += alpha_v * w.y; M.R.m[2][0] -= alpha_v * w.y;
+    M.R.m[1][2] -= alpha_v * w.x; M.R.m[2][1] += alpha_v * w.x;
+    M.R.m[0][0] += diag; M.R.m[1][1] += diag; M.R.m[2][2] += diag;
+    return M;
+}
+
+// ------------------------------------------------------------------ model
+struct MotorP
+{
+    int joint, idx_v, flags;
+    double red, effort_limit, velocity_limit, inv_slope, fvp, fvn, fdp, fdn, fds;
+};
+struct FrameP
+{
+    int joint;
+    SE3 M;
+};
+struct EncoderP
+{
+    int joint, joint_side;
+    double red;
+};
+struct Model
+{
+    int njoints = 0, nq = 0, nv = 0;
+    std::vector<int> parent, jtype, idx_q, idx_v;
+    std::vector<V3> axis;
+    std::vector<SE3> placement;
+    std::vector<Inertia> inertia;
+    std::vector<double> rotor, qlo, qhi;
+    std::vector<MotorP> motors;
+    std::vector<FrameP> contacts, imus, forces;
+    std::vector<int> contact_sensors, effort_sensors;
+    std::vector<EncoderP> encoders;
+    // force sensor -> (contact index, relative placement)  basic_sensors.cc:326-350
+    std::vector<std::vector<std::pair<int, SE3>>> force_pairs;
+};
+
+inline int jt_nv(int t) { return t == JM_JT_FREEFLYER ? 6 : (t == JM_JT_NONE ? 0 : 1); }
+inline bool is_revolute(int t) { return (t >= JM_JT_RX && t <= JM_JT_RU) || (t >= JM_JT_RUBX && t <= JM_JT_RUBU); }
+inline bool is_prismatic(int t) { return t >= JM_JT_PX && t <= JM_JT_PU; }
+inline bool is_unbounded(int t) { return t >= JM_JT_RUBX && t <= JM_JT_RUBU; }
+inline bool has_bounds(int t) { return t >= JM_JT_RX && t <= JM_JT_PU; }
+
+// ------------------------------------------------------------------ engine (one robot)
+struct Engine
+{
+    Model mdl;
+    jm_options opt;
+    // state (RobotState, engine.h:134-156)
+    std::vector<double> q, v, a, command, u, uMotor, uTransmission;
+    std::vector<Force> fExternal;       // joint frame
+    std::vector<Force> contactFrameForces;  // RobotData::contactFrameForces (joint frame)
+    std::vector<Force> contactForces;   // Robot::contactForces_ (contact frame)
+    // pinocchio::Data
+    std::vector<SE3> liMi, oMi;
+    std::vector<Motion> dv, da, da_gf;  // data.v, data.a, data.a_gf
+    std::vector<Force> df, dh, fBody;   // data.f, data.h, fPrev buffer
+    std::vector<M6> Yaba;
+    std::vector<Inertia> Ycrb;
+    struct JData
+    {
+        double U[6][6], Dinv[6][6], UDinv[6][6];
+    };
+    std::vector<JData> jd;
+    std::vector<double> du, ddq;
+    double kinetic = 0, potential = 0;
+    V3 com0;
+    Force hg, dhg;
+    // sensors
+    std::vector<double> imu, force, contact, encoder, effort;
+    int status = 0;
+    long iter = 0;
+};
+
+V3 joint_axis(const Model & m, int j)
+{
+    switch (m.jtype[j])
+    {
+    case JM_JT_RX: case JM_JT_PX: case JM_JT_RUBX: return {1, 0, 0};
+    case JM_JT_RY: case JM_JT_PY: case JM_JT_RUBY: return {0, 1, 0};
+    case JM_JT_RZ: case JM_JT_PZ: case JM_JT_RUBZ: return {0, 0, 1};
+    default: return m.axis[j];
+    }
+}
+
+// joint calc(): transform M_j(q) and joint velocity S*qd
+void joint_calc(const Model & m, int j, const double * q, const double * v, SE3 & Mj, Motion & vj)
+{
+    const int t = m.jtype[j];
+    const double * qj = q + m.idx_q[j];
+    const double * vjv = v + m.idx_v[j];
+    Mj = SE3();
+    vj = Motion();
+    if (t == JM_JT_FREEFLYER)
+    {
+        Mj.p = {qj[0], qj[1], qj[2]};
+        Mj.R = quat_to_matrix(qj[3], qj[4], qj[5], qj[6]);
+        vj = motion6(vjv);
+        return;
+    }
+    const V3 ax = joint_axis(m, j);
+    if (is_revolute(t))
+    {
+        double c, s;
+        if (is_unbounded(t)) { c = qj[0]; s = qj[1]; }
+        else { c = std::cos(qj[0]); s = std::sin(qj[0]); }
+        Mj.R = rot_axis_angle(ax, c, s);
+        vj.ang = vjv[0] * ax;
+    }
+    else  // prismatic
+    {
+        Mj.p = qj[0] * ax;
+        vj.lin = vjv[0] * ax;
+    }
+}
+// S * x for a 1-dof joint or the free-flyer
+Motion S_times(const Model & m, int j, const double * x)
+{
+    const int t = m.jtype[j];
+    if (t == JM_JT_FREEFLYER) return motion6(x);
+    const V3 ax = joint_axis(m, j);
+    Motion r;
+    if (is_revolute(t)) r.ang = x[0] * ax; else r.lin = x[0] * ax;
+    return r;
+}
+
+// pinocchio::forwardKinematics(model, data, q, v) + oMi (engine.cc:2957-2969).
+// data.a from the `a` argument is not needed by the dynamics and is refreshed by extra_terms().
+void forward_kin(Engine & e, const double * q, const double * v)
+{
+    const Model & m = e.mdl;
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        SE3 Mj; Motion vj;
+        joint_calc(m, j, q, v, Mj, vj);
+        e.liMi[j] = m.placement[j] * Mj;
+        const int p = m.parent[j];
+        e.dv[j] = vj;
+        if (p > 0)
+        {
+            e.oMi[j] = e.oMi[p] * e.liMi[j];
+            e.dv[j] = e.dv[j] + actInv(e.liMi[j], e.dv[p]);
+        }
+        else
+            e.oMi[j] = e.liMi[j];
+    }
+}
+
+// Engine::computeContactDynamics (engine.cc:3197-3238)
+V3 contact_law(const jm_options & o, V3 n, double depth, V3 vWorld)
+{
+    V3 f;
+    if (depth < 0.0)
+    {
+        const double vDepth = dot(vWorld, n);
+        const double fN = -std::min(o.contact_stiffness * depth + o.contact_damping * vDepth, 0.0);
+        f = fN * n;
+        const V3 vT = vWorld - vDepth * n;
+        const double vRatio = std::min(norm(vT) / o.contact_transition_velocity, 1.0);
+        const double fT = o.contact_friction * vRatio * fN;
+        f = f - fT * vT;
+        if (o.contact_transition_eps > EPS)
+        {
+            const double blend = -depth / o.contact_transition_eps;
+            f = std::tanh(2.0 * blend) * f;
+        }
+    }
+    return f;
+}
+
+// computeContactDynamicsAtFrame, spring-damper branch, flat ground h=0 n=z (engine.cc:3117-3195)
+Force contact_at_frame(const Engine & e, const FrameP & fr)
+{
+    const SE3 oMf = e.oMi[fr.joint] * fr.M;
+    const V3 n = {0, 0, 1};
+    const double depth = (oMf.p.z - 0.0) * n.z;
+    Force fl;
+    if (depth < 0.0)
+    {
+        const V3 vLocal = actInv(fr.M, e.dv[fr.joint]).lin;  // getFrameVelocity(LOCAL).linear
+        const V3 vWorld = oMf.R * vLocal;
+        const V3 fW = contact_law(e.opt, n, depth, vWorld);
+        // convertForceGlobalFrameToJoint (utilities/pinocchio.cc:794-809)
+        fl.lin = tmul(e.oMi[fr.joint].R, fW);
+        fl.ang = tmul(e.oMi[fr.joint].R, V3{0, 0, 0});
+        fl.ang = fl.ang + cross(fr.M.p, fl.lin);
+    }
+    return fl;
+}
+
+// SimpleMotor::computeEffort (basic_motors.cc:83-143)
+void motor_efforts(Engine & e, const double * v)
+{
+    for (size_t i = 0; i < e.mdl.motors.size(); ++i)
+    {
+        const MotorP & mp = e.mdl.motors[i];
+        const double vj = v[mp.idx_v];
+        const double vMotor = mp.red * vj;
+        double effortMin = -INF, effortMax = INF;
+        if (mp.flags & JM_MOTOR_EFFORT_LIMIT)
+        {
+            effortMin = -mp.effort_limit;
+            effortMax = mp.effort_limit;
+            if (mp.flags & JM_MOTOR_VELOCITY_LIMIT)
+            {
+                const double velocityDelta = mp.effort_limit * mp.inv_slope;
+                if (velocityDelta > 0.0)
+                {
+                    const double velocityThr = std::max(mp.velocity_limit - velocityDelta, 0.0);
+                    effortMin *= std::clamp((mp.velocity_limit + vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
+                    effortMax *= std::clamp((mp.velocity_limit - vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
+                }
+            }
+        }
+        const double uMotor = std::clamp(e.command[i], effortMin, effortMax);
+        double uT = mp.red * uMotor;
+        if (mp.flags & JM_MOTOR_FRICTION)
+        {
+            if (vj > 0.0) uT += mp.fvp * vj + mp.fdp * std::tanh(mp.fds * vj);
+            else uT += mp.fvn * vj + mp.fdn * std::tanh(mp.fds * vj);
+        }
+        e.uMotor[i] = uMotor;
+        e.uTransmission[i] = uT;
+    }
+}
+
+// 6x6 SPD inverse through Cholesky (internal::PerformStYSInversion: llt().solveInPlace(I))
+void spd_inverse(int n, const double A[6][6], double Ainv[6][6])
+{
+    double L[6][6] = {};
+    for (int j = 0; j < n; ++j)
+    {
+        double s = A[j][j];
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        L[j][j] = std::sqrt(s);
+        for (int i = j + 1; i < n; ++i)
+        {
+            double t = A[i][j];
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t / L[j][j];
+        }
+    }
+    for (int c = 0; c < n; ++c)
+    {
+        double y[6];
+        for (int i = 0; i < n; ++i)
+        {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+            y[i] = s / L[i][i];
+        }
+        for (int i = n - 1; i >= 0; --i)
+        {
+            double s = y[i];
+            for (int k = i + 1; k < n; ++k) s -= L[k][i] * Ainv[k][c];
+            Ainv[i][c] = s / L[i][i];
+        }
+    }
+}
+
+// pinocchio_overload::aba (pinocchio_overload_algorithms.h:437-489)
+void aba(Engine & e, const double * q, const double * v, const double * tau, const std::vector<Force> & fext)
+{
+    const Model & m = e.mdl;
+    const V3 g = {e.opt.gravity[0], e.opt.gravity[1], e.opt.gravity[2]};
+    const V3 gw = {e.opt.gravity[3], e.opt.gravity[4], e.opt.gravity[5]};
+    e.dv[0] = Motion();
+    e.da_gf[0] = {-g, -gw};
+    for (int i = 0; i < m.nv; ++i) e.du[i] = tau[i];
+    // Pass 1 (AbaForwardStep1)
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        SE3 Mj; Motion vj;
+        joint_calc(m, j, q, v, Mj, vj);
+        const int p = m.parent[j];
+        e.liMi[j] = m.placement[j] * Mj;
+        e.dv[j] = vj;
+        if (p > 0) e.dv[j] = e.dv[j] + actInv(e.liMi[j], e.dv[p]);
+        e.da_gf[j] = crossm(e.dv[j], vj);  // c = 0 for every supported joint
+        e.Yaba[j] = inertia_matrix(m.inertia[j]);
+        e.df[j] = vxiv(m.inertia[j], e.dv[j]);
+        e.df[j] = e.df[j] - fext[j];
+    }
+    // Pass 2 (AbaBackwardStep :136-167 and calc_aba specialisations)
+    for (int j = m.njoints - 1; j > 0; --j)
+    {
+        const int p = m.parent[j];
+        const int t = m.jtype[j];
+        const int iv = m.idx_v[j];
+        M6 & Ia = e.Yaba[j];
+        Engine::JData & jd = e.jd[j];
+        double fv[6];
+        to6(e.df[j], fv);
+        if (t == JM_JT_FREEFLYER)
+        {
+            for (int k = 0; k < 6; ++k) e.du[iv + k] -= fv[k];
+            double StU[6][6];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) { jd.U[a][b] = Ia.m[a][b]; StU[a][b] = Ia.m[a][b]; }
+            for (int a = 0; a < 6; ++a) StU[a][a] += m.rotor[iv + a];
+            spd_inverse(6, StU, jd.Dinv);
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b)
+                {
+                    double s = 0;
+                    for (int k = 0; k < 6; ++k) s += jd.U[a][k] * jd.Dinv[k][b];
+                    jd.UDinv[a][b] = s;
+                }
+            if (p > 0)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b)
+                    {
+                        double s = 0;
+                        for (int k = 0; k < 6; ++k) s += jd.UDinv[a][k] * jd.U[b][k];
+                        Ia.m[a][b] -= s;
+                    }
+        }
+        else
+        {
+            const V3 ax = joint_axis(m, j);
+            const double axv[3] = {ax.x, ax.y, ax.z};
+            const int off = is_revolute(t) ? 3 : 0;
+            // u -= S^T f
+            e.du[iv] -= axv[0] * fv[off] + axv[1] * fv[off + 1] + axv[2] * fv[off + 2];
+            // U = Ia S ; D = S^T U + Im
+            for (int a = 0; a < 6; ++a)
+                jd.U[a][0] = Ia.m[a][off] * axv[0] + Ia.m[a][off + 1] * axv[1] + Ia.m[a][off + 2] * axv[2];
+            const double D = axv[0] * jd.U[off][0] + axv[1] * jd.U[off + 1][0] + axv[2] * jd.U[off + 2][0] + m.rotor[iv];
+            jd.Dinv[0][0] = 1.0 / D;
+            for (int a = 0; a < 6; ++a) jd.UDinv[a][0] = jd.U[a][0] * jd.Dinv[0][0];
+            if (p > 0)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) Ia.m[a][b] -= jd.UDinv[a][0] * jd.U[b][0];
+        }
+        if (p > 0)
+        {
+            double pa[6], agf[6];
+            to6(e.df[j], pa);
+            to6(e.da_gf[j], agf);
+            for (int a = 0; a < 6; ++a)
+            {
+                double s = 0;
+                for (int k = 0; k < 6; ++k) s += Ia.m[a][k] * agf[k];
+                pa[a] += s;
+            }
+            const int n = jt_nv(t);
+            for (int a = 0; a < 6; ++a)
+            {
+                double s = 0;
+                for (int k = 0; k < n; ++k) s += jd.UDinv[a][k] * e.du[iv + k];
+                pa[a] += s;
+            }
+            e.df[j] = force6(pa);
+            const M6 T = se3_act_on(e.liMi[j], Ia);
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) e.Yaba[p].m[a][b] += T.m[a][b];
+            e.df[p] = e.df[p] + act(e.liMi[j], e.df[j]);
+        }
+    }
+    // Pass 3 (AbaForwardStep2)
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        const int p = m.parent[j];
+        const int t = m.jtype[j];
+        const int iv = m.idx_v[j];
+        const int n = jt_nv(t);
+        const Engine::JData & jd = e.jd[j];
+        e.da_gf[j] = e.da_gf[j] + actInv(e.liMi[j], e.da_gf[p]);
+        double agf[6];
+        to6(e.da_gf[j], agf);
+        for (int a = 0; a < n; ++a)
+        {
+            double s = 0;
+            for (int k = 0; k < n; ++k) s += jd.Dinv[a][k] * e.du[iv + k];
+            double r = 0;
+            for (int k = 0; k < 6; ++k) r += jd.UDinv[k][a] * agf[k];
+            e.ddq[iv + a] = s - r;
+        }
+        e.da_gf[j] = e.da_gf[j] + S_times(m, j, &e.ddq[iv]);
+    }
+}
+
+// Engine::computeRobotsDynamics for one robot (engine.cc:3585-3708), spring-damper contacts,
+// discrete controller (command held), no user internal dynamics, no flexibility.
+void dynamics(Engine & e, const double * q, const double * v, double * a_out)
+{
+    const Model & m = e.mdl;
+    forward_kin(e, q, v);
+    // computeAllTerms: reset, internal dynamics (bounds -> status flag), contacts
+    for (auto & f : e.fExternal) f = Force();
+    for (int j = 1; j < m.njoints; ++j)
+        if (has_bounds(m.jtype[j]))
+        {
+            const double qj = q[m.idx_q[j]];
+            if (m.qhi[m.idx_q[j]] < qj || qj < m.qlo[m.idx_q[j]]) e.status |= JM_LANE_OUT_OF_BOUNDS;
+        }
+    for (size_t i = 0; i < m.contacts.size(); ++i)
+    {
+        const FrameP & fr = m.contacts[i];
+        e.contactFrameForces[i] = contact_at_frame(e, fr);
+        e.fExternal[fr.joint] = e.fExternal[fr.joint] + e.contactFrameForces[i];
+        e.contactForces[i] = actInv(fr.M, e.contactFrameForces[i]);
+    }
+    motor_efforts(e, v);
+    for (int i = 0; i < m.nv; ++i) e.u[i] = 0.0;  // uInternal + uCustom
+    for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
+    aba(e, q, v, e.u.data(), e.fExternal);
+    for (int i = 0; i < m.nv; ++i)
+    {
+        a_out[i] = e.ddq[i];
+        if (e.ddq[i] != e.ddq[i]) e.status |= JM_LANE_NAN;
+    }
+}
+
+// pinocchio::integrate (lie_group.h:446-455 -> liegroup SE(3), SO(2), R^n)
+void integrate(const Model & m, const double * q, const double * dvv, double * qout)
+{
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        const int t = m.jtype[j];
+        const double * qj = q + m.idx_q[j];
+        const double * d = dvv + m.idx_v[j];
+        double * o = qout + m.idx_q[j];
+        if (t == JM_JT_FREEFLYER)
+        {
+            SE3 M0;
+            M0.R = quat_to_matrix(qj[3], qj[4], qj[5], qj[6]);
+            M0.p = {qj[0], qj[1], qj[2]};
+            const SE3 M1 = M0 * exp6(motion6(d));
+            double quat[4];
+            matrix_to_quat(M1.R, quat);
+            const double dp = quat[0] * qj[3] + quat[1] * qj[4] + quat[2] * qj[5] + quat[3] * qj[6];
+            if (dp < 0) for (int k = 0; k < 4; ++k) quat[k] = -quat[k];
+            const double N2 = quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3];
+            const double alpha = (3.0 - N2) / 2.0;  // firstOrderNormalize
+            o[0] = M1.p.x; o[1] = M1.p.y; o[2] = M1.p.z;
+            for (int k = 0; k < 4; ++k) o[3 + k] = quat[k] * alpha;
+        }
+        else if (is_unbounded(t))
+        {
+            const double ca = qj[0], sa = qj[1];
+            const double cw = std::cos(d[0]), sw = std::sin(d[0]);
+            const double c = cw * ca - sw * sa, s = sw * ca + cw * sa;
+            const double n2 = c * c + s * s;
+            const double k = (3.0 - n2) / 2.0;
+            o[0] = c * k; o[1] = s * k;
+        }
+        else
+            o[0] = qj[0] + d[0];
+    }
+}
+
+// computeExtraTerms (engine.cc:800-905); uses liMi / data.v / oMi of the last dynamics call.
+void extra_terms(Engine & e)
+{
+    const Model & m = e.mdl;
+    const V3 g = {e.opt.gravity[0], e.opt.gravity[1], e.opt.gravity[2]};
+    const V3 gw = {e.opt.gravity[3], e.opt.gravity[4], e.opt.gravity[5]};
+    // energies (pinocchio_overload::computeKineticEnergy :38-57, computePotentialEnergy)
+    double kin = 0;
+    for (int j = 1; j < m.njoints; ++j) kin += vtiv(m.inertia[j], e.dv[j]);
+    kin *= 0.5;
+    double rot = 0;
+    for (int i = 0; i < m.nv; ++i) rot += m.rotor[i] * e.v[i] * e.v[i];
+    kin += 0.5 * rot;
+    double pot = 0;
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        const V3 cg = e.oMi[j].p + e.oMi[j].R * m.inertia[j].c;
+        pot -= m.inertia[j].mass * dot(cg, g);
+    }
+    e.kinetic = kin;
+    e.potential = pot;
+    // subtree inertias
+    for (int j = 1; j < m.njoints; ++j) e.Ycrb[j] = m.inertia[j];
+    for (int j = m.njoints - 1; j > 0; --j)
+    {
+        const int p = m.parent[j];
+        if (p > 0) e.Ycrb[p] = add(e.Ycrb[p], act(e.liMi[j], e.Ycrb[j]));
+    }
+    // accelerations, momenta, forces
+    e.dh[0] = Force(); e.fBody[0] = Force(); e.df[0] = Force();
+    e.da[0] = Motion();
+    e.da_gf[0] = {-g, -gw};
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        const int p = m.parent[j];
+        const Motion vj = S_times(m, j, &e.v[m.idx_v[j]]);
+        Motion aj = crossm(e.dv[j], vj);  // c + v x S qd (ForwardKinematicsAccelerationStep)
+        aj = aj + S_times(m, j, &e.a[m.idx_v[j]]);
+        e.da_gf[j] = aj;
+        e.da[j] = aj + actInv(e.liMi[j], e.da[p]);
+        e.da_gf[j] = e.da_gf[j] + actInv(e.liMi[j], e.da_gf[p]);
+        e.dh[j] = mul(m.inertia[j], e.dv[j]);
+        e.fBody[j] = mul(m.inertia[j], e.da[j]);
+        e.df[j] = crossf(e.dv[j], e.dh[j]);
+        e.fBody[j] = e.fBody[j] + e.df[j];
+        e.df[j] = e.df[j] + mul(m.inertia[j], e.da_gf[j]);
+        e.df[j] = e.df[j] - e.fExternal[j];
+    }
+    for (int j = m.njoints - 1; j > 0; --j)
+    {
+        const int p = m.parent[j];
+        e.fBody[p] = e.fBody[p] + act(e.liMi[j], e.fBody[j]);
+        e.dh[p] = e.dh[p] + act(e.liMi[j], e.dh[j]);
+        if (p > 0) e.df[p] = e.df[p] + act(e.liMi[j], e.df[j]);
+    }
+    // centroidal quantities (single root joint assumed by the reference: data.liMi[1])
+    if (m.njoints > 1)
+    {
+        e.com0 = e.liMi[1].R * e.Ycrb[1].c + e.liMi[1].p;
+        e.hg = e.dh[0];
+        e.hg.ang = e.hg.ang + cross(e.hg.lin, e.com0);
+        e.dhg = e.fBody[0];
+        e.dhg.ang = e.dhg.ang + cross(e.dhg.lin, e.com0);
+    }
+}
+
+// Robot::computeSensorMeasurements, noiseless (basic_sensors.cc)
+void sensors(Engine & e)
+{
+    const Model & m = e.mdl;
+    const V3 g = {e.opt.gravity[0], e.opt.gravity[1], e.opt.gravity[2]};
+    for (size_t i = 0; i < m.imus.size(); ++i)
+    {
+        const FrameP & fr = m.imus[i];
+        const Motion vf = actInv(fr.M, e.dv[fr.joint]);
+        Motion af = actInv(fr.M, e.da[fr.joint]);
+        af.lin = af.lin + cross(vf.ang, vf.lin);  // classical acceleration
+        const M3 Rw = e.oMi[fr.joint].R * fr.M.R;
+        const V3 acc = af.lin - tmul(Rw, g);
+        double * o = &e.imu[6 * i];
+        o[0] = vf.ang.x; o[1] = vf.ang.y; o[2] = vf.ang.z;
+        o[3] = acc.x; o[4] = acc.y; o[5] = acc.z;
+    }
+    for (size_t i = 0; i < m.contact_sensors.size(); ++i)
+    {
+        const Force & f = e.contactForces[m.contact_sensors[i]];
+        e.contact[3 * i] = f.lin.x; e.contact[3 * i + 1] = f.lin.y; e.contact[3 * i + 2] = f.lin.z;
+    }
+    for (size_t i = 0; i < m.forces.size(); ++i)
+    {
+        Force s;
+        for (const auto & pr : m.force_pairs[i]) s = s + act(pr.second, e.contactForces[pr.first]);
+        to6(s, &e.force[6 * i]);
+    }
+    for (size_t i = 0; i < m.encoders.size(); ++i)
+    {
+        const EncoderP & en = m.encoders[i];
+        const int t = m.jtype[en.joint];
+        double pos;
+        if (is_unbounded(t)) pos = std::atan2(e.q[m.idx_q[en.joint] + 1], e.q[m.idx_q[en.joint]]);
+        else pos = e.q[m.idx_q[en.joint]];
+        const double vel = e.v[m.idx_v[en.joint]];
+        if (en.joint_side) { e.encoder[2 * i] = pos; e.encoder[2 * i + 1] = vel; }
+        else { e.encoder[2 * i] = pos * en.red; e.encoder[2 * i + 1] = vel * en.red; }
+    }
+    for (size_t i = 0; i < m.effort_sensors.size(); ++i) e.effort[i] = e.uMotor[m.effort_sensors[i]];
+}
+
+void check_state_nan(Engine & e)
+{
+    for (double x : e.q) if (x != x) e.status |= JM_LANE_NAN;
+    for (double x : e.v) if (x != x) e.status |= JM_LANE_NAN;
+    for (double x : e.a) if (x != x) e.status |= JM_LANE_NAN;
+}
+
+// Engine::start with an externally held command: the INIT_ITERATIONS fixed point
+// (engine.cc:1399-1467) converges after the first pass since command does not depend on a.
+void start(Engine & e)
+{
+    const Model & m = e.mdl;
+    e.status = 0;
+    e.iter = 0;
+    forward_kin(e, e.q.data(), e.v.data());
+    double forceMax = 0;
+    for (const FrameP & fr : m.contacts) forceMax = std::max(forceMax, norm(contact_at_frame(e, fr).lin));
+    if (forceMax > 1e5) e.status |= JM_LANE_FORCE_OVERFLOW;
+    dynamics(e, e.q.data(), e.v.data(), e.a.data());
+    extra_terms(e);
+    sensors(e);
+}
+
+// One fixed step (AbstractStepper::tryStep + success bookkeeping engine.cc:2132-2187)
+void try_step(Engine & e, int solver, double dt)
+{
+    const Model & m = e.mdl;
+    const int nq = m.nq, nv = m.nv;
+    if (solver == JM_SOLVER_EULER_EXPLICIT)
+    {
+        // state.sumInPlace(stateDerivative, dt): q = integrate(q, dt*v); v = v + dt*a
+        std::vector<double> inc_v(nv), qn(nq);
+        for (int i = 0; i < nv; ++i) inc_v[i] = dt * e.v[i];
+        integrate(m, e.q.data(), inc_v.data(), qn.data());
+        for (int i = 0; i < nv; ++i) e.v[i] = e.v[i] + dt * e.a[i];
+        e.q = qn;
+        dynamics(e, e.q.data(), e.v.data(), e.a.data());
+    }
+    else
+    {
+        static const double A[4][4] = {{0, 0, 0, 0}, {0.5, 0, 0, 0}, {0, 0.5, 0, 0}, {0, 0, 1.0, 0}};
+        static const double b[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+        std::vector<double> kv[4], ka[4];
+        kv[0] = e.v; ka[0] = e.a;
+        std::vector<double> incv(nv), inca(nv), qs(nq), vs(nv), as(nv);
+        for (int i = 1; i < 4; ++i)
+        {
+            std::fill(incv.begin(), incv.end(), 0.0);
+            std::fill(inca.begin(), inca.end(), 0.0);
+            for (int j = 0; j < i; ++j)
+            {
+                const double s = dt * A[i][j];
+                for (int k = 0; k < nv; ++k) { incv[k] += s * kv[j][k]; inca[k] += s * ka[j][k]; }
+            }
+            integrate(m, e.q.data(), incv.data(), qs.data());
+            for (int k = 0; k < nv; ++k) vs[k] = e.v[k] + inca[k];
+            dynamics(e, qs.data(), vs.data(), as.data());
+            kv[i] = vs; ka[i] = as;
+        }
+        std::fill(incv.begin(), incv.end(), 0.0);
+        std::fill(inca.begin(), inca.end(), 0.0);
+        for (int i = 0; i < 4; ++i)
+        {
+            const double s = dt * b[i];
+            for (int k = 0; k < nv; ++k) { incv[k] += s * kv[i][k]; inca[k] += s * ka[i][k]; }
+        }
+        integrate(m, e.q.data(), incv.data(), qs.data());
+        for (int k = 0; k < nv; ++k) e.v[k] = e.v[k] + inca[k];
+        e.q = qs;
+        dynamics(e, e.q.data(), e.v.data(), e.a.data());  // not FSAL
+    }
+    extra_terms(e);
+    ++e.iter;
+}
+
+void step(Engine & e, int solver, double dt, int n_sub, int command_changed, int update_sensors)
+{
+    check_state_nan(e);
+    if (command_changed) dynamics(e, e.q.data(), e.v.data(), e.a.data());  // a(t+), engine.cc:2030-2042
+    for (int s = 0; s < n_sub; ++s) try_step(e, solver, dt);
+    if (update_sensors) sensors(e);
+}
+
+Engine * make_engine(const jm_model_desc * d, const jm_options * o)
+{
+    Engine * e = new Engine();
+    Model & m = e->mdl;
+    m.njoints = d->njoints; m.nq = d->nq; m.nv = d->nv;
+    m.parent.assign(d->parents, d->parents + d->njoints);
+    m.jtype.assign(d->jtypes, d->jtypes + d->njoints);
+    m.idx_q.assign(d->idx_q, d->idx_q + d->njoints);
+    m.idx_v.assign(d->idx_v, d->idx_v + d->njoints);
+    m.axis.resize(d->njoints); m.placement.resize(d->njoints); m.inertia.resize(d->njoints);
+    for (int j = 0; j < d->njoints; ++j)
+    {
+        m.axis[j] = v3_from(d->axes + 3 * j);
+        m.placement[j].R = m3_from(d->placement_R + 9 * j);
+        m.placement[j].p = v3_from(d->placement_p + 3 * j);
+        m.inertia[j].mass = d->mass[j];
+        m.inertia[j].c = v3_from(d->com + 3 * j);
+        m.inertia[j].I = m3_from(d->inertia + 9 * j);
+    }
+    m.rotor.assign(d->rotor_inertia, d->rotor_inertia + d->nv);
+    m.qlo.assign(d->position_lower, d->position_lower + d->nq);
+    m.qhi.assign(d->position_upper, d->position_upper + d->nq);
+    for (int i = 0; i < d->nmotors; ++i)
+    {
+        const double * p = d->motor_params + JM_MOTOR_NPARAMS * i;
+        m.motors.push_back({d->motor_joint[i], m.idx_v[d->motor_joint[i]], d->motor_flags[i],
+                            p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]});
+    }
+    auto frames = [](int n, const int32_t * j, const double * R, const double * p) {
+        std::vector<FrameP> out;
+        for (int i = 0; i < n; ++i)
+        {
+            FrameP f;
+            f.joint = j[i];
+            f.M.R = m3_from(R + 9 * i);
+            f.M.p = v3_from(p + 3 * i);
+            out.push_back(f);
+        }
+        return out;
+    };
+    m.contacts = frames(d->ncontacts, d->contact_joint, d->contact_R, d->contact_p);
+    m.imus = frames(d->nimu, d->imu_joint, d->imu_R, d->imu_p);
+    m.forces = frames(d->nforce, d->force_joint, d->force_R, d->force_p);
+    m.contact_sensors.assign(d->contact_sensor_contact, d->contact_sensor_contact + d->ncontact_sensors);
+    m.effort_sensors.assign(d->effort_motor, d->effort_motor + d->neffort);
+    for (int i = 0; i < d->nencoder; ++i)
+        m.encoders.push_back({d->encoder_joint[i], d->encoder_joint_side[i], d->encoder_reduction[i]});
+    m.force_pairs.resize(m.forces.size());
+    for (size_t i = 0; i < m.forces.size(); ++i)
+        for (size_t c = 0; c < m.contacts.size(); ++c)
+            if (m.contacts[c].joint == m.forces[i].joint)
+            {
+                // frameRef.placement.actInv(contactFrame.placement) = F^-1 * C
+                SE3 Finv;
+                Finv.R = transpose(m.forces[i].M.R);
+                Finv.p = -(tmul(m.forces[i].M.R, m.forces[i].M.p));
+                m.force_pairs[i].push_back({(int)c, Finv * m.contacts[c].M});
+            }
+    e->opt = *o;
+    const int J = m.njoints;
+    e->q.assign(m.nq, 0); e->v.assign(m.nv, 0); e->a.assign(m.nv, 0);
+    e->command.assign(m.motors.size(), 0); e->uMotor.assign(m.motors.size(), 0);
+    e->uTransmission.assign(m.motors.size(), 0); e->u.assign(m.nv, 0);
+    e->fExternal.assign(J, Force()); e->contactFrameForces.assign(m.contacts.size(), Force());
+    e->contactForces.assign(m.contacts.size(), Force());
+    e->liMi.assign(J, SE3()); e->oMi.assign(J, SE3());
+    e->dv.assign(J, Motion()); e->da.assign(J, Motion()); e->da_gf.assign(J, Motion());
+    e->df.assign(J, Force()); e->dh.assign(J, Force()); e->fBody.assign(J, Force());
+    e->Yaba.resize(J); e->Ycrb.resize(J); e->jd.resize(J);
+    e->du.assign(m.nv, 0); e->ddq.assign(m.nv, 0);
+    e->imu.assign(6 * m.imus.size(), 0); e->force.assign(6 * m.forces.size(), 0);
+    e->contact.assign(3 * m.contact_sensors.size(), 0); e->encoder.assign(2 * m.encoders.size(), 0);
+    e->effort.assign(m.effort_sensors.size(), 0);
+    return e;
+}
+
+void copy_out(const std::vector<Force> & f, double * out)
+{
+    for (size_t i = 0; i < f.size(); ++i) to6(f[i], out + 6 * i);
+}
+}  // namespace
+
+// ------------------------------------------------------------------ C entry points (ctypes)
+extern "C"
+{
+void * orc_engine_create(const jm_model_desc * d, const jm_options * o) { return make_engine(d, o); }
+void orc_engine_destroy(void * h) { delete static_cast<Engine *>(h); }
+void orc_engine_set_options(void * h, const jm_options * o) { static_cast<Engine *>(h)->opt = *o; }
+
+void orc_engine_set_state(void * h, const double * q, const double * v, const double * a)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    std::copy(q, q + e.mdl.nq, e.q.begin());
+    std::copy(v, v + e.mdl.nv, e.v.begin());
+    if (a) std::copy(a, a + e.mdl.nv, e.a.begin()); else std::fill(e.a.begin(), e.a.end(), 0.0);
+}
+void orc_engine_set_command(void * h, const double * c)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    std::copy(c, c + e.command.size(), e.command.begin());
+}
+void orc_engine_start(void * h) { start(*static_cast<Engine *>(h)); }
+void orc_engine_step(void * h, int solver, double dt, int n_sub, int command_changed, int update_sensors)
+{
+    step(*static_cast<Engine *>(h), solver, dt, n_sub, command_changed, update_sensors);
+}
+// compute_robots_dynamics: a = f(q, v) with the held command, does not touch the state
+void orc_engine_dynamics(void * h, const double * q, const double * v, double * a_out)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    dynamics(e, q, v, a_out);
+}
+int orc_engine_status(void * h) { return static_cast<Engine *>(h)->status; }
+// field getters: same ids as JM_F_*
+int orc_engine_get(void * h, int field, double * out)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    auto cp = [&](const std::vector<double> & s) { std::copy(s.begin(), s.end(), out); return (int)s.size(); };
+    switch (field)
+    {
+    case JM_F_Q: return cp(e.q);
+    case JM_F_V: return cp(e.v);
+    case JM_F_A: return cp(e.a);
+    case JM_F_COMMAND: return cp(e.command);
+    case JM_F_U_MOTOR: return cp(e.uMotor);
+    case JM_F_U: return cp(e.u);
+    case JM_F_F_EXTERNAL: copy_out(e.fExternal, out); return 6 * (int)e.fExternal.size();
+    case JM_F_CONTACT_FORCES: copy_out(e.contactForces, out); return 6 * (int)e.contactForces.size();
+    case JM_F_IMU: return cp(e.imu);
+    case JM_F_FORCE: return cp(e.force);
+    case JM_F_CONTACT: return cp(e.contact);
+    case JM_F_ENCODER: return cp(e.encoder);
+    case JM_F_EFFORT: return cp(e.effort);
+    case JM_F_ENERGY: out[0] = e.kinetic; out[1] = e.potential; return 2;
+    case JM_F_JOINT_FORCES: copy_out(e.df, out); return 6 * (int)e.df.size();
+    case JM_F_CENTROIDAL:
+        out[0] = e.com0.x; out[1] = e.com0.y; out[2] = e.com0.z;
+        to6(e.hg, out + 3); to6(e.dhg, out + 9);
+        return 15;
+    default: return -1;
+    }
+}
+// extra debug getters for the tests: world placement of a joint (R row-major 9, p 3)
+void orc_engine_joint_placement(void * h, int joint, double * out)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = e.oMi[joint].R.m[i][j];
+    out[9] = e.oMi[joint].p.x; out[10] = e.oMi[joint].p.y; out[11] = e.oMi[joint].p.z;
+}
+void orc_integrate(void * h, const double * q, const double * dv, double * qout)
+{
+    integrate(static_cast<Engine *>(h)->mdl, q, dv, qout);
+}
+
+// ---- batch drivers over structure-of-arrays buffers X[component][B] (same layout as the GPU).
+// Lanes [lane_begin, lane_end) are processed sequentially by the calling thread: this is the
+// "one engine, one robot, one thread" shape of the reference, used for parity at batch sizes
+// and as the CPU baseline (bench.py cpu_baseline, kind "port").
+struct orc_batch_io
+{
+    int64_t B;
+    double *q, *v, *a;            // in/out
+    const double * command;       // in
+    double *u_motor, *imu, *force, *contact, *encoder, *effort, *energy, *contact_forces, *f_external;  // out, may be null
+    int32_t * status;             // out, may be null
+};
+static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
+{
+    const int64_t B = io.B;
+    for (int i = 0; i < e.mdl.nq; ++i) e.q[i] = io.q[i * B + l];
+    for (int i = 0; i < e.mdl.nv; ++i) e.v[i] = io.v[i * B + l];
+    for (int i = 0; i < e.mdl.nv; ++i) e.a[i] = io.a[i * B + l];
+    for (size_t i = 0; i < e.command.size(); ++i) e.command[i] = io.command[i * B + l];
+}
+static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
+{
+    const int64_t B = io.B;
+    for (int i = 0; i < e.mdl.nq; ++i) io.q[i * B + l] = e.q[i];
+    for (int i = 0; i < e.mdl.nv; ++i) io.v[i * B + l] = e.v[i];
+    for (int i = 0; i < e.mdl.nv; ++i) io.a[i * B + l] = e.a[i];
+    auto st = [&](double * dst, const std::vector<double> & s) {
+        if (dst) for (size_t i = 0; i < s.size(); ++i) dst[i * B + l] = s[i];
+    };
+    st(io.u_motor, e.uMotor); st(io.imu, e.imu); st(io.force, e.force); st(io.contact, e.contact);
+    st(io.encoder, e.encoder); st(io.effort, e.effort);
+    if (io.energy) { io.energy[l] = e.kinetic; io.energy[B + l] = e.potential; }
+    if (io.contact_forces)
+        for (size_t c = 0; c < e.contactForces.size(); ++c)
+        {
+            double t[6]; to6(e.contactForces[c], t);
+            for (int k = 0; k < 6; ++k) io.contact_forces[(6 * c + k) * B + l] = t[k];
+        }
+    if (io.f_external)
+        for (size_t c = 0; c < e.fExternal.size(); ++c)
+        {
+            double t[6]; to6(e.fExternal[c], t);
+            for (int k = 0; k < 6; ++k) io.f_external[(6 * c + k) * B + l] = t[k];
+        }
+    if (io.status) io.status[l] = e.status;
+}
+// mode 0 = start, 1 = step, 2 = dynamics only (a = f(q,v), q/v untouched)
+void orc_batch_run(void * h, const orc_batch_io * io, int mode, int solver, double dt, int n_sub,
+                   int command_changed, int update_sensors, int64_t lane_begin, int64_t lane_end)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    for (int64_t l = lane_begin; l < lane_end; ++l)
+    {
+        load_lane(e, *io, l);
+        e.status = 0;
+        if (mode == 0) start(e);
+        else if (mode == 1)
+        {
+            // the per-robot pinocchio::Data of the reference persists between steps; here each
+            // lane is reloaded, so refresh the kinematic data the step relies on (fExternal for
+            // extra terms comes from the dynamics evaluations inside the step itself).
+            step(e, solver, dt, n_sub, command_changed, update_sensors);
+        }
+        else
+            dynamics(e, e.q.data(), e.v.data(), e.a.data());
+        store_lane(e, *io, l);
+    }
+}
+}

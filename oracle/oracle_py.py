@@ -1,0 +1,163 @@
+"""ctypes wrapper around liboracle.so (oracle.cpp). TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+from jiminy_amd import _abi
+from jiminy_amd.model import CompiledModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[C.CDLL] = None
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "jiminy_hip.h")
+    stale = (not os.path.exists(path)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return path
+
+
+class BatchIO(C.Structure):
+    _fields_ = [("B", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "q", "v", "a", "command", "u_motor", "imu", "force", "contact", "encoder", "effort",
+        "energy", "contact_forces", "f_external", "status")]
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_engine_create.restype = C.c_void_p
+        L.orc_engine_create.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options)]
+        L.orc_engine_destroy.argtypes = [C.c_void_p]
+        L.orc_engine_set_options.argtypes = [C.c_void_p, C.POINTER(_abi.Options)]
+        pd = C.POINTER(C.c_double)
+        L.orc_engine_set_state.argtypes = [C.c_void_p, pd, pd, pd]
+        L.orc_engine_set_command.argtypes = [C.c_void_p, pd]
+        L.orc_engine_start.argtypes = [C.c_void_p]
+        L.orc_engine_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.orc_engine_dynamics.argtypes = [C.c_void_p, pd, pd, pd]
+        L.orc_engine_status.argtypes = [C.c_void_p]
+        L.orc_engine_status.restype = C.c_int
+        L.orc_engine_get.argtypes = [C.c_void_p, C.c_int, pd]
+        L.orc_engine_get.restype = C.c_int
+        L.orc_engine_joint_placement.argtypes = [C.c_void_p, C.c_int, pd]
+        L.orc_integrate.argtypes = [C.c_void_p, pd, pd, pd]
+        L.orc_batch_run.argtypes = [C.c_void_p, C.POINTER(BatchIO), C.c_int, C.c_int, C.c_double,
+                                    C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]
+        _LIB = L
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+SOLVERS = {"euler_explicit": _abi.JM_SOLVER_EULER_EXPLICIT,
+           "runge_kutta_4": _abi.JM_SOLVER_RUNGE_KUTTA_4}
+
+
+class OracleEngine:
+    """One robot, one thread: the shape of the reference `jiminy.Engine` for this path."""
+
+    def __init__(self, model: CompiledModel, **options) -> None:
+        self.model = model
+        self._desc, self._keep = _abi.make_model_desc(model)
+        self.options = _abi.make_options(**options)
+        self._L = lib()
+        self._h = C.c_void_p(self._L.orc_engine_create(C.byref(self._desc), C.byref(self.options)))
+        self._rows = _abi.field_rows(model)
+        self.t = 0.0
+
+    def __del__(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.orc_engine_destroy(self._h)
+            self._h = None
+
+    def set_options(self, **options) -> None:
+        self.options = _abi.make_options(**options)
+        self._L.orc_engine_set_options(self._h, C.byref(self.options))
+
+    def start(self, q, v, command=None) -> None:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        assert q.shape == (self.model.nq,) and v.shape == (self.model.nv,)
+        self._L.orc_engine_set_state(self._h, _p(q), _p(v), None)
+        self.set_command(np.zeros(self.model.nmotors) if command is None else command)
+        self._L.orc_engine_start(self._h)
+        self.t = 0.0
+
+    def set_state(self, q, v, a) -> None:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self._L.orc_engine_set_state(self._h, _p(q), _p(v), _p(a))
+
+    def set_command(self, command) -> None:
+        c = np.ascontiguousarray(command, dtype=np.float64).reshape(-1)
+        if c.size == 0:
+            c = np.zeros(1)
+        self._L.orc_engine_set_command(self._h, _p(c))
+
+    def step(self, dt: float, n_substeps: int = 1, solver: str = "runge_kutta_4",
+             command_changed: bool = True, update_sensors: bool = True) -> None:
+        self._L.orc_engine_step(self._h, SOLVERS[solver], float(dt), int(n_substeps),
+                                int(command_changed), int(update_sensors))
+        self.t += dt * n_substeps
+
+    def dynamics(self, q, v) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        a = np.zeros(self.model.nv)
+        self._L.orc_engine_dynamics(self._h, _p(q), _p(v), _p(a))
+        return a
+
+    def get(self, name: str) -> np.ndarray:
+        out = np.zeros(max(self._rows[name], 1))
+        n = self._L.orc_engine_get(self._h, _abi.FIELD_NAMES[name], _p(out))
+        return out[:n]
+
+    @property
+    def status(self) -> int:
+        return int(self._L.orc_engine_status(self._h))
+
+    def joint_placement(self, joint: int):
+        out = np.zeros(12)
+        self._L.orc_engine_joint_placement(self._h, joint, _p(out))
+        return out[:9].reshape(3, 3), out[9:]
+
+    def integrate(self, q, dv) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        dv = np.ascontiguousarray(dv, dtype=np.float64)
+        out = np.zeros(self.model.nq)
+        self._L.orc_integrate(self._h, _p(q), _p(dv), _p(out))
+        return out
+
+    # ---- batch drivers over SoA arrays [rows][B] (numpy float64, C-contiguous)
+    def batch_run(self, mode: str, arrays: Dict[str, np.ndarray], solver: str = "runge_kutta_4",
+                  dt: float = 1e-3, n_substeps: int = 1, command_changed: bool = True,
+                  update_sensors: bool = True, lanes=None) -> None:
+        B = arrays["q"].shape[1]
+        io = BatchIO()
+        io.B = B
+        for name, _ in BatchIO._fields_[1:]:
+            arr = arrays.get(name)
+            if arr is not None:
+                assert arr.flags.c_contiguous and arr.shape[-1] == B, name
+                want = np.int32 if name == "status" else np.float64
+                assert arr.dtype == want, name
+                setattr(io, name, arr.ctypes.data)
+        lo, hi = (0, B) if lanes is None else lanes
+        self._L.orc_batch_run(self._h, C.byref(io), {"start": 0, "step": 1, "dynamics": 2}[mode],
+                              SOLVERS[solver], float(dt), int(n_substeps), int(command_changed),
+                              int(update_sensors), lo, hi)

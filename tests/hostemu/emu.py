@@ -1,0 +1,66 @@
+"""Build + ctypes driver of the host emulation of the kernel code (tests only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict
+
+import numpy as np
+
+from jiminy_amd import _abi, codegen
+from jiminy_amd.model import CompiledModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CACHE: Dict[str, C.CDLL] = {}
+
+_FIELDS = ("q", "v", "a", "command", "u_motor", "u", "f_external", "contact_forces", "imu", "force",
+           "contact", "encoder", "effort", "energy", "joint_forces", "centroidal", "status",
+           "q_in", "v_in", "a_out", "mask", "q_init", "v_init")
+
+
+class EmuIO(C.Structure):
+    _fields_ = [("B", C.c_longlong)] + [(n, C.c_void_p) for n in _FIELDS]
+
+
+def _lib(model: CompiledModel) -> C.CDLL:
+    h = model.topology_hash()
+    if h in _CACHE:
+        return _CACHE[h]
+    hdr = codegen.write_header(model)
+    out = os.path.join(codegen.BUILD, f"libemu_{h}.so")
+    deps = [os.path.join(_HERE, "emu.cpp"), hdr] + codegen._sources()[1:] + \
+           [os.path.join(codegen.CSRC, "jm_pack.h")]
+    if (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
+                               "-ffp-contract=off", f"-DJM_TOPO_HEADER=\"{hdr}\"",
+                               os.path.join(_HERE, "emu.cpp"), "-o", out])
+    L = C.CDLL(out)
+    L.emu_run.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options), C.POINTER(EmuIO),
+                          C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+    _CACHE[h] = L
+    return L
+
+
+MODES = {"step": 0, "start": 1, "dynamics": 2, "reset": 3}
+SOLVERS = {"euler_explicit": 0, "runge_kutta_4": 1}
+
+
+def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=None,
+        solver: str = "runge_kutta_4", dt: float = 1e-3, n_substeps: int = 1,
+        command_changed: bool = True, update_sensors: bool = True, dtype=np.float64) -> None:
+    L = _lib(model)
+    desc, keep = _abi.make_model_desc(model)
+    opts = options if options is not None else _abi.make_options()
+    io = EmuIO()
+    io.B = arrays["q"].shape[-1]
+    for n in _FIELDS:
+        a = arrays.get(n)
+        if a is not None:
+            assert a.flags.c_contiguous, n
+            setattr(io, n, a.ctypes.data)
+    rc = L.emu_run(C.byref(desc), C.byref(opts), C.byref(io),
+                   _abi.JM_F64 if dtype == np.float64 else _abi.JM_F32, MODES[mode], SOLVERS[solver],
+                   float(dt), int(n_substeps), int(command_changed), int(update_sensors))
+    if rc != 0:
+        raise RuntimeError(f"emu_run failed with code {rc}")

@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from jiminy_amd import load_builtin
+from jiminy_amd.engine import BatchedEngine
+from jiminy_amd.synthetic import sample_states
+from tests.helpers import alloc_soa, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+OUTS = ("q", "v", "a", "u_motor", "imu", "force", "encoder", "effort", "contact_forces")
+
+
+def _engine(model, B, dtype, solver, dt):
+    eng = BatchedEngine(model, B, dtype=dtype, extra_outputs=("contact_forces", "energy", "f_external"))
+    eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt}})
+    return eng
+
+
+@pytest.mark.parametrize("name,B", [("cartpole", 4096), ("double_pendulum", 256), ("anymal", 256)])
+@pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
+def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
+    model = load_builtin(name)
+    st = sample_states(model, B, seed=3)
+    dt = 1e-3
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    eng = _engine(model, B, torch.float64, solver, dt)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    torch.cuda.synchronize()
+    for k in OUTS + ("energy", "f_external"):
+        got = eng.field(k).cpu().numpy()
+        assert rel_err(got, ref[k]) < 1e-12, (k, rel_err(got, ref[k]))
+    assert np.array_equal(eng.status.cpu().numpy(), ref["status"][0])
+    nsteps = 20
+    for i in range(nsteps):
+        oracle_batch(model, ref, "step", solver=solver, dt=dt, n_substeps=1, command_changed=(i == 0))
+        if i == 0:
+            eng.mark_command_changed()
+        eng.step(dt)
+    torch.cuda.synchronize()
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.sum() > 0.5 * B
+    for k in OUTS:
+        got = eng.field(k).cpu().numpy()
+        # fp64 tolerance: only operation order / FMA contraction differ from the oracle
+        assert rel_err(got, ref[k], ok) < 1e-8, (k, rel_err(got, ref[k], ok))
+    assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
+
+
+def test_anymal_1000_steps_parity_on_accelerations(gpu_device):
+    """north_star bar: <= 1e-5 relative on generalised accelerations over 1000 steps (fp64),
+    first 256 lanes, lanes that stay finite and inside the joint bounds in the oracle."""
+    model = load_builtin("anymal")
+    B, dt = 256, 1e-3
+    # small held commands and moderate velocities keep most lanes inside the bounds for 1 s
+    st = sample_states(model, B, seed=0, command_fraction=0.05, joint_vel_std=0.1,
+                       base_twist_std=0.05, joint_range=0.4)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    worst = 0.0
+    valid = np.ones(B, dtype=bool)
+    for i in range(1000):
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1,
+                     command_changed=False)
+        eng.step(dt)
+        if (i + 1) % 50 == 0:
+            valid &= ref["status"][0] == 0
+            got = eng.field("a").cpu().numpy()
+            if valid.any():
+                worst = max(worst, rel_err(got, ref["a"], valid))
+    assert valid.sum() >= 32, f"only {valid.sum()} lanes stayed valid"
+    assert worst <= 1e-5, worst
+
+
+def test_fp32_tolerance_study_cartpole(gpu_device):
+    """Config 2 of BASELINE.json: cartpole batch 4096, ABA + RK4, fp64 vs fp32."""
+    model = load_builtin("cartpole")
+    B, dt = 4096, 1e-3
+    st = sample_states(model, B, seed=5)
+    outs = {}
+    for dtype in (torch.float64, torch.float32):
+        eng = _engine(model, B, dtype, "runge_kutta_4", dt)
+        eng.set_command(torch.from_numpy(st["command"]).to(dtype))
+        eng.start(torch.from_numpy(st["q"]).to(dtype), torch.from_numpy(st["v"]).to(dtype))
+        for _ in range(100):
+            eng.step(dt)
+        outs[dtype] = eng.field("a").double().cpu().numpy()
+    err = rel_err(outs[torch.float32], outs[torch.float64])
+    assert err < 5e-3, err
+
+
+def test_compute_robots_dynamics_and_reset_lanes(gpu_device):
+    model = load_builtin("anymal")
+    B = 128
+    st = sample_states(model, B, seed=7)
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", 1e-3)
+    eng.set_command(torch.from_numpy(st["command"]))
+    q, v = torch.from_numpy(st["q"]), torch.from_numpy(st["v"])
+    eng.start(q, v)
+    a0 = eng.field("a").clone()
+    a = eng.compute_robots_dynamics(0.0, q, v)
+    assert torch.equal(a, a0)
+    for _ in range(5):
+        eng.step(1e-3)
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[::2] = True
+    a_before = eng.field("a").clone()
+    eng.reset_lanes(mask, q, v)
+    a_after = eng.field("a")
+    assert torch.equal(a_after[:, mask.cuda()], a0[:, mask.cuda()])
+    assert torch.equal(a_after[:, ~mask.cuda()], a_before[:, ~mask.cuda()])
+
+
+def test_control_flow_errors(gpu_device):
+    from jiminy_amd._lib import BadControlFlow
+    model = load_builtin("cartpole")
+    eng = BatchedEngine(model, 64)
+    with pytest.raises(BadControlFlow):
+        eng.step(1e-3)
+    eng.start(np.array([0.0, 1.0, 0.0]), np.zeros(2))
+    with pytest.raises(BadControlFlow):
+        eng.start(np.array([0.0, 1.0, 0.0]), np.zeros(2))
+    with pytest.raises(BadControlFlow):
+        eng.set_options({"stepper": {"dtMax": 1e-3}})
+    eng.stop()
+    with pytest.raises(NotImplementedError):
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri"}})
