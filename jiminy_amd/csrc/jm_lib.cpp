@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -46,8 +47,11 @@ struct jm_model
     std::vector<double> params;  // Layout<Topo>, options tail = defaults
 };
 
+enum { VARIANT_LANE = 0, VARIANT_QUAD = 1 };
+
 struct jm_batch
 {
+    int variant = VARIANT_LANE;
     const jm_model * model = nullptr;
     long long B = 0;
     int dtype = JM_F64;
@@ -109,6 +113,17 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     return A;
 }
 
+// limb-parallel kernel (4 lanes per robot): only instantiated for topologies that have the structure
+template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A, hipStream_t s)
+{
+    if constexpr (Tp::QUAD)
+    {
+        const unsigned grid = (unsigned)((b->B + 15) / 16);
+        hipLaunchKernelGGL((jm::k_quad<T, Tp>), dim3(grid), dim3(64), 0, s, A);
+    }
+    else { (void)b; (void)A; (void)s; }
+}
+
 template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stream)
 {
     HIP_TRY(hipSetDevice(b->device));
@@ -116,7 +131,8 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     const unsigned grid = (unsigned)((b->B + 63) / 64);
     const bool timed = b->timing && b->n_timed < JM_TIMING_RING;
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
-    hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);
+    if (b->variant == VARIANT_QUAD) launch_quad<T, Topo>(b, A, s);
+    else hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);
     HIP_TRY(hipGetLastError());
     if (timed)
     {
@@ -150,6 +166,7 @@ int32_t jm_model_create(const jm_model_desc * desc, jm_model ** out)
     if (!m) return fail(JM_ERUNTIME, "out of host memory");
     m->params = jm::pack_model<Topo>(*desc);
     jm::pack_options<Topo>(m->params, jm::default_options());
+    jm::pack_quad<Topo>(m->params, *desc);
     *out = m;
     return JM_OK;
 }
@@ -174,6 +191,11 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     b->dtype = dtype;
     b->device = device;
     b->params = model->params;
+    // kernel variant: limb-parallel when the topology allows it; JM_KERNEL_VARIANT=lane forces the
+    // generic one-robot-per-lane kernel (A/B measurements)
+    b->variant = Topo::QUAD ? VARIANT_QUAD : VARIANT_LANE;
+    if (const char * v = std::getenv("JM_KERNEL_VARIANT"))
+        if (std::string(v) == "lane") b->variant = VARIANT_LANE;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&b->d_params, b->params.size() * sizeof(double));
     if (e != hipSuccess)

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "jm_kernels.h"
+#include "jm_quad.h"
 
 namespace jm
 {
@@ -84,6 +85,64 @@ template<class Tp> inline std::vector<double> pack_model(const jm_model_desc & d
         }
     for (int s = 0; s < Tp::NENC; ++s) P[L::ENC + s] = d.encoder_reduction[s];
     return P;
+}
+// total size of the parameter block, including the limb table of the limb-parallel kernel
+template<class Tp> constexpr int param_total()
+{
+    if constexpr (Tp::QUAD) return QLayout<Tp>::TOTAL;
+    else return Layout<Tp>::TOTAL;
+}
+// limb table of the limb-parallel kernel (jm_quad.h QLayout), appended to the parameter block
+template<class Tp> inline void pack_quad(std::vector<double> & P, const jm_model_desc & d)
+{
+    if constexpr (Tp::QUAD)
+    {
+        using Q = QLayout<Tp>;
+        P.resize(Q::TOTAL, 0.0);
+        for (int k = 0; k < 4; ++k)
+        {
+            double * T = &P[Q::OFFSET + k * Q::QSTRIDE];
+            for (int s = 0; s < Tp::QN; ++s)
+            {
+                const int j = Tp::limb_joint[k][s];
+                double * o = T + s * Q::QJ;
+                for (int i = 0; i < 9; ++i) o[Q::J_PLC + i] = d.placement_R[9 * j + i];
+                for (int i = 0; i < 3; ++i) o[Q::J_PLC + 9 + i] = d.placement_p[3 * j + i];
+                o[Q::J_RBI] = d.mass[j];
+                for (int i = 0; i < 3; ++i) o[Q::J_RBI + 1 + i] = d.com[3 * j + i];
+                const double * I = d.inertia + 9 * j;
+                o[Q::J_RBI + 4] = I[0]; o[Q::J_RBI + 5] = I[1]; o[Q::J_RBI + 6] = I[2];
+                o[Q::J_RBI + 7] = I[4]; o[Q::J_RBI + 8] = I[5]; o[Q::J_RBI + 9] = I[8];
+                // explicit unit axis also for axis-aligned joints (the limb code is type-generic)
+                const int t = d.jtypes[j];
+                double ax[3] = {d.axes[3 * j], d.axes[3 * j + 1], d.axes[3 * j + 2]};
+                if (t == JM_JT_RX) { ax[0] = 1; ax[1] = 0; ax[2] = 0; }
+                if (t == JM_JT_RY) { ax[0] = 0; ax[1] = 1; ax[2] = 0; }
+                if (t == JM_JT_RZ) { ax[0] = 0; ax[1] = 0; ax[2] = 1; }
+                for (int i = 0; i < 3; ++i) o[Q::J_AXIS + i] = ax[i];
+                o[Q::J_ROTOR] = d.rotor_inertia[d.idx_v[j]];
+                o[Q::J_QLO] = d.position_lower[d.idx_q[j]];
+                o[Q::J_QHI] = d.position_upper[d.idx_q[j]];
+                const int m = Tp::limb_motor[k][s];
+                for (int i = 0; i < JM_MOTOR_NPARAMS; ++i) o[Q::J_MOTOR + i] = d.motor_params[JM_MOTOR_NPARAMS * m + i];
+                o[Q::J_ENC] = Tp::QHAS_ENC ? d.encoder_reduction[Tp::limb_enc[k][s]] : 1.0;
+            }
+            for (int c = 0; c < Tp::QCL; ++c)
+            {
+                const int ci = Tp::limb_contact[k][c];
+                double * o = T + Q::CONTACT + c * Q::QC;
+                for (int i = 0; i < 9; ++i) o[i] = d.contact_R[9 * ci + i];
+                for (int i = 0; i < 3; ++i) o[9 + i] = d.contact_p[3 * ci + i];
+                if constexpr (Tp::QHAS_FORCE)
+                {
+                    const int fs = Tp::limb_force[k];
+                    const double * src = &P[Layout<Tp>::FREL + 12 * (fs * Tp::NC + ci)];
+                    for (int i = 0; i < 12; ++i) o[12 + i] = src[i];
+                }
+            }
+        }
+    }
+    else { (void)P; (void)d; }
 }
 template<class Tp> inline void pack_options(std::vector<double> & P, const jm_options & o)
 {

@@ -2,8 +2,11 @@
 // compiles jiminy_amd/csrc/jm_kernels.h with g++ (-DJM_HOST_EMU) so that the kernel logic can be
 // compared with the oracle on machines without a GPU.
 #define JM_HOST_EMU 1
+#include <pthread.h>
+
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include JM_TOPO_HEADER
 #include "../../jiminy_amd/csrc/jm_kernels.h"
@@ -20,6 +23,64 @@ struct emu_io
 const char * emu_signature() { return Topo::signature; }
 }
 
+// ---- emulation of one DPP quad: 4 host threads in lock-step through a barrier
+struct QuadShared
+{
+    pthread_barrier_t bar;
+    double buf[4];
+    int ibuf[4];
+};
+struct HostQuad
+{
+    static thread_local QuadShared * sh;
+    static thread_local int k;
+    template<class T> static T quad_sum(T x)
+    {
+        sh->buf[k] = (double)x;
+        pthread_barrier_wait(&sh->bar);
+        // same association as the DPP butterflies: (x_k + x_{k^1}) + (x_{k^2} + x_{k^3})
+        const T a = (T)sh->buf[k] + (T)sh->buf[k ^ 1];
+        const T b = (T)sh->buf[k ^ 2] + (T)sh->buf[k ^ 3];
+        pthread_barrier_wait(&sh->bar);
+        return a + b;
+    }
+    static int quad_or(int x)
+    {
+        sh->ibuf[k] = x;
+        pthread_barrier_wait(&sh->bar);
+        const int r = sh->ibuf[0] | sh->ibuf[1] | sh->ibuf[2] | sh->ibuf[3];
+        pthread_barrier_wait(&sh->bar);
+        return r;
+    }
+};
+thread_local QuadShared * HostQuad::sh = nullptr;
+thread_local int HostQuad::k = 0;
+
+template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, const std::vector<T> & P)
+{
+    if constexpr (Tp::QUAD)
+    {
+        QuadShared sh;
+        pthread_barrier_init(&sh.bar, nullptr, 4);
+        const T * table = P.data() + jm::QLayout<Tp>::OFFSET;
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k]() {
+                HostQuad::sh = &sh;
+                HostQuad::k = k;
+                std::vector<T> sb(jm::QRows<Tp>::TOTAL + 1);
+                for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1>(A, r, k, table, sb.data());
+            });
+        for (auto & t : th) t.join();
+        pthread_barrier_destroy(&sh.bar);
+    }
+    else { (void)A; (void)P; }
+}
+
+static int g_variant = 0;  // 0 = one robot per lane, 1 = limb-parallel (4 lanes per robot)
+extern "C" void emu_set_variant(int v) { g_variant = v; }
+extern "C" int emu_has_quad() { return Topo::QUAD ? 1 : 0; }
+
 template<class T>
 static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io, int mode, int solver, double dt,
                int n_sub, int command_changed, int update_sensors)
@@ -28,6 +89,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     if (!jm::check_topology<Topo>(*d, why)) return JM_ETOPOLOGY;
     std::vector<double> Pd = jm::pack_model<Topo>(*d);
     jm::pack_options<Topo>(Pd, *o);
+    jm::pack_quad<Topo>(Pd, *d);
     std::vector<T> P(Pd.begin(), Pd.end());
     jm::BatchArgs<T> A;
     std::memset(&A, 0, sizeof(A));
@@ -42,6 +104,11 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.mask = (const unsigned char *)io->mask; A.q_init = (const T *)io->q_init; A.v_init = (const T *)io->v_init;
     A.B = io->B; A.mode = mode; A.solver = solver; A.n_sub = n_sub; A.command_changed = command_changed;
     A.update_sensors = update_sensors; A.dt = (T)dt;
+    if (g_variant == 1 && Topo::QUAD)
+    {
+        run_quad<T, Topo>(A, P);
+        return 0;
+    }
     std::vector<T> sb(jm::stage_rows<Topo>() + 1);
     for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1>(A, lane, sb.data());
     return 0;

@@ -30,10 +30,10 @@ def _lib(model: CompiledModel) -> C.CDLL:
     hdr = codegen.write_header(model)
     out = os.path.join(codegen.BUILD, f"libemu_{h}.so")
     deps = [os.path.join(_HERE, "emu.cpp"), hdr] + codegen._sources()[1:] + \
-           [os.path.join(codegen.CSRC, "jm_pack.h")]
+           []
     if (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
-                               "-ffp-contract=off", f"-DJM_TOPO_HEADER=\"{hdr}\"",
+                               "-ffp-contract=off", "-pthread", f"-DJM_TOPO_HEADER=\"{hdr}\"",
                                os.path.join(_HERE, "emu.cpp"), "-o", out])
     L = C.CDLL(out)
     L.emu_run.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options), C.POINTER(EmuIO),
@@ -48,8 +48,12 @@ SOLVERS = {"euler_explicit": 0, "runge_kutta_4": 1}
 
 def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=None,
         solver: str = "runge_kutta_4", dt: float = 1e-3, n_substeps: int = 1,
-        command_changed: bool = True, update_sensors: bool = True, dtype=np.float64) -> None:
+        command_changed: bool = True, update_sensors: bool = True, dtype=np.float64,
+        variant: str = "lane") -> None:
     L = _lib(model)
+    if variant == "quad" and not L.emu_has_quad():
+        raise RuntimeError("this topology has no limb-parallel variant")
+    L.emu_set_variant(1 if variant == "quad" else 0)
     desc, keep = _abi.make_model_desc(model)
     opts = options if options is not None else _abi.make_options()
     io = EmuIO()

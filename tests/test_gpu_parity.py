@@ -58,7 +58,10 @@ def test_anymal_1000_steps_parity_on_accelerations(gpu_device):
     """north_star bar: <= 1e-5 relative on generalised accelerations over 1000 steps (fp64),
     first 256 lanes, lanes that stay finite and inside the joint bounds in the oracle."""
     model = load_builtin("anymal")
-    B, dt = 256, 1e-3
+    # dt = 5e-4: with the reference's default contact parameters (k = 1e6 N/m, c = 2e3 N.s/m) and
+    # ANYmal's 0.59 kg shank, explicit RK4 at dt = 1e-3 is outside its stability region as soon as
+    # a foot touches the ground: oracle and GPU both blow up (NaN) within ~150 steps, identically.
+    B, dt = 256, 5e-4
     # Position bounds are numeric parameters of the model (same topology, same library): they are
     # opened here because the reference enforces them through its constraint solver, which is
     # outside this path; lanes are then valid as long as they stay finite.
