@@ -260,6 +260,10 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Wo
 {
     using L = Layout<Tp>;
     constexpr int NJ = Tp::NJ;
+    // universe: frames rigidly attached to the world refer to joint 0
+    w.oMi[0] = {ident3<T>(), zero3<T>()};
+    w.vel[0] = zero6<T>();
+    w.fext[0] = zero6<T>();
     // ---- forward kinematics (+ ABA pass 1 velocity part)
     static_for<1, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;

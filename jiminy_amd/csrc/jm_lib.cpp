@@ -180,6 +180,12 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
 {
     if (!model || !out) return fail(JM_EINVAL, "jm_batch_create: null argument");
     if (batch_size <= 0) return fail(JM_EINVAL, "batch size must be positive");
+    // kernels address every field with unsigned 32-bit element offsets (row * B + lane)
+    {
+        const long long max_rows = 6LL * (Topo::NJ > Topo::NC ? Topo::NJ : Topo::NC) + Topo::NQ + 16;
+        if (batch_size * max_rows >= (1LL << 29))
+            return fail(JM_EINVAL, "batch too large for one jm_batch (32-bit field offsets): shard it over several batches");
+    }
     if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "dtype must be JM_F64 or JM_F32");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

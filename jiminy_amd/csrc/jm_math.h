@@ -12,9 +12,22 @@
 // logic can be checked against the oracle on machines without a GPU. Never part of the product.
 #include <cmath>
 #define JM_DEV inline
+#define JM_REFRESH() ((void)0)
+#define JM_OPAQUE(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define JM_DEV __device__ __forceinline__
+// Compiler-only memory barrier: values read from the (lane-uniform or LDS) constant tables must
+// be re-read after it instead of being hoisted out of the evaluation loop / kept live across the
+// ABA sweeps -- re-reading LDS or the scalar cache is far cheaper than the VGPRs it would pin.
+// Opaque re-definition of a per-lane integer: address arithmetic that depends on it cannot be
+// hoisted out of the evaluation loop (LICM otherwise pins one 64-bit VGPR address per store).
+#define JM_OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef JM_NO_REFRESH
+#define JM_REFRESH() asm volatile("" ::: "memory")
+#else
+#define JM_REFRESH() ((void)0)
+#endif
 #endif
 
 namespace jm

@@ -63,26 +63,35 @@ template<class T, class X> JM_DEV AI<T> quad_sum_ai(const AI<T> & Y)
     return r;
 }
 
-// stage buffer (LDS on the GPU): element `row` of this lane at sb[row * SBS]
-template<class T, int SBS> struct StageBuf
+// stage buffer (LDS on the GPU). Limb rows are per lane (element `row` at sl[row * SL]); trunk rows
+// are identical in the 4 lanes of a quad and stored once per robot (sb[row * SB], written by the
+// lead lane only, read back by all four: LDS operations of one wave execute in order).
+template<class T, int SL, int SB> struct StageBuf
 {
+    T * sl;
     T * sb;
-    JM_DEV T get(int row) const { return sb[row * SBS]; }
-    JM_DEV void put(int row, T x) const { sb[row * SBS] = x; }
+    bool wb;  // this lane writes the trunk rows
+    JM_DEV T getl(int row) const { return sl[row * SL]; }
+    JM_DEV void putl(int row, T x) const { sl[row * SL] = x; }
+    JM_DEV T getb(int row) const { return sb[row * SB]; }
+    JM_DEV void putb(int row, T x) const { if (wb) sb[row * SB] = x; }
 };
 // rows of the stage buffer
 template<class Tp> struct QRows
 {
     static constexpr int N = Tp::QN;
-    static constexpr int Q0B = 0, V0B = 7, A0B = 13, Q0L = 19, V0L = Q0L + N, A0L = V0L + N;
-    static constexpr int ACCVB = A0L + N, ACCAB = ACCVB + 6, ACCVL = ACCAB + 6, ACCAL = ACCVL + N;
-    static constexpr int KVB = ACCAL + N, KVL = KVB + 6, TOTAL = KVL + N;
+    static constexpr int Q0B = 0, V0B = 7, A0B = 13, ACCVB = 19, ACCAB = 25, KVB = 31, NB = 37;  // trunk rows
+    static constexpr int Q0L = 0, V0L = N, A0L = 2 * N, ACCVL = 3 * N, ACCAL = 4 * N, KVL = 5 * N, NL = 6 * N;  // limb rows
 };
 
-template<class T> JM_DEV void put6(T * base, long long B, long long r, int row0, Sp<T> f)
+// All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
+// that they select the `saddr + voffset` addressing form instead of pinning a 64-bit VGPR address
+// per access (the batch size is bounded accordingly in jm_batch_create).
+template<class T> JM_DEV void put6(T * base, unsigned B, unsigned r, unsigned row0, Sp<T> f)
 {
-    T * o = base + (long long)row0 * B + r;
-    o[0] = f.l.x; o[B] = f.l.y; o[2 * B] = f.l.z; o[3 * B] = f.a.x; o[4 * B] = f.a.y; o[5 * B] = f.a.z;
+    const unsigned o = row0 * B + r;
+    base[o] = f.l.x; base[o + B] = f.l.y; base[o + 2 * B] = f.l.z;
+    base[o + 3 * B] = f.a.x; base[o + 4 * B] = f.a.y; base[o + 5 * B] = f.a.z;
 }
 
 // a = f(q, v) for one robot spread over a quad; lane k evaluates limb k.
@@ -100,7 +109,9 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     using L = Layout<Tp>;
     using Q = QLayout<Tp>;
     constexpr int N = Tp::QN;
-    const long long B = A.B;
+    const unsigned B32 = (unsigned)A.B;
+    unsigned r32 = (unsigned)r;
+    JM_OPAQUE(r32);
     const bool lead = (k == 0);
     const bool emit_sens = emit && sensors;
     // ---- encoders read the state itself (basic_sensors.cc:509-539)
@@ -116,8 +127,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     pos *= red;
                     vel *= red;
                 }
-                A.encoder[(long long)(2 * si) * B + r] = pos;
-                A.encoder[(long long)(2 * si + 1) * B + r] = vel;
+                A.encoder[(unsigned)(2 * si) * B32 + r32] = pos;
+                A.encoder[(unsigned)(2 * si + 1) * B32 + r32] = vel;
             });
     // ---- trunk kinematics (free-flyer, joint 1)
     SE3<T> liM1;
@@ -132,9 +143,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     // ---- chain kinematics
     SE3<T> liMi[N];
-    Sp<T> agf[N];   // bias accelerations v x S qd, then a_gf
-    Sp<T> fb[N];    // bias forces v x* (I v)
-    Sp<T> vlast;
+    Sp<T> vel[N];   // spatial velocities; bias acceleration / force are re-derived where they are used
+
     M3<T> oR = liM1.R;
     V3<T> op = liM1.p;
     T kin = T(0), pot = T(0), rot = T(0);
@@ -150,13 +160,12 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             liMi[s] = {plc.R * rot_rodrigues(n, c, sn), plc.p};
             const Sp<T> vj = {zero3<T>(), vl[s] * n};
             const Sp<T> v = vj + actinv_motion(liMi[s], vp);
-            agf[s] = cross_mm(v, vj);
-            const RBI<T> Y = LT.rbi(o + Q::J_RBI);
-            fb[s] = cross_mf(v, rbi_mul(Y, v));
+            vel[s] = v;
             op = op + oR * liMi[s].p;
             oR = oR * liMi[s].R;
             if (want_energy)
             {
+                const RBI<T> Y = LT.rbi(o + Q::J_RBI);
                 kin += rbi_vtiv(Y, v);
                 pot -= Y.m * dot(op + oR * Y.c, g);
                 rot += LT(o + Q::J_ROTOR) * vl[s] * vl[s];
@@ -164,8 +173,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
             vp = v;
         });
-        vlast = vp;
     }
+    const Sp<T> vlast = vel[N - 1];
     const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
     if (want_energy)
     {
@@ -178,8 +187,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         for (int i = 0; i < 6; ++i) rot += P[L::ROTOR + i] * vb[i] * vb[i];
         if (lead)
         {
-            A.energy[r] = T(0.5) * kin + T(0.5) * rot;
-            A.energy[B + r] = pot;
+            A.energy[r32] = T(0.5) * kin + T(0.5) * rot;
+            A.energy[B32 + r32] = pot;
         }
     }
     // ---- contact points on the last chain joint (engine.cc:3117-3238, 3394-3425)
@@ -201,7 +210,6 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         fext_last = fext_last + fl;
         cf[c] = actinv_force(fr, fl);
     });
-    fb[N - 1] = fb[N - 1] - fext_last;
     if (A.mode == MODE_START || A.mode == MODE_RESET)
     {
         T fmax2 = T(0);
@@ -212,11 +220,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     {
         if (A.f_external)
         {
-            if (lead) { put6(A.f_external, B, r, 0, zero6<T>()); put6(A.f_external, B, r, 6, zero6<T>()); }
+            if (lead) { put6(A.f_external, B32, r32, 0, zero6<T>()); put6(A.f_external, B32, r32, 6, zero6<T>()); }
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
-                put6(A.f_external, B, r, 6 * j, (s == N - 1) ? fext_last : zero6<T>());
+                put6(A.f_external, B32, r32, 6 * j, (s == N - 1) ? fext_last : zero6<T>());
             });
         }
         static_for<0, Tp::QCL>([&](auto cc) {
@@ -224,14 +232,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             if (A.contact_forces)
             {
                 const int ci = sel4(k, Tp::limb_contact[0][c], Tp::limb_contact[1][c], Tp::limb_contact[2][c], Tp::limb_contact[3][c]);
-                put6(A.contact_forces, B, r, 6 * ci, cf[c]);
+                put6(A.contact_forces, B32, r32, 6 * ci, cf[c]);
             }
             if constexpr (Tp::QHAS_CS)
                 if (sensors && A.contact)
                 {
                     const int si = sel4(k, Tp::limb_cs[0][c], Tp::limb_cs[1][c], Tp::limb_cs[2][c], Tp::limb_cs[3][c]);
-                    T * o = A.contact + (long long)(3 * si) * B + r;
-                    o[0] = cf[c].l.x; o[B] = cf[c].l.y; o[2 * B] = cf[c].l.z;
+                    const unsigned o = (unsigned)(3 * si) * B32 + r32;
+                    A.contact[o] = cf[c].l.x; A.contact[o + B32] = cf[c].l.y; A.contact[o + 2 * B32] = cf[c].l.z;
                 }
         });
         if constexpr (Tp::QHAS_FORCE)
@@ -243,7 +251,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     sum = sum + act_force(LT.se3(Q::CONTACT + c * Q::QC + 12), cf[c]);
                 });
                 const int si = sel4(k, Tp::limb_force[0], Tp::limb_force[1], Tp::limb_force[2], Tp::limb_force[3]);
-                put6(A.force, B, r, 6 * si, sum);
+                put6(A.force, B32, r32, 6 * si, sum);
             }
     }
     // ---- motors (one per chain joint, uniform flags; basic_motors.cc:83-143)
@@ -282,22 +290,23 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         u[s] = ut;
         if (emit)
         {
-            if (A.u_motor) A.u_motor[(long long)rm[s] * B + r] = um;
-            if (A.u) A.u[(long long)rv[s] * B + r] = ut;
+            if (A.u_motor) A.u_motor[(unsigned)rm[s] * B32 + r32] = um;
+            if (A.u) A.u[(unsigned)rv[s] * B32 + r32] = ut;
             if constexpr (Tp::QHAS_EFF)
                 if (sensors && A.effort)
                 {
                     const int si = sel4(k, Tp::limb_eff[0][s], Tp::limb_eff[1][s], Tp::limb_eff[2][s], Tp::limb_eff[3][s]);
-                    A.effort[(long long)si * B + r] = um;
+                    A.effort[(unsigned)si * B32 + r32] = um;
                 }
         }
     });
     if (emit && A.u && lead)
     {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) A.u[(long long)i * B + r] = T(0);
+        for (int i = 0; i < 6; ++i) A.u[(unsigned)i * B32 + r32] = T(0);
     }
     // ---- ABA pass 2 along the chain, leaf -> trunk (AbaBackwardStep)
+    JM_REFRESH();
     Sp<T> U[N];
     T dinv[N];
     AI<T> Ia;
@@ -306,10 +315,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         constexpr int s = decltype(sc)::value;
         constexpr int o = s * Q::QJ;
         const RBI<T> Y = LT.rbi(o + Q::J_RBI);
-        Sp<T> f = fb[s];
-        if constexpr (s == N - 1) Ia = ai_from_rbi(Y);
-        else { f = f + pa_up; Ia = ai_from_rbi(Y) + Ia; }
         const V3<T> n = LT.v3(o + Q::J_AXIS);
+        Sp<T> f = cross_mf(vel[s], rbi_mul(Y, vel[s]));  // bias force v x* (I v)
+        if constexpr (s == N - 1) { f = f - fext_last; Ia = ai_from_rbi(Y); }
+        else { f = f + pa_up; Ia = ai_from_rbi(Y) + Ia; }
+        const Sp<T> cb = cross_mm(vel[s], Sp<T>{zero3<T>(), vl[s] * n});  // bias acceleration v x S qd
         const T uj = u[s] - dot(n, f.a);
         u[s] = uj;
         const Sp<T> Us = {Ia.B * n, Ia.D * n};
@@ -318,7 +328,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         U[s] = Us;
         dinv[s] = di;
         ai_rank1_sub(Ia, Us, di);
-        const Sp<T> Ya = ai_mul(Ia, agf[s]);
+        const Sp<T> Ya = ai_mul(Ia, cb);
         const T ud = uj * di;
         const Sp<T> pa = {f.l + Ya.l + ud * Us.l, f.a + Ya.a + ud * Us.a};
         Ia = ai_transform(liMi[s], Ia);
@@ -358,19 +368,20 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             af.l = af.l + cross(vf.a, vf.l);
             const V3<T> gl = tmul(fr.R, tmul(liM1.R, g));
             const V3<T> acc3 = af.l - gl;
-            T * o = A.imu + (long long)(6 * s) * B + r;
-            o[0] = vf.a.x; o[B] = vf.a.y; o[2 * B] = vf.a.z; o[3 * B] = acc3.x; o[4 * B] = acc3.y; o[5 * B] = acc3.z;
+            put6(A.imu, B32, r32, 6 * s, Sp<T>{vf.a, acc3});
         });
     // ---- ABA pass 3 down the chain (AbaForwardStep2)
+    JM_REFRESH();
     {
         Sp<T> ap = agf1 + a1;
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const Sp<T> ag = agf[s] + actinv_motion(liMi[s], ap);
+            const V3<T> n = LT.v3(s * Q::QJ + Q::J_AXIS);
+            const Sp<T> cb = cross_mm(vel[s], Sp<T>{zero3<T>(), vl[s] * n});
+            const Sp<T> ag = cb + actinv_motion(liMi[s], ap);
             const T Ua = dot(U[s].l, ag.l) + dot(U[s].a, ag.a);
             const T dd = dinv[s] * (u[s] - Ua);
             ddq[s] = dd;
-            const V3<T> n = LT.v3(s * Q::QJ + Q::J_AXIS);
             ap = {ag.l, ag.a + dd * n};
         });
     }
@@ -381,79 +392,124 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         static_for<0, N>([&](auto sc) { bad |= (ddq[decltype(sc)::value] != ddq[decltype(sc)::value]); });
         if (bad) status |= JM_LANE_NAN;
     }
-    // ---- optional RNEA-like extra terms (engine.cc:858-904): joint wrenches, centroidal momentum
-    if (emit && (A.joint_forces || A.centroidal))
+}
+
+// Optional RNEA-like extra terms (engine.cc:858-904): joint internal wrenches (data.f) and
+// centroidal quantities.  Off the critical path: when requested, the kinematics are re-derived
+// from the state here so that nothing of the dynamics evaluation has to stay live for it.
+template<class T, class Tp, class X>
+JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, long long r, int k,
+                             const T * qb, const T * vb, const T * ql, const T * vl, const T * ddq1, const T * ddq)
+{
+    using L = Layout<Tp>;
+    using Q = QLayout<Tp>;
+    constexpr int N = Tp::QN;
+    const unsigned B32 = (unsigned)A.B, r32 = (unsigned)r;
+    const bool lead = (k == 0);
+    const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+    SE3<T> liM1;
     {
-        const Sp<T> agf1f = a1 + agf1;
-        Sp<T> vel[N], da[N], dagf[N];
-        {
-            Sp<T> vp = v1, ap = a1, agp = agf1f;
-            static_for<0, N>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                const V3<T> n = LT.v3(s * Q::QJ + Q::J_AXIS);
-                const Sp<T> vj = {zero3<T>(), vl[s] * n};
-                vel[s] = vj + actinv_motion(liMi[s], vp);
-                const Sp<T> aj = cross_mm(vel[s], vj) + Sp<T>{zero3<T>(), ddq[s] * n};
-                da[s] = aj + actinv_motion(liMi[s], ap);
-                dagf[s] = aj + actinv_motion(liMi[s], agp);
-                vp = vel[s]; ap = da[s]; agp = dagf[s];
-            });
-        }
-        Sp<T> h[N], fB[N], fj[N];
+        SE3<T> Mj;
+        Mj.R = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
+        Mj.p = {qb[0], qb[1], qb[2]};
+        liM1 = ld_se3<T>(P, L::JOINT + 1 * L::JSTRIDE) * Mj;
+    }
+    const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
+    const Sp<T> a1 = {{ddq1[0], ddq1[1], ddq1[2]}, {ddq1[3], ddq1[4], ddq1[5]}};
+    const Sp<T> agf1f = a1 + actinv_motion(liM1, Sp<T>{-g, -gw});
+    const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
+    SE3<T> liMi[N];
+    Sp<T> vel[N], da[N], dagf[N];
+    M3<T> oR = liM1.R;
+    V3<T> op = liM1.p;
+    {
+        Sp<T> vp = v1, ap = a1, agp = agf1f;
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
-            h[s] = rbi_mul(Y, vel[s]);
-            const Sp<T> vxh = cross_mf(vel[s], h[s]);
-            fB[s] = rbi_mul(Y, da[s]) + vxh;
-            fj[s] = vxh + rbi_mul(Y, dagf[s]);
-            if constexpr (s == N - 1) fj[s] = fj[s] - fext_last;
+            constexpr int o = s * Q::QJ;
+            T c, sn;
+            sincos_(ql[s], &sn, &c);
+            const V3<T> n = LT.v3(o + Q::J_AXIS);
+            const SE3<T> plc = LT.se3(o + Q::J_PLC);
+            liMi[s] = {plc.R * rot_rodrigues(n, c, sn), plc.p};
+            const Sp<T> vj = {zero3<T>(), vl[s] * n};
+            vel[s] = vj + actinv_motion(liMi[s], vp);
+            const Sp<T> aj = cross_mm(vel[s], vj) + Sp<T>{zero3<T>(), ddq[s] * n};
+            da[s] = aj + actinv_motion(liMi[s], ap);
+            dagf[s] = aj + actinv_motion(liMi[s], agp);
+            op = op + oR * liMi[s].p;
+            oR = oR * liMi[s].R;
+            vp = vel[s]; ap = da[s]; agp = dagf[s];
         });
-        static_rfor<1, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            fB[s - 1] = fB[s - 1] + act_force(liMi[s], fB[s]);
-            h[s - 1] = h[s - 1] + act_force(liMi[s], h[s]);
-            fj[s - 1] = fj[s - 1] + act_force(liMi[s], fj[s]);
-        });
-        const Sp<T> h1l = rbi_mul(Y1, v1);
-        const Sp<T> vxh1 = cross_mf(v1, h1l);
-        const Sp<T> h1 = h1l + quad_sum6<T, X>(act_force(liMi[0], h[0]));
-        const Sp<T> fB1 = rbi_mul(Y1, a1) + vxh1 + quad_sum6<T, X>(act_force(liMi[0], fB[0]));
-        const Sp<T> fj1 = vxh1 + rbi_mul(Y1, agf1f) + quad_sum6<T, X>(act_force(liMi[0], fj[0]));
-        if (A.joint_forces)
+    }
+    Sp<T> fext_last = zero6<T>();
+    static_for<0, Tp::QCL>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const SE3<T> fr = LT.se3(Q::CONTACT + c * Q::QC);
+        const T depth = op.z + dot(V3<T>{oR.m20, oR.m21, oR.m22}, fr.p);
+        if (depth < T(0))
         {
-            if (lead) { put6(A.joint_forces, B, r, 0, zero6<T>()); put6(A.joint_forces, B, r, 6, fj1); }
-            static_for<0, N>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
-                put6(A.joint_forces, B, r, 6 * j, fj[s]);
-            });
+            const V3<T> vj = vel[N - 1].l + cross(vel[N - 1].a, fr.p);
+            const V3<T> fW = contact_law<T, Tp>(P, depth, oR * vj);
+            Sp<T> fl;
+            fl.l = tmul(oR, fW);
+            fl.a = cross(fr.p, fl.l);
+            fext_last = fext_last + fl;
         }
-        if (A.centroidal)
+    });
+    Sp<T> h[N], fB[N], fj[N];
+    static_for<0, N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
+        h[s] = rbi_mul(Y, vel[s]);
+        const Sp<T> vxh = cross_mf(vel[s], h[s]);
+        fB[s] = rbi_mul(Y, da[s]) + vxh;
+        fj[s] = vxh + rbi_mul(Y, dagf[s]);
+        if constexpr (s == N - 1) fj[s] = fj[s] - fext_last;
+    });
+    static_rfor<1, N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        fB[s - 1] = fB[s - 1] + act_force(liMi[s], fB[s]);
+        h[s - 1] = h[s - 1] + act_force(liMi[s], h[s]);
+        fj[s - 1] = fj[s - 1] + act_force(liMi[s], fj[s]);
+    });
+    const Sp<T> h1l = rbi_mul(Y1, v1);
+    const Sp<T> vxh1 = cross_mf(v1, h1l);
+    const Sp<T> h1 = h1l + quad_sum6<T, X>(act_force(liMi[0], h[0]));
+    const Sp<T> fB1 = rbi_mul(Y1, a1) + vxh1 + quad_sum6<T, X>(act_force(liMi[0], fB[0]));
+    const Sp<T> fj1 = vxh1 + rbi_mul(Y1, agf1f) + quad_sum6<T, X>(act_force(liMi[0], fj[0]));
+    if (A.joint_forces)
+    {
+        if (lead) { put6(A.joint_forces, B32, r32, 0, zero6<T>()); put6(A.joint_forces, B32, r32, 6, fj1); }
+        static_for<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
+            put6(A.joint_forces, B32, r32, 6 * j, fj[s]);
+        });
+    }
+    if (A.centroidal)
+    {
+        T ms = T(0);
+        V3<T> mc = zero3<T>();
+        static_rfor<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
+            ms = ms + Y.m;
+            mc = mc + Y.m * Y.c;
+            mc = liMi[s].R * mc + ms * liMi[s].p;
+        });
+        const T mt = Y1.m + X::quad_sum(ms);
+        const V3<T> mct = Y1.m * Y1.c + V3<T>{X::quad_sum(mc.x), X::quad_sum(mc.y), X::quad_sum(mc.z)};
+        const V3<T> c1 = (T(1) / mt) * mct;
+        const V3<T> com0 = liM1.R * c1 + liM1.p;
+        Sp<T> hg = act_force(liM1, h1), dhg = act_force(liM1, fB1);
+        hg.a = hg.a + cross(hg.l, com0);
+        dhg.a = dhg.a + cross(dhg.l, com0);
+        if (lead)
         {
-            T ms = T(0);
-            V3<T> mc = zero3<T>();
-            static_rfor<0, N>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
-                ms = ms + Y.m;
-                mc = mc + Y.m * Y.c;
-                mc = liMi[s].R * mc + ms * liMi[s].p;
-            });
-            const T mt = Y1.m + X::quad_sum(ms);
-            const V3<T> mct = Y1.m * Y1.c + V3<T>{X::quad_sum(mc.x), X::quad_sum(mc.y), X::quad_sum(mc.z)};
-            const V3<T> c1 = (T(1) / mt) * mct;
-            const V3<T> com0 = liM1.R * c1 + liM1.p;
-            Sp<T> hg = act_force(liM1, h1), dhg = act_force(liM1, fB1);
-            hg.a = hg.a + cross(hg.l, com0);
-            dhg.a = dhg.a + cross(dhg.l, com0);
-            if (lead)
-            {
-                T * o = A.centroidal + r;
-                o[0] = com0.x; o[B] = com0.y; o[2 * B] = com0.z;
-                put6(A.centroidal, B, r, 3, hg);
-                put6(A.centroidal, B, r, 9, dhg);
-            }
+            A.centroidal[r32] = com0.x; A.centroidal[B32 + r32] = com0.y; A.centroidal[2 * B32 + r32] = com0.z;
+            put6(A.centroidal, B32, r32, 3, hg);
+            put6(A.centroidal, B32, r32, 9, dhg);
         }
     }
 }
@@ -476,17 +532,16 @@ template<class T> JM_DEV void integrate_freeflyer(const T * q, const T * d, T * 
     qo[3] = x * al; qo[4] = y * al; qo[5] = z * al; qo[6] = ww * al;
 }
 
-// one lane of a quad: robot r, limb k. `sbp` = this lane's stage buffer (LDS), stride SBS.
-template<class T, class Tp, class X, int SBS>
-JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, T * sbp)
+// one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.
+template<class T, class Tp, class X, int SL, int SB>
+JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S)
 {
     using Q = QLayout<Tp>;
     using R = QRows<Tp>;
     constexpr int N = Tp::QN;
-    const long long B = A.B;
+    const unsigned B32 = (unsigned)A.B, r32 = (unsigned)r;
     CPtr<T> P = (CPtr<T>)A.P;
     const LimbTable<T> LT{limb_table + k * Q::QSTRIDE};
-    const StageBuf<T, SBS> S{sbp};
     // per-lane row indices of this limb's joints
     int rq[N], rv[N], rm[N];
     static_for<0, N>([&](auto sc) {
@@ -498,46 +553,46 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     const bool lead = (k == 0);
     int status = 0;
     T qb[7], vb[6], ql[N], vl[N], cmd[N], ddq1[6], ddq[N];
-    static_for<0, N>([&](auto sc) { cmd[decltype(sc)::value] = A.command[(long long)rm[decltype(sc)::value] * B + r]; });
+    static_for<0, N>([&](auto sc) { cmd[decltype(sc)::value] = A.command[(unsigned)rm[decltype(sc)::value] * B32 + r32]; });
 
     auto load_state = [&](const T * qsrc, const T * vsrc) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) qb[i] = qsrc[(long long)i * B + r];
+        for (int i = 0; i < 7; ++i) qb[i] = qsrc[(unsigned)i * B32 + r32];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) vb[i] = vsrc[(long long)i * B + r];
+        for (int i = 0; i < 6; ++i) vb[i] = vsrc[(unsigned)i * B32 + r32];
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            ql[s] = qsrc[(long long)rq[s] * B + r];
-            vl[s] = vsrc[(long long)rv[s] * B + r];
+            ql[s] = qsrc[(unsigned)rq[s] * B32 + r32];
+            vl[s] = vsrc[(unsigned)rv[s] * B32 + r32];
         });
     };
     auto store_a = [&](T * dst) {
         if (lead)
         {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) dst[(long long)i * B + r] = ddq1[i];
+            for (int i = 0; i < 6; ++i) dst[(unsigned)i * B32 + r32] = ddq1[i];
         }
-        static_for<0, N>([&](auto sc) { dst[(long long)rv[decltype(sc)::value] * B + r] = ddq[decltype(sc)::value]; });
+        static_for<0, N>([&](auto sc) { dst[(unsigned)rv[decltype(sc)::value] * B32 + r32] = ddq[decltype(sc)::value]; });
     };
     auto store_status = [&]() {
         const int st = X::quad_or(status);
-        if (A.status && lead) A.status[r] = st;
+        if (A.status && lead) A.status[r32] = st;
     };
 
     if (A.mode == MODE_RESET)
     {
-        if (!A.mask[r]) return;  // uniform over the quad
+        if (!A.mask[r32]) return;  // uniform over the quad
         if (lead)
         {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) A.q[(long long)i * B + r] = A.q_init[(long long)i * B + r];
+            for (int i = 0; i < 7; ++i) A.q[(unsigned)i * B32 + r32] = A.q_init[(unsigned)i * B32 + r32];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) A.v[(long long)i * B + r] = A.v_init[(long long)i * B + r];
+            for (int i = 0; i < 6; ++i) A.v[(unsigned)i * B32 + r32] = A.v_init[(unsigned)i * B32 + r32];
         }
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            A.q[(long long)rq[s] * B + r] = A.q_init[(long long)rq[s] * B + r];
-            A.v[(long long)rv[s] * B + r] = A.v_init[(long long)rv[s] * B + r];
+            A.q[(unsigned)rq[s] * B32 + r32] = A.q_init[(unsigned)rq[s] * B32 + r32];
+            A.v[(unsigned)rv[s] * B32 + r32] = A.v_init[(unsigned)rv[s] * B32 + r32];
         });
     }
     if (A.mode != MODE_STEP)
@@ -553,6 +608,13 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             return;
         }
         store_a(A.a);
+        if (A.joint_forces || A.centroidal)
+        {
+            JM_REFRESH();
+            if (A.mode == MODE_RESET) load_state(A.q_init, A.v_init);
+            else load_state(A.q, A.v);
+            quad_extra_terms<T, Tp, X>(P, LT, A, r, k, qb, vb, ql, vl, ddq1, ddq);
+        }
         store_status();
         return;
     }
@@ -565,34 +627,39 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     {
         bool bad = false;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { const T x = A.q[(long long)i * B + r]; S.put(R::Q0B + i, x); bad |= (x != x); }
+        for (int i = 0; i < 7; ++i) { const T x = A.q[(unsigned)i * B32 + r32]; S.putb(R::Q0B + i, x); bad |= (x != x); }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
         {
-            const T x = A.v[(long long)i * B + r], y = A.a[(long long)i * B + r];
-            S.put(R::V0B + i, x); S.put(R::A0B + i, y);
+            const T x = A.v[(unsigned)i * B32 + r32], y = A.a[(unsigned)i * B32 + r32];
+            S.putb(R::V0B + i, x); S.putb(R::A0B + i, y);
             bad |= (x != x) || (y != y);
         }
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const T x = A.q[(long long)rq[s] * B + r], y = A.v[(long long)rv[s] * B + r], z = A.a[(long long)rv[s] * B + r];
-            S.put(R::Q0L + s, x); S.put(R::V0L + s, y); S.put(R::A0L + s, z);
+            const T x = A.q[(unsigned)rq[s] * B32 + r32], y = A.v[(unsigned)rv[s] * B32 + r32], z = A.a[(unsigned)rv[s] * B32 + r32];
+            S.putl(R::Q0L + s, x); S.putl(R::V0L + s, y); S.putl(R::A0L + s, z);
             bad |= (x != x) || (y != y) || (z != z);
         });
         if (bad) status |= JM_LANE_NAN;
     }
+    // The 4 lanes of a quad execute in lock-step on the GPU, so every lane has read the trunk
+    // rows of q/v/a before the lead lane overwrites them at commit time; the host emulation
+    // (one thread per lane) needs an explicit rendez-vous for the same guarantee.
+    X::sync();
 #pragma nounroll
     for (int e = 0; e < n_evals; ++e)
     {
         const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
         const bool last = (e == n_evals - 1);
+        JM_REFRESH();
         if (st == -1)
         {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) qb[i] = S.get(R::Q0B + i);
+            for (int i = 0; i < 7; ++i) qb[i] = S.getb(R::Q0B + i);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) vb[i] = S.get(R::V0B + i);
-            static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.get(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.get(R::V0L + decltype(sc)::value); });
+            for (int i = 0; i < 6; ++i) vb[i] = S.getb(R::V0B + i);
+            static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
         }
         else
         {
@@ -606,58 +673,58 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             else { bw = dt; aw = dt; }
             T incb[6], q0b[7];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) q0b[i] = S.get(R::Q0B + i);
+            for (int i = 0; i < 7; ++i) q0b[i] = S.getb(R::Q0B + i);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
             {
-                const T v0 = S.get(R::V0B + i);
-                const T kv = first ? v0 : S.get(R::KVB + i);
-                const T ka = first ? S.get(R::A0B + i) : ddq1[i];
-                const T av = (first || !rk4) ? bw * kv : S.get(R::ACCVB + i) + bw * kv;
-                const T aa = (first || !rk4) ? bw * ka : S.get(R::ACCAB + i) + bw * ka;
+                const T v0 = S.getb(R::V0B + i);
+                const T kv = first ? v0 : S.getb(R::KVB + i);
+                const T ka = first ? S.getb(R::A0B + i) : ddq1[i];
+                const T av = (first || !rk4) ? bw * kv : S.getb(R::ACCVB + i) + bw * kv;
+                const T aa = (first || !rk4) ? bw * ka : S.getb(R::ACCAB + i) + bw * ka;
                 if (st == 3) { incb[i] = av; vb[i] = v0 + aa; }
                 else
                 {
-                    S.put(R::ACCVB + i, av); S.put(R::ACCAB + i, aa);
-                    incb[i] = aw * kv; vb[i] = v0 + aw * ka; S.put(R::KVB + i, vb[i]);
+                    S.putb(R::ACCVB + i, av); S.putb(R::ACCAB + i, aa);
+                    incb[i] = aw * kv; vb[i] = v0 + aw * ka; S.putb(R::KVB + i, vb[i]);
                 }
             }
             integrate_freeflyer<T>(q0b, incb, qb);
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                const T q0 = S.get(R::Q0L + s), v0 = S.get(R::V0L + s);
-                const T kv = first ? v0 : S.get(R::KVL + s);
-                const T ka = first ? S.get(R::A0L + s) : ddq[s];
-                const T av = (first || !rk4) ? bw * kv : S.get(R::ACCVL + s) + bw * kv;
-                const T aa = (first || !rk4) ? bw * ka : S.get(R::ACCAL + s) + bw * ka;
+                const T q0 = S.getl(R::Q0L + s), v0 = S.getl(R::V0L + s);
+                const T kv = first ? v0 : S.getl(R::KVL + s);
+                const T ka = first ? S.getl(R::A0L + s) : ddq[s];
+                const T av = (first || !rk4) ? bw * kv : S.getl(R::ACCVL + s) + bw * kv;
+                const T aa = (first || !rk4) ? bw * ka : S.getl(R::ACCAL + s) + bw * ka;
                 if (st == 3) { ql[s] = q0 + av; vl[s] = v0 + aa; }
                 else
                 {
-                    S.put(R::ACCVL + s, av); S.put(R::ACCAL + s, aa);
-                    ql[s] = q0 + aw * kv; vl[s] = v0 + aw * ka; S.put(R::KVL + s, vl[s]);
+                    S.putl(R::ACCVL + s, av); S.putl(R::ACCAL + s, aa);
+                    ql[s] = q0 + aw * kv; vl[s] = v0 + aw * ka; S.putl(R::KVL + s, vl[s]);
                 }
             });
             if (st == 3)
             {
                 // commit: the new state becomes the start of the next sub-step
 #pragma unroll
-                for (int i = 0; i < 7; ++i) S.put(R::Q0B + i, qb[i]);
+                for (int i = 0; i < 7; ++i) S.putb(R::Q0B + i, qb[i]);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) S.put(R::V0B + i, vb[i]);
-                static_for<0, N>([&](auto sc) { S.put(R::Q0L + decltype(sc)::value, ql[decltype(sc)::value]); S.put(R::V0L + decltype(sc)::value, vl[decltype(sc)::value]); });
+                for (int i = 0; i < 6; ++i) S.putb(R::V0B + i, vb[i]);
+                static_for<0, N>([&](auto sc) { S.putl(R::Q0L + decltype(sc)::value, ql[decltype(sc)::value]); S.putl(R::V0L + decltype(sc)::value, vl[decltype(sc)::value]); });
                 if (last)
                 {
                     if (lead)
                     {
 #pragma unroll
-                        for (int i = 0; i < 7; ++i) A.q[(long long)i * B + r] = qb[i];
+                        for (int i = 0; i < 7; ++i) A.q[(unsigned)i * B32 + r32] = qb[i];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) A.v[(long long)i * B + r] = vb[i];
+                        for (int i = 0; i < 6; ++i) A.v[(unsigned)i * B32 + r32] = vb[i];
                     }
                     static_for<0, N>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
-                        A.q[(long long)rq[s] * B + r] = ql[s];
-                        A.v[(long long)rv[s] * B + r] = vl[s];
+                        A.q[(unsigned)rq[s] * B32 + r32] = ql[s];
+                        A.v[(unsigned)rv[s] * B32 + r32] = vl[s];
                     });
                 }
             }
@@ -666,13 +733,24 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         if (st == -1 || st == 3)
         {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) S.put(R::A0B + i, ddq1[i]);
-            static_for<0, N>([&](auto sc) { S.put(R::A0L + decltype(sc)::value, ddq[decltype(sc)::value]); });
+            for (int i = 0; i < 6; ++i) S.putb(R::A0B + i, ddq1[i]);
+            static_for<0, N>([&](auto sc) { S.putl(R::A0L + decltype(sc)::value, ddq[decltype(sc)::value]); });
         }
         if (last)
         {
             store_a(A.a);
             store_status();
+            if (A.joint_forces || A.centroidal)
+            {
+                // the committed state sits in the stage buffer
+                JM_REFRESH();
+#pragma unroll
+                for (int i = 0; i < 7; ++i) qb[i] = S.getb(R::Q0B + i);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vb[i] = S.getb(R::V0B + i);
+                static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
+                quad_extra_terms<T, Tp, X>(P, LT, A, r, k, qb, vb, ql, vl, ddq1, ddq);
+            }
         }
     }
 }
@@ -700,6 +778,7 @@ struct DppQuad
         x |= mov<0x4E>(x);
         return x;
     }
+    static __device__ __forceinline__ void sync() {}  // lanes of a wave are already in lock-step
 };
 
 #ifndef JM_QUAD_WAVES_PER_EU
@@ -711,13 +790,15 @@ k_quad(const BatchArgs<T> A)
 {
     using Q = QLayout<Tp>;
     __shared__ T table[Q::TABLE];
-    __shared__ T stage[QRows<Tp>::TOTAL * 64];
+    __shared__ T stage_l[QRows<Tp>::NL * 64];
+    __shared__ T stage_b[QRows<Tp>::NB * 16];
     for (int i = threadIdx.x; i < Q::TABLE; i += 64) table[i] = A.P[Q::OFFSET + i];
     __syncthreads();
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 2);
     const int k = threadIdx.x & 3;
     if (r >= A.B) return;  // uniform over the quad
-    quad_lane_run<T, Tp, DppQuad, 64>(A, r, k, table, stage + threadIdx.x);
+    const StageBuf<T, 64, 16> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    quad_lane_run<T, Tp, DppQuad, 64, 16>(A, r, k, table, S);
 }
 #endif
 }  // namespace jm

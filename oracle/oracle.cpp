@@ -1180,6 +1180,7 @@ struct orc_batch_io
     const double * command;       // in
     double *u_motor, *imu, *force, *contact, *encoder, *effort, *energy, *contact_forces, *f_external;  // out, may be null
     int32_t * status;             // out, may be null
+    double *joint_forces, *centroidal, *u;  // out, may be null
 };
 static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
@@ -1214,6 +1215,19 @@ static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
             for (int k = 0; k < 6; ++k) io.f_external[(6 * c + k) * B + l] = t[k];
         }
     if (io.status) io.status[l] = e.status;
+    if (io.joint_forces)
+        for (size_t c = 0; c < e.df.size(); ++c)
+        {
+            double t[6]; to6(e.df[c], t);
+            for (int k = 0; k < 6; ++k) io.joint_forces[(6 * c + k) * B + l] = t[k];
+        }
+    if (io.centroidal)
+    {
+        double t[15] = {e.com0.x, e.com0.y, e.com0.z};
+        to6(e.hg, t + 3); to6(e.dhg, t + 9);
+        for (int k = 0; k < 15; ++k) io.centroidal[k * B + l] = t[k];
+    }
+    st(io.u, e.u);
 }
 // mode 0 = start, 1 = step, 2 = dynamics only (a = f(q,v), q/v untouched)
 void orc_batch_run(void * h, const orc_batch_io * io, int mode, int solver, double dt, int n_sub,

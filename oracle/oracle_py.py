@@ -30,7 +30,7 @@ def build(force: bool = False) -> str:
 class BatchIO(C.Structure):
     _fields_ = [("B", C.c_int64)] + [(n, C.c_void_p) for n in (
         "q", "v", "a", "command", "u_motor", "imu", "force", "contact", "encoder", "effort",
-        "energy", "contact_forces", "f_external", "status")]
+        "energy", "contact_forces", "f_external", "status", "joint_forces", "centroidal", "u")]
 
 
 def lib() -> C.CDLL:

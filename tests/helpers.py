@@ -10,7 +10,8 @@ from jiminy_amd.model import CompiledModel
 from oracle.oracle_py import OracleEngine
 
 ORACLE_FIELDS = ("q", "v", "a", "command", "u_motor", "imu", "force", "contact", "encoder",
-                 "effort", "energy", "contact_forces", "f_external")
+                 "effort", "energy", "contact_forces", "f_external", "joint_forces", "centroidal",
+                 "u")
 
 
 def alloc_soa(model: CompiledModel, B: int, dtype=np.float64) -> Dict[str, np.ndarray]:

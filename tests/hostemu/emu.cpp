@@ -44,6 +44,7 @@ struct HostQuad
         pthread_barrier_wait(&sh->bar);
         return a + b;
     }
+    static void sync() { pthread_barrier_wait(&sh->bar); }
     static int quad_or(int x)
     {
         sh->ibuf[k] = x;
@@ -68,8 +69,9 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
             th.emplace_back([&, k]() {
                 HostQuad::sh = &sh;
                 HostQuad::k = k;
-                std::vector<T> sb(jm::QRows<Tp>::TOTAL + 1);
-                for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1>(A, r, k, table, sb.data());
+                std::vector<T> sl(jm::QRows<Tp>::NL + 1), sb(jm::QRows<Tp>::NB + 1);
+                const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};  // private trunk rows per thread
+                for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1, 1>(A, r, k, table, S);
             });
         for (auto & t : th) t.join();
         pthread_barrier_destroy(&sh.bar);

@@ -1,0 +1,56 @@
+"""Small robots authored for the test-suite (URDFs under tests/data/, written for this repo)."""
+from __future__ import annotations
+
+import os
+from typing import List
+
+from jiminy_amd.model import (CompiledModel, add_contact_points, add_motor, add_sensor,
+                              build_model_from_urdf, build_robot)
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def pendulum(armature: float = 0.0) -> CompiledModel:
+    m = build_model_from_urdf(os.path.join(DATA, "pendulum.urdf"), name="pendulum")
+    add_motor(m, "pivot", "pivot", enableVelocityLimit=False, enableEffortLimit=False,
+              enableArmature=armature > 0, armature=armature)
+    add_sensor(m, "EncoderSensor", "pivot", joint_name="pivot")
+    add_sensor(m, "ImuSensor", "tip", frame_name="tip")
+    return m
+
+
+def double_pendulum() -> CompiledModel:
+    m = build_model_from_urdf(os.path.join(DATA, "double_pendulum.urdf"), name="double_pendulum_test")
+    for j in ("shoulder", "elbow"):
+        add_motor(m, j, j, enableVelocityLimit=False, enableEffortLimit=False)
+    return m
+
+
+def point_mass() -> CompiledModel:
+    m = build_model_from_urdf(os.path.join(DATA, "point_mass.urdf"), has_freeflyer=True,
+                              name="point_mass")
+    add_contact_points(m, ["body"])
+    add_sensor(m, "ContactSensor", "body", frame_name="body")
+    add_sensor(m, "ForceSensor", "sole", frame_name="sole")
+    add_sensor(m, "ImuSensor", "sole", frame_name="sole")
+    return m
+
+
+def two_masses() -> CompiledModel:
+    m = build_model_from_urdf(os.path.join(DATA, "two_masses.urdf"), name="two_masses")
+    for j in ("slide_a", "slide_b"):
+        add_motor(m, j, j, enableVelocityLimit=False, enableEffortLimit=False)
+        add_sensor(m, "EncoderSensor", j, joint_name=j)
+    return m
+
+
+def tree_arm(has_freeflyer: bool) -> CompiledModel:
+    return build_robot(os.path.join(DATA, "tree_arm.urdf"),
+                       os.path.join(DATA, "tree_arm_hardware.toml"),
+                       has_freeflyer=has_freeflyer,
+                       name="tree_arm_ff" if has_freeflyer else "tree_arm")
+
+
+def all_test_models() -> List[CompiledModel]:
+    return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
+            tree_arm(True)]

@@ -1,0 +1,192 @@
+"""The per-lane kernel code (jiminy_amd/csrc/*.h) compiled for the host (tests/hostemu) against
+the CPU oracle: same seeded inputs, every mode, both kernel variants.  This runs without a GPU and
+pins the kernel *logic*; the `-m gpu` tests pin the device build of the same sources."""
+import numpy as np
+import pytest
+
+from jiminy_amd import load_builtin
+from jiminy_amd.synthetic import sample_states
+from tests import robots
+from tests.helpers import alloc_soa, oracle_batch, rel_err
+from tests.hostemu import emu
+
+OUTS = ("q", "v", "a", "u_motor", "u", "imu", "force", "contact", "encoder", "effort", "energy",
+        "contact_forces", "f_external", "joint_forces", "centroidal")
+
+
+def _models():
+    return {
+        "cartpole": lambda: load_builtin("cartpole"),
+        "double_pendulum": lambda: load_builtin("double_pendulum"),
+        "anymal": lambda: load_builtin("anymal"),
+        "pendulum": robots.pendulum,
+        "point_mass": robots.point_mass,
+        "two_masses": robots.two_masses,
+        "tree_arm": lambda: robots.tree_arm(False),
+        "tree_arm_ff": lambda: robots.tree_arm(True),
+    }
+
+
+def _states(model, B, seed):
+    return sample_states(model, B, seed=seed, base_height=(0.3, 0.6), grounded_fraction=0.6)
+
+
+def _pair(model, B, seed):
+    st = _states(model, B, seed)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        if st[k].shape[0]:
+            ref[k][:] = st[k]
+            got[k][:] = st[k]
+    return ref, got
+
+
+def _check(got, ref, tol, lanes=None, what=""):
+    for k in OUTS:
+        e = rel_err(got[k], ref[k], lanes)
+        assert e < tol, (what, k, e)
+
+
+@pytest.mark.parametrize("name", list(_models()))
+@pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
+def test_lane_kernel_matches_oracle(name, solver):
+    model = _models()[name]()
+    B = 24
+    ref, got = _pair(model, B, seed=2)
+    oracle_batch(model, ref, "start")
+    emu.run(model, got, "start")
+    _check(got, ref, 1e-12, what="start")
+    assert np.array_equal(got["status"], ref["status"])
+    for i in range(6):
+        kw = dict(solver=solver, dt=5e-4, n_substeps=2 if i % 2 else 1, command_changed=(i % 3 == 0))
+        oracle_batch(model, ref, "step", **kw)
+        emu.run(model, got, "step", **kw)
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.any()
+    _check(got, ref, 1e-9, ok, what="steps")
+    assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
+
+
+@pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
+def test_quad_kernel_matches_oracle(solver):
+    model = load_builtin("anymal")
+    B = 24
+    ref, got = _pair(model, B, seed=4)
+    oracle_batch(model, ref, "start")
+    emu.run(model, got, "start", variant="quad")
+    _check(got, ref, 1e-12, what="start")
+    assert np.array_equal(got["status"], ref["status"])
+    assert (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() >= 3  # contact branch exercised
+    for i in range(6):
+        kw = dict(solver=solver, dt=5e-4, n_substeps=2 if i % 2 else 1, command_changed=(i % 3 == 0))
+        oracle_batch(model, ref, "step", **kw)
+        emu.run(model, got, "step", variant="quad", **kw)
+    ok = (ref["status"][0] & 1) == 0
+    _check(got, ref, 1e-9, ok, what="steps")
+    assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
+
+
+@pytest.mark.parametrize("variant", ["lane", "quad"])
+def test_sensors_are_only_refreshed_on_request(variant):
+    model = load_builtin("anymal")
+    ref, got = _pair(model, 8, seed=5)
+    emu.run(model, got, "start", variant=variant)
+    before = {k: got[k].copy() for k in ("imu", "force", "encoder", "effort")}
+    emu.run(model, got, "step", dt=1e-3, update_sensors=False, variant=variant)
+    for k, v in before.items():
+        assert np.array_equal(got[k], v), k
+    emu.run(model, got, "step", dt=1e-3, update_sensors=True, variant=variant)
+    assert not np.array_equal(got["encoder"], before["encoder"])
+
+
+@pytest.mark.parametrize("variant", ["lane", "quad"])
+def test_dynamics_and_reset_modes(variant):
+    model = load_builtin("anymal")
+    B = 16
+    st = _states(model, B, 6)
+    ref, got = _pair(model, B, 6)
+    oracle_batch(model, ref, "start")
+    emu.run(model, got, "start", variant=variant)
+    # compute_robots_dynamics at another state leaves the bound state untouched
+    st2 = _states(model, B, 7)
+    got["q_in"], got["v_in"] = st2["q"].copy(), st2["v"].copy()
+    got["a_out"] = np.zeros_like(got["a"])
+    keep = {k: got[k].copy() for k in ("q", "v", "a", "imu")}
+    emu.run(model, got, "dynamics", variant=variant)
+    for k, v in keep.items():
+        assert np.array_equal(got[k], v), k
+    ref2 = alloc_soa(model, B)
+    ref2["q"][:], ref2["v"][:], ref2["command"][:] = st2["q"], st2["v"], st["command"]
+    oracle_batch(model, ref2, "dynamics")
+    assert rel_err(got["a_out"], ref2["a"]) < 1e-12
+    # reset of a subset of lanes == start of those lanes, the others untouched
+    for _ in range(3):
+        emu.run(model, got, "step", dt=1e-3, variant=variant)
+    mask = np.zeros(B, dtype=np.uint8)
+    mask[::3] = 1
+    got["mask"], got["q_init"], got["v_init"] = mask, st2["q"].copy(), st2["v"].copy()
+    before = {k: got[k].copy() for k in OUTS}
+    emu.run(model, got, "reset", variant=variant)
+    sel = mask.astype(bool)
+    ref3 = alloc_soa(model, B)
+    ref3["q"][:], ref3["v"][:], ref3["command"][:] = st2["q"], st2["v"], st["command"]
+    oracle_batch(model, ref3, "start")
+    for k in OUTS:
+        assert rel_err(got[k], ref3[k], sel) < 1e-12, k
+        assert np.array_equal(got[k][:, ~sel], before[k][:, ~sel]), k
+
+
+@pytest.mark.parametrize("variant", ["lane", "quad"])
+def test_fp32_build_is_within_single_precision_of_fp64(variant):
+    model = load_builtin("anymal")
+    B = 16
+    st = sample_states(model, B, seed=8, grounded_fraction=0.0, base_height=(1.0, 1.2))
+    a64, a32 = alloc_soa(model, B), alloc_soa(model, B, np.float32)
+    for k in ("q", "v", "command"):
+        a64[k][:] = st[k]
+        a32[k][:] = st[k]
+    emu.run(model, a64, "start", variant=variant)
+    emu.run(model, a32, "start", variant=variant, dtype=np.float32)
+    assert rel_err(a32["a"].astype(np.float64), a64["a"]) < 2e-4
+    for _ in range(10):
+        emu.run(model, a64, "step", dt=1e-3, variant=variant)
+        emu.run(model, a32, "step", dt=1e-3, variant=variant, dtype=np.float32)
+    assert rel_err(a32["q"].astype(np.float64), a64["q"]) < 1e-4
+    assert rel_err(a32["a"].astype(np.float64), a64["a"]) < 5e-3
+
+
+@pytest.mark.slow
+def test_long_horizon_sensitivity():
+    """1000 RK4 steps with ground contacts: the kernel code and the oracle only differ by
+    summation order, yet the worst lane drifts by many orders of magnitude (chaotic contact
+    events) while the median stays near round-off. This is the yardstick for the statistical bar
+    of the GPU contact parity test."""
+    model = load_builtin("anymal")
+    mask = model.bounded_position_mask()
+    model.position_lower[mask] = -np.inf
+    model.position_upper[mask] = np.inf
+    B, dt = 48, 5e-4
+    st = sample_states(model, B, seed=0, command_fraction=0.05, joint_vel_std=0.1,
+                       base_twist_std=0.05, joint_range=0.4)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+        got[k][:] = st[k]
+    from oracle.oracle_py import OracleEngine
+    from tests.helpers import oracle_io
+    eng = OracleEngine(model)
+    io = oracle_io(ref)
+    eng.batch_run("start", io)
+    emu.run(model, got, "start", variant="lane")
+    bad = np.zeros(B, dtype=bool)
+    for _ in range(1000):
+        eng.batch_run("step", io, solver="runge_kutta_4", dt=dt, command_changed=False)
+        emu.run(model, got, "step", solver="runge_kutta_4", dt=dt, command_changed=False, variant="lane")
+        bad |= ref["status"][0] != 0
+    ok = ~bad
+    num = np.abs(got["a"] - ref["a"]).max(axis=0)[ok]
+    den = np.maximum(np.abs(ref["a"]).max(axis=0), 1.0)[ok]
+    err = num / den
+    assert ok.sum() >= 32
+    assert np.median(err) < 1e-9
+    assert (err <= 1e-5).mean() >= 0.9
