@@ -46,7 +46,9 @@ def all_gather_observations(fields: Sequence[torch.Tensor],
     """
     world = dist.get_world_size()
     packed = pack_observations(fields, out[0] if out else None)
-    gathered = out[1] if out else torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype,
+    rows, B = int(packed.shape[0]), int(packed.shape[1])
+    gathered = out[1] if out else torch.empty((world, rows, B), dtype=packed.dtype,
                                                device=packed.device)
-    dist.all_gather_into_tensor(gathered, packed)
+    # concatenation along dim 0 of the flat view (layout accepted by both RCCL and gloo)
+    dist.all_gather_into_tensor(gathered.view(world * rows, B), packed)
     return [packed, gathered]

@@ -1,0 +1,86 @@
+"""The C-ABI shared libraries load and export every symbol include/jiminy_hip.h declares;
+the entry points that do not touch the device behave (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from jiminy_amd import _abi, _lib, codegen, load_builtin
+from tests import robots
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "jiminy_hip.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jm_[a-z_]+)\s*\(", text)))
+
+
+def _prebuilt(model):
+    path = codegen.lib_path(model)
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not built (run __graft_entry__.build())")
+    return _lib.load_for(model, allow_build=False)
+
+
+def test_header_and_loader_agree_on_the_symbol_list():
+    assert _declared_symbols() == sorted(_lib.ABI_SYMBOLS)
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "anymal", "atlas"])
+def test_library_exports_every_declared_symbol(name):
+    model = load_builtin(name)
+    lib = _prebuilt(model)
+    for sym in _declared_symbols():
+        assert hasattr(lib.L, sym), sym
+    assert lib.signature() == model.topology_signature()
+    assert lib.L.jm_abi_version() == _abi.ABI_VERSION
+
+
+def test_model_create_validates_the_topology():
+    model = load_builtin("cartpole")
+    lib = _prebuilt(model)
+    desc, keep = _abi.make_model_desc(model)
+    h = C.c_void_p()
+    assert lib.L.jm_model_create(C.byref(desc), C.byref(h)) == _abi.JM_OK and h.value
+    assert lib.L.jm_model_destroy(h) == _abi.JM_OK
+    other, keep2 = _abi.make_model_desc(load_builtin("double_pendulum"))
+    h2 = C.c_void_p()
+    rc = lib.L.jm_model_create(C.byref(other), C.byref(h2))
+    assert rc == _abi.JM_ETOPOLOGY
+    with pytest.raises(_lib.TopologyMismatch, match="topology mismatch"):
+        lib.check(rc)
+    assert lib.L.jm_model_create(None, C.byref(h2)) == _abi.JM_EINVAL
+
+
+def test_two_topology_libraries_coexist_in_one_process():
+    a, b = load_builtin("cartpole"), load_builtin("anymal")
+    la, lb = _prebuilt(a), _prebuilt(b)
+    assert la.signature() == a.topology_signature() and lb.signature() == b.topology_signature()
+    for lib, model in ((la, a), (lb, b)):
+        desc, keep = _abi.make_model_desc(model)
+        h = C.c_void_p()
+        assert lib.L.jm_model_create(C.byref(desc), C.byref(h)) == _abi.JM_OK
+        lib.L.jm_model_destroy(h)
+
+
+def test_generated_topology_header():
+    text = codegen.topology_header(load_builtin("anymal"))
+    assert "static constexpr bool QUAD = true;" in text and "limb_joint[4][3]" in text
+    assert "QUAD = false" in codegen.topology_header(robots.tree_arm(True))
+    assert codegen.quad_structure(load_builtin("atlas")) is None
+
+
+def test_model_desc_packing():
+    model = load_builtin("anymal")
+    d, keep = _abi.make_model_desc(model)
+    assert (d.njoints, d.nq, d.nv, d.nmotors, d.ncontacts) == (14, 19, 18, 12, 4)
+    assert (d.nimu, d.nforce, d.nencoder, d.neffort) == (1, 4, 12, 12)
+    assert [d.parents[i] for i in range(14)] == [int(x) for x in model.parents]
+    assert d.motor_flags[0] == _abi.JM_MOTOR_EFFORT_LIMIT | _abi.JM_MOTOR_VELOCITY_LIMIT
+    assert d.motor_params[1] == 80.0 and d.motor_params[2] == 7.5 and d.motor_params[3] == 0.02
+    rows = _abi.field_rows(model)
+    assert rows["imu"] == 6 and rows["force"] == 24 and rows["encoder"] == 24 and rows["effort"] == 12

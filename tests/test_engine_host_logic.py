@@ -1,0 +1,72 @@
+"""Host-side logic of the engine facade that does not need a GPU."""
+import math
+
+import numpy as np
+import pytest
+
+from jiminy_amd import engine as E
+
+
+def _opts(**stepper):
+    o = E.default_options()
+    o["stepper"].update(stepper)
+    return o
+
+
+def test_default_options_follow_the_reference_names():
+    o = E.default_options()
+    assert o["world"]["gravity"] == [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]
+    assert o["contacts"]["stiffness"] == 1.0e6 and o["contacts"]["damping"] == 2.0e3
+    assert o["contacts"]["transitionEps"] == 1.0e-3 and o["contacts"]["transitionVelocity"] == 1.0e-2
+    assert o["stepper"]["dtMax"] == 0.02
+
+
+def test_plan_gym_style_step():
+    # shipped ANYmal options: 5 ms control/sensor period, 40 ms env step (anymal.py:20)
+    o = _opts(dtMax=1e-3, controllerUpdatePeriod=5e-3, sensorsUpdatePeriod=5e-3)
+    launches, t_end, t_err = E.plan_step(0.0, 0.0, 0.04, o)
+    assert len(launches) == 8
+    for dt, n, cmd, sens in launches:
+        assert dt == pytest.approx(1e-3) and n == 5 and cmd and sens
+    assert t_end == pytest.approx(0.04)
+
+
+def test_plan_single_fixed_step_and_default_step_size():
+    o = _opts(dtMax=1e-3, controllerUpdatePeriod=1e-3, sensorsUpdatePeriod=1e-3)
+    launches, t_end, _ = E.plan_step(0.0, 0.0, -1.0, o)       # default = controller period
+    assert launches == [(pytest.approx(1e-3), 1, True, True)]
+    # continuous controller, dtMax sub-steps, last one shortened to land on t_end
+    o = _opts(dtMax=1e-3, controllerUpdatePeriod=0.0, sensorsUpdatePeriod=0.0)
+    launches, t_end, _ = E.plan_step(0.0, 0.0, 2.5e-3, o)
+    assert [(round(dt, 9), n) for dt, n, _, _ in launches] == [(1e-3, 2), (5e-4, 1)]
+    assert launches[0][2] and not launches[1][2] and launches[-1][3]
+
+
+def test_plan_sensor_period_multiple_of_controller_period():
+    o = _opts(dtMax=2e-3, controllerUpdatePeriod=2e-3, sensorsUpdatePeriod=4e-3)
+    launches, _, _ = E.plan_step(0.0, 0.0, 8e-3, o)
+    assert [l[3] for l in launches] == [False, True, False, True]
+    assert all(l[2] for l in launches)
+
+
+def test_time_accumulation_is_compensated():
+    o = _opts(dtMax=1e-3, controllerUpdatePeriod=1e-3, sensorsUpdatePeriod=1e-3)
+    t, err = 0.0, 0.0
+    for _ in range(10000):
+        launches, t, err = E.plan_step(t, err, 1e-3, o)
+        assert len(launches) == 1 and launches[0][1] == 1
+    assert abs(t - 10.0) < 1e-12
+
+
+def test_step_size_out_of_bounds():
+    with pytest.raises(ValueError):
+        E.plan_step(0.0, 0.0, 1e-8, _opts(dtMax=1e-3))
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from jiminy_amd import load_builtin
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        E.BatchedEngine(load_builtin("cartpole"), 8)

@@ -1,0 +1,151 @@
+"""Model compiler: URDF + hardware TOML -> flat arrays, conventions of the reference's model."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from jiminy_amd import load_builtin
+from jiminy_amd.model import (CompiledModel, JT_FREEFLYER, JT_PU, JT_PY, JT_RU, JT_RUBU, JT_RUBX,
+                              JT_RY, JT_RZ, SE3, Inertia, add_motor, add_sensor, rpy_to_matrix)
+from tests import robots
+
+
+def test_joint_order_is_depth_first_alphabetical_by_joint_name():
+    m = robots.tree_arm(True)
+    assert m.joint_names == ["universe", "root_joint", "a_slide", "a_spin", "b_yaw", "c_skew",
+                             "d_skew_slide", "d_skew_spin"]
+    assert list(m.parents) == [0, 0, 1, 2, 1, 4, 1, 6]
+    assert list(m.idx_q) == [0, 0, 7, 8, 10, 11, 12, 13]
+    assert list(m.idx_v) == [0, 0, 6, 7, 8, 9, 10, 11]
+    assert m.nq == 15 and m.nv == 12
+
+
+def test_joint_type_classification():
+    m = robots.tree_arm(False)
+    t = {n: int(x) for n, x in zip(m.joint_names, m.jtypes)}
+    assert t["a_slide"] == JT_PY          # exact +y axis -> aligned
+    assert t["a_spin"] == JT_RUBX         # continuous, aligned
+    assert t["b_yaw"] == JT_RZ
+    assert t["c_skew"] == JT_RU           # (0.6, 0, 0.8) -> unaligned, already unit
+    assert t["d_skew_slide"] == JT_PU
+    assert t["d_skew_spin"] == JT_RUBU    # (0, 1, 1) normalised
+    j = m.joint_index("d_skew_spin")
+    assert np.allclose(m.axes[j], [0, 1 / math.sqrt(2), 1 / math.sqrt(2)])
+    # -x is NOT axis aligned (ANYmal RF/RH/LH joints)
+    a = load_builtin("anymal")
+    assert int(a.jtypes[a.joint_index("RF_HFE")]) == JT_RU
+    assert np.allclose(a.axes[a.joint_index("RF_HFE")], [-1, 0, 0])
+    assert int(a.jtypes[1]) == JT_FREEFLYER
+
+
+def test_fixed_joint_inertia_lumping_matches_hand_computation():
+    m = robots.tree_arm(False)
+    # root link chain pedestal -> trunk -> plate are all rigidly attached to the universe here;
+    # with a free-flyer they are lumped into the root joint body
+    mf = robots.tree_arm(True)
+    Mt = SE3(np.eye(3), np.array([0, 0, 0.75]))
+    trunk = Inertia(4.0, np.array([0.01, -0.02, 0.03]), None)
+    R = rpy_to_matrix([0.1, 0.2, -0.3])
+    I_trunk = R @ np.array([[0.08, 0.004, -0.003], [0.004, 0.09, 0.002], [-0.003, 0.002, 0.05]]) @ R.T
+    trunk = Inertia(4.0, np.array([0.01, -0.02, 0.03]), I_trunk).transformed(Mt)
+    Mp = Mt * SE3(rpy_to_matrix([0, 0.5, 0]), np.array([0.1, 0, 0.2]))
+    Rp = rpy_to_matrix([0.3, 0, 0])
+    I_plate = Rp @ np.array([[0.004, 0, 0.001], [0, 0.006, 0], [0.001, 0, 0.005]]) @ Rp.T
+    plate = Inertia(0.7, np.array([0, 0.05, 0]), I_plate).transformed(Mp)
+    tot = trunk.add(plate)
+    assert mf.mass[1] == pytest.approx(4.7)
+    assert np.allclose(mf.com[1], tot.com, atol=1e-14)
+    assert np.allclose(mf.inertia[1], tot.I, atol=1e-14)
+    # parallel axis check against the definition: I about the common COM
+    def about(I, m_, c, pt):
+        d = c - pt
+        return I + m_ * (d @ d * np.eye(3) - np.outer(d, d))
+    ref = about(trunk.I, trunk.mass, trunk.com, tot.com) + about(plate.I, plate.mass, plate.com, tot.com)
+    assert np.allclose(tot.I, ref, atol=1e-14)
+    # joint placements accumulate the fixed transforms
+    j = m.joint_index("b_yaw")
+    assert np.allclose(m.placement_p[j], [0, 0.15, 0.85])
+    f = m.frame("tool")
+    assert f.parent_joint == m.joint_index("c_skew") and np.allclose(f.p, [0, 0, 0.3])
+
+
+def test_hardware_file_semantics():
+    m = robots.tree_arm(True)
+    assert m.contacts == ["fan", "plate", "tool"]           # registered in sorted order (robot.py:717)
+    mot = {x.name: x for x in m.motors}
+    assert mot["m_yaw"].reduction == 2.0
+    assert mot["m_yaw"].effort_limit == pytest.approx(30 / 2.0)   # URDF effort / reduction
+    assert mot["m_yaw"].velocity_limit == pytest.approx(20 * 2.0)
+    assert mot["m_yaw"].armature == pytest.approx(0.01 * 4.0)     # armature * reduction^2, forced on
+    assert not mot["m_slide"].enable_effort_limit
+    iv = int(m.idx_v[m.joint_index("b_yaw")])
+    assert m.rotor_inertia[iv] == pytest.approx(0.04)
+    assert [s["name"] for s in m.sensors["ImuSensor"]] == ["imu_tool", "imu_new"]
+    fr = m.frame("imu_new_frame")
+    assert fr.parent_joint == m.joint_index("b_yaw")
+    enc = {s["name"]: s for s in m.sensors["EncoderSensor"]}
+    assert enc["enc_yaw"]["joint_side"] is False and enc["enc_yaw"]["reduction"] == 2.0
+    assert enc["enc_spin"]["joint_side"] is True
+    with pytest.raises(ValueError):
+        add_motor(m, "m_yaw", "b_yaw")                     # duplicate motor name
+    with pytest.raises(LookupError):
+        add_motor(m, "other", "not_a_joint")
+    with pytest.raises(ValueError):
+        add_motor(m, "ff", "root_joint")                   # motors need a 1-dof joint
+    with pytest.raises(ValueError):
+        add_sensor(m, "ContactSensor", "x", frame_name="tool_nope")
+
+
+def test_neutral_and_bounds():
+    m = robots.tree_arm(True)
+    q = m.neutral()
+    assert q[6] == 1.0 and np.allclose(q[:6], 0)
+    iq = int(m.idx_q[m.joint_index("a_spin")])
+    assert q[iq] == 1.0 and q[iq + 1] == 0.0
+    mask = m.bounded_position_mask()
+    assert mask.sum() == 4 and not mask[:7].any()
+    assert m.position_lower[int(m.idx_q[m.joint_index("b_yaw")])] == -2.5
+
+
+def test_json_roundtrip_and_topology_hash():
+    m = robots.tree_arm(True)
+    m2 = CompiledModel.from_json(m.to_json())
+    assert m2.topology_signature() == m.topology_signature()
+    for k in ("placement_R", "placement_p", "mass", "com", "inertia", "rotor_inertia", "position_lower",
+              "effort_limit"):
+        assert np.array_equal(getattr(m, k), getattr(m2, k)), k
+    assert m2.motors[0] == m.motors[0]
+    # parameters do not enter the hash, structure does
+    m2.mass[1] += 1.0
+    assert m2.topology_hash() == m.topology_hash()
+    assert robots.tree_arm(False).topology_hash() != m.topology_hash()
+
+
+@pytest.mark.parametrize("name,nq,nv,nm,nc", [("double_pendulum", 2, 2, 2, 0), ("cartpole", 3, 2, 1, 0),
+                                              ("anymal", 19, 18, 12, 4), ("atlas", 37, 36, 30, 32)])
+def test_builtin_models(name, nq, nv, nm, nc):
+    m = load_builtin(name)
+    assert (m.nq, m.nv, m.nmotors, m.ncontacts) == (nq, nv, nm, nc)
+    if name == "anymal":
+        # SURVEY.md section 7 "hard parts": model order is LF, LH, RF, RH (alphabetical), the
+        # hardware file lists motors as LF, RF, LH, RH; contacts are sorted by name
+        assert m.joint_names[2:5] == ["LF_HAA", "LF_HFE", "LF_KFE"] and m.joint_names[5] == "LH_HAA"
+        assert [x.name for x in m.motors][3] == "RF_HAA"
+        assert m.contacts == ["LF_FOOT", "LH_FOOT", "RF_FOOT", "RH_FOOT"]
+        assert np.allclose(m.rotor_inertia[6:], 0.1)
+        assert m.mass.sum() == pytest.approx(52.13485)
+    if name == "cartpole":
+        assert int(m.jtypes[2]) == 10  # continuous about y -> [cos, sin]
+        assert m.mass[2] == pytest.approx(0.1) and np.allclose(m.com[2], [0, 0, 1.0])
+
+
+def test_builtin_models_match_the_reference_urdfs_when_present():
+    ref = "/root/reference/data/quadrupedal_robots/anymal/anymal.urdf"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not available on this machine")
+    from jiminy_amd.model import build_robot
+    m = build_robot(ref, has_freeflyer=True, name="anymal")
+    b = load_builtin("anymal")
+    assert m.topology_signature() == b.topology_signature()
+    assert np.array_equal(m.inertia, b.inertia) and np.array_equal(m.placement_R, b.placement_R)

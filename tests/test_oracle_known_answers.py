@@ -1,0 +1,249 @@
+"""Pins of the CPU oracle: the reference's own known-answer laws, re-expressed without
+jiminy / pinocchio (SURVEY.md section 8c lists the reference tests each of these restates).
+
+The reference holds no stored numeric vectors for this path: every pin is an analytical law, a
+conservation law, a self-consistency identity or a comparison with an independent integrator.
+"""
+import numpy as np
+import pytest
+from scipy.integrate import solve_ivp
+from scipy.linalg import expm
+
+from jiminy_amd import load_builtin
+from jiminy_amd.synthetic import sample_states
+from oracle import rbd_numpy as rbd
+from oracle.oracle_py import OracleEngine
+from tests import robots
+
+G = 9.81
+
+
+# ---- (2) reference unit_py/test_simple_pendulum.py:240-267: nonlinear pendulum vs scipy
+def test_pendulum_matches_independent_integration():
+    m = robots.pendulum()
+    e = OracleEngine(m)
+    theta0, dt, n = 1.0, 1e-3, 2000
+    e.start(np.array([theta0]), np.array([0.0]))
+    for _ in range(n):
+        e.step(dt, command_changed=False)
+    # point mass at l = 1 m below... the rod points along +z at q = 0 (inverted), axis y:
+    # theta'' = (g / l) sin(theta)
+    sol = solve_ivp(lambda t, x: [x[1], G * np.sin(x[0])], (0, n * dt), [theta0, 0.0],
+                    method="DOP853", rtol=1e-12, atol=1e-12)
+    assert abs(e.get("q")[0] - sol.y[0, -1]) < 1e-7
+    assert abs(e.get("v")[0] - sol.y[1, -1]) < 1e-7
+
+
+# ---- (3) reference test_simple_pendulum.py:100-141: armature adds to the joint inertia (I + J)
+def test_armature_enters_as_rotor_inertia():
+    J = 0.7
+    m = robots.pendulum(armature=J)
+    assert m.rotor_inertia[0] == pytest.approx(J)
+    e = OracleEngine(m)
+    theta = 0.3
+    e.start(np.array([theta]), np.array([0.0]))
+    # (m l^2 + J) theta'' = m g l sin(theta)
+    assert e.get("a")[0] == pytest.approx(5.0 * G * np.sin(theta) / (5.0 + J), rel=1e-13)
+    # linearised around the stable equilibrium (theta = pi): compare with expm over 1 s
+    w2 = 5.0 * G / (5.0 + J)
+    A = np.array([[0.0, 1.0], [-w2, 0.0]])
+    x0 = np.array([1e-4, 0.0])
+    e.start(np.array([np.pi + x0[0]]), np.array([0.0]))
+    for _ in range(1000):
+        e.step(1e-3, command_changed=False)
+    xf = expm(A * 1.0) @ x0
+    assert abs((e.get("q")[0] - np.pi) - xf[0]) < 1e-9
+    assert abs(e.get("v")[0] - xf[1]) < 1e-9
+
+
+# ---- (1) reference core/unit/engine_sanity_check.cc:45-165: energy conservation, double pendulum
+def test_double_pendulum_energy_is_conserved():
+    m = robots.double_pendulum()
+    e = OracleEngine(m)
+    e.start(np.array([1.0, 0.0]), np.zeros(2))
+    en = [e.get("energy").sum()]
+    for _ in range(10000):  # 10 s at 1 kHz, RK4
+        e.step(1e-3, command_changed=False)
+        en.append(e.get("energy").sum())
+    en = np.array(en)
+    assert en.max() - en.min() < 1e-9 * max(1.0, abs(en[0]))
+
+
+# ---- (6) reference test_double_spring_mass.py:105-127: 2-DoF linear chain, discrete control
+def test_two_mass_spring_chain_matches_exact_discretisation():
+    m = robots.two_masses()
+    e = OracleEngine(m, gravity=(0, 0, 0, 0, 0, 0))
+    k1, k2, c1, c2 = 80.0, 50.0, 1.5, 0.8
+    ma, mb = 3.0, 2.5
+    # generalised coordinates are relative (q_b is measured from mass a): M = [[ma+mb, mb],[mb, mb]]
+    M = np.array([[ma + mb, mb], [mb, mb]])
+    K, C = np.diag([k1, k2]), np.diag([c1, c2])
+    Minv = np.linalg.inv(M)
+    A = np.block([[np.zeros((2, 2)), np.eye(2)], [np.zeros((2, 2)), np.zeros((2, 2))]])
+    Bm = np.vstack([np.zeros((2, 2)), Minv])
+    dt = 1e-3
+    # zero-order hold: x+ = Ad x + Bd u, u = -K q - C v sampled at the controller period
+    aug = expm(np.block([[A, Bm], [np.zeros((2, 6))]]) * dt)
+    Ad, Bd = aug[:4, :4], aug[:4, 4:]
+    x = np.array([0.1, -0.05, 0.0, 0.2])
+    e.start(x[:2], x[2:])
+    for _ in range(2000):
+        u = -K @ x[:2] - C @ x[2:]
+        e.set_command(u)
+        e.step(dt, command_changed=True)
+        x = Ad @ x + Bd @ u
+    assert np.abs(e.get("q") - x[:2]).max() < 1e-9
+    assert np.abs(e.get("v") - x[2:]).max() < 1e-9
+
+
+def _ff_state(z, vx=0.0):
+    q = np.array([0, 0, z, 0, 0, 0, 1.0])
+    v = np.array([vx, 0, 0, 0, 0, 0.0])
+    return q, v
+
+
+# ---- (7) reference test_simple_mass.py:111-175: spring-damper contact equilibrium
+def test_point_mass_contact_equilibrium():
+    m = robots.point_mass()
+    k, c, mass = 1.0e6, 2.0e3, 2.0
+    e = OracleEngine(m, stiffness=k, damping=c, transition_eps=1.0e-6)
+    q, v = _ff_state(0.01)
+    e.start(q, v)
+    depth_min = 0.0
+    for _ in range(3000):
+        e.step(1e-4, command_changed=False)
+        depth_min = min(depth_min, e.get("q")[2])
+    weight = mass * G
+    assert abs(-e.get("q")[2] - weight / k) < 1e-7            # penetration = weight / k
+    fz = e.get("f_external").reshape(-1, 6)[1, 2]
+    assert abs(fz - weight) < 1e-6                             # f_ext_z = weight
+    assert abs(e.get("contact")[2] - weight) < 1e-6           # contact sensor
+    # force sensor mounted with a yaw offset: same vertical force, in its own frame
+    assert abs(e.get("force")[2] - weight) < 1e-6
+    assert depth_min < -weight / k                            # it did overshoot and settle
+
+
+# ---- (8) reference test_simple_mass.py:243-328: friction steady state v = Fx / (mu m g)
+def test_point_mass_friction_steady_state():
+    m = robots.point_mass()
+    mu, mass = 0.6, 2.0
+    e = OracleEngine(m, friction=mu, transition_velocity=1.0e-2, transition_eps=1.0e-6)
+    # steady sliding: constant external push is emulated by tilting gravity (Fx = m g_x)
+    gx = 0.05
+    e.set_options(gravity=(gx, 0, -G, 0, 0, 0), friction=mu, transition_velocity=1.0e-2,
+                  transition_eps=1.0e-6)
+    q, v = _ff_state(-mass * G / 1.0e6)
+    e.start(q, v)
+    for _ in range(40000):
+        e.step(1e-4, command_changed=False)
+    # f_t = mu * ratio * fN * vT with ratio = min(|vT| / v_t, 1): below v_t the law is
+    # quadratic in |vT|, above it linear: steady state of the reference's law (engine.cc:3218-3222)
+    fn = mass * G
+    fx = mass * gx
+    vt = 1.0e-2
+    v_lin = fx / (mu * fn)
+    v_expected = v_lin if v_lin >= vt else np.sqrt(fx * vt / (mu * fn))
+    assert abs(e.get("v")[0] - v_expected) < 1e-6
+
+
+# ---- (9) reference test_simulator.py:26-109: diff(v)/dt == a with the Euler stepper
+def test_euler_velocity_increment_is_the_logged_acceleration():
+    m = load_builtin("double_pendulum")
+    e = OracleEngine(m)
+    e.start(np.array([0.4, -0.2]), np.array([0.1, 0.3]), np.array([0.5, -0.2]))
+    dt = 1e-3
+    for _ in range(200):
+        v0, a0 = e.get("v").copy(), e.get("a").copy()
+        e.step(dt, solver="euler_explicit", command_changed=False)
+        assert np.abs((e.get("v") - v0) / dt - a0).max() < 1e-12
+
+
+# ---- (4) reference test_simple_pendulum.py:362-422: IMU gyro / accelerometer closed form
+def test_imu_on_pendulum_tip():
+    m = robots.pendulum()
+    e = OracleEngine(m)
+    theta, w = 0.7, 1.3
+    e.start(np.array([theta]), np.array([w]))
+    imu = e.get("imu")
+    alpha = e.get("a")[0]
+    # tip frame at l = 1 along the rod's z, rotation about y: velocity of the tip is w * l along x
+    assert np.allclose(imu[:3], [0, w, 0], atol=1e-14)
+    # classical acceleration in the frame: tangential alpha*l along x, centripetal -w^2 l along z,
+    # minus gravity expressed in the frame (R^T g with g = (0, 0, -G))
+    acc = np.array([alpha * 1.0, 0.0, -w * w * 1.0]) - np.array([G * np.sin(theta), 0.0, -G * np.cos(theta)])
+    assert np.allclose(imu[3:], acc, atol=1e-12)
+    # at rest, the accelerometer norm is g (reference test_simulator.py:105-109)
+    q, v = _ff_state(1.0)
+    pm = OracleEngine(robots.point_mass(), gravity=(0, 0, 0, 0, 0, 0))
+    pm.start(q, v)
+    assert np.linalg.norm(pm.get("imu")[3:]) < 1e-14
+    pm2 = OracleEngine(robots.point_mass(), transition_eps=1.0e-6)
+    q2, _ = _ff_state(-2.0 * G / 1.0e6)
+    pm2.start(q2, v)
+    # resting on the ground: specific force = +g along world z
+    assert abs(np.linalg.norm(pm2.get("imu")[3:]) - G) < 1e-6
+
+
+# ---- structural cross-checks for big floating-base trees (SURVEY.md 8c "coverage gap")
+@pytest.mark.parametrize("name", ["anymal", "atlas", "tree_arm", "tree_arm_ff"])
+def test_aba_satisfies_the_equation_of_motion(name):
+    model = {"tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True)}.get(
+        name, lambda: load_builtin(name))()
+    st = sample_states(model, 6, seed=1, base_height=(0.3, 0.5), grounded_fraction=1.0)
+    e = OracleEngine(model)
+    n_contact = 0
+    for l in range(6):
+        q, v, cmd = st["q"][:, l], st["v"][:, l], st["command"][:, l]
+        e.start(q, v, cmd)
+        a, u = e.get("a"), e.get("u")
+        fext = e.get("f_external").reshape(-1, 6)
+        n_contact += int(np.abs(fext).sum() > 0)
+        tau = rbd.rnea(model, q, v, a, fext) + model.rotor_inertia * a
+        scale = max(1.0, np.abs(u).max(), np.abs(tau).max())
+        assert np.abs(tau - u).max() / scale < 1e-11
+    if model.has_freeflyer:
+        assert n_contact >= 2  # the contact wrench path is part of the identity
+
+
+def test_mass_matrix_identity_on_anymal():
+    model = load_builtin("anymal")
+    st = sample_states(model, 2, seed=3, grounded_fraction=0.0, base_height=(1.0, 1.2))
+    e = OracleEngine(model)
+    q, v, cmd = st["q"][:, 0], st["v"][:, 0], st["command"][:, 0]
+    e.start(q, v, cmd)
+    M = rbd.crba(model, q) + np.diag(model.rotor_inertia)
+    h = rbd.rnea(model, q, v, np.zeros(model.nv))
+    assert np.allclose(M, M.T, atol=1e-12)
+    assert np.abs(M @ e.get("a") + h - e.get("u")).max() < 1e-10
+
+
+def test_free_floating_momentum_is_conserved():
+    model = load_builtin("anymal")
+    st = sample_states(model, 1, seed=5, grounded_fraction=0.0, base_height=(5.0, 5.0))
+    e = OracleEngine(model, gravity=(0, 0, 0, 0, 0, 0))
+    e.start(st["q"][:, 0], st["v"][:, 0], np.zeros(model.nmotors))
+    # centroidal momentum expressed at the COM in the world frame
+    def world_momentum():
+        c = e.get("centroidal")
+        return c[3:9].copy()
+    h0 = world_momentum()
+    for _ in range(300):
+        e.step(1e-3, command_changed=False)
+    h1 = world_momentum()
+    assert np.abs(h1 - h0).max() < 1e-8 * max(1.0, np.abs(h0).max())
+
+
+def test_integrate_keeps_the_manifold():
+    model = robots.tree_arm(True)
+    e = OracleEngine(model)
+    rng = np.random.default_rng(0)
+    q = sample_states(model, 1, seed=0)["q"][:, 0]
+    for _ in range(50):
+        q = e.integrate(q, 0.3 * rng.normal(size=model.nv))
+    assert abs(np.linalg.norm(q[3:7]) - 1.0) < 1e-12
+    for j in range(1, model.njoints):
+        if int(model.jtypes[j]) in (9, 10, 11, 12):
+            iq = int(model.idx_q[j])
+            assert abs(np.hypot(q[iq], q[iq + 1]) - 1.0) < 1e-12
+    # zero increment is the identity
+    assert np.allclose(e.integrate(q, np.zeros(model.nv)), q, atol=1e-15)

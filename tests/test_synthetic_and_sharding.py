@@ -1,0 +1,83 @@
+"""Synthetic state sampler and multi-process sharding (gloo, world_size 2, CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from jiminy_amd import load_builtin
+from jiminy_amd.distributed import all_gather_observations, pack_observations, shard_range
+from jiminy_amd.synthetic import lowest_contact_height, sample_states
+
+
+def test_sampled_states_are_valid_start_states():
+    m = load_builtin("anymal")
+    st = sample_states(m, 512, seed=0)
+    q, v, cmd = st["q"], st["v"], st["command"]
+    assert q.shape == (19, 512) and v.shape == (18, 512) and cmd.shape == (12, 512)
+    assert np.allclose(np.linalg.norm(q[3:7], axis=0), 1.0, atol=1e-14)
+    mask = m.bounded_position_mask()
+    assert (q[mask] >= m.position_lower[mask, None]).all() and (q[mask] <= m.position_upper[mask, None]).all()
+    z = lowest_contact_height(m, q)
+    assert z.min() > -0.0051                      # initial contact force stays far below 1e5 N
+    assert (np.abs(z[:128]) <= 0.0051).all()      # grounded quarter of the batch
+    assert (np.abs(cmd) <= 40.0).all()
+    st2 = sample_states(m, 512, seed=0)
+    assert np.array_equal(st2["q"], q)
+    assert not np.array_equal(sample_states(m, 512, seed=1)["q"], q)
+
+
+def test_cartpole_sampling_range():
+    m = load_builtin("cartpole")
+    st = sample_states(m, 256, seed=0)
+    assert np.abs(st["q"][0]).max() <= 0.05 and np.abs(st["v"]).max() <= 0.05
+    assert np.allclose(st["q"][1] ** 2 + st["q"][2] ** 2, 1.0)
+
+
+def test_shard_range_partitions_the_batch():
+    for B, W in ((65536, 8), (32768, 8), (10, 3), (5, 8)):
+        r = [shard_range(B, k, W) for k in range(W)]
+        assert r[0][0] == 0 and r[-1][1] == B
+        assert all(r[k][1] == r[k + 1][0] for k in range(W - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = 6
+        lo, hi = shard_range(2 * B, rank, world)
+        imu = torch.arange(6 * B, dtype=torch.float64).reshape(6, B) + 1000 * rank
+        enc = torch.arange(4 * B, dtype=torch.float64).reshape(4, B) - 1000 * rank
+        out = all_gather_observations([imu, enc])
+        out = all_gather_observations([imu, enc], out)        # buffer reuse path
+        packed, gathered = out
+        ok = tuple(gathered.shape) == (world, 10, B) and torch.equal(packed, pack_observations([imu, enc]))
+        for r in range(world):
+            ref = torch.cat([torch.arange(6 * B, dtype=torch.float64).reshape(6, B) + 1000 * r,
+                             torch.arange(4 * B, dtype=torch.float64).reshape(4, B) - 1000 * r])
+            ok = ok and torch.equal(gathered[r], ref)
+        ok = ok and (lo, hi) == (rank * B, (rank + 1) * B)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_observation_all_gather_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
