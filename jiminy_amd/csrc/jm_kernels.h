@@ -21,6 +21,7 @@
 //   write_sensors    Imu/Contact/Force/Encoder/EffortSensor::set core/src/hardware/basic_sensors.cc:142-164,
 //                    267-277, 368-387, 509-539, 604-618
 #pragma once
+#include <cstring>
 #include <type_traits>
 
 #include "jm_math.h"
@@ -358,6 +359,9 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Wo
     });
     // ---- ABA pass 2 (AbaBackwardStep), leaves -> root
     AI<T> Yacc[NJ];
+#ifdef JM_HOST_EMU
+    std::memset(Yacc, 0xFF, sizeof(Yacc));
+#endif
     static_rfor<1, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int p = Tp::parent[j];
@@ -697,8 +701,13 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
     const long long B = A.B;
     CPtr<T> P = (CPtr<T>)A.P;
     Work<T, Tp> w;
-    w.status = 0;
     T qs[NQ], vs[NV], as[NV], cmd[c_max(NM, 1)];
+#ifdef JM_HOST_EMU
+    // poison everything a GPU lane would find uninitialised: a read-before-write shows up as NaN
+    std::memset(&w, 0xFF, sizeof(w));
+    std::memset(qs, 0xFF, sizeof(qs)); std::memset(vs, 0xFF, sizeof(vs)); std::memset(as, 0xFF, sizeof(as));
+#endif
+    w.status = 0;
     static_for<0, NM>([&](auto mc) { cmd[decltype(mc)::value] = A.command[decltype(mc)::value * B + lane]; });
 
     if (A.mode == MODE_RESET)

@@ -283,12 +283,44 @@ template<class T> JM_DEV M3<T> quat_to_matrix(T x, T y, T z, T w)
             txz - twy, tyz + twx, T(1) - (txx + tyy)};
 }
 
+// sin and cos of a float64 angle without the libm `sincos(x, &s, &c)` out-pointer form: on the
+// device that form materialises its outputs through private (scratch) memory, and hipcc (ROCm 7.2)
+// was observed to lay those slots over live spill slots in the large unrolled kernels (wrong
+// accelerations after an integrate step, GPU only).  Cody-Waite reduction by pi/2 in three FMA
+// steps + the fdlibm kernel polynomials (< 2 ulp for |x| < 1e5; larger arguments take the slow
+// library path).
+JM_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+JM_DEV void sincos_(double x, double * s, double * c)
+{
+    if (!(__builtin_fabs(x) < 1.0e5))
+    {
 #ifdef JM_HOST_EMU
-JM_DEV void sincos_(double x, double * s, double * c) { *s = std::sin(x); *c = std::cos(x); }
+        *s = std::sin(x); *c = std::cos(x);
+#else
+        *s = ::sin(x); *c = ::cos(x);
+#endif
+        return;
+    }
+    const double fn = __builtin_rint(x * 0.63661977236758134308);
+    double r = fma_(-fn, 1.5707963267948966, x);
+    r = fma_(-fn, 6.123233995736766e-17, r);
+    r = fma_(-fn, -1.4973849048591698e-33, r);
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
+                      + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double sk = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
+                      + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double ck = 1.0 - (0.5 * z - z * pc);
+    const int n = (int)fn & 3;
+    const double s0 = (n & 1) ? ck : sk, c0 = (n & 1) ? sk : ck;
+    *s = (n & 2) ? -s0 : s0;
+    *c = ((n + 1) & 2) ? -c0 : c0;
+}
+#ifdef JM_HOST_EMU
 JM_DEV void sincos_(float x, float * s, float * c) { *s = std::sin(x); *c = std::cos(x); }
 #else
-JM_DEV void sincos_(double x, double * s, double * c) { ::sincos(x, s, c); }
-JM_DEV void sincos_(float x, float * s, float * c) { ::sincosf(x, s, c); }
+JM_DEV void sincos_(float x, float * s, float * c) { *s = ::sinf(x); *c = ::cosf(x); }
 #endif
 JM_DEV double sqrt_(double x) { return ::sqrt(x); }
 JM_DEV float sqrt_(float x) { return ::sqrtf(x); }
