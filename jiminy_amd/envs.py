@@ -1,0 +1,302 @@
+"""Vectorised environments on top of BatchedEngine: the gym_jiminy reset / step / observe surface
+for B lanes at once, every array a device tensor.
+
+Restates, for the hot-path subset, `BaseJiminyEnv` (reference
+python/gym_jiminy/common/gym_jiminy/common/envs/generic.py: reset :521, step :761,
+`_sample_state` :1300, `has_terminated` :1434, observation layout :1247-1270) and
+`WalkerJiminyEnv` (envs/locomotion.py: fall detection :361-385, survival / energy reward :387-431),
+plus the ANYmal pipeline of `gym_jiminy/envs/anymal.py:82-127` (PD controller + Mahony filter) as
+device-resident blocks.  Differences that come with batching are explicit: numerical failures are
+per lane (`truncated`), and finished lanes are re-initialised in place (`jm_batch_reset_lanes`)
+instead of raising for the whole batch.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import blocks
+from .engine import BatchedEngine
+from .model import CompiledModel, JT_FREEFLYER, load_builtin
+from .synthetic import lowest_contact_height
+
+ObsType = Dict[str, Any]
+
+
+class VecJiminyEnv:
+    """B independent single-robot environments stepped by one kernel launch.
+
+    `action` is the motor command `[B][nmotors]` unless a controller block is configured.
+    Observations follow the reference layout with a leading batch axis:
+    `{'t': (B,), 'states': {'agent': {'q': (B, nq), 'v': (B, nv)}},
+      'measurements': {SensorType: (B, n_fields, n_sensors)}}` -- zero-copy views of the
+    engine's `[rows][B]` storage.
+    """
+
+    def __init__(self, model: CompiledModel, num_envs: int, step_dt: float,
+                 engine_options: Optional[Dict[str, Dict[str, Any]]] = None,
+                 dtype: torch.dtype = torch.float64, device: Optional[torch.device] = None,
+                 simulation_duration_max: float = 86400.0, auto_reset: bool = True) -> None:
+        self.model = model
+        self.num_envs = int(num_envs)
+        self.step_dt = float(step_dt)
+        self.engine = BatchedEngine(model, num_envs, dtype=dtype, device=device)
+        self.device, self.dtype = self.engine.device, dtype
+        if engine_options:
+            self.engine.set_options(engine_options)
+        self.simulation_duration_max = float(simulation_duration_max)
+        self.auto_reset = auto_reset
+        self._generator = torch.Generator(device="cpu")
+        self.num_steps = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)
+        self._t0 = torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
+        self._q0 = None
+        self._v0 = None
+        q_neutral, _ = self._sample_state_numpy()
+        self._height_neutral = float(q_neutral[2]) if model.has_freeflyer else 0.0
+
+    # ------------------------------------------------------------------ overridable hooks
+    def _sample_state_numpy(self) -> Tuple[np.ndarray, np.ndarray]:
+        """≙ `BaseJiminyEnv._sample_state` (generic.py:1300-1334): neutral configuration clipped
+        to the bounds, free-flyer placed so that the lowest contact point touches the ground."""
+        m = self.model
+        q = m.neutral()
+        mask = m.bounded_position_mask()
+        q[mask] = np.clip(q[mask], m.position_lower[mask], m.position_upper[mask])
+        if m.has_freeflyer and m.ncontacts:
+            q[2] -= float(lowest_contact_height(m, q)[0])
+        return q, np.zeros(m.nv)
+
+    def _sample_state(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Initial state for `n` lanes, `[nq][n]` and `[nv][n]`. Default: the neutral state."""
+        q, v = self._sample_state_numpy()
+        qt = torch.as_tensor(q, dtype=self.dtype, device=self.device)[:, None].expand(-1, n)
+        vt = torch.as_tensor(v, dtype=self.dtype, device=self.device)[:, None].expand(-1, n)
+        return qt.contiguous(), vt.contiguous()
+
+    def compute_command(self, action: torch.Tensor) -> torch.Tensor:
+        """≙ `BaseJiminyEnv.compute_command` (generic.py:1140-1160): the action IS the command.
+        `action` is `[B][nmotors]`; returns `[nmotors][B]`."""
+        return action.to(self.dtype).T
+
+    def has_terminated(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(terminated, truncated) per lane: truncation on numerical failure / out-of-bounds
+        state (generic.py:1434-1470) or on the maximum simulated duration."""
+        status = self.engine.status
+        truncated = (status != 0) | (self._lane_time() >= self.simulation_duration_max)
+        return torch.zeros_like(truncated), truncated
+
+    def compute_reward(self, terminated: torch.Tensor) -> torch.Tensor:
+        return torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
+
+    def _on_reset(self, lane_mask: Optional[torch.Tensor]) -> None:
+        """Hook for controller/observer state (called with the mask of the lanes being reset)."""
+
+    # ------------------------------------------------------------------ gym surface
+    def _lane_time(self) -> torch.Tensor:
+        return self.engine.stepper_state.t - self._t0
+
+    def observation(self) -> ObsType:
+        rs = self.engine.robot_state
+        return {
+            "t": self._lane_time(),
+            "states": {"agent": {"q": rs.q.T, "v": rs.v.T}},
+            "measurements": {k: v.permute(2, 0, 1) for k, v in self.engine.sensor_measurements.items()},
+        }
+
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None
+              ) -> Tuple[ObsType, Dict[str, Any]]:
+        """≙ `BaseJiminyEnv.reset(seed, options)` for the whole batch."""
+        if seed is not None:
+            self._generator.manual_seed(int(seed))
+        self.engine.stop()
+        q, v = self._sample_state(self.num_envs)
+        self._q0, self._v0 = q, v
+        self.engine.field("command").zero_()
+        self._on_reset(None)
+        self.engine.start(q, v)
+        self.num_steps.zero_()
+        self._t0.zero_()
+        return self.observation(), {}
+
+    def step(self, action: torch.Tensor
+             ) -> Tuple[ObsType, torch.Tensor, torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        """≙ `BaseJiminyEnv.step(action)` (generic.py:761-880)."""
+        if not self.engine.is_simulation_running:
+            raise RuntimeError("No simulation running. Please call `reset` before `step`.")
+        if tuple(action.shape) != (self.num_envs, self.model.nmotors):
+            raise ValueError(f"action must have shape ({self.num_envs}, {self.model.nmotors})")
+        self._step_engine(action)
+        self.num_steps += 1
+        terminated, truncated = self.has_terminated()
+        reward = self.compute_reward(terminated)
+        info: Dict[str, Any] = {}
+        done = terminated | truncated
+        if self.auto_reset and bool(done.any()):
+            # gymnasium "next-step" autoreset would cost a launch per step; lanes are reset in
+            # place here and the final observation of the finished lanes is not returned
+            info["reset_mask"] = done
+            self.reset_lanes(done)
+        return self.observation(), reward, terminated, truncated, info
+
+    def _step_engine(self, action: torch.Tensor) -> None:
+        self.engine.set_command(self.compute_command(action))
+        self.engine.step(self.step_dt)
+
+    def reset_lanes(self, lane_mask: torch.Tensor) -> None:
+        q, v = self._sample_state(self.num_envs)
+        self._on_reset(lane_mask)
+        self.engine.reset_lanes(lane_mask, q, v)
+        self.num_steps[lane_mask] = 0
+        self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
+
+    def close(self) -> None:
+        self.engine.stop()
+
+
+class WalkerVecEnv(VecJiminyEnv):
+    """≙ `WalkerJiminyEnv` (envs/locomotion.py): legged robot with a free-flyer, fall detection
+    at half the neutral height and the 'survival' / 'energy' reward mixture."""
+
+    def __init__(self, *args: Any, reward_mixture: Optional[Dict[str, float]] = None, **kw: Any) -> None:
+        super().__init__(*args, **kw)
+        self.reward_mixture = dict(reward_mixture or {"survival": 1.0})
+        m = self.model
+        lim = torch.tensor([mo.effort_limit * mo.velocity_limit for mo in m.motors], dtype=self.dtype)
+        self._power_consumption_max = float(lim.sum())  # locomotion.py:230-236
+
+    def has_terminated(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        terminated, truncated = super().has_terminated()
+        z = self.engine.robot_state.q[2]
+        return terminated | (z < 0.5 * self._height_neutral), truncated  # locomotion.py:381-383
+
+    def compute_reward(self, terminated: torch.Tensor) -> torch.Tensor:
+        total = torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
+        if "survival" in self.reward_mixture:
+            total += self.reward_mixture["survival"]
+        if "energy" in self.reward_mixture:
+            enc = self.engine.sensor_measurements["EncoderSensor"]  # (2, n, B)
+            power = torch.clamp_min(self.engine.command * enc[1], 0.0).sum(0)
+            total -= self.reward_mixture["energy"] * power / self._power_consumption_max
+        if "failure" in self.reward_mixture:
+            total -= self.reward_mixture["failure"] * terminated.to(self.dtype)
+        return total
+
+
+class PDControlledWalkerVecEnv(WalkerVecEnv):
+    """Walker with the reference's low-level pipeline on device (gym_jiminy/envs/anymal.py:82-127):
+    `PDAdapter` (order 1: the action is the target motor velocity) -> `PDController` (ZOH command
+    integrator + PD law, run at the controller period) and a `MahonyFilter` observer per IMU.
+
+    The engine advances one controller period per launch; the command is refreshed between
+    launches from the encoder rows written by the previous launch, like the reference's
+    `_controller_handle` called from `Engine::step` at each controller breakpoint.
+    """
+
+    def __init__(self, model: CompiledModel, num_envs: int, step_dt: float, control_dt: float,
+                 kp: Any, kd: Any, mahony_kp: float = 1.0, mahony_ki: float = 0.1,
+                 target_velocity_limit: float = 100.0, target_acceleration_limit: float = 10000.0,
+                 **kw: Any) -> None:
+        opts = kw.pop("engine_options", None) or {}
+        st = dict(opts.get("stepper", {}))
+        st.setdefault("controllerUpdatePeriod", control_dt)
+        st.setdefault("sensorsUpdatePeriod", control_dt)
+        opts = dict(opts, stepper=st)
+        super().__init__(model, num_envs, step_dt, engine_options=opts, **kw)
+        self.control_dt = float(control_dt)
+        self._n_ctrl = int(round(step_dt / control_dt))
+        if abs(self._n_ctrl * control_dt - step_dt) > 1e-9:
+            raise ValueError("step_dt must be a multiple of the controller period")
+        M, B, dev, dt_ = model.nmotors, self.num_envs, self.device, self.dtype
+        # encoders in motor order
+        enc_of = {e["motor_index"]: i for i, e in enumerate(model.sensors["EncoderSensor"])
+                  if e["motor_index"] >= 0}
+        if sorted(enc_of) != list(range(M)):
+            raise ValueError("the PD pipeline needs one motor-side encoder per motor")
+        self._enc_idx = torch.tensor([enc_of[i] for i in range(M)], device=dev)
+        self.kp = torch.as_tensor(kp, dtype=dt_, device=dev)
+        self.kd = torch.as_tensor(kd, dtype=dt_, device=dev)
+        self.effort_limit = torch.tensor([m.effort_limit for m in model.motors], dtype=dt_, device=dev)
+        lo = torch.tensor([[model.position_lower[m.idx_q] * m.reduction for m in model.motors],
+                           [-target_velocity_limit] * M, [-target_acceleration_limit] * M], dtype=dt_, device=dev)
+        hi = torch.tensor([[model.position_upper[m.idx_q] * m.reduction for m in model.motors],
+                           [target_velocity_limit] * M, [target_acceleration_limit] * M], dtype=dt_, device=dev)
+        self.command_state_lower, self.command_state_upper = lo, hi
+        self.command_state = torch.zeros((3, M, B), dtype=dt_, device=dev)
+        self._accel = torch.zeros((M, B), dtype=dt_, device=dev)
+        self._torque = torch.zeros((M, B), dtype=dt_, device=dev)
+        n_imu = len(model.sensors["ImuSensor"])
+        self.mahony_kp, self.mahony_ki = float(mahony_kp), float(mahony_ki)
+        self.imu_quat = torch.zeros((4, n_imu, B), dtype=dt_, device=dev)
+        self.imu_quat[3] = 1.0
+        self._bias = torch.zeros((3, n_imu, B), dtype=dt_, device=dev)
+        self._omega = torch.zeros_like(self._bias)
+        self._cf = torch.zeros_like(self._bias)
+
+    def _encoders(self) -> torch.Tensor:
+        enc = self.engine.sensor_measurements["EncoderSensor"]   # (2, n_enc, B)
+        return enc[:, self._enc_idx]
+
+    def _on_reset(self, lane_mask: Optional[torch.Tensor]) -> None:
+        q0, _ = self._sample_state(self.num_envs)
+        target = torch.stack([q0[m.idx_q] * m.reduction for m in self.model.motors])
+        if lane_mask is None:
+            self.command_state.zero_()
+            self.command_state[0] = target
+            self.imu_quat.zero_(); self.imu_quat[3] = 1.0
+            self._bias.zero_()
+        else:
+            keep = ~lane_mask
+            self.command_state *= keep
+            self.command_state[0] += target * lane_mask
+            self.imu_quat *= keep
+            self.imu_quat[3] += lane_mask.to(self.dtype)
+            self._bias *= keep
+
+    def _step_engine(self, action: torch.Tensor) -> None:
+        a = action.to(self.dtype).T
+        blocks.pd_adapter(a, 1, self.command_state, self.command_state_lower, self.command_state_upper,
+                          False, None, self.step_dt, self._accel)
+        self.command_state[2].copy_(self._accel)
+        for _ in range(self._n_ctrl):
+            blocks.pd_controller(self._encoders(), self.command_state, self.command_state_lower,
+                                 self.command_state_upper, self.kp, self.kd, self.effort_limit,
+                                 self.control_dt, self._torque)
+            self.engine.set_command(self._torque)
+            self.engine.step(self.control_dt)
+            imu = self.engine.sensor_measurements["ImuSensor"]     # (6, n_imu, B)
+            blocks.mahony_filter(self.imu_quat, self._omega, self._cf, imu[:3], imu[3:], self._bias,
+                                 self.mahony_kp, self.mahony_ki, self.control_dt)
+
+    def observation(self) -> ObsType:
+        obs = super().observation()
+        obs["features"] = {"mahony_filter": self.imu_quat.permute(2, 0, 1)}
+        obs["actions"] = {"pd_controller": self.command_state[:2].permute(2, 0, 1)}
+        return obs
+
+
+# constants of the reference ANYmal environment (python/gym_jiminy/envs/gym_jiminy/envs/anymal.py:17-35)
+ANYMAL_STEP_DT = 0.04
+ANYMAL_CONTROL_DT = 0.005
+ANYMAL_PD_KP = (1500.0,) * 12
+ANYMAL_PD_KD = (0.01,) * 12
+ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI = 1.0, 0.1
+
+
+def make_anymal_env(num_envs: int, dtype: torch.dtype = torch.float64,
+                    device: Optional[torch.device] = None, pd_pipeline: bool = True,
+                    ode_solver: str = "euler_explicit", dt_max: float = 1e-3, **kw: Any) -> VecJiminyEnv:
+    """ANYmal with the reference's env constants; contacts use the spring-damper model of the
+    batched path (the shipped option file selects the constraint solver, outside this path)."""
+    model = load_builtin("anymal")
+    opts = {"stepper": {"odeSolver": ode_solver, "dtMax": dt_max,
+                        "controllerUpdatePeriod": ANYMAL_CONTROL_DT,
+                        "sensorsUpdatePeriod": ANYMAL_CONTROL_DT},
+            "contacts": {"model": "spring_damper"}}
+    if pd_pipeline:
+        return PDControlledWalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, ANYMAL_CONTROL_DT,
+                                        ANYMAL_PD_KP, ANYMAL_PD_KD, ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI,
+                                        engine_options=opts, dtype=dtype, device=device, **kw)
+    return WalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, engine_options=opts, dtype=dtype,
+                        device=device, **kw)
