@@ -9,7 +9,7 @@ FK + spring-damper contacts + motor law + ABA), then the extra terms and the sen
 reference, seeded synthetic states resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (`k_batch`) vs the HBM roof, from per-launch HIP-event timing on the
+  roofline      dominant kernel (`k_quad` for ANYmal) vs the HBM roof, from per-launch HIP-event timing on the
                 launch stream; `traffic` = PMC-measured HBM bytes per launch when profiles/ holds it
   cpu_baseline  the CPU oracle ("port" of the reference's single-threaded algorithm) timed on the
                 host cores on a bounded sample of the same workload (rank 0, N=1 only)
@@ -178,6 +178,8 @@ def main() -> None:
         elapsed = float(tt.item())
     status = eng.status.cpu().numpy()
     ok_frac = float((status == 0).mean())
+    nan_frac = float(((status & 1) != 0).mean())
+    oob_frac = float(((status & 2) != 0).mean())
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -186,6 +188,9 @@ def main() -> None:
         alg_bytes_per_launch = scal * sz * B
         avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+        from jiminy_amd.codegen import quad_structure
+        kernel_name = "jm::k_quad" if (quad_structure(model) is not None and
+                                       os.environ.get("JM_KERNEL_VARIANT") != "lane") else "jm::k_batch"
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
@@ -197,7 +202,8 @@ def main() -> None:
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak",
+            "metric": ("env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak"
+                       if args.model == "anymal" else f"env-steps/s (whole node) {args.model} batch {B}"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -208,10 +214,11 @@ def main() -> None:
                        "lanes_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"
                                       + (" + obs all-gather" if args.gather_obs else ""),
-                       "lanes_ok_at_end": ok_frac},
+                       "lanes_ok_at_end": ok_frac, "lanes_nan_at_end": nan_frac,
+                       "lanes_out_of_joint_bounds_at_end": oob_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "jm::k_batch", "launches_timed": n_launch,
+                         "kernel": kernel_name, "launches_timed": n_launch,
                          "avg_launch_ms": 1e3 * avg_launch_s,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         }

@@ -214,27 +214,33 @@ template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> v
     return f;
 }
 
-// symmetric 6x6 solve (Ia + diag(rot)) x = b through Cholesky (calc_aba free-flyer,
-// pinocchio_overload_algorithms.h:357-378; the explicit inverse of the reference is replaced by
-// one factorisation + one solve: x = Dinv (u - Ia a_gf))
+// symmetric positive definite 6x6 solve (Ia + diag(rot)) x = b (calc_aba free-flyer,
+// pinocchio_overload_algorithms.h:357-378).  The reference forms the explicit inverse through an
+// LL^T factorisation; here one square-root-free LDL^T factorisation + one solve:
+// x = Dinv (u - Ia a_gf).  Only the lower triangle of A is read.
 template<class T> JM_DEV void chol6_solve(T (&A)[6][6], T (&b)[6])
 {
+    T dinv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j)
     {
+        T w[6];
         T s = A[j][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
-        const T d = sqrt_(s);
-        const T dinv = T(1) / d;
-        A[j][j] = dinv;  // store inverse diagonal
+        for (int k = 0; k < j; ++k)
+        {
+            w[k] = A[j][k] * A[k][k];  // L_jk * d_k  (diagonal holds d_k)
+            s -= A[j][k] * w[k];
+        }
+        A[j][j] = s;
+        dinv[j] = T(1) / s;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i)
         {
             T t = A[i][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
-            A[i][j] = t * dinv;
+            for (int k = 0; k < j; ++k) t -= A[i][k] * w[k];
+            A[i][j] = t * dinv[j];
         }
     }
 #pragma unroll
@@ -243,15 +249,15 @@ template<class T> JM_DEV void chol6_solve(T (&A)[6][6], T (&b)[6])
         T s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= A[i][k] * b[k];
-        b[i] = s * A[i][i];
+        b[i] = s;
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i)
     {
-        T s = b[i];
+        T s = b[i] * dinv[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= A[k][i] * b[k];
-        b[i] = s * A[i][i];
+        b[i] = s;
     }
 }
 

@@ -45,6 +45,7 @@ int32_t fail(int32_t code, const std::string & msg)
 struct jm_model
 {
     std::vector<double> params;  // Layout<Topo>, options tail = defaults
+    bool root_at_origin = true;  // placement of joint 1 is the identity (limb-parallel kernel)
 };
 
 enum { VARIANT_LANE = 0, VARIANT_QUAD = 1 };
@@ -167,6 +168,12 @@ int32_t jm_model_create(const jm_model_desc * desc, jm_model ** out)
     m->params = jm::pack_model<Topo>(*desc);
     jm::pack_options<Topo>(m->params, jm::default_options());
     jm::pack_quad<Topo>(m->params, *desc);
+    if (desc->njoints > 1)
+    {
+        static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k) m->root_at_origin &= (desc->placement_R[9 + k] == I9[k]);
+        for (int k = 0; k < 3; ++k) m->root_at_origin &= (desc->placement_p[3 + k] == 0.0);
+    }
     *out = m;
     return JM_OK;
 }
@@ -199,7 +206,7 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     b->params = model->params;
     // kernel variant: limb-parallel when the topology allows it; JM_KERNEL_VARIANT=lane forces the
     // generic one-robot-per-lane kernel (A/B measurements)
-    b->variant = Topo::QUAD ? VARIANT_QUAD : VARIANT_LANE;
+    b->variant = (Topo::QUAD && model->root_at_origin) ? VARIANT_QUAD : VARIANT_LANE;
     if (const char * v = std::getenv("JM_KERNEL_VARIANT"))
         if (std::string(v) == "lane") b->variant = VARIANT_LANE;
     hipError_t e = hipSetDevice(device);

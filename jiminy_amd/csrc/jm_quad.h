@@ -136,7 +136,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         SE3<T> Mj;
         Mj.R = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
         Mj.p = {qb[0], qb[1], qb[2]};
-        liM1 = ld_se3<T>(P, L::JOINT + 1 * L::JSTRIDE) * Mj;
+        liM1 = Mj;  // the free-flyer root joint sits at the world origin (checked by jm_model_create)
     }
     const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
     const bool want_energy = emit && A.energy;
@@ -412,7 +412,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
         SE3<T> Mj;
         Mj.R = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
         Mj.p = {qb[0], qb[1], qb[2]};
-        liM1 = ld_se3<T>(P, L::JOINT + 1 * L::JSTRIDE) * Mj;
+        liM1 = Mj;
     }
     const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
     const Sp<T> a1 = {{ddq1[0], ddq1[1], ddq1[2]}, {ddq1[3], ddq1[4], ddq1[5]}};

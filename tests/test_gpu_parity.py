@@ -23,12 +23,13 @@ def _engine(model, B, dtype, solver, dt):
     return eng
 
 
-@pytest.mark.parametrize("name,B", [("cartpole", 4096), ("double_pendulum", 256), ("anymal", 256)])
+@pytest.mark.parametrize("name,B", [("cartpole", 4096), ("double_pendulum", 256), ("anymal", 256),
+                                    ("atlas", 128)])
 @pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
 def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
     model = load_builtin(name)
-    st = sample_states(model, B, seed=3)
-    dt = 1e-3
+    st = sample_states(model, B, seed=3, base_height=(0.9, 1.1) if name == "atlas" else (0.45, 0.65))
+    dt = 1e-3 if name != "atlas" else 2.5e-4
     ref = alloc_soa(model, B)
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]

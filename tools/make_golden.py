@@ -1,0 +1,47 @@
+"""Regression fixtures of the CPU oracle (tests/golden/*.npz).
+
+These are NOT reference outputs (the reference cannot run here): they
+freeze the oracle's own outputs on seeded inputs, after it passed the known-answer pins of
+tests/test_oracle_known_answers.py, so that later edits of oracle.cpp / the model compiler cannot
+silently change the numbers every GPU parity test is compared with.
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from jiminy_amd import load_builtin  # noqa: E402
+from jiminy_amd.synthetic import sample_states  # noqa: E402
+from tests.helpers import alloc_soa, oracle_batch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FIELDS = ("q", "v", "a", "u_motor", "imu", "force", "encoder", "effort", "energy", "contact_forces")
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    for name, B, kw in (("cartpole", 16, {}), ("anymal", 16, {"grounded_fraction": 0.5}),
+                        ("atlas", 8, {"base_height": (0.9, 1.0), "grounded_fraction": 0.5})):
+        model = load_builtin(name)
+        st = sample_states(model, B, seed=123, **kw)
+        arr = alloc_soa(model, B)
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+        oracle_batch(model, arr, "start")
+        out = {"in_q": st["q"], "in_v": st["v"], "in_command": st["command"]}
+        out.update({"start_" + k: arr[k].copy() for k in FIELDS})
+        for i in range(10):
+            oracle_batch(model, arr, "step", solver="runge_kutta_4", dt=5e-4, n_substeps=1,
+                         command_changed=(i == 0))
+        out.update({"rk4_" + k: arr[k].copy() for k in FIELDS})
+        out["status"] = arr["status"].copy()
+        np.savez_compressed(os.path.join(OUT, f"{name}_oracle.npz"), **out)
+        print(name, "ok", {k: v.shape for k, v in list(out.items())[:3]})
+
+
+if __name__ == "__main__":
+    main()
