@@ -206,7 +206,7 @@ int32_t jm_batch_reset_lanes(jm_batch * batch, const uint8_t * lane_mask,
                              const void * q_init, const void * v_init, void * stream);
 
 /* Per-launch kernel timing with HIP events recorded on the launch stream around every kernel
- * launch of this batch (up to 2048 launches between two summaries).  `jm_batch_timing_summary`
+ * `jm_batch_step` launch of this batch (start / reset / dynamics launches are not timed; up to 2048 launches between two summaries).  `jm_batch_timing_summary`
  * blocks until the recorded launches completed, returns their count and summed duration (ms)
  * and restarts the recording. */
 int32_t jm_batch_enable_timing(jm_batch * batch, int32_t enable);

@@ -30,86 +30,108 @@ def _arr(name: str, vals, n_min: int = 1) -> str:
 
 
 def quad_structure(model: CompiledModel):
-    """Detect the 'free-flyer trunk + 4 identical revolute chains' structure served by the
-    limb-parallel kernel (csrc/jm_quad.h). Returns a dict of index tables or None."""
-    from .model import JT_FREEFLYER, JT_RU, JT_RX, JT_RY, JT_RZ
+    """Branch-parallel decomposition served by the 4-lanes-per-robot kernel (csrc/jm_quad.h):
+
+    * the four longest leaf chains of bounded revolute joints ("limbs": lane k of a quad owns
+      limb k; shorter limbs are padded at the tip with mass-less dummy joints),
+    * everything else ("trunk tree": the free-flyer root plus the 1-dof joints the limbs hang
+      from, e.g. Atlas' back chain and neck), evaluated redundantly by the four lanes.
+
+    Requirements: free-flyer root at joint 1, contact points and force sensors only on limb tips,
+    IMUs only on trunk-tree joints, one motor per movable joint with uniform option flags, sensor
+    coverage all-or-nothing.  Returns a dict of index tables, or None when the tree does not fit
+    (the one-robot-per-lane kernel is used then)."""
+    from .model import (JT_FREEFLYER, JT_PU, JT_PX, JT_PY, JT_PZ, JT_RU, JT_RX, JT_RY, JT_RZ)
+    REV = (JT_RX, JT_RY, JT_RZ, JT_RU)
+    ONE_DOF = REV + (JT_PX, JT_PY, JT_PZ, JT_PU)
     nj = model.njoints
     parents = [int(x) for x in model.parents]
     if nj < 6 or int(model.jtypes[1]) != JT_FREEFLYER or parents[1] != 0:
         return None
     children = {j: [c for c in range(1, nj) if parents[c] == j] for j in range(nj)}
-    if len(children[0]) != 1 or len(children[1]) != 4:
+    if len(children[0]) != 1:
         return None
-    limbs = []
-    for root in children[1]:
-        chain, j = [], root
-        while True:
-            if int(model.jtypes[j]) not in (JT_RX, JT_RY, JT_RZ, JT_RU):
-                return None
+    # leaf chains: maximal paths of revolute joints ending at a leaf, every node with <= 1 child
+    chains = []
+    for leaf in [j for j in range(2, nj) if not children[j]]:
+        chain, j = [], leaf
+        while j > 1 and int(model.jtypes[j]) in REV and len(children[j]) <= 1:
             chain.append(j)
-            if len(children[j]) == 0:
-                break
-            if len(children[j]) != 1:
-                return None
-            j = children[j][0]
-        limbs.append(chain)
-    n = len(limbs[0])
-    if any(len(c) != n for c in limbs) or 1 + 4 * n != nj - 1:
+            j = parents[j]
+        if chain:
+            chains.append(chain[::-1])
+    if len(chains) < 4:
         return None
+    chains.sort(key=lambda c: (-len(c), c[0]))
+    limbs = sorted(chains[:4], key=lambda c: c[0])
+    limb_set = {j for c in limbs for j in c}
+    trunk = [j for j in range(1, nj) if j not in limb_set]          # topological (index) order
+    if any(int(model.jtypes[j]) not in ONE_DOF for j in trunk[1:]):
+        return None
+    if any(parents[c[0]] not in trunk for c in limbs) or any(parents[j] not in trunk for j in trunk[1:]):
+        return None
+    n = max(len(c) for c in limbs)
+    # the padded limbs must do most of the work, otherwise the redundancy does not pay
+    if 4 * n + len(trunk) > 2 * (nj - 1):
+        return None
+    tindex = {j: i for i, j in enumerate(trunk)}
+    movable = limb_set | set(trunk[1:])
     motor_of = {m.joint: i for i, m in enumerate(model.motors)}
-    if len(motor_of) != len(model.motors) or set(motor_of) != {j for c in limbs for j in c}:
+    if len(motor_of) != len(model.motors) or set(motor_of) != movable:
         return None
     flags = {(m.enable_effort_limit, m.enable_velocity_limit, m.enable_friction) for m in model.motors}
     if len(flags) != 1:
         return None
-    # contacts: the same number per limb, all on the last chain joint
+    pad = lambda row: list(row) + [-1] * (n - len(row))  # noqa: E731
+    # contacts: only on limb tips
     cj = [model.frames[c].parent_joint for c in model.contacts]
     limb_contacts = [[i for i, j in enumerate(cj) if j == c[-1]] for c in limbs]
-    ncl = len(limb_contacts[0])
-    if any(len(x) != ncl for x in limb_contacts) or 4 * ncl != len(cj):
+    if sum(len(x) for x in limb_contacts) != len(cj):
         return None
+    ncl = max([len(x) for x in limb_contacts] + [0])
+    padc = lambda row: list(row) + [-1] * (max(ncl, 1) - len(row))  # noqa: E731
     s = model.sensors
-    if any(model.frames[x["frame"]].parent_joint != 1 for x in s.get("ImuSensor", [])):
+    imu = [model.frames[x["frame"]].parent_joint for x in s.get("ImuSensor", [])]
+    if any(j not in tindex for j in imu):
         return None
     fj = [model.frames[x["frame"]].parent_joint for x in s.get("ForceSensor", [])]
     limb_force = [[i for i, j in enumerate(fj) if j == c[-1]] for c in limbs]
     has_force = len(fj) > 0
-    if has_force and (any(len(x) != 1 for x in limb_force) or len(fj) != 4):
+    if any(len(x) > 1 for x in limb_force) or sum(len(x) for x in limb_force) != len(fj):
         return None
     cs = [model.contacts.index(x["frame"]) for x in s.get("ContactSensor", [])]
     has_cs = len(cs) > 0
-    limb_cs = []
-    for lc in limb_contacts:
-        row = []
-        for c in lc:
-            idx = [i for i, cc in enumerate(cs) if cc == c]
-            if has_cs and len(idx) != 1:
-                return None
-            row.append(idx[0] if idx else -1)
-        limb_cs.append(row)
-    if has_cs and len(cs) != 4 * ncl:
+    if has_cs and sorted(cs) != list(range(len(cj))):
         return None
+    limb_cs = [[cs.index(c) if has_cs else -1 for c in lc] for lc in limb_contacts]
     enc = s.get("EncoderSensor", [])
     has_enc = len(enc) > 0
     sides = {bool(x["joint_side"]) for x in enc}
-    if has_enc and (len(sides) != 1 or len(enc) != 4 * n):
-        return None
     enc_of = {x["joint"]: i for i, x in enumerate(enc)}
-    if has_enc and set(enc_of) != {j for c in limbs for j in c}:
+    if has_enc and (len(sides) != 1 or len(enc_of) != len(enc) or set(enc_of) != movable):
         return None
     eff = s.get("EffortSensor", [])
     has_eff = len(eff) > 0
     eff_of = {x["motor_index"]: i for i, x in enumerate(eff)}
-    if has_eff and (len(eff) != 4 * n or set(eff_of) != set(range(len(model.motors)))):
+    if has_eff and (len(eff_of) != len(eff) or set(eff_of) != set(range(len(model.motors)))):
         return None
     return {
-        "n": n, "ncl": ncl, "limbs": limbs,
-        "motor": [[motor_of[j] for j in c] for c in limbs],
-        "contact": limb_contacts,
-        "force": [x[0] if has_force else -1 for x in limb_force],
-        "cs": limb_cs,
-        "enc": [[enc_of.get(j, -1) for j in c] for c in limbs],
-        "eff": [[eff_of.get(motor_of[j], -1) for j in c] for c in limbs],
+        "n": n, "ncl": ncl, "limbs": limbs, "trunk": trunk,
+        "trunk_parent": [-1] + [tindex[parents[j]] for j in trunk[1:]],
+        "trunk_motor": [-1] + [motor_of[j] for j in trunk[1:]],
+        "trunk_enc": [-1] + [enc_of.get(j, -1) for j in trunk[1:]],
+        "trunk_eff": [-1] + [eff_of.get(motor_of[j], -1) for j in trunk[1:]],
+        "limb_len": [len(c) for c in limbs],
+        "limb_attach": [tindex[parents[c[0]]] for c in limbs],
+        "limb_joint": [pad(c) for c in limbs],
+        "motor": [pad([motor_of[j] for j in c]) for c in limbs],
+        "limb_ncontact": [len(x) for x in limb_contacts],
+        "contact": [padc(x) for x in limb_contacts],
+        "force": [x[0] if x else -1 for x in limb_force],
+        "cs": [padc(x) for x in limb_cs],
+        "enc": [pad([enc_of.get(j, -1) for j in c]) for c in limbs],
+        "eff": [pad([eff_of.get(motor_of[j], -1) for j in c]) for c in limbs],
+        "imu_trunk": [tindex[j] for j in imu],
         "has_force": has_force, "has_cs": has_cs, "has_enc": has_enc, "has_eff": has_eff,
         "enc_side": 1 if (has_enc and True in sides) else 0,
     }
@@ -185,17 +207,28 @@ def _quad_lines(model: CompiledModel):
     q = quad_structure(model)
     if q is None:
         return ["    static constexpr bool QUAD = false;"]
+    b = lambda x: "true" if x else "false"  # noqa: E731
     return [
-        "    // limb-parallel kernel tables (csrc/jm_quad.h): 4 chains hanging off the free-flyer trunk",
+        "    // branch-parallel kernel tables (csrc/jm_quad.h): trunk tree (all lanes) + 4 limbs (one per lane)",
         "    static constexpr bool QUAD = true;",
         f"    static constexpr int QN = {q['n']};",
         f"    static constexpr int QCL = {q['ncl']};",
-        f"    static constexpr bool QHAS_FORCE = {'true' if q['has_force'] else 'false'};",
-        f"    static constexpr bool QHAS_CS = {'true' if q['has_cs'] else 'false'};",
-        f"    static constexpr bool QHAS_ENC = {'true' if q['has_enc'] else 'false'};",
-        f"    static constexpr bool QHAS_EFF = {'true' if q['has_eff'] else 'false'};",
+        f"    static constexpr int QT = {len(q['trunk'])};",
+        f"    static constexpr bool QHAS_FORCE = {b(q['has_force'])};",
+        f"    static constexpr bool QHAS_CS = {b(q['has_cs'])};",
+        f"    static constexpr bool QHAS_ENC = {b(q['has_enc'])};",
+        f"    static constexpr bool QHAS_EFF = {b(q['has_eff'])};",
         f"    static constexpr int QENC_SIDE = {q['enc_side']};",
-        _arr2("limb_joint", q["limbs"]),
+        _arr("trunk_joint", q["trunk"]),
+        _arr("trunk_parent", q["trunk_parent"]),
+        _arr("trunk_motor", q["trunk_motor"]),
+        _arr("trunk_enc", q["trunk_enc"]),
+        _arr("trunk_eff", q["trunk_eff"]),
+        _arr("imu_trunk", q["imu_trunk"]),
+        _arr("limb_len", q["limb_len"]),
+        _arr("limb_attach", q["limb_attach"]),
+        _arr("limb_ncontact", q["limb_ncontact"]),
+        _arr2("limb_joint", q["limb_joint"]),
         _arr2("limb_motor", q["motor"]),
         _arr2("limb_contact", q["contact"]),
         _arr2("limb_cs", q["cs"]),

@@ -92,7 +92,7 @@ template<class Tp> constexpr int param_total()
     if constexpr (Tp::QUAD) return QLayout<Tp>::TOTAL;
     else return Layout<Tp>::TOTAL;
 }
-// limb table of the limb-parallel kernel (jm_quad.h QLayout), appended to the parameter block
+// limb table of the branch-parallel kernel (jm_quad.h QLayout), appended to the parameter block
 template<class Tp> inline void pack_quad(std::vector<double> & P, const jm_model_desc & d)
 {
     if constexpr (Tp::QUAD)
@@ -106,6 +106,20 @@ template<class Tp> inline void pack_quad(std::vector<double> & P, const jm_model
             {
                 const int j = Tp::limb_joint[k][s];
                 double * o = T + s * Q::QJ;
+                if (j < 0)
+                {
+                    // dummy joint padding a short limb at its tip: identity placement, no mass, unit
+                    // rotor inertia (D = 1), no motor, unbounded: it never moves and transmits the
+                    // wrench of the contact points (attached to the padded tip) unchanged
+                    o[Q::J_PLC + 0] = o[Q::J_PLC + 4] = o[Q::J_PLC + 8] = 1.0;
+                    o[Q::J_AXIS] = 1.0;
+                    o[Q::J_AXP] = 1.0;
+                    o[Q::J_ROTOR] = 1.0;
+                    o[Q::J_QLO] = -1.0e300;
+                    o[Q::J_QHI] = 1.0e300;
+                    o[Q::J_ENC] = 1.0;
+                    continue;
+                }
                 for (int i = 0; i < 9; ++i) o[Q::J_PLC + i] = d.placement_R[9 * j + i];
                 for (int i = 0; i < 3; ++i) o[Q::J_PLC + 9 + i] = d.placement_p[3 * j + i];
                 o[Q::J_RBI] = d.mass[j];
@@ -119,7 +133,13 @@ template<class Tp> inline void pack_quad(std::vector<double> & P, const jm_model
                 if (t == JM_JT_RX) { ax[0] = 1; ax[1] = 0; ax[2] = 0; }
                 if (t == JM_JT_RY) { ax[0] = 0; ax[1] = 1; ax[2] = 0; }
                 if (t == JM_JT_RZ) { ax[0] = 0; ax[1] = 0; ax[2] = 1; }
-                for (int i = 0; i < 3; ++i) o[Q::J_AXIS + i] = ax[i];
+                for (int i = 0; i < 3; ++i)
+                {
+                    o[Q::J_AXIS + i] = ax[i];
+                    // axis seen from the parent joint frame: placement rotation times axis
+                    o[Q::J_AXP + i] = d.placement_R[9 * j + 3 * i] * ax[0] + d.placement_R[9 * j + 3 * i + 1] * ax[1]
+                                      + d.placement_R[9 * j + 3 * i + 2] * ax[2];
+                }
                 o[Q::J_ROTOR] = d.rotor_inertia[d.idx_v[j]];
                 o[Q::J_QLO] = d.position_lower[d.idx_q[j]];
                 o[Q::J_QHI] = d.position_upper[d.idx_q[j]];
@@ -131,13 +151,23 @@ template<class Tp> inline void pack_quad(std::vector<double> & P, const jm_model
             {
                 const int ci = Tp::limb_contact[k][c];
                 double * o = T + Q::CONTACT + c * Q::QC;
+                if (ci < 0)
+                {
+                    o[0] = o[4] = o[8] = 1.0;
+                    continue;
+                }
                 for (int i = 0; i < 9; ++i) o[i] = d.contact_R[9 * ci + i];
                 for (int i = 0; i < 3; ++i) o[9 + i] = d.contact_p[3 * ci + i];
+                o[Q::C_IDX] = (double)ci;
+                o[Q::C_CS] = (double)(Tp::limb_cs[k][c] < 0 ? 0 : Tp::limb_cs[k][c]);
                 if constexpr (Tp::QHAS_FORCE)
                 {
                     const int fs = Tp::limb_force[k];
-                    const double * src = &P[Layout<Tp>::FREL + 12 * (fs * Tp::NC + ci)];
-                    for (int i = 0; i < 12; ++i) o[12 + i] = src[i];
+                    if (fs >= 0)
+                    {
+                        const double * src = &P[Layout<Tp>::FREL + 12 * (fs * Tp::NC + ci)];
+                        for (int i = 0; i < 12; ++i) o[Q::C_FREL + i] = src[i];
+                    }
                 }
             }
         }

@@ -1,14 +1,28 @@
-// jm_quad.h -- limb-parallel variant of the per-step physics: FOUR lanes per robot.
+// jm_quad.h -- branch-parallel variant of the per-step physics: FOUR lanes per robot, ABA in the
+// coordinates of the root body.
 //
-// Why: in float64 the per-robot live state of the three ABA sweeps of an 18-DoF quadruped
-// (~300-400 scalars) does not fit the 512 VGPRs of one lane, and the one-robot-per-lane kernel
-// (jm_kernels.h) turns that into ~12 KB/lane of scratch traffic (profiles/r01_v1_*).  Here a robot
-// made of a free-flyer trunk and K = 4 kinematic chains ("limbs") of N revolute joints is spread
-// over one DPP quad: lane k of the quad owns limb k (its FK, contact point, motors and the ABA
-// sweeps along the chain -- all in registers), every lane redundantly carries the trunk, and the
-// only cross-lane traffic is the child->parent reduction of the articulated inertia / bias force
-// of the 4 limbs into the trunk (27 scalars, two `v_mov_dpp quad_perm` butterflies).  A wave64
-// therefore advances 16 robots; batch 65 536 = 4096 waves.
+// Why four lanes: in float64 the per-robot live state of the three ABA sweeps of an 18..36-DoF
+// tree does not fit the registers of one lane; the one-robot-per-lane kernel (jm_kernels.h) turns
+// that into kilobytes of scratch traffic per lane (profiles/r01_v1_*).  Here the tree is split
+// (jiminy_amd/codegen.py quad_structure) into
+//   * four LIMBS = the four longest leaf chains of revolute joints: lane k of a DPP quad owns limb
+//     k -- its kinematics, contact points, motors and its part of the ABA sweeps, all in registers;
+//     shorter limbs are padded at the tip with mass-less dummy joints so the lanes stay uniform;
+//   * the TRUNK TREE = the free-flyer root and the 1-dof joints the limbs hang from (ANYmal: only
+//     the root; Atlas: back_bkz/bky/bkx + neck), carried redundantly by the four lanes.
+// The only cross-lane traffic is the child->parent reduction of the limbs' articulated inertia and
+// bias force into the trunk joints they attach to (27 scalars, two `v_mov_dpp quad_perm`
+// butterflies each).  A wave64 advances 16 robots.
+//
+// Why root-body coordinates: every spatial quantity (velocities, inertias, forces) is expressed
+// in the frame of joint 1 instead of each joint's own frame.  Spatial vectors then propagate
+// between parent and child by plain addition -- no 6x6 congruence transform of the articulated
+// inertia (`internal::SE3actOn`, pinocchio_overload_algorithms.h:163-164: ~200 flops per joint)
+// and no `liMi.actInv` in the forward sweeps -- at the price of rotating each body's constant
+// inertia into the root frame (~60 flops).  Spatial algebra is frame invariant, so q_dd and the
+// efforts are the reference's up to rounding; local-frame outputs (fExternal, joint wrenches,
+// sensor data) are rotated back where they are emitted.  The root frame is also the best
+// conditioned choice (all lever arms < 1 m), which matters for the float32 mode.
 //
 // Limb constants differ per lane, so they cannot sit in SGPRs: they are staged once per block in
 // LDS as a [4][QSTRIDE] table (odd stride => the four distinct addresses of a `ds_read_b64` fall
@@ -21,13 +35,17 @@
 
 namespace jm
 {
-// ---------------------------------------------------------------- limb table layout (doubles)
+// ---------------------------------------------------------------- limb table layout (scalars)
 template<class Tp> struct QLayout
 {
-    static constexpr int QJ = 38;  // per chain joint: plc 12 | rbi 10 | axis 3 | rotor | qlo qhi | motor 9 | enc red
-    static constexpr int J_PLC = 0, J_RBI = 12, J_AXIS = 22, J_ROTOR = 25, J_QLO = 26, J_QHI = 27, J_MOTOR = 28, J_ENC = 37;
-    static constexpr int CONTACT = Tp::QN * QJ;        // per contact: frame 12 | force-sensor relative frame 12
-    static constexpr int QC = 24;
+    // per chain joint: plc 12 | rbi 10 | axis 3 | axis in the parent joint frame (plc.R axis) 3 |
+    //                  rotor | qlo qhi | motor 9 | encoder reduction
+    static constexpr int J_PLC = 0, J_RBI = 12, J_AXIS = 22, J_AXP = 25, J_ROTOR = 28, J_QLO = 29, J_QHI = 30, J_MOTOR = 31, J_ENC = 40;
+    static constexpr int QJ = 41;
+    // per contact point: frame 12 | contact index | contact-sensor index | force-sensor relative frame 12
+    static constexpr int C_IDX = 12, C_CS = 13, C_FREL = 14;
+    static constexpr int QC = Tp::QHAS_FORCE ? 26 : 14;
+    static constexpr int CONTACT = Tp::QN * QJ;
     static constexpr int RAW = CONTACT + Tp::QCL * QC;
     static constexpr int QSTRIDE = (RAW % 2 == 0) ? RAW + 1 : RAW;  // odd
     static constexpr int TABLE = 4 * QSTRIDE;
@@ -35,8 +53,32 @@ template<class Tp> struct QLayout
     static constexpr int TOTAL = OFFSET + TABLE;
 };
 
-// per-lane select among 4 compile-time constants
+// per-lane select among 4 compile-time constants (folds when they are all equal)
 JM_DEV int sel4(int k, int c0, int c1, int c2, int c3) { return k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3)); }
+
+// compile-time facts about the decomposition
+template<class Tp> struct QInfo
+{
+    static constexpr int N = Tp::QN, NT = Tp::QT;
+    static constexpr int NQB = 7 + (NT - 1), NVB = 6 + (NT - 1);  // trunk-tree state rows
+    static constexpr bool limb_at(int t)
+    {
+        for (int k = 0; k < 4; ++k) if (Tp::limb_attach[k] == t) return true;
+        return false;
+    }
+    static constexpr bool child_after(int t, int c)  // trunk joint t has a trunk child with index > c
+    {
+        for (int i = c + 1; i < NT; ++i) if (Tp::trunk_parent[i] == t) return true;
+        return false;
+    }
+    static constexpr bool has_child(int t) { return limb_at(t) || child_after(t, t); }
+    // is trunk child c the first contribution to the accumulators of its parent?
+    static constexpr bool first_contrib(int c) { return !limb_at(Tp::trunk_parent[c]) && !child_after(Tp::trunk_parent[c], c); }
+    static constexpr bool uniform_attach = Tp::limb_attach[0] == Tp::limb_attach[1] && Tp::limb_attach[0] == Tp::limb_attach[2] && Tp::limb_attach[0] == Tp::limb_attach[3];
+    // global row of trunk-tree state element i
+    static constexpr int qrow(int i) { return i < 7 ? Tp::idx_q[1] + i : Tp::idx_q[Tp::trunk_joint[i - 6]]; }
+    static constexpr int vrow(int i) { return i < 6 ? Tp::idx_v[1] + i : Tp::idx_v[Tp::trunk_joint[i - 5]]; }
+};
 
 // limb table accessor: element `off` of limb k
 template<class T> struct LimbTable
@@ -62,6 +104,28 @@ template<class T, class X> JM_DEV AI<T> quad_sum_ai(const AI<T> & Y)
     r.D = {X::quad_sum(Y.D.xx), X::quad_sum(Y.D.xy), X::quad_sum(Y.D.xz), X::quad_sum(Y.D.yy), X::quad_sum(Y.D.yz), X::quad_sum(Y.D.zz)};
     return r;
 }
+template<class T> JM_DEV Sp<T> operator*(T s, Sp<T> a) { return {s * a.l, s * a.a}; }
+template<class T> JM_DEV T dot6(Sp<T> a, Sp<T> b) { return dot(a.l, b.l) + dot(a.a, b.a); }
+template<class T> JM_DEV Sp<T> mask6(bool on, Sp<T> a)
+{
+    const T z = T(0);
+    return {{on ? a.l.x : z, on ? a.l.y : z, on ? a.l.z : z}, {on ? a.a.x : z, on ? a.a.y : z, on ? a.a.z : z}};
+}
+template<class T> JM_DEV AI<T> mask_ai(bool on, const AI<T> & Y)
+{
+    const T z = T(0);
+    AI<T> r;
+    r.A = {on ? Y.A.xx : z, on ? Y.A.xy : z, on ? Y.A.xz : z, on ? Y.A.yy : z, on ? Y.A.yz : z, on ? Y.A.zz : z};
+    r.B = {on ? Y.B.m00 : z, on ? Y.B.m01 : z, on ? Y.B.m02 : z, on ? Y.B.m10 : z, on ? Y.B.m11 : z, on ? Y.B.m12 : z,
+           on ? Y.B.m20 : z, on ? Y.B.m21 : z, on ? Y.B.m22 : z};
+    r.D = {on ? Y.D.xx : z, on ? Y.D.xy : z, on ? Y.D.xz : z, on ? Y.D.yy : z, on ? Y.D.yz : z, on ? Y.D.zz : z};
+    return r;
+}
+// rigid-body inertia of a body placed at (R, p), expressed in the coordinates (R, p) refer to
+template<class T> JM_DEV RBI<T> rbi_placed(const M3<T> & R, V3<T> p, const RBI<T> & Y)
+{
+    return {Y.m, R * Y.c + p, rot_sym(R, Y.I)};
+}
 
 // stage buffer (LDS on the GPU). Limb rows are per lane (element `row` at sl[row * SL]); trunk rows
 // are identical in the 4 lanes of a quad and stored once per robot (sb[row * SB], written by the
@@ -79,8 +143,8 @@ template<class T, int SL, int SB> struct StageBuf
 // rows of the stage buffer
 template<class Tp> struct QRows
 {
-    static constexpr int N = Tp::QN;
-    static constexpr int Q0B = 0, V0B = 7, A0B = 13, ACCVB = 19, ACCAB = 25, KVB = 31, NB = 37;  // trunk rows
+    static constexpr int N = Tp::QN, NQB = QInfo<Tp>::NQB, NVB = QInfo<Tp>::NVB;
+    static constexpr int Q0B = 0, V0B = NQB, A0B = V0B + NVB, ACCVB = A0B + NVB, ACCAB = ACCVB + NVB, KVB = ACCAB + NVB, NB = KVB + NVB;  // trunk rows
     static constexpr int Q0L = 0, V0L = N, A0L = 2 * N, ACCVL = 3 * N, ACCAL = 4 * N, KVL = 5 * N, NL = 6 * N;  // limb rows
 };
 
@@ -94,29 +158,171 @@ template<class T> JM_DEV void put6(T * base, unsigned B, unsigned r, unsigned ro
     base[o + 3 * B] = f.a.x; base[o + 4 * B] = f.a.y; base[o + 5 * B] = f.a.z;
 }
 
+// SimpleMotor::computeEffort (basic_motors.cc:83-143); `mp(i)` reads motor parameter i
+template<class T, int FL, class MP> JM_DEV void motor_law(MP && mp, T cmd, T vjnt, T & um, T & ut)
+{
+    const T red = mp(0), elim = mp(1), vlim = mp(2), islope = mp(3);
+    const T vmot = red * vjnt;
+    um = cmd;
+    if constexpr ((FL & JM_MOTOR_EFFORT_LIMIT) != 0)
+    {
+        T emin = -elim, emax = elim;
+        if constexpr ((FL & JM_MOTOR_VELOCITY_LIMIT) != 0)
+        {
+            const T vdelta = elim * islope;
+            if (vdelta > T(0))
+            {
+                const T vthr = fmax_(vlim - vdelta, T(0));
+                const T inv = T(1) / (vlim - vthr);
+                emin *= clamp_((vlim + vmot) * inv, T(0), T(1));
+                emax *= clamp_((vlim - vmot) * inv, T(0), T(1));
+            }
+        }
+        um = clamp_(um, emin, emax);
+    }
+    ut = red * um;
+    if constexpr ((FL & JM_MOTOR_FRICTION) != 0)
+    {
+        const T fds = mp(8);
+        if (vjnt > T(0)) ut += mp(4) * vjnt + mp(6) * tanh_(fds * vjnt);
+        else ut += mp(5) * vjnt + mp(7) * tanh_(fds * vjnt);
+    }
+}
+
+// per-lane row indices of this lane's limb
+template<class Tp> struct QIdx
+{
+    int rq[Tp::QN], rv[Tp::QN], rm[Tp::QN];
+    bool has[Tp::QN];  // false on the padded (dummy) joints of a short limb
+    int nc;            // contact points of this limb
+    int attach;        // trunk-tree index the limb hangs from
+};
+template<class Tp> JM_DEV QIdx<Tp> quad_indices(int k)
+{
+    QIdx<Tp> ix;
+    static_for<0, Tp::QN>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr auto J = [](int kk) { return Tp::limb_joint[kk][s] < 0 ? 1 : Tp::limb_joint[kk][s]; };
+        ix.rq[s] = sel4(k, Tp::idx_q[J(0)], Tp::idx_q[J(1)], Tp::idx_q[J(2)], Tp::idx_q[J(3)]);
+        ix.rv[s] = sel4(k, Tp::idx_v[J(0)], Tp::idx_v[J(1)], Tp::idx_v[J(2)], Tp::idx_v[J(3)]);
+        ix.rm[s] = sel4(k, Tp::limb_motor[0][s] < 0 ? 0 : Tp::limb_motor[0][s], Tp::limb_motor[1][s] < 0 ? 0 : Tp::limb_motor[1][s],
+                        Tp::limb_motor[2][s] < 0 ? 0 : Tp::limb_motor[2][s], Tp::limb_motor[3][s] < 0 ? 0 : Tp::limb_motor[3][s]);
+        ix.has[s] = sel4(k, s < Tp::limb_len[0], s < Tp::limb_len[1], s < Tp::limb_len[2], s < Tp::limb_len[3]) != 0;
+    });
+    ix.nc = sel4(k, Tp::limb_ncontact[0], Tp::limb_ncontact[1], Tp::limb_ncontact[2], Tp::limb_ncontact[3]);
+    ix.attach = sel4(k, Tp::limb_attach[0], Tp::limb_attach[1], Tp::limb_attach[2], Tp::limb_attach[3]);
+    return ix;
+}
+
+// kinematics of the trunk tree in root coordinates (placements X_t, velocities v_t, joint motion
+// subspaces S_t of the 1-dof joints); element 0 is the root itself (X = identity, S unused)
+template<class T, class Tp> struct TrunkKin
+{
+    SE3<T> X[Tp::QT];
+    Sp<T> v[Tp::QT];
+    Sp<T> S[Tp::QT];
+};
+template<class T, class Tp>
+JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K, int & status)
+{
+    using L = Layout<Tp>;
+    K.X[0] = {ident3<T>(), zero3<T>()};
+    K.v[0] = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
+    K.S[0] = zero6<T>();
+    static_for<1, Tp::QT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t], jt = Tp::jtype[j];
+        const T qj = qb[6 + t], vj = vb[5 + t];
+        const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+        const V3<T> n = joint_axis<T, Tp, j>(P);
+        SE3<T> li;
+        if constexpr (jt_is_rev(jt))
+        {
+            T c, sn;
+            sincos_(qj, &sn, &c);
+            constexpr int ax = jt_axis(jt);
+            if constexpr (ax >= 0) li.R = plc.R * rot_axis<T>(ax, c, sn);
+            else li.R = plc.R * rot_rodrigues(n, c, sn);
+            li.p = plc.p;
+        }
+        else
+        {
+            li.R = plc.R;
+            li.p = plc.p + plc.R * (qj * n);
+        }
+        if constexpr (tp == 0) K.X[t] = li;
+        else K.X[t] = K.X[tp] * li;
+        const V3<T> a = K.X[t].R * n;
+        if constexpr (jt_is_rev(jt)) K.S[t] = {cross(K.X[t].p, a), a};
+        else K.S[t] = {a, zero3<T>()};
+        K.v[t] = K.v[tp] + vj * K.S[t];
+        constexpr int iq = Tp::idx_q[j];
+        if (P[L::QHI + iq] < qj || qj < P[L::QLO + iq]) status |= JM_LANE_OUT_OF_BOUNDS;
+    });
+}
+// per-lane pick of the trunk joint this lane's limb hangs from
+template<class T, class Tp, class V> JM_DEV V pick_attach(int k, const V * arr)
+{
+    V r = arr[Tp::limb_attach[0]];
+    static_for<1, 4>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        if constexpr (Tp::limb_attach[kk] != Tp::limb_attach[0])
+            if (k == kk) r = arr[Tp::limb_attach[kk]];
+    });
+    return r;
+}
+// limb kinematics in root coordinates
+template<class T, class Tp>
+JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> & Xp, Sp<T> vp, const T * ql, const T * vl,
+                    M3<T> * Rs, V3<T> * ps, Sp<T> * vs, int & status)
+{
+    using Q = QLayout<Tp>;
+    M3<T> Rp = Xp.R;
+    V3<T> pp = Xp.p;
+    static_for<0, Tp::QN>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int o = s * Q::QJ;
+        T c, sn;
+        sincos_(ql[s], &sn, &c);
+        const V3<T> n = LT.v3(o + Q::J_AXIS);
+        const SE3<T> plc = LT.se3(o + Q::J_PLC);
+        const V3<T> a = Rp * LT.v3(o + Q::J_AXP);  // joint axis in root coordinates
+        ps[s] = pp + Rp * plc.p;
+        Rs[s] = Rp * (plc.R * rot_rodrigues(n, c, sn));
+        vs[s] = {vp.l + vl[s] * cross(ps[s], a), vp.a + vl[s] * a};
+        if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
+        Rp = Rs[s]; pp = ps[s]; vp = vs[s];
+    });
+    (void)ix;
+}
+
 // a = f(q, v) for one robot spread over a quad; lane k evaluates limb k.
-//   qb[7], vb[6] : trunk configuration / velocity (identical in the 4 lanes)
-//   ql[N], vl[N], cmd[N] : this limb's joints
+//   qb[NQB], vb[NVB] : trunk-tree configuration / velocity (identical in the 4 lanes)
+//   ql[N], vl[N], cmdl[N] : this limb's joints;  cmdb[NT] : commands of the trunk-tree motors
 // When `emit` (uniform) is set -- last evaluation of a step, `start`, `reset` -- the outputs that
-// derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, the extra terms
-// of engine.cc:800-905 and, if `sensors`, the sensor rows) are written right where their inputs
-// are live, so that nothing has to stay in registers for a separate output phase.
+// derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
+// if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
+// has to stay in registers for a separate output phase.
 template<class T, class Tp, class X>
-JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, long long r, int k, const int * rv,
-                      const int * rm, const T * qb, const T * vb, const T * ql, const T * vl, const T * cmd,
-                      bool emit, bool sensors, T * ddq1, T * ddq, int & status)
+JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
+                      const T * qb, const T * vb, const T * ql, const T * vl, const T * cmdb, const T * cmdl,
+                      bool emit, bool sensors, T * ddqb, T * ddq, int & status)
 {
     using L = Layout<Tp>;
     using Q = QLayout<Tp>;
-    constexpr int N = Tp::QN;
+    using I = QInfo<Tp>;
+    constexpr int N = Tp::QN, NT = Tp::QT;
+    constexpr int FL = Tp::motor_flags[0];
     const unsigned B32 = (unsigned)A.B;
-    unsigned r32 = (unsigned)r;
+    unsigned r32 = r;
     JM_OPAQUE(r32);
     const bool lead = (k == 0);
     const bool emit_sens = emit && sensors;
+    const bool want_energy = emit && A.energy;
     // ---- encoders read the state itself (basic_sensors.cc:509-539)
     if constexpr (Tp::QHAS_ENC)
         if (emit_sens && A.encoder)
+        {
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 const int si = sel4(k, Tp::limb_enc[0][s], Tp::limb_enc[1][s], Tp::limb_enc[2][s], Tp::limb_enc[3][s]);
@@ -127,171 +333,122 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     pos *= red;
                     vel *= red;
                 }
-                A.encoder[(unsigned)(2 * si) * B32 + r32] = pos;
-                A.encoder[(unsigned)(2 * si + 1) * B32 + r32] = vel;
-            });
-    // ---- trunk kinematics (free-flyer, joint 1)
-    SE3<T> liM1;
-    {
-        SE3<T> Mj;
-        Mj.R = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
-        Mj.p = {qb[0], qb[1], qb[2]};
-        liM1 = Mj;  // the free-flyer root joint sits at the world origin (checked by jm_model_create)
-    }
-    const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
-    const bool want_energy = emit && A.energy;
-    const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
-    // ---- chain kinematics
-    SE3<T> liMi[N];
-    Sp<T> vel[N];   // spatial velocities; bias acceleration / force are re-derived where they are used
-
-    M3<T> oR = liM1.R;
-    V3<T> op = liM1.p;
-    T kin = T(0), pot = T(0), rot = T(0);
-    {
-        Sp<T> vp = v1;
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int o = s * Q::QJ;
-            T c, sn;
-            sincos_(ql[s], &sn, &c);
-            const V3<T> n = LT.v3(o + Q::J_AXIS);
-            const SE3<T> plc = LT.se3(o + Q::J_PLC);
-            liMi[s] = {plc.R * rot_rodrigues(n, c, sn), plc.p};
-            const Sp<T> vj = {zero3<T>(), vl[s] * n};
-            const Sp<T> v = vj + actinv_motion(liMi[s], vp);
-            vel[s] = v;
-            op = op + oR * liMi[s].p;
-            oR = oR * liMi[s].R;
-            if (want_energy)
-            {
-                const RBI<T> Y = LT.rbi(o + Q::J_RBI);
-                kin += rbi_vtiv(Y, v);
-                pot -= Y.m * dot(op + oR * Y.c, g);
-                rot += LT(o + Q::J_ROTOR) * vl[s] * vl[s];
-            }
-            if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
-            vp = v;
-        });
-    }
-    const Sp<T> vlast = vel[N - 1];
-    const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
-    if (want_energy)
-    {
-        kin = X::quad_sum(kin);
-        pot = X::quad_sum(pot);
-        rot = X::quad_sum(rot);
-        kin += rbi_vtiv(Y1, v1);
-        pot -= Y1.m * dot(liM1.p + liM1.R * Y1.c, g);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rot += P[L::ROTOR + i] * vb[i] * vb[i];
-        if (lead)
-        {
-            A.energy[r32] = T(0.5) * kin + T(0.5) * rot;
-            A.energy[B32 + r32] = pot;
-        }
-    }
-    // ---- contact points on the last chain joint (engine.cc:3117-3238, 3394-3425)
-    Sp<T> fext_last = zero6<T>();
-    Sp<T> cf[c_max(Tp::QCL, 1)];
-    static_for<0, Tp::QCL>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const SE3<T> fr = LT.se3(Q::CONTACT + c * Q::QC);
-        const T depth = op.z + dot(V3<T>{oR.m20, oR.m21, oR.m22}, fr.p);
-        Sp<T> fl = zero6<T>();
-        if (depth < T(0))
-        {
-            const V3<T> vj = vlast.l + cross(vlast.a, fr.p);
-            const V3<T> vW = oR * vj;
-            const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
-            fl.l = tmul(oR, fW);
-            fl.a = cross(fr.p, fl.l);
-        }
-        fext_last = fext_last + fl;
-        cf[c] = actinv_force(fr, fl);
-    });
-    if (A.mode == MODE_START || A.mode == MODE_RESET)
-    {
-        T fmax2 = T(0);
-        static_for<0, Tp::QCL>([&](auto cc) { fmax2 = fmax_(fmax2, dot(cf[decltype(cc)::value].l, cf[decltype(cc)::value].l)); });
-        if (fmax2 > T(1e10)) status |= JM_LANE_FORCE_OVERFLOW;
-    }
-    if (emit)
-    {
-        if (A.f_external)
-        {
-            if (lead) { put6(A.f_external, B32, r32, 0, zero6<T>()); put6(A.f_external, B32, r32, 6, zero6<T>()); }
-            static_for<0, N>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
-                put6(A.f_external, B32, r32, 6 * j, (s == N - 1) ? fext_last : zero6<T>());
-            });
-        }
-        static_for<0, Tp::QCL>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if (A.contact_forces)
-            {
-                const int ci = sel4(k, Tp::limb_contact[0][c], Tp::limb_contact[1][c], Tp::limb_contact[2][c], Tp::limb_contact[3][c]);
-                put6(A.contact_forces, B32, r32, 6 * ci, cf[c]);
-            }
-            if constexpr (Tp::QHAS_CS)
-                if (sensors && A.contact)
+                if (ix.has[s])
                 {
-                    const int si = sel4(k, Tp::limb_cs[0][c], Tp::limb_cs[1][c], Tp::limb_cs[2][c], Tp::limb_cs[3][c]);
-                    const unsigned o = (unsigned)(3 * si) * B32 + r32;
-                    A.contact[o] = cf[c].l.x; A.contact[o + B32] = cf[c].l.y; A.contact[o + 2 * B32] = cf[c].l.z;
+                    A.encoder[(unsigned)(2 * si) * B32 + r32] = pos;
+                    A.encoder[(unsigned)(2 * si + 1) * B32 + r32] = vel;
                 }
-        });
-        if constexpr (Tp::QHAS_FORCE)
-            if (sensors && A.force)
-            {
-                Sp<T> sum = zero6<T>();
-                static_for<0, Tp::QCL>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    sum = sum + act_force(LT.se3(Q::CONTACT + c * Q::QC + 12), cf[c]);
+            });
+            if (lead)
+                static_for<1, NT>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int si = Tp::trunk_enc[t];
+                    T pos = qb[6 + t], vel = vb[5 + t];
+                    if constexpr (Tp::QENC_SIDE == 0) { pos *= P[L::ENC + si]; vel *= P[L::ENC + si]; }
+                    A.encoder[(unsigned)(2 * si) * B32 + r32] = pos;
+                    A.encoder[(unsigned)(2 * si + 1) * B32 + r32] = vel;
                 });
-                const int si = sel4(k, Tp::limb_force[0], Tp::limb_force[1], Tp::limb_force[2], Tp::limb_force[3]);
-                put6(A.force, B32, r32, 6 * si, sum);
+        }
+    // ---- root (free-flyer at the world origin, checked by jm_model_create) and trunk tree
+    const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
+    const V3<T> p1 = {qb[0], qb[1], qb[2]};
+    const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+    TrunkKin<T, Tp> K;
+    trunk_fk<T, Tp>(P, qb, vb, K, status);
+    // ---- limb kinematics
+    M3<T> Rs[N];
+    V3<T> ps[N];
+    Sp<T> vs[N];
+    limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vs, status);
+    // ---- contact points on the limb tip (engine.cc:3117-3238, 3394-3425)
+    Sp<T> fext = zero6<T>();   // total external force on the tip body, root coordinates
+    {
+        const M3<T> Rt = Rs[N - 1];
+        const V3<T> pt = ps[N - 1];
+        const Sp<T> vt = vs[N - 1];
+        Sp<T> fext_loc = zero6<T>(), fsens = zero6<T>();
+        T fmax2 = T(0);
+        auto one_contact = [&](int c) {
+            const int oc = Q::CONTACT + c * Q::QC;
+            const SE3<T> fr = LT.se3(oc);
+            const V3<T> pc = Rt * fr.p + pt;
+            const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+            const bool active = c < ix.nc;
+            Sp<T> fl = zero6<T>();
+            if (active && depth < T(0))
+            {
+                const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
+                const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
+                const V3<T> fR = tmul(R1, fW);
+                fext.l = fext.l + fR;
+                fext.a = fext.a + cross(pc, fR);
+                fmax2 = fmax_(fmax2, dot(fW, fW));
+                if (emit)
+                {
+                    fl.l = tmul(Rt, fR);
+                    fl.a = cross(fr.p, fl.l);
+                }
             }
+            if (emit && active)
+            {
+                fext_loc = fext_loc + fl;
+                const Sp<T> cf = actinv_force(fr, fl);  // Robot::contactForces_, contact frame
+                if (A.contact_forces) put6(A.contact_forces, B32, r32, 6 * (unsigned)(int)LT(oc + Q::C_IDX), cf);
+                if constexpr (Tp::QHAS_CS)
+                    if (sensors && A.contact)
+                    {
+                        const unsigned o = 3 * (unsigned)(int)LT(oc + Q::C_CS) * B32 + r32;
+                        A.contact[o] = cf.l.x; A.contact[o + B32] = cf.l.y; A.contact[o + 2 * B32] = cf.l.z;
+                    }
+                if constexpr (Tp::QHAS_FORCE)
+                    if (sensors && A.force) fsens = fsens + act_force(LT.se3(oc + Q::C_FREL), cf);
+            }
+        };
+        if constexpr (Tp::QCL <= 2)
+            static_for<0, Tp::QCL>([&](auto cc) { one_contact(decltype(cc)::value); });
+        else
+        {
+#pragma nounroll
+            for (int c = 0; c < Tp::QCL; ++c) one_contact(c);
+        }
+        if ((A.mode == MODE_START || A.mode == MODE_RESET) && fmax2 > T(1e10)) status |= JM_LANE_FORCE_OVERFLOW;
+        if (emit)
+        {
+            if (A.f_external)
+            {
+                if (lead)
+                {
+                    put6(A.f_external, B32, r32, 0, zero6<T>());
+                    static_for<0, NT>([&](auto tc) { put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[decltype(tc)::value], zero6<T>()); });
+                }
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
+                    // the tip body of a padded limb is its last real joint (the dummies share its frame)
+                    const bool tip = sel4(k, s == Tp::limb_len[0] - 1, s == Tp::limb_len[1] - 1, s == Tp::limb_len[2] - 1, s == Tp::limb_len[3] - 1) != 0;
+                    if (ix.has[s]) put6(A.f_external, B32, r32, 6 * (unsigned)j, mask6(tip, fext_loc));
+                });
+            }
+            if constexpr (Tp::QHAS_FORCE)
+                if (sensors && A.force)
+                {
+                    const int si = sel4(k, Tp::limb_force[0], Tp::limb_force[1], Tp::limb_force[2], Tp::limb_force[3]);
+                    if (si >= 0) put6(A.force, B32, r32, 6 * (unsigned)si, fsens);
+                }
+        }
     }
-    // ---- motors (one per chain joint, uniform flags; basic_motors.cc:83-143)
-    T u[N];
+    // ---- motors (one per movable joint, uniform flags; basic_motors.cc:83-143)
+    T u[N], ut[NT];
     static_for<0, N>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int o = s * Q::QJ + Q::J_MOTOR;
-        constexpr int fl = Tp::motor_flags[0];
-        const T red = LT(o), elim = LT(o + 1), vlim = LT(o + 2), islope = LT(o + 3);
-        const T vjnt = vl[s];
-        const T vmot = red * vjnt;
-        T um = cmd[s];
-        if constexpr ((fl & JM_MOTOR_EFFORT_LIMIT) != 0)
+        T um, ue;
+        motor_law<T, FL>([&](int i) { return LT(o + i); }, cmdl[s], vl[s], um, ue);
+        u[s] = ue;
+        if (emit && ix.has[s])
         {
-            T emin = -elim, emax = elim;
-            if constexpr ((fl & JM_MOTOR_VELOCITY_LIMIT) != 0)
-            {
-                const T vdelta = elim * islope;
-                if (vdelta > T(0))
-                {
-                    const T vthr = fmax_(vlim - vdelta, T(0));
-                    const T inv = T(1) / (vlim - vthr);
-                    emin *= clamp_((vlim + vmot) * inv, T(0), T(1));
-                    emax *= clamp_((vlim - vmot) * inv, T(0), T(1));
-                }
-            }
-            um = clamp_(um, emin, emax);
-        }
-        T ut = red * um;
-        if constexpr ((fl & JM_MOTOR_FRICTION) != 0)
-        {
-            const T fds = LT(o + 8);
-            if (vjnt > T(0)) ut += LT(o + 4) * vjnt + LT(o + 6) * tanh_(fds * vjnt);
-            else ut += LT(o + 5) * vjnt + LT(o + 7) * tanh_(fds * vjnt);
-        }
-        u[s] = ut;
-        if (emit)
-        {
-            if (A.u_motor) A.u_motor[(unsigned)rm[s] * B32 + r32] = um;
-            if (A.u) A.u[(unsigned)rv[s] * B32 + r32] = ut;
+            if (A.u_motor) A.u_motor[(unsigned)ix.rm[s] * B32 + r32] = um;
+            if (A.u) A.u[(unsigned)ix.rv[s] * B32 + r32] = ue;
             if constexpr (Tp::QHAS_EFF)
                 if (sensors && A.effort)
                 {
@@ -300,49 +457,126 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 }
         }
     });
+    ut[0] = T(0);
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int m = Tp::trunk_motor[t];
+        constexpr int o = L::MOTOR + JM_MOTOR_NPARAMS * m;
+        T um, ue;
+        motor_law<T, FL>([&](int i) { return P[o + i]; }, cmdb[t], vb[5 + t], um, ue);
+        ut[t] = ue;
+        if (emit && lead)
+        {
+            if (A.u_motor) A.u_motor[(unsigned)m * B32 + r32] = um;
+            if (A.u) A.u[(unsigned)Tp::idx_v[Tp::trunk_joint[t]] * B32 + r32] = ue;
+            if constexpr (Tp::QHAS_EFF)
+                if (sensors && A.effort) A.effort[(unsigned)Tp::trunk_eff[t] * B32 + r32] = um;
+        }
+    });
     if (emit && A.u && lead)
     {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) A.u[(unsigned)i * B32 + r32] = T(0);
+        for (int i = 0; i < 6; ++i) A.u[(unsigned)(Tp::idx_v[1] + i) * B32 + r32] = T(0);
     }
-    // ---- ABA pass 2 along the chain, leaf -> trunk (AbaBackwardStep)
+    // ---- ABA pass 2 along the limb, tip -> trunk (AbaBackwardStep), root coordinates
     JM_REFRESH();
-    Sp<T> U[N];
+    Sp<T> Ss[N], cs[N], Us[N];
     T dinv[N];
     AI<T> Ia;
-    Sp<T> pa_up = zero6<T>();
+    Sp<T> pa = zero6<T>();
+    T kin = T(0), rot = T(0), msum = T(0);
+    V3<T> mc = zero3<T>();
     static_rfor<0, N>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int o = s * Q::QJ;
-        const RBI<T> Y = LT.rbi(o + Q::J_RBI);
-        const V3<T> n = LT.v3(o + Q::J_AXIS);
-        Sp<T> f = cross_mf(vel[s], rbi_mul(Y, vel[s]));  // bias force v x* (I v)
-        if constexpr (s == N - 1) { f = f - fext_last; Ia = ai_from_rbi(Y); }
-        else { f = f + pa_up; Ia = ai_from_rbi(Y) + Ia; }
-        const Sp<T> cb = cross_mm(vel[s], Sp<T>{zero3<T>(), vl[s] * n});  // bias acceleration v x S qd
-        const T uj = u[s] - dot(n, f.a);
-        u[s] = uj;
-        const Sp<T> Us = {Ia.B * n, Ia.D * n};
-        const T D = dot(n, Us.a) + LT(o + Q::J_ROTOR);
+        const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(o + Q::J_RBI));
+        const V3<T> a = Rs[s] * LT.v3(o + Q::J_AXIS);
+        const Sp<T> S = {cross(ps[s], a), a};
+        Sp<T> f = cross_mf(vs[s], rbi_mul(Y, vs[s]));  // bias force v x* (I v)
+        if constexpr (s == N - 1) { f = f - fext; Ia = ai_from_rbi(Y); }
+        else { f = f + pa; Ia = ai_from_rbi(Y) + Ia; }
+        const Sp<T> c = cross_mm(vs[s], vl[s] * S);    // bias acceleration v x S qd
+        const T uj = u[s] - dot6(S, f);
+        const Sp<T> U = ai_mul(Ia, S);
+        const T D = dot6(S, U) + LT(o + Q::J_ROTOR);
         const T di = T(1) / D;
-        U[s] = Us;
-        dinv[s] = di;
-        ai_rank1_sub(Ia, Us, di);
-        const Sp<T> Ya = ai_mul(Ia, cb);
+        ai_rank1_sub(Ia, U, di);
+        const Sp<T> Ya = ai_mul(Ia, c);
         const T ud = uj * di;
-        const Sp<T> pa = {f.l + Ya.l + ud * Us.l, f.a + Ya.a + ud * Us.a};
-        Ia = ai_transform(liMi[s], Ia);
-        pa_up = act_force(liMi[s], pa);
+        pa = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
+        Ss[s] = S; cs[s] = c; Us[s] = U; dinv[s] = di; u[s] = uj;
+        if (want_energy)
+        {
+            kin += rbi_vtiv(Y, vs[s]);
+            mc = mc + Y.m * Y.c;
+            msum += Y.m;
+            rot += LT(o + Q::J_ROTOR) * vl[s] * vl[s];
+        }
     });
     // ---- child -> parent reduction over the 4 limbs (the only cross-lane step of the dynamics)
-    const AI<T> Ysum = quad_sum_ai<T, X>(Ia);
-    const Sp<T> fsum = quad_sum6<T, X>(pa_up);
-    // ---- trunk: u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf (free-flyer calc_aba + pass 3)
-    Sp<T> agf1;
+    AI<T> accA[NT];
+    Sp<T> accF[NT];
+#ifdef JM_HOST_EMU
+    std::memset(accA, 0xFF, sizeof(accA)); std::memset(accF, 0xFF, sizeof(accF));
+#endif
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (I::limb_at(t))
+        {
+            if constexpr (I::uniform_attach) { accA[t] = quad_sum_ai<T, X>(Ia); accF[t] = quad_sum6<T, X>(pa); }
+            else
+            {
+                const bool mine = ix.attach == t;
+                accA[t] = quad_sum_ai<T, X>(mask_ai(mine, Ia));
+                accF[t] = quad_sum6<T, X>(mask6(mine, pa));
+            }
+        }
+    });
+    if (want_energy)
     {
-        const AI<T> I1 = ai_from_rbi(Y1) + Ysum;
-        const Sp<T> f1 = cross_mf(v1, rbi_mul(Y1, v1)) + fsum;
-        agf1 = actinv_motion(liM1, Sp<T>{-g, -gw});  // bias v x v = 0 for the free-flyer
+        kin = X::quad_sum(kin); rot = X::quad_sum(rot); msum = X::quad_sum(msum);
+        mc = {X::quad_sum(mc.x), X::quad_sum(mc.y), X::quad_sum(mc.z)};
+    }
+    // ---- trunk tree, leaves -> root (identical in the 4 lanes)
+    Sp<T> ct[NT], Ut[NT];
+    T dinvt[NT];
+    static_rfor<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
+        const RBI<T> Y = rbi_placed(K.X[t].R, K.X[t].p, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+        const Sp<T> S = K.S[t];
+        Sp<T> f = cross_mf(K.v[t], rbi_mul(Y, K.v[t]));
+        AI<T> It = ai_from_rbi(Y);
+        if constexpr (I::has_child(t)) { f = f + accF[t]; It = It + accA[t]; }
+        const Sp<T> c = cross_mm(K.v[t], vb[5 + t] * S);
+        const T uj = ut[t] - dot6(S, f);
+        const Sp<T> U = ai_mul(It, S);
+        const T rotor = P[L::ROTOR + Tp::idx_v[j]];
+        const T D = dot6(S, U) + rotor;
+        const T di = T(1) / D;
+        ai_rank1_sub(It, U, di);
+        const Sp<T> Ya = ai_mul(It, c);
+        const T ud = uj * di;
+        const Sp<T> pt = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
+        if constexpr (I::first_contrib(t)) { accA[tp] = It; accF[tp] = pt; }
+        else { accA[tp] = accA[tp] + It; accF[tp] = accF[tp] + pt; }
+        ct[t] = c; Ut[t] = U; dinvt[t] = di; ut[t] = uj;
+        if (want_energy)
+        {
+            kin += rbi_vtiv(Y, K.v[t]);
+            mc = mc + Y.m * Y.c;
+            msum += Y.m;
+            rot += rotor * vb[5 + t] * vb[5 + t];
+        }
+    });
+    // ---- root: u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf (free-flyer calc_aba + pass 3)
+    const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
+    const Sp<T> v1 = K.v[0];
+    const Sp<T> agf1 = actinv_motion(SE3<T>{R1, p1}, Sp<T>{-g, -gw});  // bias v x v = 0 for the free-flyer
+    {
+        AI<T> I1 = ai_from_rbi(Y1);
+        Sp<T> f1 = cross_mf(v1, rbi_mul(Y1, v1));
+        if constexpr (I::has_child(0)) { I1 = I1 + accA[0]; f1 = f1 + accF[0]; }
         const Sp<T> Ya = ai_mul(I1, agf1);
         T b[6] = {-f1.l.x - Ya.l.x, -f1.l.y - Ya.l.y, -f1.l.z - Ya.l.z, -f1.a.x - Ya.a.x, -f1.a.y - Ya.a.y, -f1.a.z - Ya.a.z};
         T M[6][6];
@@ -352,44 +586,67 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         M[5][0] = I1.B.m02; M[5][1] = I1.B.m12; M[5][2] = I1.B.m22;
         M[3][3] = I1.D.xx; M[4][3] = I1.D.xy; M[5][3] = I1.D.xz; M[4][4] = I1.D.yy; M[5][4] = I1.D.yz; M[5][5] = I1.D.zz;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) M[i][i] += P[L::ROTOR + i];
+        for (int i = 0; i < 6; ++i) M[i][i] += P[L::ROTOR + Tp::idx_v[1] + i];
         chol6_solve(M, b);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ddq1[i] = b[i];
+        for (int i = 0; i < 6; ++i) ddqb[i] = b[i];
     }
-    const Sp<T> a1 = {{ddq1[0], ddq1[1], ddq1[2]}, {ddq1[3], ddq1[4], ddq1[5]}};
-    // ---- IMU on the trunk (basic_sensors.cc:142-164): data.a[1] = S ddq (bias is zero)
+    if (want_energy)
+    {
+        // Engine::computeExtraTerms energies (engine.cc:806-815, overload .h:54-55)
+        kin += rbi_vtiv(Y1, v1);
+        mc = mc + Y1.m * Y1.c;
+        msum += Y1.m;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rot += P[L::ROTOR + Tp::idx_v[1] + i] * vb[i] * vb[i];
+        if (lead)
+        {
+            A.energy[r32] = T(0.5) * kin + T(0.5) * rot;
+            A.energy[B32 + r32] = -(dot(R1 * mc, g) + msum * dot(p1, g));
+        }
+    }
+    // ---- ABA pass 3, root -> leaves (AbaForwardStep2): spatial accelerations add up directly
+    JM_REFRESH();
+    Sp<T> at[NT];
+    at[0] = agf1 + Sp<T>{{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const Sp<T> ag = at[Tp::trunk_parent[t]] + ct[t];
+        const T dd = dinvt[t] * (ut[t] - dot6(Ut[t], ag));
+        ddqb[5 + t] = dd;
+        at[t] = ag + dd * K.S[t];
+    });
+    // ---- IMUs on trunk-tree joints (basic_sensors.cc:142-164)
     if (emit_sens && A.imu && lead)
         static_for<0, Tp::NIMU>([&](auto ic) {
             constexpr int s = decltype(ic)::value;
+            constexpr int t = Tp::imu_trunk[s];
             const SE3<T> fr = ld_se3<T>(P, L::IMU + 12 * s);
-            const Sp<T> vf = actinv_motion(fr, v1);
-            Sp<T> af = actinv_motion(fr, a1);
+            const Sp<T> atrue = at[t] - agf1;  // data.a: spatial acceleration without the gravity field
+            Sp<T> vj, aj;
+            V3<T> gj = tmul(R1, g);
+            if constexpr (t == 0) { vj = K.v[0]; aj = atrue; }
+            else { vj = actinv_motion(K.X[t], K.v[t]); aj = actinv_motion(K.X[t], atrue); gj = tmul(K.X[t].R, gj); }
+            const Sp<T> vf = actinv_motion(fr, vj);
+            Sp<T> af = actinv_motion(fr, aj);
             af.l = af.l + cross(vf.a, vf.l);
-            const V3<T> gl = tmul(fr.R, tmul(liM1.R, g));
-            const V3<T> acc3 = af.l - gl;
+            const V3<T> acc3 = af.l - tmul(fr.R, gj);
             put6(A.imu, B32, r32, 6 * s, Sp<T>{vf.a, acc3});
         });
-    // ---- ABA pass 3 down the chain (AbaForwardStep2)
-    JM_REFRESH();
     {
-        Sp<T> ap = agf1 + a1;
+        Sp<T> ap = pick_attach<T, Tp>(k, at);
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const V3<T> n = LT.v3(s * Q::QJ + Q::J_AXIS);
-            const Sp<T> cb = cross_mm(vel[s], Sp<T>{zero3<T>(), vl[s] * n});
-            const Sp<T> ag = cb + actinv_motion(liMi[s], ap);
-            const T Ua = dot(U[s].l, ag.l) + dot(U[s].a, ag.a);
-            const T dd = dinv[s] * (u[s] - Ua);
+            const Sp<T> ag = ap + cs[s];
+            const T dd = dinv[s] * (u[s] - dot6(Us[s], ag));
             ddq[s] = dd;
-            ap = {ag.l, ag.a + dd * n};
+            ap = ag + dd * Ss[s];
         });
     }
     {
         bool bad = false;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) bad |= (ddq1[i] != ddq1[i]);
-        static_for<0, N>([&](auto sc) { bad |= (ddq[decltype(sc)::value] != ddq[decltype(sc)::value]); });
+        static_for<0, I::NVB>([&](auto ic) { bad |= (ddqb[decltype(ic)::value] != ddqb[decltype(ic)::value]); });
+        static_for<0, N>([&](auto sc) { bad |= ix.has[decltype(sc)::value] && (ddq[decltype(sc)::value] != ddq[decltype(sc)::value]); });
         if (bad) status |= JM_LANE_NAN;
     }
 }
@@ -397,124 +654,151 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 // Optional RNEA-like extra terms (engine.cc:858-904): joint internal wrenches (data.f) and
 // centroidal quantities.  Off the critical path: when requested, the kinematics are re-derived
 // from the state here so that nothing of the dynamics evaluation has to stay live for it.
+// Root coordinates again: body forces add up along the tree, each joint's wrench is rotated into
+// its own frame only when it is stored.
 template<class T, class Tp, class X>
-JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, long long r, int k,
-                             const T * qb, const T * vb, const T * ql, const T * vl, const T * ddq1, const T * ddq)
+JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r32, int k, const QIdx<Tp> & ix,
+                             const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq)
 {
     using L = Layout<Tp>;
     using Q = QLayout<Tp>;
-    constexpr int N = Tp::QN;
-    const unsigned B32 = (unsigned)A.B, r32 = (unsigned)r;
+    using I = QInfo<Tp>;
+    constexpr int N = Tp::QN, NT = Tp::QT;
+    const unsigned B32 = (unsigned)A.B;
     const bool lead = (k == 0);
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
-    SE3<T> liM1;
+    const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
+    const V3<T> p1 = {qb[0], qb[1], qb[2]};
+    const SE3<T> M1 = {R1, p1};
+    const Sp<T> agf1 = actinv_motion(M1, Sp<T>{-g, -gw});
+    int status = 0;
+    TrunkKin<T, Tp> K;
+    trunk_fk<T, Tp>(P, qb, vb, K, status);
+    // true spatial accelerations of the trunk tree (ForwardKinematicsAccelerationStep)
+    Sp<T> at[NT];
+    at[0] = {{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        at[t] = at[Tp::trunk_parent[t]] + cross_mm(K.v[t], vb[5 + t] * K.S[t]) + ddqb[5 + t] * K.S[t];
+    });
+    M3<T> Rs[N];
+    V3<T> ps[N];
+    Sp<T> vs[N];
+    limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vs, status);
+    // contact forces on the tip, root coordinates
+    Sp<T> fext = zero6<T>();
     {
-        SE3<T> Mj;
-        Mj.R = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
-        Mj.p = {qb[0], qb[1], qb[2]};
-        liM1 = Mj;
-    }
-    const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
-    const Sp<T> a1 = {{ddq1[0], ddq1[1], ddq1[2]}, {ddq1[3], ddq1[4], ddq1[5]}};
-    const Sp<T> agf1f = a1 + actinv_motion(liM1, Sp<T>{-g, -gw});
-    const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
-    SE3<T> liMi[N];
-    Sp<T> vel[N], da[N], dagf[N];
-    M3<T> oR = liM1.R;
-    V3<T> op = liM1.p;
-    {
-        Sp<T> vp = v1, ap = a1, agp = agf1f;
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int o = s * Q::QJ;
-            T c, sn;
-            sincos_(ql[s], &sn, &c);
-            const V3<T> n = LT.v3(o + Q::J_AXIS);
-            const SE3<T> plc = LT.se3(o + Q::J_PLC);
-            liMi[s] = {plc.R * rot_rodrigues(n, c, sn), plc.p};
-            const Sp<T> vj = {zero3<T>(), vl[s] * n};
-            vel[s] = vj + actinv_motion(liMi[s], vp);
-            const Sp<T> aj = cross_mm(vel[s], vj) + Sp<T>{zero3<T>(), ddq[s] * n};
-            da[s] = aj + actinv_motion(liMi[s], ap);
-            dagf[s] = aj + actinv_motion(liMi[s], agp);
-            op = op + oR * liMi[s].p;
-            oR = oR * liMi[s].R;
-            vp = vel[s]; ap = da[s]; agp = dagf[s];
-        });
-    }
-    Sp<T> fext_last = zero6<T>();
-    static_for<0, Tp::QCL>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const SE3<T> fr = LT.se3(Q::CONTACT + c * Q::QC);
-        const T depth = op.z + dot(V3<T>{oR.m20, oR.m21, oR.m22}, fr.p);
-        if (depth < T(0))
+        auto one_contact = [&](int c) {
+            const V3<T> pc = Rs[N - 1] * LT.v3(Q::CONTACT + c * Q::QC + 9) + ps[N - 1];
+            const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+            if (c < ix.nc && depth < T(0))
+            {
+                const V3<T> fR = tmul(R1, contact_law<T, Tp>(P, depth, R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc))));
+                fext.l = fext.l + fR;
+                fext.a = fext.a + cross(pc, fR);
+            }
+        };
+        if constexpr (Tp::QCL <= 2)
+            static_for<0, Tp::QCL>([&](auto cc) { one_contact(decltype(cc)::value); });
+        else
         {
-            const V3<T> vj = vel[N - 1].l + cross(vel[N - 1].a, fr.p);
-            const V3<T> fW = contact_law<T, Tp>(P, depth, oR * vj);
-            Sp<T> fl;
-            fl.l = tmul(oR, fW);
-            fl.a = cross(fr.p, fl.l);
-            fext_last = fext_last + fl;
+#pragma nounroll
+            for (int c = 0; c < Tp::QCL; ++c) one_contact(c);
         }
-    });
-    Sp<T> h[N], fB[N], fj[N];
-    static_for<0, N>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
-        h[s] = rbi_mul(Y, vel[s]);
-        const Sp<T> vxh = cross_mf(vel[s], h[s]);
-        fB[s] = rbi_mul(Y, da[s]) + vxh;
-        fj[s] = vxh + rbi_mul(Y, dagf[s]);
-        if constexpr (s == N - 1) fj[s] = fj[s] - fext_last;
-    });
-    static_rfor<1, N>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        fB[s - 1] = fB[s - 1] + act_force(liMi[s], fB[s]);
-        h[s - 1] = h[s - 1] + act_force(liMi[s], h[s]);
-        fj[s - 1] = fj[s - 1] + act_force(liMi[s], fj[s]);
-    });
-    const Sp<T> h1l = rbi_mul(Y1, v1);
-    const Sp<T> vxh1 = cross_mf(v1, h1l);
-    const Sp<T> h1 = h1l + quad_sum6<T, X>(act_force(liMi[0], h[0]));
-    const Sp<T> fB1 = rbi_mul(Y1, a1) + vxh1 + quad_sum6<T, X>(act_force(liMi[0], fB[0]));
-    const Sp<T> fj1 = vxh1 + rbi_mul(Y1, agf1f) + quad_sum6<T, X>(act_force(liMi[0], fj[0]));
-    if (A.joint_forces)
+    }
+    // limb: body momenta h, net body forces fB (true accelerations), joint wrenches fj (gravity
+    // field included, external forces removed), accumulated tip -> base; subtree mass / first moment
+    Sp<T> hs = zero6<T>(), fBs = zero6<T>(), fjs = zero6<T>();
+    T ms = T(0);
+    V3<T> mcs = zero3<T>();
     {
-        if (lead) { put6(A.joint_forces, B32, r32, 0, zero6<T>()); put6(A.joint_forces, B32, r32, 6, fj1); }
+        Sp<T> al[N];
+        Sp<T> ap = pick_attach<T, Tp>(k, at);
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
-            put6(A.joint_forces, B32, r32, 6 * j, fj[s]);
+            const V3<T> a = Rs[s] * LT.v3(s * Q::QJ + Q::J_AXIS);
+            const Sp<T> S = {cross(ps[s], a), a};
+            al[s] = ap + cross_mm(vs[s], vl[s] * S) + ddq[s] * S;
+            ap = al[s];
         });
-    }
-    if (A.centroidal)
-    {
-        T ms = T(0);
-        V3<T> mc = zero3<T>();
         static_rfor<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const RBI<T> Y = LT.rbi(s * Q::QJ + Q::J_RBI);
-            ms = ms + Y.m;
-            mc = mc + Y.m * Y.c;
-            mc = liMi[s].R * mc + ms * liMi[s].p;
+            const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(s * Q::QJ + Q::J_RBI));
+            const Sp<T> h = rbi_mul(Y, vs[s]);
+            const Sp<T> vxh = cross_mf(vs[s], h);
+            hs = hs + h;
+            fBs = fBs + rbi_mul(Y, al[s]) + vxh;
+            fjs = fjs + vxh + rbi_mul(Y, al[s] + agf1);
+            if constexpr (s == N - 1) fjs = fjs - fext;
+            ms += Y.m;
+            mcs = mcs + Y.m * Y.c;
+            if (A.joint_forces && ix.has[s])
+            {
+                const int j = sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
+                put6(A.joint_forces, B32, r32, 6 * (unsigned)j, actinv_force(SE3<T>{Rs[s], ps[s]}, fjs));
+            }
         });
-        const T mt = Y1.m + X::quad_sum(ms);
-        const V3<T> mct = Y1.m * Y1.c + V3<T>{X::quad_sum(mc.x), X::quad_sum(mc.y), X::quad_sum(mc.z)};
-        const V3<T> c1 = (T(1) / mt) * mct;
-        const V3<T> com0 = liM1.R * c1 + liM1.p;
-        Sp<T> hg = act_force(liM1, h1), dhg = act_force(liM1, fB1);
+    }
+    // trunk tree
+    Sp<T> hT[NT], fBT[NT], fjT[NT];
+    T mT[NT];
+    V3<T> mcT[NT];
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (I::limb_at(t))
+        {
+            const bool mine = I::uniform_attach || ix.attach == t;
+            hT[t] = quad_sum6<T, X>(mask6(mine, hs));
+            fBT[t] = quad_sum6<T, X>(mask6(mine, fBs));
+            fjT[t] = quad_sum6<T, X>(mask6(mine, fjs));
+            mT[t] = X::quad_sum(mine ? ms : T(0));
+            mcT[t] = {X::quad_sum(mine ? mcs.x : T(0)), X::quad_sum(mine ? mcs.y : T(0)), X::quad_sum(mine ? mcs.z : T(0))};
+        }
+        else
+        {
+            hT[t] = zero6<T>(); fBT[t] = zero6<T>(); fjT[t] = zero6<T>();
+            mT[t] = T(0); mcT[t] = zero3<T>();
+        }
+    });
+    static_rfor<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int j = Tp::trunk_joint[t];
+        RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+        if constexpr (t > 0) Y = rbi_placed(K.X[t].R, K.X[t].p, Y);
+        const Sp<T> h = rbi_mul(Y, K.v[t]);
+        const Sp<T> vxh = cross_mf(K.v[t], h);
+        hT[t] = hT[t] + h;
+        fBT[t] = fBT[t] + rbi_mul(Y, at[t]) + vxh;
+        fjT[t] = fjT[t] + vxh + rbi_mul(Y, at[t] + agf1);
+        mT[t] += Y.m;
+        mcT[t] = mcT[t] + Y.m * Y.c;
+        if (A.joint_forces && lead)
+        {
+            if constexpr (t > 0) put6(A.joint_forces, B32, r32, 6 * j, actinv_force(K.X[t], fjT[t]));
+            else put6(A.joint_forces, B32, r32, 6 * j, fjT[t]);
+        }
+        if constexpr (t > 0)
+        {
+            constexpr int tp = Tp::trunk_parent[t];
+            hT[tp] = hT[tp] + hT[t]; fBT[tp] = fBT[tp] + fBT[t]; fjT[tp] = fjT[tp] + fjT[t];
+            mT[tp] += mT[t]; mcT[tp] = mcT[tp] + mcT[t];
+        }
+    });
+    if (A.joint_forces && lead) put6(A.joint_forces, B32, r32, 0, zero6<T>());
+    if (A.centroidal && lead)
+    {
+        const V3<T> c1 = (T(1) / mT[0]) * mcT[0];
+        const V3<T> com0 = R1 * c1 + p1;
+        Sp<T> hg = act_force(M1, hT[0]), dhg = act_force(M1, fBT[0]);
         hg.a = hg.a + cross(hg.l, com0);
         dhg.a = dhg.a + cross(dhg.l, com0);
-        if (lead)
-        {
-            A.centroidal[r32] = com0.x; A.centroidal[B32 + r32] = com0.y; A.centroidal[2 * B32 + r32] = com0.z;
-            put6(A.centroidal, B32, r32, 3, hg);
-            put6(A.centroidal, B32, r32, 9, dhg);
-        }
+        A.centroidal[r32] = com0.x; A.centroidal[B32 + r32] = com0.y; A.centroidal[2 * B32 + r32] = com0.z;
+        put6(A.centroidal, B32, r32, 3, hg);
+        put6(A.centroidal, B32, r32, 9, dhg);
     }
 }
 
-// trunk part of pinocchio::integrate (SE(3)); identical in the 4 lanes
+// root part of pinocchio::integrate (SE(3)); identical in the 4 lanes
 template<class T> JM_DEV void integrate_freeflyer(const T * q, const T * d, T * qo)
 {
     SE3<T> M0;
@@ -538,41 +822,34 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
 {
     using Q = QLayout<Tp>;
     using R = QRows<Tp>;
-    constexpr int N = Tp::QN;
+    using I = QInfo<Tp>;
+    constexpr int N = Tp::QN, NT = Tp::QT, NQB = I::NQB, NVB = I::NVB;
     const unsigned B32 = (unsigned)A.B, r32 = (unsigned)r;
     CPtr<T> P = (CPtr<T>)A.P;
     const LimbTable<T> LT{limb_table + k * Q::QSTRIDE};
-    // per-lane row indices of this limb's joints
-    int rq[N], rv[N], rm[N];
-    static_for<0, N>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        rq[s] = sel4(k, Tp::idx_q[Tp::limb_joint[0][s]], Tp::idx_q[Tp::limb_joint[1][s]], Tp::idx_q[Tp::limb_joint[2][s]], Tp::idx_q[Tp::limb_joint[3][s]]);
-        rv[s] = sel4(k, Tp::idx_v[Tp::limb_joint[0][s]], Tp::idx_v[Tp::limb_joint[1][s]], Tp::idx_v[Tp::limb_joint[2][s]], Tp::idx_v[Tp::limb_joint[3][s]]);
-        rm[s] = sel4(k, Tp::limb_motor[0][s], Tp::limb_motor[1][s], Tp::limb_motor[2][s], Tp::limb_motor[3][s]);
-    });
+    const QIdx<Tp> ix = quad_indices<Tp>(k);
     const bool lead = (k == 0);
     int status = 0;
-    T qb[7], vb[6], ql[N], vl[N], cmd[N], ddq1[6], ddq[N];
-    static_for<0, N>([&](auto sc) { cmd[decltype(sc)::value] = A.command[(unsigned)rm[decltype(sc)::value] * B32 + r32]; });
+    T qb[NQB], vb[NVB], ql[N], vl[N], cmdl[N], cmdb[NT], ddqb[NVB], ddq[N];
+    static_for<0, N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        cmdl[s] = ix.has[s] ? A.command[(unsigned)ix.rm[s] * B32 + r32] : T(0);
+    });
+    cmdb[0] = T(0);
+    static_for<1, NT>([&](auto tc) { cmdb[decltype(tc)::value] = A.command[(unsigned)Tp::trunk_motor[decltype(tc)::value] * B32 + r32]; });
 
     auto load_state = [&](const T * qsrc, const T * vsrc) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) qb[i] = qsrc[(unsigned)i * B32 + r32];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vb[i] = vsrc[(unsigned)i * B32 + r32];
+        static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = qsrc[(unsigned)I::qrow(decltype(ic)::value) * B32 + r32]; });
+        static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = vsrc[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32]; });
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            ql[s] = qsrc[(unsigned)rq[s] * B32 + r32];
-            vl[s] = vsrc[(unsigned)rv[s] * B32 + r32];
+            ql[s] = ix.has[s] ? qsrc[(unsigned)ix.rq[s] * B32 + r32] : T(0);
+            vl[s] = ix.has[s] ? vsrc[(unsigned)ix.rv[s] * B32 + r32] : T(0);
         });
     };
     auto store_a = [&](T * dst) {
-        if (lead)
-        {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) dst[(unsigned)i * B32 + r32] = ddq1[i];
-        }
-        static_for<0, N>([&](auto sc) { dst[(unsigned)rv[decltype(sc)::value] * B32 + r32] = ddq[decltype(sc)::value]; });
+        if (lead) static_for<0, NVB>([&](auto ic) { dst[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32] = ddqb[decltype(ic)::value]; });
+        static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) dst[(unsigned)ix.rv[decltype(sc)::value] * B32 + r32] = ddq[decltype(sc)::value]; });
     };
     auto store_status = [&]() {
         const int st = X::quad_or(status);
@@ -584,15 +861,16 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         if (!A.mask[r32]) return;  // uniform over the quad
         if (lead)
         {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) A.q[(unsigned)i * B32 + r32] = A.q_init[(unsigned)i * B32 + r32];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) A.v[(unsigned)i * B32 + r32] = A.v_init[(unsigned)i * B32 + r32];
+            static_for<0, NQB>([&](auto ic) { const unsigned o = (unsigned)I::qrow(decltype(ic)::value) * B32 + r32; A.q[o] = A.q_init[o]; });
+            static_for<0, NVB>([&](auto ic) { const unsigned o = (unsigned)I::vrow(decltype(ic)::value) * B32 + r32; A.v[o] = A.v_init[o]; });
         }
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            A.q[(unsigned)rq[s] * B32 + r32] = A.q_init[(unsigned)rq[s] * B32 + r32];
-            A.v[(unsigned)rv[s] * B32 + r32] = A.v_init[(unsigned)rv[s] * B32 + r32];
+            if (ix.has[s])
+            {
+                A.q[(unsigned)ix.rq[s] * B32 + r32] = A.q_init[(unsigned)ix.rq[s] * B32 + r32];
+                A.v[(unsigned)ix.rv[s] * B32 + r32] = A.v_init[(unsigned)ix.rv[s] * B32 + r32];
+            }
         });
     }
     if (A.mode != MODE_STEP)
@@ -601,7 +879,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         else if (A.mode == MODE_RESET) load_state(A.q_init, A.v_init);
         else load_state(A.q, A.v);
         const bool emit = A.mode != MODE_DYNAMICS;
-        quad_eval<T, Tp, X>(P, LT, A, r, k, rv, rm, qb, vb, ql, vl, cmd, emit, true, ddq1, ddq, status);
+        quad_eval<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, cmdb, cmdl, emit, true, ddqb, ddq, status);
         if (A.mode == MODE_DYNAMICS)
         {
             store_a(A.a_out);
@@ -613,7 +891,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             JM_REFRESH();
             if (A.mode == MODE_RESET) load_state(A.q_init, A.v_init);
             else load_state(A.q, A.v);
-            quad_extra_terms<T, Tp, X>(P, LT, A, r, k, qb, vb, ql, vl, ddq1, ddq);
+            quad_extra_terms<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, ddqb, ddq);
         }
         store_status();
         return;
@@ -626,18 +904,24 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     const int n_evals = pre + A.n_sub * (rk4 ? 4 : 1);
     {
         bool bad = false;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { const T x = A.q[(unsigned)i * B32 + r32]; S.putb(R::Q0B + i, x); bad |= (x != x); }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-        {
-            const T x = A.v[(unsigned)i * B32 + r32], y = A.a[(unsigned)i * B32 + r32];
+        static_for<0, NQB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T x = A.q[(unsigned)I::qrow(i) * B32 + r32];
+            S.putb(R::Q0B + i, x); bad |= (x != x);
+        });
+        static_for<0, NVB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T x = A.v[(unsigned)I::vrow(i) * B32 + r32], y = A.a[(unsigned)I::vrow(i) * B32 + r32];
             S.putb(R::V0B + i, x); S.putb(R::A0B + i, y);
             bad |= (x != x) || (y != y);
-        }
+        });
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const T x = A.q[(unsigned)rq[s] * B32 + r32], y = A.v[(unsigned)rv[s] * B32 + r32], z = A.a[(unsigned)rv[s] * B32 + r32];
+            T x = T(0), y = T(0), z = T(0);
+            if (ix.has[s])
+            {
+                x = A.q[(unsigned)ix.rq[s] * B32 + r32]; y = A.v[(unsigned)ix.rv[s] * B32 + r32]; z = A.a[(unsigned)ix.rv[s] * B32 + r32];
+            }
             S.putl(R::Q0L + s, x); S.putl(R::V0L + s, y); S.putl(R::A0L + s, z);
             bad |= (x != x) || (y != y) || (z != z);
         });
@@ -655,10 +939,8 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         JM_REFRESH();
         if (st == -1)
         {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) qb[i] = S.getb(R::Q0B + i);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) vb[i] = S.getb(R::V0B + i);
+            static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
             static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
         }
         else
@@ -671,15 +953,13 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                 aw = (st == 2) ? dt : dt * T(0.5);
             }
             else { bw = dt; aw = dt; }
-            T incb[6], q0b[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) q0b[i] = S.getb(R::Q0B + i);
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-            {
+            T incb[NVB], q0b[NQB];
+            static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+            static_for<0, NVB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 const T v0 = S.getb(R::V0B + i);
                 const T kv = first ? v0 : S.getb(R::KVB + i);
-                const T ka = first ? S.getb(R::A0B + i) : ddq1[i];
+                const T ka = first ? S.getb(R::A0B + i) : ddqb[i];
                 const T av = (first || !rk4) ? bw * kv : S.getb(R::ACCVB + i) + bw * kv;
                 const T aa = (first || !rk4) ? bw * ka : S.getb(R::ACCAB + i) + bw * ka;
                 if (st == 3) { incb[i] = av; vb[i] = v0 + aa; }
@@ -688,8 +968,9 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                     S.putb(R::ACCVB + i, av); S.putb(R::ACCAB + i, aa);
                     incb[i] = aw * kv; vb[i] = v0 + aw * ka; S.putb(R::KVB + i, vb[i]);
                 }
-            }
+            });
             integrate_freeflyer<T>(q0b, incb, qb);
+            static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 const T q0 = S.getl(R::Q0L + s), v0 = S.getl(R::V0L + s);
@@ -703,38 +984,37 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                     S.putl(R::ACCVL + s, av); S.putl(R::ACCAL + s, aa);
                     ql[s] = q0 + aw * kv; vl[s] = v0 + aw * ka; S.putl(R::KVL + s, vl[s]);
                 }
+                if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
             });
             if (st == 3)
             {
                 // commit: the new state becomes the start of the next sub-step
-#pragma unroll
-                for (int i = 0; i < 7; ++i) S.putb(R::Q0B + i, qb[i]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) S.putb(R::V0B + i, vb[i]);
+                static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
+                static_for<0, NVB>([&](auto ic) { S.putb(R::V0B + decltype(ic)::value, vb[decltype(ic)::value]); });
                 static_for<0, N>([&](auto sc) { S.putl(R::Q0L + decltype(sc)::value, ql[decltype(sc)::value]); S.putl(R::V0L + decltype(sc)::value, vl[decltype(sc)::value]); });
                 if (last)
                 {
                     if (lead)
                     {
-#pragma unroll
-                        for (int i = 0; i < 7; ++i) A.q[(unsigned)i * B32 + r32] = qb[i];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) A.v[(unsigned)i * B32 + r32] = vb[i];
+                        static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + r32] = qb[decltype(ic)::value]; });
+                        static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32] = vb[decltype(ic)::value]; });
                     }
                     static_for<0, N>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
-                        A.q[(unsigned)rq[s] * B32 + r32] = ql[s];
-                        A.v[(unsigned)rv[s] * B32 + r32] = vl[s];
+                        if (ix.has[s])
+                        {
+                            A.q[(unsigned)ix.rq[s] * B32 + r32] = ql[s];
+                            A.v[(unsigned)ix.rv[s] * B32 + r32] = vl[s];
+                        }
                     });
                 }
             }
         }
-        quad_eval<T, Tp, X>(P, LT, A, r, k, rv, rm, qb, vb, ql, vl, cmd, last, A.update_sensors != 0, ddq1, ddq, status);
+        quad_eval<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, cmdb, cmdl, last, A.update_sensors != 0, ddqb, ddq, status);
         if (st == -1 || st == 3)
         {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) S.putb(R::A0B + i, ddq1[i]);
-            static_for<0, N>([&](auto sc) { S.putl(R::A0L + decltype(sc)::value, ddq[decltype(sc)::value]); });
+            static_for<0, NVB>([&](auto ic) { S.putb(R::A0B + decltype(ic)::value, ddqb[decltype(ic)::value]); });
+            static_for<0, N>([&](auto sc) { S.putl(R::A0L + decltype(sc)::value, ix.has[decltype(sc)::value] ? ddq[decltype(sc)::value] : T(0)); });
         }
         if (last)
         {
@@ -744,12 +1024,10 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             {
                 // the committed state sits in the stage buffer
                 JM_REFRESH();
-#pragma unroll
-                for (int i = 0; i < 7; ++i) qb[i] = S.getb(R::Q0B + i);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) vb[i] = S.getb(R::V0B + i);
+                static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
                 static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-                quad_extra_terms<T, Tp, X>(P, LT, A, r, k, qb, vb, ql, vl, ddq1, ddq);
+                quad_extra_terms<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, ddqb, ddq);
             }
         }
     }
@@ -784,21 +1062,38 @@ struct DppQuad
 #ifndef JM_QUAD_WAVES_PER_EU
 #define JM_QUAD_WAVES_PER_EU 1
 #endif
+// waves per block: they share one copy of the limb table. Pick the block size that keeps the most
+// waves resident per CU under the 160 KiB of LDS (a CU runs at most 2 such waves per SIMD).
+template<class T, class Tp> constexpr int quad_block_waves()
+{
+    constexpr long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
+    constexpr long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
+    int best = 1, best_resident = 0;
+    for (int w = 1; w <= 4; w *= 2)
+    {
+        long blocks = (160L * 1024) / (table + w * per_wave);
+        if (blocks * w > 8) blocks = 8 / w;
+        const int resident = (int)blocks * w;
+        if (resident >= best_resident) { best = w; best_resident = resident; }
+    }
+    return best;
+}
 template<class T, class Tp>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
+__global__ void __launch_bounds__((64 * quad_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
 k_quad(const BatchArgs<T> A)
 {
     using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * quad_block_waves<T, Tp>();
     __shared__ T table[Q::TABLE];
-    __shared__ T stage_l[QRows<Tp>::NL * 64];
-    __shared__ T stage_b[QRows<Tp>::NB * 16];
-    for (int i = threadIdx.x; i < Q::TABLE; i += 64) table[i] = A.P[Q::OFFSET + i];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
     __syncthreads();
-    const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 2);
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
     const int k = threadIdx.x & 3;
     if (r >= A.B) return;  // uniform over the quad
-    const StageBuf<T, 64, 16> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
-    quad_lane_run<T, Tp, DppQuad, 64, 16>(A, r, k, table, S);
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4>(A, r, k, table, S);
 }
 #endif
 }  // namespace jm

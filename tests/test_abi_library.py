@@ -71,7 +71,12 @@ def test_generated_topology_header():
     text = codegen.topology_header(load_builtin("anymal"))
     assert "static constexpr bool QUAD = true;" in text and "limb_joint[4][3]" in text
     assert "QUAD = false" in codegen.topology_header(robots.tree_arm(True))
-    assert codegen.quad_structure(load_builtin("atlas")) is None
+    # Atlas: back chain + neck form the trunk tree, arms (7) and legs (6, padded) are the limbs
+    q = codegen.quad_structure(load_builtin("atlas"))
+    assert q is not None and q["n"] == 7 and q["limb_len"] == [7, 7, 6, 6]
+    assert q["limb_attach"] == [3, 3, 0, 0] and q["limb_ncontact"] == [0, 0, 16, 16]
+    assert len(q["trunk"]) == 5 and q["imu_trunk"] == [3]
+    assert codegen.quad_structure(load_builtin("cartpole")) is None
 
 
 def test_model_desc_packing():

@@ -67,22 +67,40 @@ def test_lane_kernel_matches_oracle(name, solver):
     assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
 
 
+QUAD_CASES = {
+    # name: (states kwargs, dt)
+    "anymal": (dict(base_height=(0.3, 0.6), grounded_fraction=0.6), 5e-4),
+    "atlas": (dict(base_height=(0.85, 1.0), grounded_fraction=0.6), 2.5e-4),
+}
+
+
+@pytest.mark.parametrize("name", list(QUAD_CASES))
 @pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
-def test_quad_kernel_matches_oracle(solver):
-    model = load_builtin("anymal")
-    B = 24
-    ref, got = _pair(model, B, seed=4)
+def test_quad_kernel_matches_oracle(name, solver):
+    """Branch-parallel kernel (4 lanes per robot, ABA in root coordinates): ANYmal (root + 4 equal
+    limbs) and Atlas (5-joint trunk tree, padded limbs attached at two different trunk joints,
+    16 contact points per foot).  The formulation differs from the oracle's joint-local one, so
+    agreement is at accumulated round-off (1e-11), not bitwise."""
+    model = load_builtin(name)
+    kw_states, dt = QUAD_CASES[name]
+    B = 24 if name == "anymal" else 12
+    st = sample_states(model, B, seed=4, **kw_states)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+        got[k][:] = st[k]
     oracle_batch(model, ref, "start")
     emu.run(model, got, "start", variant="quad")
-    _check(got, ref, 1e-12, what="start")
+    _check(got, ref, 2e-11, what="start")
     assert np.array_equal(got["status"], ref["status"])
     assert (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() >= 3  # contact branch exercised
     for i in range(6):
-        kw = dict(solver=solver, dt=5e-4, n_substeps=2 if i % 2 else 1, command_changed=(i % 3 == 0))
+        kw = dict(solver=solver, dt=dt, n_substeps=2 if i % 2 else 1, command_changed=(i % 3 == 0))
         oracle_batch(model, ref, "step", **kw)
         emu.run(model, got, "step", variant="quad", **kw)
     ok = (ref["status"][0] & 1) == 0
-    _check(got, ref, 1e-9, ok, what="steps")
+    assert ok.sum() >= B // 2
+    _check(got, ref, 1e-8, ok, what="steps")
     assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
 
 

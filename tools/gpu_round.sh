@@ -1,0 +1,37 @@
+#!/bin/bash
+# One GPU-box pass: parity tests, the bench line, rocprofv3 kernel stats and the PMC passes
+# (separate runs, --pmc never combined with trace domains other than --kernel-trace).
+# Usage (through gpurun):  bash tools/gpu_round.sh <tag> [skip_tests]
+# Everything lands under gpurun_out/<tag>/ ; tools/summarise_profiles.py turns it into profiles/.
+set -u
+TAG=${1:-r01}
+SKIP_TESTS=${2:-0}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export PYTHONPATH=$REPO
+
+if [ "$SKIP_TESTS" != "1" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
+  tail -3 "$OUT/pytest_gpu.log"
+fi
+
+timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench rc=$?"; tail -c 600 "$OUT/bench.json"
+
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" \
+         "TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$N" -o run -- $BENCH > "$OUT/pmc_$N.log" 2>&1
+  echo "pmc $N rc=$?"
+done
+cd "$REPO"
+# keep the merge-back small: drop the per-launch traces of the PMC passes except the counter csv
+find "$OUT" -name '*agent_info.csv' -delete
+du -sh "$OUT"
