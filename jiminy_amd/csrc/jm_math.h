@@ -287,20 +287,14 @@ template<class T> JM_DEV M3<T> quat_to_matrix(T x, T y, T z, T w)
 // device that form materialises its outputs through private (scratch) memory, and hipcc (ROCm 7.2)
 // was observed to lay those slots over live spill slots in the large unrolled kernels (wrong
 // accelerations after an integrate step, GPU only).  Cody-Waite reduction by pi/2 in three FMA
-// steps + the fdlibm kernel polynomials (< 2 ulp for |x| < 1e5; larger arguments take the slow
-// library path).
+// steps + the fdlibm kernel polynomials (< 2 ulp for |x| < 1e5; larger arguments give NaN).
 JM_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 JM_DEV void sincos_(double x, double * s, double * c)
 {
-    if (!(__builtin_fabs(x) < 1.0e5))
-    {
-#ifdef JM_HOST_EMU
-        *s = std::sin(x); *c = std::cos(x);
-#else
-        *s = ::sin(x); *c = ::cos(x);
-#endif
-        return;
-    }
+    // Branch-free: |x| >= 1e5 is never a valid joint angle or dt * omega; it yields NaN, which
+    // flags the lane (JM_LANE_NAN) instead of taking a Payne-Hanek slow path that would split
+    // every kinematics block of the kernels in two.
+    x = (__builtin_fabs(x) < 1.0e5) ? x : __builtin_nan("");
     const double fn = __builtin_rint(x * 0.63661977236758134308);
     double r = fma_(-fn, 1.5707963267948966, x);
     r = fma_(-fn, 6.123233995736766e-17, r);

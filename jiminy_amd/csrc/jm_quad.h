@@ -140,12 +140,14 @@ template<class T, int SL, int SB> struct StageBuf
     JM_DEV T getb(int row) const { return sb[row * SB]; }
     JM_DEV void putb(int row, T x) const { if (wb) sb[row * SB] = x; }
 };
-// rows of the stage buffer
+// rows of the stage buffer: step-start state (q0, v0), RK accumulators (sum_i b_i k_i for the
+// velocity and acceleration parts) and the velocity of the previous stage (kv).  The previous
+// stage's acceleration is the result of the previous evaluation and stays in registers.
 template<class Tp> struct QRows
 {
     static constexpr int N = Tp::QN, NQB = QInfo<Tp>::NQB, NVB = QInfo<Tp>::NVB;
-    static constexpr int Q0B = 0, V0B = NQB, A0B = V0B + NVB, ACCVB = A0B + NVB, ACCAB = ACCVB + NVB, KVB = ACCAB + NVB, NB = KVB + NVB;  // trunk rows
-    static constexpr int Q0L = 0, V0L = N, A0L = 2 * N, ACCVL = 3 * N, ACCAL = 4 * N, KVL = 5 * N, NL = 6 * N;  // limb rows
+    static constexpr int Q0B = 0, V0B = NQB, ACCVB = V0B + NVB, ACCAB = ACCVB + NVB, KVB = ACCAB + NVB, NB = KVB + NVB;  // trunk rows
+    static constexpr int Q0L = 0, V0L = N, ACCVL = 2 * N, ACCAL = 3 * N, KVL = 4 * N, NL = 5 * N;  // limb rows
 };
 
 // All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
@@ -169,14 +171,13 @@ template<class T, int FL, class MP> JM_DEV void motor_law(MP && mp, T cmd, T vjn
         T emin = -elim, emax = elim;
         if constexpr ((FL & JM_MOTOR_VELOCITY_LIMIT) != 0)
         {
+            // branch-free form of `if (vdelta > 0) { scale the bounds }` (per-lane constants)
             const T vdelta = elim * islope;
-            if (vdelta > T(0))
-            {
-                const T vthr = fmax_(vlim - vdelta, T(0));
-                const T inv = T(1) / (vlim - vthr);
-                emin *= clamp_((vlim + vmot) * inv, T(0), T(1));
-                emax *= clamp_((vlim - vmot) * inv, T(0), T(1));
-            }
+            const bool on = vdelta > T(0);
+            const T vthr = fmax_(vlim - vdelta, T(0));
+            const T inv = T(1) / (on ? vlim - vthr : T(1));
+            emin *= on ? clamp_((vlim + vmot) * inv, T(0), T(1)) : T(1);
+            emax *= on ? clamp_((vlim - vmot) * inv, T(0), T(1)) : T(1);
         }
         um = clamp_(um, emin, emax);
     }
@@ -299,15 +300,18 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
 // a = f(q, v) for one robot spread over a quad; lane k evaluates limb k.
 //   qb[NQB], vb[NVB] : trunk-tree configuration / velocity (identical in the 4 lanes)
 //   ql[N], vl[N], cmdl[N] : this limb's joints;  cmdb[NT] : commands of the trunk-tree motors
-// When `emit` (uniform) is set -- last evaluation of a step, `start`, `reset` -- the outputs that
+// When EMIT is set -- last evaluation of a step, `start`, `reset` -- the outputs that
 // derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
 // if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
 // has to stay in registers for a separate output phase.
-template<class T, class Tp, class X>
+template<class T, class Tp, class X, bool EMIT>
 JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
                       const T * qb, const T * vb, const T * ql, const T * vl, const T * cmdb, const T * cmdl,
-                      bool emit, bool sensors, T * ddqb, T * ddq, int & status)
+                      bool sensors, T * ddqb, T * ddq, int & status)
 {
+    // compile-time: the three non-emitting evaluations of an RK4 step carry no output code at all,
+    // which keeps their basic blocks large (LDS reads of the limb table get batched ahead of use)
+    constexpr bool emit = EMIT;
     using L = Layout<Tp>;
     using Q = QLayout<Tp>;
     using I = QInfo<Tp>;
@@ -411,7 +415,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 #pragma nounroll
             for (int c = 0; c < Tp::QCL; ++c) one_contact(c);
         }
-        if ((A.mode == MODE_START || A.mode == MODE_RESET) && fmax2 > T(1e10)) status |= JM_LANE_FORCE_OVERFLOW;
+        if constexpr (EMIT)
+            if ((A.mode == MODE_START || A.mode == MODE_RESET) && fmax2 > T(1e10)) status |= JM_LANE_FORCE_OVERFLOW;
         if (emit)
         {
             if (A.f_external)
@@ -838,94 +843,58 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     cmdb[0] = T(0);
     static_for<1, NT>([&](auto tc) { cmdb[decltype(tc)::value] = A.command[(unsigned)Tp::trunk_motor[decltype(tc)::value] * B32 + r32]; });
 
-    auto load_state = [&](const T * qsrc, const T * vsrc) {
-        static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = qsrc[(unsigned)I::qrow(decltype(ic)::value) * B32 + r32]; });
-        static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = vsrc[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32]; });
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            ql[s] = ix.has[s] ? qsrc[(unsigned)ix.rq[s] * B32 + r32] : T(0);
-            vl[s] = ix.has[s] ? vsrc[(unsigned)ix.rv[s] * B32 + r32] : T(0);
-        });
-    };
-    auto store_a = [&](T * dst) {
-        if (lead) static_for<0, NVB>([&](auto ic) { dst[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32] = ddqb[decltype(ic)::value]; });
-        static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) dst[(unsigned)ix.rv[decltype(sc)::value] * B32 + r32] = ddq[decltype(sc)::value]; });
-    };
-    auto store_status = [&]() {
-        const int st = X::quad_or(status);
-        if (A.status && lead) A.status[r32] = st;
-    };
-
+    // every mode runs through the same evaluation loop (two inlined copies of the dynamics: with
+    // and without the output code): `start`, `reset` and `dynamics` are one evaluation at a given
+    // state, `step` is the RK4 / Euler state machine. The step state lives in the stage buffer.
+    const bool stepping = A.mode == MODE_STEP;
+    const T * qsrc = A.q;
+    const T * vsrc = A.v;
+    if (A.mode == MODE_DYNAMICS) { qsrc = A.q_in; vsrc = A.v_in; }
     if (A.mode == MODE_RESET)
     {
         if (!A.mask[r32]) return;  // uniform over the quad
-        if (lead)
-        {
-            static_for<0, NQB>([&](auto ic) { const unsigned o = (unsigned)I::qrow(decltype(ic)::value) * B32 + r32; A.q[o] = A.q_init[o]; });
-            static_for<0, NVB>([&](auto ic) { const unsigned o = (unsigned)I::vrow(decltype(ic)::value) * B32 + r32; A.v[o] = A.v_init[o]; });
-        }
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if (ix.has[s])
-            {
-                A.q[(unsigned)ix.rq[s] * B32 + r32] = A.q_init[(unsigned)ix.rq[s] * B32 + r32];
-                A.v[(unsigned)ix.rv[s] * B32 + r32] = A.v_init[(unsigned)ix.rv[s] * B32 + r32];
-            }
-        });
+        qsrc = A.q_init; vsrc = A.v_init;
     }
-    if (A.mode != MODE_STEP)
-    {
-        if (A.mode == MODE_DYNAMICS) load_state(A.q_in, A.v_in);
-        else if (A.mode == MODE_RESET) load_state(A.q_init, A.v_init);
-        else load_state(A.q, A.v);
-        const bool emit = A.mode != MODE_DYNAMICS;
-        quad_eval<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, cmdb, cmdl, emit, true, ddqb, ddq, status);
-        if (A.mode == MODE_DYNAMICS)
-        {
-            store_a(A.a_out);
-            return;
-        }
-        store_a(A.a);
-        if (A.joint_forces || A.centroidal)
-        {
-            JM_REFRESH();
-            if (A.mode == MODE_RESET) load_state(A.q_init, A.v_init);
-            else load_state(A.q, A.v);
-            quad_extra_terms<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, ddqb, ddq);
-        }
-        store_status();
-        return;
-    }
-
-    // ---- MODE_STEP: RK4 / Euler state machine; the step state lives in the stage buffer
     const T dt = A.dt;
     const bool rk4 = A.solver == JM_SOLVER_RUNGE_KUTTA_4;
-    const int pre = A.command_changed ? 1 : 0;
-    const int n_evals = pre + A.n_sub * (rk4 ? 4 : 1);
+    const int pre = stepping ? (A.command_changed ? 1 : 0) : 1;
+    const int n_evals = stepping ? pre + A.n_sub * (rk4 ? 4 : 1) : 1;
+    // Stage-buffer invariant at the start of every integrator step: q0/v0 = state, kv = v0,
+    // accumulators = 0, ddq(b) registers = a(state).  Every stage update is then the same
+    // straight-line code (no per-element `first stage ?` branches around the LDS reads).
     {
         bool bad = false;
         static_for<0, NQB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const T x = A.q[(unsigned)I::qrow(i) * B32 + r32];
+            const unsigned o = (unsigned)I::qrow(i) * B32 + r32;
+            const T x = qsrc[o];
             S.putb(R::Q0B + i, x); bad |= (x != x);
+            if (A.mode == MODE_RESET && lead) A.q[o] = x;
         });
         static_for<0, NVB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const T x = A.v[(unsigned)I::vrow(i) * B32 + r32], y = A.a[(unsigned)I::vrow(i) * B32 + r32];
-            S.putb(R::V0B + i, x); S.putb(R::A0B + i, y);
+            const unsigned o = (unsigned)I::vrow(i) * B32 + r32;
+            const T x = vsrc[o], y = stepping ? A.a[o] : T(0);
+            S.putb(R::V0B + i, x); S.putb(R::KVB + i, x); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
+            ddqb[i] = y;
             bad |= (x != x) || (y != y);
+            if (A.mode == MODE_RESET && lead) A.v[o] = x;
         });
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             T x = T(0), y = T(0), z = T(0);
             if (ix.has[s])
             {
-                x = A.q[(unsigned)ix.rq[s] * B32 + r32]; y = A.v[(unsigned)ix.rv[s] * B32 + r32]; z = A.a[(unsigned)ix.rv[s] * B32 + r32];
+                const unsigned oq = (unsigned)ix.rq[s] * B32 + r32, ov = (unsigned)ix.rv[s] * B32 + r32;
+                x = qsrc[oq]; y = vsrc[ov]; z = stepping ? A.a[ov] : T(0);
+                if (A.mode == MODE_RESET) { A.q[oq] = x; A.v[ov] = y; }
             }
-            S.putl(R::Q0L + s, x); S.putl(R::V0L + s, y); S.putl(R::A0L + s, z);
+            S.putl(R::Q0L + s, x); S.putl(R::V0L + s, y); S.putl(R::KVL + s, y); S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
+            ddq[s] = z;
             bad |= (x != x) || (y != y) || (z != z);
         });
-        if (bad) status |= JM_LANE_NAN;
+        // NaN guard on the incoming state (engine.cc:1737-1747)
+        if (bad && stepping) status |= JM_LANE_NAN;
     }
     // The 4 lanes of a quad execute in lock-step on the GPU, so every lane has read the trunk
     // rows of q/v/a before the lead lane overwrites them at commit time; the host emulation
@@ -937,6 +906,10 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
         const bool last = (e == n_evals - 1);
         JM_REFRESH();
+        // per-iteration opaque copy of the lane offset: the addresses of the commit / output stores
+        // must not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
+        unsigned rr = r32;
+        JM_OPAQUE(rr);
         if (st == -1)
         {
             static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
@@ -945,89 +918,112 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         }
         else
         {
-            const bool first = rk4 ? (st == 0) : true;
-            T bw, aw;
-            if (rk4)
-            {
-                bw = (st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0);
-                aw = (st == 2) ? dt : dt * T(0.5);
-            }
-            else { bw = dt; aw = dt; }
-            T incb[NVB], q0b[NQB];
+            // RK4 tableau (runge_kutta4_stepper.h:12-23): b = 1/6 1/3 1/3 1/6, A(i, i-1) = 1/2 1/2 1;
+            // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
+            // previous stage; the increments are summed in the tangent space and applied once
+            // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
+            const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
+            const T aw = (st == 2) ? dt : dt * T(0.5);
+            T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
             static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
             static_for<0, NVB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                const T v0 = S.getb(R::V0B + i);
-                const T kv = first ? v0 : S.getb(R::KVB + i);
-                const T ka = first ? S.getb(R::A0B + i) : ddqb[i];
-                const T av = (first || !rk4) ? bw * kv : S.getb(R::ACCVB + i) + bw * kv;
-                const T aa = (first || !rk4) ? bw * ka : S.getb(R::ACCAB + i) + bw * ka;
-                if (st == 3) { incb[i] = av; vb[i] = v0 + aa; }
-                else
-                {
-                    S.putb(R::ACCVB + i, av); S.putb(R::ACCAB + i, aa);
-                    incb[i] = aw * kv; vb[i] = v0 + aw * ka; S.putb(R::KVB + i, vb[i]);
-                }
+                v0b[i] = S.getb(R::V0B + i);
+                const T kv = S.getb(R::KVB + i);
+                incb[i] = S.getb(R::ACCVB + i) + bw * kv;   // sum b_i kv_i so far
+                vb[i] = S.getb(R::ACCAB + i) + bw * ddqb[i];  // sum b_i ka_i so far
             });
+            static_for<0, N>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                v0l[s] = S.getl(R::V0L + s);
+                const T kv = S.getl(R::KVL + s);
+                incl[s] = S.getl(R::ACCVL + s) + bw * kv;
+                vl[s] = S.getl(R::ACCAL + s) + bw * ddq[s];
+                ql[s] = S.getl(R::Q0L + s);
+            });
+            if (st != 3)
+            {
+                // intermediate stage: store the accumulators, state = x0 (+) A(i, i-1) dt k_{i-1}
+                static_for<0, NVB>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    S.putb(R::ACCVB + i, incb[i]); S.putb(R::ACCAB + i, vb[i]);
+                    incb[i] = aw * S.getb(R::KVB + i);
+                    vb[i] = v0b[i] + aw * ddqb[i];
+                    S.putb(R::KVB + i, vb[i]);
+                });
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    S.putl(R::ACCVL + s, incl[s]); S.putl(R::ACCAL + s, vl[s]);
+                    incl[s] = aw * S.getl(R::KVL + s);
+                    vl[s] = v0l[s] + aw * ddq[s];
+                    S.putl(R::KVL + s, vl[s]);
+                });
+            }
+            else
+            {
+                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = v0b[decltype(ic)::value] + vb[decltype(ic)::value]; });
+                static_for<0, N>([&](auto sc) { vl[decltype(sc)::value] = v0l[decltype(sc)::value] + vl[decltype(sc)::value]; });
+            }
             integrate_freeflyer<T>(q0b, incb, qb);
             static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                const T q0 = S.getl(R::Q0L + s), v0 = S.getl(R::V0L + s);
-                const T kv = first ? v0 : S.getl(R::KVL + s);
-                const T ka = first ? S.getl(R::A0L + s) : ddq[s];
-                const T av = (first || !rk4) ? bw * kv : S.getl(R::ACCVL + s) + bw * kv;
-                const T aa = (first || !rk4) ? bw * ka : S.getl(R::ACCAL + s) + bw * ka;
-                if (st == 3) { ql[s] = q0 + av; vl[s] = v0 + aa; }
-                else
-                {
-                    S.putl(R::ACCVL + s, av); S.putl(R::ACCAL + s, aa);
-                    ql[s] = q0 + aw * kv; vl[s] = v0 + aw * ka; S.putl(R::KVL + s, vl[s]);
-                }
+                ql[s] = ql[s] + incl[s];
                 if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
             });
             if (st == 3)
             {
-                // commit: the new state becomes the start of the next sub-step
+                // commit: the new state becomes the start of the next step (invariant restored)
                 static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
-                static_for<0, NVB>([&](auto ic) { S.putb(R::V0B + decltype(ic)::value, vb[decltype(ic)::value]); });
-                static_for<0, N>([&](auto sc) { S.putl(R::Q0L + decltype(sc)::value, ql[decltype(sc)::value]); S.putl(R::V0L + decltype(sc)::value, vl[decltype(sc)::value]); });
+                static_for<0, NVB>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    S.putb(R::V0B + i, vb[i]); S.putb(R::KVB + i, vb[i]); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
+                });
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    S.putl(R::Q0L + s, ql[s]); S.putl(R::V0L + s, vl[s]); S.putl(R::KVL + s, vl[s]);
+                    S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
+                });
                 if (last)
                 {
                     if (lead)
                     {
-                        static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + r32] = qb[decltype(ic)::value]; });
-                        static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + r32] = vb[decltype(ic)::value]; });
+                        static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + rr] = qb[decltype(ic)::value]; });
+                        static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = vb[decltype(ic)::value]; });
                     }
                     static_for<0, N>([&](auto sc) {
                         constexpr int s = decltype(sc)::value;
                         if (ix.has[s])
                         {
-                            A.q[(unsigned)ix.rq[s] * B32 + r32] = ql[s];
-                            A.v[(unsigned)ix.rv[s] * B32 + r32] = vl[s];
+                            A.q[(unsigned)ix.rq[s] * B32 + rr] = ql[s];
+                            A.v[(unsigned)ix.rv[s] * B32 + rr] = vl[s];
                         }
                     });
                 }
             }
         }
-        quad_eval<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, cmdb, cmdl, last, A.update_sensors != 0, ddqb, ddq, status);
-        if (st == -1 || st == 3)
-        {
-            static_for<0, NVB>([&](auto ic) { S.putb(R::A0B + decltype(ic)::value, ddqb[decltype(ic)::value]); });
-            static_for<0, N>([&](auto sc) { S.putl(R::A0L + decltype(sc)::value, ix.has[decltype(sc)::value] ? ddq[decltype(sc)::value] : T(0)); });
-        }
+        if (last && A.mode != MODE_DYNAMICS)
+            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, qb, vb, ql, vl, cmdb, cmdl, !stepping || A.update_sensors != 0, ddqb, ddq, status);
+        else
+            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
         if (last)
         {
-            store_a(A.a);
-            store_status();
-            if (A.joint_forces || A.centroidal)
+            T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
+            if (lead) static_for<0, NVB>([&](auto ic) { adst[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = ddqb[decltype(ic)::value]; });
+            static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) adst[(unsigned)ix.rv[decltype(sc)::value] * B32 + rr] = ddq[decltype(sc)::value]; });
+            if (A.mode != MODE_DYNAMICS)
             {
-                // the committed state sits in the stage buffer
-                JM_REFRESH();
-                static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
-                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
-                static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-                quad_extra_terms<T, Tp, X>(P, LT, A, r32, k, ix, qb, vb, ql, vl, ddqb, ddq);
+                const int stq = X::quad_or(status);
+                if (A.status && lead) A.status[rr] = stq;
+                if (A.joint_forces || A.centroidal)
+                {
+                    // the (committed) state sits in the stage buffer
+                    JM_REFRESH();
+                    static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+                    static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
+                    static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
+                    quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
+                }
             }
         }
     }

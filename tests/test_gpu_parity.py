@@ -202,7 +202,9 @@ def test_compute_robots_dynamics_and_reset_lanes(gpu_device):
     eng.start(q, v)
     a0 = eng.field("a").clone()
     a = eng.compute_robots_dynamics(0.0, q, v)
-    assert torch.equal(a, a0)
+    # the output-free copy of the evaluation is compiled separately (other FMA contractions):
+    # agreement at round-off; repeatability of one entry point is bitwise (reset below)
+    assert rel_err(a.cpu().numpy(), a0.cpu().numpy()) < 1e-12
     for _ in range(5):
         eng.step(1e-3)
     mask = torch.zeros(B, dtype=torch.bool)

@@ -21,7 +21,7 @@ fi
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"; tail -c 600 "$OUT/bench.json"
 
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 60 --warmup 5 --no-cpu-baseline ${BENCH_EXTRA:-}"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -32,6 +32,8 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LD
   echo "pmc $N rc=$?"
 done
 cd "$REPO"
-# keep the merge-back small: drop the per-launch traces of the PMC passes except the counter csv
-find "$OUT" -name '*agent_info.csv' -delete
+# summarise on the box (the rocpd databases are too large to merge back), keep only the summaries
+python tools/summarise_profiles.py "$OUT" "$TAG" "$OUT/summary" > "$OUT/summary.log" 2>&1
+tail -40 "$OUT/summary.log"
+find "$OUT" -name '*.db' -delete
 du -sh "$OUT"

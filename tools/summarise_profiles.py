@@ -46,7 +46,9 @@ def step_launch_filter(db, kernel_like):
 
 def main():
     src, name = sys.argv[1], sys.argv[2]
-    out_dir = os.path.join(ROOT, "profiles")
+    # optional third argument: output directory (the GPU box summarises in place, the rocpd
+    # databases themselves are too large to travel back)
+    out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     stats_db = glob.glob(os.path.join(src, "stats", "*.db"))[0]
     rows, regs = kernel_rows(stats_db)
@@ -63,7 +65,7 @@ def main():
     keep = step_launch_filter(db, like)
     durs = [d for i, d in db.execute("select dispatch_id, duration from kernels where name like ?", (like,))
             if i in keep]
-    summary = {"source": os.path.relpath(src, ROOT), "dominant_kernel": dominant,
+    summary = {"source": os.path.relpath(os.path.abspath(src), ROOT), "dominant_kernel": dominant,
                "step_launches": len(durs), "avg_step_launch_ns": statistics.mean(durs),
                "median_step_launch_ns": statistics.median(durs), "counters_per_launch_median": {}}
     for p in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
