@@ -233,7 +233,7 @@ template<class T> JM_DEV void chol6_solve(T (&A)[6][6], T (&b)[6])
             s -= A[j][k] * w[k];
         }
         A[j][j] = s;
-        dinv[j] = T(1) / s;
+        dinv[j] = rcp_(s);
 #pragma unroll
         for (int i = j + 1; i < 6; ++i)
         {

@@ -316,6 +316,22 @@ JM_DEV void sincos_(float x, float * s, float * c) { *s = std::sin(x); *c = std:
 #else
 JM_DEV void sincos_(float x, float * s, float * c) { *s = ::sinf(x); *c = ::cosf(x); }
 #endif
+// reciprocal of a well-scaled positive number (joint-space inertias D, LDL^T pivots): hardware
+// estimate + two Newton steps (<= 1 ulp) instead of the 12-instruction IEEE division sequence
+// (no denormal / overflow rescaling: D is a physical inertia, never near the exponent limits)
+#ifdef JM_HOST_EMU
+JM_DEV double rcp_(double x) { return 1.0 / x; }
+JM_DEV float rcp_(float x) { return 1.0f / x; }
+#else
+JM_DEV double rcp_(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+JM_DEV float rcp_(float x) { return 1.0f / x; }
+#endif
 JM_DEV double sqrt_(double x) { return ::sqrt(x); }
 JM_DEV float sqrt_(float x) { return ::sqrtf(x); }
 JM_DEV double tanh_(double x) { return ::tanh(x); }

@@ -146,8 +146,13 @@ template<class T, int SL, int SB> struct StageBuf
 template<class Tp> struct QRows
 {
     static constexpr int N = Tp::QN, NQB = QInfo<Tp>::NQB, NVB = QInfo<Tp>::NVB;
-    static constexpr int Q0B = 0, V0B = NQB, ACCVB = V0B + NVB, ACCAB = ACCVB + NVB, KVB = ACCAB + NVB, NB = KVB + NVB;  // trunk rows
-    static constexpr int Q0L = 0, V0L = N, ACCVL = 2 * N, ACCAL = 3 * N, KVL = 4 * N, NL = 5 * N;  // limb rows
+    static constexpr int Q0B = 0, V0B = NQB, ACCVB = V0B + NVB, ACCAB = ACCVB + NVB, KVB = ACCAB + NVB;  // trunk rows
+    static constexpr int Q0L = 0, V0L = N, ACCVL = 2 * N, ACCAL = 3 * N, KVL = 4 * N;  // limb rows
+    // Long limbs (register-bound kernels): the evaluation re-reads the stage velocity (= the kv rows)
+    // and the held commands from LDS where it needs them instead of keeping them live in VGPRs.
+    static constexpr bool LONG = N > 4;
+    static constexpr int CMDL = 5 * N, NL = LONG ? 6 * N : 5 * N;
+    static constexpr int CMDB = KVB + NVB, NB = LONG ? CMDB + Tp::QT : CMDB;
 };
 
 // All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
@@ -221,15 +226,28 @@ template<class T, class Tp> struct TrunkKin
 {
     SE3<T> X[Tp::QT];
     Sp<T> v[Tp::QT];
-    Sp<T> S[Tp::QT];
 };
+// motion subspace of trunk joint t in root coordinates, re-derived from its placement (cheaper
+// than keeping 6 more scalars per joint live across the sweeps)
+template<class T, class Tp, int t> JM_DEV Sp<T> trunk_S(CPtr<T> P, const TrunkKin<T, Tp> & K)
+{
+    constexpr int j = Tp::trunk_joint[t], jt = Tp::jtype[j];
+    constexpr int ax = jt_axis(jt);
+    V3<T> a;
+    const M3<T> & R = K.X[t].R;
+    if constexpr (ax == 0) a = {R.m00, R.m10, R.m20};
+    else if constexpr (ax == 1) a = {R.m01, R.m11, R.m21};
+    else if constexpr (ax == 2) a = {R.m02, R.m12, R.m22};
+    else a = R * joint_axis<T, Tp, j>(P);
+    if constexpr (jt_is_rev(jt)) return {cross(K.X[t].p, a), a};
+    else return {a, zero3<T>()};
+}
 template<class T, class Tp>
 JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K, int & status)
 {
     using L = Layout<Tp>;
     K.X[0] = {ident3<T>(), zero3<T>()};
     K.v[0] = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
-    K.S[0] = zero6<T>();
     static_for<1, Tp::QT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t], jt = Tp::jtype[j];
@@ -253,14 +271,129 @@ JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K,
         }
         if constexpr (tp == 0) K.X[t] = li;
         else K.X[t] = K.X[tp] * li;
-        const V3<T> a = K.X[t].R * n;
-        if constexpr (jt_is_rev(jt)) K.S[t] = {cross(K.X[t].p, a), a};
-        else K.S[t] = {a, zero3<T>()};
-        K.v[t] = K.v[tp] + vj * K.S[t];
+        K.v[t] = K.v[tp] + vj * trunk_S<T, Tp, t>(P, K);
         constexpr int iq = Tp::idx_q[j];
         if (P[L::QHI + iq] < qj || qj < P[L::QLO + iq]) status |= JM_LANE_OUT_OF_BOUNDS;
     });
 }
+// ---- quad-distributed storage of per-trunk-joint data ---------------------------------------
+// The trunk tree is evaluated identically by the 4 lanes of a quad; keeping its per-joint data
+// (placement, velocity, U, 1/D, u) in every lane would cost 4x the registers for nothing.  Joint t
+// is therefore KEPT by lane (t-1) & 3 only (slot (t-1) >> 2) and broadcast over the quad with a
+// DPP quad_perm when a sweep needs it: 2 v_mov_dpp per scalar instead of a live register pair
+// in all four lanes across the limb sweeps.
+template<class T, class X, int LANE> JM_DEV V3<T> qbcast(V3<T> a) { return {X::template bcast<LANE>(a.x), X::template bcast<LANE>(a.y), X::template bcast<LANE>(a.z)}; }
+template<class T, class X, int LANE> JM_DEV Sp<T> qbcast(Sp<T> a) { return {qbcast<T, X, LANE>(a.l), qbcast<T, X, LANE>(a.a)}; }
+template<class T, class X, int LANE> JM_DEV M3<T> qbcast(const M3<T> & a)
+{
+    return {X::template bcast<LANE>(a.m00), X::template bcast<LANE>(a.m01), X::template bcast<LANE>(a.m02),
+            X::template bcast<LANE>(a.m10), X::template bcast<LANE>(a.m11), X::template bcast<LANE>(a.m12),
+            X::template bcast<LANE>(a.m20), X::template bcast<LANE>(a.m21), X::template bcast<LANE>(a.m22)};
+}
+template<class T, class Tp> struct TrunkStore
+{
+    static constexpr int SLOTS = (Tp::QT + 2) / 4 > 0 ? (Tp::QT + 2) / 4 : 1;  // ceil((QT-1)/4)
+    SE3<T> X[SLOTS];
+    Sp<T> v[SLOTS];
+    Sp<T> U[SLOTS];
+    T dinv[SLOTS], u[SLOTS];
+    template<int t> static constexpr int lane() { return (t - 1) & 3; }
+    template<int t> static constexpr int slot() { return (t - 1) >> 2; }
+    template<int t> JM_DEV void put_kin(int k, const SE3<T> & Xt, Sp<T> vt)
+    {
+        if (k == lane<t>()) { X[slot<t>()] = Xt; v[slot<t>()] = vt; }
+    }
+    template<int t> JM_DEV void put_aba(int k, Sp<T> Ut, T di, T uj)
+    {
+        if (k == lane<t>()) { U[slot<t>()] = Ut; dinv[slot<t>()] = di; u[slot<t>()] = uj; }
+    }
+    template<int t, class Xq> JM_DEV void get_kin(SE3<T> & Xt, Sp<T> & vt) const
+    {
+        Xt = {qbcast<T, Xq, lane<t>()>(X[slot<t>()].R), qbcast<T, Xq, lane<t>()>(X[slot<t>()].p)};
+        vt = qbcast<T, Xq, lane<t>()>(v[slot<t>()]);
+    }
+    template<int t, class Xq> JM_DEV void get_aba(Sp<T> & Ut, T & di, T & uj) const
+    {
+        Ut = qbcast<T, Xq, lane<t>()>(U[slot<t>()]);
+        di = Xq::template bcast<lane<t>()>(dinv[slot<t>()]);
+        uj = Xq::template bcast<lane<t>()>(u[slot<t>()]);
+    }
+};
+// motion subspace of a trunk joint placed at X (root coordinates)
+template<class T, class Tp, int t> JM_DEV Sp<T> trunk_S_at(CPtr<T> P, const SE3<T> & Xt)
+{
+    constexpr int j = Tp::trunk_joint[t], jt = Tp::jtype[j];
+    constexpr int ax = jt_axis(jt);
+    V3<T> a;
+    const M3<T> & R = Xt.R;
+    if constexpr (ax == 0) a = {R.m00, R.m10, R.m20};
+    else if constexpr (ax == 1) a = {R.m01, R.m11, R.m21};
+    else if constexpr (ax == 2) a = {R.m02, R.m12, R.m22};
+    else a = R * joint_axis<T, Tp, j>(P);
+    if constexpr (jt_is_rev(jt)) return {cross(Xt.p, a), a};
+    else return {a, zero3<T>()};
+}
+// placement of trunk joint t relative to its parent joint: jointPlacement * M_j(q)
+template<class T, class Tp, int t> JM_DEV SE3<T> trunk_liMi(CPtr<T> P, T qj)
+{
+    using L = Layout<Tp>;
+    constexpr int j = Tp::trunk_joint[t], jt = Tp::jtype[j];
+    const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+    const V3<T> n = joint_axis<T, Tp, j>(P);
+    SE3<T> li;
+    if constexpr (jt_is_rev(jt))
+    {
+        T c, sn;
+        sincos_(qj, &sn, &c);
+        constexpr int ax = jt_axis(jt);
+        if constexpr (ax >= 0) li.R = plc.R * rot_axis<T>(ax, c, sn);
+        else li.R = plc.R * rot_rodrigues(n, c, sn);
+        li.p = plc.p;
+    }
+    else
+    {
+        li.R = plc.R;
+        li.p = plc.p + plc.R * (qj * n);
+    }
+    return li;
+}
+// Forward kinematics of the trunk tree into the distributed store; also hands every lane the
+// placement / velocity of the trunk joint its limb hangs from (picked up where it is computed).
+template<class T, class Tp, class Xq>
+JM_DEV void trunk_fk_store(CPtr<T> P, int k, const QIdx<Tp> & ix, const T * qb, const T * vb, TrunkStore<T, Tp> & TS,
+                           SE3<T> & Xatt, Sp<T> & vatt, int & status)
+{
+    using L = Layout<Tp>;
+    const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
+    Xatt = {ident3<T>(), zero3<T>()};
+    vatt = v1;
+    SE3<T> Xprev = Xatt;
+    Sp<T> vprev = v1;
+    static_for<1, Tp::QT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
+        const T qj = qb[6 + t], vj = vb[5 + t];
+        const SE3<T> li = trunk_liMi<T, Tp, t>(P, qj);
+        SE3<T> Xt;
+        Sp<T> vpar;
+        if constexpr (tp == 0) { Xt = li; vpar = v1; }
+        else
+        {
+            SE3<T> Xp;
+            if constexpr (tp == t - 1) { Xp = Xprev; vpar = vprev; }
+            else TS.template get_kin<tp, Xq>(Xp, vpar);
+            Xt = Xp * li;
+        }
+        const Sp<T> vt = vpar + vj * trunk_S_at<T, Tp, t>(P, Xt);
+        TS.template put_kin<t>(k, Xt, vt);
+        if constexpr (QInfo<Tp>::limb_at(t))
+            if (ix.attach == t) { Xatt = Xt; vatt = vt; }
+        Xprev = Xt; vprev = vt;
+        constexpr int iq = Tp::idx_q[j];
+        if (P[L::QHI + iq] < qj || qj < P[L::QLO + iq]) status |= JM_LANE_OUT_OF_BOUNDS;
+    });
+}
+
 // per-lane pick of the trunk joint this lane's limb hangs from
 template<class T, class Tp, class V> JM_DEV V pick_attach(int k, const V * arr)
 {
@@ -272,10 +405,12 @@ template<class T, class Tp, class V> JM_DEV V pick_attach(int k, const V * arr)
     });
     return r;
 }
-// limb kinematics in root coordinates
+// limb kinematics in root coordinates. Only the placements are kept per joint; the velocities are
+// unwound from the tip in the backward sweep (v_{s-1} = v_s - S_s qd_s) and re-accumulated in the
+// forward sweep, which is cheaper than 6 more live scalars per joint.
 template<class T, class Tp>
 JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> & Xp, Sp<T> vp, const T * ql, const T * vl,
-                    M3<T> * Rs, V3<T> * ps, Sp<T> * vs, int & status)
+                    M3<T> * Rs, V3<T> * ps, Sp<T> & vtip, int & status)
 {
     using Q = QLayout<Tp>;
     M3<T> Rp = Xp.R;
@@ -290,10 +425,11 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
         const V3<T> a = Rp * LT.v3(o + Q::J_AXP);  // joint axis in root coordinates
         ps[s] = pp + Rp * plc.p;
         Rs[s] = Rp * (plc.R * rot_rodrigues(n, c, sn));
-        vs[s] = {vp.l + vl[s] * cross(ps[s], a), vp.a + vl[s] * a};
+        vp = {vp.l + vl[s] * cross(ps[s], a), vp.a + vl[s] * a};
         if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
-        Rp = Rs[s]; pp = ps[s]; vp = vs[s];
+        Rp = Rs[s]; pp = ps[s];
     });
+    vtip = vp;
     (void)ix;
 }
 
@@ -304,11 +440,17 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
 // derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
 // if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
 // has to stay in registers for a separate output phase.
-template<class T, class Tp, class X, bool EMIT>
+template<class T, class Tp, class X, bool EMIT, class SB>
 JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
-                      const T * qb, const T * vb, const T * ql, const T * vl, const T * cmdb, const T * cmdl,
+                      const SB & S_, const T * qb, const T * vb_, const T * ql, const T * vl_, const T * cmdb_, const T * cmdl_,
                       bool sensors, T * ddqb, T * ddq, int & status)
 {
+    // velocities / commands: registers for short limbs, re-read from the stage buffer for long ones
+    using RW = QRows<Tp>;
+    auto vlq = [&](int s) -> T { if constexpr (RW::LONG) return S_.getl(RW::KVL + s); else return vl_[s]; };
+    auto vbq = [&](int i) -> T { if constexpr (RW::LONG) return S_.getb(RW::KVB + i); else return vb_[i]; };
+    auto cmdlq = [&](int s) -> T { if constexpr (RW::LONG) return S_.getl(RW::CMDL + s); else return cmdl_[s]; };
+    auto cmdbq = [&](int t) -> T { if constexpr (RW::LONG) return S_.getb(RW::CMDB + t); else return cmdb_[t]; };
     // compile-time: the three non-emitting evaluations of an RK4 step carry no output code at all,
     // which keeps their basic blocks large (LDS reads of the limb table get batched ahead of use)
     constexpr bool emit = EMIT;
@@ -330,7 +472,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 const int si = sel4(k, Tp::limb_enc[0][s], Tp::limb_enc[1][s], Tp::limb_enc[2][s], Tp::limb_enc[3][s]);
-                T pos = ql[s], vel = vl[s];
+                T pos = ql[s], vel = vlq(s);
                 if constexpr (Tp::QENC_SIDE == 0)
                 {
                     const T red = LT(s * Q::QJ + Q::J_ENC);
@@ -347,7 +489,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 static_for<1, NT>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
                     constexpr int si = Tp::trunk_enc[t];
-                    T pos = qb[6 + t], vel = vb[5 + t];
+                    T pos = qb[6 + t], vel = vbq(5 + t);
                     if constexpr (Tp::QENC_SIDE == 0) { pos *= P[L::ENC + si]; vel *= P[L::ENC + si]; }
                     A.encoder[(unsigned)(2 * si) * B32 + r32] = pos;
                     A.encoder[(unsigned)(2 * si + 1) * B32 + r32] = vel;
@@ -357,19 +499,25 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
     const V3<T> p1 = {qb[0], qb[1], qb[2]};
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
-    TrunkKin<T, Tp> K;
-    trunk_fk<T, Tp>(P, qb, vb, K, status);
+    const Sp<T> v1 = {{vb_[0], vb_[1], vb_[2]}, {vb_[3], vb_[4], vb_[5]}};
+    TrunkStore<T, Tp> TS;
+#ifdef JM_HOST_EMU
+    std::memset(&TS, 0xFF, sizeof(TS));
+#endif
+    SE3<T> Xatt;
+    Sp<T> vatt;
+    trunk_fk_store<T, Tp, X>(P, k, ix, qb, vb_, TS, Xatt, vatt, status);
     // ---- limb kinematics
     M3<T> Rs[N];
     V3<T> ps[N];
-    Sp<T> vs[N];
-    limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vs, status);
+    Sp<T> vtip;
+    limb_fk<T, Tp>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status);
     // ---- contact points on the limb tip (engine.cc:3117-3238, 3394-3425)
     Sp<T> fext = zero6<T>();   // total external force on the tip body, root coordinates
     {
         const M3<T> Rt = Rs[N - 1];
         const V3<T> pt = ps[N - 1];
-        const Sp<T> vt = vs[N - 1];
+        const Sp<T> vt = vtip;
         Sp<T> fext_loc = zero6<T>(), fsens = zero6<T>();
         T fmax2 = T(0);
         auto one_contact = [&](int c) {
@@ -448,7 +596,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         constexpr int s = decltype(sc)::value;
         constexpr int o = s * Q::QJ + Q::J_MOTOR;
         T um, ue;
-        motor_law<T, FL>([&](int i) { return LT(o + i); }, cmdl[s], vl[s], um, ue);
+        motor_law<T, FL>([&](int i) { return LT(o + i); }, cmdlq(s), vlq(s), um, ue);
         u[s] = ue;
         if (emit && ix.has[s])
         {
@@ -468,7 +616,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         constexpr int m = Tp::trunk_motor[t];
         constexpr int o = L::MOTOR + JM_MOTOR_NPARAMS * m;
         T um, ue;
-        motor_law<T, FL>([&](int i) { return P[o + i]; }, cmdb[t], vb[5 + t], um, ue);
+        motor_law<T, FL>([&](int i) { return P[o + i]; }, cmdbq(t), vbq(5 + t), um, ue);
         ut[t] = ue;
         if (emit && lead)
         {
@@ -485,39 +633,52 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     }
     // ---- ABA pass 2 along the limb, tip -> trunk (AbaBackwardStep), root coordinates
     JM_REFRESH();
-    Sp<T> Ss[N], cs[N], Us[N];
+    // Forward-sweep inputs per joint: long limbs keep only the joint axis (with ps: 6 scalars) and
+    // re-derive S, the parent velocity and the bias acceleration on the way down; short limbs have
+    // registers to spare and keep S and c (12 scalars) instead of ~30 extra VALU per joint.
+    constexpr bool KEEP_SC = N <= 4;
+    V3<T> as[N];
+    Sp<T> Ss[KEEP_SC ? N : 1], cs[KEEP_SC ? N : 1];
+    Sp<T> Us[N];
     T dinv[N];
     AI<T> Ia;
     Sp<T> pa = zero6<T>();
     T kin = T(0), rot = T(0), msum = T(0);
     V3<T> mc = zero3<T>();
-    static_rfor<0, N>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int o = s * Q::QJ;
-        const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(o + Q::J_RBI));
-        const V3<T> a = Rs[s] * LT.v3(o + Q::J_AXIS);
-        const Sp<T> S = {cross(ps[s], a), a};
-        Sp<T> f = cross_mf(vs[s], rbi_mul(Y, vs[s]));  // bias force v x* (I v)
-        if constexpr (s == N - 1) { f = f - fext; Ia = ai_from_rbi(Y); }
-        else { f = f + pa; Ia = ai_from_rbi(Y) + Ia; }
-        const Sp<T> c = cross_mm(vs[s], vl[s] * S);    // bias acceleration v x S qd
-        const T uj = u[s] - dot6(S, f);
-        const Sp<T> U = ai_mul(Ia, S);
-        const T D = dot6(S, U) + LT(o + Q::J_ROTOR);
-        const T di = T(1) / D;
-        ai_rank1_sub(Ia, U, di);
-        const Sp<T> Ya = ai_mul(Ia, c);
-        const T ud = uj * di;
-        pa = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
-        Ss[s] = S; cs[s] = c; Us[s] = U; dinv[s] = di; u[s] = uj;
-        if (want_energy)
-        {
-            kin += rbi_vtiv(Y, vs[s]);
-            mc = mc + Y.m * Y.c;
-            msum += Y.m;
-            rot += LT(o + Q::J_ROTOR) * vl[s] * vl[s];
-        }
-    });
+    {
+        Sp<T> vcur = vtip;
+        static_rfor<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int o = s * Q::QJ;
+            const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(o + Q::J_RBI));
+            const V3<T> a = Rs[s] * LT.v3(o + Q::J_AXIS);
+            const Sp<T> S = {cross(ps[s], a), a};
+            Sp<T> f = cross_mf(vcur, rbi_mul(Y, vcur));  // bias force v x* (I v)
+            if constexpr (s == N - 1) { f = f - fext; Ia = ai_from_rbi(Y); }
+            else { f = f + pa; Ia = ai_from_rbi(Y) + Ia; }
+            if (want_energy)
+            {
+                kin += rbi_vtiv(Y, vcur);
+                mc = mc + Y.m * Y.c;
+                msum += Y.m;
+                rot += LT(o + Q::J_ROTOR) * vlq(s) * vlq(s);
+            }
+            const Sp<T> vj = vlq(s) * S;
+            vcur = vcur - vj;                              // velocity of the parent joint
+            const Sp<T> c = cross_mm(vcur, vj);            // bias acceleration v x S qd (S x S = 0)
+            const T uj = u[s] - dot6(S, f);
+            const Sp<T> U = ai_mul(Ia, S);
+            const T D = dot6(S, U) + LT(o + Q::J_ROTOR);
+            const T di = rcp_(D);
+            ai_rank1_sub(Ia, U, di);
+            const Sp<T> Ya = ai_mul(Ia, c);
+            const T ud = uj * di;
+            pa = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
+            Us[s] = U; dinv[s] = di; u[s] = uj;
+            if constexpr (KEEP_SC) { Ss[s] = S; cs[s] = c; }
+            else as[s] = a;
+        });
+    }
     // ---- child -> parent reduction over the 4 limbs (the only cross-lane step of the dynamics)
     AI<T> accA[NT];
     Sp<T> accF[NT];
@@ -542,41 +703,43 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         kin = X::quad_sum(kin); rot = X::quad_sum(rot); msum = X::quad_sum(msum);
         mc = {X::quad_sum(mc.x), X::quad_sum(mc.y), X::quad_sum(mc.z)};
     }
-    // ---- trunk tree, leaves -> root (identical in the 4 lanes)
-    Sp<T> ct[NT], Ut[NT];
-    T dinvt[NT];
+    // ---- trunk tree, leaves -> root (identical in the 4 lanes; per-joint data fetched from / kept
+    // in the quad-distributed store)
     static_rfor<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
-        const RBI<T> Y = rbi_placed(K.X[t].R, K.X[t].p, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
-        const Sp<T> S = K.S[t];
-        Sp<T> f = cross_mf(K.v[t], rbi_mul(Y, K.v[t]));
+        SE3<T> Xt;
+        Sp<T> vt;
+        TS.template get_kin<t, X>(Xt, vt);
+        const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+        const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
+        Sp<T> f = cross_mf(vt, rbi_mul(Y, vt));
         AI<T> It = ai_from_rbi(Y);
         if constexpr (I::has_child(t)) { f = f + accF[t]; It = It + accA[t]; }
-        const Sp<T> c = cross_mm(K.v[t], vb[5 + t] * S);
+        const Sp<T> vj = vbq(5 + t) * S;
+        const Sp<T> c = cross_mm(vt - vj, vj);   // parent velocity x S qd
         const T uj = ut[t] - dot6(S, f);
         const Sp<T> U = ai_mul(It, S);
         const T rotor = P[L::ROTOR + Tp::idx_v[j]];
         const T D = dot6(S, U) + rotor;
-        const T di = T(1) / D;
+        const T di = rcp_(D);
         ai_rank1_sub(It, U, di);
         const Sp<T> Ya = ai_mul(It, c);
         const T ud = uj * di;
         const Sp<T> pt = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
         if constexpr (I::first_contrib(t)) { accA[tp] = It; accF[tp] = pt; }
         else { accA[tp] = accA[tp] + It; accF[tp] = accF[tp] + pt; }
-        ct[t] = c; Ut[t] = U; dinvt[t] = di; ut[t] = uj;
+        TS.template put_aba<t>(k, U, di, uj);
         if (want_energy)
         {
-            kin += rbi_vtiv(Y, K.v[t]);
+            kin += rbi_vtiv(Y, vt);
             mc = mc + Y.m * Y.c;
             msum += Y.m;
-            rot += rotor * vb[5 + t] * vb[5 + t];
+            rot += rotor * vbq(5 + t) * vbq(5 + t);
         }
     });
     // ---- root: u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf (free-flyer calc_aba + pass 3)
     const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
-    const Sp<T> v1 = K.v[0];
     const Sp<T> agf1 = actinv_motion(SE3<T>{R1, p1}, Sp<T>{-g, -gw});  // bias v x v = 0 for the free-flyer
     {
         AI<T> I1 = ai_from_rbi(Y1);
@@ -603,7 +766,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         mc = mc + Y1.m * Y1.c;
         msum += Y1.m;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) rot += P[L::ROTOR + Tp::idx_v[1] + i] * vb[i] * vb[i];
+        for (int i = 0; i < 6; ++i) rot += P[L::ROTOR + Tp::idx_v[1] + i] * vb_[i] * vb_[i];
         if (lead)
         {
             A.energy[r32] = T(0.5) * kin + T(0.5) * rot;
@@ -612,42 +775,84 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     }
     // ---- ABA pass 3, root -> leaves (AbaForwardStep2): spatial accelerations add up directly
     JM_REFRESH();
-    Sp<T> at[NT];
-    at[0] = agf1 + Sp<T>{{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
-    static_for<1, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const Sp<T> ag = at[Tp::trunk_parent[t]] + ct[t];
-        const T dd = dinvt[t] * (ut[t] - dot6(Ut[t], ag));
-        ddqb[5 + t] = dd;
-        at[t] = ag + dd * K.S[t];
-    });
-    // ---- IMUs on trunk-tree joints (basic_sensors.cc:142-164)
-    if (emit_sens && A.imu && lead)
-        static_for<0, Tp::NIMU>([&](auto ic) {
-            constexpr int s = decltype(ic)::value;
-            constexpr int t = Tp::imu_trunk[s];
-            const SE3<T> fr = ld_se3<T>(P, L::IMU + 12 * s);
-            const Sp<T> atrue = at[t] - agf1;  // data.a: spatial acceleration without the gravity field
-            Sp<T> vj, aj;
-            V3<T> gj = tmul(R1, g);
-            if constexpr (t == 0) { vj = K.v[0]; aj = atrue; }
-            else { vj = actinv_motion(K.X[t], K.v[t]); aj = actinv_motion(K.X[t], atrue); gj = tmul(K.X[t].R, gj); }
-            const Sp<T> vf = actinv_motion(fr, vj);
-            Sp<T> af = actinv_motion(fr, aj);
-            af.l = af.l + cross(vf.a, vf.l);
-            const V3<T> acc3 = af.l - tmul(fr.R, gj);
-            put6(A.imu, B32, r32, 6 * s, Sp<T>{vf.a, acc3});
-        });
+    const Sp<T> at0 = agf1 + Sp<T>{{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
+    // IMU on a trunk-tree joint (basic_sensors.cc:142-164), evaluated where the joint's
+    // acceleration is produced
+    auto imu_at = [&](auto tcst, const SE3<T> & Xt, Sp<T> vt, Sp<T> atg) {
+        constexpr int t = decltype(tcst)::value;
+        if constexpr (EMIT)
+            if (emit_sens && A.imu && lead)
+                static_for<0, Tp::NIMU>([&](auto ic) {
+                    constexpr int s = decltype(ic)::value;
+                    if constexpr (Tp::imu_trunk[s] == t)
+                    {
+                        const SE3<T> fr = ld_se3<T>(P, L::IMU + 12 * s);
+                        const Sp<T> atrue = atg - agf1;  // data.a: spatial acceleration without the gravity field
+                        Sp<T> vj, aj;
+                        V3<T> gj = tmul(R1, g);
+                        if constexpr (t == 0) { vj = vt; aj = atrue; }
+                        else { vj = actinv_motion(Xt, vt); aj = actinv_motion(Xt, atrue); gj = tmul(Xt.R, gj); }
+                        const Sp<T> vf = actinv_motion(fr, vj);
+                        Sp<T> af = actinv_motion(fr, aj);
+                        af.l = af.l + cross(vf.a, vf.l);
+                        const V3<T> acc3 = af.l - tmul(fr.R, gj);
+                        put6(A.imu, B32, r32, 6 * s, Sp<T>{vf.a, acc3});
+                    }
+                });
+    };
+    imu_at(std::integral_constant<int, 0>{}, SE3<T>{ident3<T>(), zero3<T>()}, v1, at0);
+    Sp<T> ap = at0;   // acceleration / velocity of the trunk joint this lane's limb hangs from
+    Sp<T> vp = v1;
     {
-        Sp<T> ap = pick_attach<T, Tp>(k, at);
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            const Sp<T> ag = ap + cs[s];
-            const T dd = dinv[s] * (u[s] - dot6(Us[s], ag));
-            ddq[s] = dd;
-            ap = ag + dd * Ss[s];
+        // accelerations of trunk joints with a non-adjacent, non-root parent are re-fetched from
+        // the store; chains (the common case) carry them in `aprev`
+        Sp<T> atst[TrunkStore<T, Tp>::SLOTS];
+        Sp<T> aprev = at0;
+        static_for<1, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int tp = Tp::trunk_parent[t];
+            SE3<T> Xt;
+            Sp<T> vt, Ut;
+            T di, uj;
+            TS.template get_kin<t, X>(Xt, vt);
+            TS.template get_aba<t, X>(Ut, di, uj);
+            const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
+            const Sp<T> vj = vbq(5 + t) * S;
+            Sp<T> apar;
+            if constexpr (tp == 0) apar = at0;
+            else if constexpr (tp == t - 1) apar = aprev;
+            else apar = qbcast<T, X, TrunkStore<T, Tp>::template lane<tp>()>(atst[TrunkStore<T, Tp>::template slot<tp>()]);
+            const Sp<T> ag = apar + cross_mm(vt - vj, vj);
+            const T dd = di * (uj - dot6(Ut, ag));
+            ddqb[5 + t] = dd;
+            const Sp<T> att = ag + dd * S;
+            if (k == TrunkStore<T, Tp>::template lane<t>()) atst[TrunkStore<T, Tp>::template slot<t>()] = att;
+            aprev = att;
+            if constexpr (I::limb_at(t))
+                if (ix.attach == t) { ap = att; vp = vt; }
+            imu_at(tc, Xt, vt, att);
         });
     }
+    static_for<0, N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (KEEP_SC)
+        {
+            const Sp<T> ag = ap + cs[s];
+            const T dd = ix.has[s] ? dinv[s] * (u[s] - dot6(Us[s], ag)) : T(0);
+            ddq[s] = dd;
+            ap = ag + dd * Ss[s];
+        }
+        else
+        {
+            const Sp<T> S = {cross(ps[s], as[s]), as[s]};
+            const Sp<T> vj = vlq(s) * S;
+            const Sp<T> ag = ap + cross_mm(vp, vj);
+            const T dd = ix.has[s] ? dinv[s] * (u[s] - dot6(Us[s], ag)) : T(0);  // dummy joints never move
+            ddq[s] = dd;
+            ap = ag + dd * S;
+            vp = vp + vj;
+        }
+    });
     {
         bool bad = false;
         static_for<0, I::NVB>([&](auto ic) { bad |= (ddqb[decltype(ic)::value] != ddqb[decltype(ic)::value]); });
@@ -684,12 +889,23 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     at[0] = {{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
     static_for<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        at[t] = at[Tp::trunk_parent[t]] + cross_mm(K.v[t], vb[5 + t] * K.S[t]) + ddqb[5 + t] * K.S[t];
+        const Sp<T> S = trunk_S<T, Tp, t>(P, K);
+        at[t] = at[Tp::trunk_parent[t]] + cross_mm(K.v[t], vb[5 + t] * S) + ddqb[5 + t] * S;
     });
     M3<T> Rs[N];
     V3<T> ps[N];
     Sp<T> vs[N];
-    limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vs, status);
+    {
+        Sp<T> vtip;
+        limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vtip, status);
+        Sp<T> vp = pick_attach<T, Tp>(k, K.v);
+        static_for<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const V3<T> a = Rs[s] * LT.v3(s * Q::QJ + Q::J_AXIS);
+            vs[s] = {vp.l + vl[s] * cross(ps[s], a), vp.a + vl[s] * a};
+            vp = vs[s];
+        });
+    }
     // contact forces on the tip, root coordinates
     Sp<T> fext = zero6<T>();
     {
@@ -842,6 +1058,11 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     });
     cmdb[0] = T(0);
     static_for<1, NT>([&](auto tc) { cmdb[decltype(tc)::value] = A.command[(unsigned)Tp::trunk_motor[decltype(tc)::value] * B32 + r32]; });
+    if constexpr (R::LONG)
+    {
+        static_for<0, N>([&](auto sc) { S.putl(R::CMDL + decltype(sc)::value, cmdl[decltype(sc)::value]); });
+        static_for<0, NT>([&](auto tc) { S.putb(R::CMDB + decltype(tc)::value, cmdb[decltype(tc)::value]); });
+    }
 
     // every mode runs through the same evaluation loop (two inlined copies of the dynamics: with
     // and without the output code): `start`, `reset` and `dynamics` are one evaluation at a given
@@ -900,130 +1121,144 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     // rows of q/v/a before the lead lane overwrites them at commit time; the host emulation
     // (one thread per lane) needs an explicit rendez-vous for the same guarantee.
     X::sync();
-#pragma nounroll
-    for (int e = 0; e < n_evals; ++e)
-    {
-        const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
-        const bool last = (e == n_evals - 1);
-        JM_REFRESH();
-        // per-iteration opaque copy of the lane offset: the addresses of the commit / output stores
-        // must not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
-        unsigned rr = r32;
-        JM_OPAQUE(rr);
+    // the limb table staged by k_quad is first read below: its block barrier sits here, after the
+    // state loads were issued, so that the two memory round trips of a wave's prologue overlap
+    X::table_ready();
+    // state of evaluation e: a(t+) refresh (-1), RK stages 1..3 (0..2), end of step / Euler (3)
+    auto advance = [&](int st, bool last, unsigned rr) {
         if (st == -1)
+    {
+        static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+        static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
+        static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
+    }
+    else
+    {
+        // RK4 tableau (runge_kutta4_stepper.h:12-23): b = 1/6 1/3 1/3 1/6, A(i, i-1) = 1/2 1/2 1;
+        // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
+        // previous stage; the increments are summed in the tangent space and applied once
+        // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
+        const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
+        const T aw = (st == 2) ? dt : dt * T(0.5);
+        T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
+        static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+        static_for<0, NVB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            v0b[i] = S.getb(R::V0B + i);
+            const T kv = S.getb(R::KVB + i);
+            incb[i] = S.getb(R::ACCVB + i) + bw * kv;   // sum b_i kv_i so far
+            vb[i] = S.getb(R::ACCAB + i) + bw * ddqb[i];  // sum b_i ka_i so far
+        });
+        static_for<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            v0l[s] = S.getl(R::V0L + s);
+            const T kv = S.getl(R::KVL + s);
+            incl[s] = S.getl(R::ACCVL + s) + bw * kv;
+            vl[s] = S.getl(R::ACCAL + s) + bw * ddq[s];
+            ql[s] = S.getl(R::Q0L + s);
+        });
+        if (st != 3)
         {
-            static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
-            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
-            static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-        }
-        else
-        {
-            // RK4 tableau (runge_kutta4_stepper.h:12-23): b = 1/6 1/3 1/3 1/6, A(i, i-1) = 1/2 1/2 1;
-            // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
-            // previous stage; the increments are summed in the tangent space and applied once
-            // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
-            const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
-            const T aw = (st == 2) ? dt : dt * T(0.5);
-            T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
-            static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+            // intermediate stage: store the accumulators, state = x0 (+) A(i, i-1) dt k_{i-1}
             static_for<0, NVB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                v0b[i] = S.getb(R::V0B + i);
-                const T kv = S.getb(R::KVB + i);
-                incb[i] = S.getb(R::ACCVB + i) + bw * kv;   // sum b_i kv_i so far
-                vb[i] = S.getb(R::ACCAB + i) + bw * ddqb[i];  // sum b_i ka_i so far
+                S.putb(R::ACCVB + i, incb[i]); S.putb(R::ACCAB + i, vb[i]);
+                incb[i] = aw * S.getb(R::KVB + i);
+                vb[i] = v0b[i] + aw * ddqb[i];
+                S.putb(R::KVB + i, vb[i]);
             });
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                v0l[s] = S.getl(R::V0L + s);
-                const T kv = S.getl(R::KVL + s);
-                incl[s] = S.getl(R::ACCVL + s) + bw * kv;
-                vl[s] = S.getl(R::ACCAL + s) + bw * ddq[s];
-                ql[s] = S.getl(R::Q0L + s);
+                S.putl(R::ACCVL + s, incl[s]); S.putl(R::ACCAL + s, vl[s]);
+                incl[s] = aw * S.getl(R::KVL + s);
+                vl[s] = v0l[s] + aw * ddq[s];
+                S.putl(R::KVL + s, vl[s]);
             });
-            if (st != 3)
-            {
-                // intermediate stage: store the accumulators, state = x0 (+) A(i, i-1) dt k_{i-1}
-                static_for<0, NVB>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    S.putb(R::ACCVB + i, incb[i]); S.putb(R::ACCAB + i, vb[i]);
-                    incb[i] = aw * S.getb(R::KVB + i);
-                    vb[i] = v0b[i] + aw * ddqb[i];
-                    S.putb(R::KVB + i, vb[i]);
-                });
-                static_for<0, N>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    S.putl(R::ACCVL + s, incl[s]); S.putl(R::ACCAL + s, vl[s]);
-                    incl[s] = aw * S.getl(R::KVL + s);
-                    vl[s] = v0l[s] + aw * ddq[s];
-                    S.putl(R::KVL + s, vl[s]);
-                });
-            }
-            else
-            {
-                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = v0b[decltype(ic)::value] + vb[decltype(ic)::value]; });
-                static_for<0, N>([&](auto sc) { vl[decltype(sc)::value] = v0l[decltype(sc)::value] + vl[decltype(sc)::value]; });
-            }
-            integrate_freeflyer<T>(q0b, incb, qb);
-            static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
+        }
+        else
+        {
+            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = v0b[decltype(ic)::value] + vb[decltype(ic)::value]; });
+            static_for<0, N>([&](auto sc) { vl[decltype(sc)::value] = v0l[decltype(sc)::value] + vl[decltype(sc)::value]; });
+        }
+        integrate_freeflyer<T>(q0b, incb, qb);
+        static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
+        static_for<0, N>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            ql[s] = ql[s] + incl[s];
+            if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
+        });
+        if (st == 3)
+        {
+            // commit: the new state becomes the start of the next step (invariant restored)
+            static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
+            static_for<0, NVB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                S.putb(R::V0B + i, vb[i]); S.putb(R::KVB + i, vb[i]); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
+            });
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                ql[s] = ql[s] + incl[s];
-                if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
+                S.putl(R::Q0L + s, ql[s]); S.putl(R::V0L + s, vl[s]); S.putl(R::KVL + s, vl[s]);
+                S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
             });
-            if (st == 3)
+            if (last)
             {
-                // commit: the new state becomes the start of the next step (invariant restored)
-                static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
-                static_for<0, NVB>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    S.putb(R::V0B + i, vb[i]); S.putb(R::KVB + i, vb[i]); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
-                });
-                static_for<0, N>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    S.putl(R::Q0L + s, ql[s]); S.putl(R::V0L + s, vl[s]); S.putl(R::KVL + s, vl[s]);
-                    S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
-                });
-                if (last)
+                if (lead)
                 {
-                    if (lead)
-                    {
-                        static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + rr] = qb[decltype(ic)::value]; });
-                        static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = vb[decltype(ic)::value]; });
-                    }
-                    static_for<0, N>([&](auto sc) {
-                        constexpr int s = decltype(sc)::value;
-                        if (ix.has[s])
-                        {
-                            A.q[(unsigned)ix.rq[s] * B32 + rr] = ql[s];
-                            A.v[(unsigned)ix.rv[s] * B32 + rr] = vl[s];
-                        }
-                    });
+                    static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + rr] = qb[decltype(ic)::value]; });
+                    static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = vb[decltype(ic)::value]; });
                 }
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if (ix.has[s])
+                    {
+                        A.q[(unsigned)ix.rq[s] * B32 + rr] = ql[s];
+                        A.v[(unsigned)ix.rv[s] * B32 + rr] = vl[s];
+                    }
+                });
             }
         }
-        if (last && A.mode != MODE_DYNAMICS)
-            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, qb, vb, ql, vl, cmdb, cmdl, !stepping || A.update_sensors != 0, ddqb, ddq, status);
+    }
+    };
+    // The n-1 output-free evaluations run in the hot loop; the last one (outputs, sensors, optional
+    // extra terms) is peeled off so that its register pressure does not leak into the loop.
+#pragma nounroll
+    for (int e = 0; e < n_evals - 1; ++e)
+    {
+        const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+        JM_REFRESH();
+        // per-iteration opaque copy of the lane offset: the addresses of the commit stores must
+        // not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
+        unsigned rr = r32;
+        JM_OPAQUE(rr);
+        advance(st, false, rr);
+        quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+    }
+    {
+        const int e = n_evals - 1;
+        const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+        JM_REFRESH();
+        unsigned rr = r32;
+        JM_OPAQUE(rr);
+        advance(st, true, rr);
+        if (A.mode != MODE_DYNAMICS)
+            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, !stepping || A.update_sensors != 0, ddqb, ddq, status);
         else
-            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
-        if (last)
+            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
+        if (lead) static_for<0, NVB>([&](auto ic) { adst[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = ddqb[decltype(ic)::value]; });
+        static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) adst[(unsigned)ix.rv[decltype(sc)::value] * B32 + rr] = ddq[decltype(sc)::value]; });
+        if (A.mode != MODE_DYNAMICS)
         {
-            T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
-            if (lead) static_for<0, NVB>([&](auto ic) { adst[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = ddqb[decltype(ic)::value]; });
-            static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) adst[(unsigned)ix.rv[decltype(sc)::value] * B32 + rr] = ddq[decltype(sc)::value]; });
-            if (A.mode != MODE_DYNAMICS)
+            const int stq = X::quad_or(status);
+            if (A.status && lead) A.status[rr] = stq;
+            if (A.joint_forces || A.centroidal)
             {
-                const int stq = X::quad_or(status);
-                if (A.status && lead) A.status[rr] = stq;
-                if (A.joint_forces || A.centroidal)
-                {
-                    // the (committed) state sits in the stage buffer
-                    JM_REFRESH();
-                    static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
-                    static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
-                    static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-                    quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
-                }
+                // the (committed) state sits in the stage buffer
+                JM_REFRESH();
+                static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
+                static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
+                quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
             }
         }
     }
@@ -1046,6 +1281,8 @@ struct DppQuad
         x = x + perm<0x4E>(x);  // quad_perm [2,3,0,1]
         return x;
     }
+    // value of lane LANE of the quad, in all four lanes (quad_perm [L,L,L,L])
+    template<int LANE, class T> static __device__ __forceinline__ T bcast(T x) { return perm<LANE * 0x55>(x); }
     static __device__ __forceinline__ int quad_or(int x)
     {
         x |= mov<0xB1>(x);
@@ -1053,6 +1290,7 @@ struct DppQuad
         return x;
     }
     static __device__ __forceinline__ void sync() {}  // lanes of a wave are already in lock-step
+    static __device__ __forceinline__ void table_ready() { __syncthreads(); }
 };
 
 #ifndef JM_QUAD_WAVES_PER_EU
@@ -1084,10 +1322,11 @@ k_quad(const BatchArgs<T> A)
     __shared__ T stage_l[QRows<Tp>::NL * NTH];
     __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
     for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
-    __syncthreads();
     const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
     const int k = threadIdx.x & 3;
-    if (r >= A.B) return;  // uniform over the quad
+    // early exits are whole quads; waves that still run meet at the barrier inside quad_lane_run
+    // (DppQuad::table_ready), terminated waves are not waited for
+    if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4>(A, r, k, table, S);
 }

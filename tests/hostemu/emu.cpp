@@ -44,7 +44,16 @@ struct HostQuad
         pthread_barrier_wait(&sh->bar);
         return a + b;
     }
+    template<int LANE, class T> static T bcast(T x)
+    {
+        sh->buf[k] = (double)x;
+        pthread_barrier_wait(&sh->bar);
+        const T r = (T)sh->buf[LANE];
+        pthread_barrier_wait(&sh->bar);
+        return r;
+    }
     static void sync() { pthread_barrier_wait(&sh->bar); }
+    static void table_ready() {}
     static int quad_or(int x)
     {
         sh->ibuf[k] = x;

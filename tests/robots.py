@@ -51,6 +51,16 @@ def tree_arm(has_freeflyer: bool) -> CompiledModel:
                        name="tree_arm_ff" if has_freeflyer else "tree_arm")
 
 
+def crane_walker() -> CompiledModel:
+    """Free-flyer whose tree decomposes (codegen.quad_structure) into a trunk tree with a prismatic
+    and an unaligned revolute joint, two 3-joint arms on the turret and two 2-joint legs on the
+    base: uneven (padded) limbs attached at two different trunk joints, 1 or 2 contact points per
+    limb, contact / force / IMU sensors, friction-enabled motors."""
+    return build_robot(os.path.join(DATA, "crane_walker.urdf"),
+                       os.path.join(DATA, "crane_walker_hardware.toml"),
+                       has_freeflyer=True, name="crane_walker")
+
+
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
-            tree_arm(True)]
+            tree_arm(True), crane_walker()]

@@ -58,14 +58,18 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
     assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
 
 
-@pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff"])
+@pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff",
+                                   "crane_walker"])
 def test_small_robots_cover_every_joint_type(gpu_device, robot):
-    """Lane kernel on the authored test robots: aligned / unaligned revolute and prismatic joints,
-    unbounded joints, fixed and floating base, friction motors, world-fixed contact frames."""
+    """Authored test robots: aligned / unaligned revolute and prismatic joints, unbounded joints,
+    fixed and floating base, friction motors, world-fixed contact frames (lane kernel) and, with
+    crane_walker, the branch-parallel kernel on a trunk tree with a prismatic + an unaligned joint,
+    padded limbs on two attachment joints and a ragged batch (B % 16 != 0)."""
     from tests import robots
     model = {"pendulum": robots.pendulum, "point_mass": robots.point_mass, "two_masses": robots.two_masses,
-             "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True)}[robot]()
-    B, dt = 192, 5e-4
+             "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True),
+             "crane_walker": robots.crane_walker}[robot]()
+    B, dt = (203, 2.5e-4) if robot == "crane_walker" else (192, 5e-4)
     st = sample_states(model, B, seed=21, base_height=(0.3, 0.6), grounded_fraction=0.5)
     ref = alloc_soa(model, B)
     for k in ("q", "v", "command"):

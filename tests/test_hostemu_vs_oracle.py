@@ -24,6 +24,7 @@ def _models():
         "two_masses": robots.two_masses,
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
+        "crane_walker": robots.crane_walker,
     }
 
 
@@ -71,6 +72,7 @@ QUAD_CASES = {
     # name: (states kwargs, dt)
     "anymal": (dict(base_height=(0.3, 0.6), grounded_fraction=0.6), 5e-4),
     "atlas": (dict(base_height=(0.85, 1.0), grounded_fraction=0.6), 2.5e-4),
+    "crane_walker": (dict(base_height=(0.45, 0.65), grounded_fraction=0.6), 2.5e-4),
 }
 
 
@@ -81,7 +83,7 @@ def test_quad_kernel_matches_oracle(name, solver):
     limbs) and Atlas (5-joint trunk tree, padded limbs attached at two different trunk joints,
     16 contact points per foot).  The formulation differs from the oracle's joint-local one, so
     agreement is at accumulated round-off (1e-11), not bitwise."""
-    model = load_builtin(name)
+    model = robots.crane_walker() if name == "crane_walker" else load_builtin(name)
     kw_states, dt = QUAD_CASES[name]
     B = 24 if name == "anymal" else 12
     st = sample_states(model, B, seed=4, **kw_states)
