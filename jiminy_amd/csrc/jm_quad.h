@@ -150,7 +150,11 @@ template<class Tp> struct QRows
     static constexpr int Q0L = 0, V0L = N, ACCVL = 2 * N, ACCAL = 3 * N, KVL = 4 * N;  // limb rows
     // Long limbs (register-bound kernels): the evaluation re-reads the stage velocity (= the kv rows)
     // and the held commands from LDS where it needs them instead of keeping them live in VGPRs.
+#ifdef JM_QUAD_LEAN
+    static constexpr bool LONG = true;   // tuning: register-lean variant regardless of the limb length
+#else
     static constexpr bool LONG = N > 4;
+#endif
     static constexpr int CMDL = 5 * N, NL = LONG ? 6 * N : 5 * N;
     static constexpr int CMDB = KVB + NVB, NB = LONG ? CMDB + Tp::QT : CMDB;
 };
@@ -636,7 +640,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     // Forward-sweep inputs per joint: long limbs keep only the joint axis (with ps: 6 scalars) and
     // re-derive S, the parent velocity and the bias acceleration on the way down; short limbs have
     // registers to spare and keep S and c (12 scalars) instead of ~30 extra VALU per joint.
-    constexpr bool KEEP_SC = N <= 4;
+    constexpr bool KEEP_SC = !QRows<Tp>::LONG;
     V3<T> as[N];
     Sp<T> Ss[KEEP_SC ? N : 1], cs[KEEP_SC ? N : 1];
     Sp<T> Us[N];
@@ -1127,97 +1131,97 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     // state of evaluation e: a(t+) refresh (-1), RK stages 1..3 (0..2), end of step / Euler (3)
     auto advance = [&](int st, bool last, unsigned rr) {
         if (st == -1)
-    {
-        static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
-        static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
-        static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-    }
-    else
-    {
-        // RK4 tableau (runge_kutta4_stepper.h:12-23): b = 1/6 1/3 1/3 1/6, A(i, i-1) = 1/2 1/2 1;
-        // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
-        // previous stage; the increments are summed in the tangent space and applied once
-        // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
-        const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
-        const T aw = (st == 2) ? dt : dt * T(0.5);
-        T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
-        static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
-        static_for<0, NVB>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            v0b[i] = S.getb(R::V0B + i);
-            const T kv = S.getb(R::KVB + i);
-            incb[i] = S.getb(R::ACCVB + i) + bw * kv;   // sum b_i kv_i so far
-            vb[i] = S.getb(R::ACCAB + i) + bw * ddqb[i];  // sum b_i ka_i so far
-        });
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            v0l[s] = S.getl(R::V0L + s);
-            const T kv = S.getl(R::KVL + s);
-            incl[s] = S.getl(R::ACCVL + s) + bw * kv;
-            vl[s] = S.getl(R::ACCAL + s) + bw * ddq[s];
-            ql[s] = S.getl(R::Q0L + s);
-        });
-        if (st != 3)
         {
-            // intermediate stage: store the accumulators, state = x0 (+) A(i, i-1) dt k_{i-1}
-            static_for<0, NVB>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                S.putb(R::ACCVB + i, incb[i]); S.putb(R::ACCAB + i, vb[i]);
-                incb[i] = aw * S.getb(R::KVB + i);
-                vb[i] = v0b[i] + aw * ddqb[i];
-                S.putb(R::KVB + i, vb[i]);
-            });
-            static_for<0, N>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                S.putl(R::ACCVL + s, incl[s]); S.putl(R::ACCAL + s, vl[s]);
-                incl[s] = aw * S.getl(R::KVL + s);
-                vl[s] = v0l[s] + aw * ddq[s];
-                S.putl(R::KVL + s, vl[s]);
-            });
+            static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
+            static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
         }
         else
         {
-            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = v0b[decltype(ic)::value] + vb[decltype(ic)::value]; });
-            static_for<0, N>([&](auto sc) { vl[decltype(sc)::value] = v0l[decltype(sc)::value] + vl[decltype(sc)::value]; });
-        }
-        integrate_freeflyer<T>(q0b, incb, qb);
-        static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
-        static_for<0, N>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            ql[s] = ql[s] + incl[s];
-            if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
-        });
-        if (st == 3)
-        {
-            // commit: the new state becomes the start of the next step (invariant restored)
-            static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
+            // RK4 tableau (runge_kutta4_stepper.h:12-23): b = 1/6 1/3 1/3 1/6, A(i, i-1) = 1/2 1/2 1;
+            // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
+            // previous stage; the increments are summed in the tangent space and applied once
+            // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
+            const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
+            const T aw = (st == 2) ? dt : dt * T(0.5);
+            T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
+            static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
             static_for<0, NVB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                S.putb(R::V0B + i, vb[i]); S.putb(R::KVB + i, vb[i]); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
+                v0b[i] = S.getb(R::V0B + i);
+                const T kv = S.getb(R::KVB + i);
+                incb[i] = S.getb(R::ACCVB + i) + bw * kv;   // sum b_i kv_i so far
+                vb[i] = S.getb(R::ACCAB + i) + bw * ddqb[i];  // sum b_i ka_i so far
             });
             static_for<0, N>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                S.putl(R::Q0L + s, ql[s]); S.putl(R::V0L + s, vl[s]); S.putl(R::KVL + s, vl[s]);
-                S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
+                v0l[s] = S.getl(R::V0L + s);
+                const T kv = S.getl(R::KVL + s);
+                incl[s] = S.getl(R::ACCVL + s) + bw * kv;
+                vl[s] = S.getl(R::ACCAL + s) + bw * ddq[s];
+                ql[s] = S.getl(R::Q0L + s);
             });
-            if (last)
+            if (st != 3)
             {
-                if (lead)
-                {
-                    static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + rr] = qb[decltype(ic)::value]; });
-                    static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = vb[decltype(ic)::value]; });
-                }
+                // intermediate stage: store the accumulators, state = x0 (+) A(i, i-1) dt k_{i-1}
+                static_for<0, NVB>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    S.putb(R::ACCVB + i, incb[i]); S.putb(R::ACCAB + i, vb[i]);
+                    incb[i] = aw * S.getb(R::KVB + i);
+                    vb[i] = v0b[i] + aw * ddqb[i];
+                    S.putb(R::KVB + i, vb[i]);
+                });
                 static_for<0, N>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
-                    if (ix.has[s])
-                    {
-                        A.q[(unsigned)ix.rq[s] * B32 + rr] = ql[s];
-                        A.v[(unsigned)ix.rv[s] * B32 + rr] = vl[s];
-                    }
+                    S.putl(R::ACCVL + s, incl[s]); S.putl(R::ACCAL + s, vl[s]);
+                    incl[s] = aw * S.getl(R::KVL + s);
+                    vl[s] = v0l[s] + aw * ddq[s];
+                    S.putl(R::KVL + s, vl[s]);
                 });
             }
+            else
+            {
+                static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = v0b[decltype(ic)::value] + vb[decltype(ic)::value]; });
+                static_for<0, N>([&](auto sc) { vl[decltype(sc)::value] = v0l[decltype(sc)::value] + vl[decltype(sc)::value]; });
+            }
+            integrate_freeflyer<T>(q0b, incb, qb);
+            static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
+            static_for<0, N>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                ql[s] = ql[s] + incl[s];
+                if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }  // dummy joints never move
+            });
+            if (st == 3)
+            {
+                // commit: the new state becomes the start of the next step (invariant restored)
+                static_for<0, NQB>([&](auto ic) { S.putb(R::Q0B + decltype(ic)::value, qb[decltype(ic)::value]); });
+                static_for<0, NVB>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    S.putb(R::V0B + i, vb[i]); S.putb(R::KVB + i, vb[i]); S.putb(R::ACCVB + i, T(0)); S.putb(R::ACCAB + i, T(0));
+                });
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    S.putl(R::Q0L + s, ql[s]); S.putl(R::V0L + s, vl[s]); S.putl(R::KVL + s, vl[s]);
+                    S.putl(R::ACCVL + s, T(0)); S.putl(R::ACCAL + s, T(0));
+                });
+                if (last)
+                {
+                    if (lead)
+                    {
+                        static_for<0, NQB>([&](auto ic) { A.q[(unsigned)I::qrow(decltype(ic)::value) * B32 + rr] = qb[decltype(ic)::value]; });
+                        static_for<0, NVB>([&](auto ic) { A.v[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = vb[decltype(ic)::value]; });
+                    }
+                    static_for<0, N>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        if (ix.has[s])
+                        {
+                            A.q[(unsigned)ix.rq[s] * B32 + rr] = ql[s];
+                            A.v[(unsigned)ix.rv[s] * B32 + rr] = vl[s];
+                        }
+                    });
+                }
+            }
         }
-    }
     };
     // The n-1 output-free evaluations run in the hot loop; the last one (outputs, sensors, optional
     // extra terms) is peeled off so that its register pressure does not leak into the loop.

@@ -107,6 +107,8 @@ def main():
         json.dump(summary, f, indent=1)
     latest = {k: summary.get(k) for k in ("model", "batch", "dtype", "hbm_bytes_per_launch",
                                           "hbm_bytes_per_launch_uncorrected", "dominant_kernel", "source")}
+    latest["valu_insts_per_wave"] = summary.get("SQ_INSTS_VALU_per_wave")
+    latest["waves_per_launch"] = c.get("SQ_WAVES")
     latest["from"] = f"profiles/{name}_pmc.json"
     with open(os.path.join(out_dir, "pmc_latest.json"), "w") as f:
         json.dump(latest, f, indent=1)
