@@ -212,6 +212,28 @@ int32_t jm_batch_reset_lanes(jm_batch * batch, const uint8_t * lane_mask,
 int32_t jm_batch_enable_timing(jm_batch * batch, int32_t enable);
 int32_t jm_batch_timing_summary(jm_batch * batch, int32_t * n_launches, double * total_ms);
 
+/* ---- gym_jiminy pipeline blocks, batched: one lane = one environment.
+ * Topology independent; arrays are device pointers in the dtype of the call, `[rows][B]`.
+ *
+ * jm_block_pd_controller ≙ `pd_controller` + `integrate_zoh`
+ *   (python/gym_jiminy/common/gym_jiminy/common/blocks/proportional_derivative_controller.py:23-163):
+ *   advances the command state (position, velocity, acceleration targets, `[3][M][B]`, in place) by
+ *   one controller period under its bounds and writes the clipped PD torques `[M][B]`.
+ *   `encoder` is the raw JM_F_ENCODER field (`[n_enc][2][B]`), `encoder_index[m]` the encoder of
+ *   motor m; `lower` / `upper` are `[3][M]`, `kp`, `kd`, `effort_limit` `[M]` host arrays.
+ * jm_block_mahony_filter ≙ `mahony_filter` (blocks/mahony_filter.py:28-101): `imu` is the raw
+ *   JM_F_IMU field (`[n_imu][6][B]`), `quat` `[4][n_imu][B]` (xyzw) and `bias` `[3][n_imu][B]`
+ *   are updated in place, `omega` / `cf` `[3][n_imu][B]` receive the de-biased rates. */
+#define JM_BLOCK_MAX_MOTORS 40
+int32_t jm_block_pd_controller(int32_t dtype, int64_t batch_size, int32_t nmotors, const void * encoder,
+                               const int32_t * encoder_index, void * command_state,
+                               const double * lower, const double * upper, const double * kp,
+                               const double * kd, const double * effort_limit, double control_dt,
+                               void * out_torque, void * stream);
+int32_t jm_block_mahony_filter(int32_t dtype, int64_t batch_size, int32_t n_imu, const void * imu,
+                               void * quat, void * omega, void * cf, void * bias, double kp, double ki,
+                               double dt, void * stream);
+
 /* Copy the message of the last error raised on the calling thread. */
 int32_t jm_last_error(char * buffer, size_t size);
 

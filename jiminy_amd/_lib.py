@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "jm_batch_create", "jm_batch_destroy", "jm_batch_set_options", "jm_batch_workspace_rows",
     "jm_batch_bind", "jm_batch_start", "jm_batch_stop", "jm_batch_step", "jm_batch_dynamics",
     "jm_batch_reset_lanes", "jm_batch_enable_timing", "jm_batch_timing_summary", "jm_last_error",
+    "jm_block_pd_controller", "jm_block_mahony_filter",
 )
 
 
@@ -71,6 +72,11 @@ class HipLibrary:
         L.jm_batch_enable_timing.argtypes = [vp, C.c_int32]
         L.jm_batch_timing_summary.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.jm_last_error.argtypes = [C.c_char_p, C.c_size_t]
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.jm_block_pd_controller.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, ip, vp, dp, dp, dp, dp, dp,
+                                             C.c_double, vp, vp]
+        L.jm_block_mahony_filter.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, vp, vp, vp, vp,
+                                             C.c_double, C.c_double, C.c_double, vp]
         for name in ABI_SYMBOLS:
             getattr(L, name)  # AttributeError if a declared symbol is not exported
             if name not in ("jm_topology_signature",):

@@ -4,9 +4,15 @@ Mahony attitude filter.
 
 They restate the numba kernels of the reference
 (python/gym_jiminy/common/gym_jiminy/common/blocks/proportional_derivative_controller.py:22-260,
-mahony_filter.py:28-101) as elementwise tensor programs over `[rows][B]` arrays; every lane is
-one environment.  Scalar branches of the reference become `torch.where` selections with the same
-arithmetic per lane.  They run wherever their tensors live (the HIP device in production).
+mahony_filter.py:28-101) over `[rows][B]` arrays; every lane is one environment.
+
+Two forms of the per-controller-tick blocks:
+* `HipBlocks.pd_controller` / `HipBlocks.mahony_filter`: ONE hand-written HIP kernel launch each
+  (csrc/jm_blocks.h behind `jm_block_*` of include/jiminy_hip.h) -- what the environments use;
+* `pd_controller` / `mahony_filter` / `integrate_zoh`: the same arithmetic as elementwise tensor
+  programs (scalar branches become `torch.where`), ~40 launches per block.  They run wherever their
+  tensors live and serve as the readable specification the kernels are tested against.
+`pd_adapter` runs once per environment step and stays a tensor program.
 """
 from __future__ import annotations
 
@@ -15,6 +21,62 @@ from typing import Optional, Tuple
 import torch
 
 EARTH_SURFACE_GRAVITY = 9.81
+
+
+class HipBlocks:
+    """Per-controller-tick pipeline blocks as single HIP kernel launches (`jm_block_*`).
+
+    Bound to one engine: uses its topology library, device, dtype and launch stream.  All tensors
+    are `[rows][B]`-shaped, contiguous, on the engine's device."""
+
+    def __init__(self, engine, encoder_index, command_state_lower, command_state_upper, kp, kd,
+                 motors_effort_limit) -> None:
+        import ctypes as C
+
+        import numpy as np
+        from . import _abi
+        self._C = C
+        self._eng = engine
+        self._L = engine._lib.L
+        self._check = engine._lib.check
+        self._dtype = _abi.JM_F64 if engine.dtype == torch.float64 else _abi.JM_F32
+
+        def host(x, shape):
+            a = np.ascontiguousarray(torch.as_tensor(x).detach().cpu().numpy(), dtype=np.float64)
+            if a.shape != shape:
+                raise ValueError(f"expected an array of shape {shape}, got {a.shape}")
+            return a
+        M = engine.model.nmotors
+        self._M = M
+        self._enc = np.ascontiguousarray(torch.as_tensor(encoder_index).cpu().numpy(), dtype=np.int32)
+        self._lo, self._hi = host(command_state_lower, (3, M)), host(command_state_upper, (3, M))
+        self._kp, self._kd, self._lim = host(kp, (M,)), host(kd, (M,)), host(motors_effort_limit, (M,))
+
+    def _ptr(self, t: torch.Tensor):
+        if not t.is_contiguous() or t.device != self._eng.device or t.dtype != self._eng.dtype:
+            raise ValueError("pipeline block tensors must be contiguous engine-dtype tensors on the engine's device")
+        return self._C.c_void_p(t.data_ptr())
+
+    def pd_controller(self, command_state: torch.Tensor, control_dt: float, out: torch.Tensor) -> None:
+        """≙ `pd_controller` (proportional_derivative_controller.py:101-163) on the engine's raw
+        encoder field; `command_state` `[3][M][B]` is advanced in place, `out` `[M][B]`."""
+        C = self._C
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        self._check(self._L.jm_block_pd_controller(
+            self._dtype, self._eng.batch_size, self._M, self._ptr(self._eng.field("encoder")),
+            self._enc.ctypes.data_as(ip), self._ptr(command_state), self._lo.ctypes.data_as(dp),
+            self._hi.ctypes.data_as(dp), self._kp.ctypes.data_as(dp), self._kd.ctypes.data_as(dp),
+            self._lim.ctypes.data_as(dp), float(control_dt), self._ptr(out), self._eng._stream()))
+
+    def mahony_filter(self, q: torch.Tensor, omega: torch.Tensor, cf: torch.Tensor, bias_hat: torch.Tensor,
+                      kp: float, ki: float, dt: float) -> None:
+        """≙ `mahony_filter` (mahony_filter.py:28-101) on the engine's raw IMU field; `q`
+        `[4][n_imu][B]`, the others `[3][n_imu][B]`, all updated in place."""
+        n_imu = q.shape[1]
+        self._check(self._L.jm_block_mahony_filter(
+            self._dtype, self._eng.batch_size, n_imu, self._ptr(self._eng.field("imu")), self._ptr(q),
+            self._ptr(omega), self._ptr(cf), self._ptr(bias_hat), float(kp), float(ki), float(dt),
+            self._eng._stream()))
 
 
 def integrate_zoh(state: torch.Tensor, state_min: torch.Tensor, state_max: torch.Tensor,

@@ -21,6 +21,7 @@
 
 #include "jm_kernels.h"
 #include "jm_pack.h"
+#include "jm_blocks.h"
 
 #define JM_ABI_VERSION 1
 
@@ -373,6 +374,56 @@ int32_t jm_batch_timing_summary(jm_batch * b, int32_t * n_launches, double * tot
     *n_launches = (int32_t)b->n_timed;
     *total_ms = sum;
     b->n_timed = 0;
+    return JM_OK;
+}
+
+int32_t jm_block_pd_controller(int32_t dtype, int64_t B, int32_t M, const void * encoder,
+                               const int32_t * encoder_index, void * command_state, const double * lower,
+                               const double * upper, const double * kp, const double * kd,
+                               const double * effort_limit, double control_dt, void * out_torque, void * stream)
+{
+    if (!encoder || !encoder_index || !command_state || !lower || !upper || !kp || !kd || !effort_limit || !out_torque)
+        return fail(JM_EINVAL, "jm_block_pd_controller: null argument");
+    if (B <= 0 || M <= 0 || M > JM_BLOCK_MAX_MOTORS) return fail(JM_EINVAL, "jm_block_pd_controller: bad sizes");
+    if (control_dt < 0.0) return fail(JM_EINVAL, "Integration backward in time is not supported.");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_pd_controller: bad dtype");
+    jm::PdParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M;
+    p.dt = control_dt;
+    for (int m = 0; m < M; ++m)
+    {
+        p.enc_index[m] = encoder_index[m];
+        for (int k = 0; k < 3; ++k) { p.lo[k][m] = lower[k * M + m]; p.hi[k][m] = upper[k * M + m]; }
+        p.kp[m] = kp[m]; p.kd[m] = kd[m]; p.effort_limit[m] = effort_limit[m];
+    }
+    const unsigned grid = (unsigned)((B + 255) / 256);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_pd_controller<double>), dim3(grid), dim3(256), 0, s, p, (const double *)encoder,
+                           (double *)command_state, (double *)out_torque, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_pd_controller<float>), dim3(grid), dim3(256), 0, s, p, (const float *)encoder,
+                           (float *)command_state, (float *)out_torque, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_block_mahony_filter(int32_t dtype, int64_t B, int32_t n_imu, const void * imu, void * quat, void * omega,
+                               void * cf, void * bias, double kp, double ki, double dt, void * stream)
+{
+    if (!imu || !quat || !omega || !cf || !bias) return fail(JM_EINVAL, "jm_block_mahony_filter: null argument");
+    if (B <= 0 || n_imu <= 0) return fail(JM_EINVAL, "jm_block_mahony_filter: bad sizes");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_mahony_filter: bad dtype");
+    const unsigned grid = (unsigned)((B + 255) / 256);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_mahony<double>), dim3(grid), dim3(256), 0, s, n_imu, (const double *)imu, (double *)quat,
+                           (double *)omega, (double *)cf, (double *)bias, kp, ki, dt, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_mahony<float>), dim3(grid), dim3(256), 0, s, n_imu, (const float *)imu, (float *)quat,
+                           (float *)omega, (float *)cf, (float *)bias, kp, ki, dt, (long long)B);
+    HIP_TRY(hipGetLastError());
     return JM_OK;
 }
 

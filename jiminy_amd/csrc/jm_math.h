@@ -334,6 +334,8 @@ JM_DEV float rcp_(float x) { return 1.0f / x; }
 #endif
 JM_DEV double sqrt_(double x) { return ::sqrt(x); }
 JM_DEV float sqrt_(float x) { return ::sqrtf(x); }
+JM_DEV double trunc_(double x) { return ::trunc(x); }
+JM_DEV float trunc_(float x) { return ::truncf(x); }
 JM_DEV double tanh_(double x) { return ::tanh(x); }
 JM_DEV float tanh_(float x) { return ::tanhf(x); }
 JM_DEV double atan2_(double y, double x) { return ::atan2(y, x); }

@@ -233,6 +233,13 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         self._bias = torch.zeros((3, n_imu, B), dtype=dt_, device=dev)
         self._omega = torch.zeros_like(self._bias)
         self._cf = torch.zeros_like(self._bias)
+        # per-tick blocks as single HIP launches (JIMINY_AMD_TENSOR_BLOCKS=1 selects the tensor
+        # programs of blocks.py instead: A/B measurements and debugging only)
+        import os
+        self._hip_blocks = None
+        if os.environ.get("JIMINY_AMD_TENSOR_BLOCKS", "0") != "1":
+            self._hip_blocks = blocks.HipBlocks(self.engine, self._enc_idx, lo, hi, self.kp, self.kd,
+                                                self.effort_limit)
 
     def _encoders(self) -> torch.Tensor:
         enc = self.engine.sensor_measurements["EncoderSensor"]   # (2, n_enc, B)
@@ -259,15 +266,25 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         blocks.pd_adapter(a, 1, self.command_state, self.command_state_lower, self.command_state_upper,
                           False, None, self.step_dt, self._accel)
         self.command_state[2].copy_(self._accel)
+        hb = self._hip_blocks
         for _ in range(self._n_ctrl):
-            blocks.pd_controller(self._encoders(), self.command_state, self.command_state_lower,
-                                 self.command_state_upper, self.kp, self.kd, self.effort_limit,
-                                 self.control_dt, self._torque)
-            self.engine.set_command(self._torque)
+            if hb is not None:
+                # torques go straight into the engine's command rows
+                hb.pd_controller(self.command_state, self.control_dt, self.engine.field("command"))
+                self.engine.mark_command_changed()
+            else:
+                blocks.pd_controller(self._encoders(), self.command_state, self.command_state_lower,
+                                     self.command_state_upper, self.kp, self.kd, self.effort_limit,
+                                     self.control_dt, self._torque)
+                self.engine.set_command(self._torque)
             self.engine.step(self.control_dt)
-            imu = self.engine.sensor_measurements["ImuSensor"]     # (6, n_imu, B)
-            blocks.mahony_filter(self.imu_quat, self._omega, self._cf, imu[:3], imu[3:], self._bias,
+            if hb is not None:
+                hb.mahony_filter(self.imu_quat, self._omega, self._cf, self._bias,
                                  self.mahony_kp, self.mahony_ki, self.control_dt)
+            else:
+                imu = self.engine.sensor_measurements["ImuSensor"]     # (6, n_imu, B)
+                blocks.mahony_filter(self.imu_quat, self._omega, self._cf, imu[:3], imu[3:], self._bias,
+                                     self.mahony_kp, self.mahony_ki, self.control_dt)
 
     def observation(self) -> ObsType:
         obs = super().observation()

@@ -61,3 +61,79 @@ def test_auto_reset_of_failed_lanes(gpu_device):
             assert bool((obs["states"]["agent"]["q"][m] == q_neutral).all())   # neutral state again
             assert int(env.engine.status[m].abs().sum()) == 0
     assert n_reset >= B // 2
+
+
+def test_hip_pipeline_blocks_match_the_tensor_programs(gpu_device, monkeypatch):
+    """`jm_block_pd_controller` / `jm_block_mahony_filter` (one HIP launch each) against the tensor
+    programs of jiminy_amd/blocks.py (themselves pinned to the scalar restatement of the reference's
+    numba kernels by tests/test_blocks.py): random command states that hit the position / velocity
+    / acceleration bounds, random IMU data, two IMUs, still and moving lanes."""
+    from jiminy_amd import blocks, load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    B, M = 1000, model.nmotors
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    enc = eng.field("encoder")
+    enc.copy_((rnd(*enc.shape) - 0.5) * 4.0)
+    lo = torch.stack([-1.0 - rnd(M), -5.0 - rnd(M), -50.0 - 50 * rnd(M)])
+    hi = torch.stack([1.0 + rnd(M), 5.0 + rnd(M), 50.0 + 50 * rnd(M)])
+    kp, kd, lim = 100 + 1000 * rnd(M), 0.01 + 0.1 * rnd(M), 20 + 60 * rnd(M)
+    cs = torch.stack([(rnd(M, B) - 0.5) * 2.6, (rnd(M, B) - 0.5) * 13, (rnd(M, B) - 0.5) * 250]).to(gpu_device)
+    enc_idx = torch.randperm(M, generator=g)
+    hb = blocks.HipBlocks(eng, enc_idx, lo, hi, kp, kd, lim)
+    dev = lambda x: x.to(gpu_device)  # noqa: E731
+    # One application from identical inputs per comparison (the ZOH integrator is discontinuous --
+    # trunc(), bound activations --, so round-off would be amplified by chaining two independent
+    # trajectories); the inputs of application i+1 are the tensor program's outputs of application i.
+    for dt in (5e-3, 5e-3, 5e-3, 0.0):
+        cs_ref, cs_hip = cs.clone(), cs.clone()
+        out_ref = torch.zeros(M, B, dtype=torch.float64, device=gpu_device)
+        out_hip = torch.zeros_like(out_ref)
+        encv = enc.view(M, 2, B).permute(1, 0, 2)[:, enc_idx.to(gpu_device)]
+        blocks.pd_controller(encv, cs_ref, dev(lo), dev(hi), dev(kp), dev(kd), dev(lim), dt, out_ref)
+        hb.pd_controller(cs_hip, dt, out_hip)
+        torch.cuda.synchronize()
+        assert float((cs_ref - cs_hip).abs().max()) <= 1e-14 * float(cs_ref.abs().max())
+        assert float((out_ref - out_hip).abs().max()) <= 1e-14 * float(out_ref.abs().max())
+        assert float((cs_ref - cs).abs().max()) > 0 or dt == 0.0
+        cs = cs_ref
+    # Mahony: ANYmal has one IMU; emulate the engine's raw field with two IMUs through a view
+    imu = eng.field("imu")
+    imu.copy_((rnd(*imu.shape) - 0.5) * torch.tensor([1, 1, 1, 20, 20, 20], dtype=torch.float64)[:, None])
+    imu[:, ::7] = 0.0    # still lanes: cf == 0 -> early return of the reference
+    n_imu = 1
+    quat = torch.nn.functional.normalize(rnd(4, n_imu, B) - 0.5, dim=0).to(gpu_device)
+    bias = ((rnd(3, n_imu, B) - 0.5) * 0.1).to(gpu_device)
+    bias[:, :, ::7] = 0.0
+    ref = [quat.clone(), torch.zeros_like(bias), torch.zeros_like(bias), bias.clone()]
+    hip = [quat.clone(), torch.zeros_like(bias), torch.zeros_like(bias), bias.clone()]
+    v = imu.view(n_imu, 6, B).permute(1, 0, 2)
+    for _ in range(4):
+        for a, b in zip(ref, hip):
+            b.copy_(a)
+        blocks.mahony_filter(ref[0], ref[1], ref[2], v[:3], v[3:], ref[3], 1.0, 0.1, 5e-3)
+        hb.mahony_filter(hip[0], hip[1], hip[2], hip[3], 1.0, 0.1, 5e-3)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, hip):
+            assert float((a - b).abs().max()) <= 1e-14 * max(float(a.abs().max()), 1.0)
+    assert bool((hip[0][:, :, ::7] == quat[:, :, ::7]).all())   # still lanes untouched
+
+
+def test_env_with_hip_blocks_equals_env_with_tensor_blocks(gpu_device, monkeypatch):
+    B = 128
+    g = torch.Generator(device="cpu").manual_seed(1)
+    actions = [(torch.rand(B, 12, generator=g, dtype=torch.float64) - 0.5).to(gpu_device) for _ in range(4)]
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("JIMINY_AMD_TENSOR_BLOCKS", flag)
+        env = make_anymal_env(B, dt_max=5e-4, auto_reset=False)
+        env.reset(seed=0)
+        for a in actions:
+            obs, *_ = env.step(a)
+        outs.append((obs["states"]["agent"]["q"].clone(), obs["features"]["mahony_filter"].clone(),
+                     obs["actions"]["pd_controller"].clone()))
+        env.close()
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) < 1e-6

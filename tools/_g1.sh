@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r01j
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r01j/pytest_gpu.log 2>&1; tail -5 gpurun_out/r01j/pytest_gpu.log
-timeout 300 python bench.py --no-cpu-baseline --steps 100 > gpurun_out/r01j/bench_anymal.json 2>gpurun_out/r01j/err.log; python -c "import json; d=json.loads(open('gpurun_out/r01j/bench_anymal.json').read()); print('anymal', d['value'], d['roofline']['avg_launch_ms'])"
-timeout 300 python bench.py --no-cpu-baseline --model atlas --batch 32768 --steps 60 --warmup 25 --dt 2.5e-4 > gpurun_out/r01j/bench_atlas.json 2>>gpurun_out/r01j/err.log; python -c "import json; d=json.loads(open('gpurun_out/r01j/bench_atlas.json').read()); print('atlas', d['value'], d['roofline']['avg_launch_ms'])"
+mkdir -p gpurun_out/r01p
+timeout 900 python -m pytest tests/test_gpu_env.py -m gpu -x -q > gpurun_out/r01p/pytest_env.log 2>&1; tail -15 gpurun_out/r01p/pytest_env.log
+timeout 300 python tools/bench_env.py > gpurun_out/r01p/env_hip.json 2> gpurun_out/r01p/env_hip.err; cat gpurun_out/r01p/env_hip.json
+JIMINY_AMD_TENSOR_BLOCKS=1 timeout 300 python tools/bench_env.py > gpurun_out/r01p/env_tensor.json 2> gpurun_out/r01p/env_tensor.err; cat gpurun_out/r01p/env_tensor.json

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""gym-steps/s of the device-resident ANYmal pipeline (BASELINE.json configs[4] shape on one GPU):
+PDAdapter -> PDController (5 ms) -> physics (explicit Euler, dtMax 1 ms, spring-damper ground)
+-> Mahony filter, 40 ms per environment step, random actions, B environments.
+    python tools/bench_env.py [--envs 65536] [--steps 20]
+Prints one JSON line.  JIMINY_AMD_TENSOR_BLOCKS=1 runs the per-tick blocks as tensor programs."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jiminy_amd.envs import make_anymal_env  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--solver", default="euler_explicit")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver)
+    env.reset(seed=0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    action = ((torch.rand(args.envs, 12, generator=g, dtype=torch.float64) - 0.5) * 0.5).to(dev)
+    for _ in range(args.warmup):
+        env.step(action)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_reset = 0
+    for _ in range(args.steps):
+        _, _, _, _, info = env.step(action)
+        n_reset += int(info["reset_mask"].sum()) if "reset_mask" in info else 0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "gym-steps/s ANYmal PD + Mahony pipeline", "value": args.envs * args.steps / el,
+                      "ms_per_env_step": 1e3 * el / args.steps, "envs": args.envs, "steps": args.steps,
+                      "integrator_steps_per_env_step": 40, "solver": args.solver, "lanes_reset": n_reset,
+                      "blocks": "tensor" if os.environ.get("JIMINY_AMD_TENSOR_BLOCKS") == "1" else "hip"}))
+
+
+if __name__ == "__main__":
+    main()
