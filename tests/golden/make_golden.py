@@ -4,14 +4,14 @@ These are NOT reference outputs (the reference cannot run here, see DESIGN.md se
 freeze the oracle's own outputs on seeded inputs, after it passed the known-answer pins of
 tests/test_oracle_known_answers.py, so that later edits of oracle.cpp / the model compiler cannot
 silently change the numbers every GPU parity test is compared with.
-    python tools/make_golden.py
+    python tests/golden/make_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from jiminy_amd import load_builtin  # noqa: E402

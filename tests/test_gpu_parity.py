@@ -234,3 +234,40 @@ def test_control_flow_errors(gpu_device):
     eng.stop()
     with pytest.raises(NotImplementedError):
         eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri"}})
+
+
+@pytest.mark.parametrize("name", ["anymal", "atlas"])
+@pytest.mark.parametrize("solver", ["runge_kutta_4", "euler_explicit"])
+def test_multi_substep_launches_match_oracle(gpu_device, name, solver):
+    """One launch = several integrator steps (the controller period of the environments:
+    `dtMax` < `controllerUpdatePeriod`), with and without the a(t+) refresh after a command change,
+    on a ragged batch (B % 64 != 0, B % 16 != 0)."""
+    model = load_builtin(name)
+    B = 77
+    dt = 5e-4 if name == "anymal" else 2.5e-4
+    n_sub = 5
+    st = sample_states(model, B, seed=11, base_height=(0.9, 1.1) if name == "atlas" else (0.45, 0.65))
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    eng = BatchedEngine(model, B, dtype=torch.float64, extra_outputs=EXTRA)
+    eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
+                                 "sensorsUpdatePeriod": n_sub * dt}})
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        changed = i % 2 == 0
+        if changed:
+            cmd = st["command"] * rng.uniform(0.5, 1.0)
+            ref["command"][:] = cmd
+            eng.set_command(torch.from_numpy(cmd))
+        oracle_batch(model, ref, "step", solver=solver, dt=dt, n_substeps=n_sub, command_changed=changed)
+        eng.step(n_sub * dt)
+    torch.cuda.synchronize()
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.sum() > 0.5 * B
+    for k in OUTS + ("u", "energy", "f_external"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
+    assert abs(eng.stepper_state.t - 4 * n_sub * dt) < 1e-12
