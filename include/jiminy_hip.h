@@ -72,7 +72,7 @@ enum {
 enum { JM_F64 = 0, JM_F32 = 1 };
 
 /* ---- ODE solvers (core/include/jiminy/core/engine/engine.h:30-38 `odeSolver`) */
-enum { JM_SOLVER_EULER_EXPLICIT = 0, JM_SOLVER_RUNGE_KUTTA_4 = 1 };
+enum { JM_SOLVER_EULER_EXPLICIT = 0, JM_SOLVER_RUNGE_KUTTA_4 = 1, JM_SOLVER_RUNGE_KUTTA_DOPRI = 2 };
 
 /* ---- motor flags */
 enum { JM_MOTOR_EFFORT_LIMIT = 1, JM_MOTOR_VELOCITY_LIMIT = 2, JM_MOTOR_FRICTION = 4 };
@@ -89,7 +89,9 @@ enum {
     JM_LANE_NAN = 1,            /* NaN in q/v/a (engine.cc:1737-1747, abstract_stepper.cc:41-48) */
     JM_LANE_OUT_OF_BOUNDS = 2,  /* a bounded joint left [lower, upper]: the reference would switch
                                    to its constraint solver (engine.cc:3285-3298, 3722) */
-    JM_LANE_FORCE_OVERFLOW = 4  /* initial contact force > 1e5 N (engine.cc:1338-1345) */
+    JM_LANE_FORCE_OVERFLOW = 4, /* initial contact force > 1e5 N (engine.cc:1338-1345) */
+    JM_LANE_STEPPER_FAILURE = 8 /* adaptive stepper: step size below 1e-10 s or too many successive
+                                   failed iterations (engine.cc:2340-2384 raises for the robot) */
 };
 
 /* ---- model description: plain arrays, all host memory, copied by jm_model_create.
@@ -211,6 +213,36 @@ int32_t jm_batch_reset_lanes(jm_batch * batch, const uint8_t * lane_mask,
  * and restarts the recording. */
 int32_t jm_batch_enable_timing(jm_batch * batch, int32_t enable);
 int32_t jm_batch_timing_summary(jm_batch * batch, int32_t * n_launches, double * total_ms);
+
+/* ---- adaptive stepping: `odeSolver = "runge_kutta_dopri"`, the reference's default
+ * (core/include/jiminy/core/stepper/runge_kutta_dopri_stepper.h, core/src/stepper/runge_kutta_dopri_stepper.cc,
+ *  step-size selection of core/src/engine/engine.cc:2021-2222).  Every lane carries its own step size.
+ * The caller lends (jm_batch_bind_adaptive):
+ *   workspace  [jm_batch_adaptive_workspace_rows()][B] scalars of the batch dtype (stage derivatives),
+ *   state_f64  [5][B] float64: t, dt, dtLargest, dtLargestPrev, (scratch) -- initialise t = 0 and the
+ *              three step sizes to 1e-6 (StepperState::reset, engine.h:219-236, engine.cc:1176),
+ *   state_i32  [6][B] int32: iter, iterFailed, successiveIterTooLarge, successiveIterFailed, (2 scratch) = 0.
+ * jm_batch_step_adaptive advances every lane from its `t` to the breakpoint `t_next` (the caller splits
+ * Engine::step at controller / sensor breakpoints exactly as for the fixed-step solvers), then refreshes
+ * the extra terms and, if asked, the sensors.  `new_step` != 0 on the first interval of an Engine::step
+ * call (resets the successive-failure counters, clears the status row).  Lanes whose step size falls
+ * below 1e-10 s or that fail more than `successive_iter_failed_max` times in a row get
+ * JM_LANE_STEPPER_FAILURE (the reference raises for its single robot, engine.cc:2340-2384).
+ * The call synchronises the stream once per attempt (active-lane count); `attempts_out` (optional)
+ * receives the number of attempts, `max_attempts` bounds it. */
+typedef struct jm_adaptive_options
+{
+    double tol_rel;                     /* stepper.tolRel  (1e-4) */
+    double tol_abs;                     /* stepper.tolAbs  (1e-5) */
+    double dt_max;                      /* stepper.dtMax */
+    double dt_restore_threshold_rel;    /* stepper.dtRestoreThresholdRel (0.2) */
+    int32_t successive_iter_failed_max; /* stepper.successiveIterFailedMax (1000) */
+} jm_adaptive_options;
+int32_t jm_batch_adaptive_workspace_rows(const jm_batch * batch);
+int32_t jm_batch_bind_adaptive(jm_batch * batch, void * workspace, double * state_f64, int32_t * state_i32);
+int32_t jm_batch_step_adaptive(jm_batch * batch, double t_next, const jm_adaptive_options * options,
+                               int32_t new_step, int32_t command_changed, int32_t update_sensors,
+                               int32_t max_attempts, int32_t * attempts_out, void * stream);
 
 /* ---- gym_jiminy pipeline blocks, batched: one lane = one environment.
  * Topology independent; arrays are device pointers in the dtype of the call, `[rows][B]`.

@@ -15,10 +15,10 @@ JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
 JM_ELOOKUP, JM_ENOTIMPL, JM_ETOPOLOGY = -4, -5, -6
 
 JM_F64, JM_F32 = 0, 1
-JM_SOLVER_EULER_EXPLICIT, JM_SOLVER_RUNGE_KUTTA_4 = 0, 1
+JM_SOLVER_EULER_EXPLICIT, JM_SOLVER_RUNGE_KUTTA_4, JM_SOLVER_RUNGE_KUTTA_DOPRI = 0, 1, 2
 JM_MOTOR_EFFORT_LIMIT, JM_MOTOR_VELOCITY_LIMIT, JM_MOTOR_FRICTION = 1, 2, 4
 JM_MOTOR_NPARAMS = 9
-JM_LANE_OK, JM_LANE_NAN, JM_LANE_OUT_OF_BOUNDS, JM_LANE_FORCE_OVERFLOW = 0, 1, 2, 4
+JM_LANE_OK, JM_LANE_NAN, JM_LANE_OUT_OF_BOUNDS, JM_LANE_FORCE_OVERFLOW, JM_LANE_STEPPER_FAILURE = 0, 1, 2, 4, 8
 
 (JM_F_Q, JM_F_V, JM_F_A, JM_F_COMMAND, JM_F_U_MOTOR, JM_F_U, JM_F_F_EXTERNAL,
  JM_F_CONTACT_FORCES, JM_F_IMU, JM_F_FORCE, JM_F_CONTACT, JM_F_ENCODER, JM_F_EFFORT,
@@ -65,6 +65,17 @@ class Options(C.Structure):
         ("contact_friction", C.c_double),
         ("contact_transition_eps", C.c_double),
         ("contact_transition_velocity", C.c_double),
+    ]
+
+
+class AdaptiveOptions(C.Structure):
+    """struct jm_adaptive_options (include/jiminy_hip.h)."""
+    _fields_ = [
+        ("tol_rel", C.c_double),
+        ("tol_abs", C.c_double),
+        ("dt_max", C.c_double),
+        ("dt_restore_threshold_rel", C.c_double),
+        ("successive_iter_failed_max", C.c_int32),
     ]
 
 

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict
+from typing import Dict, Optional, Tuple
 
 from . import _abi, codegen
 from .model import CompiledModel
@@ -35,7 +35,7 @@ _EXC = {
     _abi.JM_ETOPOLOGY: TopologyMismatch,
 }
 
-_LIBS: Dict[str, "HipLibrary"] = {}
+_LIBS: Dict[Tuple[str, int], "HipLibrary"] = {}
 
 # every symbol include/jiminy_hip.h declares
 ABI_SYMBOLS = (
@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "jm_batch_bind", "jm_batch_start", "jm_batch_stop", "jm_batch_step", "jm_batch_dynamics",
     "jm_batch_reset_lanes", "jm_batch_enable_timing", "jm_batch_timing_summary", "jm_last_error",
     "jm_block_pd_controller", "jm_block_mahony_filter",
+    "jm_batch_adaptive_workspace_rows", "jm_batch_bind_adaptive", "jm_batch_step_adaptive",
 )
 
 
@@ -73,6 +74,10 @@ class HipLibrary:
         L.jm_batch_timing_summary.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.jm_last_error.argtypes = [C.c_char_p, C.c_size_t]
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.jm_batch_adaptive_workspace_rows.argtypes = [vp]
+        L.jm_batch_bind_adaptive.argtypes = [vp, vp, vp, vp]
+        L.jm_batch_step_adaptive.argtypes = [vp, C.c_double, C.POINTER(_abi.AdaptiveOptions), C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int32, ip, vp]
         L.jm_block_pd_controller.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, ip, vp, dp, dp, dp, dp, dp,
                                              C.c_double, vp, vp]
         L.jm_block_mahony_filter.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, vp, vp, vp, vp,
@@ -95,21 +100,23 @@ class HipLibrary:
         raise _EXC.get(rc, JiminyError)(buf.value.decode() or f"jiminy_hip error {rc}")
 
 
-def load_for(model: CompiledModel, allow_build: bool = True) -> HipLibrary:
-    """Return the HIP library specialised for `model`'s topology, building it if needed."""
-    h = model.topology_hash()
-    lib = _LIBS.get(h)
+def load_for(model: CompiledModel, allow_build: bool = True, variant: Optional[int] = None) -> HipLibrary:
+    """Return the HIP library specialised for `model`'s topology (build variant `variant`, default:
+    the one codegen.preferred_variant names), building it if needed."""
+    v = codegen.preferred_variant(model) if variant is None else variant
+    key = (model.topology_hash(), v)
+    lib = _LIBS.get(key)
     if lib is not None:
         return lib
-    path = codegen.lib_path(model)
+    path = codegen.lib_path(model, v)
     # Build only when the prebuilt library is missing (e.g. a user-supplied URDF): staleness is
     # handled by `__graft_entry__.build()` / JIMINY_AMD_REBUILD=1, never implicitly, so that a
     # snapshot copied to another machine does not recompile because of file timestamps.
-    rebuild = os.environ.get("JIMINY_AMD_REBUILD", "0") == "1" and codegen.is_stale(model)
+    rebuild = os.environ.get("JIMINY_AMD_REBUILD", "0") == "1" and codegen.is_stale(model, v)
     if allow_build and (not os.path.exists(path) or rebuild):
-        path = codegen.build_library(model)
+        path = codegen.build_library(model, variant=v)
     lib = HipLibrary(path)
     if lib.signature() != model.topology_signature():
         raise TopologyMismatch(f"{path} was built for another topology")
-    _LIBS[h] = lib
+    _LIBS[key] = lib
     return lib

@@ -7,10 +7,11 @@ C ABI of include/jiminy_hip.h.  Built in-tree so that it travels with the reposi
 """
 from __future__ import annotations
 
+import json
 import os
 import shutil
 import subprocess
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -238,10 +239,36 @@ def _quad_lines(model: CompiledModel):
     ]
 
 
-def lib_path(model: CompiledModel) -> str:
-    # JIMINY_AMD_LIB_TAG selects an experimental build variant (tuning A/B runs only)
+# Build variants.  hipcc 7.2 mis-compiles the evaluation loop of some register-bound topologies
+# (DESIGN.md section 4.6): the engine verifies every library on first use (BatchedEngine self-test)
+# and moves on to the next variant when a build fails the check.  `build_variants.json` (tracked)
+# records the variant a topology is known to need, so that `__graft_entry__.build()` compiles it
+# ahead of time.
+BUILD_VARIANTS: Tuple[Tuple[str, ...], ...] = (
+    (),
+    ("-mllvm", "-disable-machine-licm"),
+    ("-O1",),
+)
+_VARIANT_FILE = os.path.join(CSRC, "build_variants.json")
+
+
+def preferred_variant(model: CompiledModel) -> int:
+    env = os.environ.get("JIMINY_AMD_BUILD_VARIANT")
+    if env is not None:
+        return int(env)
+    try:
+        with open(_VARIANT_FILE) as f:
+            return int(json.load(f).get(model.topology_hash(), {}).get("variant", 0))
+    except (OSError, ValueError):
+        return 0
+
+
+def lib_path(model: CompiledModel, variant: Optional[int] = None) -> str:
+    v = preferred_variant(model) if variant is None else variant
+    # JIMINY_AMD_LIB_TAG selects an experimental build (tuning A/B runs only)
     tag = os.environ.get("JIMINY_AMD_LIB_TAG", "")
-    return os.path.join(BUILD, f"libjm_{model.topology_hash()}{('_' + tag) if tag else ''}.so")
+    return os.path.join(BUILD, f"libjm_{model.topology_hash()}{('_v%d' % v) if v else ''}"
+                               f"{('_' + tag) if tag else ''}.so")
 
 
 def header_path(model: CompiledModel) -> str:
@@ -260,12 +287,12 @@ def write_header(model: CompiledModel) -> str:
 
 def _sources() -> List[str]:
     return [os.path.join(CSRC, n) for n in ("jm_lib.cpp", "jm_kernels.h", "jm_math.h", "jm_quad.h",
-                                            "jm_pack.h")] + \
+                                            "jm_pack.h", "jm_adaptive.h", "jm_blocks.h")] + \
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 
-def is_stale(model: CompiledModel) -> bool:
-    lib = lib_path(model)
+def is_stale(model: CompiledModel, variant: Optional[int] = None) -> bool:
+    lib = lib_path(model, variant)
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
@@ -274,11 +301,12 @@ def is_stale(model: CompiledModel) -> bool:
 
 
 def build_library(model: CompiledModel, force: bool = False, verbose: bool = False,
-                  extra_flags: Optional[List[str]] = None) -> str:
+                  extra_flags: Optional[List[str]] = None, variant: Optional[int] = None) -> str:
     """Compile the HIP library specialised for `model`'s topology (gfx950)."""
     hdr = write_header(model)
-    lib = lib_path(model)
-    if not force and not is_stale(model):
+    v = preferred_variant(model) if variant is None else variant
+    lib = lib_path(model, v)
+    if not force and not is_stale(model, v):
         return lib
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         raise RuntimeError(
@@ -288,6 +316,7 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
            "-x", "hip", os.path.join(CSRC, "jm_lib.cpp"),
            f"-DJM_TOPO_HEADER=\"{hdr}\"", "-o", lib + ".tmp",
            "-Wno-unused-value", "-ffp-contract=fast"]
+    cmd += list(BUILD_VARIANTS[v])
     cmd += extra_flags or []
     if verbose:
         print(" ".join(cmd))

@@ -112,7 +112,9 @@ template<class T> struct BatchArgs
     int mode, solver, n_sub, command_changed, update_sensors;
     T dt;
 };
-enum { MODE_STEP = 0, MODE_START = 1, MODE_DYNAMICS = 2, MODE_RESET = 3 };
+// MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
+// the lane status into the existing one: the closing launch of an adaptive-step interval
+enum { MODE_STEP = 0, MODE_START = 1, MODE_DYNAMICS = 2, MODE_RESET = 3, MODE_REFRESH = 4 };
 
 // ---------------------------------------------------------------- per-lane working set
 template<class T, class Tp> struct Work
@@ -736,15 +738,18 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
             return;
         }
         // Engine::start: refuse huge initial contact forces (engine.cc:1310-1346)
-        T fmax2 = T(0);
-        static_for<0, Tp::NC>([&](auto cc) {
-            const Sp<T> & f = w.cf[decltype(cc)::value];
-            fmax2 = fmax_(fmax2, dot(f.l, f.l));
-        });
-        if (fmax2 > T(1e10)) w.status |= JM_LANE_FORCE_OVERFLOW;
+        if (A.mode != MODE_REFRESH)
+        {
+            T fmax2 = T(0);
+            static_for<0, Tp::NC>([&](auto cc) {
+                const Sp<T> & f = w.cf[decltype(cc)::value];
+                fmax2 = fmax_(fmax2, dot(f.l, f.l));
+            });
+            if (fmax2 > T(1e10)) w.status |= JM_LANE_FORCE_OVERFLOW;
+        }
         static_for<0, NV>([&](auto ic) { A.a[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
-        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, w.ddq, w, true);
-        if (A.status) A.status[lane] = w.status;
+        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, w.ddq, w, A.mode != MODE_REFRESH || A.update_sensors != 0);
+        if (A.status) A.status[lane] = (A.mode == MODE_REFRESH) ? (A.status[lane] | w.status) : w.status;
         return;
     }
 

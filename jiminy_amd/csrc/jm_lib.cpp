@@ -22,6 +22,7 @@
 #include "jm_kernels.h"
 #include "jm_pack.h"
 #include "jm_blocks.h"
+#include "jm_adaptive.h"
 
 #define JM_ABI_VERSION 1
 
@@ -62,6 +63,12 @@ struct jm_batch
     void * d_params = nullptr;
     void * field[JM_F_COUNT] = {};
     bool started = false;
+    // adaptive stepper: caller-owned workspace / per-lane state, library-owned active-lane counter
+    void * ad_ws = nullptr;
+    double * ad_fs = nullptr;
+    int32_t * ad_is = nullptr;
+    int32_t * ad_count = nullptr;       // device
+    int32_t * ad_count_host = nullptr;  // pinned host
     // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs (begin, end), ring of JM_TIMING_RING launches
@@ -157,6 +164,67 @@ int32_t check_bound(const jm_batch * b, bool need_command)
 }
 }  // namespace
 
+namespace
+{
+template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_adaptive_options * o, int32_t new_step,
+                                               int32_t command_changed, int32_t update_sensors, int32_t max_attempts,
+                                               int32_t * attempts_out, void * stream)
+{
+    const hipStream_t s = (hipStream_t)stream;
+    using R = jm::AdaptiveRows<Topo>;
+    T * ws = (T *)b->ad_ws;
+    const long long B = b->B;
+    jm::AdaptiveArgs<T> D;
+    D.P = (const T *)b->d_params;
+    D.q = (T *)b->field[JM_F_Q]; D.v = (T *)b->field[JM_F_V]; D.a = (T *)b->field[JM_F_A];
+    D.ws = ws; D.fs = b->ad_fs; D.is = b->ad_is; D.status = (int32_t *)b->field[JM_F_STATUS];
+    D.n_active = b->ad_count; D.B = B;
+    D.t_next = t_next; D.tol_rel = o->tol_rel; D.tol_abs = o->tol_abs; D.dt_max = o->dt_max;
+    D.dt_restore_threshold_rel = o->dt_restore_threshold_rel; D.succ_failed_max = o->successive_iter_failed_max;
+    D.new_step = new_step; D.stage = 0;
+    if (D.status && new_step) HIP_TRY(hipMemsetAsync(D.status, 0, sizeof(int32_t) * B, s));
+    // FSAL fix when the command changed at the breakpoint: a(t+) (engine.cc:2030-2042)
+    if (command_changed)
+    {
+        auto A = make_args<T>(b);
+        A.mode = jm::MODE_DYNAMICS; A.q_in = D.q; A.v_in = D.v; A.a_out = D.a;
+        const int32_t rc = launch<T>(b, A, stream);
+        if (rc != JM_OK) return rc;
+    }
+    const unsigned g256 = (unsigned)((B + 255) / 256), g128 = (unsigned)((B + 127) / 128);
+    int attempts = 0;
+    for (;; ++attempts)
+    {
+        HIP_TRY(hipMemsetAsync(b->ad_count, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL((jm::k_dopri_prepare<T, Topo>), dim3(g256), dim3(256), 0, s, D);
+        D.new_step = 0;
+        HIP_TRY(hipMemcpyAsync(b->ad_count_host, b->ad_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (*b->ad_count_host == 0) break;
+        if (attempts >= max_attempts) return fail(JM_ERUNTIME, "adaptive stepper: too many attempts for one breakpoint interval");
+        for (int i = 1; i <= 6; ++i)
+        {
+            D.stage = i;
+            hipLaunchKernelGGL((jm::k_dopri_stage<T, Topo>), dim3(g128), dim3(128), 0, s, D);
+            auto A = make_args<T>(b);
+            A.mode = jm::MODE_DYNAMICS;
+            A.q_in = ws + (long long)R::QS * B;
+            A.v_in = ws + (long long)(R::KV + (i - 1) * Topo::NV) * B;
+            A.a_out = ws + (long long)(R::KA + (i - 1) * Topo::NV) * B;
+            const int32_t rc = launch<T>(b, A, stream);
+            if (rc != JM_OK) return rc;
+        }
+        hipLaunchKernelGGL((jm::k_dopri_finish<T, Topo>), dim3(g128), dim3(128), 0, s, D);
+        HIP_TRY(hipGetLastError());
+    }
+    if (attempts_out) *attempts_out = attempts;
+    // extra terms + sensors at the breakpoint (engine.cc:2148, 2386-2410)
+    auto A = make_args<T>(b);
+    A.mode = jm::MODE_REFRESH; A.update_sensors = update_sensors;
+    return launch<T>(b, A, stream);
+}
+}  // namespace
+
 extern "C"
 {
 const char * jm_topology_signature(void) { return Topo::signature; }
@@ -234,6 +302,8 @@ int32_t jm_batch_destroy(jm_batch * b)
     if (!b) return JM_OK;
     (void)hipSetDevice(b->device);
     if (b->d_params) (void)hipFree(b->d_params);
+    if (b->ad_count) (void)hipFree(b->ad_count);
+    if (b->ad_count_host) (void)hipHostFree(b->ad_count_host);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     delete b;
     return JM_OK;
@@ -311,6 +381,43 @@ int32_t jm_batch_step(jm_batch * b, int32_t solver, double dt, int32_t n_substep
     A.mode = jm::MODE_STEP; A.solver = solver; A.dt = (float)dt; A.n_sub = n_substeps;
     A.command_changed = command_changed; A.update_sensors = update_sensors;
     return launch<float>(b, A, stream);
+}
+
+// ---- adaptive Dormand-Prince stepping (jm_adaptive.h)
+int32_t jm_batch_adaptive_workspace_rows(const jm_batch * b)
+{
+    (void)b;
+    return jm::AdaptiveRows<Topo>::TOTAL;
+}
+int32_t jm_batch_bind_adaptive(jm_batch * b, void * workspace, double * state_f64, int32_t * state_i32)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_bind_adaptive: null batch");
+    b->ad_ws = workspace; b->ad_fs = state_f64; b->ad_is = state_i32;
+    if (!b->ad_count)
+    {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipMalloc((void **)&b->ad_count, sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc((void **)&b->ad_count_host, sizeof(int32_t), hipHostMallocDefault));
+    }
+    return JM_OK;
+}
+int32_t jm_batch_step_adaptive(jm_batch * b, double t_next, const jm_adaptive_options * options, int32_t new_step,
+                               int32_t command_changed, int32_t update_sensors, int32_t max_attempts,
+                               int32_t * attempts_out, void * stream)
+{
+    if (!b || !options) return fail(JM_EINVAL, "jm_batch_step_adaptive: null argument");
+    if (!b->started)
+        return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before using step method.");
+    if (!b->ad_ws || !b->ad_fs || !b->ad_is)
+        return fail(JM_ECONTROLFLOW, "jm_batch_bind_adaptive must be called before the adaptive stepper is used");
+    if (!(options->tol_rel > 0.0) || !(options->tol_abs > 0.0)) return fail(JM_EINVAL, "tolRel and tolAbs must be positive");
+    if (!(options->dt_max >= 1e-6) || !(options->dt_max <= 0.02 + 1e-12)) return fail(JM_EINVAL, "'dtMax' option is out of range.");
+    int32_t rc = check_bound(b, true);
+    if (rc != JM_OK) return rc;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->dtype == JM_F64)
+        return step_adaptive<double>(b, t_next, options, new_step, command_changed, update_sensors, max_attempts, attempts_out, stream);
+    return step_adaptive<float>(b, t_next, options, new_step, command_changed, update_sensors, max_attempts, attempts_out, stream);
 }
 
 int32_t jm_batch_dynamics(jm_batch * b, const void * q_in, const void * v_in, void * a_out, void * stream)

@@ -303,13 +303,19 @@ template<class T, class Tp> struct TrunkStore
     T dinv[SLOTS], u[SLOTS];
     template<int t> static constexpr int lane() { return (t - 1) & 3; }
     template<int t> static constexpr int slot() { return (t - 1) >> 2; }
+    // The first write of a slot in program order goes to ALL lanes: a register assigned on one lane
+    // only is `undef` to the compiler on the others, and the quad broadcast reads it on all of them
+    // (observed: non-deterministic trunk data).  Forward sweeps fill a slot from its lowest joint,
+    // the backward sweep from its highest one.
+    template<int t> static constexpr bool first_fwd() { return lane<t>() == 0; }
+    template<int t> static constexpr bool first_bwd() { return t == Tp::QT - 1 || lane<t>() == 3; }
     template<int t> JM_DEV void put_kin(int k, const SE3<T> & Xt, Sp<T> vt)
     {
-        if (k == lane<t>()) { X[slot<t>()] = Xt; v[slot<t>()] = vt; }
+        if (first_fwd<t>() || k == lane<t>()) { X[slot<t>()] = Xt; v[slot<t>()] = vt; }
     }
     template<int t> JM_DEV void put_aba(int k, Sp<T> Ut, T di, T uj)
     {
-        if (k == lane<t>()) { U[slot<t>()] = Ut; dinv[slot<t>()] = di; u[slot<t>()] = uj; }
+        if (first_bwd<t>() || k == lane<t>()) { U[slot<t>()] = Ut; dinv[slot<t>()] = di; u[slot<t>()] = uj; }
     }
     template<int t, class Xq> JM_DEV void get_kin(SE3<T> & Xt, Sp<T> & vt) const
     {
@@ -399,13 +405,28 @@ JM_DEV void trunk_fk_store(CPtr<T> P, int k, const QIdx<Tp> & ix, const T * qb, 
 }
 
 // per-lane pick of the trunk joint this lane's limb hangs from
+// Value-level selects: `on ? a : b` scalar by scalar.  (A select between two array ELEMENTS under a
+// lane condition gets rewritten by the optimiser into one load with a per-lane index, which turns the
+// whole register array into a private-memory array: scratch traffic, and this hipcc has been seen
+// to overlay such arrays with live spill slots.)
+template<class T> JM_DEV V3<T> msel(bool on, V3<T> a, V3<T> b) { return {on ? a.x : b.x, on ? a.y : b.y, on ? a.z : b.z}; }
+template<class T> JM_DEV Sp<T> msel(bool on, Sp<T> a, Sp<T> b) { return {msel(on, a.l, b.l), msel(on, a.a, b.a)}; }
+template<class T> JM_DEV M3<T> msel(bool on, const M3<T> & a, const M3<T> & b)
+{
+    return {on ? a.m00 : b.m00, on ? a.m01 : b.m01, on ? a.m02 : b.m02, on ? a.m10 : b.m10, on ? a.m11 : b.m11,
+            on ? a.m12 : b.m12, on ? a.m20 : b.m20, on ? a.m21 : b.m21, on ? a.m22 : b.m22};
+}
+template<class T> JM_DEV SE3<T> msel(bool on, const SE3<T> & a, const SE3<T> & b) { return {msel(on, a.R, b.R), msel(on, a.p, b.p)}; }
 template<class T, class Tp, class V> JM_DEV V pick_attach(int k, const V * arr)
 {
     V r = arr[Tp::limb_attach[0]];
     static_for<1, 4>([&](auto kc) {
         constexpr int kk = decltype(kc)::value;
         if constexpr (Tp::limb_attach[kk] != Tp::limb_attach[0])
-            if (k == kk) r = arr[Tp::limb_attach[kk]];
+        {
+            const V alt = arr[Tp::limb_attach[kk]];
+            r = msel(k == kk, alt, r);
+        }
     });
     return r;
 }
@@ -504,6 +525,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     const V3<T> p1 = {qb[0], qb[1], qb[2]};
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     const Sp<T> v1 = {{vb_[0], vb_[1], vb_[2]}, {vb_[3], vb_[4], vb_[5]}};
+    // every lane keeps only "its" trunk joints (see TrunkStore: first write of a slot is unconditional)
     TrunkStore<T, Tp> TS;
 #ifdef JM_HOST_EMU
     std::memset(&TS, 0xFF, sizeof(TS));
@@ -830,7 +852,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             const T dd = di * (uj - dot6(Ut, ag));
             ddqb[5 + t] = dd;
             const Sp<T> att = ag + dd * S;
-            if (k == TrunkStore<T, Tp>::template lane<t>()) atst[TrunkStore<T, Tp>::template slot<t>()] = att;
+            if (TrunkStore<T, Tp>::template first_fwd<t>() || k == TrunkStore<T, Tp>::template lane<t>())
+                atst[TrunkStore<T, Tp>::template slot<t>()] = att;
             aprev = att;
             if constexpr (I::limb_at(t))
                 if (ix.attach == t) { ap = att; vp = vt; }
@@ -1245,7 +1268,8 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         JM_OPAQUE(rr);
         advance(st, true, rr);
         if (A.mode != MODE_DYNAMICS)
-            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, !stepping || A.update_sensors != 0, ddqb, ddq, status);
+            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
+                                      (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
         else
             quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
         T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
@@ -1254,7 +1278,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         if (A.mode != MODE_DYNAMICS)
         {
             const int stq = X::quad_or(status);
-            if (A.status && lead) A.status[rr] = stq;
+            if (A.status && lead) A.status[rr] = (A.mode == MODE_REFRESH) ? (A.status[rr] | stq) : stq;
             if (A.joint_forces || A.centroidal)
             {
                 // the (committed) state sits in the stage buffer
@@ -1325,6 +1349,7 @@ k_quad(const BatchArgs<T> A)
     __shared__ T table[Q::TABLE];
     __shared__ T stage_l[QRows<Tp>::NL * NTH];
     __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+#pragma nounroll
     for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
     const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
     const int k = threadIdx.x & 3;

@@ -14,15 +14,17 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+import warnings
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
-from . import _abi
+from . import _abi, codegen
 from ._lib import BadControlFlow, HipLibrary, load_for
-from .model import CompiledModel
+from .model import (JT_FREEFLYER, JT_RUBU, JT_RUBX, JT_RUBY, JT_RUBZ, CompiledModel)
 
 # constants of reference core/include/jiminy/core/constants.h:18-20
 STEPPER_MIN_TIMESTEP = 1e-10
@@ -31,32 +33,33 @@ SIMULATION_MAX_TIMESTEP = 0.02
 EPS = float(np.finfo(np.float64).eps)
 
 SOLVER_IDS = {"euler_explicit": _abi.JM_SOLVER_EULER_EXPLICIT,
-              "runge_kutta_4": _abi.JM_SOLVER_RUNGE_KUTTA_4}
+              "runge_kutta_4": _abi.JM_SOLVER_RUNGE_KUTTA_4,
+              "runge_kutta_dopri": _abi.JM_SOLVER_RUNGE_KUTTA_DOPRI}
 
 
 def default_options() -> Dict[str, Dict[str, Any]]:
     """Hot-path subset of `Engine::getDefaultEngineOptions` (reference engine.h:260-481),
-    same names; defaults identical except where the batched path restricts the choice:
-    `odeSolver` (reference default "runge_kutta_dopri" is adaptive, per-lane step sizes are
-    outside the batched path) and `contacts.model` (reference default "constraint")."""
+    same names and defaults (`odeSolver` = "runge_kutta_dopri": adaptive, every lane carries its
+    own step size), except `contacts.model` (reference default "constraint", outside this path)."""
     return {
         "world": {"gravity": [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]},
-        "stepper": {"odeSolver": "runge_kutta_4", "dtMax": SIMULATION_MAX_TIMESTEP,
+        "stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1.0e-5, "tolRel": 1.0e-4,
+                    "dtMax": SIMULATION_MAX_TIMESTEP, "dtRestoreThresholdRel": 0.2,
+                    "successiveIterFailedMax": 1000,
                     "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
         "contacts": {"model": "spring_damper", "stiffness": 1.0e6, "damping": 2.0e3,
                      "friction": 1.0, "transitionEps": 1.0e-3, "transitionVelocity": 1.0e-2},
     }
 
 
-def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
-              ) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
-    """Fixed-step schedule of one `Engine::step(step_size)` call.
+def _breakpoint_intervals(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
+                          ) -> Tuple[List[Tuple[float, float, bool, bool]], float, float]:
+    """Breakpoint schedule of one `Engine::step(step_size)` call.
 
     Re-states the breakpoint logic of the reference's discrete branch (engine.cc:1755-1795 end
-    time with Kahan compensation; :1920-1940 controller breakpoints; :1985-2090 time to the next
-    breakpoint and sub-step size; :2386-2410 sensor breakpoints) for solvers whose step size is
-    not error-controlled.  Returns (launches, t_end, t_error) where each launch is
-    `(dt, n_substeps, command_changed, update_sensors)`.
+    time with Kahan compensation; :1920-1940 controller breakpoints; :1985-2016 time to the next
+    breakpoint; :2386-2410 sensor breakpoints).  Returns (intervals, t_end, t_error) with one
+    `(t_next, dt_next, command_changed, update_sensors)` per interval between two breakpoints.
     """
     st = options["stepper"]
     dt_max = float(st["dtMax"])
@@ -79,7 +82,7 @@ def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dic
         nxt = period - math.fmod(time, period)
         return nxt < SIMULATION_MIN_TIMESTEP or period - nxt < STEPPER_MIN_TIMESTEP
 
-    launches: List[Tuple[float, int, bool, bool]] = []
+    intervals: List[Tuple[float, float, bool, bool]] = []
     while t_end - t >= STEPPER_MIN_TIMESTEP:
         command_changed = hit(ctrl, t)
         if math.isfinite(update_period):
@@ -91,8 +94,30 @@ def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dic
                 dt_next = t_end - t
         else:
             dt_next = t_end - t
-        t_next = t + dt_next
-        # sub-steps of dtMax, last one shortened to land on the breakpoint (engine.cc:2063-2089)
+        t = t + dt_next
+        intervals.append((t, dt_next, command_changed, hit(sens, t)))
+    return intervals, t_end, t_error
+
+
+def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
+                     ) -> Tuple[List[Tuple[float, bool, bool]], float, float]:
+    """Adaptive solver: `(t_next, command_changed, update_sensors)` per breakpoint interval; the
+    step sizes inside an interval are chosen per lane on the device (engine.cc:2021-2222)."""
+    intervals, t_end, t_err = _breakpoint_intervals(t, t_error, step_size, options)
+    return [(tn, c, s) for tn, _, c, s in intervals], t_end, t_err
+
+
+def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
+              ) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
+    """Fixed-step schedule of one `Engine::step(step_size)` call: the breakpoint intervals cut in
+    sub-steps of `dtMax`, the last one shortened to land on the breakpoint (engine.cc:2063-2089).
+    Returns (launches, t_end, t_error) where each launch is
+    `(dt, n_substeps, command_changed, update_sensors)`.
+    """
+    dt_max = float(options["stepper"]["dtMax"])
+    intervals, t_end, t_error = _breakpoint_intervals(t, t_error, step_size, options)
+    launches: List[Tuple[float, int, bool, bool]] = []
+    for _, dt_next, command_changed, update_sensors in intervals:
         n_full = int(math.floor((dt_next + STEPPER_MIN_TIMESTEP) / dt_max))
         rem = dt_next - n_full * dt_max
         groups: List[Tuple[float, int]] = []
@@ -102,8 +127,6 @@ def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dic
             groups.append((rem, 1))
         elif not groups:
             groups.append((dt_next, 1))
-        t = t_next
-        update_sensors = hit(sens, t)
         for i, (dt, n) in enumerate(groups):
             launches.append((dt, n, command_changed and i == 0,
                              update_sensors and i == len(groups) - 1))
@@ -134,12 +157,115 @@ class StepperState:
     q: torch.Tensor
     v: torch.Tensor
     a: torch.Tensor
+    # adaptive solver only: per-lane step size / estimated largest step size / counters, shape (B,)
+    dt_lanes: Optional[torch.Tensor] = None
+    dt_largest: Optional[torch.Tensor] = None
+    iter_lanes: Optional[torch.Tensor] = None
+    iter_failed_lanes: Optional[torch.Tensor] = None
+
+
+_VERIFIED: Dict[Tuple[str, torch.dtype], int] = {}
+
+
+def _probe_state(model: CompiledModel, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Deterministic, generic state for the library self-test: joints spread around the neutral
+    configuration inside their bounds, a tilted base some decimetres above the ground (part of the
+    contact points end up below it), moderate velocities and commands."""
+    rng = np.random.default_rng(20240917)
+    q = np.tile(model.neutral()[:, None], (1, n))
+    lo, hi = model.position_lower, model.position_upper
+    for j in range(1, model.njoints):
+        t, iq = int(model.jtypes[j]), int(model.idx_q[j])
+        if t == JT_FREEFLYER:
+            q[iq:iq + 2] = rng.uniform(-0.2, 0.2, (2, n))
+            q[iq + 2] = rng.uniform(0.2, 0.7, n)
+            quat = np.concatenate([0.2 * rng.standard_normal((3, n)), np.ones((1, n))])
+            q[iq + 3:iq + 7] = quat / np.linalg.norm(quat, axis=0)
+        elif t in (JT_RUBX, JT_RUBY, JT_RUBZ, JT_RUBU):
+            th = rng.uniform(-1.0, 1.0, n)
+            q[iq], q[iq + 1] = np.cos(th), np.sin(th)
+        else:
+            l = lo[iq] if np.isfinite(lo[iq]) else -1.0e9
+            h = hi[iq] if np.isfinite(hi[iq]) else 1.0e9
+            c = min(max(0.0, l), h)
+            q[iq] = np.clip(c + rng.uniform(-0.5, 0.5, n), l, h)
+    v = 0.5 * rng.standard_normal((model.nv, n))
+    scale = np.array([min(m.effort_limit, 20.0) for m in model.motors]).reshape(-1, 1)
+    cmd = rng.uniform(-1.0, 1.0, (model.nmotors, n)) * scale if model.nmotors else np.zeros((0, n))
+    return q, v, cmd
+
+
+def _library_self_test(model: CompiledModel, variant: int, dtype: torch.dtype, device: torch.device) -> float:
+    """Consistency check of one compiled library.  The evaluation loop of the step kernel and its
+    peeled last evaluation are two separately optimised copies of the same code: an explicit-Euler
+    step with and without the `a(t+)` refresh (command unchanged) must agree to round-off -- the
+    first takes the acceleration from the in-loop copy, the second from `start`; a second step
+    (one more pass through the loop, from a state the kernel itself produced) must agree too.
+    Returns the largest relative disagreement over (v, a)."""
+    n, dt = 64, 1e-4
+    q, v, cmd = (torch.as_tensor(x, dtype=dtype, device=device) for x in _probe_state(model, n))
+    outs = []
+    for changed in (False, True):
+        probe = BatchedEngine(model, n, dtype=dtype, device=device, extra_outputs=(), _lib_variant=variant)
+        probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt,
+                                       "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0}})
+        if model.nmotors:
+            probe.set_command(cmd)
+        probe.start(q, v)
+        res = []
+        for _ in range(2):
+            if changed:
+                probe.mark_command_changed()
+            probe.step(dt)
+            res += [probe._fields["v"].clone(), probe._fields["a"].clone()]
+        outs.append((res, probe.status.clone()))
+        probe.stop()
+    ok = (outs[0][1] & _abi.JM_LANE_NAN) == 0
+    if not bool(ok.any()):
+        return float("inf")   # a state this tame never produces NaN in a sound library
+    err = 0.0
+    for x, y in zip(outs[0][0], outs[1][0]):
+        scale = torch.clamp(x[:, ok].abs().max(), min=1.0)
+        e = float(((x - y)[:, ok]).abs().max() / scale)
+        err = max(err, e if e == e else float("inf"))
+    return err
+
+
+def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
+    """The HIP library of `model`, checked once per process, topology and dtype by
+    `_library_self_test`.  A build that fails the check is a toolchain mis-compile (DESIGN.md
+    section 4.6): the next build variant (codegen.BUILD_VARIANTS) is compiled and checked instead;
+    when none passes the engine refuses to run rather than integrate garbage."""
+    key = (model.topology_hash(), dtype)
+    if key in _VERIFIED:
+        return load_for(model, variant=_VERIFIED[key])
+    first = codegen.preferred_variant(model)
+    if os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
+        return load_for(model, variant=first)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    tried = []
+    for variant in [first] + [i for i in range(len(codegen.BUILD_VARIANTS)) if i != first]:
+        err = _library_self_test(model, variant, dtype, device)
+        tried.append(f"variant {variant}: {err:.3e}")
+        if err <= tol:
+            if variant != first:
+                warnings.warn(f"{model.name}: HIP library build variant {first} failed the kernel self-test "
+                              f"({'; '.join(tried)}); using variant {variant} "
+                              f"({' '.join(codegen.BUILD_VARIANTS[variant]) or 'default flags'}). Record it in "
+                              "jiminy_amd/csrc/build_variants.json to pre-build it.")
+            _VERIFIED[key] = variant
+            return load_for(model, variant=variant)
+    raise RuntimeError(
+        f"kernel self-test failed for every build variant of topology {model.topology_hash()} "
+        f"({model.name}; {'; '.join(tried)}): the in-loop and the peeled evaluation disagree, the "
+        "HIP library was mis-compiled for this topology")
 
 
 class BatchedEngine:
     def __init__(self, model: CompiledModel, batch_size: int, dtype: torch.dtype = torch.float64,
                  device: Optional[torch.device] = None,
-                 extra_outputs: Tuple[str, ...] = ("contact_forces",)) -> None:
+                 extra_outputs: Tuple[str, ...] = ("contact_forces",),
+                 _lib_variant: Optional[int] = None) -> None:
         if dtype not in (torch.float64, torch.float32):
             raise ValueError("dtype must be torch.float64 or torch.float32")
         if not torch.cuda.is_available():
@@ -152,7 +278,9 @@ class BatchedEngine:
             else torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the batched engine needs a HIP ('cuda') device")
-        self._lib: HipLibrary = load_for(model)
+        # `_lib_variant` is internal (probe engines of the library self-test)
+        self._lib: HipLibrary = (load_for(model, variant=_lib_variant) if _lib_variant is not None
+                                 else _verified_library(model, dtype, self.device))
         self._L = self._lib.L
         self._desc, self._keep = _abi.make_model_desc(model)
         self._model_h = C.c_void_p()
@@ -180,6 +308,8 @@ class BatchedEngine:
         self._dt = 0.0
         self._iter = 0
         self._command_dirty = True
+        self._adaptive: Optional[Dict[str, torch.Tensor]] = None
+        self.adaptive_attempts = 0   # device attempts of the last `step` with the adaptive solver
         self._apply_options()
 
     # ------------------------------------------------------------------ memory
@@ -242,6 +372,10 @@ class BatchedEngine:
         dt_max = float(st["dtMax"])
         if not (SIMULATION_MIN_TIMESTEP - EPS <= dt_max <= SIMULATION_MAX_TIMESTEP + EPS):
             raise ValueError("'dtMax' option is out of range.")  # engine.cc:2668-2673
+        if int(st["successiveIterFailedMax"]) < 1:
+            raise ValueError("'successiveIterFailedMax' must be strictly positive.")  # engine.cc:2677-2684
+        if not (float(st["tolAbs"]) > 0.0 and float(st["tolRel"]) > 0.0):
+            raise ValueError("'tolAbs' and 'tolRel' must be strictly positive.")
         cp, sp = float(st["controllerUpdatePeriod"]), float(st["sensorsUpdatePeriod"])
         for p in (cp, sp):
             if EPS < p < SIMULATION_MIN_TIMESTEP:
@@ -279,8 +413,14 @@ class BatchedEngine:
     @property
     def stepper_state(self) -> StepperState:
         f = self._fields
-        return StepperState(self._iter, 0, self._t, self._t_prev, self._t_error, self._dt,
-                            f["q"], f["v"], f["a"])
+        ad = self._adaptive
+        if ad is None:
+            return StepperState(self._iter, 0, self._t, self._t_prev, self._t_error, self._dt,
+                                f["q"], f["v"], f["a"])
+        # adaptive solver: `iter` / `iter_failed` / `dt` report the worst lane (one host sync)
+        return StepperState(int(ad["i32"][0].max()), int(ad["i32"][1].max()), self._t, self._t_prev,
+                            self._t_error, float(ad["f64"][1].min()), f["q"], f["v"], f["a"],
+                            ad["f64"][1], ad["f64"][2], ad["i32"][0], ad["i32"][1])
 
     @property
     def status(self) -> torch.Tensor:
@@ -358,6 +498,7 @@ class BatchedEngine:
         self._dt = 0.0
         self._iter = 0
         self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
+        self._setup_adaptive()
         self._running = True
         self._command_dirty = False
 
@@ -367,11 +508,59 @@ class BatchedEngine:
             self._lib.check(self._L.jm_batch_stop(self._batch_h))
         self._running = False
 
+    def _setup_adaptive(self) -> None:
+        """Workspace and per-lane stepper state of the adaptive solver (`StepperState::reset`,
+        engine.h:219-236: dt = dtLargest = dtLargestPrev = SIMULATION_MIN_TIMESTEP)."""
+        if self._options["stepper"]["odeSolver"] != "runge_kutta_dopri":
+            self._adaptive = None
+            return
+        B = self.batch_size
+        if self._adaptive is None:
+            rows = int(self._L.jm_batch_adaptive_workspace_rows(self._batch_h))
+            self._adaptive = {
+                "ws": torch.zeros((rows, B), dtype=self.dtype, device=self.device),
+                "f64": torch.zeros((5, B), dtype=torch.float64, device=self.device),
+                "i32": torch.zeros((6, B), dtype=torch.int32, device=self.device),
+            }
+            ad = self._adaptive
+            self._lib.check(self._L.jm_batch_bind_adaptive(
+                self._batch_h, C.c_void_p(ad["ws"].data_ptr()), C.c_void_p(ad["f64"].data_ptr()),
+                C.c_void_p(ad["i32"].data_ptr())))
+        ad = self._adaptive
+        ad["f64"].zero_()
+        ad["f64"][1:4] = SIMULATION_MIN_TIMESTEP
+        ad["i32"].zero_()
+
+    def _step_adaptive(self, step_dt: float) -> None:
+        st = self._options["stepper"]
+        intervals, t_end, t_err = plan_breakpoints(self._t, self._t_error, float(step_dt), self._options)
+        o = _abi.AdaptiveOptions(float(st["tolRel"]), float(st["tolAbs"]), float(st["dtMax"]),
+                                 float(st["dtRestoreThresholdRel"]), int(st["successiveIterFailedMax"]))
+        stream = self._stream()
+        attempts = C.c_int32(0)
+        self.adaptive_attempts = 0
+        for i, (t_next, cmd_bp, sens) in enumerate(intervals):
+            changed = cmd_bp and self._command_dirty
+            self._lib.check(self._L.jm_batch_step_adaptive(
+                self._batch_h, float(t_next), C.byref(o), int(i == 0), int(changed), int(sens),
+                100000, C.byref(attempts), stream))
+            if changed:
+                self._command_dirty = False
+            self.adaptive_attempts += int(attempts.value)
+        self._t_prev = self._t
+        self._t = t_end
+        self._t_error = t_err
+
     def step(self, step_dt: float = -1.0) -> None:
-        """≙ `Engine::step(stepSize)` for fixed-step solvers (reference engine.cc:1724-2417)."""
+        """≙ `Engine::step(stepSize)` (reference engine.cc:1724-2417): fixed-step solvers advance
+        all lanes with one launch per breakpoint interval; the adaptive solver iterates attempts on
+        the device until every lane reached the breakpoint."""
         if not self._running:
             raise BadControlFlow("No simulation running. Please start one before using step "
                                  "method.")
+        if self._adaptive is not None:
+            self._step_adaptive(step_dt)
+            return
         launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options)
         solver = SOLVER_IDS[self._options["stepper"]["odeSolver"]]
         stream = self._stream()
@@ -413,6 +602,12 @@ class BatchedEngine:
         self._lib.check(self._L.jm_batch_reset_lanes(
             self._batch_h, C.c_void_p(mask.data_ptr()), C.c_void_p(q.data_ptr()),
             C.c_void_p(v.data_ptr()), self._stream()))
+        if self._adaptive is not None:
+            m_ = mask.bool()
+            ad = self._adaptive
+            ad["f64"][1:4, m_] = SIMULATION_MIN_TIMESTEP
+            ad["f64"][0, m_] = self._t
+            ad["i32"][:, m_] = 0
 
     # ------------------------------------------------------------------ measurement helpers
     def enable_timing(self, enable: bool = True) -> None:

@@ -1014,6 +1014,266 @@ void step(Engine & e, int solver, double dt, int n_sub, int command_changed, int
     if (update_sensors) sensors(e);
 }
 
+// ------------------------------------------------------------------ adaptive Dormand-Prince stepper
+// Reference: core/include/jiminy/core/stepper/runge_kutta_dopri_stepper.h:12-58 (tableau, constants),
+// core/src/stepper/runge_kutta_dopri_stepper.cc:18-87 (adjustStep / computeError),
+// core/src/stepper/abstract_runge_kutta_stepper.cc:24-77 (tryStepImpl, FSAL),
+// core/src/stepper/abstract_stepper.cc:15-62 (tryStep, NaN check -> IS_ERROR),
+// core/src/engine/engine.cc:2021-2222 (step-size selection between two breakpoints),
+// State::difference = pinocchio::difference (lie_group.h:463-471; Pinocchio v2.7.0 explog.hpp log3 / log6).
+namespace dopri
+{
+const double A[7][7] = {
+    {0, 0, 0, 0, 0, 0, 0},
+    {1.0 / 5.0, 0, 0, 0, 0, 0, 0},
+    {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0, 0},
+    {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0, 0, 0, 0},
+    {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0, 0, 0},
+    {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0, 0},
+    {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0}};
+const double b[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
+const double e[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0, 187.0 / 2100.0, 1.0 / 40.0};
+constexpr double STEPPER_ORDER = 5.0, SAFETY = 0.8, ERROR_THRESHOLD = 0.5, MIN_FACTOR = 0.2, MAX_FACTOR = 5.0;
+}
+constexpr double STEPPER_MIN_TIMESTEP = 1e-10, SIMULATION_MIN_TIMESTEP = 1e-6;
+
+// Pinocchio v2.7.0 log3 (explog.hpp)
+V3 log3(const M3 & R)
+{
+    const double PI_value = 3.14159265358979323846;
+    double tr = R.m[0][0] + R.m[1][1] + R.m[2][2];
+    double theta;
+    if (tr >= 3.0) { tr = 3.0; theta = 0.0; }
+    else if (tr <= -1.0) { tr = -1.0; theta = PI_value; }
+    else theta = std::acos((tr - 1.0) / 2.0);
+    V3 res;
+    if (theta >= PI_value - 1e-2)
+    {
+        const double cphi = -(tr - 1.0) / 2.0;
+        const double beta = theta * theta / (1.0 + cphi);
+        const double t0 = (R.m[0][0] + cphi) * beta, t1 = (R.m[1][1] + cphi) * beta, t2 = (R.m[2][2] + cphi) * beta;
+        res.x = (R.m[2][1] > R.m[1][2] ? 1.0 : -1.0) * (t0 > 0 ? std::sqrt(t0) : 0.0);
+        res.y = (R.m[0][2] > R.m[2][0] ? 1.0 : -1.0) * (t1 > 0 ? std::sqrt(t1) : 0.0);
+        res.z = (R.m[1][0] > R.m[0][1] ? 1.0 : -1.0) * (t2 > 0 ? std::sqrt(t2) : 0.0);
+    }
+    else
+    {
+        const double prec3 = std::pow(EPS, 1.0 / 4.0);  // TaylorSeriesExpansion<double>::precision<3>()
+        const double t = ((theta > prec3) ? theta / std::sin(theta) : 1.0) / 2.0;
+        res.x = t * (R.m[2][1] - R.m[1][2]);
+        res.y = t * (R.m[0][2] - R.m[2][0]);
+        res.z = t * (R.m[1][0] - R.m[0][1]);
+    }
+    return res;
+}
+// Pinocchio v2.7.0 log6 (explog.hpp): [linear; angular]
+Motion log6(const SE3 & M)
+{
+    const V3 w = log3(M.R);
+    const double t2 = dot(w, w);
+    const double t = std::sqrt(t2);
+    double alpha, beta;
+    const double prec3 = std::pow(EPS, 1.0 / 4.0);
+    if (t < prec3)
+    {
+        alpha = 1.0 - t2 / 12.0 - t2 * t2 / 720.0;
+        beta = 1.0 / 12.0 + t2 / 720.0;
+    }
+    else
+    {
+        const double st = std::sin(t), ct = std::cos(t);
+        alpha = t * st / (2.0 * (1.0 - ct));
+        beta = 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
+    }
+    const V3 lin = alpha * M.p - 0.5 * cross(w, M.p) + (beta * dot(w, M.p)) * w;
+    return {lin, w};
+}
+// pinocchio::difference(model, q0, q1): tangent vector d such that q0 (+) d = q1
+void difference(const Model & m, const double * q0, const double * q1, double * out)
+{
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        const int t = m.jtype[j];
+        const double * a = q0 + m.idx_q[j];
+        const double * bq = q1 + m.idx_q[j];
+        double * o = out + m.idx_v[j];
+        if (t == JM_JT_FREEFLYER)
+        {
+            SE3 M0, M1;
+            M0.R = quat_to_matrix(a[3], a[4], a[5], a[6]); M0.p = {a[0], a[1], a[2]};
+            M1.R = quat_to_matrix(bq[3], bq[4], bq[5], bq[6]); M1.p = {bq[0], bq[1], bq[2]};
+            SE3 rel;   // M0.actInv(M1)
+            rel.R = transpose(M0.R) * M1.R;
+            rel.p = tmul(M0.R, M1.p - M0.p);
+            to6(log6(rel), o);
+        }
+        else if (is_unbounded(t))
+        {
+            // SO(2): R = R0^T R1 from (cos, sin) pairs, log = signed angle (liegroup/special-orthogonal.hpp)
+            const double c = a[0] * bq[0] + a[1] * bq[1], sn = a[0] * bq[1] - a[1] * bq[0];
+            const double tr = 2.0 * c;
+            const double PI_value = 3.14159265358979323846;
+            double theta;
+            if (tr > 2.0) theta = 0.0;
+            else if (tr < -2.0) theta = (sn >= 0.0) ? PI_value : -PI_value;
+            else if (tr > 2.0 - 1e-2) theta = std::asin((sn - (-sn)) / 2.0);
+            else theta = (sn >= 0.0) ? std::acos(tr / 2.0) : -std::acos(tr / 2.0);
+            o[0] = theta;
+        }
+        else
+            o[0] = bq[0] - a[0];
+    }
+}
+
+struct AdaptiveState   // per robot: StepperState (engine.h:216-250) + the per-step failure counters
+{
+    double t = 0.0, dt = SIMULATION_MIN_TIMESTEP, dtLargest = SIMULATION_MIN_TIMESTEP, dtLargestPrev = SIMULATION_MIN_TIMESTEP;
+    long iter = 0, iterFailed = 0;
+    int successiveIterTooLarge = 0, successiveIterFailed = 0;
+};
+struct AdaptiveOptions
+{
+    double tolRel = 1e-4, tolAbs = 1e-5, dtMax = 0.02, dtRestoreThresholdRel = 0.2;
+    int successiveIterFailedMax = 1000;
+};
+
+// RungeKuttaDOPRIStepper::tryStep: returns 0 = success, 1 = failure (error too large), 2 = error (NaN)
+int dopri_try_step(Engine & e, const AdaptiveOptions & ao, double & t, double & dt)
+{
+    const Model & m = e.mdl;
+    const int nq = m.nq, nv = m.nv;
+    std::vector<double> kv[7], ka[7];
+    kv[0] = e.v; ka[0] = e.a;
+    std::vector<double> incv(nv), inca(nv), qs(nq), vs(nv), as(nv);
+    for (int i = 1; i < 7; ++i)
+    {
+        std::fill(incv.begin(), incv.end(), 0.0);
+        std::fill(inca.begin(), inca.end(), 0.0);
+        for (int j = 0; j < i; ++j)
+        {
+            const double s = dt * dopri::A[i][j];
+            for (int k = 0; k < nv; ++k) { incv[k] += s * kv[j][k]; inca[k] += s * ka[j][k]; }
+        }
+        integrate(m, e.q.data(), incv.data(), qs.data());
+        for (int k = 0; k < nv; ++k) vs[k] = e.v[k] + inca[k];
+        dynamics(e, qs.data(), vs.data(), as.data());
+        kv[i] = vs; ka[i] = as;
+    }
+    // candidate solution
+    std::vector<double> qsol(nq), vsol(nv);
+    std::fill(incv.begin(), incv.end(), 0.0);
+    std::fill(inca.begin(), inca.end(), 0.0);
+    for (int i = 0; i < 7; ++i)
+    {
+        const double s = dt * dopri::b[i];
+        for (int k = 0; k < nv; ++k) { incv[k] += s * kv[i][k]; inca[k] += s * ka[i][k]; }
+    }
+    integrate(m, e.q.data(), incv.data(), qsol.data());
+    for (int k = 0; k < nv; ++k) vsol[k] = e.v[k] + inca[k];
+    // computeError: scale = tolAbs + tolRel |x0 (-) 0|
+    std::vector<double> qzero(nq, 0.0), scale_q(nv), scale_v(nv);
+    difference(m, e.q.data(), qzero.data(), scale_q.data());
+    for (int k = 0; k < nv; ++k)
+    {
+        scale_q[k] = std::fabs(scale_q[k]) * ao.tolRel + ao.tolAbs;
+        scale_v[k] = std::fabs(0.0 - e.v[k]) * ao.tolRel + ao.tolAbs;
+    }
+    std::vector<double> qoth(nq), voth(nv), errq(nv);
+    std::fill(incv.begin(), incv.end(), 0.0);
+    std::fill(inca.begin(), inca.end(), 0.0);
+    for (int i = 0; i < 7; ++i)
+    {
+        const double s = dt * dopri::e[i];
+        for (int k = 0; k < nv; ++k) { incv[k] += s * kv[i][k]; inca[k] += s * ka[i][k]; }
+    }
+    integrate(m, e.q.data(), incv.data(), qoth.data());
+    for (int k = 0; k < nv; ++k) voth[k] = e.v[k] + inca[k];
+    difference(m, qsol.data(), qoth.data(), errq.data());
+    double error = 0.0;
+    bool nan = false;
+    for (int k = 0; k < nv; ++k)
+    {
+        const double eq = std::fabs(errq[k] / scale_q[k]), ev = std::fabs((voth[k] - vsol[k]) / scale_v[k]);
+        nan |= (eq != eq) || (ev != ev);
+        error = std::max(error, std::max(eq, ev));
+    }
+    if (nan) return 2;   // "The estimated integration error contains 'nan'."
+    // adjustStep (boost odeint controlled stepper rule)
+    if (error < 1.0)
+    {
+        const double dt_done = dt;
+        if (error < std::min(dopri::ERROR_THRESHOLD, std::pow(dopri::SAFETY, dopri::STEPPER_ORDER)))
+        {
+            const double clipped = std::max(error, std::pow(dopri::MAX_FACTOR / dopri::SAFETY, -dopri::STEPPER_ORDER));
+            dt *= dopri::SAFETY * std::pow(clipped, -1.0 / dopri::STEPPER_ORDER);
+        }
+        // abstract_stepper.cc:41-48: NaN in the new derivative -> IS_ERROR, state not committed
+        for (double x : ka[6]) if (x != x) return 2;
+        // success: state <- solution, derivative <- k_last (FSAL)
+        e.q = qsol; e.v = vsol; e.a = ka[6];
+        t += dt_done;
+        return 0;
+    }
+    dt *= std::max(dopri::SAFETY * std::pow(error, -1.0 / (dopri::STEPPER_ORDER - 2.0)), dopri::MIN_FACTOR);
+    return 1;
+}
+
+// One breakpoint interval [t, tNext] of Engine::step with the adaptive stepper (engine.cc:2021-2222).
+void step_dopri(Engine & e, AdaptiveState & S, const AdaptiveOptions & ao, double tNext, int command_changed,
+                int update_sensors)
+{
+    check_state_nan(e);
+    bool hasDynamicsChanged = command_changed != 0;
+    double & t = S.t; double & dt = S.dt; double & dtLargest = S.dtLargest;
+    bool isBreakpointReached = false;
+    while (tNext - t > STEPPER_MIN_TIMESTEP)
+    {
+        if (hasDynamicsChanged)
+        {
+            dynamics(e, e.q.data(), e.v.data(), e.a.data());   // FSAL fix: a(t+)
+            hasDynamicsChanged = false;
+        }
+        if (dt < STEPPER_MIN_TIMESTEP) { e.status |= JM_LANE_STEPPER_FAILURE; break; }
+        double dtResidualThr = STEPPER_MIN_TIMESTEP;
+        if (S.successiveIterTooLarge == 0)
+            dtResidualThr = std::min(std::max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP);
+        if (tNext - t < dt || (S.successiveIterTooLarge <= 1 && tNext - t < dt + dtResidualThr)) dt = tNext - t;
+        if (dt > SIMULATION_MIN_TIMESTEP)
+        {
+            const double dtResidual = std::fmod(dt, SIMULATION_MIN_TIMESTEP);
+            if (dtResidual > STEPPER_MIN_TIMESTEP && dtResidual < SIMULATION_MIN_TIMESTEP - STEPPER_MIN_TIMESTEP &&
+                dt - dtResidual > STEPPER_MIN_TIMESTEP)
+                dt -= dtResidual;
+        }
+        if (S.successiveIterFailed > ao.successiveIterFailedMax) { e.status |= JM_LANE_STEPPER_FAILURE; break; }
+        isBreakpointReached = (dtLargest > dt);
+        dtLargest = dt;
+        const int rc = dopri_try_step(e, ao, t, dtLargest);
+        if (rc == 0)
+        {
+            S.successiveIterTooLarge = 0;
+            S.successiveIterFailed = 0;
+            extra_terms(e);
+            ++S.iter; ++e.iter;
+            if (isBreakpointReached)
+            {
+                const double thr = S.dtLargestPrev * ao.dtRestoreThresholdRel;
+                if (dt < dtLargest && dtLargest < thr) dtLargest = S.dtLargestPrev;
+            }
+            S.dtLargestPrev = dtLargest;
+        }
+        else
+        {
+            if (rc == 2) dtLargest *= 0.1;
+            if (rc == 1) ++S.successiveIterTooLarge;
+            ++S.successiveIterFailed;
+            ++S.iterFailed;
+        }
+        dt = std::min(dtLargest, ao.dtMax);
+    }
+    if (update_sensors) sensors(e);
+}
+
 Engine * make_engine(const jm_model_desc * d, const jm_options * o)
 {
     Engine * e = new Engine();
@@ -1229,6 +1489,13 @@ static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
     }
     st(io.u, e.u);
 }
+// adaptive-step batch driver: per-lane stepper state arrays [B] (t, dt, dtLargest, dtLargestPrev as
+// doubles; iter, iterFailed, successiveIterTooLarge, successiveIterFailed as int64)
+struct orc_adaptive_io
+{
+    double *t, *dt, *dt_largest, *dt_largest_prev;
+    int64_t *iter, *iter_failed, *succ_too_large, *succ_failed;
+};
 // mode 0 = start, 1 = step, 2 = dynamics only (a = f(q,v), q/v untouched)
 void orc_batch_run(void * h, const orc_batch_io * io, int mode, int solver, double dt, int n_sub,
                    int command_changed, int update_sensors, int64_t lane_begin, int64_t lane_end)
@@ -1248,6 +1515,32 @@ void orc_batch_run(void * h, const orc_batch_io * io, int mode, int solver, doub
         }
         else
             dynamics(e, e.q.data(), e.v.data(), e.a.data());
+        store_lane(e, *io, l);
+    }
+}
+
+void orc_batch_run_dopri(void * h, const orc_batch_io * io, const orc_adaptive_io * ad, double t_next, double tol_rel,
+                         double tol_abs, double dt_max, double dt_restore_threshold_rel, int succ_failed_max,
+                         int new_step, int command_changed, int update_sensors, int64_t lane_begin, int64_t lane_end)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    AdaptiveOptions ao;
+    ao.tolRel = tol_rel; ao.tolAbs = tol_abs; ao.dtMax = dt_max; ao.dtRestoreThresholdRel = dt_restore_threshold_rel;
+    ao.successiveIterFailedMax = succ_failed_max;
+    for (int64_t l = lane_begin; l < lane_end; ++l)
+    {
+        load_lane(e, *io, l);
+        e.status = io->status ? (io->status[l] & ~JM_LANE_OUT_OF_BOUNDS) : 0;
+        AdaptiveState S;
+        S.t = ad->t[l]; S.dt = ad->dt[l]; S.dtLargest = ad->dt_largest[l]; S.dtLargestPrev = ad->dt_largest_prev[l];
+        S.iter = ad->iter[l]; S.iterFailed = ad->iter_failed[l];
+        S.successiveIterTooLarge = new_step ? 0 : (int)ad->succ_too_large[l];
+        S.successiveIterFailed = new_step ? 0 : (int)ad->succ_failed[l];
+        e.status = 0;
+        step_dopri(e, S, ao, t_next, command_changed, update_sensors);
+        ad->t[l] = S.t; ad->dt[l] = S.dt; ad->dt_largest[l] = S.dtLargest; ad->dt_largest_prev[l] = S.dtLargestPrev;
+        ad->iter[l] = S.iter; ad->iter_failed[l] = S.iterFailed;
+        ad->succ_too_large[l] = S.successiveIterTooLarge; ad->succ_failed[l] = S.successiveIterFailed;
         store_lane(e, *io, l);
     }
 }

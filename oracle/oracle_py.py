@@ -33,6 +33,21 @@ class BatchIO(C.Structure):
         "energy", "contact_forces", "f_external", "status", "joint_forces", "centroidal", "u")]
 
 
+class AdaptiveIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("t", "dt", "dt_largest", "dt_largest_prev", "iter",
+                                          "iter_failed", "succ_too_large", "succ_failed")]
+
+
+def adaptive_state(B: int) -> Dict[str, np.ndarray]:
+    """Per-lane stepper state of the adaptive (Dormand-Prince) solver, as `StepperState::reset`
+    leaves it (engine.h:219-236, dtInit = SIMULATION_MIN_TIMESTEP, engine.cc:1176)."""
+    st = {k: np.full(B, 1e-6) for k in ("dt", "dt_largest", "dt_largest_prev")}
+    st["t"] = np.zeros(B)
+    for k in ("iter", "iter_failed", "succ_too_large", "succ_failed"):
+        st[k] = np.zeros(B, dtype=np.int64)
+    return st
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
@@ -55,6 +70,9 @@ def lib() -> C.CDLL:
         L.orc_integrate.argtypes = [C.c_void_p, pd, pd, pd]
         L.orc_batch_run.argtypes = [C.c_void_p, C.POINTER(BatchIO), C.c_int, C.c_int, C.c_double,
                                     C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]
+        L.orc_batch_run_dopri.argtypes = [C.c_void_p, C.POINTER(BatchIO), C.POINTER(AdaptiveIO), C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int64, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -161,3 +179,29 @@ class OracleEngine:
         self._L.orc_batch_run(self._h, C.byref(io), {"start": 0, "step": 1, "dynamics": 2}[mode],
                               SOLVERS[solver], float(dt), int(n_substeps), int(command_changed),
                               int(update_sensors), lo, hi)
+
+    def batch_run_dopri(self, arrays: Dict[str, np.ndarray], adaptive: Dict[str, np.ndarray], t_next: float,
+                        tol_rel: float = 1e-4, tol_abs: float = 1e-5, dt_max: float = 0.02,
+                        dt_restore_threshold_rel: float = 0.2, successive_iter_failed_max: int = 1000,
+                        new_step: bool = True, command_changed: bool = True, update_sensors: bool = True,
+                        lanes=None) -> None:
+        """Advance every lane to the breakpoint `t_next` with the adaptive Dormand-Prince stepper
+        (the reference's default `odeSolver`), per-lane step sizes in `adaptive` (see adaptive_state)."""
+        B = arrays["q"].shape[1]
+        io = BatchIO()
+        io.B = B
+        for name, _ in BatchIO._fields_[1:]:
+            arr = arrays.get(name)
+            if arr is not None:
+                assert arr.flags.c_contiguous and arr.shape[-1] == B, name
+                setattr(io, name, arr.ctypes.data)
+        ad = AdaptiveIO()
+        for name, _ in AdaptiveIO._fields_:
+            a = adaptive[name]
+            assert a.flags.c_contiguous and a.shape == (B,), name
+            setattr(ad, name, a.ctypes.data)
+        lo, hi = (0, B) if lanes is None else lanes
+        self._L.orc_batch_run_dopri(self._h, C.byref(io), C.byref(ad), float(t_next), float(tol_rel),
+                                    float(tol_abs), float(dt_max), float(dt_restore_threshold_rel),
+                                    int(successive_iter_failed_max), int(new_step), int(command_changed),
+                                    int(update_sensors), lo, hi)

@@ -32,7 +32,7 @@ def _lib(model: CompiledModel) -> C.CDLL:
     deps = [os.path.join(_HERE, "emu.cpp"), hdr] + codegen._sources()[1:] + \
            []
     if (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
+        subprocess.check_call(["g++", "-O1", *os.environ.get("EMU_EXTRA_FLAGS", "").split(), "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
                                "-ffp-contract=off", "-pthread", f"-DJM_TOPO_HEADER=\"{hdr}\"",
                                os.path.join(_HERE, "emu.cpp"), "-o", out])
     L = C.CDLL(out)

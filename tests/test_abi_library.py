@@ -89,3 +89,39 @@ def test_model_desc_packing():
     assert d.motor_params[1] == 80.0 and d.motor_params[2] == 7.5 and d.motor_params[3] == 0.02
     rows = _abi.field_rows(model)
     assert rows["imu"] == 6 and rows["force"] == 24 and rows["encoder"] == 24 and rows["effort"] == 12
+
+
+def test_build_variants_bookkeeping(monkeypatch, tmp_path):
+    """codegen.BUILD_VARIANTS / build_variants.json: the variant recorded for a topology selects the
+    library file the loader opens; variant 0 is the plain flag set."""
+    import json
+    model = robots.crane_walker()
+    monkeypatch.delenv("JIMINY_AMD_BUILD_VARIANT", raising=False)
+    monkeypatch.delenv("JIMINY_AMD_LIB_TAG", raising=False)
+    assert codegen.BUILD_VARIANTS[0] == ()
+    recorded = json.load(open(os.path.join(codegen.CSRC, "build_variants.json")))
+    assert all(0 <= int(v["variant"]) < len(codegen.BUILD_VARIANTS) for v in recorded.values())
+    want = int(recorded.get(model.topology_hash(), {"variant": 0})["variant"])
+    assert codegen.preferred_variant(model) == want
+    assert codegen.lib_path(model).endswith(f"libjm_{model.topology_hash()}" + (f"_v{want}.so" if want else ".so"))
+    assert codegen.lib_path(model, 0).endswith(f"libjm_{model.topology_hash()}.so")
+    assert codegen.lib_path(model, 2).endswith(f"libjm_{model.topology_hash()}_v2.so")
+    monkeypatch.setenv("JIMINY_AMD_BUILD_VARIANT", "2")
+    assert codegen.preferred_variant(model) == 2
+    monkeypatch.setattr(codegen, "_VARIANT_FILE", str(tmp_path / "absent.json"))
+    monkeypatch.delenv("JIMINY_AMD_BUILD_VARIANT")
+    assert codegen.preferred_variant(model) == 0
+
+
+def test_probe_state_of_the_library_self_test_is_valid():
+    """engine._probe_state: inside the joint bounds, unit quaternion / unit (cos, sin) pairs."""
+    from jiminy_amd import engine
+    for model in (load_builtin("atlas"), robots.tree_arm(True), robots.crane_walker(), load_builtin("cartpole")):
+        q, v, cmd = engine._probe_state(model, 16)
+        assert q.shape == (model.nq, 16) and v.shape == (model.nv, 16) and cmd.shape == (model.nmotors, 16)
+        m = model.bounded_position_mask()
+        assert np.all(q[m] >= model.position_lower[m][:, None] - 1e-12)
+        assert np.all(q[m] <= model.position_upper[m][:, None] + 1e-12)
+        if model.has_freeflyer:
+            assert np.allclose(np.linalg.norm(q[3:7], axis=0), 1.0)
+        assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(cmd).all()

@@ -90,6 +90,43 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
     assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
 
 
+def test_library_self_test_guards_against_miscompiled_builds(gpu_device, monkeypatch):
+    """Every HIP library is checked on first use (engine._verified_library): a build whose in-loop
+    evaluation disagrees with its peeled copy is replaced by the next build variant.  crane_walker's
+    default-flag build is such a case with hipcc 7.2; whichever variant ends
+    up selected, the engine must match the oracle."""
+    from jiminy_amd import codegen, engine as engine_mod
+    from tests import robots
+    model = robots.crane_walker()
+    monkeypatch.setenv("JIMINY_AMD_BUILD_VARIANT", "0")
+    monkeypatch.setattr(engine_mod, "_VERIFIED", {})
+    B, dt = 64, 2.5e-4
+    st = sample_states(model, B, seed=5, base_height=(0.3, 0.6), grounded_fraction=0.5)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    chosen = engine_mod._VERIFIED[(model.topology_hash(), torch.float64)]
+    assert 0 <= chosen < len(codegen.BUILD_VARIANTS)
+    if chosen != 0:
+        assert any("failed the kernel self-test" in str(w.message) for w in caught)
+    assert eng._lib.path == codegen.lib_path(model, chosen)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    for i in range(4):
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        eng.step(dt)
+    ok = (ref["status"][0] & 1) == 0
+    for k in OUTS:
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-9, k
+    # the self-test itself: a sound library agrees with itself to round-off
+    assert engine_mod._library_self_test(model, chosen, torch.float64, eng.device) < 1e-9
+
+
 def test_anymal_generic_lane_kernel_matches_oracle(gpu_device, monkeypatch):
     """The one-robot-per-lane kernel (used for topologies without the 4-limb structure) on ANYmal."""
     monkeypatch.setenv("JM_KERNEL_VARIANT", "lane")
@@ -232,8 +269,13 @@ def test_control_flow_errors(gpu_device):
     with pytest.raises(BadControlFlow):
         eng.set_options({"stepper": {"dtMax": 1e-3}})
     eng.stop()
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri"}})   # the reference's default solver
     with pytest.raises(NotImplementedError):
-        eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri"}})
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_fehlberg"}})
+    with pytest.raises(NotImplementedError):
+        eng.set_options({"contacts": {"model": "constraint"}})
+    with pytest.raises(ValueError):
+        eng.set_options({"stepper": {"tolRel": 0.0}})
 
 
 @pytest.mark.parametrize("name", ["anymal", "atlas"])
@@ -271,3 +313,91 @@ def test_multi_substep_launches_match_oracle(gpu_device, name, solver):
     for k in OUTS + ("u", "energy", "f_external"):
         assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
     assert abs(eng.stepper_state.t - 4 * n_sub * dt) < 1e-12
+
+
+def _dopri_pair(model, B, st, step_dt, n_steps, tol_rel, tol_abs, dt_max=0.02, ctrl=0.0):
+    """Engine with the adaptive solver vs the oracle's restatement of the reference's adaptive loop,
+    same breakpoints; returns (engine, ref arrays, oracle adaptive state)."""
+    from jiminy_amd.engine import plan_breakpoints
+    from oracle.oracle_py import OracleEngine, adaptive_state
+    from tests.helpers import oracle_io
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        if st[k].shape[0]:
+            ref[k][:] = st[k]
+    orc = OracleEngine(model)
+    io = oracle_io(ref)
+    orc.batch_run("start", io)
+    ad = adaptive_state(B)
+    eng = BatchedEngine(model, B, dtype=torch.float64, extra_outputs=EXTRA)
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolRel": tol_rel, "tolAbs": tol_abs,
+                                 "dtMax": dt_max, "controllerUpdatePeriod": ctrl, "sensorsUpdatePeriod": ctrl}})
+    if model.nmotors:
+        eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    t, t_err = 0.0, 0.0
+    for _ in range(n_steps):
+        intervals, t_end, t_err = plan_breakpoints(t, t_err, step_dt, eng.get_options())
+        for i, (t_next, cmd, sens) in enumerate(intervals):
+            orc.batch_run_dopri(io, ad, t_next, tol_rel=tol_rel, tol_abs=tol_abs, dt_max=dt_max,
+                                new_step=(i == 0), command_changed=False, update_sensors=sens)
+        t = t_end
+        eng.step(step_dt)
+    torch.cuda.synchronize()
+    return eng, ref, ad
+
+
+@pytest.mark.parametrize("robot", ["pendulum", "double_pendulum", "cartpole"])
+def test_adaptive_dopri_matches_oracle_small_robots(gpu_device, robot):
+    """`odeSolver = "runge_kutta_dopri"` (reference default) on the one-robot-per-lane kernel: every
+    lane carries its own step size.  The accept / reject decisions are discontinuous in the error
+    estimate, so agreement is statistical: nearly all lanes follow the oracle's step sequence
+    (round-off agreement), the rest stay within the integration tolerance."""
+    from tests import robots
+    model = {"pendulum": robots.pendulum, "double_pendulum": robots.double_pendulum,
+             "cartpole": lambda: load_builtin("cartpole")}[robot]()
+    B = 192
+    st = sample_states(model, B, seed=31)
+    eng, ref, ad = _dopri_pair(model, B, st, 0.01, 30, 1e-6, 1e-7)
+    err = np.abs(eng.field("q").cpu().numpy() - ref["q"]).max(axis=0)
+    assert np.median(err) < 1e-10 and err.max() < 1e-4, (np.median(err), err.max())
+    ss = eng.stepper_state
+    same = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.mean() > 0.9
+    assert np.allclose(ss.dt_largest.cpu().numpy()[same], ad["dt_largest"][same], rtol=1e-6)
+    assert int(eng.status.abs().sum()) == 0
+
+
+def test_adaptive_dopri_anymal_free_flight_and_energy(gpu_device):
+    """Branch-parallel kernel under the adaptive solver: ANYmal in free flight (no contact, zero
+    command, unbounded joints so that no lane is flagged), tight tolerances: matches the oracle and
+    conserves the total energy."""
+    model = load_builtin("anymal")
+    mask = model.bounded_position_mask()
+    model.position_lower[mask] = -np.inf
+    model.position_upper[mask] = np.inf
+    B = 64
+    st = sample_states(model, B, seed=12, base_height=(5.0, 6.0), grounded_fraction=0.0, command_fraction=0.0)
+    eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 20, 1e-8, 1e-9)
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-7, k
+    e_gpu = eng.field("energy").cpu().numpy().sum(axis=0)
+    e_ref = ref["energy"].sum(axis=0)
+    assert np.abs(e_gpu - e_ref).max() < 1e-6 * np.abs(e_ref).max()
+    assert int(eng.stepper_state.iter) >= 20 and eng.adaptive_attempts >= 1
+
+
+def test_adaptive_dopri_with_controller_breakpoints_and_contacts(gpu_device):
+    """Default tolerances (tolRel 1e-4, tolAbs 1e-5), 5 ms controller / sensor breakpoints, ANYmal
+    landing on the spring-damper ground: lanes reach every breakpoint, none is lost, the state stays
+    within the integration tolerance of the oracle for most lanes."""
+    model = load_builtin("anymal")
+    B = 128
+    st = sample_states(model, B, seed=13, base_height=(0.5, 0.6), grounded_fraction=0.5, command_fraction=0.1)
+    eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 8, 1e-4, 1e-5, ctrl=5e-3)
+    ok = (ref["status"][0] & 9) == 0
+    stt = eng.status.cpu().numpy()
+    assert ((stt & 9) == 0)[ok].mean() > 0.95
+    err = np.abs(eng.field("q").cpu().numpy() - ref["q"]).max(axis=0)[ok & ((stt & 9) == 0)]
+    assert np.median(err) < 1e-6 and (err < 1e-2).mean() > 0.95, (np.median(err), err.max())
+    assert abs(eng.stepper_state.t - 0.04) < 1e-12
