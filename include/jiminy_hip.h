@@ -266,6 +266,31 @@ int32_t jm_block_mahony_filter(int32_t dtype, int64_t batch_size, int32_t n_imu,
                                void * quat, void * omega, void * cf, void * bias, double kp, double ki,
                                double dt, void * stream);
 
+/* ---- Sensor white noise and bias (sensor part), batched.
+ *
+ * jm_block_sensor_noise ≙ `AbstractSensorBase::measureData` (core/src/hardware/abstract_sensor.cc:71-85)
+ *   and, with `rot_bias_inv`, `ImuSensor::measureData` (core/src/hardware/basic_sensors.cc:166-187),
+ *   applied in place to one raw measurement field (`data`, device, `[n_sensors][n_fields][B]`, e.g.
+ *   JM_F_IMU) right after the step that refreshed it: white noise `normal(generator, 0, noiseStd)`
+ *   first (float ziggurat over a PCG32 stream, core/src/utilities/random.cc:10-167), then the additive
+ *   bias, then (IMU) the rotation bias applied to both 3-vectors. `rng_state` (device, uint64
+ *   `[n_sensors][B]`) is the PCG32 state of every (sensor, lane), advanced exactly as the reference
+ *   advances `AbstractSensorBase::generator_`. `noise_std`, `bias` are host arrays
+ *   `[n_sensors][n_fields]` (NULL = option left empty), `rot_bias_inv` a host array `[n_sensors][9]`
+ *   (row-major `exp3(-bias.head<3>())`, basic_sensors.cc:121-129) or NULL.
+ * jm_sensor_rng_seed ≙ the generator seeding of `AbstractSensorTpl<T>::resetAll(seed)`
+ *   (core/include/jiminy/core/hardware/abstract_sensor.hxx:213-226): for every lane,
+ *   `std::seed_seq{group_seed[lane]}.generate` of `n_sensors` words, sensor s gets the PCG32 state
+ *   `word_s | 3`. Host arrays in, host array `[n_sensors][B]` out (upload it as `rng_state`). */
+#define JM_NOISE_MAX_ROWS 128
+#define JM_NOISE_MAX_FIELDS 6
+#define JM_NOISE_MAX_ROT 8
+int32_t jm_block_sensor_noise(int32_t dtype, int64_t batch_size, int32_t n_sensors, int32_t n_fields,
+                              void * data, uint64_t * rng_state, const double * noise_std,
+                              const double * bias, const double * rot_bias_inv, void * stream);
+int32_t jm_sensor_rng_seed(const uint32_t * group_seed, int64_t batch_size, int32_t n_sensors,
+                           uint64_t * state_out);
+
 /* Copy the message of the last error raised on the calling thread. */
 int32_t jm_last_error(char * buffer, size_t size);
 

@@ -240,7 +240,7 @@ def _quad_lines(model: CompiledModel):
 
 
 # Build variants.  hipcc 7.2 mis-compiles the evaluation loop of some register-bound topologies
-# (DESIGN.md section 4.6): the engine verifies every library on first use (BatchedEngine self-test)
+# (DESIGN.md section 4.7): the engine verifies every library on first use (BatchedEngine self-test)
 # and moves on to the next variant when a build fails the check.  `build_variants.json` (tracked)
 # records the variant a topology is known to need, so that `__graft_entry__.build()` compiles it
 # ahead of time.
@@ -287,7 +287,7 @@ def write_header(model: CompiledModel) -> str:
 
 def _sources() -> List[str]:
     return [os.path.join(CSRC, n) for n in ("jm_lib.cpp", "jm_kernels.h", "jm_math.h", "jm_quad.h",
-                                            "jm_pack.h", "jm_adaptive.h", "jm_blocks.h")] + \
+                                            "jm_pack.h", "jm_adaptive.h", "jm_blocks.h", "jm_random.h")] + \
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 

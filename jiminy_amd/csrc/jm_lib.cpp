@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -23,6 +26,7 @@
 #include "jm_pack.h"
 #include "jm_blocks.h"
 #include "jm_adaptive.h"
+#include "jm_random.h"
 
 #define JM_ABI_VERSION 1
 
@@ -531,6 +535,76 @@ int32_t jm_block_mahony_filter(int32_t dtype, int64_t B, int32_t n_imu, const vo
         hipLaunchKernelGGL((jm::k_mahony<float>), dim3(grid), dim3(256), 0, s, n_imu, (const float *)imu, (float *)quat,
                            (float *)omega, (float *)cf, (float *)bias, kp, ki, dt, (long long)B);
     HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_block_sensor_noise(int32_t dtype, int64_t B, int32_t n_sensors, int32_t n_fields, void * data,
+                              uint64_t * rng_state, const double * noise_std, const double * bias,
+                              const double * rot_bias_inv, void * stream)
+{
+    if (!data) return fail(JM_EINVAL, "jm_block_sensor_noise: null data");
+    if (B <= 0 || n_sensors <= 0 || n_fields <= 0 || n_fields > JM_NOISE_MAX_FIELDS ||
+        n_sensors * n_fields > JM_NOISE_MAX_ROWS)
+        return fail(JM_EINVAL, "jm_block_sensor_noise: bad sizes");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_sensor_noise: bad dtype");
+    if (noise_std && !rng_state) return fail(JM_EINVAL, "jm_block_sensor_noise: noise needs the generator states");
+    if (rot_bias_inv && (n_fields != 6 || n_sensors > JM_NOISE_MAX_ROT || !bias))
+        return fail(JM_EINVAL, "jm_block_sensor_noise: the rotation bias applies to IMU fields (6 rows) with a bias");
+    if (!noise_std && !bias) return JM_OK;
+    jm::NoiseParams p{};
+    p.n_sensors = n_sensors; p.n_fields = n_fields;
+    p.has_noise = noise_std != nullptr; p.has_bias = bias != nullptr; p.has_rot = rot_bias_inv != nullptr;
+    for (int i = 0; i < n_sensors * n_fields; ++i)
+    {
+        if (noise_std)
+        {
+            if (!(noise_std[i] >= 0.0)) return fail(JM_EINVAL, "jm_block_sensor_noise: negative noise standard deviation");
+            p.noise_std[i] = (float)noise_std[i];
+        }
+        if (bias) p.bias[i] = bias[i];
+    }
+    if (rot_bias_inv)
+        for (int s = 0; s < n_sensors; ++s)
+            for (int k = 0; k < 9; ++k) p.rot[s][k] = rot_bias_inv[9 * s + k];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    // ziggurat tables: computed once on the host (random.cc:66-96), one copy per device
+    static std::mutex mtx;
+    static std::map<int, jm::rnd::ZigguratTables *> tables;
+    jm::rnd::ZigguratTables * tab = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mtx);
+        auto it = tables.find(dev);
+        if (it == tables.end())
+        {
+            jm::rnd::ZigguratTables host;
+            jm::rnd::ziggurat_tables(host);
+            HIP_TRY(hipMalloc((void **)&tab, sizeof(host)));
+            HIP_TRY(hipMemcpy(tab, &host, sizeof(host), hipMemcpyHostToDevice));
+            tables[dev] = tab;
+        }
+        else tab = it->second;
+    }
+    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)n_sensors);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_sensor_noise<double>), grid, dim3(256), 0, s, p, tab, (double *)data, rng_state, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_sensor_noise<float>), grid, dim3(256), 0, s, p, tab, (float *)data, rng_state, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_sensor_rng_seed(const uint32_t * group_seed, int64_t B, int32_t n_sensors, uint64_t * state_out)
+{
+    if (!group_seed || !state_out || B <= 0 || n_sensors <= 0) return fail(JM_EINVAL, "jm_sensor_rng_seed: bad arguments");
+    std::vector<uint32_t> words((size_t)n_sensors);
+    for (int64_t lane = 0; lane < B; ++lane)
+    {
+        std::seed_seq seq{group_seed[lane]};
+        seq.generate(words.begin(), words.end());
+        for (int32_t s = 0; s < n_sensors; ++s) state_out[(size_t)s * B + lane] = jm::rnd::pcg32_init(words[s]);
+    }
     return JM_OK;
 }
 

@@ -1,0 +1,164 @@
+// jm_random.h -- sensor white noise and bias as a batched HIP kernel: one PCG32 stream per
+// (sensor, lane), consumed exactly like the reference consumes the per-sensor generator.
+//
+// Reference:
+//   PCG32 (pcg32_fast: 64-bit MCG, XSH-RS output)      core/src/utilities/random.cc:10-37
+//   uniform = std::generate_canonical<float, 24>        core/src/utilities/random.cc:41-44
+//   normal  = ziggurat, 128 strips, float arithmetic    core/src/utilities/random.cc:52-167
+//   AbstractSensorBase::measureData (noise, then bias)  core/src/hardware/abstract_sensor.cc:71-85
+//   ImuSensor::measureData (+ rotation bias)            core/src/hardware/basic_sensors.cc:166-187
+//   generator seeding, one std::seed_seq per sensor group  core/include/jiminy/core/hardware/abstract_sensor.hxx:213-226
+// The integer stream (PCG32 outputs, strip index, fast-path samples = 98.8 % of the draws) is
+// bit-exact; the wedge / tail samples go through logf / expf, whose device implementation may
+// differ from glibc's in the last float ulp.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifndef JM_HOST_EMU
+#include <hip/hip_runtime.h>
+#define JM_RDEV __host__ __device__ inline
+#else
+#define JM_RDEV inline
+#endif
+
+#include "../../include/jiminy_hip.h"
+
+namespace jm
+{
+namespace rnd
+{
+// random.cc:10-13: the constructor forces the two low bits (an MCG needs an odd state)
+JM_RDEV uint64_t pcg32_init(uint64_t seed) { return seed | 3ULL; }
+// random.cc:15-37 with the constants folded: opBits = 3, xShift = 22, bottomSpare - randShiftMax = 22
+JM_RDEV uint32_t pcg32_next(uint64_t & state)
+{
+    state *= 6364136223846793005ULL;
+    uint64_t s = state;
+    const unsigned rshift = (unsigned)(s >> 61);
+    s ^= s >> 22;
+    return (uint32_t)(s >> (22u + rshift));
+}
+// std::generate_canonical<float, 24> over a 32-bit generator (libstdc++ bits/random.tcc): one
+// draw, float(g()) / 2^32, results that round up to 1 are replaced by nextafter(1, 0)
+JM_RDEV float uniform01(uint64_t & state)
+{
+    const float r = (float)pcg32_next(state) / 4294967296.0f;
+    return r >= 1.0f ? 0.99999994f : r;
+}
+
+struct ZigguratTables
+{
+    uint32_t kn[128];
+    float fn[128], wn[128];
+};
+// random.cc:66-96 (host, double precision, evaluated once)
+inline void ziggurat_tables(ZigguratTables & z)
+{
+    const double m1 = 2147483648.0;
+    const double vn = 9.91256303526217e-03;
+    double dn = 3.442619855899, tn = dn;
+    const double q = vn / std::exp(-0.5 * dn * dn);
+    z.kn[0] = (uint32_t)((dn / q) * m1);
+    z.kn[1] = 0;
+    z.wn[0] = (float)(q / m1);
+    z.wn[127] = (float)(dn / m1);
+    z.fn[0] = 1.0f;
+    z.fn[127] = (float)std::exp(-0.5 * dn * dn);
+    for (int i = 126; i >= 1; --i)
+    {
+        dn = std::sqrt(-2.0 * std::log(vn / dn + std::exp(-0.5 * dn * dn)));
+        z.kn[i + 1] = (uint32_t)((dn / tn) * m1);
+        tn = dn;
+        z.fn[i] = (float)std::exp(-0.5 * dn * dn);
+        z.wn[i] = (float)(dn / m1);
+    }
+}
+// random.cc:103-160. `std::fabs(hz)` of an int32 is a double; the comparison is done in double.
+template<class Tab> JM_RDEV float normal01(uint64_t & state, const Tab & kn, const float * fn, const float * wn)
+{
+    // the reference is built without FMA contraction: keep `a + b * c` as two roundings
+#pragma clang fp contract(off)
+    const float r = 3.442620f;
+    int32_t hz = (int32_t)pcg32_next(state);
+    uint32_t iz = (uint32_t)hz & 127u;
+    if (fabs((double)hz) < (double)kn[iz]) return (float)hz * wn[iz];
+    for (;;)
+    {
+        float x, y;
+        if (iz == 0)
+        {
+            for (;;)
+            {
+                x = -0.2904764f * logf(uniform01(state));
+                y = -logf(uniform01(state));
+                if (x * x <= y + y) break;
+            }
+            return hz <= 0 ? -r - x : r + x;
+        }
+        x = (float)hz * wn[iz];
+        if (fn[iz] + uniform01(state) * (fn[iz - 1] - fn[iz]) < expf(-0.5f * x * x)) return x;
+        hz = (int32_t)pcg32_next(state);
+        iz = (uint32_t)hz & 127u;
+        if (fabs((double)hz) < (double)kn[iz]) return (float)hz * wn[iz];
+    }
+}
+}  // namespace rnd
+
+struct NoiseParams
+{
+    int n_sensors, n_fields;
+    int has_noise, has_bias, has_rot;
+    float noise_std[JM_NOISE_MAX_ROWS];      // [sensor][field]
+    double bias[JM_NOISE_MAX_ROWS];          // [sensor][field] (IMU: the last 6 of its 9 bias entries)
+    double rot[JM_NOISE_MAX_ROT][9];         // IMU: exp3(-bias.head<3>()), row-major
+};
+
+#ifndef JM_HOST_EMU
+// data: [n_sensors * n_fields][B] (row = sensor * n_fields + field), rng: [n_sensors][B]
+template<class T>
+__global__ void __launch_bounds__(256) k_sensor_noise(const NoiseParams p, const rnd::ZigguratTables * tables, T * data,
+                                                      uint64_t * rng, long long B)
+{
+    __shared__ uint32_t kn[128];
+    __shared__ float fn[128], wn[128];
+    if (threadIdx.x < 128)
+    {
+        kn[threadIdx.x] = tables->kn[threadIdx.x];
+        fn[threadIdx.x] = tables->fn[threadIdx.x];
+        wn[threadIdx.x] = tables->wn[threadIdx.x];
+    }
+    __syncthreads();
+    const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (lane >= B) return;
+    T * d = data + (long long)s * p.n_fields * B + lane;
+    double x[JM_NOISE_MAX_FIELDS];
+    for (int f = 0; f < p.n_fields; ++f) x[f] = (double)d[(long long)f * B];
+    if (p.has_noise)
+    {
+        uint64_t st = rng[(long long)s * B + lane];
+        // get() += normal(generator_, 0.0F, noiseStd.cast<float>()).cast<double>()
+        for (int f = 0; f < p.n_fields; ++f)
+            x[f] += (double)(rnd::normal01(st, kn, fn, wn) * p.noise_std[s * p.n_fields + f] + 0.0f);
+        rng[(long long)s * B + lane] = st;
+    }
+    if (p.has_bias)
+    {
+        for (int f = 0; f < p.n_fields; ++f) x[f] += p.bias[s * p.n_fields + f];
+        if (p.has_rot)
+        {
+            const double * R = p.rot[s];
+            for (int h = 0; h < 6; h += 3)
+            {
+                const double a = x[h], b = x[h + 1], c = x[h + 2];
+                x[h] = R[0] * a + R[1] * b + R[2] * c;
+                x[h + 1] = R[3] * a + R[4] * b + R[5] * c;
+                x[h + 2] = R[6] * a + R[7] * b + R[8] * c;
+            }
+        }
+    }
+    for (int f = 0; f < p.n_fields; ++f) d[(long long)f * B] = (T)x[f];
+}
+#endif
+}  // namespace jm

@@ -28,6 +28,7 @@ from .model import (JT_FREEFLYER, JT_RUBU, JT_RUBX, JT_RUBY, JT_RUBZ, CompiledMo
 
 # constants of reference core/include/jiminy/core/constants.h:18-20
 STEPPER_MIN_TIMESTEP = 1e-10
+INIT_ITERATIONS = 4   # engine.cc:61
 SIMULATION_MIN_TIMESTEP = 1e-6
 SIMULATION_MAX_TIMESTEP = 0.02
 EPS = float(np.finfo(np.float64).eps)
@@ -164,6 +165,18 @@ class StepperState:
     iter_failed_lanes: Optional[torch.Tensor] = None
 
 
+def _exp3(w: np.ndarray) -> np.ndarray:
+    """Rodrigues' formula with pinocchio::exp3's small-angle series (explog.hpp, v2.7.0)."""
+    t2 = float(w @ w)
+    t = math.sqrt(t2)
+    K = np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+    if t < 1e-8:   # TaylorSeriesExpansion precision
+        a, b = 1.0 - t2 / 6.0, 0.5 - t2 / 24.0
+    else:
+        a, b = math.sin(t) / t, (1.0 - math.cos(t)) / t2
+    return np.eye(3) + a * K + b * (K @ K)
+
+
 _VERIFIED: Dict[Tuple[str, torch.dtype], int] = {}
 
 
@@ -234,7 +247,7 @@ def _library_self_test(model: CompiledModel, variant: int, dtype: torch.dtype, d
 def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
     """The HIP library of `model`, checked once per process, topology and dtype by
     `_library_self_test`.  A build that fails the check is a toolchain mis-compile (DESIGN.md
-    section 4.6): the next build variant (codegen.BUILD_VARIANTS) is compiled and checked instead;
+    section 4.7): the next build variant (codegen.BUILD_VARIANTS) is compiled and checked instead;
     when none passes the engine refuses to run rather than integrate garbage."""
     key = (model.topology_hash(), dtype)
     if key in _VERIFIED:
@@ -309,6 +322,7 @@ class BatchedEngine:
         self._iter = 0
         self._command_dirty = True
         self._adaptive: Optional[Dict[str, torch.Tensor]] = None
+        self._sensor_noise: Dict[str, Dict[str, Any]] = {}
         self.adaptive_attempts = 0   # device attempts of the last `step` with the adaptive solver
         self._apply_options()
 
@@ -498,6 +512,11 @@ class BatchedEngine:
         self._dt = 0.0
         self._iter = 0
         self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
+        if self._sensor_noise:
+            # `Engine::start` measures the sensors INIT_ITERATIONS times while it solves the initial
+            # acceleration / sensor / controller coupling, then once more (engine.cc:61,1400-1441,
+            # 1470-1480): same number of draws here, so that the streams stay aligned
+            self._apply_sensor_noise(discard_rounds=INIT_ITERATIONS)
         self._setup_adaptive()
         self._running = True
         self._command_dirty = False
@@ -547,6 +566,12 @@ class BatchedEngine:
             if changed:
                 self._command_dirty = False
             self.adaptive_attempts += int(attempts.value)
+            if sens and self._sensor_noise:
+                if float(st["sensorsUpdatePeriod"]) <= 0.0:
+                    raise NotImplementedError(
+                        "sensor noise with the adaptive solver needs a positive sensorsUpdatePeriod "
+                        "(lanes take different internal steps)")
+                self._apply_sensor_noise()
         self._t_prev = self._t
         self._t = t_end
         self._t_error = t_err
@@ -564,12 +589,17 @@ class BatchedEngine:
         launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options)
         solver = SOLVER_IDS[self._options["stepper"]["odeSolver"]]
         stream = self._stream()
+        # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
+        per_step_noise = bool(self._sensor_noise) and float(self._options["stepper"]["sensorsUpdatePeriod"]) <= 0.0
         for dt, n, cmd_bp, sens in launches:
-            changed = cmd_bp and self._command_dirty
-            self._lib.check(self._L.jm_batch_step(self._batch_h, solver, dt, n, int(changed),
-                                                  int(sens), stream))
-            if changed:
-                self._command_dirty = False
+            for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
+                changed = cmd_bp and self._command_dirty and k == 0
+                self._lib.check(self._L.jm_batch_step(self._batch_h, solver, dt, n_k, int(changed),
+                                                      int(sens), stream))
+                if changed:
+                    self._command_dirty = False
+                if sens and self._sensor_noise:
+                    self._apply_sensor_noise()
             self._iter += n
             self._dt = dt
         self._t_prev = self._t
@@ -608,6 +638,95 @@ class BatchedEngine:
             ad["f64"][1:4, m_] = SIMULATION_MIN_TIMESTEP
             ad["f64"][0, m_] = self._t
             ad["i32"][:, m_] = 0
+
+    # ------------------------------------------------------------------ sensor noise and bias
+    _SENSOR_FIELDS = {"ImuSensor": ("imu", 6), "ForceSensor": ("force", 6), "ContactSensor": ("contact", 3),
+                      "EncoderSensor": ("encoder", 2), "EffortSensor": ("effort", 1)}
+
+    def set_sensor_options(self, sensor_type: str, noise_std: Any = None, bias: Any = None) -> None:
+        """≙ `sensor.set_options({"noiseStd": ..., "bias": ...})` for every sensor of one type
+        (reference abstract_sensor.h:66-100): white noise and bias applied to the raw measurement
+        after every sensor refresh (`AbstractSensorBase::measureData`, abstract_sensor.cc:71-85;
+        `ImuSensor::measureData`, basic_sensors.cc:166-187).  `noise_std` is `(n_fields,)` or
+        `(n_sensors, n_fields)`; `bias` likewise, except for IMUs where it has 9 entries: a rotation
+        bias (angle-axis) followed by the gyroscope and accelerometer biases.  `None` leaves the
+        option empty.  Not allowed while a simulation is running (abstract_sensor.cc:87-96)."""
+        if self._running:
+            raise BadControlFlow("Robot already locked, probably because a simulation is running. "
+                                 "Please stop it before setting sensor options.")
+        if sensor_type not in self._SENSOR_FIELDS:
+            raise LookupError(f"unknown sensor type '{sensor_type}'")
+        field, nf = self._SENSOR_FIELDS[sensor_type]
+        n = len(self.model.sensors.get(sensor_type, []))
+        if n == 0:
+            raise LookupError(f"the robot has no sensor of type '{sensor_type}'")
+        nb = 9 if sensor_type == "ImuSensor" else nf
+
+        def table(x, cols, what):
+            if x is None:
+                return None
+            a = np.asarray(x, dtype=np.float64)
+            if a.ndim == 1:
+                a = np.tile(a[None, :], (n, 1))
+            if a.shape != (n, cols):
+                raise ValueError(f"{what} must have shape ({cols},) or ({n}, {cols})")
+            return np.ascontiguousarray(a)
+        std, b = table(noise_std, nf, "noise_std"), table(bias, nb, "bias")
+        if std is None and b is None:
+            self._sensor_noise.pop(sensor_type, None)
+            return
+        if std is not None and np.any(std < 0.0):
+            raise ValueError("noise_std must be non-negative")
+        entry: Dict[str, Any] = {"field": field, "n": n, "nf": nf, "std": std, "bias": None, "rot": None,
+                                 "rng": self._sensor_noise.get(sensor_type, {}).get("rng")}
+        if b is not None:
+            if sensor_type == "ImuSensor":
+                # sensorRotationBiasInv_ = exp3(-bias.head<3>()) (basic_sensors.cc:121-129)
+                entry["rot"] = np.ascontiguousarray(np.stack([_exp3(-b[i, :3]).reshape(9) for i in range(n)]))
+                entry["bias"] = np.ascontiguousarray(b[:, 3:])
+            else:
+                entry["bias"] = b
+        self._sensor_noise[sensor_type] = entry
+
+    def seed_sensors(self, seeds: Any) -> None:
+        """Seed the per-(sensor, lane) PCG32 generators, ≙ `AbstractSensorTpl::resetAll(seed)`
+        (abstract_sensor.hxx:213-226) for every lane.  `seeds` maps a sensor type to the `(B,)`
+        uint32 group seeds the reference would draw with `g()` in `Robot::reset` (robot.cc:135-141);
+        an `int` derives them as `seed + lane * n_types + index(type)` (types in sorted order; the
+        reference iterates an unordered_map there, so it defines no order to mirror)."""
+        types = sorted(self._sensor_noise)
+        B = self.batch_size
+        for g, stype in enumerate(types):
+            e = self._sensor_noise[stype]
+            if isinstance(seeds, dict):
+                if stype not in seeds:
+                    continue
+                gs = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds[stype], dtype=np.uint32), (B,)))
+            else:
+                gs = ((int(seeds) + np.arange(B, dtype=np.uint64) * len(types) + g) & 0xFFFFFFFF).astype(np.uint32)
+            out = np.empty((e["n"], B), dtype=np.uint64)
+            self._lib.check(self._L.jm_sensor_rng_seed(
+                gs.ctypes.data_as(C.POINTER(C.c_uint32)), B, e["n"], out.ctypes.data_as(C.POINTER(C.c_uint64))))
+            e["rng"] = torch.from_numpy(out.view(np.int64)).to(self.device)
+
+    def _apply_sensor_noise(self, discard_rounds: int = 0) -> None:
+        dp = C.POINTER(C.c_double)
+        dtype = _abi.JM_F64 if self.dtype == torch.float64 else _abi.JM_F32
+        for stype, e in self._sensor_noise.items():
+            if e["std"] is not None and e["rng"] is None:
+                raise BadControlFlow(f"{stype}: noise is enabled but the generators were never seeded "
+                                     "(call seed_sensors first)")
+            ptr = lambda a: a.ctypes.data_as(dp) if a is not None else None  # noqa: E731
+            rng = C.c_void_p(e["rng"].data_ptr()) if e["rng"] is not None else None
+            if discard_rounds and e["std"] is not None:
+                scratch = torch.zeros_like(self._fields[e["field"]])
+                for _ in range(discard_rounds):
+                    self._lib.check(self._L.jm_block_sensor_noise(
+                        dtype, self.batch_size, e["n"], e["nf"], C.c_void_p(scratch.data_ptr()), rng,
+                        ptr(e["std"]), None, None, self._stream()))
+            self._lib.check(self._L.jm_block_sensor_noise(
+                dtype, self.batch_size, e["n"], e["nf"], C.c_void_p(self._fields[e["field"]].data_ptr()), rng,
+                ptr(e["std"]), ptr(e["bias"]), ptr(e["rot"]), self._stream()))
 
     # ------------------------------------------------------------------ measurement helpers
     def enable_timing(self, enable: bool = True) -> None:

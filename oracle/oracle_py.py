@@ -17,10 +17,10 @@ _LIB: Optional[C.CDLL] = None
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "oracle.cpp")
-    hdr = os.path.join(_HERE, "..", "include", "jiminy_hip.h")
+    srcs = (os.path.join(_HERE, "oracle.cpp"), os.path.join(_HERE, "oracle_random.cpp"),
+            os.path.join(_HERE, "..", "include", "jiminy_hip.h"))
     stale = (not os.path.exists(path)) or any(
-        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in (src, hdr))
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -70,6 +70,17 @@ def lib() -> C.CDLL:
         L.orc_integrate.argtypes = [C.c_void_p, pd, pd, pd]
         L.orc_batch_run.argtypes = [C.c_void_p, C.POINTER(BatchIO), C.c_int, C.c_int, C.c_double,
                                     C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]
+        u32p, u64p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+        L.orc_pcg32_stream.argtypes = [u64p, C.c_int64, u32p]
+        L.orc_uniform_stream.argtypes = [u64p, C.c_int64, fp]
+        L.orc_normal_stream.argtypes = [u64p, C.c_int64, fp]
+        L.orc_ziggurat_tables.argtypes = [u32p, fp, fp]
+        L.orc_seed_seq.argtypes = [C.c_uint32, C.c_int32, u32p]
+        L.orc_sensor_rng_seed.argtypes = [u32p, C.c_int64, C.c_int32, u64p]
+        L.orc_sensor_noise.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, u64p, pd, pd, pd]
+        for f in (L.orc_pcg32_stream, L.orc_uniform_stream, L.orc_normal_stream, L.orc_ziggurat_tables,
+                  L.orc_seed_seq, L.orc_sensor_rng_seed, L.orc_sensor_noise):
+            f.restype = None
         L.orc_batch_run_dopri.argtypes = [C.c_void_p, C.POINTER(BatchIO), C.POINTER(AdaptiveIO), C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int64, C.c_int64]
@@ -205,3 +216,53 @@ class OracleEngine:
                                     float(tol_abs), float(dt_max), float(dt_restore_threshold_rel),
                                     int(successive_iter_failed_max), int(new_step), int(command_changed),
                                     int(update_sensors), lo, hi)
+
+
+# ---- sensor noise path (oracle_random.cpp)
+def pcg32_stream(state: int, n: int, kind: str = "bits"):
+    """`n` outputs of one PCG32 stream started from `state` (already or-ed with 3 by the
+    constructor): raw 32-bit words ("bits"), uniform01 ("uniform") or normal01 ("normal").
+    Returns (values, final state)."""
+    st = C.c_uint64(state)
+    if kind == "bits":
+        out = np.empty(n, dtype=np.uint32)
+        lib().orc_pcg32_stream(C.byref(st), n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    else:
+        out = np.empty(n, dtype=np.float32)
+        fn = lib().orc_uniform_stream if kind == "uniform" else lib().orc_normal_stream
+        fn(C.byref(st), n, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out, int(st.value)
+
+
+def ziggurat_tables():
+    kn, fn, wn = np.empty(128, np.uint32), np.empty(128, np.float32), np.empty(128, np.float32)
+    lib().orc_ziggurat_tables(kn.ctypes.data_as(C.POINTER(C.c_uint32)), fn.ctypes.data_as(C.POINTER(C.c_float)),
+                              wn.ctypes.data_as(C.POINTER(C.c_float)))
+    return kn, fn, wn
+
+
+def seed_seq(seed: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint32)
+    lib().orc_seed_seq(seed, n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def sensor_rng_seed(group_seed: np.ndarray, n_sensors: int) -> np.ndarray:
+    gs = np.ascontiguousarray(group_seed, dtype=np.uint32)
+    out = np.empty((n_sensors, gs.shape[0]), dtype=np.uint64)
+    lib().orc_sensor_rng_seed(gs.ctypes.data_as(C.POINTER(C.c_uint32)), gs.shape[0], n_sensors,
+                              out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
+
+
+def sensor_noise(data: np.ndarray, rng: np.ndarray, n_sensors: int, n_fields: int, noise_std=None, bias=None,
+                 rot=None) -> None:
+    """In place on `data` `[n_sensors * n_fields][B]` float64 and `rng` `[n_sensors][B]` uint64."""
+    assert data.dtype == np.float64 and data.flags.c_contiguous and data.shape[0] == n_sensors * n_fields
+    assert rng is None or (rng.dtype == np.uint64 and rng.flags.c_contiguous)
+    pd = C.POINTER(C.c_double)
+    arr = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    std, b, r = arr(noise_std), arr(bias), arr(rot)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(pd)  # noqa: E731
+    lib().orc_sensor_noise(data.shape[1], n_sensors, n_fields, data.ctypes.data_as(pd),
+                           None if rng is None else rng.ctypes.data_as(C.POINTER(C.c_uint64)), ptr(std), ptr(b), ptr(r))

@@ -93,7 +93,7 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
 def test_library_self_test_guards_against_miscompiled_builds(gpu_device, monkeypatch):
     """Every HIP library is checked on first use (engine._verified_library): a build whose in-loop
     evaluation disagrees with its peeled copy is replaced by the next build variant.  crane_walker's
-    default-flag build is such a case with hipcc 7.2 (DESIGN.md section 4.6); whichever variant ends
+    default-flag build is such a case with hipcc 7.2 (DESIGN.md section 4.7); whichever variant ends
     up selected, the engine must match the oracle."""
     from jiminy_amd import codegen, engine as engine_mod
     from tests import robots
@@ -401,3 +401,70 @@ def test_adaptive_dopri_with_controller_breakpoints_and_contacts(gpu_device):
     err = np.abs(eng.field("q").cpu().numpy() - ref["q"]).max(axis=0)[ok & ((stt & 9) == 0)]
     assert np.median(err) < 1e-6 and (err < 1e-2).mean() > 0.95, (np.median(err), err.max())
     assert abs(eng.stepper_state.t - 0.04) < 1e-12
+
+
+@pytest.mark.parametrize("name,B", [("anymal", 1), ("anymal", 3), ("anymal", 65), ("cartpole", 1), ("cartpole", 67)])
+def test_ragged_and_tiny_batches(gpu_device, name, B):
+    """Batch sizes that fill neither a quad-wave (16 robots) nor a block: the tail lanes must be
+    computed, the padding lanes must not touch memory (guard rows around every field)."""
+    model = load_builtin(name)
+    dt = 1e-3
+    st = sample_states(model, B, seed=17)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    for i in range(5):
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        eng.step(dt)
+    ok = (ref["status"][0] & 1) == 0
+    for k in OUTS:
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-9, k
+    assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
+
+
+def test_empty_batch_is_rejected(gpu_device):
+    with pytest.raises(ValueError, match="batch size must be positive"):
+        BatchedEngine(load_builtin("cartpole"), 0)
+
+
+def test_full_size_batch_replica_invariance_and_repeatability(gpu_device):
+    """BASELINE size (ANYmal, B = 65 536), checked through size-independent properties: the batch is
+    256 replicas of one seeded 256-lane block, so (i) every replica must equal the first one bit for
+    bit wherever it sits in the grid, (ii) the first block must match the oracle, (iii) re-running
+    from the same state after `stop()` reproduces the result bit for bit (the reference's own pin:
+    gym_jiminy unit_py/test_pipeline_control.py:315-330)."""
+    model = load_builtin("anymal")
+    blk, reps, dt, steps = 256, 256, 1e-3, 10
+    B = blk * reps
+    st = sample_states(model, blk, seed=23)
+    q = torch.from_numpy(np.tile(st["q"], (1, reps)))
+    v = torch.from_numpy(np.tile(st["v"], (1, reps)))
+    cmd = torch.from_numpy(np.tile(st["command"], (1, reps)))
+    ref = alloc_soa(model, blk)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    for i in range(steps):
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    runs = []
+    for rep in range(2):
+        eng.set_command(cmd)
+        eng.start(q, v)
+        for i in range(steps):
+            eng.step(dt)
+        runs.append({k: eng.field(k).clone() for k in OUTS})
+        eng.stop()
+    ok = (ref["status"][0] & 1) == 0
+    for k in OUTS:
+        x = runs[0][k]
+        first = x[:, :blk]
+        assert torch.equal(x.view(x.shape[0], reps, blk), first[:, None, :].expand(-1, reps, -1)) or \
+            bool(((x.view(x.shape[0], reps, blk) == first[:, None, :]) | torch.isnan(first[:, None, :])).all()), k
+        assert rel_err(first.cpu().numpy(), ref[k], ok) < 1e-9, k
+        same = (runs[0][k] == runs[1][k]) | (torch.isnan(runs[0][k]) & torch.isnan(runs[1][k]))
+        assert bool(same.all()), k

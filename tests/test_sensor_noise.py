@@ -1,0 +1,279 @@
+"""Sensor white noise / bias path (sensor part).
+
+CPU part: the oracle (oracle/oracle_random.cpp) against independent restatements -- PCG-XSH-RS 64/32
+(MCG) in Python integers, std::seed_seq from its specification ([rand.util.seedseq]) in numpy, the
+ziggurat against the normal distribution (moments, Kolmogorov-Smirnov, tail mass).
+GPU part (`-m gpu`): jm_block_sensor_noise / jm_sensor_rng_seed through the C ABI against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py
+
+M64 = (1 << 64) - 1
+MULT = 6364136223846793005
+
+
+def py_pcg32(state, n):
+    """pcg32_fast of the PCG paper (mcg_xsh_rs_64_32): state *= MULT; output of the new state."""
+    out = []
+    for _ in range(n):
+        state = (state * MULT) & M64
+        s = state
+        rshift = s >> 61
+        s ^= s >> 22
+        out.append((s >> (22 + rshift)) & 0xFFFFFFFF)
+    return out, state
+
+
+def py_seed_seq(seeds, n):
+    """std::seed_seq::generate, transcribed from the C++ standard [rand.util.seedseq]/8."""
+    v = [s & 0xFFFFFFFF for s in seeds]
+    s = len(v)
+    b = [0x8B8B8B8B] * n
+    t = 11 if n >= 623 else 7 if n >= 68 else 5 if n >= 39 else 3 if n >= 7 else (n - 1) // 2
+    p = (n - t) // 2
+    q = p + t
+    m = max(s + 1, n)
+    T = lambda x: (x ^ (x >> 27)) & 0xFFFFFFFF  # noqa: E731
+    for k in range(m):
+        r1 = (1664525 * T(b[k % n] ^ b[(k + p) % n] ^ b[(k - 1) % n])) & 0xFFFFFFFF
+        if k == 0:
+            r2 = r1 + s
+        elif k <= s:
+            r2 = r1 + (k % n) + v[k - 1]
+        else:
+            r2 = r1 + (k % n)
+        r2 &= 0xFFFFFFFF
+        b[(k + p) % n] = (b[(k + p) % n] + r1) & 0xFFFFFFFF
+        b[(k + q) % n] = (b[(k + q) % n] + r2) & 0xFFFFFFFF
+        b[k % n] = r2
+    for k in range(m, m + n):
+        r3 = (1566083941 * T((b[k % n] + b[(k + p) % n] + b[(k - 1) % n]) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        r4 = (r3 - (k % n)) & 0xFFFFFFFF
+        b[(k + p) % n] ^= r3
+        b[(k + q) % n] ^= r4
+        b[k % n] = r4
+    return b
+
+
+@pytest.mark.parametrize("seed", [0, 1, 0xcafef00dd15ea5e5, 2**64 - 1, 123456789])
+def test_oracle_pcg32_is_the_mcg_xsh_rs_generator(seed):
+    want, st_want = py_pcg32(seed | 3, 257)       # random.cc:10-13: the constructor ors the state with 3
+    got, st_got = oracle_py.pcg32_stream(seed, 257)
+    assert got.tolist() == want and st_got == st_want
+
+
+def test_pcg32_jump_law():
+    """An MCG's state after n draws is state * MULT^n: a size-independent check of a long stream."""
+    n = 1_000_003
+    _, st = oracle_py.pcg32_stream(42, n)
+    assert st == ((42 | 3) * pow(MULT, n, 1 << 64)) & M64
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (0, 4), (7, 3), (2**32 - 1, 8), (12345, 39), (99, 70)])
+def test_seed_seq_matches_the_standard_algorithm(seed, n):
+    assert oracle_py.seed_seq(seed, n).tolist() == py_seed_seq([seed], n)
+
+
+def test_sensor_generators_are_seeded_per_sensor_from_the_group_seed():
+    gs = np.array([0, 1, 77, 2**32 - 1], dtype=np.uint32)
+    st = oracle_py.sensor_rng_seed(gs, 5)
+    for lane, g in enumerate(gs):
+        words = py_seed_seq([int(g)], 5)
+        assert st[:, lane].tolist() == [w | 3 for w in words]
+
+
+def test_uniform_is_generate_canonical_of_one_word():
+    bits, _ = oracle_py.pcg32_stream(5, 4096)
+    u, _ = oracle_py.pcg32_stream(5, 4096, "uniform")
+    want = bits.astype(np.float32) / np.float32(4294967296.0)
+    want[want >= 1.0] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    assert np.array_equal(u, want) and u.min() >= 0.0 and u.max() < 1.0
+
+
+def test_ziggurat_tables_and_fast_path():
+    kn, fn, wn = oracle_py.ziggurat_tables()
+    assert fn[0] == 1.0 and np.all(np.diff(fn) < 0) and kn[1] == 0 and np.all(np.diff(wn[1:]) > 0)
+    # the strip boundaries x_i = wn[i] * 2^31 satisfy fn[i] = exp(-x_i^2 / 2)
+    x = wn.astype(np.float64) * 2147483648.0
+    assert np.allclose(fn[1:], np.exp(-0.5 * x[1:] ** 2), rtol=2e-6)
+    # fast path: |hz| < kn[iz]  ->  hz * wn[iz]
+    bits, _ = oracle_py.pcg32_stream(9, 20000)
+    z, _ = oracle_py.pcg32_stream(9, 20000, "normal")
+    hz = bits.view(np.int32)
+    i = 0
+    checked = 0
+    for k in range(2000):            # walk the stream while only fast-path samples were drawn
+        iz = int(hz[i]) & 127
+        if abs(int(hz[i])) < int(kn[iz]):
+            assert z[k] == np.float32(hz[i]) * wn[iz]
+            i += 1
+            checked += 1
+        else:
+            break
+    assert checked > 20
+
+
+def test_ziggurat_is_standard_normal():
+    from scipy import stats
+    n = 2_000_000
+    z, _ = oracle_py.pcg32_stream(2024, n, "normal")
+    z = z.astype(np.float64)
+    assert abs(z.mean()) < 4.0 / np.sqrt(n)
+    assert abs(z.var() - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(stats.skew(z)) < 0.01 and abs(stats.kurtosis(z)) < 0.02
+    assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
+    tail = np.mean(np.abs(z) > 3.442620)       # mass beyond the ziggurat base strip
+    assert abs(tail - 2 * stats.norm.sf(3.442620)) < 5e-5
+
+
+def test_oracle_measure_data_order_noise_then_bias_then_rotation():
+    """AbstractSensorBase::measureData / ImuSensor::measureData on known numbers."""
+    B, n, nf = 3, 2, 6
+    data = np.arange(n * nf * B, dtype=np.float64).reshape(n * nf, B).copy()
+    d0 = data.copy()
+    rng = oracle_py.sensor_rng_seed(np.array([5, 6, 7], dtype=np.uint32), n)
+    rng0 = rng.copy()
+    std = np.array([[0.1, 0.2, 0.3, 0.4, 0.5, 0.6], [0, 0, 0, 1, 1, 1]], dtype=np.float64)
+    bias = np.arange(12, dtype=np.float64).reshape(2, 6) * 0.01
+    th = 0.3
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    rot = np.stack([Rz.reshape(9), np.eye(3).reshape(9)])
+    oracle_py.sensor_noise(data, rng, n, nf, std, bias, rot)
+    for s in range(n):
+        for l in range(B):
+            z, st = oracle_py.pcg32_stream(int(rng0[s, l]), nf, "normal")
+            assert st == int(rng[s, l])
+            x = d0[s * nf:(s + 1) * nf, l] + (z * std[s].astype(np.float32) + np.float32(0)).astype(np.float64) + bias[s]
+            R = rot[s].reshape(3, 3)
+            want = np.concatenate([R @ x[:3], R @ x[3:]])
+            assert np.allclose(data[s * nf:(s + 1) * nf, l], want, rtol=0, atol=1e-14)
+    # noise-free call leaves the generators alone
+    rng1 = rng.copy()
+    oracle_py.sensor_noise(data, rng, n, nf, None, bias, None)
+    assert np.array_equal(rng, rng1)
+
+
+# --------------------------------------------------------------------------- GPU: C ABI vs oracle
+def _ulp_diff(a, b):
+    ai = a.astype(np.float32).view(np.int32).astype(np.int64)
+    bi = b.astype(np.float32).view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name", ["f64", "f32"])
+def test_hip_sensor_noise_matches_oracle(gpu_device, dtype_name):
+    """jm_sensor_rng_seed is bit-exact; jm_block_sensor_noise reproduces the oracle's generator
+    states bit for bit after 50 rounds (every accept / reject decision agreed) and its noise to
+    <= 1 float ulp (the wedge / tail samples go through the device's logf / expf)."""
+    import torch
+    from jiminy_amd import _abi, _lib, load_builtin
+    lib = _lib.load_for(load_builtin("cartpole"))
+    B, n, nf, rounds = 4099, 3, 6, 50
+    tdt = torch.float64 if dtype_name == "f64" else torch.float32
+    gs = (np.arange(B, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    st_host = np.empty((n, B), dtype=np.uint64)
+    lib.check(lib.L.jm_sensor_rng_seed(gs.ctypes.data_as(C.POINTER(C.c_uint32)), B, n,
+                                       st_host.ctypes.data_as(C.POINTER(C.c_uint64))))
+    st_ref = oracle_py.sensor_rng_seed(gs, n)
+    assert np.array_equal(st_host, st_ref)
+    std = np.linspace(0.05, 2.0, n * nf).reshape(n, nf)
+    bias = np.linspace(-1.0, 1.0, n * nf).reshape(n, nf)
+    th = np.array([0.2, -0.4, 0.0])
+    rot = np.stack([np.array([[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1.0]]).reshape(9) for t in th])
+    rng_dev = torch.from_numpy(st_host.view(np.int64).copy()).cuda()
+    dp = C.POINTER(C.c_double)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    worst = 0
+    for r in range(rounds):
+        base = np.random.default_rng(r).standard_normal((n * nf, B))
+        if dtype_name == "f32":
+            base = base.astype(np.float32).astype(np.float64)
+        data_dev = torch.from_numpy(base).to(tdt).cuda()
+        lib.check(lib.L.jm_block_sensor_noise(
+            _abi.JM_F64 if dtype_name == "f64" else _abi.JM_F32, B, n, nf, C.c_void_p(data_dev.data_ptr()),
+            C.c_void_p(rng_dev.data_ptr()), std.ctypes.data_as(dp), bias.ctypes.data_as(dp), rot.ctypes.data_as(dp), stream))
+        ref = base.copy()
+        oracle_py.sensor_noise(ref, st_ref, n, nf, std, bias, rot)
+        got = data_dev.cpu().numpy().astype(np.float64)
+        if dtype_name == "f64":
+            # the perturbation itself (got - base) is a float: compare it in float ulps via the
+            # un-rotated, un-biased difference bound below, and the values in absolute terms
+            assert np.max(np.abs(got - ref)) < 2e-6 * np.max(std), r
+        else:
+            # float storage: a few float ulps of the largest term (sums can cancel, so the bound
+            # is absolute, not relative to the result)
+            assert np.max(np.abs(got - ref)) < 1e-5, r
+        worst = max(worst, float(np.max(np.abs(got - ref))))
+    assert np.array_equal(rng_dev.cpu().numpy().view(np.uint64), st_ref)
+    # exactness of the fast path: with zero bias / identity rotation most samples are bit-identical
+    base = np.zeros((n * nf, B))
+    data_dev = torch.zeros((n * nf, B), dtype=torch.float64).cuda()
+    lib.check(lib.L.jm_block_sensor_noise(_abi.JM_F64, B, n, nf, C.c_void_p(data_dev.data_ptr()),
+                                          C.c_void_p(rng_dev.data_ptr()), std.ctypes.data_as(dp), None, None, stream))
+    oracle_py.sensor_noise(base, st_ref, n, nf, std, None, None)
+    got = data_dev.cpu().numpy()
+    same = got == base
+    assert same.mean() > 0.98
+    assert np.max(_ulp_diff(got[~same], base[~same])) <= 1 if (~same).any() else True
+
+
+@pytest.mark.gpu
+def test_engine_sensor_noise_at_sensor_breakpoints(gpu_device):
+    """Engine level: noise / bias are applied once per sensor refresh (start: INIT_ITERATIONS
+    discarded draws + one), reproducibly for a given seed, and leave the dynamics untouched."""
+    import torch
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import INIT_ITERATIONS, BatchedEngine
+    from jiminy_amd.synthetic import sample_states
+    model = load_builtin("anymal")
+    B, dt = 64, 1e-3
+    st = sample_states(model, B, seed=4)
+
+    def run(noise, seed=3):
+        eng = BatchedEngine(model, B, dtype=torch.float64)
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 2 * dt,
+                                     "sensorsUpdatePeriod": 2 * dt}})
+        if noise:
+            eng.set_sensor_options("ImuSensor", noise_std=[0.01, 0.01, 0.01, 0.1, 0.1, 0.1],
+                                   bias=[0.0, 0.0, 0.1, 0.001, 0.002, 0.003, 0.0, 0.0, 0.05])
+            eng.set_sensor_options("EncoderSensor", noise_std=[1e-3, 1e-2])
+            eng.set_sensor_options("EffortSensor", bias=[0.5])
+            eng.seed_sensors(seed)
+        eng.set_command(torch.from_numpy(st["command"]))
+        eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+        out = [{k: eng.field(k).clone() for k in ("imu", "encoder", "effort", "q", "a")}]
+        for i in range(3):
+            eng.step(2 * dt)
+            out.append({k: eng.field(k).clone() for k in ("imu", "encoder", "effort", "q", "a")})
+        rng = {k: v["rng"].clone() for k, v in eng._sensor_noise.items() if v["rng"] is not None}
+        eng.stop()
+        return out, rng
+    clean, _ = run(False)
+    noisy, rng = run(True)
+    again, rng2 = run(True)
+    other, _ = run(True, seed=4)
+    for a, b in zip(noisy, again):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k          # reproducible
+    assert all(torch.equal(rng[k], rng2[k]) for k in rng)
+    assert not torch.equal(noisy[1]["imu"], other[1]["imu"])
+    for c, n_ in zip(clean, noisy):
+        assert torch.equal(c["q"], n_["q"]) and torch.equal(c["a"], n_["a"])   # physics untouched
+        assert torch.allclose(n_["effort"], c["effort"] + 0.5, rtol=0, atol=1e-12)
+        d = (n_["encoder"] - c["encoder"]).view(-1, 2, B)
+        assert 0.3e-3 < float(d[:, 0].std()) < 3e-3 and 0.3e-2 < float(d[:, 1].std()) < 3e-2
+    # stream position: (INIT_ITERATIONS + 1) rounds at start + one per sensor breakpoint (3 steps)
+    n_imu = len(model.sensors["ImuSensor"])
+    gs = ((3 + np.arange(B, dtype=np.uint64) * 3 + sorted(["ImuSensor", "EncoderSensor", "EffortSensor"]).index("ImuSensor"))
+          & 0xFFFFFFFF).astype(np.uint32)
+    st_ref = oracle_py.sensor_rng_seed(gs, n_imu)
+    scratch = np.zeros((n_imu * 6, B))
+    for _ in range(INIT_ITERATIONS + 1 + 3):
+        oracle_py.sensor_noise(scratch, st_ref, n_imu, 6, np.tile([0.01, 0.01, 0.01, 0.1, 0.1, 0.1], (n_imu, 1)), None, None)
+    assert np.array_equal(rng["ImuSensor"].cpu().numpy().view(np.uint64), st_ref)
