@@ -137,3 +137,28 @@ def test_env_with_hip_blocks_equals_env_with_tensor_blocks(gpu_device, monkeypat
         env.close()
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) < 1e-6
+
+
+def test_ppo_learner_on_the_device_resident_pipeline(gpu_device):
+    """BASELINE configs[4] on one GPU: rollouts of the ANYmal pipeline feed the PPO update without
+    leaving the device (examples/ppo_anymal.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import ppo_anymal as ppo
+    from jiminy_amd.envs import make_anymal_env
+    env = make_anymal_env(256, device=gpu_device)
+    obs_d, _ = env.reset(seed=0)
+    obs = ppo.flatten_anymal_obs(obs_d)
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.shape == (256, 64)
+    learner = ppo.PPO(obs.shape[1], env.model.nmotors, gpu_device, epochs=1, minibatches=2)
+
+    def env_step(action):
+        o, r, term, trunc, _ = env.step(0.25 * torch.tanh(action).double())
+        return ppo.flatten_anymal_obs(o), r.float(), term | trunc
+    for _ in range(2):
+        buf, obs = learner.rollout(obs, env_step, 4)
+        stats = learner.update(buf)
+        assert all(v.is_cuda for v in buf.values())
+        assert np.isfinite(stats["loss"]) and bool(torch.isfinite(buf["adv"]).all())
+    env.close()
