@@ -1328,6 +1328,9 @@ struct DppQuad
 // waves resident per CU under the 160 KiB of LDS (a CU runs at most 2 such waves per SIMD).
 template<class T, class Tp> constexpr int quad_block_waves()
 {
+#ifdef JM_QUAD_BLOCK_WAVES
+    return JM_QUAD_BLOCK_WAVES;   // tuning override
+#endif
     constexpr long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
     constexpr long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
     int best = 1, best_resident = 0;

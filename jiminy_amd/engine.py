@@ -46,7 +46,7 @@ def default_options() -> Dict[str, Dict[str, Any]]:
         "world": {"gravity": [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]},
         "stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1.0e-5, "tolRel": 1.0e-4,
                     "dtMax": SIMULATION_MAX_TIMESTEP, "dtRestoreThresholdRel": 0.2,
-                    "successiveIterFailedMax": 1000,
+                    "successiveIterFailedMax": 1000, "iterMax": 0,
                     "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
         "contacts": {"model": "spring_damper", "stiffness": 1.0e6, "damping": 2.0e3,
                      "friction": 1.0, "transitionEps": 1.0e-3, "transitionVelocity": 1.0e-2},
@@ -605,6 +605,31 @@ class BatchedEngine:
         self._t_prev = self._t
         self._t = t_end
         self._t_error = t_err
+
+    def simulate(self, t_end: float, q_init: Any, v_init: Any, a_init: Any = None,
+                 callback: Optional[Any] = None) -> None:
+        """≙ `Engine::simulate(tEnd, qInit, vInit, aInit, callback)` (reference engine.cc:1614-1699):
+        reset, start, step by the stepper update period (else `dtMax`) until `t_end`, until
+        `callback()` returns False or until `stepper.iterMax` integration steps, then stop."""
+        if t_end < 5e-3:
+            raise ValueError("Simulation duration cannot be shorter than 5ms.")   # engine.cc:1628-1631
+        command = self._fields["command"].clone()
+        self.reset()
+        self._fields["command"].copy_(command)   # the held command stands for the controller
+        self.start(q_init, v_init, a_init)
+        st = self._options["stepper"]
+        periods = [float(p) for p in (st["controllerUpdatePeriod"], st["sensorsUpdatePeriod"]) if float(p) > EPS]
+        period = min(periods) if periods else float(st["dtMax"])
+        iter_max = int(st.get("iterMax", 0))
+        while True:
+            if t_end - self._t < SIMULATION_MIN_TIMESTEP:
+                break
+            if callback is not None and not callback():
+                break
+            if 0 < iter_max <= self.stepper_state.iter:
+                break
+            self.step(min(period, t_end - self._t))
+        self.stop()
 
     def compute_robots_dynamics(self, t: float, q: Any, v: Any) -> torch.Tensor:
         """≙ `Engine.compute_robots_dynamics(t, [q], [v]) -> [a]` (pywrap engine.cc:634-638)."""

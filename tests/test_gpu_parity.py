@@ -468,3 +468,30 @@ def test_full_size_batch_replica_invariance_and_repeatability(gpu_device):
         assert rel_err(first.cpu().numpy(), ref[k], ok) < 1e-9, k
         same = (runs[0][k] == runs[1][k]) | (torch.isnan(runs[0][k]) & torch.isnan(runs[1][k]))
         assert bool(same.all()), k
+
+
+def test_simulate_runs_to_t_end_or_until_the_callback_stops_it(gpu_device):
+    """≙ `Engine::simulate` (engine.cc:1614-1699): end time, abort callback, `iterMax`, 5 ms floor."""
+    model = load_builtin("double_pendulum")
+    B, dt = 8, 1e-3
+    st = sample_states(model, B, seed=2)
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    eng.set_command(torch.from_numpy(st["command"]))
+    q0, v0 = torch.from_numpy(st["q"]), torch.from_numpy(st["v"])
+    with pytest.raises(ValueError, match="shorter than 5ms"):
+        eng.simulate(1e-3, q0, v0)
+    eng.simulate(0.05, q0, v0)
+    assert not eng.is_simulation_running and abs(eng.stepper_state.t - 0.05) < 1e-12 and eng.stepper_state.iter == 50
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start")
+    for i in range(50):
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+    assert rel_err(eng.field("q").cpu().numpy(), ref["q"], np.ones(B, bool)) < 1e-10
+    calls = []
+    eng.simulate(0.05, q0, v0, callback=lambda: len(calls) < 7 and not calls.append(0))
+    assert eng.stepper_state.iter == 7
+    eng.set_options({"stepper": {"iterMax": 12}})
+    eng.simulate(0.05, q0, v0)
+    assert eng.stepper_state.iter == 12
