@@ -90,8 +90,10 @@ enum {
     JM_LANE_OUT_OF_BOUNDS = 2,  /* a bounded joint left [lower, upper]: the reference would switch
                                    to its constraint solver (engine.cc:3285-3298, 3722) */
     JM_LANE_FORCE_OVERFLOW = 4, /* initial contact force > 1e5 N (engine.cc:1338-1345) */
-    JM_LANE_STEPPER_FAILURE = 8 /* adaptive stepper: step size below 1e-10 s or too many successive
+    JM_LANE_STEPPER_FAILURE = 8,/* adaptive stepper: step size below 1e-10 s or too many successive
                                    failed iterations (engine.cc:2340-2384 raises for the robot) */
+    JM_LANE_SOLVER_FAILURE = 16 /* constraint model: the PGS solver hit its iteration cap on the last
+                                   evaluation (engine.cc:3755-3768 counts `successiveSolveFailed`) */
 };
 
 /* ---- model description: plain arrays, all host memory, copied by jm_model_create.
@@ -163,8 +165,31 @@ enum {
     JM_F_CENTROIDAL = 15,  /* [15] out com(3), hg(6), dhg(6) (engine.cc:889-904)    optional */
     JM_F_STATUS = 16,      /* [1] int32 per lane, JM_LANE_* bits */
     JM_F_WORKSPACE = 17,   /* scratch, jm_batch_workspace_rows() rows */
-    JM_F_COUNT = 18
+    JM_F_CON_FLAGS = 18,   /* [n_flag_rows] int32 in/out: per constraint, bit 0 = enabled, bit 1 = reversed
+                              (AbstractConstraintBase::isEnabled_, JointConstraint::isReversed_) */
+    JM_F_CON_DATA = 19,    /* [n_data_rows] in/out: JointConstraint::configurationRef_ per bounded joint, then
+                              the Lagrange multipliers `lambda_` of every constraint row (PGS warm start) */
+    JM_F_COUNT = 20
 };
+
+/* ---- `contacts.model = "constraint"` (the reference's default contact model, engine.h:273) and the
+ * joint position bounds it enforces: options of the boxed forward dynamics
+ * (core/src/solver/constraint_solvers.cc:335-448, core/src/engine/engine.cc:3253-3338, 3710-3866).
+ * Constraint rows of one robot, in the reference's registry order (robot/model.h:40-46):
+ *   one row per bounded 1-dof joint (`JointConstraint`, model joint order; continuous joints never
+ *   activate and own no row), then 4 rows per contact point (`FrameConstraint` with the translation
+ *   and the rotation about the ground normal fixed: x, y, z, torsion; core/src/robot/model.cc:817-823).
+ * Only explicit fixed-step solvers are available with this model on the batched path. */
+enum { JM_CONTACT_SPRING_DAMPER = 0, JM_CONTACT_CONSTRAINT = 1 };
+typedef struct jm_constraint_options {
+    int32_t contact_model;      /* contacts.model: JM_CONTACT_*                      */
+    int32_t pgs_iter_max;       /* PGS_MAX_ITERATIONS = 100 (engine.cc:62)            */
+    double torsion;             /* contacts.torsion            0.0                    */
+    double stabilization_freq;  /* contacts.stabilizationFreq  20.0 (Baumgarte)       */
+    double regularization;      /* constraints.regularization  1e-3                   */
+    double tol_abs;             /* stepper.tolAbs 1e-5: PGS tolerances (engine.cc:1372-1373) */
+    double tol_rel;             /* stepper.tolRel 1e-4                                */
+} jm_constraint_options;
 
 typedef struct jm_model jm_model;
 typedef struct jm_batch jm_batch;
@@ -184,6 +209,16 @@ int32_t jm_batch_destroy(jm_batch * batch);
 int32_t jm_batch_set_options(jm_batch * batch, const jm_options * options);
 /* Number of [B]-rows of scratch the caller must provide through JM_F_WORKSPACE. */
 int32_t jm_batch_workspace_rows(const jm_batch * batch);
+/* Constraint contact model: options (not while a simulation is running) and the row counts of the
+ * per-lane constraint state the caller lends through JM_F_CON_FLAGS (int32), JM_F_CON_DATA and
+ * JM_F_WORKSPACE (batch dtype; the delassus matrix J M^-1 J^T of every lane and the PGS vectors).
+ * With JM_CONTACT_CONSTRAINT, start / step / dynamics / reset_lanes run the constrained evaluation:
+ * joint-bound and contact constraints are switched with the reference's hysteresis
+ * (engine.cc:3285-3298, 3145-3193) and the multipliers solved by projected Gauss-Seidel
+ * (constraint_solvers.cc:107-333) on every dynamics evaluation. */
+int32_t jm_batch_set_constraint_options(jm_batch * batch, const jm_constraint_options * options);
+int32_t jm_batch_constraint_rows(const jm_batch * batch, int32_t * n_flag_rows, int32_t * n_data_rows,
+                                 int32_t * n_workspace_rows);
 /* Lend a device pointer for one field; NULL unbinds an optional output. */
 int32_t jm_batch_bind(jm_batch * batch, int32_t field, void * device_ptr);
 

@@ -19,11 +19,14 @@ JM_SOLVER_EULER_EXPLICIT, JM_SOLVER_RUNGE_KUTTA_4, JM_SOLVER_RUNGE_KUTTA_DOPRI =
 JM_MOTOR_EFFORT_LIMIT, JM_MOTOR_VELOCITY_LIMIT, JM_MOTOR_FRICTION = 1, 2, 4
 JM_MOTOR_NPARAMS = 9
 JM_LANE_OK, JM_LANE_NAN, JM_LANE_OUT_OF_BOUNDS, JM_LANE_FORCE_OVERFLOW, JM_LANE_STEPPER_FAILURE = 0, 1, 2, 4, 8
+JM_LANE_SOLVER_FAILURE = 16
+JM_CONTACT_SPRING_DAMPER, JM_CONTACT_CONSTRAINT = 0, 1
+CONTACT_MODELS = {"spring_damper": JM_CONTACT_SPRING_DAMPER, "constraint": JM_CONTACT_CONSTRAINT}
 
 (JM_F_Q, JM_F_V, JM_F_A, JM_F_COMMAND, JM_F_U_MOTOR, JM_F_U, JM_F_F_EXTERNAL,
  JM_F_CONTACT_FORCES, JM_F_IMU, JM_F_FORCE, JM_F_CONTACT, JM_F_ENCODER, JM_F_EFFORT,
  JM_F_ENERGY, JM_F_JOINT_FORCES, JM_F_CENTROIDAL, JM_F_STATUS, JM_F_WORKSPACE,
- JM_F_COUNT) = range(19)
+ JM_F_CON_FLAGS, JM_F_CON_DATA, JM_F_COUNT) = range(21)
 
 FIELD_NAMES = {
     "q": JM_F_Q, "v": JM_F_V, "a": JM_F_A, "command": JM_F_COMMAND, "u_motor": JM_F_U_MOTOR,
@@ -31,6 +34,7 @@ FIELD_NAMES = {
     "imu": JM_F_IMU, "force": JM_F_FORCE, "contact": JM_F_CONTACT, "encoder": JM_F_ENCODER,
     "effort": JM_F_EFFORT, "energy": JM_F_ENERGY, "joint_forces": JM_F_JOINT_FORCES,
     "centroidal": JM_F_CENTROIDAL, "status": JM_F_STATUS, "workspace": JM_F_WORKSPACE,
+    "con_flags": JM_F_CON_FLAGS, "con_data": JM_F_CON_DATA,
 }
 
 _pi = C.POINTER(C.c_int32)
@@ -66,6 +70,45 @@ class Options(C.Structure):
         ("contact_transition_eps", C.c_double),
         ("contact_transition_velocity", C.c_double),
     ]
+
+
+class ConstraintOptions(C.Structure):
+    """struct jm_constraint_options (include/jiminy_hip.h)."""
+    _fields_ = [
+        ("contact_model", C.c_int32),
+        ("pgs_iter_max", C.c_int32),
+        ("torsion", C.c_double),
+        ("stabilization_freq", C.c_double),
+        ("regularization", C.c_double),
+        ("tol_abs", C.c_double),
+        ("tol_rel", C.c_double),
+    ]
+
+
+def make_constraint_options(model="constraint", torsion=0.0, stabilization_freq=20.0,
+                            regularization=1.0e-3, tol_abs=1.0e-5, tol_rel=1.0e-4,
+                            pgs_iter_max=100) -> ConstraintOptions:
+    """Defaults = reference engine.h:262-286, 307-325 (`contacts`, `constraints`, `stepper.tol*`),
+    PGS_MAX_ITERATIONS engine.cc:62."""
+    o = ConstraintOptions()
+    o.contact_model = CONTACT_MODELS[model]
+    o.pgs_iter_max = int(pgs_iter_max)
+    o.torsion = float(torsion)
+    o.stabilization_freq = float(stabilization_freq)
+    o.regularization = float(regularization)
+    o.tol_abs = float(tol_abs)
+    o.tol_rel = float(tol_rel)
+    return o
+
+
+def constraint_rows(model: CompiledModel) -> Dict[str, int]:
+    """Rows of the per-lane constraint state: one constraint per bounded 1-dof joint (model joint
+    order) then one per contact point with 4 rows (x, y, z, torsion)."""
+    nb = int(sum(1 for t in model.jtypes if 1 <= int(t) <= 8))
+    nc = model.ncontacts
+    nr = nb + 4 * nc
+    return {"n_bounds": nb, "n_contacts": nc, "n_rows": nr, "con_flags": nb + nc,
+            "con_data": nb + nr, "workspace": nr * nr + 4 * nr}
 
 
 class AdaptiveOptions(C.Structure):

@@ -1,0 +1,568 @@
+// jm_constraint.h -- `contacts.model = "constraint"` on the batched path: joint position bounds and
+// contact points as kinematic constraints, multipliers by projected Gauss-Seidel, one robot per lane.
+//
+// Reference functions restated here (paths relative to the reference tree):
+//   switch_constraints   computePositionLimitsForcesAlgo               core/src/engine/engine.cc:3253-3338
+//                        computeContactDynamicsAtFrame (CONSTRAINT)    engine.cc:3145-3193
+//   constraint rows      JointConstraint::computeJacobianAndDrift      core/src/constraints/joint_constraint.cc:139-163
+//                        FrameConstraint::computeJacobianAndDrift      core/src/constraints/frame_constraint.cc:103-183
+//                        Model::computeConstraints (drift kinematics)  core/src/robot/model.cc:1238-1287
+//   delassus + solve     PGSSolver::SolveBoxedForwardDynamics          core/src/solver/constraint_solvers.cc:335-448
+//                        computeJMinvJt / solveJMinvJtv                pinocchio_overload_algorithms.h:491-551
+//   pgs                  PGSSolver::ProjectedGaussSeidelSolver / Iter  constraint_solvers.cc:107-333
+//   outputs              Engine::computeAcceleration                   engine.cc:3710-3866
+//   start passes         Engine::start INIT_ITERATIONS loop            engine.cc:1380-1467
+//
+// Formulation.  The reference factorises the dense joint-space inertia matrix (CRBA + Cholesky) and
+// forms J M^-1 J^T through triangular solves with a dense Jacobian.  Here nothing of size nv x nv is
+// ever formed: the unconstrained acceleration is the articulated-body solve the spring-damper path
+// already runs (ABA == M^-1 (u - nle) exactly, armature included), and every column of the delassus
+// matrix is one *bias-free* articulated-body solve re-using the articulated inertias of that
+// evaluation (U, 1/D, liMi, the factorised root block): a unit constraint force is pushed to the root
+// (6 scalars per joint) and the resulting joint accelerations are read back at the constraint rows.
+// The final acceleration is the free one plus one more such solve with the multipliers applied.
+// Same mathematics (A = J M^-1 J^T, b = -(drift + J a_free)), same PGS sweep order and warm start,
+// hence the same iterates up to round-off.  Per lane only the m x m delassus matrix and four m-vectors
+// live in HBM (caller-owned workspace, structure-of-arrays), addressed with run-time row indices; the
+// tree sweeps stay fully unrolled on compile-time joint indices.
+#pragma once
+#include "jm_kernels.h"
+
+namespace jm
+{
+template<class T> struct ConArgs
+{
+    int32_t * flags;  // [NF][B]  bit 0 enabled, bit 1 reversed
+    T * data;         // [ND][B]  reference configuration per bounded joint, then lambda per row
+    T * ws;           // [WTOTAL][B]
+    T kp, kd;         // Baumgarte gains of contacts.stabilizationFreq (abstract_constraint.cc:88-98)
+    T torsion, reg, tol_abs, tol_rel;
+    int iter_max;
+};
+struct WithCon
+{
+    static constexpr bool ON = true;
+    template<class T, class Tp> using WorkT = WorkC<T, Tp>;
+    template<class T> using ArgsT = ConArgs<T>;
+};
+
+template<class Tp> struct ConRows
+{
+    static constexpr int count_bounded()
+    {
+        int n = 0;
+        for (int j = 1; j < Tp::NJ; ++j) n += jt_bounded(Tp::jtype[j]) ? 1 : 0;
+        return n;
+    }
+    static constexpr int NB = count_bounded();  // JointConstraint rows (model joint order)
+    static constexpr int NC = Tp::NC;           // FrameConstraint blocks of 4 rows
+    static constexpr int NR = NB + 4 * NC;
+    static constexpr int NF = NB + NC;
+    static constexpr int ND = NB + NR;
+    static constexpr int LAM = NB;  // first lambda row in `data`
+    static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WTOTAL = WD + NR;
+    static constexpr int bjoint(int k)
+    {
+        int n = 0;
+        for (int j = 1; j < Tp::NJ; ++j)
+            if (jt_bounded(Tp::jtype[j]))
+            {
+                if (n == k) return j;
+                ++n;
+            }
+        return 0;
+    }
+};
+
+JM_DEV double cabs_(double x) { return __builtin_fabs(x); }
+JM_DEV float cabs_(float x) { return __builtin_fabsf(x); }
+
+template<int NW> struct RowMaskN
+{
+    unsigned long long w[NW];
+    JM_DEV void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = 0ull;
+    }
+    JM_DEV bool test(int r) const { return (w[r >> 6] >> (r & 63)) & 1ull; }
+    JM_DEV void set(int r) { w[r >> 6] |= 1ull << (r & 63); }
+    JM_DEV bool any() const
+    {
+        unsigned long long o = 0ull;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) o |= w[i];
+        return o != 0ull;
+    }
+};
+
+// dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias
+// of the last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).
+// Also returns the spatial accelerations `da` of every joint (joint frame).
+template<class T, class Tp, class FT, class FB>
+JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T (&dd)[Tp::NV], Sp<T> (&da)[Tp::NJ])
+{
+    constexpr int NJ = Tp::NJ;
+    Sp<T> pf[NJ];
+    T ur[Tp::NV];
+    static_for<1, NJ>([&](auto jc) { pf[decltype(jc)::value] = zero6<T>() - fb(jc); });
+    static_for<0, Tp::NV>([&](auto ic) { ur[decltype(ic)::value] = tau(ic); });
+    static_rfor<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        constexpr int t = Tp::jtype[j];
+        constexpr int iv = Tp::idx_v[j];
+        if constexpr (t == JM_JT_FREEFLYER)
+        {
+            ur[iv] -= pf[j].l.x; ur[iv + 1] -= pf[j].l.y; ur[iv + 2] -= pf[j].l.z;
+            ur[iv + 3] -= pf[j].a.x; ur[iv + 4] -= pf[j].a.y; ur[iv + 5] -= pf[j].a.z;
+        }
+        else
+        {
+            const T uj = ur[iv] - joint_St_dot<T, Tp, j>(P, pf[j]);
+            ur[iv] = uj;
+            if constexpr (p > 0)
+            {
+                const T ud = uj * w.dinv[j];
+                const Sp<T> pa = {pf[j].l + ud * w.U[j].l, pf[j].a + ud * w.U[j].a};
+                pf[p] = pf[p] + act_force(w.liMi[j], pa);
+            }
+        }
+    });
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        constexpr int t = Tp::jtype[j];
+        constexpr int iv = Tp::idx_v[j];
+        if constexpr (t == JM_JT_FREEFLYER)
+        {
+            T b[6] = {ur[iv], ur[iv + 1], ur[iv + 2], ur[iv + 3], ur[iv + 4], ur[iv + 5]};
+            chol6_resolve(w.rootA, w.rootdinv, b);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dd[iv + k] = b[k];
+            da[j] = {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
+        }
+        else
+        {
+            Sp<T> ag;
+            if constexpr (p > 0) ag = actinv_motion(w.liMi[j], da[p]);
+            else ag = zero6<T>();
+            const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
+            const T ddj = w.dinv[j] * (ur[iv] - Ua);
+            dd[iv] = ddj;
+            const V3<T> n = joint_axis<T, Tp, j>(P);
+            if constexpr (jt_is_rev(t)) da[j] = {ag.l, ag.a + ddj * n};
+            else da[j] = {ag.l + ddj * n, ag.a};
+        }
+    });
+}
+
+// J_row . dd for every active row, written through `put(row, value)`
+template<class T, class Tp, class RowMask, class PUT>
+JM_DEV void rows_of_motion(CPtr<T> P, const WorkC<T, Tp> & w, const RowMask & act, const RowMask & rev,
+                           const T (&dd)[Tp::NV], const Sp<T> (&da)[Tp::NJ], PUT && put)
+{
+    using L = Layout<Tp>;
+    using R = ConRows<Tp>;
+    static_for<0, R::NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int iv = Tp::idx_v[R::bjoint(k)];
+        if (act.test(k)) put(k, rev.test(k) ? -dd[iv] : dd[iv]);
+    });
+    static_for<0, R::NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int j = Tp::contact_joint[c];
+        constexpr int r0 = R::NB + 4 * c;
+        if (act.test(r0))
+        {
+            const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+            const V3<T> lin = w.oMi[j].R * (da[j].l + cross(da[j].a, pc));
+            const V3<T> ang = w.oMi[j].R * da[j].a;
+            put(r0, lin.x); put(r0 + 1, lin.y); put(r0 + 2, lin.z); put(r0 + 3, ang.z);
+        }
+    });
+}
+
+// Cholesky solve A x = b over the active rows (start pass with `ignoreBounds`, solveJMinvJtv).
+// The lower triangle and the diagonal of A are used as factor storage and restored afterwards
+// (diagonal from a backup, lower triangle mirrored from the upper one like constraint_solvers.cc:421).
+template<class T, class Tp, class RowMask, class WS, class LAM>
+JM_DEV bool chol_solve_active(const RowMask & act, WS && ws, LAM && lam)
+{
+    using R = ConRows<Tp>;
+    constexpr int NR = R::NR;
+    bool ok = true;
+    for (int j = 0; j < NR; ++j)
+    {
+        if (!act.test(j)) continue;
+        ws(R::WD + j) = ws(R::WA + j * NR + j);
+        T s = ws(R::WA + j * NR + j);
+        for (int k = 0; k < j; ++k)
+            if (act.test(k)) { const T l = ws(R::WA + j * NR + k); s -= l * l; }
+        ok &= s > T(0);
+        const T d = sqrt_(s);
+        ws(R::WA + j * NR + j) = d;
+        for (int i = j + 1; i < NR; ++i)
+        {
+            if (!act.test(i)) continue;
+            T t = ws(R::WA + i * NR + j);
+            for (int k = 0; k < j; ++k)
+                if (act.test(k)) t -= ws(R::WA + i * NR + k) * ws(R::WA + j * NR + k);
+            ws(R::WA + i * NR + j) = t / d;
+        }
+    }
+    for (int i = 0; i < NR; ++i)
+    {
+        if (!act.test(i)) continue;
+        T s = ws(R::WB + i);
+        for (int k = 0; k < i; ++k)
+            if (act.test(k)) s -= ws(R::WA + i * NR + k) * lam(k);
+        lam(i) = s / ws(R::WA + i * NR + i);
+    }
+    for (int i = NR - 1; i >= 0; --i)
+    {
+        if (!act.test(i)) continue;
+        T s = lam(i);
+        for (int k = i + 1; k < NR; ++k)
+            if (act.test(k)) s -= ws(R::WA + k * NR + i) * lam(k);
+        lam(i) = s / ws(R::WA + i * NR + i);
+    }
+    for (int i = 0; i < NR; ++i)
+    {
+        if (!act.test(i)) continue;
+        ws(R::WA + i * NR + i) = ws(R::WD + i);
+        for (int k = 0; k < i; ++k)
+            if (act.test(k)) ws(R::WA + i * NR + k) = ws(R::WA + k * NR + i);
+    }
+    return ok;
+}
+
+// PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333) over the active rows.
+template<class T, class Tp, class RowMask, class WS, class LAM>
+JM_DEV bool pgs_solve(const ConArgs<T> & C, T friction, const RowMask & act, WS && ws, LAM && lam)
+{
+    using R = ConRows<Tp>;
+    constexpr int NR = R::NR;
+    const T eps = Eps<T>::eps;
+    auto col_dot = [&](int i) {
+        T s = T(0);
+        for (int k = 0; k < NR; ++k)
+            if (act.test(k)) s += ws(R::WA + k * NR + i) * lam(k);
+        return s;
+    };
+    for (int r = 0; r < NR; ++r) ws(R::WY + r) = T(0);
+    const bool torsion_zero = C.torsion < eps, friction_zero = friction < eps;
+    const unsigned iter_max = (unsigned)C.iter_max;
+    for (unsigned iter = 0; iter < iter_max; ++iter)
+    {
+        for (int r = 0; r < NR; ++r) ws(R::WYP + r) = ws(R::WY + r);
+        // under-relaxation schedule (constraint_solvers.cc:248-258)
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        // block 0 of every constraint: joint bounds, then the normal force of every contact
+        for (int r = 0; r < NR; r += (r < R::NB ? 1 : 4))
+        {
+            if (!act.test(r)) continue;
+            const int i0 = r < R::NB ? r : r + 2;
+            const T y = ws(R::WB + i0) - col_dot(i0);
+            ws(R::WY + i0) = y;
+            const T e = lam(i0) + w * y / ws(R::WA + i0 * NR + i0);
+            lam(i0) = fmax_(e, T(0));  // clamp(e, 0, inf)
+        }
+        // block 1: torsional friction {3, 2}
+        for (int r = R::NB; r < NR; r += 4)
+        {
+            if (!act.test(r)) continue;
+            if (torsion_zero) { lam(r + 3) = lam(r + 3) * T(0); continue; }
+            const int i0 = r + 3;
+            const T y = ws(R::WB + i0) - col_dot(i0);
+            ws(R::WY + i0) = y;
+            const T e = lam(i0) + w * y / ws(R::WA + i0 * NR + i0);
+            const T thr = C.torsion * lam(r + 2);
+            lam(i0) = clamp_(e, -thr, thr);
+        }
+        // block 2: friction cone {0, 1, 2}
+        for (int r = R::NB; r < NR; r += 4)
+        {
+            if (!act.test(r)) continue;
+            if (friction_zero) { lam(r) = lam(r) * T(0); lam(r + 1) = lam(r + 1) * T(0); continue; }
+            const T y0 = ws(R::WB + r) - col_dot(r);
+            ws(R::WY + r) = y0;
+            const T y1 = ws(R::WB + r + 1) - col_dot(r + 1);
+            ws(R::WY + r + 1) = y1;
+            const T a00 = ws(R::WA + r * NR + r), a11 = ws(R::WA + (r + 1) * NR + r + 1);
+            const T a_max = a11 > a00 ? a11 : a00;
+            T e0 = lam(r) + w * y0 / a_max;
+            T e1 = lam(r + 1) + w * y1 / a_max;
+            const T thr = friction * lam(r + 2);
+            const T n2 = e0 * e0 + e1 * e1;
+            if (n2 > thr * thr)
+            {
+                const T scale = thr / sqrt_(n2);
+                e0 *= scale;
+                e1 *= scale;
+            }
+            lam(r) = e0;
+            lam(r + 1) = e1;
+        }
+        // stagnation of the residuals (constraint_solvers.cc:263-278)
+        T ymax = T(0);
+        for (int r = 0; r < NR; ++r)
+            if (act.test(r)) ymax = fmax_(ymax, cabs_(ws(R::WY + r)));
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        bool done = true;
+        for (int r = 0; r < NR; ++r)
+            if (act.test(r)) done &= cabs_(ws(R::WY + r) - ws(R::WYP + r)) < tol;
+        if (done) return true;
+    }
+    return false;
+}
+
+template<class T, class Tp, class CA>
+JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
+                             long long lane, long long B, int start_passes)
+{
+    using L = Layout<Tp>;
+    using R = ConRows<Tp>;
+    constexpr int NJ = Tp::NJ, NV = Tp::NV, NR = R::NR;
+    // ---- unconstrained part: FK, motors, ABA without contact forces
+    eval_dynamics<T, Tp>(P, q, v, cmd, w);
+    w.status &= ~JM_LANE_SOLVER_FAILURE;
+    if constexpr (NR == 0) return;
+    auto flag = [&](int r) -> int32_t & { return C.flags[(size_t)r * B + lane]; };
+    auto dat = [&](int r) -> T & { return C.data[(size_t)r * B + lane]; };
+    auto lam = [&](int r) -> T & { return C.data[(size_t)(R::LAM + r) * B + lane]; };
+    auto ws = [&](int r) -> T & { return C.ws[(size_t)r * B + lane]; };
+    const T eps_tr = P[L::OPT + 9], friction = P[L::OPT + 8];
+    const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+
+    // ---- constraint switching
+    constexpr int NWORDS = ((NR + 63) / 64 > 0) ? (NR + 63) / 64 : 1;
+    using RowMask = RowMaskN<NWORDS>;
+    RowMask act, rev;
+    act.clear();
+    rev.clear();
+    static_for<0, R::NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int iq = Tp::idx_q[R::bjoint(k)];
+        int32_t f = flag(k);
+        if (start_passes > 0)
+        {
+            // Engine::start: JointConstraint::reset + enable, not reversed (engine.cc:1266-1308)
+            f = 1;
+            dat(k) = q[iq];
+            lam(k) = T(0);
+        }
+        const T qj = q[iq], lo = P[L::QLO + iq], hi = P[L::QHI + iq];
+        if (hi < qj || qj < lo)
+        {
+            dat(k) = clamp_(qj, lo, hi);
+            f = 1 | (hi < qj ? 2 : 0);
+        }
+        else if (lo + eps_tr < qj && qj < hi - eps_tr)
+        {
+            f &= ~1;
+            lam(k) = T(0);
+        }
+        flag(k) = f;
+        if (f & 1) act.set(k);
+        if (f & 2) rev.set(k);
+    });
+    T depth[R::NC > 0 ? R::NC : 1];
+    static_for<0, R::NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int j = Tp::contact_joint[c];
+        constexpr int r0 = R::NB + 4 * c;
+        const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+        const T d = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, pc);
+        depth[c] = d;
+        int32_t f = flag(R::NB + c);
+        if (start_passes > 0)
+        {
+            f = 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
+        }
+        if (d < T(0)) f = 1;
+        else if (d > eps_tr)
+        {
+            f = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
+        }
+        flag(R::NB + c) = f;
+        if (f & 1) { act.set(r0); act.set(r0 + 1); act.set(r0 + 2); act.set(r0 + 3); }
+    });
+    if (!act.any()) return;  // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
+
+    // ---- delassus matrix, one bias-free articulated-body solve per active row
+    T dd[NV];
+    Sp<T> da[NJ];
+#pragma nounroll
+    for (int r = 0; r < NR; ++r)
+    {
+        if (!act.test(r)) continue;
+        int jr = 0, tiv = -1;
+        T tsgn = T(0);
+        Sp<T> fu = zero6<T>();
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (r == k) { tiv = Tp::idx_v[R::bjoint(k)]; tsgn = rev.test(k) ? T(-1) : T(1); }
+        });
+        static_for<0, R::NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int j = Tp::contact_joint[c];
+            constexpr int r0 = R::NB + 4 * c;
+            if (r >= r0 && r < r0 + 4)
+            {
+                const int d = r - r0;
+                const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+                const M3<T> & Rj = w.oMi[j].R;
+                // unit force (x, y, z) or unit torque about z at the contact point, world aligned
+                const V3<T> col = d == 0 ? V3<T>{Rj.m00, Rj.m01, Rj.m02}
+                                : d == 1 ? V3<T>{Rj.m10, Rj.m11, Rj.m12} : V3<T>{Rj.m20, Rj.m21, Rj.m22};
+                if (d < 3) fu = {col, cross(pc, col)};
+                else fu = {zero3<T>(), col};
+                jr = j;
+            }
+        });
+        delta_aba<T, Tp>(P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
+                         [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); }, dd, da);
+        rows_of_motion<T, Tp>(P, w, act, rev, dd, da, [&](int l, T val) { ws(R::WA + l * NR + r) = val; });
+        // regularisation (constraint_solvers.cc:376-387)
+        const T arr = ws(R::WA + r * NR + r);
+        ws(R::WA + r * NR + r) = arr + fmax_(arr * C.reg, T(1.0e-11));
+    }
+
+    // ---- passes: one in normal operation; Engine::start runs INIT_ITERATIONS with its `u` bookkeeping
+    const int n_pass = start_passes > 0 ? start_passes : 1;
+    T uq[NV];  // RobotState::u seen by this pass minus the motor efforts already inside the free solve
+    static_for<0, NV>([&](auto ic) { uq[decltype(ic)::value] = start_passes > 0 ? -w.ueff[decltype(ic)::value] : T(0); });
+    Sp<T> fsum[NJ];
+    T ddq_free[NV];
+    static_for<0, NV>([&](auto ic) { ddq_free[decltype(ic)::value] = w.ddq[decltype(ic)::value]; });
+#pragma nounroll
+    for (int pass = 0; pass < n_pass; ++pass)
+    {
+        // free acceleration of this pass (joint accelerations + spatial accelerations, gravity field removed)
+        T af[NV];
+        Sp<T> sa[NJ];
+        static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] = ddq_free[decltype(ic)::value]; });
+        static_for<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
+        });
+        if (start_passes > 0)
+        {
+            delta_aba<T, Tp>(P, w, [&](auto ic) { return uq[decltype(ic)::value]; },
+                             [&](auto) { return zero6<T>(); }, dd, da);
+            static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] += dd[decltype(ic)::value]; });
+            static_for<1, NJ>([&](auto jc) { sa[decltype(jc)::value] = sa[decltype(jc)::value] + da[decltype(jc)::value]; });
+        }
+        // b = -(drift + J a_free)
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int jn = R::bjoint(k);
+            constexpr int iq = Tp::idx_q[jn], iv = Tp::idx_v[jn];
+            if (act.test(k))
+            {
+                const T s = C.kp * (q[iq] - dat(k)) + C.kd * v[iv] + af[iv];
+                ws(R::WB + k) = rev.test(k) ? s : -s;
+            }
+        });
+        static_for<0, R::NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int j = Tp::contact_joint[c];
+            constexpr int r0 = R::NB + 4 * c;
+            if (act.test(r0))
+            {
+                const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+                const M3<T> & Rj = w.oMi[j].R;
+                const V3<T> vlin = Rj * (w.vel[j].l + cross(w.vel[j].a, pc));
+                const V3<T> vang = Rj * w.vel[j].a;
+                V3<T> alin = Rj * (sa[j].l + cross(sa[j].a, pc));
+                const V3<T> aang = Rj * sa[j].a;
+                alin = alin + cross(vang, vlin);
+                ws(R::WB + r0) = -(alin.x + C.kd * vlin.x);
+                ws(R::WB + r0 + 1) = -(alin.y + C.kd * vlin.y);
+                ws(R::WB + r0 + 2) = -(alin.z + C.kp * depth[c] + C.kd * vlin.z);
+                ws(R::WB + r0 + 3) = -(aang.z + C.kd * vang.z);
+            }
+        });
+        // multipliers
+        bool ok;
+        if (start_passes > 0 && pass == 0)
+        {
+            ok = chol_solve_active<T, Tp>(act, ws, lam);
+            if (!ok) w.status |= JM_LANE_NAN;
+        }
+        else
+        {
+            ok = pgs_solve<T, Tp>(C, friction, act, ws, lam);
+            if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
+            else w.status |= JM_LANE_SOLVER_FAILURE;
+        }
+        // constraint forces of this pass: joint efforts + wrenches on the contact bodies
+        T tl[NV];
+        static_for<0, NV>([&](auto ic) { tl[decltype(ic)::value] = T(0); });
+        static_for<1, NJ>([&](auto jc) { fsum[decltype(jc)::value] = zero6<T>(); });
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int iv = Tp::idx_v[R::bjoint(k)];
+            if (act.test(k)) tl[iv] = rev.test(k) ? -lam(k) : lam(k);
+        });
+        static_for<0, R::NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int j = Tp::contact_joint[c];
+            constexpr int r0 = R::NB + 4 * c;
+            if (act.test(r0))
+            {
+                const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);
+                const V3<T> fW = {lam(r0), lam(r0 + 1), lam(r0 + 2)};
+                const V3<T> tW = {T(0), T(0), lam(r0 + 3)};
+                // convertForceGlobalFrameToJoint (utilities/pinocchio.cc:794-809)
+                Sp<T> fl;
+                fl.l = tmul(w.oMi[j].R, fW);
+                fl.a = tmul(w.oMi[j].R, tW) + cross(fr.p, fl.l);
+                fsum[j] = fsum[j] + fl;
+                // Robot::contactForces_ in the contact frame (engine.cc:3806-3817)
+                w.cf[c] = {tmul(fr.R, fl.l), tmul(fr.R, tmul(w.oMi[j].R, tW))};
+            }
+        });
+        delta_aba<T, Tp>(P, w, [&](auto ic) { return tl[decltype(ic)::value]; },
+                         [&](auto jc) { return fsum[decltype(jc)::value]; }, dd, da);
+        static_for<0, NV>([&](auto ic) { w.ddq[decltype(ic)::value] = af[decltype(ic)::value] + dd[decltype(ic)::value]; });
+        // Engine::start: the next pass sees u = uInternal (bounds multipliers of this pass, added with a
+        // plus sign whatever the direction, engine.cc:3786-3790) + motor efforts (engine.cc:1456-1465)
+        static_for<0, NV>([&](auto ic) { uq[decltype(ic)::value] = T(0); });
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int iv = Tp::idx_v[R::bjoint(k)];
+            if (act.test(k)) uq[iv] = lam(k);
+        });
+    }
+    // ---- outputs of the last pass: total efforts, external wrenches
+    static_for<0, NV>([&](auto ic) { w.ueff[decltype(ic)::value] += uq[decltype(ic)::value]; });
+    static_for<1, NJ>([&](auto jc) { w.fext[decltype(jc)::value] = w.fext[decltype(jc)::value] + fsum[decltype(jc)::value]; });
+    static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (w.ddq[i] != w.ddq[i]) w.status |= JM_LANE_NAN;
+    });
+}
+
+#ifndef JM_HOST_EMU
+template<class T, class Tp>
+__global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const ConArgs<T> C)
+{
+    __shared__ T lds[stage_rows<Tp>() * 64];
+    const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= A.B) return;
+    lane_run<T, Tp, 64, WithCon>(A, lane, lds + threadIdx.x, C);
+}
+#endif
+}  // namespace jm

@@ -133,6 +133,22 @@ template<class T, class Tp> struct Work
     T umotor[c_max(Tp::NM, 1)];
     T ddq[Tp::NV];
     int status;
+    static constexpr bool CONSTRAINED = false;
+};
+// working set of the constraint contact model (jm_constraint.h): keeps the factorised root block
+template<class T, class Tp> struct WorkC : Work<T, Tp>
+{
+    T rootA[6][6];   // LDL^T factor of (Ia_root + rotor) left by chol6_solve (unit lower + diagonal)
+    T rootdinv[6];
+    static constexpr bool CONSTRAINED = true;
+};
+// evaluation policy of lane_run: plain (spring-damper contacts) or constraint contact model
+template<class T> struct NoConArgs {};
+struct NoCon
+{
+    static constexpr bool ON = false;
+    template<class T, class Tp> using WorkT = Work<T, Tp>;
+    template<class T> using ArgsT = NoConArgs<T>;
 };
 
 template<class T, class Tp, int J> JM_DEV V3<T> joint_axis(CPtr<T> P)
@@ -263,9 +279,32 @@ template<class T> JM_DEV void chol6_solve(T (&A)[6][6], T (&b)[6])
     }
 }
 
+// second solve with the factor left in `A` by chol6_solve (`dinv[j]` = 1 / A[j][j])
+template<class T> JM_DEV void chol6_resolve(const T (&A)[6][6], const T (&dinv)[6], T (&b)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+    {
+        T s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= A[i][k] * b[k];
+        b[i] = s;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+    {
+        T s = b[i] * dinv[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= A[k][i] * b[k];
+        b[i] = s;
+    }
+}
+
 // ---------------------------------------------------------------- a = f(q, v) with held command
-template<class T, class Tp>
-JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Work<T, Tp> & w)
+// W = Work<T, Tp>: spring-damper contact model.  W = WorkC<T, Tp>: the unconstrained part of the
+// constraint contact model (no contact forces, no out-of-bounds flag, root factor kept).
+template<class T, class Tp, class W>
+JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w)
 {
     using L = Layout<Tp>;
     constexpr int NJ = Tp::NJ;
@@ -294,7 +333,7 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Wo
         }
         w.agf[j] = cross_mm(w.vel[j], vj);  // c_j = 0 for every supported joint
         w.fext[j] = zero6<T>();
-        if constexpr (jt_bounded(Tp::jtype[j]))
+        if constexpr (jt_bounded(Tp::jtype[j]) && !W::CONSTRAINED)
         {
             constexpr int iq = Tp::idx_q[j];
             if (P[L::QHI + iq] < q[iq] || q[iq] < P[L::QLO + iq]) w.status |= JM_LANE_OUT_OF_BOUNDS;
@@ -307,7 +346,7 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Wo
         const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);
         const T depth = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, fr.p);
         Sp<T> fl = zero6<T>();
-        if (depth < T(0))
+        if (!W::CONSTRAINED && depth < T(0))
         {
             // world velocity of the contact point: oMi.R (v_lin + w x p_frame)
             const V3<T> vj = w.vel[j].l + cross(w.vel[j].a, fr.p);
@@ -399,6 +438,16 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, Wo
 #pragma unroll
             for (int k = 0; k < 6; ++k) A[k][k] += P[L::ROTOR + iv + k];
             chol6_solve(A, b);
+            if constexpr (W::CONSTRAINED)
+            {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                {
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) w.rootA[r][c] = A[r][c];
+                    w.rootdinv[r] = rcp_(A[r][r]);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) w.ddq[iv + k] = b[k];
             w.agf[j] = w.agf[j] + Sp<T>{{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
@@ -500,9 +549,9 @@ template<class T, class Tp> JM_DEV void integrate_q(CPtr<T> P, const T * q, cons
 // ---------------------------------------------------------------- extra terms + sensors
 // Uses the kinematic data (liMi, oMi, vel, fext, cf, umotor) left in `w` by the last dynamics
 // evaluation, which is at the new state (engine.cc:2143-2151).
-template<class T, class Tp>
+template<class T, class Tp, class W>
 JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long lane, const T * q, const T * v,
-                                    const T * acc, Work<T, Tp> & w, bool sensors)
+                                    const T * acc, W & w, bool sensors)
 {
     using L = Layout<Tp>;
     constexpr int NJ = Tp::NJ;
@@ -701,14 +750,33 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 //       [2NV,3NV) velocity of the previous stage.
 template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
 
-template<class T, class Tp, int SBS>
-JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
+// constraint contact model (jm_constraint.h): the free evaluation above + constraint switching +
+// the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence
+template<class T, class Tp, class CA>
+JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
+                             long long lane, long long B, int start_passes);
+
+template<class T, class Tp, class CON, class W>
+JM_DEV void eval_any(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w,
+                     const typename CON::template ArgsT<T> & C, long long lane, long long B, int start_passes)
+{
+    if constexpr (CON::ON) eval_constrained<T, Tp>(P, q, v, cmd, w, C, lane, B, start_passes);
+    else
+    {
+        (void)C; (void)lane; (void)B; (void)start_passes;
+        eval_dynamics<T, Tp>(P, q, v, cmd, w);
+    }
+}
+
+template<class T, class Tp, int SBS, class CON = NoCon>
+JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
+                     const typename CON::template ArgsT<T> & C = typename CON::template ArgsT<T>{})
 {
     using L = Layout<Tp>;
     constexpr int NQ = Tp::NQ, NV = Tp::NV, NM = Tp::NM;
     const long long B = A.B;
     CPtr<T> P = (CPtr<T>)A.P;
-    Work<T, Tp> w;
+    typename CON::template WorkT<T, Tp> w;
     T qs[NQ], vs[NV], as[NV], cmd[c_max(NM, 1)];
 #ifdef JM_HOST_EMU
     // poison everything a GPU lane would find uninitialised: a read-before-write shows up as NaN
@@ -731,14 +799,14 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
         const T * vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
         static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
         static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
-        eval_dynamics<T, Tp>(P, qs, vs, cmd, w);
+        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B, (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : 0);
         if (A.mode == MODE_DYNAMICS)
         {
             static_for<0, NV>([&](auto ic) { A.a_out[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
             return;
         }
         // Engine::start: refuse huge initial contact forces (engine.cc:1310-1346)
-        if (A.mode != MODE_REFRESH)
+        if (A.mode != MODE_REFRESH && !CON::ON)
         {
             T fmax2 = T(0);
             static_for<0, Tp::NC>([&](auto cc) {
@@ -815,7 +883,7 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb)
                 static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = vs[decltype(ic)::value]; });
             }
         }
-        eval_dynamics<T, Tp>(P, qs, vs, cmd, w);
+        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B, 0);
         static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = w.ddq[decltype(ic)::value]; });
         if (k == -1 || k == 3)
             static_for<0, NV>([&](auto ic) { A.a[decltype(ic)::value * B + lane] = as[decltype(ic)::value]; });

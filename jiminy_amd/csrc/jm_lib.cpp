@@ -23,6 +23,7 @@
 #include JM_TOPO_HEADER
 
 #include "jm_kernels.h"
+#include "jm_constraint.h"
 #include "jm_pack.h"
 #include "jm_blocks.h"
 #include "jm_adaptive.h"
@@ -73,6 +74,8 @@ struct jm_batch
     int32_t * ad_is = nullptr;
     int32_t * ad_count = nullptr;       // device
     int32_t * ad_count_host = nullptr;  // pinned host
+    // constraint contact model (jm_constraint.h)
+    jm_constraint_options copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
     // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs (begin, end), ring of JM_TIMING_RING launches
@@ -147,7 +150,24 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     // (cheaper, single-evaluation) start / reset / dynamics launches
     const bool timed = b->timing && A.mode == jm::MODE_STEP && b->n_timed < JM_TIMING_RING;
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
-    if (b->variant == VARIANT_QUAD) launch_quad<T, Topo>(b, A, s);
+    if (b->copt.contact_model == JM_CONTACT_CONSTRAINT)
+    {
+        using R = jm::ConRows<Topo>;
+        if (R::NR > 0 && (!b->field[JM_F_CON_FLAGS] || !b->field[JM_F_CON_DATA] || !b->field[JM_F_WORKSPACE]))
+            return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': the con_flags, con_data and workspace fields must be bound");
+        jm::ConArgs<T> C;
+        C.flags = (int32_t *)b->field[JM_F_CON_FLAGS];
+        C.data = (T *)b->field[JM_F_CON_DATA];
+        C.ws = (T *)b->field[JM_F_WORKSPACE];
+        const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
+        C.kp = (T)(omega * omega);
+        C.kd = (T)(2.0 * omega);
+        C.torsion = (T)b->copt.torsion; C.reg = (T)b->copt.regularization;
+        C.tol_abs = (T)b->copt.tol_abs; C.tol_rel = (T)b->copt.tol_rel;
+        C.iter_max = b->copt.pgs_iter_max;
+        hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
+    }
+    else if (b->variant == VARIANT_QUAD) launch_quad<T, Topo>(b, A, s);
     else hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);
     HIP_TRY(hipGetLastError());
     if (timed)
@@ -324,7 +344,35 @@ int32_t jm_batch_set_options(jm_batch * b, const jm_options * o)
     jm::pack_options<Topo>(b->params, *o);
     return upload_params(b);
 }
-int32_t jm_batch_workspace_rows(const jm_batch *) { return 0; }
+int32_t jm_batch_workspace_rows(const jm_batch * b)
+{
+    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? jm::ConRows<Topo>::WTOTAL : 0;
+}
+int32_t jm_batch_set_constraint_options(jm_batch * b, const jm_constraint_options * o)
+{
+    if (!b || !o) return fail(JM_EINVAL, "jm_batch_set_constraint_options: null argument");
+    if (b->started)
+        return fail(JM_ECONTROLFLOW, "options cannot be changed while a simulation is running");  // engine.cc:2656-2662
+    if (o->contact_model != JM_CONTACT_SPRING_DAMPER && o->contact_model != JM_CONTACT_CONSTRAINT)
+        return fail(JM_EINVAL, "The requested contact model is not available.");  // engine.cc:2741-2747
+    if (!(o->regularization >= 0.0)) return fail(JM_EINVAL, "Constraint option 'regularization' must be positive.");
+    if (!(o->stabilization_freq >= 0.0)) return fail(JM_EINVAL, "Contact option 'stabilizationFreq' must be positive.");
+    if (!(o->torsion >= 0.0)) return fail(JM_EINVAL, "contacts.torsion must be non-negative");
+    if (!(o->tol_abs > 0.0) || !(o->tol_rel > 0.0)) return fail(JM_EINVAL, "tolAbs and tolRel must be positive");
+    if (o->pgs_iter_max <= 50) return fail(JM_EINVAL, "pgs_iter_max must exceed 50 (relaxation schedule of the PGS solver)");
+    // one-robot-per-lane kernel with 64-bit row offsets into the workspace; the batch must still fit
+    b->copt = *o;
+    return JM_OK;
+}
+int32_t jm_batch_constraint_rows(const jm_batch * b, int32_t * n_flag_rows, int32_t * n_data_rows, int32_t * n_workspace_rows)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_constraint_rows: null batch");
+    using R = jm::ConRows<Topo>;
+    if (n_flag_rows) *n_flag_rows = R::NF;
+    if (n_data_rows) *n_data_rows = R::ND;
+    if (n_workspace_rows) *n_workspace_rows = R::WTOTAL;
+    return JM_OK;
+}
 int32_t jm_batch_bind(jm_batch * b, int32_t field, void * ptr)
 {
     if (!b) return fail(JM_EINVAL, "jm_batch_bind: null batch");
@@ -414,6 +462,8 @@ int32_t jm_batch_step_adaptive(jm_batch * b, double t_next, const jm_adaptive_op
         return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before using step method.");
     if (!b->ad_ws || !b->ad_fs || !b->ad_is)
         return fail(JM_ECONTROLFLOW, "jm_batch_bind_adaptive must be called before the adaptive stepper is used");
+    if (b->copt.contact_model == JM_CONTACT_CONSTRAINT)
+        return fail(JM_ENOTIMPL, "contacts.model = 'constraint' is only available with the fixed-step solvers on the batched path");
     if (!(options->tol_rel > 0.0) || !(options->tol_abs > 0.0)) return fail(JM_EINVAL, "tolRel and tolAbs must be positive");
     if (!(options->dt_max >= 1e-6) || !(options->dt_max <= 0.02 + 1e-12)) return fail(JM_EINVAL, "'dtMax' option is out of range.");
     int32_t rc = check_bound(b, true);

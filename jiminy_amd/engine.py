@@ -41,7 +41,8 @@ SOLVER_IDS = {"euler_explicit": _abi.JM_SOLVER_EULER_EXPLICIT,
 def default_options() -> Dict[str, Dict[str, Any]]:
     """Hot-path subset of `Engine::getDefaultEngineOptions` (reference engine.h:260-481),
     same names and defaults (`odeSolver` = "runge_kutta_dopri": adaptive, every lane carries its
-    own step size), except `contacts.model` (reference default "constraint", outside this path)."""
+    own step size), except `contacts.model`: the reference default "constraint" is available with
+    the fixed-step solvers only, so the default here stays "spring_damper" (the north-star config)."""
     return {
         "world": {"gravity": [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]},
         "stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1.0e-5, "tolRel": 1.0e-4,
@@ -49,7 +50,9 @@ def default_options() -> Dict[str, Dict[str, Any]]:
                     "successiveIterFailedMax": 1000, "iterMax": 0,
                     "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
         "contacts": {"model": "spring_damper", "stiffness": 1.0e6, "damping": 2.0e3,
-                     "friction": 1.0, "transitionEps": 1.0e-3, "transitionVelocity": 1.0e-2},
+                     "friction": 1.0, "torsion": 0.0, "transitionEps": 1.0e-3,
+                     "transitionVelocity": 1.0e-2, "stabilizationFreq": 20.0},
+        "constraints": {"solver": "PGS", "regularization": 1.0e-3},
     }
 
 
@@ -380,9 +383,18 @@ class BatchedEngine:
             raise NotImplementedError(
                 f"odeSolver '{st['odeSolver']}' is not available on the batched path "
                 f"(available: {sorted(SOLVER_IDS)})")
-        if ct["model"] != "spring_damper":
+        if ct["model"] not in _abi.CONTACT_MODELS:
+            raise ValueError("The requested contact model is not available.")  # engine.cc:2741-2747
+        if ct["model"] == "constraint" and st["odeSolver"] == "runge_kutta_dopri":
             raise NotImplementedError(
-                "only contacts.model='spring_damper' is available on the batched path")
+                "contacts.model='constraint' is available with the fixed-step solvers "
+                "('euler_explicit', 'runge_kutta_4') on the batched path")
+        if new["constraints"]["solver"] != "PGS":
+            raise ValueError("The requested constraint solver is not available.")  # engine.cc:2720-2728
+        if float(new["constraints"]["regularization"]) < 0.0:
+            raise ValueError("Constraint option 'regularization' must be positive.")  # engine.cc:2730-2735
+        if float(ct["stabilizationFreq"]) < 0.0:
+            raise ValueError("Contact option 'stabilizationFreq' must be positive.")  # engine.cc:2758-2763
         dt_max = float(st["dtMax"])
         if not (SIMULATION_MIN_TIMESTEP - EPS <= dt_max <= SIMULATION_MAX_TIMESTEP + EPS):
             raise ValueError("'dtMax' option is out of range.")  # engine.cc:2668-2673
@@ -412,6 +424,23 @@ class BatchedEngine:
                               friction=ct["friction"], transition_eps=ct["transitionEps"],
                               transition_velocity=ct["transitionVelocity"])
         self._lib.check(self._L.jm_batch_set_options(self._batch_h, C.byref(o)))
+        # constraint contact model: PGS tolerances are the stepper tolerances (engine.cc:1366-1374)
+        st = self._options["stepper"]
+        co = _abi.make_constraint_options(
+            model=ct["model"], torsion=ct["torsion"], stabilization_freq=ct["stabilizationFreq"],
+            regularization=self._options["constraints"]["regularization"],
+            tol_abs=st["tolAbs"], tol_rel=st["tolRel"])
+        self._lib.check(self._L.jm_batch_set_constraint_options(self._batch_h, C.byref(co)))
+        if ct["model"] == "constraint" and "con_flags" not in self._fields:
+            # per-lane constraint state + delassus workspace (caller-owned, like every batch field)
+            nf, nd, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            self._lib.check(self._L.jm_batch_constraint_rows(self._batch_h, C.byref(nf), C.byref(nd), C.byref(nw)))
+            B = self.batch_size
+            self._fields["con_flags"] = torch.zeros((max(nf.value, 1), B), dtype=torch.int32, device=self.device)
+            self._fields["con_data"] = torch.zeros((max(nd.value, 1), B), dtype=self.dtype, device=self.device)
+            self._fields["workspace"] = torch.zeros((max(nw.value, 1), B), dtype=self.dtype, device=self.device)
+            for name in ("con_flags", "con_data", "workspace"):
+                self._bind(name)
 
     # ------------------------------------------------------------------ state access
     @property

@@ -141,3 +141,56 @@ def lowest_contact_height(model: CompiledModel, q: np.ndarray) -> np.ndarray:
         f = model.frames[c]
         z.append((ps[f.parent_joint] + Rs[f.parent_joint] @ f.p)[:, 2])
     return np.min(np.stack(z), axis=0)
+
+
+def sample_standing_states(model: CompiledModel, batch_size: int, seed: int = 0,
+                           joint_noise: float = 0.15, base_angle_max: float = 0.08,
+                           depth_range=(-2.0e-3, 5.0e-4), twist_std: float = 0.05,
+                           joint_vel_std: float = 0.2, command_fraction: float = 0.3,
+                           out_of_bounds_fraction: float = 0.25,
+                           out_of_bounds_max: float = 0.02) -> Dict[str, np.ndarray]:
+    """Seeded states for `contacts.model = "constraint"`: a floating-base robot standing on the
+    ground (neutral stance + joint noise, small base tilt, lowest contact point at a depth
+    U(depth_range) so that several contact constraints are active or inside the hysteresis band),
+    slow motion, and a fraction of the lanes with one to three bounded joints pushed past a
+    position limit by up to `out_of_bounds_max` (joint-bound constraints active, both directions).
+    Returns {'q', 'v', 'command'} laid out `[rows][B]` (float64)."""
+    rng = np.random.default_rng(seed)
+    B = int(batch_size)
+    q = np.repeat(model.neutral()[:, None], B, axis=1)
+    v = np.zeros((model.nv, B))
+    bounded = []
+    for j in range(1, model.njoints):
+        t, iq, iv = int(model.jtypes[j]), int(model.idx_q[j]), int(model.idx_v[j])
+        if t == JT_FREEFLYER:
+            q[iq + 0] = rng.uniform(-0.5, 0.5, B)
+            q[iq + 1] = rng.uniform(-0.5, 0.5, B)
+            q[iq + 2] = 1.0
+            axis = rng.normal(size=(3, B))
+            q[iq + 3:iq + 7] = _quat_from_axis_angle(axis, rng.uniform(0.0, base_angle_max, B))
+            v[iv:iv + 6] = rng.normal(0.0, twist_std, (6, B))
+        elif t in (JT_RUBX, JT_RUBY, JT_RUBZ, JT_RUBU):
+            th = rng.uniform(-joint_noise, joint_noise, B)
+            q[iq], q[iq + 1] = np.cos(th), np.sin(th)
+            v[iv] = rng.normal(0, joint_vel_std, B)
+        else:
+            lo, hi = model.position_lower[iq], model.position_upper[iq]
+            mid = np.clip(q[iq], lo + 0.05, hi - 0.05)
+            q[iq] = np.clip(mid + rng.uniform(-joint_noise, joint_noise, B), lo + 0.02, hi - 0.02)
+            v[iv] = rng.normal(0.0, joint_vel_std, B)
+            bounded.append((iq, lo, hi))
+    n_oob = int(round(out_of_bounds_fraction * B)) if bounded else 0
+    for lane in range(n_oob):
+        for _ in range(int(rng.integers(1, 4))):
+            iq, lo, hi = bounded[int(rng.integers(len(bounded)))]
+            over = rng.uniform(-0.5e-3, out_of_bounds_max)  # slightly inside = hysteresis band
+            q[iq, lane] = hi + over if rng.random() < 0.5 else lo - over
+    cmd = np.zeros((model.nmotors, B))
+    for i, m in enumerate(model.motors):
+        lim = m.effort_limit if np.isfinite(m.effort_limit) else 1.0
+        cmd[i] = rng.uniform(-command_fraction * lim, command_fraction * lim, B)
+    if model.has_freeflyer and model.ncontacts > 0:
+        zmin = lowest_contact_height(model, q)
+        q[2] += rng.uniform(depth_range[0], depth_range[1], B) - zmin
+    return {"q": np.ascontiguousarray(q), "v": np.ascontiguousarray(v),
+            "command": np.ascontiguousarray(cmd)}

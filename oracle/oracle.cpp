@@ -443,6 +443,26 @@ struct Engine
     std::vector<double> imu, force, contact, encoder, effort;
     int status = 0;
     long iter = 0;
+    // ---- `contacts.model = "constraint"`: per-robot constraint registry + solver state
+    jm_constraint_options copt{JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+    struct BoundCon  // JointConstraint (core/src/constraints/joint_constraint.cc)
+    {
+        int joint = 0;
+        bool enabled = false, reversed = false;
+        double ref = 0.0, lambda = 0.0;
+    };
+    struct FrameCon  // FrameConstraint with dofsFixed = {x, y, z, rot z} (core/src/robot/model.cc:817-823)
+    {
+        bool enabled = false;
+        double lambda[4] = {0, 0, 0, 0};
+    };
+    std::vector<BoundCon> bcon;
+    std::vector<FrameCon> fcon;
+    std::vector<double> uInternal;
+    int pgsIterLast = 0;
+    // optional per-lane storage of the constraint state for the batch drivers ([rows][B])
+    int32_t * con_flags = nullptr;
+    double * con_data = nullptr;
 };
 
 V3 joint_axis(const Model & m, int j)
@@ -753,10 +773,514 @@ void aba(Engine & e, const double * q, const double * v, const double * tau, con
     }
 }
 
+// ------------------------------------------------------------------ constraint contact model
+// Restates, in the reference's own formulation (dense joint-space inertia matrix + Cholesky,
+// dense constraint Jacobian, J M^-1 J^T, projected Gauss-Seidel):
+//   Engine::computeInternalDynamics  bounds hysteresis      engine.cc:3253-3338, 3340-3363
+//   computeContactDynamicsAtFrame    contact hysteresis     engine.cc:3117-3195 (CONSTRAINT branch)
+//   Model::computeConstraints        crba + drift kinematics core/src/robot/model.cc:1238-1287
+//   JointConstraint / FrameConstraint::computeJacobianAndDrift
+//                                    core/src/constraints/joint_constraint.cc:139-163, frame_constraint.cc:103-183
+//   pinocchio_overload::crba / computeJMinvJt / solveJMinvJtv
+//                                    pinocchio_overload_algorithms.h:99-124, 491-551
+//   PGSSolver                        core/src/solver/constraint_solvers.cc:107-448
+//   Engine::computeAcceleration      engine.cc:3710-3866
+// pinocchio::crba, nonLinearEffects, cholesky::decompose/solve (Pinocchio v2.7.0, not in tree) are
+// replaced by their dense definitions: M = sum_bodies X^T I X + diag(rotorInertia), nle = RNEA(q, v, 0),
+// M = L L^T.  The device path uses a different formulation (articulated-body solves), which is the point.
+struct Dense
+{
+    int r = 0, c = 0;
+    std::vector<double> d;
+    Dense() {}
+    Dense(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, 0.0) {}
+    double & operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+};
+
+// lower Cholesky factor in place (Eigen::LLT); returns false if not positive definite
+bool llt_inplace(Dense & A)
+{
+    const int n = A.r;
+    for (int j = 0; j < n; ++j)
+    {
+        double s = A(j, j);
+        for (int k = 0; k < j; ++k) s -= A(j, k) * A(j, k);
+        if (!(s > 0.0)) return false;
+        A(j, j) = std::sqrt(s);
+        for (int i = j + 1; i < n; ++i)
+        {
+            double t = A(i, j);
+            for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k);
+            A(i, j) = t / A(j, j);
+        }
+    }
+    return true;
+}
+void llt_solve(const Dense & L, double * x)  // x <- (L L^T)^-1 x
+{
+    const int n = L.r;
+    for (int i = 0; i < n; ++i)
+    {
+        double s = x[i];
+        for (int k = 0; k < i; ++k) s -= L(i, k) * x[k];
+        x[i] = s / L(i, i);
+    }
+    for (int i = n - 1; i >= 0; --i)
+    {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= L(k, i) * x[k];
+        x[i] = s / L(i, i);
+    }
+}
+
+void init_constraints(Engine & e)
+{
+    const Model & m = e.mdl;
+    if (e.bcon.empty() && e.fcon.empty())
+    {
+        for (int j = 1; j < m.njoints; ++j)
+            if (has_bounds(m.jtype[j]))
+            {
+                Engine::BoundCon b;
+                b.joint = j;
+                e.bcon.push_back(b);
+            }
+        e.fcon.resize(m.contacts.size());
+    }
+    e.uInternal.assign(m.nv, 0.0);
+}
+
+// Engine::start: resetConstraints + "enable constraints by default" (engine.cc:1266-1308)
+void reset_constraints(Engine & e)
+{
+    init_constraints(e);
+    for (auto & b : e.bcon)
+    {
+        b.ref = e.q[e.mdl.idx_q[b.joint]];  // JointConstraint::reset: configurationRef_ = q
+        b.lambda = 0.0;
+        b.reversed = false;
+        b.enabled = true;
+    }
+    for (auto & f : e.fcon)
+    {
+        f.enabled = true;
+        for (double & l : f.lambda) l = 0.0;
+    }
+}
+
+// computePositionLimitsForcesAlgo (engine.cc:3253-3338) for every bounded joint
+void toggle_bounds(Engine & e, const double * q)
+{
+    const Model & m = e.mdl;
+    const double eps = e.opt.contact_transition_eps;
+    for (auto & b : e.bcon)
+    {
+        const int iq = m.idx_q[b.joint];
+        const double qj = q[iq], lo = m.qlo[iq], hi = m.qhi[iq];
+        if (hi < qj || qj < lo)
+        {
+            b.ref = std::clamp(qj, lo, hi);
+            b.reversed = hi < qj;
+            b.enabled = true;
+        }
+        else if (lo + eps < qj && qj < hi - eps)
+        {
+            b.lambda = 0.0;  // AbstractConstraintBase::disable
+            b.enabled = false;
+        }
+    }
+}
+
+// computeContactDynamicsAtFrame, CONSTRAINT branch, flat ground (engine.cc:3145-3193)
+void toggle_contacts(Engine & e)
+{
+    const Model & m = e.mdl;
+    for (size_t i = 0; i < m.contacts.size(); ++i)
+    {
+        const FrameP & fr = m.contacts[i];
+        const SE3 oMf = e.oMi[fr.joint] * fr.M;
+        const double depth = (oMf.p.z - 0.0) * 1.0;
+        if (depth < 0.0) e.fcon[i].enabled = true;
+        else if (depth > e.opt.contact_transition_eps)
+        {
+            for (double & l : e.fcon[i].lambda) l = 0.0;
+            e.fcon[i].enabled = false;
+        }
+        // contactFrameForces stay zero with this model; contactForces_ = actInv(0) (engine.cc:3417-3424)
+        e.contactFrameForces[i] = Force();
+        e.contactForces[i] = Force();
+    }
+}
+
+bool has_constraints(const Engine & e)
+{
+    for (const auto & b : e.bcon) if (b.enabled) return true;
+    for (const auto & f : e.fcon) if (f.enabled) return true;
+    return false;
+}
+
+// PGSSolver::ProjectedGaussSeidelSolver over the packed active rows (constraint_solvers.cc:107-333)
+struct PgsRowSet
+{
+    // one entry per active constraint: start index, dim, number of blocks (1 = joint bound, 3 = contact)
+    struct C { int start, dim, nblocks; };
+    std::vector<C> cons;
+};
+bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const std::vector<double> & b,
+               std::vector<double> & x, int & iters)
+{
+    const int n = (int)b.size();
+    const double friction = e.opt.contact_friction, torsion = e.copt.torsion;
+    const unsigned iterMax = (unsigned)e.copt.pgs_iter_max;
+    std::vector<double> y(n, 0.0), yPrev(n, 0.0);
+    auto col_dot = [&](int i) {
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += A(k, i) * x[k];
+        return s;
+    };
+    for (unsigned iter = 0; iter < iterMax; ++iter)
+    {
+        yPrev = y;
+        const double ratio = (static_cast<double>(iterMax - 20U) - iter) / (iterMax - 20U - 30U);
+        double w = 1.0;
+        if (ratio < 1.0)
+        {
+            w = 0.01;
+            if (ratio > 0.0) w += (1.0 - 0.01) * std::pow(ratio, 2.0);
+        }
+        for (int blk = 0; blk < 3; ++blk)
+            for (const auto & c : rs.cons)
+            {
+                if (c.nblocks <= blk) continue;
+                const int o = c.start;
+                // blocks (constraint_solvers.cc:48-87): 0: {2} lo 0 hi inf (joint bound: {0});
+                // 1: {3, 2} hi = torsion; 2: {0, 1, 2} hi = friction
+                int fIndex[3] = {0, 0, 0}, fSize = 1;
+                double lo = 0.0, hi = INF;
+                bool isZero = false;
+                if (c.nblocks == 3)
+                {
+                    if (blk == 0) { fIndex[0] = 2; fSize = 1; }
+                    else if (blk == 1) { fIndex[0] = 3; fIndex[1] = 2; fSize = 2; hi = torsion; isZero = torsion < EPS; }
+                    else { fIndex[0] = 0; fIndex[1] = 1; fIndex[2] = 2; fSize = 3; hi = friction; isZero = friction < EPS; }
+                }
+                const int i0 = o + fIndex[0];
+                double & el = x[i0];
+                if (isZero)
+                {
+                    el *= 0;
+                    for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= 0;
+                    continue;
+                }
+                double A_max = A(i0, i0);
+                y[i0] = b[i0] - col_dot(i0);
+                for (int j = 1; j < fSize - 1; ++j)
+                {
+                    const int k = o + fIndex[j];
+                    y[k] = b[k] - col_dot(k);
+                    if (A(k, k) > A_max) A_max = A(k, k);
+                }
+                el += w * y[i0] / A_max;
+                for (int j = 1; j < fSize - 1; ++j)
+                {
+                    const int k = o + fIndex[j];
+                    x[k] += w * y[k] / A_max;
+                }
+                if (fSize == 1) el = std::clamp(el, lo, hi);
+                else
+                {
+                    const double thr = hi * x[o + fIndex[fSize - 1]];
+                    if (fSize == 2) el = std::clamp(el, -thr, thr);
+                    else
+                    {
+                        double squaredNorm = el * el;
+                        for (int j = 1; j < fSize - 1; ++j) squaredNorm += x[o + fIndex[j]] * x[o + fIndex[j]];
+                        if (squaredNorm > thr * thr)
+                        {
+                            const double scale = thr / std::sqrt(squaredNorm);
+                            el *= scale;
+                            for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= scale;
+                        }
+                    }
+                }
+            }
+        double ymax = 0.0;
+        for (int i = 0; i < n; ++i) ymax = std::max(ymax, std::fabs(y[i]));
+        const double tol = e.copt.tol_abs + e.copt.tol_rel * ymax + EPS;
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok &= std::fabs(y[i] - yPrev[i]) < tol;
+        if (ok)
+        {
+            iters = (int)iter + 1;
+            return true;
+        }
+    }
+    iters = (int)iterMax;
+    return false;
+}
+
+// Engine::computeAcceleration (engine.cc:3710-3866). `u` is RobotState::u (in: efforts without the
+// constraint forces; out: + joint-bound multipliers), e.fExternal likewise for the contact forces.
+void compute_acceleration(Engine & e, const double * q, const double * v, std::vector<double> & u, bool ignoreBounds)
+{
+    const Model & m = e.mdl;
+    const int nv = m.nv, NJ = m.njoints;
+    e.status &= ~JM_LANE_SOLVER_FAILURE;  // status of the last evaluation
+    e.pgsIterLast = 0;
+    if (!has_constraints(e))
+    {
+        aba(e, q, v, u.data(), e.fExternal);
+        return;
+    }
+    const V3 g = {e.opt.gravity[0], e.opt.gravity[1], e.opt.gravity[2]};
+    const V3 gw = {e.opt.gravity[3], e.opt.gravity[4], e.opt.gravity[5]};
+    // ---- world-frame joint Jacobian columns (data.J) and supports
+    std::vector<Motion> Jw(nv);
+    std::vector<int> dof_joint(nv);
+    for (int j = 1; j < NJ; ++j)
+    {
+        const int n = jt_nv(m.jtype[j]), iv = m.idx_v[j];
+        for (int k = 0; k < n; ++k)
+        {
+            double unit[6] = {0, 0, 0, 0, 0, 0};
+            unit[k] = 1.0;
+            Jw[iv + k] = act(e.oMi[j], S_times(m, j, unit));
+            dof_joint[iv + k] = j;
+        }
+    }
+    auto supports = [&](int joint, int dof) {  // dof belongs to an ancestor-or-self of joint
+        for (int j = joint; j > 0; j = m.parent[j]) if (dof_joint[dof] == j) return true;
+        return false;
+    };
+    // ---- joint-space inertia matrix with rotor armature (pinocchio_overload::crba :99-124)
+    Dense M(nv, nv);
+    for (int j = 1; j < NJ; ++j)
+    {
+        std::vector<int> sup;
+        for (int a = 0; a < nv; ++a) if (supports(j, a)) sup.push_back(a);
+        std::vector<Motion> X(sup.size());
+        std::vector<Force> IX(sup.size());
+        for (size_t a = 0; a < sup.size(); ++a)
+        {
+            X[a] = actInv(e.oMi[j], Jw[sup[a]]);
+            IX[a] = mul(m.inertia[j], X[a]);
+        }
+        for (size_t a = 0; a < sup.size(); ++a)
+            for (size_t b2 = 0; b2 < sup.size(); ++b2)
+                M(sup[a], sup[b2]) += dot(X[a].lin, IX[b2].lin) + dot(X[a].ang, IX[b2].ang);
+    }
+    for (int i = 0; i < nv; ++i) M(i, i) += m.rotor[i];
+    // ---- non-linear effects: RNEA(q, v, 0) with gravity (pinocchio::nonLinearEffects)
+    std::vector<double> nle(nv, 0.0);
+    {
+        std::vector<Motion> ag(NJ);
+        std::vector<Force> f(NJ);
+        ag[0] = {-g, -gw};
+        for (int j = 1; j < NJ; ++j)
+        {
+            const Motion vj = S_times(m, j, &v[m.idx_v[j]]);
+            ag[j] = crossm(e.dv[j], vj) + actInv(e.liMi[j], ag[m.parent[j]]);
+            f[j] = mul(m.inertia[j], ag[j]) + vxiv(m.inertia[j], e.dv[j]);
+        }
+        for (int j = NJ - 1; j > 0; --j)
+        {
+            const int n = jt_nv(m.jtype[j]), iv = m.idx_v[j];
+            for (int k = 0; k < n; ++k)
+            {
+                double unit[6] = {0, 0, 0, 0, 0, 0};
+                unit[k] = 1.0;
+                const Motion S = S_times(m, j, unit);
+                nle[iv + k] = dot(S.lin, f[j].lin) + dot(S.ang, f[j].ang);
+            }
+            if (m.parent[j] > 0) f[m.parent[j]] = f[m.parent[j]] + act(e.liMi[j], f[j]);
+        }
+    }
+    // ---- drift kinematics: accelerations with ddq = 0 and no gravity (model.cc:1252-1268)
+    std::vector<Motion> adrift(NJ);
+    for (int j = 1; j < NJ; ++j)
+    {
+        const Motion vj = S_times(m, j, &v[m.idx_v[j]]);
+        adrift[j] = crossm(e.dv[j], vj);
+        if (m.parent[j] > 0) adrift[j] = adrift[j] + actInv(e.liMi[j], adrift[m.parent[j]]);
+    }
+    // ---- data.u = u + sum_j J_j^T fext_j (engine.cc:3733-3749)
+    std::vector<double> du(u);
+    for (int j = 1; j < NJ; ++j)
+    {
+        double fv[6];
+        to6(e.fExternal[j], fv);
+        bool any = false;
+        for (double x : fv) any |= std::fabs(x) > EPS;
+        if (!any) continue;
+        for (int a = 0; a < nv; ++a)
+            if (supports(j, a))
+            {
+                const Motion X = actInv(e.oMi[j], Jw[a]);  // LOCAL joint Jacobian column
+                du[a] += dot(X.lin, e.fExternal[j].lin) + dot(X.ang, e.fExternal[j].ang);
+            }
+    }
+    // ---- Jacobian, drift, multipliers of the enabled constraints, packed (constraint_solvers.cc:340-360)
+    const double omega = 2.0 * M_PI * e.copt.stabilization_freq;  // setBaumgarteFreq (abstract_constraint.cc:88-98)
+    const double kp = omega * omega, kd = 2.0 * omega;
+    PgsRowSet rs;
+    int rows = 0;
+    for (const auto & b : e.bcon) if (b.enabled) { rs.cons.push_back({rows, 1, 1}); rows += 1; }
+    for (const auto & f : e.fcon) if (f.enabled) { rs.cons.push_back({rows, 4, 3}); rows += 4; }
+    Dense J(rows, nv);
+    std::vector<double> gamma(rows, 0.0), lambda(rows, 0.0);
+    int r = 0;
+    for (const auto & b : e.bcon)
+    {
+        if (!b.enabled) continue;
+        const int iq = m.idx_q[b.joint], iv = m.idx_v[b.joint];
+        const double sgn = b.reversed ? -1.0 : 1.0;
+        J(r, iv) = sgn;
+        gamma[r] = sgn * (kp * (q[iq] - b.ref) + kd * v[iv]);
+        lambda[r] = b.lambda;
+        ++r;
+    }
+    for (size_t i = 0; i < e.fcon.size(); ++i)
+    {
+        if (!e.fcon[i].enabled) continue;
+        const FrameP & fr = m.contacts[i];
+        const SE3 oMf = e.oMi[fr.joint] * fr.M;
+        const double depth = oMf.p.z;
+        // frame Jacobian in (rotationLocal = identity, frame translation): transformLocal.actInv(data.J col)
+        for (int a = 0; a < nv; ++a)
+        {
+            if (!supports(fr.joint, a)) continue;
+            const V3 lin = Jw[a].lin - cross(oMf.p, Jw[a].ang);
+            J(r + 0, a) = lin.x; J(r + 1, a) = lin.y; J(r + 2, a) = lin.z; J(r + 3, a) = Jw[a].ang.z;
+        }
+        // velocity and drift acceleration, LOCAL_WORLD_ALIGNED
+        const Motion vl = actInv(fr.M, e.dv[fr.joint]);
+        const Motion al = actInv(fr.M, adrift[fr.joint]);
+        const V3 vlin = oMf.R * vl.lin, vang = oMf.R * vl.ang;
+        V3 dlin = oMf.R * al.lin, dang = oMf.R * al.ang;
+        dlin = dlin + cross(vang, vlin);
+        // Baumgarte: reference transform moved to the ground surface every evaluation
+        // (engine.cc:3186-3193) -> deltaPosition = depth * n, deltaRotation = 0
+        dlin = dlin + kp * V3{0.0, 0.0, depth} + kd * vlin;
+        dang = dang + kd * vang;
+        gamma[r] = dlin.x; gamma[r + 1] = dlin.y; gamma[r + 2] = dlin.z; gamma[r + 3] = dang.z;
+        for (int k = 0; k < 4; ++k) lambda[r + k] = e.fcon[i].lambda[k];
+        r += 4;
+    }
+    // ---- JMinvJt (computeJMinvJt :491-533) + regularisation (constraint_solvers.cc:376-387)
+    Dense L = M;
+    if (!llt_inplace(L)) e.status |= JM_LANE_NAN;
+    Dense Y(nv, rows);  // L^-1 J^T
+    for (int c = 0; c < rows; ++c)
+    {
+        for (int i = 0; i < nv; ++i)
+        {
+            double s = J(c, i);
+            for (int k = 0; k < i; ++k) s -= L(i, k) * Y(k, c);
+            Y(i, c) = s / L(i, i);
+        }
+    }
+    Dense A(rows, rows);
+    for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < rows; ++j)
+        {
+            double s = 0.0;
+            for (int k = 0; k < nv; ++k) s += Y(k, i) * Y(k, j);
+            A(i, j) = s;
+        }
+    for (int i = 0; i < rows; ++i) A(i, i) += std::max(A(i, i) * e.copt.regularization, 1.0e-11);
+    // ---- dynamic drift: torque_residual = M^-1 (u - nle); b = -gamma - J torque_residual
+    std::vector<double> tr(nv);
+    for (int i = 0; i < nv; ++i) tr[i] = du[i] - nle[i];
+    llt_solve(L, tr.data());
+    std::vector<double> b(rows);
+    for (int i = 0; i < rows; ++i)
+    {
+        double s = 0.0;
+        for (int k = 0; k < nv; ++k) s += J(i, k) * tr[k];
+        b[i] = -gamma[i] - s;
+    }
+    // ---- multipliers
+    bool ok = true;
+    if (ignoreBounds)
+    {
+        Dense LA = A;
+        if (!llt_inplace(LA)) e.status |= JM_LANE_NAN;
+        lambda = b;
+        llt_solve(LA, lambda.data());  // solveJMinvJtv :535-551
+        e.pgsIterLast = 0;
+    }
+    else ok = pgs_solve(e, rs, A, b, lambda, e.pgsIterLast);
+    if (!ok) e.status |= JM_LANE_SOLVER_FAILURE;
+    // ---- ddq = M^-1 J^T lambda + torque_residual
+    std::vector<double> ddq(nv, 0.0);
+    for (int k = 0; k < nv; ++k)
+    {
+        double s = 0.0;
+        for (int i = 0; i < rows; ++i) s += J(i, k) * lambda[i];
+        ddq[k] = s;
+    }
+    llt_solve(L, ddq.data());
+    for (int k = 0; k < nv; ++k) e.ddq[k] = ddq[k] + tr[k];
+    // ---- write the multipliers back; bounds efforts and contact forces (engine.cc:3770-3857)
+    r = 0;
+    for (auto & bc : e.bcon)
+    {
+        if (!bc.enabled) continue;
+        bc.lambda = lambda[r++];
+        const int iv = m.idx_v[bc.joint];
+        e.uInternal[iv] += bc.lambda;
+        u[iv] += bc.lambda;
+    }
+    for (size_t i = 0; i < e.fcon.size(); ++i)
+    {
+        if (!e.fcon[i].enabled) continue;
+        for (int k = 0; k < 4; ++k) e.fcon[i].lambda[k] = lambda[r + k];
+        const FrameP & fr = m.contacts[i];
+        const SE3 oMf = e.oMi[fr.joint] * fr.M;
+        const V3 fW = {lambda[r], lambda[r + 1], lambda[r + 2]};
+        const V3 tW = {0.0, 0.0, lambda[r + 3]};
+        e.contactForces[i].lin = tmul(oMf.R, fW);
+        e.contactForces[i].ang = tmul(oMf.R, tW);
+        Force fl;  // convertForceGlobalFrameToJoint
+        fl.lin = tmul(e.oMi[fr.joint].R, fW);
+        fl.ang = tmul(e.oMi[fr.joint].R, tW) + cross(fr.M.p, fl.lin);
+        e.fExternal[fr.joint] = e.fExternal[fr.joint] + fl;
+        r += 4;
+    }
+}
+
+// Engine::computeRobotsDynamics with `contacts.model = "constraint"` (engine.cc:3585-3708):
+// computeAllTerms (hysteresis) -> motors -> u -> computeAcceleration
+void dynamics_constraint(Engine & e, const double * q, const double * v, double * a_out)
+{
+    const Model & m = e.mdl;
+    if (e.uInternal.empty()) init_constraints(e);
+    forward_kin(e, q, v);
+    for (auto & f : e.fExternal) f = Force();
+    std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
+    toggle_bounds(e, q);
+    toggle_contacts(e);
+    motor_efforts(e, v);
+    for (int i = 0; i < m.nv; ++i) e.u[i] = e.uInternal[i];
+    for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
+    compute_acceleration(e, q, v, e.u, false);
+    for (int i = 0; i < m.nv; ++i)
+    {
+        a_out[i] = e.ddq[i];
+        if (e.ddq[i] != e.ddq[i]) e.status |= JM_LANE_NAN;
+    }
+}
+
 // Engine::computeRobotsDynamics for one robot (engine.cc:3585-3708), spring-damper contacts,
 // discrete controller (command held), no user internal dynamics, no flexibility.
 void dynamics(Engine & e, const double * q, const double * v, double * a_out)
 {
+    if (e.copt.contact_model == JM_CONTACT_CONSTRAINT)
+    {
+        dynamics_constraint(e, q, v, a_out);
+        return;
+    }
     const Model & m = e.mdl;
     forward_kin(e, q, v);
     // computeAllTerms: reset, internal dynamics (bounds -> status flag), contacts
@@ -940,8 +1464,47 @@ void check_state_nan(Engine & e)
 
 // Engine::start with an externally held command: the INIT_ITERATIONS fixed point
 // (engine.cc:1399-1467) converges after the first pass since command does not depend on a.
+// Engine::start with `contacts.model = "constraint"` (engine.cc:1266-1308, 1380-1467): every
+// constraint is enabled first, computeAllTerms applies the hysteresis, then INIT_ITERATIONS = 4
+// passes of computeAcceleration -- the first one with `ignoreBounds` (exact unbounded solve) and
+// with RobotState::u still zero, the next ones warm-started PGS solves with
+// u = uInternal (incl. the bound multipliers of the previous pass) + motor efforts.
+void start_constraint(Engine & e)
+{
+    const Model & m = e.mdl;
+    e.status = 0;
+    e.iter = 0;
+    forward_kin(e, e.q.data(), e.v.data());
+    reset_constraints(e);
+    for (auto & f : e.fExternal) f = Force();
+    toggle_bounds(e, e.q.data());
+    toggle_contacts(e);
+    std::fill(e.u.begin(), e.u.end(), 0.0);
+    for (int it = 0; it < 4; ++it)
+    {
+        for (auto & f : e.fExternal) f = Force();
+        std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
+        compute_acceleration(e, e.q.data(), e.v.data(), e.u, it == 0);
+        for (int i = 0; i < m.nv; ++i)
+        {
+            e.a[i] = e.ddq[i];
+            if (e.ddq[i] != e.ddq[i]) e.status |= JM_LANE_NAN;
+        }
+        extra_terms(e);
+        sensors(e);
+        motor_efforts(e, e.v.data());
+        for (int i = 0; i < m.nv; ++i) e.u[i] = e.uInternal[i];
+        for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
+    }
+}
+
 void start(Engine & e)
 {
+    if (e.copt.contact_model == JM_CONTACT_CONSTRAINT)
+    {
+        start_constraint(e);
+        return;
+    }
     const Model & m = e.mdl;
     e.status = 0;
     e.iter = 0;
@@ -1362,6 +1925,23 @@ extern "C"
 void * orc_engine_create(const jm_model_desc * d, const jm_options * o) { return make_engine(d, o); }
 void orc_engine_destroy(void * h) { delete static_cast<Engine *>(h); }
 void orc_engine_set_options(void * h, const jm_options * o) { static_cast<Engine *>(h)->opt = *o; }
+void orc_engine_set_constraint_options(void * h, const jm_constraint_options * o) { static_cast<Engine *>(h)->copt = *o; }
+// per-lane constraint state of the batch drivers: flags int32 [NB + NC][B], data [2 NB + 4 NC][B]
+// (reference configuration and multiplier of every bounded joint, then 4 multipliers per contact)
+void orc_engine_bind_constraints(void * h, int32_t * flags, double * data)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    e.con_flags = flags;
+    e.con_data = data;
+}
+int orc_engine_constraint_counts(void * h, int * n_bounds, int * n_contacts)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    if (e.uInternal.empty()) init_constraints(e);
+    *n_bounds = (int)e.bcon.size();
+    *n_contacts = (int)e.fcon.size();
+    return e.pgsIterLast;
+}
 
 void orc_engine_set_state(void * h, const double * q, const double * v, const double * a)
 {
@@ -1445,6 +2025,23 @@ struct orc_batch_io
 static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
     const int64_t B = io.B;
+    if (e.con_flags && e.con_data)
+    {
+        if (e.uInternal.empty()) init_constraints(e);
+        const int64_t nb = (int64_t)e.bcon.size(), nc = (int64_t)e.fcon.size();
+        for (int64_t k = 0; k < nb; ++k)
+        {
+            const int32_t f = e.con_flags[k * B + l];
+            e.bcon[k].enabled = f & 1; e.bcon[k].reversed = (f & 2) != 0;
+            e.bcon[k].ref = e.con_data[k * B + l];
+            e.bcon[k].lambda = e.con_data[(nb + k) * B + l];
+        }
+        for (int64_t c = 0; c < nc; ++c)
+        {
+            e.fcon[c].enabled = e.con_flags[(nb + c) * B + l] & 1;
+            for (int k = 0; k < 4; ++k) e.fcon[c].lambda[k] = e.con_data[(2 * nb + 4 * c + k) * B + l];
+        }
+    }
     for (int i = 0; i < e.mdl.nq; ++i) e.q[i] = io.q[i * B + l];
     for (int i = 0; i < e.mdl.nv; ++i) e.v[i] = io.v[i * B + l];
     for (int i = 0; i < e.mdl.nv; ++i) e.a[i] = io.a[i * B + l];
@@ -1453,6 +2050,21 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
     const int64_t B = io.B;
+    if (e.con_flags && e.con_data)
+    {
+        const int64_t nb = (int64_t)e.bcon.size(), nc = (int64_t)e.fcon.size();
+        for (int64_t k = 0; k < nb; ++k)
+        {
+            e.con_flags[k * B + l] = (e.bcon[k].enabled ? 1 : 0) | (e.bcon[k].reversed ? 2 : 0);
+            e.con_data[k * B + l] = e.bcon[k].ref;
+            e.con_data[(nb + k) * B + l] = e.bcon[k].lambda;
+        }
+        for (int64_t c = 0; c < nc; ++c)
+        {
+            e.con_flags[(nb + c) * B + l] = e.fcon[c].enabled ? 1 : 0;
+            for (int k = 0; k < 4; ++k) e.con_data[(2 * nb + 4 * c + k) * B + l] = e.fcon[c].lambda[k];
+        }
+    }
     for (int i = 0; i < e.mdl.nq; ++i) io.q[i * B + l] = e.q[i];
     for (int i = 0; i < e.mdl.nv; ++i) io.v[i * B + l] = e.v[i];
     for (int i = 0; i < e.mdl.nv; ++i) io.a[i * B + l] = e.a[i];

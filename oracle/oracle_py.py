@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         L.orc_engine_create.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options)]
         L.orc_engine_destroy.argtypes = [C.c_void_p]
         L.orc_engine_set_options.argtypes = [C.c_void_p, C.POINTER(_abi.Options)]
+        L.orc_engine_set_constraint_options.argtypes = [C.c_void_p, C.POINTER(_abi.ConstraintOptions)]
+        L.orc_engine_bind_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_engine_constraint_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_engine_constraint_counts.restype = C.c_int
         pd = C.POINTER(C.c_double)
         L.orc_engine_set_state.argtypes = [C.c_void_p, pd, pd, pd]
         L.orc_engine_set_command.argtypes = [C.c_void_p, pd]
@@ -116,6 +120,28 @@ class OracleEngine:
     def set_options(self, **options) -> None:
         self.options = _abi.make_options(**options)
         self._L.orc_engine_set_options(self._h, C.byref(self.options))
+
+    # ---- `contacts.model = "constraint"`
+    def set_constraint_options(self, **options) -> None:
+        self.constraint_options = _abi.make_constraint_options(**options)
+        self._L.orc_engine_set_constraint_options(self._h, C.byref(self.constraint_options))
+
+    def bind_constraints(self, flags: Optional[np.ndarray], data: Optional[np.ndarray]) -> None:
+        """Per-lane constraint state of the batch drivers (`_abi.constraint_rows`): `flags` int32
+        `[con_flags][B]`, `data` float64 `[con_data][B]`; with single-robot calls pass `[rows][1]`."""
+        if flags is None:
+            self._L.orc_engine_bind_constraints(self._h, None, None)
+            self._con = None
+            return
+        assert flags.dtype == np.int32 and data.dtype == np.float64
+        assert flags.flags.c_contiguous and data.flags.c_contiguous
+        self._con = (flags, data)
+        self._L.orc_engine_bind_constraints(self._h, flags.ctypes.data, data.ctypes.data)
+
+    @property
+    def pgs_iterations(self) -> int:
+        nb, nc = C.c_int(0), C.c_int(0)
+        return int(self._L.orc_engine_constraint_counts(self._h, C.byref(nb), C.byref(nc)))
 
     def start(self, q, v, command=None) -> None:
         q = np.ascontiguousarray(q, dtype=np.float64)

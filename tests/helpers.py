@@ -28,9 +28,19 @@ def oracle_io(arr: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
 
 
 def oracle_batch(model: CompiledModel, arr: Dict[str, np.ndarray], mode: str, options=None,
-                 **kw) -> None:
+                 constraint_options=None, **kw) -> None:
     e = OracleEngine(model, **(options or {}))
+    if constraint_options is not None:
+        e.set_constraint_options(**constraint_options)
+        e.bind_constraints(arr["con_flags"], arr["con_data"])
     e.batch_run(mode, oracle_io(arr), **kw)
+
+
+def alloc_constraint_state(model: CompiledModel, arr: Dict[str, np.ndarray], B: int, dtype=np.float64) -> None:
+    """Add the per-lane constraint state rows (`contacts.model = "constraint"`) to an SoA dict."""
+    rows = _abi.constraint_rows(model)
+    arr["con_flags"] = np.zeros((max(rows["con_flags"], 1), B), dtype=np.int32)
+    arr["con_data"] = np.zeros((max(rows["con_data"], 1), B), dtype=dtype)
 
 
 def rel_err(x: np.ndarray, ref: np.ndarray, lanes=None) -> float:

@@ -4,12 +4,14 @@
 #define JM_HOST_EMU 1
 #include <pthread.h>
 
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
 #include JM_TOPO_HEADER
 #include "../../jiminy_amd/csrc/jm_kernels.h"
+#include "../../jiminy_amd/csrc/jm_constraint.h"
 #include "../../jiminy_amd/csrc/jm_pack.h"
 
 extern "C"
@@ -88,6 +90,21 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
     else { (void)A; (void)P; }
 }
 
+// constraint contact model: options + per-lane state rows (flags int32 [NF][B], data [ND][B]); the
+// delassus workspace is allocated here
+static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+static void * g_con_flags = nullptr;
+static void * g_con_data = nullptr;
+extern "C" void emu_set_constraints(const jm_constraint_options * o, void * flags, void * data)
+{
+    g_copt = *o;
+    g_con_flags = flags;
+    g_con_data = data;
+}
+extern "C" void emu_constraint_rows(int * nf, int * nd, int * nw)
+{
+    *nf = jm::ConRows<Topo>::NF; *nd = jm::ConRows<Topo>::ND; *nw = jm::ConRows<Topo>::WTOTAL;
+}
 static int g_variant = 0;  // 0 = one robot per lane, 1 = limb-parallel (4 lanes per robot)
 extern "C" void emu_set_variant(int v) { g_variant = v; }
 extern "C" int emu_has_quad() { return Topo::QUAD ? 1 : 0; }
@@ -121,6 +138,18 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         return 0;
     }
     std::vector<T> sb(jm::stage_rows<Topo>() + 1);
+    if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
+    {
+        std::vector<T> wsp((size_t)(jm::ConRows<Topo>::WTOTAL + 1) * io->B, (T)std::nan(""));
+        jm::ConArgs<T> C;
+        C.flags = (int32_t *)g_con_flags; C.data = (T *)g_con_data; C.ws = wsp.data();
+        const double omega = 2.0 * 3.14159265358979323846 * g_copt.stabilization_freq;
+        C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
+        C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
+        C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
+        for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1, jm::WithCon>(A, lane, sb.data(), C);
+        return 0;
+    }
     for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1>(A, lane, sb.data());
     return 0;
 }

@@ -38,6 +38,8 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L = C.CDLL(out)
     L.emu_run.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options), C.POINTER(EmuIO),
                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+    L.emu_set_constraints.argtypes = [C.POINTER(_abi.ConstraintOptions), C.c_void_p, C.c_void_p]
+    L.emu_set_constraints.restype = None
     _CACHE[h] = L
     return L
 
@@ -49,8 +51,14 @@ SOLVERS = {"euler_explicit": 0, "runge_kutta_4": 1}
 def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=None,
         solver: str = "runge_kutta_4", dt: float = 1e-3, n_substeps: int = 1,
         command_changed: bool = True, update_sensors: bool = True, dtype=np.float64,
-        variant: str = "lane") -> None:
+        variant: str = "lane", constraint_options=None) -> None:
     L = _lib(model)
+    if constraint_options is not None:
+        co = _abi.make_constraint_options(**constraint_options)
+        L.emu_set_constraints(C.byref(co), arrays["con_flags"].ctypes.data, arrays["con_data"].ctypes.data)
+    else:
+        co = _abi.make_constraint_options(model="spring_damper")
+        L.emu_set_constraints(C.byref(co), None, None)
     if variant == "quad" and not L.emu_has_quad():
         raise RuntimeError("this topology has no limb-parallel variant")
     L.emu_set_variant(1 if variant == "quad" else 0)

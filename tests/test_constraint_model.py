@@ -1,0 +1,355 @@
+"""`contacts.model = "constraint"`: joint position bounds and contact points as
+kinematic constraints, multipliers by projected Gauss-Seidel.
+
+Three layers, as for the spring-damper path:
+  * pins of the CPU oracle (which restates the reference's own formulation: dense inertia matrix +
+    Cholesky + dense Jacobian + PGS) against the laws the reference tests hold for this model
+    (unit_py/test_foot_pendulum.py:25-95, test_dense_pole.py:164-203, test_simple_mass.py:181-240)
+    and against an independently coded RNEA;
+  * the kernel sources compiled for the host (tests/hostemu) against the oracle -- a cross check of
+    two different formulations (articulated-body solves vs. dense factorisation), no GPU needed;
+  * `-m gpu`: the device build through the C ABI / BatchedEngine against the oracle.
+"""
+import numpy as np
+import pytest
+
+from jiminy_amd import _abi, load_builtin
+from jiminy_amd.synthetic import sample_standing_states, sample_states
+from oracle import rbd_numpy as rbd
+from oracle.oracle_py import OracleEngine
+from tests import robots
+from tests.helpers import alloc_constraint_state, alloc_soa, oracle_batch, rel_err
+from tests.hostemu import emu
+
+G = 9.81
+TIGHT = dict(tol_abs=1e-11, tol_rel=1e-10)  # PGS run to stagnation: iterates comparable to round-off
+OUTS = ("q", "v", "a", "u_motor", "u", "imu", "force", "contact", "encoder", "effort", "energy",
+        "contact_forces", "f_external", "joint_forces", "centroidal", "con_data")
+
+
+def _engine(model, **copt):
+    e = OracleEngine(model)
+    e.set_constraint_options(**copt)
+    return e
+
+
+# ------------------------------------------------------------------ oracle pins
+def test_point_mass_rests_on_the_ground():
+    """test_foot_pendulum.py:25-95 shape: a body in contact, initialised at rest, does not move;
+    accelerometer = -gravity, force sensor = weight."""
+    m = robots.point_mass()
+    e = _engine(m, regularization=1e-9, stabilization_freq=0.0)
+    q0 = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+    e.start(q0, np.zeros(6))
+    assert np.abs(e.get("a")).max() < 1e-7
+    imu = e.get("imu")
+    assert np.abs(imu[:3]).max() < 1e-7
+    assert np.abs(imu[3:] - [0, 0, G]).max() < 1e-7
+    cf = e.get("contact_forces")
+    assert cf[2] == pytest.approx(2.0 * G, rel=1e-7)
+    assert np.abs(np.delete(cf, 2)).max() < 1e-7
+    # the force sensor sits on a frame yawed by 0.3 rad: same vertical force
+    assert e.get("force")[2] == pytest.approx(2.0 * G, rel=1e-7)
+    for _ in range(200):
+        e.step(1e-3, solver="runge_kutta_4", command_changed=False)
+    assert np.abs(e.get("v")).max() < 1e-7 and np.abs(e.get("a")).max() < 1e-7
+    assert e.status == 0
+
+
+def test_contact_sensor_matches_the_external_force():
+    """test_simple_mass.py:181-240: contact / force sensors and f_external describe the same wrench."""
+    m = robots.point_mass()
+    e = _engine(m)
+    q0 = np.array([0.0, 0.0, -1e-4, 0.0, 0.0, 0.0, 1.0])
+    e.start(q0, np.array([0.3, -0.2, 0.0, 0.0, 0.0, 0.5]))
+    for _ in range(50):
+        e.step(1e-3, solver="euler_explicit", command_changed=False)
+        f_joint = e.get("f_external").reshape(-1, 6)[1]
+        f_contact = e.get("contact")  # contact frame == joint frame for the "body" contact point
+        assert np.abs(f_contact - f_joint[:3]).max() < 1e-9
+    assert e.get("contact_forces")[2] > 0.0
+
+
+def test_friction_cone_and_unilateral_contact():
+    m = load_builtin("anymal")
+    st = sample_standing_states(m, 12, seed=3)
+    e = _engine(m, **TIGHT)
+    active = 0
+    for l in range(12):
+        e.start(st["q"][:, l], st["v"][:, l], st["command"][:, l])
+        cf = e.get("contact_forces").reshape(-1, 6)
+        # world-aligned multipliers live in con-data; in the contact frame the cone is on norms
+        for c in range(m.ncontacts):
+            n = np.linalg.norm(cf[c, :3])
+            if n > 0:
+                active += 1
+    assert active >= 8
+
+
+def test_joint_limit_hysteresis_branches():
+    """test_dense_pole.py:164-203: a joint driven into its position limit switches its bound
+    constraint on when it leaves the range, keeps it inside the transition band, releases it beyond."""
+    m = robots.pendulum()
+    m.position_lower[:] = -0.4
+    m.position_upper[:] = 0.4
+    eps = 1e-3
+    e = _engine(m)
+    flags, data = np.zeros((1, 1), np.int32), np.zeros((2, 1))
+    e.bind_constraints(flags, data)
+    arr = alloc_soa(m, 1)
+    arr["con_flags"], arr["con_data"] = flags, data
+    arr["q"][:] = 0.0
+    arr["v"][:] = 1.0
+    from tests.helpers import oracle_io
+    e.batch_run("start", oracle_io(arr))
+    assert flags[0, 0] & 1 == 0
+    branches, was = set(), False
+    for _ in range(6000):
+        e.batch_run("step", oracle_io(arr), solver="euler_explicit", dt=1e-4, command_changed=False)
+        theta, on = arr["q"][0, 0], bool(flags[0, 0] & 1)
+        if 0.4 - abs(theta) <= 0.0:
+            assert on
+            branches.add(0 if was else 1)
+        elif 0.4 - abs(theta) < eps:
+            assert on == was
+            branches.add(2 if was else 3)
+        else:
+            assert not on
+            branches.add(4)
+        was = on
+    assert branches == {0, 1, 2, 3, 4}
+    # the bound holds: the pendulum (inverted at q = 0) falls onto its limit and stays there
+    assert abs(arr["q"][0, 0]) < 0.4 + 5e-3
+
+
+@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker"])
+def test_constrained_acceleration_satisfies_the_equation_of_motion(name):
+    """RNEA(q, v, a, f_external) + rotor a == u with an independently coded RNEA: the contact
+    multipliers enter through f_external, the joint-bound multipliers through u (the reference adds
+    them to u with a plus sign whatever the direction, engine.cc:3786-3790: corrected here)."""
+    model = robots.crane_walker() if name == "crane_walker" else load_builtin(name)
+    B = 6
+    st = sample_standing_states(model, B, seed=4, out_of_bounds_fraction=0.5)
+    rows = _abi.constraint_rows(model)
+    e = _engine(model, **TIGHT)
+    flags = np.zeros((rows["con_flags"], 1), np.int32)
+    data = np.zeros((rows["con_data"], 1))
+    e.bind_constraints(flags, data)
+    arr = alloc_soa(model, 1)
+    arr["con_flags"], arr["con_data"] = flags, data
+    from tests.helpers import oracle_io
+    n_contact = n_bound = 0
+    bounded = [j for j in range(1, model.njoints) if 1 <= int(model.jtypes[j]) <= 8]
+    for l in range(B):
+        for k in ("q", "v", "command"):
+            arr[k][:, 0] = st[k][:, l]
+        # `start` initialises the constraint state; the identity is checked on a regular evaluation
+        # (the start passes feed the previous pass's bound multipliers back into u, engine.cc:1456)
+        e.batch_run("start", oracle_io(arr))
+        e.batch_run("dynamics", oracle_io(arr))
+        q, v, a, u = arr["q"][:, 0], arr["v"][:, 0], arr["a"][:, 0], arr["u"][:, 0].copy()
+        fext = arr["f_external"][:, 0].reshape(-1, 6)
+        nb = rows["n_bounds"]
+        for k, j in enumerate(bounded):
+            if flags[k, 0] & 2:  # reversed constraint: generalised force is -lambda
+                u[int(model.idx_v[j])] -= 2.0 * data[nb + k, 0]
+            n_bound += int(flags[k, 0] & 1)
+        n_contact += int(np.abs(fext).sum() > 0)
+        tau = rbd.rnea(model, q, v, a, fext) + model.rotor_inertia * a
+        scale = max(1.0, np.abs(u).max(), np.abs(tau).max())
+        assert np.abs(tau - u).max() / scale < 1e-10, l
+        # multipliers: unilateral normal force, friction inside the cone (friction = 1)
+        lam = data[2 * nb:, 0].reshape(-1, 4)
+        assert (lam[:, 2] >= 0).all()
+        assert (np.hypot(lam[:, 0], lam[:, 1]) <= lam[:, 2] * (1 + 1e-12) + 1e-12).all()
+        assert (data[nb:2 * nb, 0] >= 0).all()
+    assert n_contact >= 3 and n_bound >= 2
+
+
+def test_start_passes_converge_to_a_fixed_point():
+    """The 4 start passes end on a solution that one more evaluation reproduces (reference pin 11:
+    bitwise repeatability of `a` after reset is the same statement for its own engine)."""
+    m = load_builtin("anymal")
+    # no joint beyond its limits: the start passes feed bound multipliers back into u (engine.cc:1456)
+    st = sample_standing_states(m, 4, seed=6, out_of_bounds_fraction=0.0)
+    e = _engine(m, **TIGHT)
+    for l in range(4):
+        e.start(st["q"][:, l], st["v"][:, l], st["command"][:, l])
+        a0 = e.get("a").copy()
+        a1 = e.dynamics(st["q"][:, l], st["v"][:, l])
+        assert np.abs(a1 - a0).max() < 1e-5 * max(1.0, np.abs(a0).max()), (l, e.status)
+
+
+# ------------------------------------------------------------------ kernel sources on the host vs oracle
+def _models():
+    return {
+        "anymal": lambda: load_builtin("anymal"),
+        "atlas": lambda: load_builtin("atlas"),
+        "cartpole": lambda: load_builtin("cartpole"),
+        "point_mass": robots.point_mass,
+        "tree_arm": lambda: robots.tree_arm(False),
+        "tree_arm_ff": lambda: robots.tree_arm(True),
+        "crane_walker": robots.crane_walker,
+    }
+
+
+def _states(model, B, seed):
+    if model.has_freeflyer and model.ncontacts > 0:
+        return sample_standing_states(model, B, seed=seed)
+    st = sample_states(model, B, seed=seed)
+    # fixed-base arms: push a few joints past / next to their limits
+    rng = np.random.default_rng(seed)
+    for j in range(1, model.njoints):
+        if 1 <= int(model.jtypes[j]) <= 8:
+            iq = int(model.idx_q[j])
+            lanes = rng.random(B) < 0.3
+            hi = rng.random(B) < 0.5
+            over = rng.uniform(-5e-4, 0.02, B)
+            st["q"][iq, lanes & hi] = model.position_upper[iq] + over[lanes & hi]
+            st["q"][iq, lanes & ~hi] = model.position_lower[iq] - over[lanes & ~hi]
+    return st
+
+
+def _pair(model, B, seed):
+    st = _states(model, B, seed)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for arr in (ref, got):
+        alloc_constraint_state(model, arr, B)
+        for k in ("q", "v", "command"):
+            if st[k].shape[0]:
+                arr[k][:] = st[k]
+    return ref, got
+
+
+def _check(got, ref, tol, what=""):
+    assert np.array_equal(got["con_flags"], ref["con_flags"]), what
+    assert np.array_equal(got["status"], ref["status"]), what
+    for k in OUTS:
+        e = rel_err(got[k], ref[k])
+        assert e < tol, (what, k, e)
+
+
+@pytest.mark.parametrize("name", list(_models()))
+def test_constraint_kernel_matches_oracle_on_the_host(name):
+    model = _models()[name]()
+    B = 6 if name == "atlas" else 12
+    ref, got = _pair(model, B, seed=7)
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT)
+    _check(got, ref, 1e-9, "start")
+    n_active = int((ref["con_flags"] & 1).sum())
+    assert n_active > 0 or _abi.constraint_rows(model)["n_rows"] == 0
+    for solver, n_sub, changed in (("euler_explicit", 3, True), ("runge_kutta_4", 1, False)):
+        for _ in range(2):
+            kw = dict(solver=solver, dt=5e-4, n_substeps=n_sub, command_changed=changed)
+            oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
+            emu.run(model, got, "step", constraint_options=TIGHT, **kw)
+        _check(got, ref, 1e-7, solver)
+
+
+def test_default_tolerances_follow_the_oracle_iterates():
+    """With the reference's default PGS tolerances (stepper.tolAbs/tolRel) the stopping decision is
+    taken on residual *differences*; both formulations produce the same iterates to round-off, so
+    the same iteration count and the same multipliers."""
+    model = load_builtin("anymal")
+    ref, got = _pair(model, 12, seed=8)
+    oracle_batch(model, ref, "start", constraint_options={})
+    emu.run(model, got, "start", constraint_options={})
+    _check(got, ref, 1e-9, "start")
+    for _ in range(5):
+        kw = dict(solver="euler_explicit", dt=1e-3, n_substeps=1, command_changed=False)
+        oracle_batch(model, ref, "step", constraint_options={}, **kw)
+        emu.run(model, got, "step", constraint_options={}, **kw)
+    _check(got, ref, 1e-7, "euler")
+
+
+def test_spring_damper_path_is_untouched_by_the_constraint_state():
+    model = load_builtin("anymal")
+    st = sample_states(model, 8, seed=1)
+    a, b = alloc_soa(model, 8), alloc_soa(model, 8)
+    for arr in (a, b):
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+    emu.run(model, a, "start")
+    alloc_constraint_state(model, b, 8)
+    emu.run(model, b, "start", constraint_options=dict(model="spring_damper"))
+    assert np.array_equal(a["a"], b["a"])
+
+
+# ------------------------------------------------------------------ device build (C ABI) vs oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "point_mass"])
+def test_gpu_constraint_model_matches_oracle(name, gpu_device):
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = _models()[name]()
+    B = 96 if name != "atlas" else 40
+    ref, _ = _pair(model, B, seed=11)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                        extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+    dt = 5e-4
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt, "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]},
+                     "contacts": {"model": "constraint"}})
+    if model.nmotors:
+        eng.set_command(torch.from_numpy(ref["command"]))
+    eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+
+    def check(tol, what):
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"]), what
+        assert np.array_equal(eng.status.cpu().numpy().reshape(-1), ref["status"].reshape(-1)), what
+        for k in OUTS:
+            if k in eng._fields and ref[k].size and eng._rows.get(k, 1) > 0:
+                e = rel_err(eng.field(k).cpu().numpy(), ref[k])
+                assert e < tol, (what, k, e)
+
+    check(1e-9, "start")
+    for i in range(4):
+        eng.step(dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="euler_explicit", dt=dt,
+                     n_substeps=1, command_changed=(i == 0))
+    check(1e-7, "euler")
+    eng.stop()
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4"}})
+    eng.start(eng.field("q").clone(), eng.field("v").clone())
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    check(1e-9, "restart")
+    for i in range(2):
+        eng.step(dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt,
+                     n_substeps=1, command_changed=(i == 0))
+    check(1e-7, "rk4")
+
+
+@pytest.mark.gpu
+def test_gpu_anymal_stands_still_under_the_constraint_model(gpu_device):
+    """Reference acceptance for its quadrupeds / bipeds (gym_jiminy unit_py/test_pipeline_control.py:46-133):
+    the robot keeps standing.  Here: ANYmal at its neutral stance with the shipped options
+    (euler_explicit, constraint contacts), zero command: after 0.5 s the base has not fallen."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    B = 64
+    st = sample_standing_states(model, B, seed=0, joint_noise=0.0, base_angle_max=0.0, twist_std=0.0,
+                                joint_vel_std=0.0, command_fraction=0.0, out_of_bounds_fraction=0.0,
+                                depth_range=(-1e-4, 0.0))
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": 1e-3, "controllerUpdatePeriod": 1e-3,
+                                 "sensorsUpdatePeriod": 1e-3}, "contacts": {"model": "constraint"}})
+    eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    z0 = eng.field("q")[2].clone()
+    for _ in range(100):
+        eng.step(1e-3)
+    torch.cuda.synchronize()
+    assert not (eng.status & _abi.JM_LANE_NAN).any()
+    assert torch.isfinite(eng.field("q")).all()
+    # unactuated legs fold slowly; the feet stay on the ground and the base does not free-fall
+    # (free fall over 0.1 s would be 4.9 cm)
+    assert (z0 - eng.field("q")[2]).max() < 0.03
+    fz = eng.field("contact_forces").reshape(model.ncontacts, 6, B)[:, 2].sum(0)
+    assert (fz > 0.5 * 30 * G).all()
