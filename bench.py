@@ -34,6 +34,11 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
+def _abi_rows(model):
+    from jiminy_amd import _abi
+    return _abi.constraint_rows(model)
+
+
 def algorithmic_scalars(model) -> int:
     """Scalars that must cross HBM once per env-step (SURVEY.md 8d / BASELINE.md section 3):
     reads q, v, a_prev, command; writes q, v, a; writes the sensor outputs."""
@@ -44,29 +49,39 @@ def algorithmic_scalars(model) -> int:
     return (model.nq + 2 * model.nv + model.nmotors) + (model.nq + 2 * model.nv) + obs
 
 
-def cpu_baseline(model, states, dt: float, budget_s: float = 12.0):
+def cpu_baseline(model, states, dt: float, budget_s: float = 12.0, solver: str = "runge_kutta_4",
+                 constraint_options=None):
     """Oracle timed on the host: 1 thread (the reference's shape: one engine, one robot, one
     thread), then all cores with independent slices (the SubprocVecEnv analogue without IPC)."""
     from oracle.oracle_py import OracleEngine
-    from tests.helpers import alloc_soa, oracle_io
+    from tests.helpers import alloc_constraint_state, alloc_soa, oracle_io
 
     def make(B):
         arr = alloc_soa(model, B)
         for k in ("q", "v", "command"):
             arr[k][:] = states[k][:, :B]
+        if constraint_options is not None:
+            alloc_constraint_state(model, arr, B)
         return arr
+
+    def OracleEngineFor(arr):
+        e = OracleEngine(model)
+        if constraint_options is not None:
+            e.set_constraint_options(**constraint_options)
+            e.bind_constraints(arr["con_flags"], arr["con_data"])
+        return e
 
     n_lanes, n_steps = 512, 4
     arr = make(n_lanes)
-    e = OracleEngine(model)
+    e = OracleEngineFor(arr)
     io = oracle_io(arr)
     e.batch_run("start", io)
-    e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+    e.batch_run("step", io, solver=solver, dt=dt, n_substeps=1, command_changed=False)
     t0 = time.perf_counter()
     done = 0
     while time.perf_counter() - t0 < budget_s * 0.5:
         for _ in range(n_steps):
-            e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1,
+            e.batch_run("step", io, solver=solver, dt=dt, n_substeps=1,
                         command_changed=False)
         done += n_lanes * n_steps
     single = done / (time.perf_counter() - t0)
@@ -74,7 +89,7 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0):
     cores = os.cpu_count() or 1
     per = 256
     arrs = [make(per) for _ in range(cores)]
-    engines = [OracleEngine(model) for _ in range(cores)]
+    engines = [OracleEngineFor(a) for a in arrs]
     ios = [oracle_io(a) for a in arrs]
     for eng, i in zip(engines, ios):
         eng.batch_run("start", i)
@@ -83,7 +98,7 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0):
 
     def work(k):
         while time.perf_counter() < stop_at:
-            engines[k].batch_run("step", ios[k], solver="runge_kutta_4", dt=dt, n_substeps=1,
+            engines[k].batch_run("step", ios[k], solver=solver, dt=dt, n_substeps=1,
                                  command_changed=False)
             counts[k] += per
 
@@ -97,7 +112,8 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0):
     return {
         "value": single, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n_lanes} lanes of the same seeded ANYmal batch stepped for ~{budget_s * 0.5:.0f} s "
-                  f"by oracle/liboracle.so (g++ -O3, float64, RK4 dt={dt})",
+                  f"by oracle/liboracle.so (g++ -O3, float64, {solver} dt={dt}"
+                  + (", constraint contact model" if constraint_options is not None else "") + ")",
         "all_cores": {"value": multi, "cores": cores,
                       "sample": f"{cores} threads x {per} lanes, independent slices, "
                                 f"~{budget_s * 0.5:.0f} s"},
@@ -112,7 +128,11 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=65536, help="lanes per GPU")
     ap.add_argument("--model", default="anymal")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--solver", default="runge_kutta_4")
+    ap.add_argument("--solver", default=None, help="default: runge_kutta_4 (euler_explicit with the constraint model)")
+    ap.add_argument("--contact-model", default="spring_damper", choices=["spring_damper", "constraint"],
+                    help="'constraint': secondary workload, the contact model the reference's shipped ANYmal "
+                         "options select (joint bounds + contact points as constraints, PGS), robots standing "
+                         "on four feet")
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--gather-obs", action="store_true",
                     help="all-gather the observation block over RCCL every step (config 4 topology)")
@@ -124,13 +144,16 @@ def main() -> None:
                          "region, and reports the worst fraction of valid lanes seen before a reset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    constrained = args.contact_model == "constraint"
+    if args.solver is None:
+        args.solver = "euler_explicit" if constrained else "runge_kutta_4"
 
     import torch
     import torch.distributed as dist
 
     from jiminy_amd import load_builtin
     from jiminy_amd.engine import BatchedEngine
-    from jiminy_amd.synthetic import sample_states
+    from jiminy_amd.synthetic import sample_standing_states, sample_states
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,10 +171,18 @@ def main() -> None:
     model = load_builtin(args.model)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     B = args.batch
-    states = sample_states(model, B, seed=rank)
+    if constrained:
+        # robots standing on all their feet (lowest contact point 5-6 mm into the ground, small joint /
+        # attitude noise), 5 % of the lanes with joints beyond a position limit
+        states = sample_standing_states(model, B, seed=rank, joint_noise=0.01, base_angle_max=0.004,
+                                        depth_range=(-6e-3, -5e-3), twist_std=0.02, joint_vel_std=0.05,
+                                        command_fraction=0.1, out_of_bounds_fraction=0.05)
+    else:
+        states = sample_states(model, B, seed=rank)
     eng = BatchedEngine(model, B, dtype=dtype, device=device, extra_outputs=("contact_forces",))
     eng.set_options({"stepper": {"odeSolver": args.solver, "dtMax": args.dt,
-                                 "controllerUpdatePeriod": args.dt, "sensorsUpdatePeriod": args.dt}})
+                                 "controllerUpdatePeriod": args.dt, "sensorsUpdatePeriod": args.dt},
+                     "contacts": {"model": args.contact_model}})
     eng.set_command(torch.from_numpy(states["command"]).to(dtype))
     eng.start(torch.from_numpy(states["q"]).to(dtype), torch.from_numpy(states["v"]).to(dtype))
 
@@ -170,7 +201,7 @@ def main() -> None:
         eng.step(args.dt)
         n_done += 1
         if args.episode > 0 and n_done % args.episode == 0:
-            st = eng.status
+            st = eng.status & ~16  # JM_LANE_SOLVER_FAILURE is not a lane failure
             torch.minimum(ok_min, (st == 0).double().mean(), out=ok_min)
             torch.maximum(nan_max, ((st & 1) != 0).double().mean(), out=nan_max)
             torch.maximum(oob_max, ((st & 2) != 0).double().mean(), out=oob_max)
@@ -189,7 +220,7 @@ def main() -> None:
         one_step()
     if args.episode > 0:
         # one untimed pass through the episode-boundary code (lazy torch kernels, reset launch)
-        torch.minimum(ok_min, (eng.status == 0).double().mean(), out=ok_min)
+        torch.minimum(ok_min, ((eng.status & ~16) == 0).double().mean(), out=ok_min)
         eng.reset_lanes(all_lanes, q_seed, v_seed)
         n_done = 0
     barrier()
@@ -206,6 +237,9 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     status = eng.status.cpu().numpy()
+    pgs_fail = float(((status & 16) != 0).mean())
+    active = float((eng.field("con_flags") & 1).sum(0).double().mean().item()) if constrained else None
+    status = status & ~16
     ok_frac = min(float((status == 0).mean()), float(ok_min.item()))
     nan_frac = max(float(((status & 1) != 0).mean()), float(nan_max.item()))
     oob_frac = max(float(((status & 2) != 0).mean()), float(oob_max.item()))
@@ -223,6 +257,14 @@ def main() -> None:
         traffic = None
         valu = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if constrained:
+            # + the per-lane constraint state read and written once per step (flags int32, reference
+            # configurations + multipliers); the delassus workspace is scratch, not algorithmic traffic
+            rows = _abi_rows(model)
+            alg_bytes_per_launch += 2 * (rows["con_flags"] * 4 + rows["con_data"] * sz) * B
+            achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+            kernel_name = "jm::k_constrained"
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json")
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
@@ -244,20 +286,24 @@ def main() -> None:
                 traffic = None
         out = {
             "metric": ("env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak"
-                       if args.model == "anymal" else f"env-steps/s (whole node) {args.model} batch {B}"),
+                       if args.model == "anymal" and not constrained
+                       else f"env-steps/s (whole node) {args.model} batch {B}"
+                            + (" constraint contact model" if constrained else "")),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} nq{model.nq} nv{model.nv} {model.nmotors} motors "
-                                   f"{model.ncontacts} spring-damper contact points, "
+                                   f"{model.ncontacts} {'constraint (PGS)' if constrained else 'spring-damper'} contact points, "
                                    f"{args.solver} dt={args.dt} command held, extra terms + sensors",
                        "lanes_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"
                                       + (" + obs all-gather" if args.gather_obs else ""),
                        "episode_steps": args.episode,
                        "lanes_ok_min": ok_frac, "lanes_nan_max": nan_frac,
-                       "lanes_out_of_joint_bounds_max": oob_frac},
+                       "lanes_out_of_joint_bounds_max": oob_frac,
+                       **({"mean_active_constraints": active, "lanes_pgs_iteration_cap_last_eval": pgs_fail}
+                          if constrained else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "launches_timed": n_launch,
@@ -266,7 +312,8 @@ def main() -> None:
                          "secondary": valu},
         }
         if world == 1 and not args.no_cpu_baseline and args.model == "anymal":
-            out["cpu_baseline"] = cpu_baseline(model, states, args.dt)
+            out["cpu_baseline"] = cpu_baseline(model, states, args.dt, solver=args.solver,
+                                               constraint_options={} if constrained else None)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -179,7 +179,7 @@ enum {
  *   one row per bounded 1-dof joint (`JointConstraint`, model joint order; continuous joints never
  *   activate and own no row), then 4 rows per contact point (`FrameConstraint` with the translation
  *   and the rotation about the ground normal fixed: x, y, z, torsion; core/src/robot/model.cc:817-823).
- * Only explicit fixed-step solvers are available with this model on the batched path. */
+ * Only explicit fixed-step solvers and float64 batches are available with this model on the batched path. */
 enum { JM_CONTACT_SPRING_DAMPER = 0, JM_CONTACT_CONSTRAINT = 1 };
 typedef struct jm_constraint_options {
     int32_t contact_model;      /* contacts.model: JM_CONTACT_*                      */

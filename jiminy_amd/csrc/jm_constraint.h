@@ -60,7 +60,9 @@ template<class Tp> struct ConRows
     static constexpr int NF = NB + NC;
     static constexpr int ND = NB + NR;
     static constexpr int LAM = NB;  // first lambda row in `data`
-    static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WTOTAL = WD + NR;
+    // workspace rows: delassus matrix over the PACKED active rows (stride NR), then b, y, y_prev, a diagonal
+    // backup and the packed multipliers x
+    static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WX = WD + NR, WTOTAL = WX + NR;
     static constexpr int bjoint(int k)
     {
         int n = 0;
@@ -94,7 +96,64 @@ template<int NW> struct RowMaskN
         for (int i = 0; i < NW; ++i) o |= w[i];
         return o != 0ull;
     }
+    JM_DEV int count() const
+    {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) n += __builtin_popcountll(w[i]);
+        return n;
+    }
+    // number of set bits below row r = packed index of row r among the active rows
+    JM_DEV int rank(int r) const
+    {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+        {
+            const int lo = r - 64 * i;  // bits of word i below r
+            const unsigned long long m = lo >= 64 ? ~0ull : (lo <= 0 ? 0ull : ((1ull << lo) - 1ull));
+            n += __builtin_popcountll(w[i] & m);
+        }
+        return n;
+    }
+    // index of the lowest set bit, which is cleared (the mask must not be empty)
+    JM_DEV int pop_lowest()
+    {
+        int r = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (!found && w[i] != 0ull)
+            {
+                r = 64 * i + __builtin_ctzll(w[i]);
+                w[i] &= w[i] - 1ull;
+                found = true;
+            }
+        return r;
+    }
 };
+
+// visits every contact point: compile-time parent joint `jc`, run-time contact index `c` (robots with many
+// contact points per body -- Atlas: 16 per foot -- would otherwise unroll every loop per point)
+template<class Tp> constexpr bool joint_has_contact(int j)
+{
+    for (int c = 0; c < Tp::NC; ++c)
+        if (Tp::contact_joint[c] == j) return true;
+    return false;
+}
+template<class Tp, class F> JM_DEV void for_contacts(F && f)
+{
+    if constexpr (Tp::NC > 0)
+        static_for<1, Tp::NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (joint_has_contact<Tp>(j))
+            {
+#pragma nounroll
+                for (int c = 0; c < Tp::NC; ++c)
+                    if (Tp::contact_joint[c] == j) f(jc, c);
+            }
+        });
+}
 
 // dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias
 // of the last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).
@@ -169,10 +228,9 @@ JM_DEV void rows_of_motion(CPtr<T> P, const WorkC<T, Tp> & w, const RowMask & ac
         constexpr int iv = Tp::idx_v[R::bjoint(k)];
         if (act.test(k)) put(k, rev.test(k) ? -dd[iv] : dd[iv]);
     });
-    static_for<0, R::NC>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        constexpr int j = Tp::contact_joint[c];
-        constexpr int r0 = R::NB + 4 * c;
+    for_contacts<Tp>([&](auto jc, int c) {
+        constexpr int j = decltype(jc)::value;
+        const int r0 = R::NB + 4 * c;
         if (act.test(r0))
         {
             const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
@@ -183,79 +241,69 @@ JM_DEV void rows_of_motion(CPtr<T> P, const WorkC<T, Tp> & w, const RowMask & ac
     });
 }
 
-// Cholesky solve A x = b over the active rows (start pass with `ignoreBounds`, solveJMinvJtv).
+// Cholesky solve A x = b over the m packed rows (start pass with `ignoreBounds`, solveJMinvJtv).
 // The lower triangle and the diagonal of A are used as factor storage and restored afterwards
 // (diagonal from a backup, lower triangle mirrored from the upper one like constraint_solvers.cc:421).
-template<class T, class Tp, class RowMask, class WS, class LAM>
-JM_DEV bool chol_solve_active(const RowMask & act, WS && ws, LAM && lam)
+template<class T, class Tp, class WS>
+JM_DEV bool chol_solve_packed(int m, WS && ws)
 {
     using R = ConRows<Tp>;
     constexpr int NR = R::NR;
     bool ok = true;
-    for (int j = 0; j < NR; ++j)
+    for (int j = 0; j < m; ++j)
     {
-        if (!act.test(j)) continue;
         ws(R::WD + j) = ws(R::WA + j * NR + j);
         T s = ws(R::WA + j * NR + j);
-        for (int k = 0; k < j; ++k)
-            if (act.test(k)) { const T l = ws(R::WA + j * NR + k); s -= l * l; }
+        for (int k = 0; k < j; ++k) { const T l = ws(R::WA + j * NR + k); s -= l * l; }
         ok &= s > T(0);
         const T d = sqrt_(s);
         ws(R::WA + j * NR + j) = d;
-        for (int i = j + 1; i < NR; ++i)
+        for (int i = j + 1; i < m; ++i)
         {
-            if (!act.test(i)) continue;
             T t = ws(R::WA + i * NR + j);
-            for (int k = 0; k < j; ++k)
-                if (act.test(k)) t -= ws(R::WA + i * NR + k) * ws(R::WA + j * NR + k);
+            for (int k = 0; k < j; ++k) t -= ws(R::WA + i * NR + k) * ws(R::WA + j * NR + k);
             ws(R::WA + i * NR + j) = t / d;
         }
     }
-    for (int i = 0; i < NR; ++i)
+    for (int i = 0; i < m; ++i)
     {
-        if (!act.test(i)) continue;
         T s = ws(R::WB + i);
-        for (int k = 0; k < i; ++k)
-            if (act.test(k)) s -= ws(R::WA + i * NR + k) * lam(k);
-        lam(i) = s / ws(R::WA + i * NR + i);
+        for (int k = 0; k < i; ++k) s -= ws(R::WA + i * NR + k) * ws(R::WX + k);
+        ws(R::WX + i) = s / ws(R::WA + i * NR + i);
     }
-    for (int i = NR - 1; i >= 0; --i)
+    for (int i = m - 1; i >= 0; --i)
     {
-        if (!act.test(i)) continue;
-        T s = lam(i);
-        for (int k = i + 1; k < NR; ++k)
-            if (act.test(k)) s -= ws(R::WA + k * NR + i) * lam(k);
-        lam(i) = s / ws(R::WA + i * NR + i);
+        T s = ws(R::WX + i);
+        for (int k = i + 1; k < m; ++k) s -= ws(R::WA + k * NR + i) * ws(R::WX + k);
+        ws(R::WX + i) = s / ws(R::WA + i * NR + i);
     }
-    for (int i = 0; i < NR; ++i)
+    for (int i = 0; i < m; ++i)
     {
-        if (!act.test(i)) continue;
         ws(R::WA + i * NR + i) = ws(R::WD + i);
-        for (int k = 0; k < i; ++k)
-            if (act.test(k)) ws(R::WA + i * NR + k) = ws(R::WA + k * NR + i);
+        for (int k = 0; k < i; ++k) ws(R::WA + i * NR + k) = ws(R::WA + k * NR + i);
     }
     return ok;
 }
 
-// PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333) over the active rows.
-template<class T, class Tp, class RowMask, class WS, class LAM>
-JM_DEV bool pgs_solve(const ConArgs<T> & C, T friction, const RowMask & act, WS && ws, LAM && lam)
+// PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333) over the m packed rows:
+// the first `nb` rows are joint bounds, then blocks of 4 rows (x, y, z, torsion) per active contact.
+template<class T, class Tp, class WS>
+JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS && ws)
 {
     using R = ConRows<Tp>;
     constexpr int NR = R::NR;
     const T eps = Eps<T>::eps;
     auto col_dot = [&](int i) {
         T s = T(0);
-        for (int k = 0; k < NR; ++k)
-            if (act.test(k)) s += ws(R::WA + k * NR + i) * lam(k);
+        for (int k = 0; k < m; ++k) s += ws(R::WA + k * NR + i) * ws(R::WX + k);
         return s;
     };
-    for (int r = 0; r < NR; ++r) ws(R::WY + r) = T(0);
+    for (int r = 0; r < m; ++r) ws(R::WY + r) = T(0);
     const bool torsion_zero = C.torsion < eps, friction_zero = friction < eps;
     const unsigned iter_max = (unsigned)C.iter_max;
     for (unsigned iter = 0; iter < iter_max; ++iter)
     {
-        for (int r = 0; r < NR; ++r) ws(R::WYP + r) = ws(R::WY + r);
+        for (int r = 0; r < m; ++r) ws(R::WYP + r) = ws(R::WY + r);
         // under-relaxation schedule (constraint_solvers.cc:248-258)
         const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
         T w = T(1);
@@ -265,41 +313,38 @@ JM_DEV bool pgs_solve(const ConArgs<T> & C, T friction, const RowMask & act, WS 
             if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
         }
         // block 0 of every constraint: joint bounds, then the normal force of every contact
-        for (int r = 0; r < NR; r += (r < R::NB ? 1 : 4))
+        for (int r = 0; r < m; r += (r < nb ? 1 : 4))
         {
-            if (!act.test(r)) continue;
-            const int i0 = r < R::NB ? r : r + 2;
+            const int i0 = r < nb ? r : r + 2;
             const T y = ws(R::WB + i0) - col_dot(i0);
             ws(R::WY + i0) = y;
-            const T e = lam(i0) + w * y / ws(R::WA + i0 * NR + i0);
-            lam(i0) = fmax_(e, T(0));  // clamp(e, 0, inf)
+            const T e = ws(R::WX + i0) + w * y / ws(R::WA + i0 * NR + i0);
+            ws(R::WX + i0) = fmax_(e, T(0));  // clamp(e, 0, inf)
         }
         // block 1: torsional friction {3, 2}
-        for (int r = R::NB; r < NR; r += 4)
+        for (int r = nb; r < m; r += 4)
         {
-            if (!act.test(r)) continue;
-            if (torsion_zero) { lam(r + 3) = lam(r + 3) * T(0); continue; }
+            if (torsion_zero) { ws(R::WX + r + 3) = ws(R::WX + r + 3) * T(0); continue; }
             const int i0 = r + 3;
             const T y = ws(R::WB + i0) - col_dot(i0);
             ws(R::WY + i0) = y;
-            const T e = lam(i0) + w * y / ws(R::WA + i0 * NR + i0);
-            const T thr = C.torsion * lam(r + 2);
-            lam(i0) = clamp_(e, -thr, thr);
+            const T e = ws(R::WX + i0) + w * y / ws(R::WA + i0 * NR + i0);
+            const T thr = C.torsion * ws(R::WX + r + 2);
+            ws(R::WX + i0) = clamp_(e, -thr, thr);
         }
         // block 2: friction cone {0, 1, 2}
-        for (int r = R::NB; r < NR; r += 4)
+        for (int r = nb; r < m; r += 4)
         {
-            if (!act.test(r)) continue;
-            if (friction_zero) { lam(r) = lam(r) * T(0); lam(r + 1) = lam(r + 1) * T(0); continue; }
+            if (friction_zero) { ws(R::WX + r) = ws(R::WX + r) * T(0); ws(R::WX + r + 1) = ws(R::WX + r + 1) * T(0); continue; }
             const T y0 = ws(R::WB + r) - col_dot(r);
             ws(R::WY + r) = y0;
             const T y1 = ws(R::WB + r + 1) - col_dot(r + 1);
             ws(R::WY + r + 1) = y1;
             const T a00 = ws(R::WA + r * NR + r), a11 = ws(R::WA + (r + 1) * NR + r + 1);
             const T a_max = a11 > a00 ? a11 : a00;
-            T e0 = lam(r) + w * y0 / a_max;
-            T e1 = lam(r + 1) + w * y1 / a_max;
-            const T thr = friction * lam(r + 2);
+            T e0 = ws(R::WX + r) + w * y0 / a_max;
+            T e1 = ws(R::WX + r + 1) + w * y1 / a_max;
+            const T thr = friction * ws(R::WX + r + 2);
             const T n2 = e0 * e0 + e1 * e1;
             if (n2 > thr * thr)
             {
@@ -307,17 +352,15 @@ JM_DEV bool pgs_solve(const ConArgs<T> & C, T friction, const RowMask & act, WS 
                 e0 *= scale;
                 e1 *= scale;
             }
-            lam(r) = e0;
-            lam(r + 1) = e1;
+            ws(R::WX + r) = e0;
+            ws(R::WX + r + 1) = e1;
         }
         // stagnation of the residuals (constraint_solvers.cc:263-278)
         T ymax = T(0);
-        for (int r = 0; r < NR; ++r)
-            if (act.test(r)) ymax = fmax_(ymax, cabs_(ws(R::WY + r)));
+        for (int r = 0; r < m; ++r) ymax = fmax_(ymax, cabs_(ws(R::WY + r)));
         const T tol = C.tol_abs + C.tol_rel * ymax + eps;
         bool done = true;
-        for (int r = 0; r < NR; ++r)
-            if (act.test(r)) done &= cabs_(ws(R::WY + r) - ws(R::WYP + r)) < tol;
+        for (int r = 0; r < m; ++r) done &= cabs_(ws(R::WY + r) - ws(R::WYP + r)) < tol;
         if (done) return true;
     }
     return false;
@@ -350,48 +393,45 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     static_for<0, R::NB>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int iq = Tp::idx_q[R::bjoint(k)];
-        int32_t f = flag(k);
-        if (start_passes > 0)
-        {
-            // Engine::start: JointConstraint::reset + enable, not reversed (engine.cc:1266-1308)
-            f = 1;
-            dat(k) = q[iq];
-            lam(k) = T(0);
-        }
+        // state of the constraint: loaded once, updated in registers, stored once
+        // Engine::start: JointConstraint::reset + enable, not reversed (engine.cc:1266-1308)
+        const bool init = start_passes > 0;
+        int32_t f = init ? 1 : flag(k);
         const T qj = q[iq], lo = P[L::QLO + iq], hi = P[L::QHI + iq];
+        T ref = init ? qj : dat(k);
+        bool clear = init;
         if (hi < qj || qj < lo)
         {
-            dat(k) = clamp_(qj, lo, hi);
+            ref = clamp_(qj, lo, hi);
             f = 1 | (hi < qj ? 2 : 0);
         }
         else if (lo + eps_tr < qj && qj < hi - eps_tr)
         {
             f &= ~1;
-            lam(k) = T(0);
+            clear = true;  // AbstractConstraintBase::disable
         }
         flag(k) = f;
+        dat(k) = ref;
+        if (clear) lam(k) = T(0);
         if (f & 1) act.set(k);
         if (f & 2) rev.set(k);
     });
-    T depth[R::NC > 0 ? R::NC : 1];
-    static_for<0, R::NC>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        constexpr int j = Tp::contact_joint[c];
-        constexpr int r0 = R::NB + 4 * c;
+    for_contacts<Tp>([&](auto jc, int c) {
+        constexpr int j = decltype(jc)::value;
+        const int r0 = R::NB + 4 * c;
         const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
         const T d = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, pc);
-        depth[c] = d;
-        int32_t f = flag(R::NB + c);
-        if (start_passes > 0)
-        {
-            f = 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
-        }
+        const bool init = start_passes > 0;
+        int32_t f = init ? 1 : flag(R::NB + c);
+        bool clear = init;
         if (d < T(0)) f = 1;
         else if (d > eps_tr)
         {
             f = 0;
+            clear = true;
+        }
+        if (clear)
+        {
 #pragma unroll
             for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
         }
@@ -403,10 +443,14 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     // ---- delassus matrix, one bias-free articulated-body solve per active row
     T dd[NV];
     Sp<T> da[NJ];
+    // (each lane walks ITS OWN active rows, lowest first: a wave runs max-over-lanes solves, not the
+    // union of the rows active anywhere in the wave; column index = packed index of the row)
+    const int m_act = act.count(), nb_act = act.rank(R::NB);
+    RowMask rem = act;
 #pragma nounroll
-    for (int r = 0; r < NR; ++r)
+    for (int pk = 0; pk < m_act; ++pk)
     {
-        if (!act.test(r)) continue;
+        const int r = rem.pop_lowest();
         int jr = 0, tiv = -1;
         T tsgn = T(0);
         Sp<T> fu = zero6<T>();
@@ -414,10 +458,9 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             constexpr int k = decltype(kc)::value;
             if (r == k) { tiv = Tp::idx_v[R::bjoint(k)]; tsgn = rev.test(k) ? T(-1) : T(1); }
         });
-        static_for<0, R::NC>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int j = Tp::contact_joint[c];
-            constexpr int r0 = R::NB + 4 * c;
+        for_contacts<Tp>([&](auto jc, int c) {
+            constexpr int j = decltype(jc)::value;
+            const int r0 = R::NB + 4 * c;
             if (r >= r0 && r < r0 + 4)
             {
                 const int d = r - r0;
@@ -433,10 +476,10 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         });
         delta_aba<T, Tp>(P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
                          [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); }, dd, da);
-        rows_of_motion<T, Tp>(P, w, act, rev, dd, da, [&](int l, T val) { ws(R::WA + l * NR + r) = val; });
+        rows_of_motion<T, Tp>(P, w, act, rev, dd, da, [&](int l, T val) { ws(R::WA + act.rank(l) * NR + pk) = val; });
         // regularisation (constraint_solvers.cc:376-387)
-        const T arr = ws(R::WA + r * NR + r);
-        ws(R::WA + r * NR + r) = arr + fmax_(arr * C.reg, T(1.0e-11));
+        const T arr = ws(R::WA + pk * NR + pk);
+        ws(R::WA + pk * NR + pk) = arr + fmax_(arr * C.reg, T(1.0e-11));
     }
 
     // ---- passes: one in normal operation; Engine::start runs INIT_ITERATIONS with its `u` bookkeeping
@@ -472,41 +515,68 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             if (act.test(k))
             {
                 const T s = C.kp * (q[iq] - dat(k)) + C.kd * v[iv] + af[iv];
-                ws(R::WB + k) = rev.test(k) ? s : -s;
+                ws(R::WB + act.rank(k)) = rev.test(k) ? s : -s;
             }
         });
-        static_for<0, R::NC>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int j = Tp::contact_joint[c];
-            constexpr int r0 = R::NB + 4 * c;
+        for_contacts<Tp>([&](auto jc, int c) {
+            constexpr int j = decltype(jc)::value;
+            const int r0 = R::NB + 4 * c;
             if (act.test(r0))
             {
                 const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
                 const M3<T> & Rj = w.oMi[j].R;
+                const T depth = w.oMi[j].p.z + dot(V3<T>{Rj.m20, Rj.m21, Rj.m22}, pc);
                 const V3<T> vlin = Rj * (w.vel[j].l + cross(w.vel[j].a, pc));
                 const V3<T> vang = Rj * w.vel[j].a;
                 V3<T> alin = Rj * (sa[j].l + cross(sa[j].a, pc));
                 const V3<T> aang = Rj * sa[j].a;
                 alin = alin + cross(vang, vlin);
-                ws(R::WB + r0) = -(alin.x + C.kd * vlin.x);
-                ws(R::WB + r0 + 1) = -(alin.y + C.kd * vlin.y);
-                ws(R::WB + r0 + 2) = -(alin.z + C.kp * depth[c] + C.kd * vlin.z);
-                ws(R::WB + r0 + 3) = -(aang.z + C.kd * vang.z);
+                const int p0 = act.rank(r0);
+                ws(R::WB + p0) = -(alin.x + C.kd * vlin.x);
+                ws(R::WB + p0 + 1) = -(alin.y + C.kd * vlin.y);
+                ws(R::WB + p0 + 2) = -(alin.z + C.kp * depth + C.kd * vlin.z);
+                ws(R::WB + p0 + 3) = -(aang.z + C.kd * vang.z);
             }
         });
-        // multipliers
+        // multipliers: gather the warm start into the packed vector, solve, scatter back
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (act.test(k)) ws(R::WX + act.rank(k)) = lam(k);
+        });
+        for_contacts<Tp>([&](auto, int c) {
+            const int r0 = R::NB + 4 * c;
+            if (act.test(r0))
+            {
+                const int p0 = act.rank(r0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ws(R::WX + p0 + i) = lam(r0 + i);
+            }
+        });
         bool ok;
         if (start_passes > 0 && pass == 0)
         {
-            ok = chol_solve_active<T, Tp>(act, ws, lam);
+            ok = chol_solve_packed<T, Tp>(m_act, ws);
             if (!ok) w.status |= JM_LANE_NAN;
         }
         else
         {
-            ok = pgs_solve<T, Tp>(C, friction, act, ws, lam);
+            ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
             if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
             else w.status |= JM_LANE_SOLVER_FAILURE;
         }
+        static_for<0, R::NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (act.test(k)) lam(k) = ws(R::WX + act.rank(k));
+        });
+        for_contacts<Tp>([&](auto, int c) {
+            const int r0 = R::NB + 4 * c;
+            if (act.test(r0))
+            {
+                const int p0 = act.rank(r0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lam(r0 + i) = ws(R::WX + p0 + i);
+            }
+        });
         // constraint forces of this pass: joint efforts + wrenches on the contact bodies
         T tl[NV];
         static_for<0, NV>([&](auto ic) { tl[decltype(ic)::value] = T(0); });
@@ -516,10 +586,9 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             constexpr int iv = Tp::idx_v[R::bjoint(k)];
             if (act.test(k)) tl[iv] = rev.test(k) ? -lam(k) : lam(k);
         });
-        static_for<0, R::NC>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int j = Tp::contact_joint[c];
-            constexpr int r0 = R::NB + 4 * c;
+        for_contacts<Tp>([&](auto jc, int c) {
+            constexpr int j = decltype(jc)::value;
+            const int r0 = R::NB + 4 * c;
             if (act.test(r0))
             {
                 const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);

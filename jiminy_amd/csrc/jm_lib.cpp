@@ -152,20 +152,26 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
     if (b->copt.contact_model == JM_CONTACT_CONSTRAINT)
     {
-        using R = jm::ConRows<Topo>;
-        if (R::NR > 0 && (!b->field[JM_F_CON_FLAGS] || !b->field[JM_F_CON_DATA] || !b->field[JM_F_WORKSPACE]))
-            return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': the con_flags, con_data and workspace fields must be bound");
-        jm::ConArgs<T> C;
-        C.flags = (int32_t *)b->field[JM_F_CON_FLAGS];
-        C.data = (T *)b->field[JM_F_CON_DATA];
-        C.ws = (T *)b->field[JM_F_WORKSPACE];
-        const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
-        C.kp = (T)(omega * omega);
-        C.kd = (T)(2.0 * omega);
-        C.torsion = (T)b->copt.torsion; C.reg = (T)b->copt.regularization;
-        C.tol_abs = (T)b->copt.tol_abs; C.tol_rel = (T)b->copt.tol_rel;
-        C.iter_max = b->copt.pgs_iter_max;
-        hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
+        // float64 only: the reference's precision; its PGS tolerances (1e-5 absolute on residual
+        // differences) are below float32 round-off of the delassus products
+        if constexpr (std::is_same<T, double>::value)
+        {
+            using R = jm::ConRows<Topo>;
+            if (R::NR > 0 && (!b->field[JM_F_CON_FLAGS] || !b->field[JM_F_CON_DATA] || !b->field[JM_F_WORKSPACE]))
+                return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': the con_flags, con_data and workspace fields must be bound");
+            jm::ConArgs<T> C;
+            C.flags = (int32_t *)b->field[JM_F_CON_FLAGS];
+            C.data = (T *)b->field[JM_F_CON_DATA];
+            C.ws = (T *)b->field[JM_F_WORKSPACE];
+            const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
+            C.kp = (T)(omega * omega);
+            C.kd = (T)(2.0 * omega);
+            C.torsion = (T)b->copt.torsion; C.reg = (T)b->copt.regularization;
+            C.tol_abs = (T)b->copt.tol_abs; C.tol_rel = (T)b->copt.tol_rel;
+            C.iter_max = b->copt.pgs_iter_max;
+            hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
+        }
+        else return fail(JM_ENOTIMPL, "contacts.model = 'constraint' needs a float64 batch");
     }
     else if (b->variant == VARIANT_QUAD) launch_quad<T, Topo>(b, A, s);
     else hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);

@@ -389,6 +389,8 @@ class BatchedEngine:
             raise NotImplementedError(
                 "contacts.model='constraint' is available with the fixed-step solvers "
                 "('euler_explicit', 'runge_kutta_4') on the batched path")
+        if ct["model"] == "constraint" and self.dtype != torch.float64:
+            raise NotImplementedError("contacts.model='constraint' needs a float64 engine")
         if new["constraints"]["solver"] != "PGS":
             raise ValueError("The requested constraint solver is not available.")  # engine.cc:2720-2728
         if float(new["constraints"]["regularization"]) < 0.0:
@@ -620,9 +622,13 @@ class BatchedEngine:
         stream = self._stream()
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
         per_step_noise = bool(self._sensor_noise) and float(self._options["stepper"]["sensorsUpdatePeriod"]) <= 0.0
+        constraint_model = self._options["contacts"]["model"] == "constraint"
         for dt, n, cmd_bp, sens in launches:
             for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
-                changed = cmd_bp and self._command_dirty and k == 0
+                # a(t+) refresh at a controller breakpoint (engine.cc:2030-2042): skipped when the held
+                # command was not rewritten (the evaluation is idempotent) -- except with the constraint
+                # contact model, where the reference's refresh re-runs the warm-started PGS solve
+                changed = cmd_bp and (self._command_dirty or constraint_model) and k == 0
                 self._lib.check(self._L.jm_batch_step(self._batch_h, solver, dt, n_k, int(changed),
                                                       int(sens), stream))
                 if changed:

@@ -17,7 +17,7 @@ from typing import Any, Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import blocks
+from . import _abi, blocks
 from .engine import BatchedEngine
 from .model import CompiledModel, JT_FREEFLYER, load_builtin
 from .synthetic import lowest_contact_height
@@ -83,7 +83,9 @@ class VecJiminyEnv:
     def has_terminated(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(terminated, truncated) per lane: truncation on numerical failure / out-of-bounds
         state (generic.py:1434-1470) or on the maximum simulated duration."""
-        status = self.engine.status
+        # a PGS solve that hit its iteration cap is not fatal (the reference only counts it,
+        # engine.cc:3755-3768)
+        status = self.engine.status & ~_abi.JM_LANE_SOLVER_FAILURE
         truncated = (status != 0) | (self._lane_time() >= self.simulation_duration_max)
         return torch.zeros_like(truncated), truncated
 
@@ -303,14 +305,16 @@ ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI = 1.0, 0.1
 
 def make_anymal_env(num_envs: int, dtype: torch.dtype = torch.float64,
                     device: Optional[torch.device] = None, pd_pipeline: bool = True,
-                    ode_solver: str = "euler_explicit", dt_max: float = 1e-3, **kw: Any) -> VecJiminyEnv:
-    """ANYmal with the reference's env constants; contacts use the spring-damper model of the
-    batched path (the shipped option file selects the constraint solver, outside this path)."""
+                    ode_solver: str = "euler_explicit", dt_max: float = 1e-3,
+                    contact_model: str = "spring_damper", **kw: Any) -> VecJiminyEnv:
+    """ANYmal with the reference's env constants. `contact_model="constraint"` selects what the
+    shipped option file selects (anymal_options.toml:24: joint bounds and contact points as
+    constraints, PGS); the default stays the spring-damper model of the north-star configuration."""
     model = load_builtin("anymal")
     opts = {"stepper": {"odeSolver": ode_solver, "dtMax": dt_max,
                         "controllerUpdatePeriod": ANYMAL_CONTROL_DT,
                         "sensorsUpdatePeriod": ANYMAL_CONTROL_DT},
-            "contacts": {"model": "spring_damper"}}
+            "contacts": {"model": contact_model}}
     if pd_pipeline:
         return PDControlledWalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, ANYMAL_CONTROL_DT,
                                         ANYMAL_PD_KP, ANYMAL_PD_KD, ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI,

@@ -22,12 +22,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--solver", default="euler_explicit")
+    ap.add_argument("--contact-model", default="spring_damper", choices=("spring_damper", "constraint"))
+    ap.add_argument("--zero-action", action="store_true", help="hold the neutral stance (standing robots)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver)
+    env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver, contact_model=args.contact_model)
     env.reset(seed=0)
     g = torch.Generator(device="cpu").manual_seed(0)
     action = ((torch.rand(args.envs, 12, generator=g, dtype=torch.float64) - 0.5) * 0.5).to(dev)
+    if args.zero_action:
+        action = torch.zeros_like(action)
     for _ in range(args.warmup):
         env.step(action)
     torch.cuda.synchronize()
@@ -38,7 +42,14 @@ def main():
         n_reset += int(info["reset_mask"].sum()) if "reset_mask" in info else 0
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    extra = {}
+    if args.contact_model == "constraint":
+        eng = env.engine
+        extra = {"mean_active_constraints": (eng.field("con_flags") & 1).sum(0).double().mean().item(),
+                 "mean_base_height": eng.field("q")[2].mean().item(),
+                 "lanes_pgs_not_converged_last_eval": ((eng.status & 16) != 0).double().mean().item()}
     print(json.dumps({"metric": "gym-steps/s ANYmal PD + Mahony pipeline", "value": args.envs * args.steps / el,
+                      "contact_model": args.contact_model, **extra,
                       "ms_per_env_step": 1e3 * el / args.steps, "envs": args.envs, "steps": args.steps,
                       "integrator_steps_per_env_step": 40, "solver": args.solver, "lanes_reset": n_reset,
                       "blocks": "tensor" if os.environ.get("JIMINY_AMD_TENSOR_BLOCKS") == "1" else "hip"}))
