@@ -28,6 +28,15 @@
 #pragma once
 #include "jm_kernels.h"
 
+// tuning switches (A/B measurements)
+#ifndef JM_CON_MASKS
+#define JM_CON_MASKS 1  // path-restricted sweeps of the bias-free solves
+#endif
+#ifndef JM_CON_XLDS
+#define JM_CON_XLDS 0   // packed multipliers in LDS during the PGS solve (faster solve, but the extra 14 kB
+                        // per block cost one resident wave per CU: measured slower on warm-started workloads)
+#endif
+
 namespace jm
 {
 template<class T> struct ConArgs
@@ -38,6 +47,9 @@ template<class T> struct ConArgs
     T kp, kd;         // Baumgarte gains of contacts.stabilizationFreq (abstract_constraint.cc:88-98)
     T torsion, reg, tol_abs, tol_rel;
     int iter_max;
+    // set by the kernel: per-lane on-chip vector (LDS) of the packed multipliers, element p at xl[p * xstride]
+    T * xl;
+    int xstride;
 };
 struct WithCon
 {
@@ -63,6 +75,13 @@ template<class Tp> struct ConRows
     // workspace rows: delassus matrix over the PACKED active rows (stride NR), then b, y, y_prev, a diagonal
     // backup and the packed multipliers x
     static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WX = WD + NR, WTOTAL = WX + NR;
+    // bit mask of the ancestors-or-self of joint j (the joints a force applied on body j travels through)
+    static constexpr unsigned long long anc_mask(int j)
+    {
+        unsigned long long m = 0ull;
+        for (int i = j; i > 0; i = Tp::parent[i]) m |= 1ull << i;
+        return m;
+    }
     static constexpr int bjoint(int k)
     {
         int n = 0;
@@ -158,10 +177,15 @@ template<class Tp, class F> JM_DEV void for_contacts(F && f)
 // dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias
 // of the last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).
 // Also returns the spatial accelerations `da` of every joint (joint frame).
+// `bmask`: joints that carry a non-zero bias force / effort in the leaves-to-root sweep (bit j), `fmask`:
+// joints whose acceleration is wanted from the root-to-leaves sweep; the others are skipped (their
+// `dd` / `da` are left untouched: callers only read what they asked for).
 template<class T, class Tp, class FT, class FB>
-JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T (&dd)[Tp::NV], Sp<T> (&da)[Tp::NJ])
+JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T (&dd)[Tp::NV], Sp<T> (&da)[Tp::NJ],
+                      unsigned long long bmask = ~0ull, unsigned long long fmask = ~0ull)
 {
     constexpr int NJ = Tp::NJ;
+    static_assert(NJ <= 64, "joint masks are 64-bit");
     Sp<T> pf[NJ];
     T ur[Tp::NV];
     static_for<1, NJ>([&](auto jc) { pf[decltype(jc)::value] = zero6<T>() - fb(jc); });
@@ -176,7 +200,7 @@ JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T 
             ur[iv] -= pf[j].l.x; ur[iv + 1] -= pf[j].l.y; ur[iv + 2] -= pf[j].l.z;
             ur[iv + 3] -= pf[j].a.x; ur[iv + 4] -= pf[j].a.y; ur[iv + 5] -= pf[j].a.z;
         }
-        else
+        else if (!JM_CON_MASKS || ((bmask >> j) & 1ull))
         {
             const T uj = ur[iv] - joint_St_dot<T, Tp, j>(P, pf[j]);
             ur[iv] = uj;
@@ -201,7 +225,7 @@ JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T 
             for (int k = 0; k < 6; ++k) dd[iv + k] = b[k];
             da[j] = {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
         }
-        else
+        else if (!JM_CON_MASKS || ((fmask >> j) & 1ull))
         {
             Sp<T> ag;
             if constexpr (p > 0) ag = actinv_motion(w.liMi[j], da[p]);
@@ -293,9 +317,33 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
     using R = ConRows<Tp>;
     constexpr int NR = R::NR;
     const T eps = Eps<T>::eps;
+    // the packed multipliers live on chip for the duration of the solve (they are read m times per row
+    // update); the delassus column is fetched 8 entries at a time so that the loads are in flight together
+    // (the sum itself keeps the sequential order of `A.col(i).dot(x)`)
+    T * const xl = C.xl;
+    const int xs = C.xstride;
+    for (int r = 0; r < m; ++r) xl[r * xs] = ws(R::WX + r);
     auto col_dot = [&](int i) {
         T s = T(0);
-        for (int k = 0; k < m; ++k) s += ws(R::WA + k * NR + i) * ws(R::WX + k);
+        int k = 0;
+        for (; k + 8 <= m; k += 8)
+        {
+            T av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = ws(R::WA + (k + u) * NR + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += av[u] * xl[(k + u) * xs];
+        }
+        if (k + 4 <= m)
+        {
+            T av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = ws(R::WA + (k + u) * NR + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += av[u] * xl[(k + u) * xs];
+            k += 4;
+        }
+        for (; k < m; ++k) s += ws(R::WA + k * NR + i) * xl[k * xs];
         return s;
     };
     for (int r = 0; r < m; ++r) ws(R::WY + r) = T(0);
@@ -318,33 +366,33 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             const int i0 = r < nb ? r : r + 2;
             const T y = ws(R::WB + i0) - col_dot(i0);
             ws(R::WY + i0) = y;
-            const T e = ws(R::WX + i0) + w * y / ws(R::WA + i0 * NR + i0);
-            ws(R::WX + i0) = fmax_(e, T(0));  // clamp(e, 0, inf)
+            const T e = xl[(i0) * xs] + w * y / ws(R::WA + i0 * NR + i0);
+            xl[(i0) * xs] = fmax_(e, T(0));  // clamp(e, 0, inf)
         }
         // block 1: torsional friction {3, 2}
         for (int r = nb; r < m; r += 4)
         {
-            if (torsion_zero) { ws(R::WX + r + 3) = ws(R::WX + r + 3) * T(0); continue; }
+            if (torsion_zero) { xl[(r + 3) * xs] = xl[(r + 3) * xs] * T(0); continue; }
             const int i0 = r + 3;
             const T y = ws(R::WB + i0) - col_dot(i0);
             ws(R::WY + i0) = y;
-            const T e = ws(R::WX + i0) + w * y / ws(R::WA + i0 * NR + i0);
-            const T thr = C.torsion * ws(R::WX + r + 2);
-            ws(R::WX + i0) = clamp_(e, -thr, thr);
+            const T e = xl[(i0) * xs] + w * y / ws(R::WA + i0 * NR + i0);
+            const T thr = C.torsion * xl[(r + 2) * xs];
+            xl[(i0) * xs] = clamp_(e, -thr, thr);
         }
         // block 2: friction cone {0, 1, 2}
         for (int r = nb; r < m; r += 4)
         {
-            if (friction_zero) { ws(R::WX + r) = ws(R::WX + r) * T(0); ws(R::WX + r + 1) = ws(R::WX + r + 1) * T(0); continue; }
+            if (friction_zero) { xl[(r) * xs] = xl[(r) * xs] * T(0); xl[(r + 1) * xs] = xl[(r + 1) * xs] * T(0); continue; }
             const T y0 = ws(R::WB + r) - col_dot(r);
             ws(R::WY + r) = y0;
             const T y1 = ws(R::WB + r + 1) - col_dot(r + 1);
             ws(R::WY + r + 1) = y1;
             const T a00 = ws(R::WA + r * NR + r), a11 = ws(R::WA + (r + 1) * NR + r + 1);
             const T a_max = a11 > a00 ? a11 : a00;
-            T e0 = ws(R::WX + r) + w * y0 / a_max;
-            T e1 = ws(R::WX + r + 1) + w * y1 / a_max;
-            const T thr = friction * ws(R::WX + r + 2);
+            T e0 = xl[(r) * xs] + w * y0 / a_max;
+            T e1 = xl[(r + 1) * xs] + w * y1 / a_max;
+            const T thr = friction * xl[(r + 2) * xs];
             const T n2 = e0 * e0 + e1 * e1;
             if (n2 > thr * thr)
             {
@@ -352,8 +400,8 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
                 e0 *= scale;
                 e1 *= scale;
             }
-            ws(R::WX + r) = e0;
-            ws(R::WX + r + 1) = e1;
+            xl[(r) * xs] = e0;
+            xl[(r + 1) * xs] = e1;
         }
         // stagnation of the residuals (constraint_solvers.cc:263-278)
         T ymax = T(0);
@@ -361,8 +409,13 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
         const T tol = C.tol_abs + C.tol_rel * ymax + eps;
         bool done = true;
         for (int r = 0; r < m; ++r) done &= cabs_(ws(R::WY + r) - ws(R::WYP + r)) < tol;
-        if (done) return true;
+        if (done)
+        {
+            for (int r = 0; r < m; ++r) ws(R::WX + r) = xl[r * xs];
+            return true;
+        }
     }
+    for (int r = 0; r < m; ++r) ws(R::WX + r) = xl[r * xs];
     return false;
 }
 
@@ -439,6 +492,15 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         if (f & 1) { act.set(r0); act.set(r0 + 1); act.set(r0 + 2); act.set(r0 + 3); }
     });
     if (!act.any()) return;  // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
+    // joints whose acceleration some active row reads (columns of the delassus matrix)
+    unsigned long long fmask = 0ull;
+    static_for<0, R::NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (act.test(k)) fmask |= R::anc_mask(R::bjoint(k));
+    });
+    for_contacts<Tp>([&](auto jc, int c) {
+        if (act.test(R::NB + 4 * c)) fmask |= R::anc_mask(decltype(jc)::value);
+    });
 
     // ---- delassus matrix, one bias-free articulated-body solve per active row
     T dd[NV];
@@ -454,9 +516,15 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         int jr = 0, tiv = -1;
         T tsgn = T(0);
         Sp<T> fu = zero6<T>();
+        unsigned long long bmask = 0ull;
         static_for<0, R::NB>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            if (r == k) { tiv = Tp::idx_v[R::bjoint(k)]; tsgn = rev.test(k) ? T(-1) : T(1); }
+            if (r == k)
+            {
+                tiv = Tp::idx_v[R::bjoint(k)];
+                tsgn = rev.test(k) ? T(-1) : T(1);
+                bmask = R::anc_mask(R::bjoint(k));
+            }
         });
         for_contacts<Tp>([&](auto jc, int c) {
             constexpr int j = decltype(jc)::value;
@@ -472,10 +540,11 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 if (d < 3) fu = {col, cross(pc, col)};
                 else fu = {zero3<T>(), col};
                 jr = j;
+                bmask = R::anc_mask(j);
             }
         });
         delta_aba<T, Tp>(P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
-                         [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); }, dd, da);
+                         [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); }, dd, da, bmask, fmask);
         rows_of_motion<T, Tp>(P, w, act, rev, dd, da, [&](int l, T val) { ws(R::WA + act.rank(l) * NR + pk) = val; });
         // regularisation (constraint_solvers.cc:376-387)
         const T arr = ws(R::WA + pk * NR + pk);
@@ -625,13 +694,24 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
 }
 
 #ifndef JM_HOST_EMU
+// One wave per SIMD (512 registers): capping the registers for 2-3 resident waves was measured 1.5x
+// slower (more spill traffic), see DESIGN.md section 4.8.
 template<class T, class Tp>
 __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const ConArgs<T> C)
 {
     __shared__ T lds[stage_rows<Tp>() * 64];
     const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
     if (lane >= A.B) return;
-    lane_run<T, Tp, 64, WithCon>(A, lane, lds + threadIdx.x, C);
+    ConArgs<T> Cl = C;
+#if JM_CON_XLDS
+    __shared__ T xs[(ConRows<Tp>::NR > 0 ? ConRows<Tp>::NR : 1) * 64];
+    Cl.xl = xs + threadIdx.x;
+    Cl.xstride = 64;
+#else
+    Cl.xl = C.ws + (size_t)ConRows<Tp>::WX * A.B + lane;  // workspace rows (HBM)
+    Cl.xstride = (int)A.B;
+#endif
+    lane_run<T, Tp, 64, WithCon>(A, lane, lds + threadIdx.x, Cl);
 }
 #endif
 }  // namespace jm

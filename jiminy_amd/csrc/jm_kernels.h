@@ -745,7 +745,8 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 }
 
 // ---------------------------------------------------------------- one lane, all modes
-// `sb` is the per-lane stage buffer (LDS on the GPU): element r at sb[r * SBS].
+// `sb` is the per-lane stage buffer (LDS on the GPU): element r at sb[r * SBS]; SBS = 0: the stride is
+// the run-time `sb_stride` (stage rows kept in an HBM workspace, constraint-model kernel).
 // Rows: [0,NV) accumulated velocity increment, [NV,2NV) accumulated acceleration increment,
 //       [2NV,3NV) velocity of the previous stage.
 template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
@@ -770,8 +771,10 @@ JM_DEV void eval_any(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w,
 
 template<class T, class Tp, int SBS, class CON = NoCon>
 JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
-                     const typename CON::template ArgsT<T> & C = typename CON::template ArgsT<T>{})
+                     const typename CON::template ArgsT<T> & C = typename CON::template ArgsT<T>{},
+                     long long sb_stride = 0)
 {
+    const long long SBSr = SBS > 0 ? (long long)SBS : sb_stride;
     using L = Layout<Tp>;
     constexpr int NQ = Tp::NQ, NV = Tp::NV, NM = Tp::NM;
     const long long B = A.B;
@@ -863,18 +866,18 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
             static_for<0, NV>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const T v0 = A.v[i * B + lane];
-                const T kv = first ? v0 : sb[(2 * NV + i) * SBS];
+                const T kv = first ? v0 : sb[(2 * NV + i) * SBSr];
                 const T ka = first ? A.a[i * B + lane] : as[i];
                 T accv, acca;
                 if (!rk4) { accv = bw * kv; acca = bw * ka; }
                 else
                 {
-                    accv = first ? bw * kv : sb[i * SBS] + bw * kv;
-                    acca = first ? bw * ka : sb[(NV + i) * SBS] + bw * ka;
-                    if (k != 3) { sb[i * SBS] = accv; sb[(NV + i) * SBS] = acca; }
+                    accv = first ? bw * kv : sb[i * SBSr] + bw * kv;
+                    acca = first ? bw * ka : sb[(NV + i) * SBSr] + bw * ka;
+                    if (k != 3) { sb[i * SBSr] = accv; sb[(NV + i) * SBSr] = acca; }
                 }
                 if (k == 3) { incv[i] = accv; vs[i] = v0 + acca; }
-                else { incv[i] = aw * kv; vs[i] = v0 + aw * ka; sb[(2 * NV + i) * SBS] = vs[i]; }
+                else { incv[i] = aw * kv; vs[i] = v0 + aw * ka; sb[(2 * NV + i) * SBSr] = vs[i]; }
             });
             integrate_q<T, Tp>(P, q0, incv, qs);
             if (k == 3)

@@ -15,11 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from jiminy_amd import load_builtin  # noqa: E402
-from jiminy_amd.synthetic import sample_states  # noqa: E402
-from tests.helpers import alloc_soa, oracle_batch  # noqa: E402
+from jiminy_amd.synthetic import sample_standing_states, sample_states  # noqa: E402
+from tests.helpers import alloc_constraint_state, alloc_soa, oracle_batch  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 FIELDS = ("q", "v", "a", "u_motor", "imu", "force", "encoder", "effort", "energy", "contact_forces")
+CON_FIELDS = FIELDS + ("u", "con_data", "con_flags")
+CON_OPTIONS = dict(tol_abs=1e-11, tol_rel=1e-10)  # PGS run to stagnation: fixtures insensitive to round-off
 
 
 def main() -> None:
@@ -41,6 +43,24 @@ def main() -> None:
         out["status"] = arr["status"].copy()
         np.savez_compressed(os.path.join(OUT, f"{name}_oracle.npz"), **out)
         print(name, "ok", {k: v.shape for k, v in list(out.items())[:3]})
+    # contacts.model = "constraint": standing robots, some joints beyond their limits
+    for name, B in (("anymal", 16), ("atlas", 4)):
+        model = load_builtin(name)
+        st = sample_standing_states(model, B, seed=321)
+        arr = alloc_soa(model, B)
+        alloc_constraint_state(model, arr, B)
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+        oracle_batch(model, arr, "start", constraint_options=CON_OPTIONS)
+        out = {"in_q": st["q"], "in_v": st["v"], "in_command": st["command"]}
+        out.update({"start_" + k: arr[k].copy() for k in CON_FIELDS})
+        for i in range(6):
+            oracle_batch(model, arr, "step", constraint_options=CON_OPTIONS, solver="euler_explicit", dt=5e-4,
+                         n_substeps=1, command_changed=True)
+        out.update({"euler_" + k: arr[k].copy() for k in CON_FIELDS})
+        out["status"] = arr["status"].copy()
+        np.savez_compressed(os.path.join(OUT, f"{name}_constraint_oracle.npz"), **out)
+        print(name, "constraint ok, active constraints per lane", (arr["con_flags"] & 1).sum(0))
 
 
 if __name__ == "__main__":

@@ -147,6 +147,8 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
         C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
         C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
+        std::vector<T> xvec(jm::ConRows<Topo>::NR + 1, (T)std::nan(""));
+        C.xl = xvec.data(); C.xstride = 1;
         for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1, jm::WithCon>(A, lane, sb.data(), C);
         return 0;
     }
