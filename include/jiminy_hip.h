@@ -256,7 +256,8 @@ int32_t jm_batch_timing_summary(jm_batch * batch, int32_t * n_launches, double *
  *   workspace  [jm_batch_adaptive_workspace_rows()][B] scalars of the batch dtype (stage derivatives),
  *   state_f64  [5][B] float64: t, dt, dtLargest, dtLargestPrev, (scratch) -- initialise t = 0 and the
  *              three step sizes to 1e-6 (StepperState::reset, engine.h:219-236, engine.cc:1176),
- *   state_i32  [6][B] int32: iter, iterFailed, successiveIterTooLarge, successiveIterFailed, (2 scratch) = 0.
+ *   state_i32  [7][B] int32: iter, iterFailed, successiveIterTooLarge, successiveIterFailed, (2 scratch rows,
+ *              then the list of the lanes still active in the current attempt) = 0.
  * jm_batch_step_adaptive advances every lane from its `t` to the breakpoint `t_next` (the caller splits
  * Engine::step at controller / sensor breakpoints exactly as for the fixed-step solvers), then refreshes
  * the extra terms and, if asked, the sensors.  `new_step` != 0 on the first interval of an Engine::step

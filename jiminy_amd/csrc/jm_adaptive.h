@@ -1,11 +1,14 @@
 // jm_adaptive.h -- adaptive Dormand-Prince stepping (the reference's default `odeSolver`), one
 // robot per lane with its OWN step size, built around the unchanged dynamics kernels.
 //
-// One attempt of all lanes = k_dopri_prepare (choose dt per lane) -> 6 x [k_dopri_stage (stage
-// state on the manifold) -> dynamics launch (MODE_DYNAMICS of k_quad / k_batch)] -> k_dopri_finish
-// (embedded error estimate, accept / reject, next step size).  Lanes that already reached the
-// breakpoint idle with dt = 0.  The host (jm_lib.cpp: jm_batch_step_adaptive) repeats attempts
-// until no lane is active; stage derivatives live in a caller-provided workspace `[rows][B]`.
+// One attempt = k_dopri_prepare (all lanes: choose dt, append the lanes that still have to move to the
+// ACTIVE LIST) -> 6 x [k_dopri_stage (stage state on the manifold) -> dynamics launch (MODE_DYNAMICS of
+// k_quad / k_batch)] -> k_dopri_finish (embedded error estimate, accept / reject, next step size), the
+// last three over the n active lanes only: the stage kernels gather lane map[c] into COMPACT workspace
+// rows `[rows][n]` (stage configuration, stage derivatives, a copy of the held command), the dynamics
+// kernels run unchanged on that dense batch of n robots, the finish kernel scatters the accepted state
+// back.  The host (jm_lib.cpp: jm_batch_step_adaptive) repeats attempts until the list is empty; the
+// work of an interval is the sum of the lanes' own attempts, not lanes x attempts of the stiffest one.
 //
 // Reference restated here:
 //   tableau / constants   core/include/jiminy/core/stepper/runge_kutta_dopri_stepper.h:12-58
@@ -38,13 +41,15 @@ constexpr double STEPPER_MIN_TIMESTEP = 1e-10, SIMULATION_MIN_TIMESTEP = 1e-6;
 
 // per-lane stepper state (always float64, whatever the state dtype): rows of `[B]`
 enum { AD_T = 0, AD_DT = 1, AD_DT_LARGEST = 2, AD_DT_LARGEST_PREV = 3, AD_DT_TRY = 4, AD_NROWS_F = 5 };
-enum { AD_ITER = 0, AD_ITER_FAILED = 1, AD_SUCC_TOO_LARGE = 2, AD_SUCC_FAILED = 3, AD_ACTIVE = 4, AD_BP_REACHED = 5, AD_NROWS_I = 6 };
+enum { AD_ITER = 0, AD_ITER_FAILED = 1, AD_SUCC_TOO_LARGE = 2, AD_SUCC_FAILED = 3, AD_ACTIVE = 4, AD_BP_REACHED = 5, AD_MAP = 6, AD_NROWS_I = 7 };
 
 template<class T> struct AdaptiveArgs
 {
     const T * P;
     T * q; T * v; T * a;          // state = x0, k_0 = (v, a); committed on success
-    T * ws;                       // workspace: kv[6][nv], ka[6][nv], qs[nq]   (rows of [B])
+    T * ws;                       // workspace: kv[6][nv], ka[6][nv], qs[nq], command[nm]: COMPACT rows of [n_act]
+    const T * command;            // held command [nm][B]
+    long long n_act;              // active lanes of this attempt (host copy of *n_active)
     double * fs;                  // [AD_NROWS_F][B]
     int32_t * is;                 // [AD_NROWS_I][B]
     int32_t * status;
@@ -55,7 +60,7 @@ template<class T> struct AdaptiveArgs
 };
 template<class Tp> struct AdaptiveRows
 {
-    static constexpr int KV = 0, KA = 6 * Tp::NV, QS = 12 * Tp::NV, TOTAL = 12 * Tp::NV + Tp::NQ;
+    static constexpr int KV = 0, KA = 6 * Tp::NV, QS = 12 * Tp::NV, CMD = 12 * Tp::NV + Tp::NQ, TOTAL = CMD + Tp::NM;
 };
 
 JM_DEV double acos_(double x) { return ::acos(x); }
@@ -184,7 +189,8 @@ __global__ void __launch_bounds__(256) k_dopri_prepare(const AdaptiveArgs<T> A)
     }
     fs[AD_DT_TRY * B] = active ? dt : 0.0;
     is[AD_ACTIVE * B] = active;
-    if (active) atomicAdd(A.n_active, 1);
+    // active list (order irrelevant: lanes are independent and every kernel is lane-position agnostic)
+    if (active) A.is[(long long)AD_MAP * B + atomicAdd(A.n_active, 1)] = (int32_t)lane;
 }
 
 // ---- stage i (1..6): x_i = x0 (+) dt sum_j A_ij k_j ; k_i.v = v_i is stored, k_i.a comes from the dynamics launch
@@ -193,11 +199,18 @@ __global__ void __launch_bounds__(128) k_dopri_stage(const AdaptiveArgs<T> A)
 {
     using R = AdaptiveRows<Tp>;
     constexpr int NQ = Tp::NQ, NV = Tp::NV;
-    const long long lane = (long long)blockIdx.x * 128 + threadIdx.x;
-    if (lane >= A.B) return;
-    const long long B = A.B;
+    const long long c = (long long)blockIdx.x * 128 + threadIdx.x;   // position in the active list
+    // `n_act` (host copy, sizes the grid and the compact rows) is an upper bound of the current list
+    // length when several attempts are issued per synchronisation: the device counter is authoritative
+    if (c >= A.n_act || c >= *A.n_active) return;
+    const long long B = A.B, N = A.n_act;
+    const long long lane = A.is[(long long)AD_MAP * B + c];
     CPtr<T> P = (CPtr<T>)A.P;
     const int i = A.stage;
+    if (i == 1)
+        static_for<0, Tp::NM>([&](auto mc) {
+            A.ws[(long long)(R::CMD + decltype(mc)::value) * N + c] = A.command[decltype(mc)::value * B + lane];
+        });
     const T dt = (T)A.fs[AD_DT_TRY * B + lane];
     T q0[NQ], incv[NV], qs[NQ];
     static_for<0, NQ>([&](auto ic) { q0[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
@@ -209,11 +222,11 @@ __global__ void __launch_bounds__(128) k_dopri_stage(const AdaptiveArgs<T> A)
     for (int j = 1; j < i; ++j)
     {
         const T s = dt * (T)dopri::A[i][j];
-        const T * kv = A.ws + (long long)(R::KV + (j - 1) * NV) * B + lane;
-        static_for<0, NV>([&](auto ic) { incv[decltype(ic)::value] += s * kv[decltype(ic)::value * B]; });
+        const T * kv = A.ws + (long long)(R::KV + (j - 1) * NV) * N + c;
+        static_for<0, NV>([&](auto ic) { incv[decltype(ic)::value] += s * kv[decltype(ic)::value * N]; });
     }
     integrate_q<T, Tp>(P, q0, incv, qs);
-    static_for<0, NQ>([&](auto ic) { A.ws[(long long)(R::QS + decltype(ic)::value) * B + lane] = qs[decltype(ic)::value]; });
+    static_for<0, NQ>([&](auto ic) { A.ws[(long long)(R::QS + decltype(ic)::value) * N + c] = qs[decltype(ic)::value]; });
     // velocity part (reuses incv as the acceleration increment)
     {
         const T s = dt * (T)dopri::A[i][0];
@@ -222,11 +235,11 @@ __global__ void __launch_bounds__(128) k_dopri_stage(const AdaptiveArgs<T> A)
     for (int j = 1; j < i; ++j)
     {
         const T s = dt * (T)dopri::A[i][j];
-        const T * ka = A.ws + (long long)(R::KA + (j - 1) * NV) * B + lane;
-        static_for<0, NV>([&](auto ic) { incv[decltype(ic)::value] += s * ka[decltype(ic)::value * B]; });
+        const T * ka = A.ws + (long long)(R::KA + (j - 1) * NV) * N + c;
+        static_for<0, NV>([&](auto ic) { incv[decltype(ic)::value] += s * ka[decltype(ic)::value * N]; });
     }
-    T * kvi = A.ws + (long long)(R::KV + (i - 1) * NV) * B + lane;
-    static_for<0, NV>([&](auto ic) { kvi[decltype(ic)::value * B] = A.v[decltype(ic)::value * B + lane] + incv[decltype(ic)::value]; });
+    T * kvi = A.ws + (long long)(R::KV + (i - 1) * NV) * N + c;
+    static_for<0, NV>([&](auto ic) { kvi[decltype(ic)::value * N] = A.v[decltype(ic)::value * B + lane] + incv[decltype(ic)::value]; });
 }
 
 // ---- error estimate, accept / reject, next step size (runge_kutta_dopri_stepper.cc, engine.cc:2132-2221)
@@ -235,9 +248,10 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
 {
     using R = AdaptiveRows<Tp>;
     constexpr int NQ = Tp::NQ, NV = Tp::NV;
-    const long long lane = (long long)blockIdx.x * 128 + threadIdx.x;
-    if (lane >= A.B) return;
-    const long long B = A.B;
+    const long long c = (long long)blockIdx.x * 128 + threadIdx.x;   // position in the active list
+    if (c >= A.n_act || c >= *A.n_active) return;
+    const long long B = A.B, N = A.n_act;
+    const long long lane = A.is[(long long)AD_MAP * B + c];
     double * fs = A.fs + lane;
     int32_t * is = A.is + lane;
     if (!is[AD_ACTIVE * B]) return;
@@ -258,11 +272,11 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
     for (int j = 1; j < 7; ++j)
     {
         const T s = dtT * (T)dopri::E[j];
-        const T * kv = A.ws + (long long)(R::KV + (j - 1) * NV) * B + lane;
-        static_for<0, NV>([&](auto ic) { d[decltype(ic)::value] += s * kv[decltype(ic)::value * B]; });
+        const T * kv = A.ws + (long long)(R::KV + (j - 1) * NV) * N + c;
+        static_for<0, NV>([&](auto ic) { d[decltype(ic)::value] += s * kv[decltype(ic)::value * N]; });
     }
     integrate_q<T, Tp>(P, q0, d, qb);                       // other solution
-    static_for<0, NQ>([&](auto ic) { qa[decltype(ic)::value] = A.ws[(long long)(R::QS + decltype(ic)::value) * B + lane]; });  // solution
+    static_for<0, NQ>([&](auto ic) { qa[decltype(ic)::value] = A.ws[(long long)(R::QS + decltype(ic)::value) * N + c]; });  // solution
     difference_q<T, Tp>(qa, qb, d);
     double error = 0.0;
     bool nan = false;
@@ -272,8 +286,8 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
         error = fmax(error, e);
     });
     // velocity part
-    const T * kv6 = A.ws + (long long)(R::KV + 5 * NV) * B + lane;   // k_6.v = solution velocity
-    const T * ka6 = A.ws + (long long)(R::KA + 5 * NV) * B + lane;   // k_6.a = f(solution): FSAL
+    const T * kv6 = A.ws + (long long)(R::KV + 5 * NV) * N + c;   // k_6.v = solution velocity
+    const T * ka6 = A.ws + (long long)(R::KA + 5 * NV) * N + c;   // k_6.a = f(solution): FSAL
     {
         const T s = dtT * (T)dopri::E[0];
         static_for<0, NV>([&](auto ic) { d[decltype(ic)::value] = s * A.a[decltype(ic)::value * B + lane]; });
@@ -281,18 +295,18 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
     for (int j = 1; j < 7; ++j)
     {
         const T s = dtT * (T)dopri::E[j];
-        const T * ka = A.ws + (long long)(R::KA + (j - 1) * NV) * B + lane;
-        static_for<0, NV>([&](auto ic) { d[decltype(ic)::value] += s * ka[decltype(ic)::value * B]; });
+        const T * ka = A.ws + (long long)(R::KA + (j - 1) * NV) * N + c;
+        static_for<0, NV>([&](auto ic) { d[decltype(ic)::value] += s * ka[decltype(ic)::value * N]; });
     }
     bool a_nan = false;
     static_for<0, NV>([&](auto ic) {
         constexpr int k = decltype(ic)::value;
         const T v0 = A.v[k * B + lane];
         const T scv = fabs_(T(0) - v0) * (T)A.tol_rel + (T)A.tol_abs;
-        const double e = (double)fabs_(((v0 + d[k]) - kv6[k * B]) / scv);
+        const double e = (double)fabs_(((v0 + d[k]) - kv6[k * N]) / scv);
         nan |= (e != e);
         error = fmax(error, e);
-        const T an = ka6[k * B];
+        const T an = ka6[k * N];
         a_nan |= (an != an);
     });
     double dtLargest = dt;   // tryStep(..., dtLargest) updates it in place
@@ -317,8 +331,8 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
         static_for<0, NQ>([&](auto ic) { A.q[decltype(ic)::value * B + lane] = qa[decltype(ic)::value]; });
         static_for<0, NV>([&](auto ic) {
             constexpr int k = decltype(ic)::value;
-            A.v[k * B + lane] = kv6[k * B];
-            A.a[k * B + lane] = ka6[k * B];
+            A.v[k * B + lane] = kv6[k * N];
+            A.a[k * B + lane] = ka6[k * N];
         });
         fs[AD_T * B] += dt;
         is[AD_SUCC_TOO_LARGE * B] = 0;

@@ -135,7 +135,7 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
     if constexpr (Tp::QUAD)
     {
         constexpr int nth = 64 * jm::quad_block_waves<T, Tp>();  // 4 lanes per robot
-        const unsigned grid = (unsigned)((b->B + nth / 4 - 1) / (nth / 4));
+        const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));  // A.B <= b->B (compact adaptive batches)
         hipLaunchKernelGGL((jm::k_quad<T, Tp>), dim3(grid), dim3(nth), 0, s, A);
     }
     else { (void)b; (void)A; (void)s; }
@@ -145,7 +145,7 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
 {
     HIP_TRY(hipSetDevice(b->device));
     const hipStream_t s = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((b->B + 63) / 64);
+    const unsigned grid = (unsigned)((A.B + 63) / 64);
     // only the step launches are timed: the roofline leg prices one pass of the hot path, not the
     // (cheaper, single-evaluation) start / reset / dynamics launches
     const bool timed = b->timing && A.mode == jm::MODE_STEP && b->n_timed < JM_TIMING_RING;
@@ -222,31 +222,51 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
         const int32_t rc = launch<T>(b, A, stream);
         if (rc != JM_OK) return rc;
     }
-    const unsigned g256 = (unsigned)((B + 255) / 256), g128 = (unsigned)((B + 127) / 128);
+    D.command = (const T *)b->field[JM_F_COMMAND];
+    D.n_act = B;  // upper bound of the active-list length: the list only shrinks within an interval
+    const unsigned g256 = (unsigned)((B + 255) / 256);
     int attempts = 0;
-    for (;; ++attempts)
+    for (;;)
     {
+        // all lanes: step-size selection + the list of the lanes that still have to move
         HIP_TRY(hipMemsetAsync(b->ad_count, 0, sizeof(int32_t), s));
         hipLaunchKernelGGL((jm::k_dopri_prepare<T, Topo>), dim3(g256), dim3(256), 0, s, D);
         D.new_step = 0;
         HIP_TRY(hipMemcpyAsync(b->ad_count_host, b->ad_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (*b->ad_count_host == 0) break;
+        const long long n = *b->ad_count_host;
+        if (n == 0) break;
         if (attempts >= max_attempts) return fail(JM_ERUNTIME, "adaptive stepper: too many attempts for one breakpoint interval");
-        for (int i = 1; i <= 6; ++i)
+        // The n active lanes only: compact workspace rows [rows][n], dense batch of n robots for the dynamics
+        // kernels.  Short lists are launch-bound: several attempts are then issued per synchronisation, the
+        // grids and row strides stay sized for n while the kernels read the current length on the device.
+        D.n_act = n;
+        const int burst = n > 16384 ? 1 : (n > 2048 ? 3 : 8);
+        const unsigned g128 = (unsigned)((n + 127) / 128);
+        for (int k = 0; k < burst; ++k, ++attempts)
         {
-            D.stage = i;
-            hipLaunchKernelGGL((jm::k_dopri_stage<T, Topo>), dim3(g128), dim3(128), 0, s, D);
-            auto A = make_args<T>(b);
-            A.mode = jm::MODE_DYNAMICS;
-            A.q_in = ws + (long long)R::QS * B;
-            A.v_in = ws + (long long)(R::KV + (i - 1) * Topo::NV) * B;
-            A.a_out = ws + (long long)(R::KA + (i - 1) * Topo::NV) * B;
-            const int32_t rc = launch<T>(b, A, stream);
-            if (rc != JM_OK) return rc;
+            if (k > 0)
+            {
+                HIP_TRY(hipMemsetAsync(b->ad_count, 0, sizeof(int32_t), s));
+                hipLaunchKernelGGL((jm::k_dopri_prepare<T, Topo>), dim3(g256), dim3(256), 0, s, D);
+            }
+            for (int i = 1; i <= 6; ++i)
+            {
+                D.stage = i;
+                hipLaunchKernelGGL((jm::k_dopri_stage<T, Topo>), dim3(g128), dim3(128), 0, s, D);
+                auto A = make_args<T>(b);
+                A.mode = jm::MODE_DYNAMICS;
+                A.B = n;
+                A.command = ws + (long long)R::CMD * n;
+                A.q_in = ws + (long long)R::QS * n;
+                A.v_in = ws + (long long)(R::KV + (i - 1) * Topo::NV) * n;
+                A.a_out = ws + (long long)(R::KA + (i - 1) * Topo::NV) * n;
+                const int32_t rc = launch<T>(b, A, stream);
+                if (rc != JM_OK) return rc;
+            }
+            hipLaunchKernelGGL((jm::k_dopri_finish<T, Topo>), dim3(g128), dim3(128), 0, s, D);
+            HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL((jm::k_dopri_finish<T, Topo>), dim3(g128), dim3(128), 0, s, D);
-        HIP_TRY(hipGetLastError());
     }
     if (attempts_out) *attempts_out = attempts;
     // extra terms + sensors at the breakpoint (engine.cc:2148, 2386-2410)

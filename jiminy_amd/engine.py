@@ -247,6 +247,71 @@ def _library_self_test(model: CompiledModel, variant: int, dtype: torch.dtype, d
     return err
 
 
+_CON_VERIFIED: Dict[Tuple[str, int], float] = {}
+
+
+def _constraint_self_test(model: CompiledModel, variant: int, device: torch.device) -> float:
+    """Consistency check of the constraint-model kernel of one compiled library, from the device's
+    own outputs: the joint wrenches of the RNEA-style extra terms (`joint_forces`, computed from
+    `a` and `f_external` by sweeps that share nothing with the constrained solve) must reproduce the
+    total effort vector, `S^T f_j + rotor a_j == u_j`, on probe lanes with active contact and
+    joint-bound constraints.  Returns the largest relative residual over the lanes without NaN."""
+    from .model import JT_PU, JT_PX, JT_RU, JT_RX
+    n, dt = 64, 1e-4
+    q, v, cmd = _probe_state(model, n)
+    rng = np.random.default_rng(7)
+    bounded = [j for j in range(1, model.njoints) if JT_RX <= int(model.jtypes[j]) <= JT_PU]
+    for lane in range(0, n, 2):  # every other lane: one or two joints past a position limit
+        for j in rng.permutation(bounded)[:2]:
+            iq = int(model.idx_q[j])
+            lo, hi = model.position_lower[iq], model.position_upper[iq]
+            if np.isfinite(hi) and rng.random() < 0.5:
+                q[iq, lane] = hi + 0.01
+            elif np.isfinite(lo):
+                q[iq, lane] = lo - 0.01
+    if model.has_freeflyer and model.ncontacts:
+        from .synthetic import lowest_contact_height
+        q[2] += -2.0e-3 - lowest_contact_height(model, q)
+    probe = BatchedEngine(model, n, dtype=torch.float64, device=device,
+                          extra_outputs=("joint_forces",), _lib_variant=variant)
+    probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                   "sensorsUpdatePeriod": dt}, "contacts": {"model": "constraint"}},
+                      _skip_constraint_check=True)
+    if model.nmotors:
+        probe.set_command(torch.as_tensor(cmd, dtype=torch.float64))
+    probe.start(torch.as_tensor(q), torch.as_tensor(v))
+    for _ in range(3):
+        probe.step(dt)
+    torch.cuda.synchronize(device)
+    a = probe.field("a").cpu().numpy()
+    u = probe.field("u").cpu().numpy().copy()
+    jf = probe.field("joint_forces").cpu().numpy().reshape(model.njoints, 6, n)
+    flags = probe.field("con_flags").cpu().numpy()
+    data = probe.field("con_data").cpu().numpy()
+    status = probe.status.cpu().numpy().reshape(-1)
+    probe.stop()
+    nb = len(bounded)
+    for k, j in enumerate(bounded):  # reversed bound: generalised force is -lambda (engine.cc:3786-3790 adds +lambda)
+        u[int(model.idx_v[j])] -= np.where(flags[k] & 2, 2.0 * data[nb + k], 0.0)
+    tau = np.zeros_like(u)
+    for j in range(1, model.njoints):
+        t, iv = int(model.jtypes[j]), int(model.idx_v[j])
+        if t == JT_FREEFLYER:
+            tau[iv:iv + 6] = jf[j]
+        else:
+            ax = {0: (1, 0, 0), 1: (0, 1, 0), 2: (0, 0, 1)}.get(
+                {1: 0, 2: 1, 3: 2, 5: 0, 6: 1, 7: 2, 9: 0, 10: 1, 11: 2}.get(t, -1), tuple(model.axes[j]))
+            part = jf[j, 0:3] if JT_PX <= t <= JT_PU else jf[j, 3:6]
+            tau[iv] = ax[0] * part[0] + ax[1] * part[1] + ax[2] * part[2]
+    tau += model.rotor_inertia[:, None] * a
+    ok = (status & _abi.JM_LANE_NAN) == 0
+    if not ok.any():
+        return float("inf")
+    scale = np.maximum(np.abs(u[:, ok]).max(axis=0), 1.0)
+    res = np.abs(tau - u)[:, ok].max(axis=0) / scale
+    return float(res.max()) if np.isfinite(res).all() else float("inf")
+
+
 def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
     """The HIP library of `model`, checked once per process, topology and dtype by
     `_library_self_test`.  A build that fails the check is a toolchain mis-compile (DESIGN.md
@@ -367,7 +432,7 @@ class BatchedEngine:
     def get_options(self) -> Dict[str, Dict[str, Any]]:
         return {k: dict(v) for k, v in self._options.items()}
 
-    def set_options(self, options: Dict[str, Dict[str, Any]]) -> None:
+    def set_options(self, options: Dict[str, Dict[str, Any]], _skip_constraint_check: bool = False) -> None:
         """≙ `Engine::setOptions` (reference engine.cc:2654-2795), hot-path subset."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before updating the options.")
@@ -418,6 +483,24 @@ class BatchedEngine:
             raise ValueError("The size of the gravity force vector must be 6.")
         self._options = new
         self._apply_options()
+        if ct["model"] == "constraint" and not _skip_constraint_check:
+            self._check_constraint_kernel()
+
+    def _check_constraint_kernel(self) -> None:
+        """First use of the constraint model for this topology in the process: run the kernel
+        self-test and refuse to run a library that fails it."""
+        key = (self.model.topology_hash(), _VERIFIED.get((self.model.topology_hash(), self.dtype),
+                                                         codegen.preferred_variant(self.model)))
+        if key in _CON_VERIFIED or os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
+            return
+        err = _constraint_self_test(self.model, key[1], self.device)
+        if not err <= 1e-8:
+            raise RuntimeError(
+                f"constraint-model kernel self-test failed for topology {self.model.topology_hash()} "
+                f"({self.model.name}, build variant {key[1]}): equation-of-motion residual {err:.3e}. "
+                "The compiled library is unsound (toolchain mis-compile, DESIGN.md section 4.7); rebuild it "
+                "with another variant (JIMINY_AMD_BUILD_VARIANT).")
+        _CON_VERIFIED[key] = err
 
     def _apply_options(self) -> None:
         ct = self._options["contacts"]
@@ -570,7 +653,7 @@ class BatchedEngine:
             self._adaptive = {
                 "ws": torch.zeros((rows, B), dtype=self.dtype, device=self.device),
                 "f64": torch.zeros((5, B), dtype=torch.float64, device=self.device),
-                "i32": torch.zeros((6, B), dtype=torch.int32, device=self.device),
+                "i32": torch.zeros((7, B), dtype=torch.int32, device=self.device),
             }
             ad = self._adaptive
             self._lib.check(self._L.jm_batch_bind_adaptive(
