@@ -179,7 +179,9 @@ enum {
  *   one row per bounded 1-dof joint (`JointConstraint`, model joint order; continuous joints never
  *   activate and own no row), then 4 rows per contact point (`FrameConstraint` with the translation
  *   and the rotation about the ground normal fixed: x, y, z, torsion; core/src/robot/model.cc:817-823).
- * Only explicit fixed-step solvers and float64 batches are available with this model on the batched path. */
+ * Float64 batches only.  With the adaptive stepper the constraint state of the active lanes travels with
+ * them (gathered / scattered around every attempt); call jm_batch_set_constraint_options before
+ * jm_batch_adaptive_workspace_rows, whose result depends on the contact model. */
 enum { JM_CONTACT_SPRING_DAMPER = 0, JM_CONTACT_CONSTRAINT = 1 };
 typedef struct jm_constraint_options {
     int32_t contact_model;      /* contacts.model: JM_CONTACT_*                      */
@@ -326,6 +328,23 @@ int32_t jm_block_sensor_noise(int32_t dtype, int64_t batch_size, int32_t n_senso
                               const double * bias, const double * rot_bias_inv, void * stream);
 int32_t jm_sensor_rng_seed(const uint32_t * group_seed, int64_t batch_size, int32_t n_sensors,
                            uint64_t * state_out);
+
+/* ---- Sensor delay and jitter, batched.
+ * jm_block_sensor_delay ≙ `AbstractSensorTpl<T>::interpolateData`
+ *   (core/include/jiminy/core/hardware/abstract_sensor.hxx:305-429), the first half of `measureDataAll`: call it
+ *   after every sensor refresh, before jm_block_sensor_noise.  `data` (device, `[n_sensors][n_fields][B]`) is
+ *   overwritten with the measurement delayed by `delay[s] + uniform(0, jitter[s])` read from the history ring
+ *   `history` (device, `[slots][n_sensors * n_fields][B]`, raw measurements the caller stored after each
+ *   refresh, the current one included): zero-order hold (`order` 0) or linear interpolation (1), the oldest
+ *   sample while the ring does not reach back far enough.  `slot[i]` / `times[i]` (host, i < n_history <= 64,
+ *   ascending times, the last one the current time) name the ring slot and the time of the i-th oldest sample.
+ *   The uniform number is drawn from `rng_state` (the generators of jm_block_sensor_noise) on every call,
+ *   whether or not a jitter is configured, as the reference does; `history` NULL only takes that draw. */
+#define JM_DELAY_MAX_HISTORY 64
+int32_t jm_block_sensor_delay(int32_t dtype, int64_t batch_size, int32_t n_sensors, int32_t n_fields, void * data,
+                              const void * history, const int32_t * slot, const double * times, int32_t n_history,
+                              uint64_t * rng_state, const double * delay, const double * jitter,
+                              int32_t interpolation_order, void * stream);
 
 /* Copy the message of the last error raised on the calling thread. */
 int32_t jm_last_error(char * buffer, size_t size);

@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "jm_block_pd_controller", "jm_block_mahony_filter",
     "jm_batch_adaptive_workspace_rows", "jm_batch_bind_adaptive", "jm_batch_step_adaptive",
     "jm_block_sensor_noise", "jm_sensor_rng_seed",
-    "jm_batch_set_constraint_options", "jm_batch_constraint_rows",
+    "jm_batch_set_constraint_options", "jm_batch_constraint_rows", "jm_block_sensor_delay",
 )
 
 
@@ -86,6 +86,8 @@ class HipLibrary:
                                              C.c_double, C.c_double, C.c_double, vp]
         L.jm_block_sensor_noise.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, dp, dp, dp, vp]
         L.jm_sensor_rng_seed.argtypes = [C.POINTER(C.c_uint32), C.c_int64, C.c_int32, C.POINTER(C.c_uint64)]
+        L.jm_block_sensor_delay.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, ip, dp, C.c_int32, vp,
+                                            dp, dp, C.c_int32, vp]
         L.jm_batch_set_constraint_options.argtypes = [vp, C.POINTER(_abi.ConstraintOptions)]
         L.jm_batch_constraint_rows.argtypes = [vp, ip, ip, ip]
         for name in ABI_SYMBOLS:

@@ -20,6 +20,7 @@
 //                         difference; Pinocchio v2.7.0 explog.hpp log3 / log6 restated)
 #pragma once
 #include "jm_kernels.h"
+#include "jm_constraint.h"
 
 namespace jm
 {
@@ -50,6 +51,11 @@ template<class T> struct AdaptiveArgs
     T * ws;                       // workspace: kv[6][nv], ka[6][nv], qs[nq], command[nm]: COMPACT rows of [n_act]
     const T * command;            // held command [nm][B]
     long long n_act;              // active lanes of this attempt (host copy of *n_active)
+    // constraint contact model: per-lane constraint state (null = spring-damper model) and its compact copy
+    // (flags: library-owned int32 [NF][n]; data: workspace rows CDATA), gathered at stage 1, scattered back
+    // by the finish kernel whether the step is accepted or not (the reference's constraint objects are
+    // mutated by every evaluation, engine.cc:3253-3338, 3145-3193)
+    int32_t * con_flags; T * con_data; int32_t * con_flags_c;
     double * fs;                  // [AD_NROWS_F][B]
     int32_t * is;                 // [AD_NROWS_I][B]
     int32_t * status;
@@ -61,6 +67,8 @@ template<class T> struct AdaptiveArgs
 template<class Tp> struct AdaptiveRows
 {
     static constexpr int KV = 0, KA = 6 * Tp::NV, QS = 12 * Tp::NV, CMD = 12 * Tp::NV + Tp::NQ, TOTAL = CMD + Tp::NM;
+    // constraint contact model: + compact constraint data and delassus workspace
+    static constexpr int CDATA = TOTAL, CWS = CDATA + ConRows<Tp>::ND, TOTAL_CON = CWS + ConRows<Tp>::WTOTAL;
 };
 
 JM_DEV double acos_(double x) { return ::acos(x); }
@@ -211,6 +219,11 @@ __global__ void __launch_bounds__(128) k_dopri_stage(const AdaptiveArgs<T> A)
         static_for<0, Tp::NM>([&](auto mc) {
             A.ws[(long long)(R::CMD + decltype(mc)::value) * N + c] = A.command[decltype(mc)::value * B + lane];
         });
+    if (i == 1 && A.con_flags)
+    {
+        for (int r = 0; r < ConRows<Tp>::NF; ++r) A.con_flags_c[(long long)r * N + c] = A.con_flags[(long long)r * B + lane];
+        for (int r = 0; r < ConRows<Tp>::ND; ++r) A.ws[(long long)(R::CDATA + r) * N + c] = A.con_data[(long long)r * B + lane];
+    }
     const T dt = (T)A.fs[AD_DT_TRY * B + lane];
     T q0[NQ], incv[NV], qs[NQ];
     static_for<0, NQ>([&](auto ic) { q0[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
@@ -255,6 +268,11 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
     double * fs = A.fs + lane;
     int32_t * is = A.is + lane;
     if (!is[AD_ACTIVE * B]) return;
+    if (A.con_flags)
+    {
+        for (int r = 0; r < ConRows<Tp>::NF; ++r) A.con_flags[(long long)r * B + lane] = A.con_flags_c[(long long)r * N + c];
+        for (int r = 0; r < ConRows<Tp>::ND; ++r) A.con_data[(long long)r * B + lane] = A.ws[(long long)(R::CDATA + r) * N + c];
+    }
     CPtr<T> P = (CPtr<T>)A.P;
     const double dt = fs[AD_DT_TRY * B];
     const T dtT = (T)dt;

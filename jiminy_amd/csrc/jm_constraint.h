@@ -32,6 +32,9 @@
 #ifndef JM_CON_MASKS
 #define JM_CON_MASKS 1  // path-restricted sweeps of the bias-free solves
 #endif
+#ifndef JM_CON_REBUILD
+#define JM_CON_REBUILD 1  // rebuild liMi in the bias-free solves instead of reading it back from scratch
+#endif
 #ifndef JM_CON_XLDS
 #define JM_CON_XLDS 0   // packed multipliers in LDS during the PGS solve (faster solve, but the extra 14 kB
                         // per block cost one resident wave per CU: measured slower on warm-started workloads)
@@ -174,6 +177,33 @@ template<class Tp, class F> JM_DEV void for_contacts(F && f)
         });
 }
 
+// liMi of a 1-dof joint rebuilt from the cached joint coordinate (WorkC::jcs) and the constant placement
+// (scalar loads): the column solves are bound by the traffic of the spilled working set, not by flops
+template<class T, class Tp, int J> JM_DEV SE3<T> limi_rebuilt(CPtr<T> P, const WorkC<T, Tp> & w)
+{
+#if JM_CON_REBUILD
+    using L = Layout<Tp>;
+    constexpr int t = Tp::jtype[J];
+    const SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
+    SE3<T> Mj;
+    if constexpr (jt_is_rev(t))
+    {
+        constexpr int ax = jt_axis(t);
+        if constexpr (ax >= 0) Mj.R = rot_axis<T>(ax, w.jcs[J][0], w.jcs[J][1]);
+        else Mj.R = rot_rodrigues(joint_axis<T, Tp, J>(P), w.jcs[J][0], w.jcs[J][1]);
+        Mj.p = zero3<T>();
+    }
+    else
+    {
+        Mj.R = ident3<T>();
+        Mj.p = w.jcs[J][0] * joint_axis<T, Tp, J>(P);
+    }
+    return plc * Mj;
+#else
+    return w.liMi[J];
+#endif
+}
+
 // dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias
 // of the last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).
 // Also returns the spatial accelerations `da` of every joint (joint frame).
@@ -208,7 +238,7 @@ JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T 
             {
                 const T ud = uj * w.dinv[j];
                 const Sp<T> pa = {pf[j].l + ud * w.U[j].l, pf[j].a + ud * w.U[j].a};
-                pf[p] = pf[p] + act_force(w.liMi[j], pa);
+                pf[p] = pf[p] + act_force(limi_rebuilt<T, Tp, j>(P, w), pa);
             }
         }
     });
@@ -228,7 +258,7 @@ JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T 
         else if (!JM_CON_MASKS || ((fmask >> j) & 1ull))
         {
             Sp<T> ag;
-            if constexpr (p > 0) ag = actinv_motion(w.liMi[j], da[p]);
+            if constexpr (p > 0) ag = actinv_motion(limi_rebuilt<T, Tp, j>(P, w), da[p]);
             else ag = zero6<T>();
             const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
             const T ddj = w.dinv[j] * (ur[iv] - Ua);
@@ -426,9 +456,22 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     using L = Layout<Tp>;
     using R = ConRows<Tp>;
     constexpr int NJ = Tp::NJ, NV = Tp::NV, NR = R::NR;
+    // `start_passes` < 0: refresh only -- no switching, no solve: the stored multipliers (those of the last
+    // evaluation, which an adaptive step took at this very state) are applied to the free acceleration, so
+    // that the outputs are the ones the reference reads after its last evaluation (engine.cc:2143-2151)
+    const bool refresh = start_passes < 0;
     // ---- unconstrained part: FK, motors, ABA without contact forces
     eval_dynamics<T, Tp>(P, q, v, cmd, w);
     w.status &= ~JM_LANE_SOLVER_FAILURE;
+    static_for<1, Tp::NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int t = Tp::jtype[j];
+        constexpr int iq = Tp::idx_q[j];
+        if constexpr (t == JM_JT_FREEFLYER) { w.jcs[j][0] = T(0); w.jcs[j][1] = T(0); }
+        else if constexpr (jt_is_unb(t)) { w.jcs[j][0] = q[iq]; w.jcs[j][1] = q[iq + 1]; }
+        else if constexpr (jt_is_rev(t)) sincos_(q[iq], &w.jcs[j][1], &w.jcs[j][0]);
+        else { w.jcs[j][0] = q[iq]; w.jcs[j][1] = T(0); }
+    });
     if constexpr (NR == 0) return;
     auto flag = [&](int r) -> int32_t & { return C.flags[(size_t)r * B + lane]; };
     auto dat = [&](int r) -> T & { return C.data[(size_t)r * B + lane]; };
@@ -450,22 +493,25 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         // Engine::start: JointConstraint::reset + enable, not reversed (engine.cc:1266-1308)
         const bool init = start_passes > 0;
         int32_t f = init ? 1 : flag(k);
-        const T qj = q[iq], lo = P[L::QLO + iq], hi = P[L::QHI + iq];
-        T ref = init ? qj : dat(k);
-        bool clear = init;
-        if (hi < qj || qj < lo)
+        if (!refresh)
         {
-            ref = clamp_(qj, lo, hi);
-            f = 1 | (hi < qj ? 2 : 0);
+            const T qj = q[iq], lo = P[L::QLO + iq], hi = P[L::QHI + iq];
+            T ref = init ? qj : dat(k);
+            bool clear = init;
+            if (hi < qj || qj < lo)
+            {
+                ref = clamp_(qj, lo, hi);
+                f = 1 | (hi < qj ? 2 : 0);
+            }
+            else if (lo + eps_tr < qj && qj < hi - eps_tr)
+            {
+                f &= ~1;
+                clear = true;  // AbstractConstraintBase::disable
+            }
+            flag(k) = f;
+            dat(k) = ref;
+            if (clear) lam(k) = T(0);
         }
-        else if (lo + eps_tr < qj && qj < hi - eps_tr)
-        {
-            f &= ~1;
-            clear = true;  // AbstractConstraintBase::disable
-        }
-        flag(k) = f;
-        dat(k) = ref;
-        if (clear) lam(k) = T(0);
         if (f & 1) act.set(k);
         if (f & 2) rev.set(k);
     });
@@ -476,19 +522,22 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         const T d = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, pc);
         const bool init = start_passes > 0;
         int32_t f = init ? 1 : flag(R::NB + c);
-        bool clear = init;
-        if (d < T(0)) f = 1;
-        else if (d > eps_tr)
+        if (!refresh)
         {
-            f = 0;
-            clear = true;
-        }
-        if (clear)
-        {
+            bool clear = init;
+            if (d < T(0)) f = 1;
+            else if (d > eps_tr)
+            {
+                f = 0;
+                clear = true;
+            }
+            if (clear)
+            {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
+                for (int i = 0; i < 4; ++i) lam(r0 + i) = T(0);
+            }
+            flag(R::NB + c) = f;
         }
-        flag(R::NB + c) = f;
         if (f & 1) { act.set(r0); act.set(r0 + 1); act.set(r0 + 2); act.set(r0 + 3); }
     });
     if (!act.any()) return;  // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
@@ -510,7 +559,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     const int m_act = act.count(), nb_act = act.rank(R::NB);
     RowMask rem = act;
 #pragma nounroll
-    for (int pk = 0; pk < m_act; ++pk)
+    for (int pk = 0; pk < (refresh ? 0 : m_act); ++pk)
     {
         const int r = rem.pop_lowest();
         int jr = 0, tiv = -1;
@@ -576,76 +625,79 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] += dd[decltype(ic)::value]; });
             static_for<1, NJ>([&](auto jc) { sa[decltype(jc)::value] = sa[decltype(jc)::value] + da[decltype(jc)::value]; });
         }
-        // b = -(drift + J a_free)
-        static_for<0, R::NB>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int jn = R::bjoint(k);
-            constexpr int iq = Tp::idx_q[jn], iv = Tp::idx_v[jn];
-            if (act.test(k))
-            {
-                const T s = C.kp * (q[iq] - dat(k)) + C.kd * v[iv] + af[iv];
-                ws(R::WB + act.rank(k)) = rev.test(k) ? s : -s;
-            }
-        });
-        for_contacts<Tp>([&](auto jc, int c) {
-            constexpr int j = decltype(jc)::value;
-            const int r0 = R::NB + 4 * c;
-            if (act.test(r0))
-            {
-                const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
-                const M3<T> & Rj = w.oMi[j].R;
-                const T depth = w.oMi[j].p.z + dot(V3<T>{Rj.m20, Rj.m21, Rj.m22}, pc);
-                const V3<T> vlin = Rj * (w.vel[j].l + cross(w.vel[j].a, pc));
-                const V3<T> vang = Rj * w.vel[j].a;
-                V3<T> alin = Rj * (sa[j].l + cross(sa[j].a, pc));
-                const V3<T> aang = Rj * sa[j].a;
-                alin = alin + cross(vang, vlin);
-                const int p0 = act.rank(r0);
-                ws(R::WB + p0) = -(alin.x + C.kd * vlin.x);
-                ws(R::WB + p0 + 1) = -(alin.y + C.kd * vlin.y);
-                ws(R::WB + p0 + 2) = -(alin.z + C.kp * depth + C.kd * vlin.z);
-                ws(R::WB + p0 + 3) = -(aang.z + C.kd * vang.z);
-            }
-        });
-        // multipliers: gather the warm start into the packed vector, solve, scatter back
-        static_for<0, R::NB>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (act.test(k)) ws(R::WX + act.rank(k)) = lam(k);
-        });
-        for_contacts<Tp>([&](auto, int c) {
-            const int r0 = R::NB + 4 * c;
-            if (act.test(r0))
-            {
-                const int p0 = act.rank(r0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ws(R::WX + p0 + i) = lam(r0 + i);
-            }
-        });
-        bool ok;
-        if (start_passes > 0 && pass == 0)
+        if (!refresh)
         {
-            ok = chol_solve_packed<T, Tp>(m_act, ws);
-            if (!ok) w.status |= JM_LANE_NAN;
-        }
-        else
-        {
-            ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
-            if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
-            else w.status |= JM_LANE_SOLVER_FAILURE;
-        }
-        static_for<0, R::NB>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if (act.test(k)) lam(k) = ws(R::WX + act.rank(k));
-        });
-        for_contacts<Tp>([&](auto, int c) {
-            const int r0 = R::NB + 4 * c;
-            if (act.test(r0))
-            {
-                const int p0 = act.rank(r0);
+            // b = -(drift + J a_free)
+            static_for<0, R::NB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int jn = R::bjoint(k);
+                constexpr int iq = Tp::idx_q[jn], iv = Tp::idx_v[jn];
+                if (act.test(k))
+                {
+                    const T s = C.kp * (q[iq] - dat(k)) + C.kd * v[iv] + af[iv];
+                    ws(R::WB + act.rank(k)) = rev.test(k) ? s : -s;
+                }
+            });
+            for_contacts<Tp>([&](auto jc, int c) {
+                constexpr int j = decltype(jc)::value;
+                const int r0 = R::NB + 4 * c;
+                if (act.test(r0))
+                {
+                    const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+                    const M3<T> & Rj = w.oMi[j].R;
+                    const T depth = w.oMi[j].p.z + dot(V3<T>{Rj.m20, Rj.m21, Rj.m22}, pc);
+                    const V3<T> vlin = Rj * (w.vel[j].l + cross(w.vel[j].a, pc));
+                    const V3<T> vang = Rj * w.vel[j].a;
+                    V3<T> alin = Rj * (sa[j].l + cross(sa[j].a, pc));
+                    const V3<T> aang = Rj * sa[j].a;
+                    alin = alin + cross(vang, vlin);
+                    const int p0 = act.rank(r0);
+                    ws(R::WB + p0) = -(alin.x + C.kd * vlin.x);
+                    ws(R::WB + p0 + 1) = -(alin.y + C.kd * vlin.y);
+                    ws(R::WB + p0 + 2) = -(alin.z + C.kp * depth + C.kd * vlin.z);
+                    ws(R::WB + p0 + 3) = -(aang.z + C.kd * vang.z);
+                }
+            });
+            // multipliers: gather the warm start into the packed vector, solve, scatter back
+            static_for<0, R::NB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (act.test(k)) ws(R::WX + act.rank(k)) = lam(k);
+            });
+            for_contacts<Tp>([&](auto, int c) {
+                const int r0 = R::NB + 4 * c;
+                if (act.test(r0))
+                {
+                    const int p0 = act.rank(r0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lam(r0 + i) = ws(R::WX + p0 + i);
+                    for (int i = 0; i < 4; ++i) ws(R::WX + p0 + i) = lam(r0 + i);
+                }
+            });
+            bool ok;
+            if (start_passes > 0 && pass == 0)
+            {
+                ok = chol_solve_packed<T, Tp>(m_act, ws);
+                if (!ok) w.status |= JM_LANE_NAN;
             }
-        });
+            else
+            {
+                ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
+                if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
+                else w.status |= JM_LANE_SOLVER_FAILURE;
+            }
+            static_for<0, R::NB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (act.test(k)) lam(k) = ws(R::WX + act.rank(k));
+            });
+            for_contacts<Tp>([&](auto, int c) {
+                const int r0 = R::NB + 4 * c;
+                if (act.test(r0))
+                {
+                    const int p0 = act.rank(r0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lam(r0 + i) = ws(R::WX + p0 + i);
+                }
+            });
+        }
         // constraint forces of this pass: joint efforts + wrenches on the contact bodies
         T tl[NV];
         static_for<0, NV>([&](auto ic) { tl[decltype(ic)::value] = T(0); });

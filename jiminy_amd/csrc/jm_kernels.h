@@ -140,6 +140,9 @@ template<class T, class Tp> struct WorkC : Work<T, Tp>
 {
     T rootA[6][6];   // LDL^T factor of (Ia_root + rotor) left by chol6_solve (unit lower + diagonal)
     T rootdinv[6];
+    // joint coordinate of every 1-dof joint as (cos, sin) or (displacement, -): the bias-free solves
+    // rebuild liMi from these 2 scalars + the constant placement instead of re-reading 12 scalars per joint
+    T jcs[Tp::NJ][2];
     static constexpr bool CONSTRAINED = true;
 };
 // evaluation policy of lane_run: plain (spring-damper contacts) or constraint contact model
@@ -752,7 +755,8 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
 
 // constraint contact model (jm_constraint.h): the free evaluation above + constraint switching +
-// the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence
+// the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence, < 0 only re-applies the
+// stored multipliers (MODE_REFRESH)
 template<class T, class Tp, class CA>
 JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
                              long long lane, long long B, int start_passes);
@@ -802,7 +806,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
         const T * vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
         static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
         static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
-        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B, (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : 0);
+        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B,
+                             (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0));
         if (A.mode == MODE_DYNAMICS)
         {
             static_for<0, NV>([&](auto ic) { A.a_out[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });

@@ -73,6 +73,9 @@ struct jm_batch
     double * ad_fs = nullptr;
     int32_t * ad_is = nullptr;
     int32_t * ad_count = nullptr;       // device
+    int32_t * ad_flags = nullptr;       // device, compact constraint flags [NF][B] (constraint model + adaptive)
+    // compact-batch overrides of the constraint state pointers (adaptive stepper), null = bound fields
+    int32_t * ov_flags = nullptr; void * ov_data = nullptr; void * ov_ws = nullptr;
     int32_t * ad_count_host = nullptr;  // pinned host
     // constraint contact model (jm_constraint.h)
     jm_constraint_options copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
@@ -160,9 +163,9 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             if (R::NR > 0 && (!b->field[JM_F_CON_FLAGS] || !b->field[JM_F_CON_DATA] || !b->field[JM_F_WORKSPACE]))
                 return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': the con_flags, con_data and workspace fields must be bound");
             jm::ConArgs<T> C;
-            C.flags = (int32_t *)b->field[JM_F_CON_FLAGS];
-            C.data = (T *)b->field[JM_F_CON_DATA];
-            C.ws = (T *)b->field[JM_F_WORKSPACE];
+            C.flags = b->ov_flags ? b->ov_flags : (int32_t *)b->field[JM_F_CON_FLAGS];
+            C.data = b->ov_data ? (T *)b->ov_data : (T *)b->field[JM_F_CON_DATA];
+            C.ws = b->ov_ws ? (T *)b->ov_ws : (T *)b->field[JM_F_WORKSPACE];
             const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
             C.kp = (T)(omega * omega);
             C.kd = (T)(2.0 * omega);
@@ -224,6 +227,12 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
     }
     D.command = (const T *)b->field[JM_F_COMMAND];
     D.n_act = B;  // upper bound of the active-list length: the list only shrinks within an interval
+    const bool constrained = b->copt.contact_model == JM_CONTACT_CONSTRAINT && jm::ConRows<Topo>::NR > 0;
+    D.con_flags = constrained ? (int32_t *)b->field[JM_F_CON_FLAGS] : nullptr;
+    D.con_data = constrained ? (T *)b->field[JM_F_CON_DATA] : nullptr;
+    D.con_flags_c = b->ad_flags;
+    if (constrained && (!D.con_flags || !D.con_data || !b->ad_flags))
+        return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': bind con_flags / con_data, then jm_batch_bind_adaptive");
     const unsigned g256 = (unsigned)((B + 255) / 256);
     int attempts = 0;
     for (;;)
@@ -261,7 +270,14 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
                 A.q_in = ws + (long long)R::QS * n;
                 A.v_in = ws + (long long)(R::KV + (i - 1) * Topo::NV) * n;
                 A.a_out = ws + (long long)(R::KA + (i - 1) * Topo::NV) * n;
+                if (constrained)
+                {
+                    b->ov_flags = b->ad_flags;
+                    b->ov_data = ws + (long long)R::CDATA * n;
+                    b->ov_ws = ws + (long long)R::CWS * n;
+                }
                 const int32_t rc = launch<T>(b, A, stream);
+                b->ov_flags = nullptr; b->ov_data = nullptr; b->ov_ws = nullptr;
                 if (rc != JM_OK) return rc;
             }
             hipLaunchKernelGGL((jm::k_dopri_finish<T, Topo>), dim3(g128), dim3(128), 0, s, D);
@@ -354,6 +370,7 @@ int32_t jm_batch_destroy(jm_batch * b)
     (void)hipSetDevice(b->device);
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->ad_count) (void)hipFree(b->ad_count);
+    if (b->ad_flags) (void)hipFree(b->ad_flags);
     if (b->ad_count_host) (void)hipHostFree(b->ad_count_host);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     delete b;
@@ -465,8 +482,8 @@ int32_t jm_batch_step(jm_batch * b, int32_t solver, double dt, int32_t n_substep
 // ---- adaptive Dormand-Prince stepping (jm_adaptive.h)
 int32_t jm_batch_adaptive_workspace_rows(const jm_batch * b)
 {
-    (void)b;
-    return jm::AdaptiveRows<Topo>::TOTAL;
+    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? jm::AdaptiveRows<Topo>::TOTAL_CON
+                                                                 : jm::AdaptiveRows<Topo>::TOTAL;
 }
 int32_t jm_batch_bind_adaptive(jm_batch * b, void * workspace, double * state_f64, int32_t * state_i32)
 {
@@ -476,6 +493,8 @@ int32_t jm_batch_bind_adaptive(jm_batch * b, void * workspace, double * state_f6
     {
         HIP_TRY(hipSetDevice(b->device));
         HIP_TRY(hipMalloc((void **)&b->ad_count, sizeof(int32_t)));
+        if (jm::ConRows<Topo>::NF > 0)
+            HIP_TRY(hipMalloc((void **)&b->ad_flags, sizeof(int32_t) * (size_t)jm::ConRows<Topo>::NF * (size_t)b->B));
         HIP_TRY(hipHostMalloc((void **)&b->ad_count_host, sizeof(int32_t), hipHostMallocDefault));
     }
     return JM_OK;
@@ -489,8 +508,8 @@ int32_t jm_batch_step_adaptive(jm_batch * b, double t_next, const jm_adaptive_op
         return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before using step method.");
     if (!b->ad_ws || !b->ad_fs || !b->ad_is)
         return fail(JM_ECONTROLFLOW, "jm_batch_bind_adaptive must be called before the adaptive stepper is used");
-    if (b->copt.contact_model == JM_CONTACT_CONSTRAINT)
-        return fail(JM_ENOTIMPL, "contacts.model = 'constraint' is only available with the fixed-step solvers on the batched path");
+    if (b->copt.contact_model == JM_CONTACT_CONSTRAINT && b->dtype != JM_F64)
+        return fail(JM_ENOTIMPL, "contacts.model = 'constraint' needs a float64 batch");
     if (!(options->tol_rel > 0.0) || !(options->tol_abs > 0.0)) return fail(JM_EINVAL, "tolRel and tolAbs must be positive");
     if (!(options->dt_max >= 1e-6) || !(options->dt_max <= 0.02 + 1e-12)) return fail(JM_EINVAL, "'dtMax' option is out of range.");
     int32_t rc = check_bound(b, true);
@@ -668,6 +687,45 @@ int32_t jm_block_sensor_noise(int32_t dtype, int64_t B, int32_t n_sensors, int32
         hipLaunchKernelGGL((jm::k_sensor_noise<double>), grid, dim3(256), 0, s, p, tab, (double *)data, rng_state, (long long)B);
     else
         hipLaunchKernelGGL((jm::k_sensor_noise<float>), grid, dim3(256), 0, s, p, tab, (float *)data, rng_state, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_block_sensor_delay(int32_t dtype, int64_t B, int32_t n_sensors, int32_t n_fields, void * data,
+                              const void * history, const int32_t * slot, const double * times, int32_t n_history,
+                              uint64_t * rng_state, const double * delay, const double * jitter, int32_t order,
+                              void * stream)
+{
+    if (!data) return fail(JM_EINVAL, "jm_block_sensor_delay: null data");
+    if (B <= 0 || n_sensors <= 0 || n_fields <= 0 || n_fields > JM_NOISE_MAX_FIELDS || n_sensors > JM_NOISE_MAX_ROWS)
+        return fail(JM_EINVAL, "jm_block_sensor_delay: bad sizes");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_sensor_delay: bad dtype");
+    if (order != 0 && order != 1)
+        return fail(JM_ENOTIMPL, "`delayInterpolationOrder` must be either 0 or 1.");  // abstract_sensor.hxx:399-403
+    if (history && (!slot || !times || n_history < 1 || n_history > JM_DELAY_MAX_HISTORY))
+        return fail(JM_EINVAL, "jm_block_sensor_delay: the history needs 1..64 samples with their slots and times");
+    if (!history && !rng_state) return JM_OK;
+    jm::DelayParams p{};
+    p.n_sensors = n_sensors; p.n_fields = n_fields; p.order = order;
+    p.has_history = history != nullptr; p.n_hist = history ? n_history : 0;
+    for (int i = 0; i < p.n_hist; ++i)
+    {
+        if (i > 0 && !(times[i] >= times[i - 1])) return fail(JM_EINVAL, "jm_block_sensor_delay: sample times must ascend");
+        p.slot[i] = slot[i];
+        p.times[i] = times[i];
+    }
+    for (int s = 0; s < n_sensors; ++s)
+    {
+        p.delay[s] = delay ? delay[s] : 0.0;
+        p.jitter[s] = jitter ? (float)jitter[s] : 0.0f;
+        if (!(p.delay[s] >= 0.0) || !(p.jitter[s] >= 0.0f)) return fail(JM_EINVAL, "jm_block_sensor_delay: negative delay or jitter");
+    }
+    const dim3 grid((unsigned)((B + 255) / 256), (unsigned)n_sensors);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_sensor_delay<double>), grid, dim3(256), 0, s, p, (double *)data, (const double *)history, rng_state, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_sensor_delay<float>), grid, dim3(256), 0, s, p, (float *)data, (const float *)history, rng_state, (long long)B);
     HIP_TRY(hipGetLastError());
     return JM_OK;
 }

@@ -114,6 +114,101 @@ struct NoiseParams
     double rot[JM_NOISE_MAX_ROT][9];         // IMU: exp3(-bias.head<3>()), row-major
 };
 
+// ---- sensor delay and jitter: AbstractSensorTpl<T>::interpolateData (abstract_sensor.hxx:305-429)
+#define JM_DELAY_MAX_HISTORY 64
+struct DelayParams
+{
+    int n_sensors, n_fields, n_hist, order, has_history;
+    int slot[JM_DELAY_MAX_HISTORY];      // physical ring slot of the i-th oldest sample
+    double times[JM_DELAY_MAX_HISTORY];  // ascending sample times, the last one is the current time
+    double delay[JM_NOISE_MAX_ROWS];     // [sensor]
+    float jitter[JM_NOISE_MAX_ROWS];     // [sensor]
+};
+// index of the sample to read (and the interpolation ratio towards the next one) for the desired time
+JM_RDEV void delay_lookup(const DelayParams & p, int s, double delay, int & idx, double & ratio)
+{
+    const int n = p.n_hist;
+    const double EPS = 2.220446049250313e-16;
+    double timeDesired = p.times[n - 1] - delay;
+    // zero-order hold: bias the comparison so that a delay equal to a multiple of the period always
+    // picks the same side (abstract_sensor.hxx:322-330)
+    if (p.order == 0) timeDesired += 1.0e-10;
+    // bisectLeft (abstract_sensor.hxx:334-375)
+    long left = 0, right = n - 1, mid = 0, idxLeft;
+    if (timeDesired >= p.times[n - 1]) idxLeft = right;
+    else if (timeDesired < p.times[0]) idxLeft = -1;
+    else
+    {
+        bool found = false;
+        idxLeft = 0;
+        while (left < right)
+        {
+            mid = (left + right) / 2;
+            if (timeDesired < p.times[mid]) right = mid;
+            else if (timeDesired > p.times[mid]) left = mid + 1;
+            else { idxLeft = mid; found = true; break; }
+        }
+        if (!found) idxLeft = (timeDesired < p.times[mid]) ? mid - 1 : mid;
+    }
+    ratio = 0.0;
+    if (timeDesired >= 0.0 && idxLeft + 1 < n)
+    {
+        // the reference raises "No data old enough is available" for idxLeft < 0: the caller sizes the
+        // history so that this cannot happen; the oldest sample is the graceful answer
+        idx = idxLeft < 0 ? 0 : (int)idxLeft;
+        if (p.order == 1 && idxLeft >= 0)
+            ratio = (timeDesired - p.times[idxLeft]) / (p.times[idxLeft + 1] - p.times[idxLeft]);
+    }
+    else if (p.delay[s] > EPS || (double)p.jitter[s] > EPS)
+    {
+        // buffer not fully initialised yet: the oldest value (abstract_sensor.hxx:405-421)
+        idx = n - 1;
+        for (int i = 0; i < n; ++i)
+            if (p.times[i] > 0.0) { idx = i - 1 > 0 ? i - 1 : 0; break; }
+    }
+    else idx = n - 1;
+}
+
+#ifndef JM_HOST_EMU
+// data [n_sensors * n_fields][B]: overwritten with the delayed measurement read from the history ring
+// `hist` [slots][n_sensors * n_fields][B]; rng [n_sensors][B] (one uniform draw per sensor and call, taken
+// whether or not a jitter is configured, exactly like the reference)
+template<class T>
+__global__ void __launch_bounds__(256) k_sensor_delay(const DelayParams p, T * data, const T * hist, uint64_t * rng, long long B)
+{
+    const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (lane >= B) return;
+    double delay = p.delay[s];
+    if (rng)
+    {
+        uint64_t st = rng[(long long)s * B + lane];
+        // uniform(generator_, 0.0F, jitter) = std::uniform_real_distribution<float>(0, jitter)(g)
+        const float u = rnd::uniform01(st);
+        delay += (double)(u * (p.jitter[s] - 0.0f) + 0.0f);
+        rng[(long long)s * B + lane] = st;
+    }
+    if (!p.has_history) return;
+    int idx;
+    double ratio;
+    delay_lookup(p, s, delay, idx, ratio);
+    const long long rows = (long long)p.n_sensors * p.n_fields;
+    const T * h0 = hist + ((long long)p.slot[idx] * rows + (long long)s * p.n_fields) * B + lane;
+    T * d = data + (long long)s * p.n_fields * B + lane;
+    if (ratio != 0.0)
+    {
+        const T * h1 = hist + ((long long)p.slot[idx + 1] * rows + (long long)s * p.n_fields) * B + lane;
+        for (int f = 0; f < p.n_fields; ++f)
+        {
+            const double a = (double)h0[(long long)f * B], b = (double)h1[(long long)f * B];
+            d[(long long)f * B] = (T)(a + ratio * (b - a));
+        }
+    }
+    else
+        for (int f = 0; f < p.n_fields; ++f) d[(long long)f * B] = h0[(long long)f * B];
+}
+#endif
+
 #ifndef JM_HOST_EMU
 // data: [n_sensors * n_fields][B] (row = sensor * n_fields + field), rng: [n_sensors][B]
 template<class T>

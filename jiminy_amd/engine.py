@@ -450,10 +450,6 @@ class BatchedEngine:
                 f"(available: {sorted(SOLVER_IDS)})")
         if ct["model"] not in _abi.CONTACT_MODELS:
             raise ValueError("The requested contact model is not available.")  # engine.cc:2741-2747
-        if ct["model"] == "constraint" and st["odeSolver"] == "runge_kutta_dopri":
-            raise NotImplementedError(
-                "contacts.model='constraint' is available with the fixed-step solvers "
-                "('euler_explicit', 'runge_kutta_4') on the batched path")
         if ct["model"] == "constraint" and self.dtype != torch.float64:
             raise NotImplementedError("contacts.model='constraint' needs a float64 engine")
         if new["constraints"]["solver"] != "PGS":
@@ -630,7 +626,8 @@ class BatchedEngine:
             # `Engine::start` measures the sensors INIT_ITERATIONS times while it solves the initial
             # acceleration / sensor / controller coupling, then once more (engine.cc:61,1400-1441,
             # 1470-1480): same number of draws here, so that the streams stay aligned
-            self._apply_sensor_noise(discard_rounds=INIT_ITERATIONS)
+            self._reset_sensor_history()
+            self._apply_sensor_noise(discard_rounds=INIT_ITERATIONS, t_now=0.0)
         self._setup_adaptive()
         self._running = True
         self._command_dirty = False
@@ -648,8 +645,10 @@ class BatchedEngine:
             self._adaptive = None
             return
         B = self.batch_size
+        rows = int(self._L.jm_batch_adaptive_workspace_rows(self._batch_h))  # depends on the contact model
+        if self._adaptive is not None and self._adaptive["ws"].shape[0] != rows:
+            self._adaptive = None
         if self._adaptive is None:
-            rows = int(self._L.jm_batch_adaptive_workspace_rows(self._batch_h))
             self._adaptive = {
                 "ws": torch.zeros((rows, B), dtype=self.dtype, device=self.device),
                 "f64": torch.zeros((5, B), dtype=torch.float64, device=self.device),
@@ -672,8 +671,9 @@ class BatchedEngine:
         stream = self._stream()
         attempts = C.c_int32(0)
         self.adaptive_attempts = 0
+        constraint_model = self._options["contacts"]["model"] == "constraint"
         for i, (t_next, cmd_bp, sens) in enumerate(intervals):
-            changed = cmd_bp and self._command_dirty
+            changed = cmd_bp and (self._command_dirty or constraint_model)
             self._lib.check(self._L.jm_batch_step_adaptive(
                 self._batch_h, float(t_next), C.byref(o), int(i == 0), int(changed), int(sens),
                 100000, C.byref(attempts), stream))
@@ -685,7 +685,7 @@ class BatchedEngine:
                     raise NotImplementedError(
                         "sensor noise with the adaptive solver needs a positive sensorsUpdatePeriod "
                         "(lanes take different internal steps)")
-                self._apply_sensor_noise()
+                self._apply_sensor_noise(t_now=float(t_next))
         self._t_prev = self._t
         self._t = t_end
         self._t_error = t_err
@@ -706,8 +706,10 @@ class BatchedEngine:
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
         per_step_noise = bool(self._sensor_noise) and float(self._options["stepper"]["sensorsUpdatePeriod"]) <= 0.0
         constraint_model = self._options["contacts"]["model"] == "constraint"
+        t_now = self._t
         for dt, n, cmd_bp, sens in launches:
             for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
+                t_now += dt * n_k
                 # a(t+) refresh at a controller breakpoint (engine.cc:2030-2042): skipped when the held
                 # command was not rewritten (the evaluation is idempotent) -- except with the constraint
                 # contact model, where the reference's refresh re-runs the warm-started PGS solve
@@ -717,7 +719,7 @@ class BatchedEngine:
                 if changed:
                     self._command_dirty = False
                 if sens and self._sensor_noise:
-                    self._apply_sensor_noise()
+                    self._apply_sensor_noise(t_now=t_now)
             self._iter += n
             self._dt = dt
         self._t_prev = self._t
@@ -786,14 +788,19 @@ class BatchedEngine:
     _SENSOR_FIELDS = {"ImuSensor": ("imu", 6), "ForceSensor": ("force", 6), "ContactSensor": ("contact", 3),
                       "EncoderSensor": ("encoder", 2), "EffortSensor": ("effort", 1)}
 
-    def set_sensor_options(self, sensor_type: str, noise_std: Any = None, bias: Any = None) -> None:
-        """≙ `sensor.set_options({"noiseStd": ..., "bias": ...})` for every sensor of one type
+    def set_sensor_options(self, sensor_type: str, noise_std: Any = None, bias: Any = None, delay: Any = None,
+                           jitter: Any = None, delay_interpolation_order: int = 0) -> None:
+        """≙ `sensor.set_options({"noiseStd": ..., "bias": ..., "delay": ..., "jitter": ...,
+        "delayInterpolationOrder": ...})` for every sensor of one type
         (reference abstract_sensor.h:66-100): white noise and bias applied to the raw measurement
         after every sensor refresh (`AbstractSensorBase::measureData`, abstract_sensor.cc:71-85;
         `ImuSensor::measureData`, basic_sensors.cc:166-187).  `noise_std` is `(n_fields,)` or
         `(n_sensors, n_fields)`; `bias` likewise, except for IMUs where it has 9 entries: a rotation
         bias (angle-axis) followed by the gyroscope and accelerometer biases.  `None` leaves the
-        option empty.  Not allowed while a simulation is running (abstract_sensor.cc:87-96)."""
+        option empty.  `delay` / `jitter` (seconds, scalar or `(n_sensors,)`): the measurement is read
+        `delay + uniform(0, jitter)` in the past from the history of raw measurements, zero-order hold or
+        linear interpolation (`AbstractSensorTpl::interpolateData`, abstract_sensor.hxx:305-429); needs a
+        positive `sensorsUpdatePeriod`.  Not allowed while a simulation is running (abstract_sensor.cc:87-96)."""
         if self._running:
             raise BadControlFlow("Robot already locked, probably because a simulation is running. "
                                  "Please stop it before setting sensor options.")
@@ -815,13 +822,25 @@ class BatchedEngine:
                 raise ValueError(f"{what} must have shape ({cols},) or ({n}, {cols})")
             return np.ascontiguousarray(a)
         std, b = table(noise_std, nf, "noise_std"), table(bias, nb, "bias")
-        if std is None and b is None:
+
+        def per_sensor(x, what):
+            a = np.broadcast_to(np.asarray(0.0 if x is None else x, dtype=np.float64), (n,)).copy()
+            if np.any(a < 0.0):
+                raise ValueError(f"{what} must be non-negative")
+            return np.ascontiguousarray(a)
+        dly, jit = per_sensor(delay, "delay"), per_sensor(jitter, "jitter")
+        has_delay = bool(np.any(dly > EPS) or np.any(jit > EPS))
+        if int(delay_interpolation_order) not in (0, 1):
+            raise NotImplementedError("`delayInterpolationOrder` must be either 0 or 1.")  # abstract_sensor.hxx:399-403
+        if std is None and b is None and not has_delay:
             self._sensor_noise.pop(sensor_type, None)
             return
         if std is not None and np.any(std < 0.0):
             raise ValueError("noise_std must be non-negative")
         entry: Dict[str, Any] = {"field": field, "n": n, "nf": nf, "std": std, "bias": None, "rot": None,
-                                 "rng": self._sensor_noise.get(sensor_type, {}).get("rng")}
+                                 "rng": self._sensor_noise.get(sensor_type, {}).get("rng"),
+                                 "delay": dly if has_delay else None, "jitter": jit if has_delay else None,
+                                 "order": int(delay_interpolation_order), "hist": None, "samples": []}
         if b is not None:
             if sensor_type == "ImuSensor":
                 # sensorRotationBiasInv_ = exp3(-bias.head<3>()) (basic_sensors.cc:121-129)
@@ -852,24 +871,73 @@ class BatchedEngine:
                 gs.ctypes.data_as(C.POINTER(C.c_uint32)), B, e["n"], out.ctypes.data_as(C.POINTER(C.c_uint64))))
             e["rng"] = torch.from_numpy(out.view(np.int64)).to(self.device)
 
-    def _apply_sensor_noise(self, discard_rounds: int = 0) -> None:
+    def _reset_sensor_history(self) -> None:
+        """`AbstractSensorTpl::resetAll`: empty history (abstract_sensor.hxx:196-199).  The ring holds the raw
+        measurements of the last `delayMax + SIMULATION_MAX_TIMESTEP` seconds, like the reference's buffer
+        (abstract_sensor.hxx:456-461), at one sample per sensor refresh."""
+        period = float(self._options["stepper"]["sensorsUpdatePeriod"])
+        for stype, e in self._sensor_noise.items():
+            e["samples"] = []
+            e["hist"] = None
+            if e["delay"] is None:
+                continue
+            if period <= 0.0:
+                raise NotImplementedError(f"{stype}: sensor delay needs a positive sensorsUpdatePeriod")
+            delay_max = float((e["delay"] + e["jitter"]).max())
+            slots = int(math.ceil((delay_max + SIMULATION_MAX_TIMESTEP) / period)) + 3
+            if slots > 64:
+                raise NotImplementedError(f"{stype}: the delay spans more than 64 sensor periods")
+            rows = max(self._rows[e["field"]], 1)
+            e["hist"] = torch.zeros((slots, rows, self.batch_size), dtype=self.dtype, device=self.device)
+
+    def _apply_sensor_noise(self, discard_rounds: int = 0, t_now: float = 0.0) -> None:
+        """`AbstractSensorTpl::measureDataAll` (abstract_sensor.hxx:431-443) on the raw measurements the
+        physics launch just wrote: delay (history lookup + the jitter draw), then white noise and bias."""
         dp = C.POINTER(C.c_double)
         dtype = _abi.JM_F64 if self.dtype == torch.float64 else _abi.JM_F32
         for stype, e in self._sensor_noise.items():
             if e["std"] is not None and e["rng"] is None:
                 raise BadControlFlow(f"{stype}: noise is enabled but the generators were never seeded "
                                      "(call seed_sensors first)")
+            if e["delay"] is not None and float(e["jitter"].max()) > EPS and e["rng"] is None:
+                raise BadControlFlow(f"{stype}: jitter is enabled but the generators were never seeded "
+                                     "(call seed_sensors first)")
             ptr = lambda a: a.ctypes.data_as(dp) if a is not None else None  # noqa: E731
             rng = C.c_void_p(e["rng"].data_ptr()) if e["rng"] is not None else None
-            if discard_rounds and e["std"] is not None:
-                scratch = torch.zeros_like(self._fields[e["field"]])
-                for _ in range(discard_rounds):
+            field = self._fields[e["field"]]
+            hist, slot_p, time_p, n_hist = None, None, None, 0
+            if e["hist"] is not None:
+                # store the raw measurement of this refresh (several refreshes at one time, as in `start`,
+                # hold the same raw data: one sample)
+                samples = e["samples"]
+                if samples and abs(samples[-1][1] - t_now) <= EPS:
+                    slot = samples[-1][0]
+                else:
+                    n_slots = e["hist"].shape[0]
+                    used = {sl for sl, _ in samples}
+                    if len(samples) == n_slots:
+                        slot = samples.pop(0)[0]
+                    else:
+                        slot = next(i for i in range(n_slots) if i not in used)
+                    samples.append((slot, float(t_now)))
+                e["hist"][slot].copy_(field)
+                slots = np.ascontiguousarray([sl for sl, _ in samples], dtype=np.int32)
+                times = np.ascontiguousarray([tm for _, tm in samples], dtype=np.float64)
+                hist = C.c_void_p(e["hist"].data_ptr())
+                slot_p, time_p, n_hist = slots.ctypes.data_as(C.POINTER(C.c_int32)), times.ctypes.data_as(dp), len(samples)
+            scratch = torch.zeros_like(field) if discard_rounds else None
+            for rnd in range(discard_rounds + 1):
+                last = rnd == discard_rounds
+                target = C.c_void_p((field if last else scratch).data_ptr())
+                # interpolateData: one uniform draw per sensor and round, jitter or not (abstract_sensor.hxx:316-318)
+                if hist is not None or rng is not None:
+                    self._lib.check(self._L.jm_block_sensor_delay(
+                        dtype, self.batch_size, e["n"], e["nf"], target, hist, slot_p, time_p, n_hist, rng,
+                        ptr(e["delay"]), ptr(e["jitter"]), e["order"], self._stream()))
+                if e["std"] is not None or (last and e["bias"] is not None):
                     self._lib.check(self._L.jm_block_sensor_noise(
-                        dtype, self.batch_size, e["n"], e["nf"], C.c_void_p(scratch.data_ptr()), rng,
-                        ptr(e["std"]), None, None, self._stream()))
-            self._lib.check(self._L.jm_block_sensor_noise(
-                dtype, self.batch_size, e["n"], e["nf"], C.c_void_p(self._fields[e["field"]].data_ptr()), rng,
-                ptr(e["std"]), ptr(e["bias"]), ptr(e["rot"]), self._stream()))
+                        dtype, self.batch_size, e["n"], e["nf"], target, rng, ptr(e["std"]),
+                        ptr(e["bias"]) if last else None, ptr(e["rot"]) if last else None, self._stream()))
 
     # ------------------------------------------------------------------ measurement helpers
     def enable_timing(self, enable: bool = True) -> None:

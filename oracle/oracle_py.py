@@ -82,6 +82,9 @@ def lib() -> C.CDLL:
         L.orc_seed_seq.argtypes = [C.c_uint32, C.c_int32, u32p]
         L.orc_sensor_rng_seed.argtypes = [u32p, C.c_int64, C.c_int32, u64p]
         L.orc_sensor_noise.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, u64p, pd, pd, pd]
+        L.orc_sensor_delay.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, pd, C.POINTER(C.c_int32), pd, C.c_int32,
+                                       u64p, pd, pd, C.c_int32]
+        L.orc_sensor_delay.restype = None
         for f in (L.orc_pcg32_stream, L.orc_uniform_stream, L.orc_normal_stream, L.orc_ziggurat_tables,
                   L.orc_seed_seq, L.orc_sensor_rng_seed, L.orc_sensor_noise):
             f.restype = None
@@ -292,3 +295,25 @@ def sensor_noise(data: np.ndarray, rng: np.ndarray, n_sensors: int, n_fields: in
     ptr = lambda a: None if a is None else a.ctypes.data_as(pd)  # noqa: E731
     lib().orc_sensor_noise(data.shape[1], n_sensors, n_fields, data.ctypes.data_as(pd),
                            None if rng is None else rng.ctypes.data_as(C.POINTER(C.c_uint64)), ptr(std), ptr(b), ptr(r))
+
+
+def sensor_delay(data: np.ndarray, hist, slot, times, rng, n_sensors: int, n_fields: int, delay=None, jitter=None,
+                 order: int = 0) -> None:
+    """`interpolateData` in place on `data` `[n_sensors * n_fields][B]` (float64) from the history ring
+    `hist` `[slots][n_sensors * n_fields][B]`; `slot` / `times` describe the samples, oldest first.
+    `rng` `[n_sensors][B]` uint64 takes one uniform draw per sensor (None: no generator)."""
+    assert data.dtype == np.float64 and data.flags.c_contiguous
+    pd = C.POINTER(C.c_double)
+    arr = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    ptr = lambda a: None if a is None else a.ctypes.data_as(pd)  # noqa: E731
+    dl, jt = arr(delay), arr(jitter)
+    if hist is not None:
+        assert hist.dtype == np.float64 and hist.flags.c_contiguous
+        sl = np.ascontiguousarray(slot, dtype=np.int32)
+        tm = np.ascontiguousarray(times, dtype=np.float64)
+        n_hist = len(sl)
+        hp, sp, tp = hist.ctypes.data_as(pd), sl.ctypes.data_as(C.POINTER(C.c_int32)), tm.ctypes.data_as(pd)
+    else:
+        n_hist, hp, sp, tp = 0, None, None, None
+    lib().orc_sensor_delay(data.shape[1], n_sensors, n_fields, data.ctypes.data_as(pd), hp, sp, tp, n_hist,
+                           None if rng is None else rng.ctypes.data_as(C.POINTER(C.c_uint64)), ptr(dl), ptr(jt), order)

@@ -198,4 +198,77 @@ void orc_sensor_noise(int64_t B, int32_t n_sensors, int32_t n_fields, double * d
             for (int32_t f = 0; f < n_fields; ++f) data[((size_t)s * n_fields + f) * B + l] = x[f];
         }
 }
+
+// interpolateData of every (sensor, lane) (abstract_sensor.hxx:305-429): data [n_sensors][n_fields][B] is
+// overwritten with the delayed measurement read from hist [slots][n_sensors * n_fields][B]; slot / times
+// [n_hist] name the ring slot and the time of the i-th oldest sample (the last one is the current time).
+// One `uniform(generator_, 0.0F, jitter)` draw per sensor and call; hist null: only that draw.
+void orc_sensor_delay(int64_t B, int32_t n_sensors, int32_t n_fields, double * data, const double * hist,
+                      const int32_t * slot, const double * times, int32_t n_hist, uint64_t * rng,
+                      const double * delay, const double * jitter, int32_t order)
+{
+    const int64_t rows = (int64_t)n_sensors * n_fields;
+    const double EPS = std::numeric_limits<double>::epsilon();
+    for (int32_t s = 0; s < n_sensors; ++s)
+        for (int64_t l = 0; l < B; ++l)
+        {
+            double d = delay ? delay[s] : 0.0;
+            const float jit = jitter ? static_cast<float>(jitter[s]) : 0.0F;
+            if (rng)
+            {
+                Pcg32 g(rng[(size_t)s * B + l]);
+                d += std::uniform_real_distribution<float>(0.0F, jit)(g);
+                rng[(size_t)s * B + l] = g.state();
+            }
+            if (!hist) continue;
+            double timeDesired = times[n_hist - 1] - d;
+            if (order == 0) timeDesired += 1e-10;  // STEPPER_MIN_TIMESTEP
+            std::ptrdiff_t idxLeft;
+            {
+                std::ptrdiff_t left = 0, right = n_hist - 1, mid = 0;
+                if (timeDesired >= times[n_hist - 1]) idxLeft = right;
+                else if (timeDesired < times[0]) idxLeft = -1;
+                else
+                {
+                    bool found = false;
+                    idxLeft = 0;
+                    while (left < right)
+                    {
+                        mid = (left + right) / 2;
+                        if (timeDesired < times[mid]) right = mid;
+                        else if (timeDesired > times[mid]) left = mid + 1;
+                        else { idxLeft = mid; found = true; break; }
+                    }
+                    if (!found) idxLeft = (timeDesired < times[mid]) ? mid - 1 : mid;
+                }
+            }
+            auto sample = [&](std::ptrdiff_t i, int32_t f) {
+                return hist[((size_t)slot[i] * rows + (size_t)s * n_fields + f) * B + l];
+            };
+            for (int32_t f = 0; f < n_fields; ++f)
+            {
+                double out;
+                if (timeDesired >= 0.0 && idxLeft + 1 < n_hist)
+                {
+                    if (idxLeft < 0) out = sample(0, f);  // the reference throws "No data old enough is available."
+                    else if (order == 0) out = sample(idxLeft, f);
+                    else
+                    {
+                        const double ratio = (timeDesired - times[idxLeft]) / (times[idxLeft + 1] - times[idxLeft]);
+                        const double prev = sample(idxLeft, f), next = sample(idxLeft + 1, f);
+                        out = prev + ratio * (next - prev);
+                    }
+                }
+                else if ((delay && delay[s] > EPS) || jit > EPS)
+                {
+                    std::ptrdiff_t index = n_hist - 1;
+                    for (std::ptrdiff_t i = 0; i < n_hist; ++i)
+                        if (times[i] > 0) { index = std::max<std::ptrdiff_t>(0, i - 1); break; }
+                    out = sample(index, f);
+                }
+                else out = sample(n_hist - 1, f);
+                data[((size_t)s * n_fields + f) * B + l] = out;
+            }
+        }
+}
 }

@@ -272,8 +272,10 @@ def test_control_flow_errors(gpu_device):
     eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri"}})   # the reference's default solver
     with pytest.raises(NotImplementedError):
         eng.set_options({"stepper": {"odeSolver": "runge_kutta_fehlberg"}})
-    with pytest.raises(NotImplementedError):
-        eng.set_options({"contacts": {"model": "constraint"}})
+    with pytest.raises(ValueError):
+        eng.set_options({"contacts": {"model": "impulse"}})   # engine.cc:2741-2747
+    eng.set_options({"contacts": {"model": "constraint"}})     # the reference's default contact model
+    eng.set_options({"contacts": {"model": "spring_damper"}})
     with pytest.raises(ValueError):
         eng.set_options({"stepper": {"tolRel": 0.0}})
 

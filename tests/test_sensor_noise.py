@@ -275,5 +275,128 @@ def test_engine_sensor_noise_at_sensor_breakpoints(gpu_device):
     st_ref = oracle_py.sensor_rng_seed(gs, n_imu)
     scratch = np.zeros((n_imu * 6, B))
     for _ in range(INIT_ITERATIONS + 1 + 3):
+        # measureDataAll = interpolateData (one uniform draw per sensor, jitter or not) then measureData
+        oracle_py.sensor_delay(scratch, None, None, None, st_ref, n_imu, 6)
         oracle_py.sensor_noise(scratch, st_ref, n_imu, 6, np.tile([0.01, 0.01, 0.01, 0.1, 0.1, 0.1], (n_imu, 1)), None, None)
     assert np.array_equal(rng["ImuSensor"].cpu().numpy().view(np.uint64), st_ref)
+
+
+# ------------------------------------------------------------------ delay and jitter (interpolateData)
+def _ramp_history(n, nf, B, times, slots, n_slots):
+    """history whose sample taken at time t holds the value 100 * t + row + 0.001 * lane in every row"""
+    hist = np.full((n_slots, n * nf, B), np.nan)
+    for sl, t in zip(slots, times):
+        hist[sl] = 100.0 * t + np.arange(n * nf)[:, None] + 1e-3 * np.arange(B)[None, :]
+    return hist
+
+
+def test_oracle_delay_zero_order_hold_and_linear_interpolation():
+    """abstract_sensor.hxx:305-429 on a ramp: ZOH returns the sample at or before t - delay (a delay equal
+    to a multiple of the period picks the sample exactly that old), order 1 interpolates, no delay returns
+    the newest sample, and before the history reaches back far enough the oldest sample is returned."""
+    n, nf, B, period = 2, 3, 5, 5e-3
+    times = [k * period for k in range(6)]           # 0 .. 25 ms, current time 25 ms
+    slots = [3, 4, 5, 0, 1, 2]                         # a rotated ring
+    hist = _ramp_history(n, nf, B, times, slots, 6)
+    base = np.arange(n * nf)[:, None] + 1e-3 * np.arange(B)[None, :]
+    data = np.zeros((n * nf, B))
+    oracle_py.sensor_delay(data, hist, slots, times, None, n, nf, delay=[2 * period, 0.012], order=0)
+    assert np.allclose(data[:nf], 100 * times[3] + base[:nf], atol=1e-12)      # exactly two periods old
+    assert np.allclose(data[nf:], 100 * times[2] + base[nf:], atol=1e-12)      # 25 - 12 = 13 ms -> sample at 10 ms
+    oracle_py.sensor_delay(data, hist, slots, times, None, n, nf, delay=[0.012, 0.0], order=1)
+    assert np.allclose(data[:nf], 100 * 0.013 + base[:nf], atol=1e-10)         # linear in t on a ramp
+    assert np.allclose(data[nf:], 100 * times[5] + base[nf:], atol=1e-12)      # no delay: newest
+    # early in the simulation: t = 5 ms, delay 12 ms -> desired time < 0 -> the oldest sample
+    oracle_py.sensor_delay(data, hist, slots[:2], times[:2], None, n, nf, delay=[0.012, 0.012], order=0)
+    assert np.allclose(data, 100 * times[0] + base, atol=1e-12)
+
+
+def test_oracle_jitter_takes_one_uniform_draw_per_sensor_and_call():
+    n, nf, B = 3, 2, 7
+    gs = np.arange(B, dtype=np.uint32) + 11
+    rng = oracle_py.sensor_rng_seed(gs, n)
+    ref = rng.copy()
+    data = np.zeros((n * nf, B))
+    oracle_py.sensor_delay(data, None, None, None, rng, n, nf, jitter=[0.0, 1e-3, 2e-3])
+    for s_ in range(n):
+        for l in range(B):
+            _, st = oracle_py.pcg32_stream(int(ref[s_, l]), 1, "uniform")
+            assert int(rng[s_, l]) == st
+    # with a history: the delay is delay + u * jitter, u from that draw
+    times = [0.0, 1e-3, 2e-3, 3e-3, 4e-3]
+    hist = _ramp_history(n, nf, B, times, range(5), 5)
+    rng2 = ref.copy()
+    oracle_py.sensor_delay(data, hist, range(5), times, rng2, n, nf, delay=[1e-3] * 3, jitter=[0.0, 1e-3, 2e-3], order=1)
+    base = np.arange(n * nf)[:, None] + 1e-3 * np.arange(B)[None, :]
+    for s_ in range(n):
+        for l in range(B):
+            u, _ = oracle_py.pcg32_stream(int(ref[s_, l]), 1, "uniform")
+            jit = np.float32(u[0]) * np.float32([0.0, 1e-3, 2e-3][s_])
+            want = 100 * (4e-3 - (1e-3 + float(jit))) + base[s_ * nf:(s_ + 1) * nf, l]
+            assert np.allclose(data[s_ * nf:(s_ + 1) * nf, l], want, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [0, 1])
+def test_hip_sensor_delay_matches_oracle(gpu_device, order):
+    import torch
+    from jiminy_amd import _abi, _lib, load_builtin
+    lib = _lib.load_for(load_builtin("cartpole"))
+    n, nf, B = 4, 6, 4099
+    rs = np.random.default_rng(5)
+    times = np.cumsum(np.r_[0.0, rs.uniform(0.5e-3, 2e-3, 11)])
+    slots = list(rs.permutation(14)[:12])
+    hist = np.zeros((14, n * nf, B))
+    for sl in slots:
+        hist[sl] = rs.normal(size=(n * nf, B))
+    delay, jitter = np.array([0.0, 1.5e-3, 4e-3, 0.05]), np.array([0.0, 1e-3, 0.0, 2e-3])
+    rng = oracle_py.sensor_rng_seed(np.arange(B, dtype=np.uint32) * 7 + 1, n)
+    ref, st_ref = np.zeros((n * nf, B)), rng.copy()
+    oracle_py.sensor_delay(ref, hist, slots, times, st_ref, n, nf, delay=delay, jitter=jitter, order=order)
+    dev = torch.zeros((n * nf, B), dtype=torch.float64, device=gpu_device)
+    hist_dev = torch.from_numpy(hist).to(gpu_device)
+    st_dev = torch.from_numpy(rng.view(np.int64)).to(gpu_device)
+    sl = np.ascontiguousarray(slots, dtype=np.int32)
+    dp = C.POINTER(C.c_double)
+    lib.check(lib.L.jm_block_sensor_delay(
+        _abi.JM_F64, B, n, nf, C.c_void_p(dev.data_ptr()), C.c_void_p(hist_dev.data_ptr()),
+        sl.ctypes.data_as(C.POINTER(C.c_int32)), np.ascontiguousarray(times).ctypes.data_as(dp), len(slots),
+        C.c_void_p(st_dev.data_ptr()), delay.ctypes.data_as(dp), jitter.ctypes.data_as(dp), order, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(st_dev.cpu().numpy().view(np.uint64), st_ref)          # integer stream: bit exact
+    got = dev.cpu().numpy()
+    if order == 0:
+        assert np.array_equal(got, ref)                                            # a copy of one sample
+    else:
+        assert np.abs(got - ref).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_engine_encoder_delay_reads_the_past(gpu_device):
+    """Engine level: an encoder delayed by 3 ms with 1 ms sensor refreshes returns the raw reading taken three
+    refreshes earlier (the oldest one while the history is shorter), the physics is untouched."""
+    import torch
+    from jiminy_amd.engine import BatchedEngine
+    from tests import robots
+    model = robots.pendulum()
+    B, dt = 8, 1e-3
+
+    def run(delay):
+        eng = BatchedEngine(model, B, dtype=torch.float64)
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                     "sensorsUpdatePeriod": dt}})
+        if delay:
+            eng.set_sensor_options("EncoderSensor", delay=delay)
+        eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
+        q0 = torch.linspace(0.1, 0.8, B, dtype=torch.float64)[None, :]
+        eng.start(q0, torch.zeros((1, B), dtype=torch.float64))
+        out = [eng.field("encoder").clone()]
+        for _ in range(8):
+            eng.step(dt)
+            out.append(eng.field("encoder").clone())
+        return out, eng.field("q").clone()
+    raw, q_raw = run(0.0)
+    late, q_late = run(3e-3)
+    assert torch.equal(q_raw, q_late)
+    for k in range(9):
+        assert torch.equal(late[k], raw[max(k - 3, 0)]), k
