@@ -169,7 +169,10 @@ enum {
                               (AbstractConstraintBase::isEnabled_, JointConstraint::isReversed_) */
     JM_F_CON_DATA = 19,    /* [n_data_rows] in/out: JointConstraint::configurationRef_ per bounded joint, then
                               the Lagrange multipliers `lambda_` of every constraint row (PGS warm start) */
-    JM_F_COUNT = 20
+    JM_F_FRICTION = 20,    /* [1] in, optional: contacts.friction of every lane (domain randomisation of the ground
+                              friction, gym_jiminy envs/locomotion.py:257-262); constraint contact model only,
+                              unbound = the batch-wide contacts.friction option */
+    JM_F_COUNT = 21
 };
 
 /* ---- `contacts.model = "constraint"` (the reference's default contact model, engine.h:273) and the

@@ -288,7 +288,7 @@ def write_header(model: CompiledModel) -> str:
 def _sources() -> List[str]:
     return [os.path.join(CSRC, n) for n in ("jm_lib.cpp", "jm_kernels.h", "jm_math.h", "jm_quad.h",
                                             "jm_pack.h", "jm_adaptive.h", "jm_blocks.h", "jm_random.h",
-                                            "jm_constraint.h")] + \
+                                            "jm_constraint.h", "jm_lib_constraint.cpp")] + \
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 
@@ -313,14 +313,27 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
         raise RuntimeError(
             f"hipcc not found ({HIPCC}); cannot build the HIP library for topology "
             f"{model.topology_hash()} and no prebuilt {lib} exists")
-    cmd = [HIPCC, f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip", os.path.join(CSRC, "jm_lib.cpp"),
-           f"-DJM_TOPO_HEADER=\"{hdr}\"", "-o", lib + ".tmp",
-           "-Wno-unused-value", "-ffp-contract=fast"]
-    cmd += list(BUILD_VARIANTS[v])
-    cmd += extra_flags or []
+    # two translation units compiled in parallel (the constraint-model kernel is the longest single compile
+    # of a large topology), then linked into one shared library
+    common = [f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+              f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"]
+    common += list(BUILD_VARIANTS[v])
+    common += extra_flags or []
+    objs = [lib + ".main.o", lib + ".con.o"]
+    cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]],
+            [HIPCC] + common + ["-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[1]]]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        for c in cmds:
+            print(" ".join(c))
+    procs = [subprocess.Popen(c) for c in cmds]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise subprocess.CalledProcessError(next(r for r in rcs if r), cmds[[bool(r) for r in rcs].index(True)])
+    link = [HIPCC, f"--offload-arch={OFFLOAD_ARCH}", "-fPIC", "-shared", *objs, "-o", lib + ".tmp"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    for o in objs:
+        os.remove(o)
     os.replace(lib + ".tmp", lib)
     return lib

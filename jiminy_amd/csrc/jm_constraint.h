@@ -47,6 +47,7 @@ template<class T> struct ConArgs
     int32_t * flags;  // [NF][B]  bit 0 enabled, bit 1 reversed
     T * data;         // [ND][B]  reference configuration per bounded joint, then lambda per row
     T * ws;           // [WTOTAL][B]
+    const T * friction;  // [B] per-lane contacts.friction, or null (lane-uniform option)
     T kp, kd;         // Baumgarte gains of contacts.stabilizationFreq (abstract_constraint.cc:88-98)
     T torsion, reg, tol_abs, tol_rel;
     int iter_max;
@@ -477,7 +478,8 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     auto dat = [&](int r) -> T & { return C.data[(size_t)r * B + lane]; };
     auto lam = [&](int r) -> T & { return C.data[(size_t)(R::LAM + r) * B + lane]; };
     auto ws = [&](int r) -> T & { return C.ws[(size_t)r * B + lane]; };
-    const T eps_tr = P[L::OPT + 9], friction = P[L::OPT + 8];
+    const T eps_tr = P[L::OPT + 9];
+    const T friction = C.friction ? C.friction[lane] : P[L::OPT + 8];
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
 
     // ---- constraint switching

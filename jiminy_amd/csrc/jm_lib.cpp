@@ -31,6 +31,14 @@
 
 #define JM_ABI_VERSION 1
 
+#ifdef JM_SPLIT_CONSTRAINT
+// the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
+namespace jm
+{
+extern template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
+}
+#endif
+
 namespace
 {
 thread_local std::string g_last_error;
@@ -166,6 +174,11 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             C.flags = b->ov_flags ? b->ov_flags : (int32_t *)b->field[JM_F_CON_FLAGS];
             C.data = b->ov_data ? (T *)b->ov_data : (T *)b->field[JM_F_CON_DATA];
             C.ws = b->ov_ws ? (T *)b->ov_ws : (T *)b->field[JM_F_WORKSPACE];
+            // per-lane friction: bound field, except in the compact batches of the adaptive stepper (lane order
+            // differs there: not supported together)
+            C.friction = b->ov_flags ? nullptr : (const T *)b->field[JM_F_FRICTION];
+            if (b->ov_flags && b->field[JM_F_FRICTION])
+                return fail(JM_ENOTIMPL, "per-lane friction is not available with the adaptive stepper");
             const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
             C.kp = (T)(omega * omega);
             C.kd = (T)(2.0 * omega);

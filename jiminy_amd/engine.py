@@ -523,6 +523,24 @@ class BatchedEngine:
             for name in ("con_flags", "con_data", "workspace"):
                 self._bind(name)
 
+    def set_lane_friction(self, friction: Optional[Any]) -> None:
+        """Ground friction coefficient of every lane (`contacts.friction` randomised per environment as
+        `WalkerJiminyEnv._setup` does per episode, gym_jiminy envs/locomotion.py:257-262).  `(B,)` values, or
+        None to go back to the batch-wide option.  Constraint contact model, fixed-step solvers."""
+        if friction is None:
+            self._fields.pop("friction", None)
+            self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["friction"], None))
+            return
+        if self._options["contacts"]["model"] != "constraint":
+            raise NotImplementedError("per-lane friction needs contacts.model='constraint'")
+        f = torch.as_tensor(friction, dtype=self.dtype, device=self.device).reshape(1, -1)
+        if f.shape[1] != self.batch_size or bool((f < 0).any()):
+            raise ValueError("friction must hold one non-negative value per lane")
+        if "friction" not in self._fields:
+            self._fields["friction"] = torch.empty((1, self.batch_size), dtype=self.dtype, device=self.device)
+            self._bind("friction")
+        self._fields["friction"].copy_(f)
+
     # ------------------------------------------------------------------ state access
     @property
     def is_simulation_running(self) -> bool:

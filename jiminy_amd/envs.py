@@ -38,8 +38,14 @@ class VecJiminyEnv:
     def __init__(self, model: CompiledModel, num_envs: int, step_dt: float,
                  engine_options: Optional[Dict[str, Dict[str, Any]]] = None,
                  dtype: torch.dtype = torch.float64, device: Optional[torch.device] = None,
-                 simulation_duration_max: float = 86400.0, auto_reset: bool = True) -> None:
+                 simulation_duration_max: float = 86400.0, auto_reset: bool = True,
+                 std_ratio: Optional[Dict[str, float]] = None) -> None:
         self.model = model
+        # ≙ `WalkerJiminyEnv(std_ratio=...)` (envs/locomotion.py:100-135): scale of the episode-wise
+        # randomisation.  Supported keys: 'ground' (friction coefficient of every environment, constraint
+        # contact model) and 'sensors' (white noise, bias, delay and jitter of every sensor type, drawn once per
+        # `reset()` for the whole batch: the sensor options are lane-uniform kernel parameters)
+        self.std_ratio = dict(std_ratio or {})
         self.num_envs = int(num_envs)
         self.step_dt = float(step_dt)
         self.engine = BatchedEngine(model, num_envs, dtype=dtype, device=device)
@@ -117,6 +123,8 @@ class VecJiminyEnv:
         self._q0, self._v0 = q, v
         self.engine.field("command").zero_()
         self._on_reset(None)
+        self._randomise_ground(None)
+        self._randomise_sensors()
         self.engine.start(q, v)
         self.num_steps.zero_()
         self._t0.zero_()
@@ -149,9 +157,62 @@ class VecJiminyEnv:
     def reset_lanes(self, lane_mask: torch.Tensor) -> None:
         q, v = self._sample_state(self.num_envs)
         self._on_reset(lane_mask)
+        self._randomise_ground(lane_mask)
         self.engine.reset_lanes(lane_mask, q, v)
         self.num_steps[lane_mask] = 0
         self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
+
+    def _randomise_ground(self, lane_mask: Optional[torch.Tensor]) -> None:
+        """Ground friction of the environments being reset, ≙ `sample(*GROUND_FRICTION_RANGE,
+        scale=std_ratio['ground'], enable_log_scale=True)` (envs/locomotion.py:28, 257-262 with
+        utils/misc.py:178-219: 10 ** (mean + dev * U(-1, 1)), mean = 1.1, dev = 0.9 * scale)."""
+        scale = float(self.std_ratio.get("ground", 0.0))
+        if scale <= 0.0:
+            return
+        lo, hi = 0.2, 2.0
+        u = torch.rand(self.num_envs, generator=self._generator, dtype=torch.float64) * 2.0 - 1.0
+        mu = (10.0 ** (0.5 * (lo + hi) + 0.5 * scale * (hi - lo) * u)).to(self.dtype).to(self.device)
+        if lane_mask is not None and "friction" in self.engine._fields:
+            mu = torch.where(lane_mask, mu, self.engine.field("friction")[0])
+        self.engine.set_lane_friction(mu)
+
+    # scales of envs/locomotion.py:40-61 (delay [s]; noise and bias per field)
+    SENSOR_DELAY_SCALE = {"EncoderSensor": 3.0e-3, "EffortSensor": 0.0, "ContactSensor": 0.0, "ForceSensor": 0.0,
+                          "ImuSensor": 0.0}
+    SENSOR_NOISE_SCALE = {"EncoderSensor": (0.0, 0.02), "EffortSensor": (10.0,), "ContactSensor": (2.0, 2.0, 2.0),
+                          "ForceSensor": (2.0, 2.0, 2.0, 10.0, 10.0, 10.0),
+                          "ImuSensor": (0.0, 0.0, 0.0, 0.01, 0.01, 0.01, 0.2, 0.2, 0.2)}
+
+    def _randomise_sensors(self) -> None:
+        """Sensor noise, bias, delay and jitter, ≙ envs/locomotion.py:264-288: for every sensor
+        `delay, jitter ~ U(0, s * SENSOR_DELAY_SCALE)`, `bias, noiseStd ~ s * SENSOR_NOISE_SCALE * U(-1, 1)`
+        (the reference scales both with the *noise* table; a negative standard deviation is its own business:
+        the magnitude is used here).  Called by `reset()` while no simulation is running."""
+        scale = float(self.std_ratio.get("sensors", 0.0))
+        if scale <= 0.0:
+            return
+        rg = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._generator)))
+        any_rng = False
+        for stype, table in self.SENSOR_NOISE_SCALE.items():
+            n = len(self.model.sensors.get(stype, []))
+            if n == 0:
+                continue
+            sc = scale * np.asarray(table)
+            nf = self.engine._SENSOR_FIELDS[stype][1]
+            nb = 9 if stype == "ImuSensor" else nf
+            bias = rg.uniform(-1.0, 1.0, (n, len(sc))) * sc
+            std = np.abs(rg.uniform(-1.0, 1.0, (n, len(sc))) * sc)
+            if stype == "ImuSensor":
+                # 9 bias entries (rotation, gyro, accel) but 6 measured fields: noise on the last 6
+                std = std[:, 3:]
+            else:
+                bias, std = bias[:, :nb], std[:, :nf]
+            dmax = scale * self.SENSOR_DELAY_SCALE[stype]
+            delay, jitter = rg.uniform(0.0, dmax, n), rg.uniform(0.0, dmax, n)
+            self.engine.set_sensor_options(stype, noise_std=std, bias=bias, delay=delay, jitter=jitter)
+            any_rng = True
+        if any_rng:
+            self.engine.seed_sensors(int(rg.integers(0, 2 ** 31 - 1)))
 
     def close(self) -> None:
         self.engine.stop()

@@ -463,6 +463,7 @@ struct Engine
     // optional per-lane storage of the constraint state for the batch drivers ([rows][B])
     int32_t * con_flags = nullptr;
     double * con_data = nullptr;
+    const double * lane_friction = nullptr;  // [B] contacts.friction of every lane, or null
 };
 
 V3 joint_axis(const Model & m, int j)
@@ -1934,6 +1935,7 @@ void orc_engine_bind_constraints(void * h, int32_t * flags, double * data)
     e.con_flags = flags;
     e.con_data = data;
 }
+void orc_engine_bind_friction(void * h, const double * friction) { static_cast<Engine *>(h)->lane_friction = friction; }
 int orc_engine_constraint_counts(void * h, int * n_bounds, int * n_contacts)
 {
     Engine & e = *static_cast<Engine *>(h);
@@ -2025,6 +2027,7 @@ struct orc_batch_io
 static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
     const int64_t B = io.B;
+    if (e.lane_friction) e.opt.contact_friction = e.lane_friction[l];
     if (e.con_flags && e.con_data)
     {
         if (e.uInternal.empty()) init_constraints(e);

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         L.orc_engine_set_options.argtypes = [C.c_void_p, C.POINTER(_abi.Options)]
         L.orc_engine_set_constraint_options.argtypes = [C.c_void_p, C.POINTER(_abi.ConstraintOptions)]
         L.orc_engine_bind_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_engine_bind_friction.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_bind_friction.restype = None
         L.orc_engine_constraint_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_engine_constraint_counts.restype = C.c_int
         pd = C.POINTER(C.c_double)
@@ -140,6 +142,11 @@ class OracleEngine:
         assert flags.flags.c_contiguous and data.flags.c_contiguous
         self._con = (flags, data)
         self._L.orc_engine_bind_constraints(self._h, flags.ctypes.data, data.ctypes.data)
+
+    def bind_friction(self, friction: Optional[np.ndarray]) -> None:
+        """Per-lane `contacts.friction` of the batch drivers (`[B]` float64), None = the engine option."""
+        self._friction = None if friction is None else np.ascontiguousarray(friction, dtype=np.float64)
+        self._L.orc_engine_bind_friction(self._h, None if friction is None else self._friction.ctypes.data)
 
     @property
     def pgs_iterations(self) -> int:

@@ -95,6 +95,8 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
 static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
 static void * g_con_flags = nullptr;
 static void * g_con_data = nullptr;
+static void * g_friction = nullptr;
+extern "C" void emu_set_friction(void * friction) { g_friction = friction; }
 extern "C" void emu_set_constraints(const jm_constraint_options * o, void * flags, void * data)
 {
     g_copt = *o;
@@ -143,6 +145,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         std::vector<T> wsp((size_t)(jm::ConRows<Topo>::WTOTAL + 1) * io->B, (T)std::nan(""));
         jm::ConArgs<T> C;
         C.flags = (int32_t *)g_con_flags; C.data = (T *)g_con_data; C.ws = wsp.data();
+        C.friction = (const T *)g_friction;
         const double omega = 2.0 * 3.14159265358979323846 * g_copt.stabilization_freq;
         C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
         C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;

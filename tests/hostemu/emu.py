@@ -40,6 +40,8 @@ def _lib(model: CompiledModel) -> C.CDLL:
                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
     L.emu_set_constraints.argtypes = [C.POINTER(_abi.ConstraintOptions), C.c_void_p, C.c_void_p]
     L.emu_set_constraints.restype = None
+    L.emu_set_friction.argtypes = [C.c_void_p]
+    L.emu_set_friction.restype = None
     _CACHE[h] = L
     return L
 
@@ -56,6 +58,8 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     if constraint_options is not None:
         co = _abi.make_constraint_options(**constraint_options)
         L.emu_set_constraints(C.byref(co), arrays["con_flags"].ctypes.data, arrays["con_data"].ctypes.data)
+        fr = arrays.get("friction")
+        L.emu_set_friction(fr.ctypes.data if fr is not None else None)
     else:
         co = _abi.make_constraint_options(model="spring_damper")
         L.emu_set_constraints(C.byref(co), None, None)

@@ -477,3 +477,76 @@ def test_gpu_constraint_model_under_the_adaptive_stepper(gpu_device):
     # the robots are still standing on the ground
     fz = eng.field("contact_forces").reshape(model.ncontacts, 6, B)[:, 2].sum(0).cpu().numpy()
     assert (fz[ok] > 0).mean() > 0.9
+
+
+def test_per_lane_friction_on_the_host():
+    """`JM_F_FRICTION`: every lane solves its friction cones with its own coefficient (ground-friction
+    randomisation of the reference's locomotion envs): kernel sources on the host vs the oracle, and the
+    cone bound |lambda_t| <= mu_lane * lambda_n."""
+    model = load_builtin("anymal")
+    B = 12
+    ref, got = _pair(model, B, seed=9)
+    mu = np.linspace(0.05, 1.5, B)
+    ref["friction"] = mu.copy()
+    got["friction"] = mu.copy()
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT)
+    for _ in range(3):
+        kw = dict(solver="euler_explicit", dt=5e-4, n_substeps=1, command_changed=True)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
+        emu.run(model, got, "step", constraint_options=TIGHT, **kw)
+    ref.pop("friction"), got.pop("friction")
+    _check(got, ref, 1e-7, "per-lane friction")
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    lam = got["con_data"][2 * nb:].reshape(-1, 4, B)
+    assert (np.hypot(lam[:, 0], lam[:, 1]) <= mu[None, :] * lam[:, 2] * (1 + 1e-9) + 1e-9).all()
+    assert (lam[:, 2] > 0).any()
+
+
+@pytest.mark.gpu
+def test_gpu_per_lane_friction_and_env_ground_randomisation(gpu_device):
+    """Device build: per-lane friction against the oracle, then the ANYmal environment with the reference's
+    shipped contact model and `std_ratio={'ground': ...}`: every environment gets its own friction
+    coefficient at reset, the multipliers stay inside each lane's own cone."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.envs import make_anymal_env
+    model = load_builtin("anymal")
+    B = 64
+    ref, _ = _pair(model, B, seed=15)
+    mu = np.linspace(0.05, 1.8, B)
+    ref["friction"] = mu.copy()
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    dt = 5e-4
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt, "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]},
+                     "contacts": {"model": "constraint"}})
+    eng.set_lane_friction(mu)
+    eng.set_command(torch.from_numpy(ref["command"]))
+    eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    for _ in range(3):
+        eng.step(dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="euler_explicit", dt=dt, n_substeps=1,
+                     command_changed=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
+    for k in ("q", "v", "a", "con_data"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-5, k
+    with pytest.raises(NotImplementedError):
+        spring = BatchedEngine(model, 4, dtype=torch.float64, device=gpu_device)
+        spring.set_lane_friction(np.ones(4))
+
+    env = make_anymal_env(256, device=gpu_device, contact_model="constraint", std_ratio={"ground": 0.3})
+    env.reset(seed=5)
+    fr = env.engine.field("friction")[0].clone()
+    lo, hi = 10 ** (1.1 - 0.27), 10 ** (1.1 + 0.27)
+    assert float(fr.min()) >= lo - 1e-9 and float(fr.max()) <= hi + 1e-9 and float(fr.std()) > 0.5
+    action = torch.zeros((256, model.nmotors), dtype=torch.float64, device=gpu_device)
+    for _ in range(2):
+        env.step(action)
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    lam = env.engine.field("con_data")[2 * nb:].reshape(-1, 4, 256)
+    assert bool((torch.hypot(lam[:, 0], lam[:, 1]) <= fr[None, :] * lam[:, 2] * (1 + 1e-9) + 1e-9).all())
+    assert bool((lam[:, 2] > 0).any())

@@ -162,3 +162,30 @@ def test_ppo_learner_on_the_device_resident_pipeline(gpu_device):
         assert all(v.is_cuda for v in buf.values())
         assert np.isfinite(stats["loss"]) and bool(torch.isfinite(buf["adv"]).all())
     env.close()
+
+
+def test_env_sensor_randomisation(gpu_device):
+    """`std_ratio={'sensors': s}` (≙ WalkerJiminyEnv, envs/locomotion.py:264-288): noise, bias, delay and
+    jitter are configured for every sensor type at reset; the physics is untouched, the measurements are not,
+    and a given seed reproduces the same episode."""
+    def run(std_ratio, seed=7):
+        env = make_anymal_env(32, device=gpu_device, std_ratio=std_ratio)
+        env.reset(seed=seed)
+        action = torch.zeros((32, env.model.nmotors), dtype=torch.float64, device=gpu_device)
+        for _ in range(2):
+            env.step(action)
+        out = {k: env.engine.field(k).clone() for k in ("q", "encoder", "imu", "effort")}
+        opts = {k: (None if v["delay"] is None else v["delay"].copy()) for k, v in env.engine._sensor_noise.items()}
+        env.close()
+        return out, opts
+    clean, _ = run(None)
+    noisy, opts = run({"sensors": 1.0})
+    again, _ = run({"sensors": 1.0})
+    assert set(opts) >= {"EncoderSensor", "ImuSensor", "EffortSensor"}
+    assert opts["EncoderSensor"] is not None and 0.0 <= opts["EncoderSensor"].max() <= 3.0e-3
+    assert opts["ImuSensor"] is None                      # SENSOR_DELAY_SCALE[ImuSensor] = 0
+    # (the PD controller reads the measured encoders, so the motion itself differs, as in the reference)
+    for k in ("encoder", "imu", "effort"):
+        assert torch.isfinite(noisy[k]).all()
+        assert torch.equal(noisy[k], again[k]), k
+    assert not torch.equal(clean["imu"], noisy["imu"]) and not torch.equal(clean["effort"], noisy["effort"])
