@@ -142,6 +142,12 @@ def main() -> None:
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--minibatches", type=int, default=4)
+    ap.add_argument("--contact-model", default="spring_damper", choices=["spring_damper", "constraint"],
+                    help="'constraint' = the contact model of the reference's shipped ANYmal options")
+    ap.add_argument("--std-ratio-ground", type=float, default=0.0,
+                    help="ground-friction randomisation per environment (constraint contact model)")
+    ap.add_argument("--std-ratio-sensors", type=float, default=0.0,
+                    help="sensor noise / bias / delay randomisation (drawn per reset for the batch)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,7 +157,8 @@ def main() -> None:
         dist.init_process_group("nccl")     # RCCL
     rank = dist.get_rank() if world > 1 else 0
     from jiminy_amd.envs import make_anymal_env
-    env = make_anymal_env(args.envs, device=dev)
+    std_ratio = {k: v for k, v in (("ground", args.std_ratio_ground), ("sensors", args.std_ratio_sensors)) if v > 0}
+    env = make_anymal_env(args.envs, device=dev, contact_model=args.contact_model, std_ratio=std_ratio or None)
     obs_d, _ = env.reset(seed=rank)
     obs = flatten_anymal_obs(obs_d)
     ppo = PPO(obs.shape[1], env.model.nmotors, dev, epochs=args.epochs, minibatches=args.minibatches)

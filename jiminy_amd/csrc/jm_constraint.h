@@ -35,6 +35,10 @@
 #ifndef JM_CON_REBUILD
 #define JM_CON_REBUILD 1  // rebuild liMi in the bias-free solves instead of reading it back from scratch
 #endif
+#ifndef JM_CON_PGS_REG
+#define JM_CON_PGS_REG 0   // robots with <= 32 constraint rows: PGS vectors in registers, fully unrolled sweeps
+                          // (measured slower: every lane pays for all NR x NR predicated slots, + 7 kB of scratch)
+#endif
 #ifndef JM_CON_XLDS
 #define JM_CON_XLDS 0   // packed multipliers in LDS during the PGS solve (faster solve, but the extra 14 kB
                         // per block cost one resident wave per CU: measured slower on warm-started workloads)
@@ -450,6 +454,125 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
     return false;
 }
 
+// The same solve for robots with at most 32 constraint rows (ANYmal: 28): the sweeps are unrolled on
+// compile-time packed indices, so that x, b, y live in registers (no store -> load round trip through memory
+// between two row updates of the Gauss-Seidel chain) and every delassus entry sits at a constant offset: the
+// loads of the next rows do not depend on the multipliers being updated and are issued ahead of them.
+// Rows beyond the lane's m and rows of another block are skipped by run-time predicates; the arithmetic and
+// its order are those of pgs_solve_packed.
+template<class T, class Tp, class WS>
+JM_DEV bool pgs_solve_regs(const ConArgs<T> & C, T friction, int m, int nb, WS && ws)
+{
+    using R = ConRows<Tp>;
+    constexpr int NR = R::NR;
+    const T eps = Eps<T>::eps;
+    T x[NR], bb[NR], y[NR], yp[NR];
+    static_for<0, NR>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        x[p] = p < m ? ws(R::WX + p) : T(0);
+        bb[p] = p < m ? ws(R::WB + p) : T(0);
+        y[p] = T(0);
+    });
+    auto col_dot = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        T s = T(0);
+        static_for<0, NR>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const T a = k < m ? ws(R::WA + k * NR + i) : T(0);
+            s += a * x[k];
+        });
+        return s;
+    };
+    const bool torsion_zero = C.torsion < eps, friction_zero = friction < eps;
+    const unsigned iter_max = (unsigned)C.iter_max;
+    bool converged = false;
+#pragma nounroll
+    for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
+    {
+        static_for<0, NR>([&](auto pc) { yp[decltype(pc)::value] = y[decltype(pc)::value]; });
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        // the three block passes of the reference (0: bounds + normals, 1: torsion, 2: friction cones) as a
+        // run-time loop around ONE unrolled visit of the rows: a row acts in the pass its kind belongs to.
+        // The residual of the first row of a friction pair is parked until its partner has its own (both
+        // are taken before either multiplier moves, constraint_solvers.cc:175-195).
+#pragma nounroll
+        for (int blk = 0; blk < 3; ++blk)
+        {
+            T y0_pair = T(0);
+            static_for<0, NR>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                const int dof = (p - nb) & 3;  // 0..3 = x, y, z (normal), torsion for the rows of a contact
+                const bool bound = p < nb;
+                const int kind = bound ? 0 : (dof == 2 ? 0 : (dof == 3 ? 1 : 2));
+                if (p < m && kind == blk)
+                {
+                    if (blk == 1 && torsion_zero) x[p] = x[p] * T(0);
+                    else if (blk == 2 && friction_zero) x[p] = x[p] * T(0);
+                    else
+                    {
+                        const T yy = bb[p] - col_dot(pc);
+                        y[p] = yy;
+                        const T app = ws(R::WA + p * NR + p);
+                        if (blk == 0) x[p] = fmax_(x[p] + w * yy / app, T(0));
+                        else if (blk == 1)
+                        {
+                            if constexpr (p >= 1)
+                            {
+                                const T thr = C.torsion * x[p - 1];
+                                x[p] = clamp_(x[p] + w * yy / app, -thr, thr);
+                            }
+                        }
+                        else if (dof == 0) y0_pair = yy;
+                        else
+                        {
+                            if constexpr (p >= 1 && p + 1 < NR)
+                            {
+                                const T a00 = ws(R::WA + (p - 1) * NR + p - 1);
+                                const T a_max = app > a00 ? app : a00;
+                                T e0 = x[p - 1] + w * y0_pair / a_max;
+                                T e1 = x[p] + w * yy / a_max;
+                                const T thr = friction * x[p + 1];
+                                const T n2 = e0 * e0 + e1 * e1;
+                                if (n2 > thr * thr)
+                                {
+                                    const T scale = thr / sqrt_(n2);
+                                    e0 *= scale;
+                                    e1 *= scale;
+                                }
+                                x[p - 1] = e0;
+                                x[p] = e1;
+                            }
+                        }
+                    }
+                }
+            });
+        }
+        T ymax = T(0);
+        static_for<0, NR>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            if (p < m) ymax = fmax_(ymax, cabs_(y[p]));
+        });
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        bool done = true;
+        static_for<0, NR>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            if (p < m) done &= cabs_(y[p] - yp[p]) < tol;
+        });
+        converged = done;
+    }
+    static_for<0, NR>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if (p < m) ws(R::WX + p) = x[p];
+    });
+    return converged;
+}
+
 template<class T, class Tp, class CA>
 JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
                              long long lane, long long B, int start_passes)
@@ -682,7 +805,8 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             }
             else
             {
-                ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
+                if constexpr (JM_CON_PGS_REG && NR <= 32) ok = pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
+            else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
                 if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
                 else w.status |= JM_LANE_SOLVER_FAILURE;
             }

@@ -21,6 +21,13 @@ fi
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"; tail -c 600 "$OUT/bench.json"
 
+# secondary workloads (one JSON line each): adaptive solver, constraint contact model, environment pipelines
+timeout 300 python tools/bench_adaptive.py --intervals 5 > "$OUT/adaptive.json" 2>/dev/null
+timeout 600 python bench.py --contact-model constraint --steps 40 --warmup 5 > "$OUT/bench_constraint.json" 2>/dev/null
+timeout 300 python tools/bench_env.py --envs 65536 --steps 10 --warmup 2 > "$OUT/env_spring.json" 2>/dev/null
+timeout 300 python tools/bench_env.py --envs 65536 --steps 5 --warmup 2 --contact-model constraint --zero-action > "$OUT/env_constraint.json" 2>/dev/null
+head -c 400 "$OUT/adaptive.json" "$OUT/bench_constraint.json" "$OUT/env_spring.json" "$OUT/env_constraint.json"
+
 BENCH="python $REPO/bench.py --steps 60 --warmup 5 --no-cpu-baseline ${BENCH_EXTRA:-}"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
