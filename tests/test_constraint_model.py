@@ -550,3 +550,78 @@ def test_gpu_per_lane_friction_and_env_ground_randomisation(gpu_device):
     lam = env.engine.field("con_data")[2 * nb:].reshape(-1, 4, 256)
     assert bool((torch.hypot(lam[:, 0], lam[:, 1]) <= fr[None, :] * lam[:, 2] * (1 + 1e-9) + 1e-9).all())
     assert bool((lam[:, 2] > 0).any())
+
+
+@pytest.mark.gpu
+def test_gpu_constraint_model_full_size_replicas_and_repeatability(gpu_device):
+    """BASELINE size (ANYmal, B = 65 536) with the constraint model, through size-independent properties: the
+    batch is 256 replicas of one seeded 256-lane block, so every replica must equal the first one bit for bit
+    wherever it sits in the grid (state, multipliers, flags), the first block must match the oracle, and a second
+    run from the same state reproduces the first bit for bit (reference pin: test_pipeline_control.py:315-330)."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    blk, reps, dt, steps = 256, 256, 1e-3, 3
+    B = blk * reps
+    st = sample_standing_states(model, blk, seed=17)
+    q = torch.from_numpy(np.tile(st["q"], (1, reps)))
+    v = torch.from_numpy(np.tile(st["v"], (1, reps)))
+    cmd = torch.from_numpy(np.tile(st["command"], (1, reps)))
+    ref = alloc_soa(model, blk)
+    alloc_constraint_state(model, ref, blk)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    oracle_batch(model, ref, "start", constraint_options={})
+    for _ in range(steps):
+        oracle_batch(model, ref, "step", constraint_options={}, solver="euler_explicit", dt=dt, n_substeps=1,
+                     command_changed=True)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt}, "contacts": {"model": "constraint"}})
+    names = ("q", "v", "a", "imu", "contact_forces", "con_data", "con_flags")
+    runs = []
+    for _ in range(2):
+        eng.set_command(cmd)
+        eng.start(q, v)
+        for _ in range(steps):
+            eng.step(dt)
+        torch.cuda.synchronize()
+        runs.append({k: eng.field(k).clone() for k in names})
+        eng.stop()
+    for k in names:
+        x = runs[0][k]
+        first = x[:, :blk]
+        assert torch.equal(x.view(x.shape[0], reps, blk), first[:, None, :].expand(-1, reps, -1)), k
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    assert np.array_equal(runs[0]["con_flags"][:, :blk].cpu().numpy(), ref["con_flags"])
+    # default PGS tolerances: same iterates, same stopping sweep on both sides up to rare ties
+    for k in ("q", "v", "a", "con_data"):
+        assert rel_err(runs[0][k][:, :blk].cpu().numpy(), ref[k]) < 1e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 65])
+def test_gpu_constraint_model_ragged_and_tiny_batches(gpu_device, B):
+    """Batch sizes that do not fill a wave: tail lanes computed, padding lanes silent."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    ref, _ = _pair(model, B, seed=23)
+    dt = 1e-3
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt, "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]},
+                     "contacts": {"model": "constraint"}})
+    eng.set_command(torch.from_numpy(ref["command"]))
+    eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    for _ in range(2):
+        eng.step(dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt, n_substeps=1,
+                     command_changed=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
+    for k in ("q", "v", "a", "con_data", "imu"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-5, k
