@@ -689,7 +689,9 @@ class BatchedEngine:
         stream = self._stream()
         attempts = C.c_int32(0)
         self.adaptive_attempts = 0
-        constraint_model = self._options["contacts"]["model"] == "constraint"
+        # (only discrete controllers have breakpoints: engine.cc:1919-1940)
+        constraint_model = (self._options["contacts"]["model"] == "constraint"
+                            and float(st["controllerUpdatePeriod"]) > EPS)
         for i, (t_next, cmd_bp, sens) in enumerate(intervals):
             changed = cmd_bp and (self._command_dirty or constraint_model)
             self._lib.check(self._L.jm_batch_step_adaptive(
@@ -723,7 +725,9 @@ class BatchedEngine:
         stream = self._stream()
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
         per_step_noise = bool(self._sensor_noise) and float(self._options["stepper"]["sensorsUpdatePeriod"]) <= 0.0
-        constraint_model = self._options["contacts"]["model"] == "constraint"
+        # (only discrete controllers have breakpoints: engine.cc:1919-1940)
+        constraint_model = (self._options["contacts"]["model"] == "constraint"
+                            and float(self._options["stepper"]["controllerUpdatePeriod"]) > EPS)
         t_now = self._t
         for dt, n, cmd_bp, sens in launches:
             for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
