@@ -805,6 +805,13 @@ class BatchedEngine:
             ad["f64"][1:4, m_] = SIMULATION_MIN_TIMESTEP
             ad["f64"][0, m_] = self._t
             ad["i32"][:, m_] = 0
+        # a re-initialised lane starts with an empty sensor history (`AbstractSensorTpl::resetAll`): every
+        # stored sample of that lane becomes its fresh raw measurement, which is what the delay lookup returns
+        # while "the buffer is not fully initialised" (abstract_sensor.hxx:405-421)
+        for e in self._sensor_noise.values():
+            if e.get("hist") is not None:
+                m_ = mask.bool()
+                e["hist"][:, :, m_] = self._fields[e["field"]][:, m_].unsqueeze(0)
 
     # ------------------------------------------------------------------ sensor noise and bias
     _SENSOR_FIELDS = {"ImuSensor": ("imu", 6), "ForceSensor": ("force", 6), "ContactSensor": ("contact", 3),

@@ -400,3 +400,34 @@ def test_engine_encoder_delay_reads_the_past(gpu_device):
     assert torch.equal(q_raw, q_late)
     for k in range(9):
         assert torch.equal(late[k], raw[max(k - 3, 0)]), k
+
+
+@pytest.mark.gpu
+def test_engine_delay_history_of_reset_lanes_starts_afresh(gpu_device):
+    """`reset_lanes`: the delayed readings of a re-initialised lane come from its new episode only."""
+    import torch
+    from jiminy_amd.engine import BatchedEngine
+    from tests import robots
+    model = robots.pendulum()
+    B, dt = 6, 1e-3
+    eng = BatchedEngine(model, B, dtype=torch.float64)
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt}})
+    eng.set_sensor_options("EncoderSensor", delay=3e-3)
+    eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
+    q0 = torch.linspace(0.1, 0.6, B, dtype=torch.float64)[None, :]
+    eng.start(q0, torch.zeros((1, B), dtype=torch.float64))
+    for _ in range(5):
+        eng.step(dt)
+    mask = torch.tensor([1, 0, 1, 0, 0, 0], dtype=torch.uint8)
+    q_new = torch.full((1, B), -0.7, dtype=torch.float64)
+    eng.reset_lanes(mask, q_new, torch.zeros((1, B), dtype=torch.float64))
+    kept = eng.field("encoder")[:, 1].clone()
+    eng.step(dt)
+    enc = eng.field("encoder")
+    # reset lanes: the 3 ms old sample is the post-reset reading (position -0.7, zero velocity)
+    assert torch.allclose(enc[0, [0, 2]], torch.full((2,), -0.7, dtype=torch.float64, device=enc.device), atol=1e-12)
+    assert float(enc[1, [0, 2]].abs().max()) < 1e-12
+    # the other lanes keep reading their own past
+    assert not torch.allclose(enc[0, 1], torch.tensor(-0.7, dtype=torch.float64, device=enc.device))
+    assert torch.isfinite(kept).all()
