@@ -39,6 +39,9 @@
 #define JM_CON_PGS_REG 0   // robots with <= 32 constraint rows: PGS vectors in registers, fully unrolled sweeps
                           // (measured slower: every lane pays for all NR x NR predicated slots, + 7 kB of scratch)
 #endif
+#ifndef JM_CON_XALIAS
+#define JM_CON_XALIAS 1  // PGS multipliers in the (unused) RK stage rows of LDS for non-RK4 launches
+#endif
 #ifndef JM_CON_XLDS
 #define JM_CON_XLDS 0   // packed multipliers in LDS during the PGS solve (faster solve, but the extra 14 kB
                         // per block cost one resident wave per CU: measured slower on warm-started workloads)
@@ -58,6 +61,9 @@ template<class T> struct ConArgs
     // set by the kernel: per-lane on-chip vector (LDS) of the packed multipliers, element p at xl[p * xstride]
     T * xl;
     int xstride;
+    // optional on-chip rows for the PGS residuals y (null: workspace rows), usable when m <= yrows
+    T * yl;
+    int ystride, yrows;
 };
 struct WithCon
 {
@@ -381,12 +387,17 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
         for (; k < m; ++k) s += ws(R::WA + k * NR + i) * xl[k * xs];
         return s;
     };
-    for (int r = 0; r < m; ++r) ws(R::WY + r) = T(0);
+    // residuals y: on chip when the kernel lent enough rows, else in the workspace; the reference's test on
+    // |y - yPrev| (yPrev = copy taken before the sweep) is evaluated where y is rewritten -- a row that the
+    // sweep does not touch contributes 0 either way -- so no copy is kept
+    const bool y_chip = C.yl != nullptr && m <= C.yrows;
+    auto Y = [&](int r) -> T & { return y_chip ? C.yl[r * C.ystride] : ws(R::WY + r); };
+    for (int r = 0; r < m; ++r) Y(r) = T(0);
     const bool torsion_zero = C.torsion < eps, friction_zero = friction < eps;
     const unsigned iter_max = (unsigned)C.iter_max;
     for (unsigned iter = 0; iter < iter_max; ++iter)
     {
-        for (int r = 0; r < m; ++r) ws(R::WYP + r) = ws(R::WY + r);
+        T dmax = T(0);  // max |y - yPrev| of this sweep
         // under-relaxation schedule (constraint_solvers.cc:248-258)
         const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
         T w = T(1);
@@ -400,7 +411,8 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
         {
             const int i0 = r < nb ? r : r + 2;
             const T y = ws(R::WB + i0) - col_dot(i0);
-            ws(R::WY + i0) = y;
+            dmax = fmax_(dmax, cabs_(y - Y(i0)));
+            Y(i0) = y;
             const T e = xl[(i0) * xs] + w * y / ws(R::WA + i0 * NR + i0);
             xl[(i0) * xs] = fmax_(e, T(0));  // clamp(e, 0, inf)
         }
@@ -410,7 +422,8 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             if (torsion_zero) { xl[(r + 3) * xs] = xl[(r + 3) * xs] * T(0); continue; }
             const int i0 = r + 3;
             const T y = ws(R::WB + i0) - col_dot(i0);
-            ws(R::WY + i0) = y;
+            dmax = fmax_(dmax, cabs_(y - Y(i0)));
+            Y(i0) = y;
             const T e = xl[(i0) * xs] + w * y / ws(R::WA + i0 * NR + i0);
             const T thr = C.torsion * xl[(r + 2) * xs];
             xl[(i0) * xs] = clamp_(e, -thr, thr);
@@ -420,9 +433,11 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
         {
             if (friction_zero) { xl[(r) * xs] = xl[(r) * xs] * T(0); xl[(r + 1) * xs] = xl[(r + 1) * xs] * T(0); continue; }
             const T y0 = ws(R::WB + r) - col_dot(r);
-            ws(R::WY + r) = y0;
+            dmax = fmax_(dmax, cabs_(y0 - Y(r)));
+            Y(r) = y0;
             const T y1 = ws(R::WB + r + 1) - col_dot(r + 1);
-            ws(R::WY + r + 1) = y1;
+            dmax = fmax_(dmax, cabs_(y1 - Y(r + 1)));
+            Y(r + 1) = y1;
             const T a00 = ws(R::WA + r * NR + r), a11 = ws(R::WA + (r + 1) * NR + r + 1);
             const T a_max = a11 > a00 ? a11 : a00;
             T e0 = xl[(r) * xs] + w * y0 / a_max;
@@ -440,10 +455,9 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
         }
         // stagnation of the residuals (constraint_solvers.cc:263-278)
         T ymax = T(0);
-        for (int r = 0; r < m; ++r) ymax = fmax_(ymax, cabs_(ws(R::WY + r)));
+        for (int r = 0; r < m; ++r) ymax = fmax_(ymax, cabs_(Y(r)));
         const T tol = C.tol_abs + C.tol_rel * ymax + eps;
-        bool done = true;
-        for (int r = 0; r < m; ++r) done &= cabs_(ws(R::WY + r) - ws(R::WYP + r)) < tol;
+        const bool done = dmax < tol;  // all |y - yPrev| < tol
         if (done)
         {
             for (int r = 0; r < m; ++r) ws(R::WX + r) = xl[r * xs];
@@ -885,9 +899,28 @@ __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const 
     __shared__ T xs[(ConRows<Tp>::NR > 0 ? ConRows<Tp>::NR : 1) * 64];
     Cl.xl = xs + threadIdx.x;
     Cl.xstride = 64;
+    Cl.yl = nullptr; Cl.ystride = 0; Cl.yrows = 0;
 #else
-    Cl.xl = C.ws + (size_t)ConRows<Tp>::WX * A.B + lane;  // workspace rows (HBM)
-    Cl.xstride = (int)A.B;
+    // The packed multipliers of the PGS solve are read m times per row update: they live in LDS whenever
+    // that is free, i.e. in the Runge-Kutta stage rows, which only `runge_kutta_4` steps use (the shipped
+    // robots integrate with `euler_explicit`); otherwise in the workspace rows (HBM).
+    constexpr bool fits = ConRows<Tp>::NR <= stage_rows<Tp>();
+    const bool stage_rows_free = A.mode != MODE_STEP || A.solver != JM_SOLVER_RUNGE_KUTTA_4;
+    Cl.yl = nullptr; Cl.ystride = 0; Cl.yrows = 0;
+    if (JM_CON_XALIAS && fits && stage_rows_free)
+    {
+        Cl.xl = lds + threadIdx.x;
+        Cl.xstride = 64;
+        // the residuals take what is left of the stage rows (used when the lane's active rows fit)
+        Cl.yl = lds + (size_t)ConRows<Tp>::NR * 64 + threadIdx.x;
+        Cl.ystride = 64;
+        Cl.yrows = stage_rows<Tp>() - ConRows<Tp>::NR;
+    }
+    else
+    {
+        Cl.xl = C.ws + (size_t)ConRows<Tp>::WX * A.B + lane;
+        Cl.xstride = (int)A.B;
+    }
 #endif
     lane_run<T, Tp, 64, WithCon>(A, lane, lds + threadIdx.x, Cl);
 }

@@ -152,6 +152,8 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
         std::vector<T> xvec(jm::ConRows<Topo>::NR + 1, (T)std::nan(""));
         C.xl = xvec.data(); C.xstride = 1;
+        std::vector<T> yvec(8, (T)std::nan(""));
+        C.yl = yvec.data(); C.ystride = 1; C.yrows = 7;   // exercises both homes of the residuals
         for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1, jm::WithCon>(A, lane, sb.data(), C);
         return 0;
     }
