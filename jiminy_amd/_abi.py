@@ -108,7 +108,7 @@ def constraint_rows(model: CompiledModel) -> Dict[str, int]:
     nc = model.ncontacts
     nr = nb + 4 * nc
     return {"n_bounds": nb, "n_contacts": nc, "n_rows": nr, "con_flags": nb + nc,
-            "con_data": nb + nr, "workspace": nr * nr + 5 * nr}
+            "con_data": nb + nr, "workspace": nr * nr + 5 * nr + 3 * model.nv}
 
 
 class AdaptiveOptions(C.Structure):

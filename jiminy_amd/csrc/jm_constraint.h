@@ -64,6 +64,10 @@ template<class T> struct ConArgs
     // optional on-chip rows for the PGS residuals y (null: workspace rows), usable when m <= yrows
     T * yl;
     int ystride, yrows;
+    // runge_kutta_4 launches: the stage rows are live between two evaluations; they are parked in these
+    // workspace rows around every PGS solve (null: nothing to park)
+    T * park;
+    int park_rows;
 };
 struct WithCon
 {
@@ -88,7 +92,8 @@ template<class Tp> struct ConRows
     static constexpr int LAM = NB;  // first lambda row in `data`
     // workspace rows: delassus matrix over the PACKED active rows (stride NR), then b, y, y_prev, a diagonal
     // backup and the packed multipliers x
-    static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WX = WD + NR, WTOTAL = WX + NR;
+    static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WX = WD + NR, WPARK = WX + NR,
+                         WTOTAL = WPARK + 3 * Tp::NV;  // + the parked Runge-Kutta stage rows (3 nv)
     // bit mask of the ancestors-or-self of joint j (the joints a force applied on body j travels through)
     static constexpr unsigned long long anc_mask(int j)
     {
@@ -819,8 +824,12 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             }
             else
             {
-                if constexpr (JM_CON_PGS_REG && NR <= 32) ok = pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
+                if (C.park)
+                for (int r = 0; r < C.park_rows; ++r) C.park[(size_t)r * B] = C.xl[r * C.xstride];
+            if constexpr (JM_CON_PGS_REG && NR <= 32) ok = pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
             else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
+            if (C.park)
+                for (int r = 0; r < C.park_rows; ++r) C.xl[r * C.xstride] = C.park[(size_t)r * B];
                 if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
                 else w.status |= JM_LANE_SOLVER_FAILURE;
             }
@@ -900,6 +909,7 @@ __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const 
     Cl.xl = xs + threadIdx.x;
     Cl.xstride = 64;
     Cl.yl = nullptr; Cl.ystride = 0; Cl.yrows = 0;
+    Cl.park = nullptr; Cl.park_rows = 0;
 #else
     // The packed multipliers of the PGS solve are read m times per row update: they live in LDS whenever
     // that is free, i.e. in the Runge-Kutta stage rows, which only `runge_kutta_4` steps use (the shipped
@@ -907,8 +917,15 @@ __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const 
     constexpr bool fits = ConRows<Tp>::NR <= stage_rows<Tp>();
     const bool stage_rows_free = A.mode != MODE_STEP || A.solver != JM_SOLVER_RUNGE_KUTTA_4;
     Cl.yl = nullptr; Cl.ystride = 0; Cl.yrows = 0;
-    if (JM_CON_XALIAS && fits && stage_rows_free)
+    Cl.park = nullptr; Cl.park_rows = 0;
+    if (JM_CON_XALIAS && fits)
     {
+        if (!stage_rows_free)
+        {
+            // runge_kutta_4: the solve borrows the stage rows and gives them back (xl is the first of them)
+            Cl.park = C.ws + (size_t)ConRows<Tp>::WPARK * A.B + lane;
+            Cl.park_rows = stage_rows<Tp>();
+        }
         Cl.xl = lds + threadIdx.x;
         Cl.xstride = 64;
         // the residuals take what is left of the stage rows (used when the lane's active rows fit)

@@ -187,6 +187,7 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             C.iter_max = b->copt.pgs_iter_max;
             C.xl = nullptr; C.xstride = 0;  // set by the kernel (LDS)
             C.yl = nullptr; C.ystride = 0; C.yrows = 0;
+            C.park = nullptr; C.park_rows = 0;
             hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
         }
         else return fail(JM_ENOTIMPL, "contacts.model = 'constraint' needs a float64 batch");

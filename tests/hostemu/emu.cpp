@@ -154,6 +154,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         C.xl = xvec.data(); C.xstride = 1;
         std::vector<T> yvec(8, (T)std::nan(""));
         C.yl = yvec.data(); C.ystride = 1; C.yrows = 7;   // exercises both homes of the residuals
+        C.park = nullptr; C.park_rows = 0;
         for (long long lane = 0; lane < io->B; ++lane) jm::lane_run<T, Topo, 1, jm::WithCon>(A, lane, sb.data(), C);
         return 0;
     }
