@@ -220,95 +220,104 @@ template<class T, class Tp, int J> JM_DEV SE3<T> limi_rebuilt(CPtr<T> P, const W
 #endif
 }
 
-// dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias
-// of the last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).
-// Also returns the spatial accelerations `da` of every joint (joint frame).
+// depth of a joint in the tree (joints hanging from the universe: 1)
+template<class Tp> constexpr int joint_depth(int j)
+{
+    int d = 0;
+    for (int i = j; i > 0; i = Tp::parent[i]) ++d;
+    return d;
+}
+template<class Tp> constexpr int max_depth()
+{
+    int m = 1;
+    for (int j = 1; j < Tp::NJ; ++j) m = joint_depth<Tp>(j) > m ? joint_depth<Tp>(j) : m;
+    return m;
+}
+
+// dd = M^-1 (tau + sum_j J_j^T fb_j): bias-free articulated-body solve with the articulated inertias of the
+// last eval_dynamics.  `tau(ic)` joint efforts, `fb(jc)` force applied ON body j (joint frame).  The joint
+// accelerations and the spatial acceleration of every joint are handed to `visit(jc, ddj, da_j)` (ddj points to
+// the nv_j accelerations of joint j) as the root-to-leaves sweep produces them.
+// Joints are numbered depth-first (parents before children, a subtree is contiguous), so neither sweep needs a
+// per-joint array: the leaves-to-root sweep keeps ONE bias-force accumulator per tree depth (a joint collects
+// its children's contributions in the slot of its own depth and hands its total to the slot above), the
+// root-to-leaves sweep ONE spatial acceleration per depth.  That is 2 x depth x 6 scalars of temporaries
+// instead of 2 x njoints x 6 -- the temporaries of these solves were what the kernel spilled most.
 // `bmask`: joints that carry a non-zero bias force / effort in the leaves-to-root sweep (bit j), `fmask`:
-// joints whose acceleration is wanted from the root-to-leaves sweep; the others are skipped (their
-// `dd` / `da` are left untouched: callers only read what they asked for).
-template<class T, class Tp, class FT, class FB>
-JM_DEV void delta_aba(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, T (&dd)[Tp::NV], Sp<T> (&da)[Tp::NJ],
-                      unsigned long long bmask = ~0ull, unsigned long long fmask = ~0ull)
+// joints whose acceleration is wanted; the others are skipped.
+template<class T, class Tp, class FT, class FB, class VIS>
+JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, VIS && visit,
+                         unsigned long long bmask = ~0ull, unsigned long long fmask = ~0ull)
 {
     constexpr int NJ = Tp::NJ;
+    constexpr int MD = max_depth<Tp>();
     static_assert(NJ <= 64, "joint masks are 64-bit");
-    Sp<T> pf[NJ];
+    Sp<T> acc[MD + 1];
     T ur[Tp::NV];
-    static_for<1, NJ>([&](auto jc) { pf[decltype(jc)::value] = zero6<T>() - fb(jc); });
+    static_for<0, MD + 1>([&](auto dc) { acc[decltype(dc)::value] = zero6<T>(); });
     static_for<0, Tp::NV>([&](auto ic) { ur[decltype(ic)::value] = tau(ic); });
     static_rfor<1, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int p = Tp::parent[j];
         constexpr int t = Tp::jtype[j];
         constexpr int iv = Tp::idx_v[j];
+        constexpr int d = joint_depth<Tp>(j);
         if constexpr (t == JM_JT_FREEFLYER)
         {
-            ur[iv] -= pf[j].l.x; ur[iv + 1] -= pf[j].l.y; ur[iv + 2] -= pf[j].l.z;
-            ur[iv + 3] -= pf[j].a.x; ur[iv + 4] -= pf[j].a.y; ur[iv + 5] -= pf[j].a.z;
+            const Sp<T> pf = acc[d] - fb(jc);
+            acc[d] = zero6<T>();
+            ur[iv] -= pf.l.x; ur[iv + 1] -= pf.l.y; ur[iv + 2] -= pf.l.z;
+            ur[iv + 3] -= pf.a.x; ur[iv + 4] -= pf.a.y; ur[iv + 5] -= pf.a.z;
         }
         else if (!JM_CON_MASKS || ((bmask >> j) & 1ull))
         {
-            const T uj = ur[iv] - joint_St_dot<T, Tp, j>(P, pf[j]);
+            const Sp<T> pf = acc[d] - fb(jc);
+            acc[d] = zero6<T>();
+            const T uj = ur[iv] - joint_St_dot<T, Tp, j>(P, pf);
             ur[iv] = uj;
             if constexpr (p > 0)
             {
                 const T ud = uj * w.dinv[j];
-                const Sp<T> pa = {pf[j].l + ud * w.U[j].l, pf[j].a + ud * w.U[j].a};
-                pf[p] = pf[p] + act_force(limi_rebuilt<T, Tp, j>(P, w), pa);
+                const Sp<T> pa = {pf.l + ud * w.U[j].l, pf.a + ud * w.U[j].a};
+                acc[d - 1] = acc[d - 1] + act_force(limi_rebuilt<T, Tp, j>(P, w), pa);
             }
         }
     });
+    Sp<T> lvl[MD + 1];
     static_for<1, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int p = Tp::parent[j];
         constexpr int t = Tp::jtype[j];
         constexpr int iv = Tp::idx_v[j];
+        constexpr int d = joint_depth<Tp>(j);
         if constexpr (t == JM_JT_FREEFLYER)
         {
             T b[6] = {ur[iv], ur[iv + 1], ur[iv + 2], ur[iv + 3], ur[iv + 4], ur[iv + 5]};
             chol6_resolve(w.rootA, w.rootdinv, b);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dd[iv + k] = b[k];
-            da[j] = {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
+            lvl[d] = {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
+            visit(jc, b, lvl[d]);
         }
         else if (!JM_CON_MASKS || ((fmask >> j) & 1ull))
         {
             Sp<T> ag;
-            if constexpr (p > 0) ag = actinv_motion(limi_rebuilt<T, Tp, j>(P, w), da[p]);
+            if constexpr (p > 0) ag = actinv_motion(limi_rebuilt<T, Tp, j>(P, w), lvl[d - 1]);
             else ag = zero6<T>();
             const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
             const T ddj = w.dinv[j] * (ur[iv] - Ua);
-            dd[iv] = ddj;
             const V3<T> n = joint_axis<T, Tp, j>(P);
-            if constexpr (jt_is_rev(t)) da[j] = {ag.l, ag.a + ddj * n};
-            else da[j] = {ag.l + ddj * n, ag.a};
+            if constexpr (jt_is_rev(t)) lvl[d] = {ag.l, ag.a + ddj * n};
+            else lvl[d] = {ag.l + ddj * n, ag.a};
+            visit(jc, &ddj, lvl[d]);
         }
     });
 }
 
-// J_row . dd for every active row, written through `put(row, value)`
-template<class T, class Tp, class RowMask, class PUT>
-JM_DEV void rows_of_motion(CPtr<T> P, const WorkC<T, Tp> & w, const RowMask & act, const RowMask & rev,
-                           const T (&dd)[Tp::NV], const Sp<T> (&da)[Tp::NJ], PUT && put)
+// index of the joint-bound constraint row of joint j, or -1
+template<class Tp> constexpr int bound_row_of(int j)
 {
-    using L = Layout<Tp>;
-    using R = ConRows<Tp>;
-    static_for<0, R::NB>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int iv = Tp::idx_v[R::bjoint(k)];
-        if (act.test(k)) put(k, rev.test(k) ? -dd[iv] : dd[iv]);
-    });
-    for_contacts<Tp>([&](auto jc, int c) {
-        constexpr int j = decltype(jc)::value;
-        const int r0 = R::NB + 4 * c;
-        if (act.test(r0))
-        {
-            const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
-            const V3<T> lin = w.oMi[j].R * (da[j].l + cross(da[j].a, pc));
-            const V3<T> ang = w.oMi[j].R * da[j].a;
-            put(r0, lin.x); put(r0 + 1, lin.y); put(r0 + 2, lin.z); put(r0 + 3, ang.z);
-        }
-    });
+    for (int k = 0; k < ConRows<Tp>::NB; ++k)
+        if (ConRows<Tp>::bjoint(k) == j) return k;
+    return -1;
 }
 
 // Cholesky solve A x = b over the m packed rows (start pass with `ignoreBounds`, solveJMinvJtv).
@@ -696,8 +705,6 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     });
 
     // ---- delassus matrix, one bias-free articulated-body solve per active row
-    T dd[NV];
-    Sp<T> da[NJ];
     // (each lane walks ITS OWN active rows, lowest first: a wave runs max-over-lanes solves, not the
     // union of the rows active anywhere in the wave; column index = packed index of the row)
     const int m_act = act.count(), nb_act = act.rank(R::NB);
@@ -736,9 +743,35 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 bmask = R::anc_mask(j);
             }
         });
-        delta_aba<T, Tp>(P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
-                         [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); }, dd, da, bmask, fmask);
-        rows_of_motion<T, Tp>(P, w, act, rev, dd, da, [&](int l, T val) { ws(R::WA + act.rank(l) * NR + pk) = val; });
+        // J_row . dd of every active row = column pk of the delassus matrix, written as the sweep reaches the joints
+        delta_sweeps<T, Tp>(
+            P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
+            [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); },
+            [&](auto jc, const T * ddj, const Sp<T> & daj) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int k = bound_row_of<Tp>(j);
+                if constexpr (k >= 0)
+                {
+                    if (act.test(k)) ws(R::WA + act.rank(k) * NR + pk) = rev.test(k) ? -ddj[0] : ddj[0];
+                }
+                if constexpr (joint_has_contact<Tp>(j))
+                {
+#pragma nounroll
+                    for (int c = 0; c < Tp::NC; ++c)
+                        if (Tp::contact_joint[c] == j && act.test(R::NB + 4 * c))
+                        {
+                            const V3<T> pc = ld_v3<T>(P, L::CONTACT + 12 * c + 9);
+                            const V3<T> lin = w.oMi[j].R * (daj.l + cross(daj.a, pc));
+                            const V3<T> ang = w.oMi[j].R * daj.a;
+                            const int p0 = act.rank(R::NB + 4 * c);
+                            ws(R::WA + p0 * NR + pk) = lin.x;
+                            ws(R::WA + (p0 + 1) * NR + pk) = lin.y;
+                            ws(R::WA + (p0 + 2) * NR + pk) = lin.z;
+                            ws(R::WA + (p0 + 3) * NR + pk) = ang.z;
+                        }
+                }
+            },
+            bmask, fmask);
         // regularisation (constraint_solvers.cc:376-387)
         const T arr = ws(R::WA + pk * NR + pk);
         ws(R::WA + pk * NR + pk) = arr + fmax_(arr * C.reg, T(1.0e-11));
@@ -760,14 +793,20 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] = ddq_free[decltype(ic)::value]; });
         static_for<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
+            // (only the joints that carry contact points are read below)
+            if constexpr (joint_has_contact<Tp>(j)) sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
+            else sa[j] = zero6<T>();
         });
         if (start_passes > 0)
         {
-            delta_aba<T, Tp>(P, w, [&](auto ic) { return uq[decltype(ic)::value]; },
-                             [&](auto) { return zero6<T>(); }, dd, da);
-            static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] += dd[decltype(ic)::value]; });
-            static_for<1, NJ>([&](auto jc) { sa[decltype(jc)::value] = sa[decltype(jc)::value] + da[decltype(jc)::value]; });
+            delta_sweeps<T, Tp>(P, w, [&](auto ic) { return uq[decltype(ic)::value]; }, [&](auto) { return zero6<T>(); },
+                                [&](auto jc, const T * ddj, const Sp<T> & daj) {
+                                    constexpr int j = decltype(jc)::value;
+                                    constexpr int iv = Tp::idx_v[j];
+                                    constexpr int nvj = Tp::jtype[j] == JM_JT_FREEFLYER ? 6 : 1;
+                                    static_for<0, nvj>([&](auto kc) { af[iv + decltype(kc)::value] += ddj[decltype(kc)::value]; });
+                                    sa[j] = sa[j] + daj;
+                                });
         }
         if (!refresh)
         {
@@ -873,9 +912,16 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 w.cf[c] = {tmul(fr.R, fl.l), tmul(fr.R, tmul(w.oMi[j].R, tW))};
             }
         });
-        delta_aba<T, Tp>(P, w, [&](auto ic) { return tl[decltype(ic)::value]; },
-                         [&](auto jc) { return fsum[decltype(jc)::value]; }, dd, da);
-        static_for<0, NV>([&](auto ic) { w.ddq[decltype(ic)::value] = af[decltype(ic)::value] + dd[decltype(ic)::value]; });
+        delta_sweeps<T, Tp>(P, w, [&](auto ic) { return tl[decltype(ic)::value]; },
+                            [&](auto jc) { return fsum[decltype(jc)::value]; },
+                            [&](auto jc, const T * ddj, const Sp<T> &) {
+                                constexpr int j = decltype(jc)::value;
+                                constexpr int iv = Tp::idx_v[j];
+                                constexpr int nvj = Tp::jtype[j] == JM_JT_FREEFLYER ? 6 : 1;
+                                static_for<0, nvj>([&](auto kc) {
+                                    w.ddq[iv + decltype(kc)::value] = af[iv + decltype(kc)::value] + ddj[decltype(kc)::value];
+                                });
+                            });
         // Engine::start: the next pass sees u = uInternal (bounds multipliers of this pass, added with a
         // plus sign whatever the direction, engine.cc:3786-3790) + motor efforts (engine.cc:1456-1465)
         static_for<0, NV>([&](auto ic) { uq[decltype(ic)::value] = T(0); });
