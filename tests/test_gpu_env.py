@@ -121,6 +121,71 @@ def test_hip_pipeline_blocks_match_the_tensor_programs(gpu_device, monkeypatch):
     assert bool((hip[0][:, :, ::7] == quat[:, :, ::7]).all())   # still lanes untouched
 
 
+def test_hip_pipeline_blocks_match_the_oracle(gpu_device):
+    """`jm_block_pd_controller` / `jm_block_mahony_filter` on the device DIRECTLY against
+    oracle/blocks_numpy.py -- the scalar, statement-by-statement restatement of the reference's numba
+    kernels (proportional_derivative_controller.py:22-163, mahony_filter.py:28-95), one environment at a
+    time like the reference -- with nothing of jiminy_amd/blocks.py in between.  Random command states
+    that hit the position / velocity / acceleration bounds, shuffled encoder order, still and moving
+    IMUs; each application starts from identical inputs (the ZOH integrator is discontinuous)."""
+    from jiminy_amd import blocks, load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    from oracle import blocks_numpy as orc
+    model = load_builtin("anymal")
+    B, M = 384, model.nmotors
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    rg = np.random.default_rng(11)
+    enc = (rg.random((M, 2, B)) - 0.5) * 4.0           # raw encoder field [n_enc][2][B]
+    eng.field("encoder").copy_(torch.from_numpy(enc.reshape(2 * M, B)))
+    lo = np.stack([-1.0 - rg.random(M), -5.0 - rg.random(M), -50.0 - 50 * rg.random(M)])
+    hi = np.stack([1.0 + rg.random(M), 5.0 + rg.random(M), 50.0 + 50 * rg.random(M)])
+    kp, kd, lim = 100 + 1000 * rg.random(M), 0.01 + 0.1 * rg.random(M), 20 + 60 * rg.random(M)
+    cs = np.stack([(rg.random((M, B)) - 0.5) * 2.6, (rg.random((M, B)) - 0.5) * 13, (rg.random((M, B)) - 0.5) * 250])
+    enc_idx = rg.permutation(M)
+    hb = blocks.HipBlocks(eng, torch.from_numpy(enc_idx), torch.from_numpy(lo), torch.from_numpy(hi),
+                          torch.from_numpy(kp), torch.from_numpy(kd), torch.from_numpy(lim))
+    n_bound_hits = 0
+    for dt in (5e-3, 5e-3, 5e-3, 0.0):
+        cs_dev = torch.from_numpy(cs).to(gpu_device)
+        out_dev = torch.zeros((M, B), dtype=torch.float64, device=gpu_device)
+        hb.pd_controller(cs_dev, dt, out_dev)
+        cs_ref, out_ref = cs.copy(), np.zeros((M, B))
+        for lane in range(B):
+            state = np.ascontiguousarray(cs_ref[:, :, lane])
+            o = np.zeros(M)
+            orc.pd_controller(enc[enc_idx, :, lane].T, state, lo, hi, kp, kd, lim, dt, o)
+            cs_ref[:, :, lane], out_ref[:, lane] = state, o
+        got_cs, got_out = cs_dev.cpu().numpy(), out_dev.cpu().numpy()
+        assert np.abs(got_cs - cs_ref).max() <= 1e-13 * np.abs(cs_ref).max()
+        assert np.abs(got_out - out_ref).max() <= 1e-13 * np.abs(out_ref).max()
+        n_bound_hits += int((np.abs(out_ref) == lim[:, None]).sum())
+        n_bound_hits += int(((cs_ref[1] == lo[1][:, None]) | (cs_ref[1] == hi[1][:, None])).sum())
+        cs = cs_ref
+    assert n_bound_hits > 100   # the saturation branches are exercised
+    # ---- Mahony filter (ANYmal: one IMU)
+    imu = (rg.random((6, B)) - 0.5) * np.array([1, 1, 1, 20, 20, 20.0])[:, None]
+    imu[:, ::7] = 0.0           # still lanes: cf == 0 -> the early return of the reference
+    eng.field("imu").copy_(torch.from_numpy(imu))
+    quat = rg.random((4, 1, B)) - 0.5
+    quat /= np.linalg.norm(quat, axis=0, keepdims=True)
+    bias = (rg.random((3, 1, B)) - 0.5) * 0.1
+    bias[:, :, ::7] = 0.0
+    for _ in range(4):
+        dev = [torch.from_numpy(x).to(gpu_device) for x in (quat, np.zeros_like(bias), np.zeros_like(bias), bias)]
+        hb.mahony_filter(dev[0], dev[1], dev[2], dev[3], 1.0, 0.1, 5e-3)
+        q_ref, b_ref = quat.copy(), bias.copy()
+        om_ref, cf_ref = np.zeros_like(bias), np.zeros_like(bias)
+        for lane in range(B):
+            q1, b1 = np.ascontiguousarray(q_ref[:, :, lane]), np.ascontiguousarray(b_ref[:, :, lane])
+            om, cf = np.zeros((3, 1)), np.zeros((3, 1))
+            orc.mahony_filter(q1, om, cf, imu[:3, lane][:, None], imu[3:, lane][:, None], b1, 1.0, 0.1, 5e-3)
+            q_ref[:, :, lane], b_ref[:, :, lane], om_ref[:, :, lane], cf_ref[:, :, lane] = q1, b1, om, cf
+        for got, want in zip(dev, (q_ref, om_ref, cf_ref, b_ref)):
+            assert np.abs(got.cpu().numpy() - want).max() <= 1e-13 * max(np.abs(want).max(), 1.0)
+        quat, bias = q_ref, b_ref
+    assert (quat[:, :, ::7] == dev[0].cpu().numpy()[:, :, ::7]).all()
+
+
 def test_env_with_hip_blocks_equals_env_with_tensor_blocks(gpu_device, monkeypatch):
     B = 128
     g = torch.Generator(device="cpu").manual_seed(1)

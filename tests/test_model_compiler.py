@@ -149,3 +149,103 @@ def test_builtin_models_match_the_reference_urdfs_when_present():
     b = load_builtin("anymal")
     assert m.topology_signature() == b.topology_signature()
     assert np.array_equal(m.inertia, b.inertia) and np.array_equal(m.placement_R, b.placement_R)
+
+
+# ---- pins that do not go through CompiledModel's own construction: the URDF XML walked directly --------------
+def _urdf_composite(urdf_path):
+    """Total mass, centre of mass and inertia about the root-link origin of a URDF at its zero
+    configuration, from the XML alone: own element walk, own roll-pitch-yaw convention (URDF: fixed-axis
+    X-Y-Z = Rz Ry Rx), nothing imported from jiminy_amd.model."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(urdf_path).getroot()
+
+    def floats(s, n):
+        return np.array([float(x) for x in s.split()]) if s else np.zeros(n)
+
+    def rot(rpy):
+        r, p, y = rpy
+        Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+        Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+        Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+        return Rz @ Ry @ Rx
+
+    def origin(e):
+        o = e.find("origin") if e is not None else None
+        if o is None:
+            return np.eye(3), np.zeros(3)
+        return rot(floats(o.get("rpy"), 3)), floats(o.get("xyz"), 3)
+    links = {l.get("name"): l for l in root.findall("link")}
+    children, child_names = {}, set()
+    for j in root.findall("joint"):
+        children.setdefault(j.find("parent").get("link"), []).append(j)
+        child_names.add(j.find("child").get("link"))
+    (root_link,) = [n for n in links if n not in child_names]
+    tot_m, tot_mc, tot_I = 0.0, np.zeros(3), np.zeros((3, 3))
+    stack = [(root_link, np.eye(3), np.zeros(3))]
+    while stack:
+        name, R, p = stack.pop()
+        inert = links[name].find("inertial")
+        if inert is not None and inert.find("mass") is not None:
+            m = float(inert.find("mass").get("value"))
+            Ri, pi = origin(inert)
+            i = inert.find("inertia")
+            I = np.zeros((3, 3))
+            if i is not None:
+                ixx, ixy, ixz, iyy, iyz, izz = (float(i.get(k, 0.0)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz"))
+                I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+            c = p + R @ pi                      # COM in the root-link frame
+            Iw = (R @ Ri) @ I @ (R @ Ri).T      # rotational inertia about the COM, root-link axes
+            tot_m += m
+            tot_mc += m * c
+            tot_I += Iw + m * (c @ c * np.eye(3) - np.outer(c, c))   # parallel axis to the origin
+        for j in children.get(name, []):
+            Rj, pj = origin(j)
+            stack.append((j.find("child").get("link"), R @ Rj, p + R @ pj))
+    return tot_m, tot_mc / tot_m, tot_I
+
+
+def _model_composite(m):
+    """The same three quantities from the compiled model at its neutral configuration, root joint at the
+    origin (free-flyer) -- plain sums over the joints' bodies."""
+    from jiminy_amd.synthetic import joint_world_placements
+    Rs, ps = joint_world_placements(m, m.neutral())
+    tot_m, tot_mc, tot_I = 0.0, np.zeros(3), np.zeros((3, 3))
+    for j in range(1, m.njoints):
+        R, p = Rs[j][0], ps[j][0]
+        c = p + R @ m.com[j]
+        tot_m += m.mass[j]
+        tot_mc += m.mass[j] * c
+        tot_I += R @ m.inertia[j] @ R.T + m.mass[j] * (c @ c * np.eye(3) - np.outer(c, c))
+    return tot_m, tot_mc / tot_m, tot_I
+
+
+# frozen from the reference's URDF files by `_urdf_composite` (total mass [kg], COM [m], diagonal of the
+# composite inertia about the root-link origin [kg m^2]); the XML itself is re-walked when the reference
+# tree is present
+URDF_COMPOSITES = {
+    "anymal": ("quadrupedal_robots/anymal/anymal.urdf", None),
+    "atlas": ("bipedal_robots/atlas/atlas.urdf", None),
+}
+FROZEN_COMPOSITES = {
+    "anymal": (52.134849999999986, [-0.009001324210294755, -9.012968292868901e-05, -0.07019512926579306],
+               [2.396821450925352, 6.452496555268907, 6.267118106699941]),
+    "atlas": (174.05030000000002, [0.00012255752916805809, 0.0010554102245931125, 0.28773675163260287],
+              [56.410983630038714, 46.106879692483204, 13.53299071151775]),
+}
+
+
+@pytest.mark.parametrize("name", ["anymal", "atlas"])
+def test_composite_inertia_matches_the_urdf_xml(name):
+    m = load_builtin(name)
+    got = _model_composite(m)
+    frozen = FROZEN_COMPOSITES[name]
+    assert got[0] == pytest.approx(frozen[0], rel=1e-12)
+    assert np.allclose(got[1], frozen[1], rtol=0, atol=1e-12)
+    assert np.allclose(np.diag(got[2]), frozen[2], rtol=1e-12)
+    urdf = os.path.join(os.environ.get("JIMINY_REFERENCE", "/root/reference"), "data", URDF_COMPOSITES[name][0])
+    if not os.path.exists(urdf):
+        pytest.skip("reference URDF not available on this machine: checked against the frozen values only")
+    want = _urdf_composite(urdf)
+    assert got[0] == pytest.approx(want[0], rel=1e-13)
+    assert np.allclose(got[1], want[1], rtol=0, atol=1e-13)
+    assert np.allclose(got[2], want[2], rtol=1e-12, atol=1e-12)
