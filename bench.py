@@ -20,13 +20,31 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): re-exec this very
+    command line under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1, and hand its
+    exit code back.  (The driver launches the ranks itself; this path makes the script self-contained.)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 # float64 vector issue: one wave64 VALU instruction occupies a SIMD for 4 cycles (16 lanes / clk,
@@ -86,38 +104,92 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0, solver: str =
         done += n_lanes * n_steps
     single = done / (time.perf_counter() - t0)
 
+    # all cores: one PROCESS per core (no GIL, no shared allocator), each stepping its own slice
     cores = os.cpu_count() or 1
     per = 256
-    arrs = [make(per) for _ in range(cores)]
-    engines = [OracleEngineFor(a) for a in arrs]
-    ios = [oracle_io(a) for a in arrs]
-    for eng, i in zip(engines, ios):
-        eng.batch_run("start", i)
-    counts = [0] * cores
-    stop_at = time.perf_counter() + budget_s * 0.5
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    q_out = ctx.Queue()
+    start_evt = ctx.Event()
+    span = budget_s * 0.5
 
     def work(k):
-        while time.perf_counter() < stop_at:
-            engines[k].batch_run("step", ios[k], solver=solver, dt=dt, n_substeps=1,
-                                 command_changed=False)
-            counts[k] += per
+        a = make(per)
+        eng = OracleEngineFor(a)
+        i = oracle_io(a)
+        eng.batch_run("start", i)
+        eng.batch_run("step", i, solver=solver, dt=dt, n_substeps=1, command_changed=False)
+        start_evt.wait()
+        n, t_begin = 0, time.perf_counter()
+        while time.perf_counter() - t_begin < span:
+            eng.batch_run("step", i, solver=solver, dt=dt, n_substeps=1, command_changed=False)
+            n += per
+        q_out.put((n, time.perf_counter() - t_begin))
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    multi = sum(counts) / (time.perf_counter() - t0)
+    procs = [ctx.Process(target=work, args=(k,)) for k in range(cores)]
+    for pr in procs:
+        pr.start()
+    time.sleep(1.0)            # let every worker finish its warm-up before the common start
+    start_evt.set()
+    res = [q_out.get() for _ in procs]
+    for pr in procs:
+        pr.join()
+    multi = sum(n / t for n, t in res)
     return {
         "value": single, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n_lanes} lanes of the same seeded ANYmal batch stepped for ~{budget_s * 0.5:.0f} s "
                   f"by oracle/liboracle.so (g++ -O3, float64, {solver} dt={dt}"
                   + (", constraint contact model" if constraint_options is not None else "") + ")",
         "all_cores": {"value": multi, "cores": cores,
-                      "sample": f"{cores} threads x {per} lanes, independent slices, "
+                      "sample": f"{cores} processes x {per} lanes, independent slices, "
                                 f"~{budget_s * 0.5:.0f} s"},
     }
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """The N > 1 control path without a GPU: rendezvous, barrier, the asynchronous observation gather and
+    the max-over-ranks timing on CPU tensors over gloo; prints the same JSON shape with `value` null."""
+    import torch
+    import torch.distributed as dist
+
+    from jiminy_amd import load_builtin
+    from jiminy_amd.distributed import ObservationGather, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_ranks = dist.get_world_size() if world > 1 else 1
+    if n_ranks != args.gpus:
+        raise SystemExit(f"process group has {n_ranks} ranks, --gpus {args.gpus} requested")
+    model = load_builtin(args.model)
+    B = (shard_range(args.batch, rank, world)[1] - shard_range(args.batch, rank, world)[0]) if args.strong else args.batch
+    B = min(B, 512)
+    rows = [torch.full((6, B), float(rank), dtype=torch.float64), torch.full((2 * model.nmotors, B), float(rank), dtype=torch.float64)]
+    gather = ObservationGather() if (args.gather_obs and world > 1) else None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if gather is not None:
+            gather.launch(rows)
+    ok = True
+    if gather is not None:
+        g = gather.result()
+        ok = all(bool((g[r] == float(r)).all()) for r in range(world))
+        gather.drain()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no physics)", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                          "n_ranks_rccl": n_ranks, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "gather_ok": ok, "scaling": "strong" if args.strong else "weak",
+                          "lanes_per_gpu": B, "ms_per_step": 1e3 * elapsed / max(args.steps, 1)}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main() -> None:
@@ -135,7 +207,14 @@ def main() -> None:
                          "on four feet")
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--gather-obs", action="store_true",
-                    help="all-gather the observation block over RCCL every step (config 4 topology)")
+                    help="all-gather the observation block over RCCL every step (config 4 topology); asynchronous, "
+                         "overlapped with the next step")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL batch, sharded over the ranks (config 4: "
+                         "--model atlas --batch 32768 --strong --gather-obs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / collective path only (gloo on CPU tensors, no physics): "
+                         "what the world-size-2 CPU test of the N > 1 path runs")
     ap.add_argument("--episode", type=int, default=20,
                     help="steps between all-lane resets to the seeded states (0 = never). The reference "
                          "enforces joint bounds through its constraint solver (out of scope, DESIGN.md "
@@ -144,6 +223,8 @@ def main() -> None:
                          "region, and reports the worst fraction of valid lanes seen before a reset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))
     constrained = args.contact_model == "constraint"
     if args.solver is None:
         args.solver = "euler_explicit" if constrained else "runge_kutta_4"
@@ -158,19 +239,34 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU for LOCAL_RANK={local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    n_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        n_ranks = dist.get_world_size()
+        if n_ranks != args.gpus:
+            raise SystemExit(f"process group has {n_ranks} ranks, --gpus {args.gpus} requested")
 
     model = load_builtin(args.model)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    B = args.batch
+    if args.strong:
+        from jiminy_amd.distributed import shard_range
+        if args.batch % world:
+            raise SystemExit("--strong needs a global batch that is a multiple of the number of GPUs")
+        lo, hi = shard_range(args.batch, rank, world)
+        B = hi - lo
+    else:
+        B = args.batch
     if constrained:
         # robots standing on all their feet (lowest contact point 5-6 mm into the ground, small joint /
         # attitude noise), 5 % of the lanes with joints beyond a position limit
@@ -187,7 +283,10 @@ def main() -> None:
     eng.start(torch.from_numpy(states["q"]).to(dtype), torch.from_numpy(states["v"]).to(dtype))
 
     obs_rows = [eng.field(k) for k in ("imu", "force", "encoder", "effort") if eng._rows[k] > 0]
-    gather_out = None
+    gather = None
+    if args.gather_obs and world > 1:
+        from jiminy_amd.distributed import ObservationGather
+        gather = ObservationGather()
     q_seed = torch.from_numpy(states["q"]).to(dtype).to(device)
     v_seed = torch.from_numpy(states["v"]).to(dtype).to(device)
     all_lanes = torch.ones(B, dtype=torch.uint8, device=device)
@@ -206,10 +305,10 @@ def main() -> None:
             torch.maximum(nan_max, ((st & 1) != 0).double().mean(), out=nan_max)
             torch.maximum(oob_max, ((st & 2) != 0).double().mean(), out=oob_max)
             eng.reset_lanes(all_lanes, q_seed, v_seed)
-        if args.gather_obs and world > 1:
-            from jiminy_amd.distributed import all_gather_observations
-            nonlocal gather_out
-            gather_out = all_gather_observations(obs_rows, gather_out)
+        if gather is not None:
+            # asynchronous: RCCL runs on the process group's stream behind an event of this stream; the
+            # next step's launches overlap with it (the learner would call gather.result() where it reads)
+            gather.launch(obs_rows)
 
     def barrier() -> None:
         if world > 1:
@@ -228,6 +327,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    if gather is not None:
+        gather.drain()     # the timed region ends when the last gathered block has landed
     barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = eng.timing_summary()
@@ -291,14 +392,15 @@ def main() -> None:
                             + (" constraint contact model" if constrained else "")),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "n_ranks_rccl": n_ranks,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} nq{model.nq} nv{model.nv} {model.nmotors} motors "
                                    f"{model.ncontacts} {'constraint (PGS)' if constrained else 'spring-damper'} contact points, "
                                    f"{args.solver} dt={args.dt} command held, extra terms + sensors",
                        "lanes_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"
-                                      + (" + obs all-gather" if args.gather_obs else ""),
+                                      + (" + async obs all-gather (RCCL)" if gather is not None else ""),
                        "episode_steps": args.episode,
                        "lanes_ok_min": ok_frac, "lanes_nan_max": nan_frac,
                        "lanes_out_of_joint_bounds_max": oob_frac,

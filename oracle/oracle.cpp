@@ -443,6 +443,9 @@ struct Engine
     std::vector<double> imu, force, contact, encoder, effort;
     int status = 0;
     long iter = 0;
+    // stepper buffers (sized on first use: the reference guarantees no allocation inside `step`,
+    // core/unit/engine_sanity_check.cc:118-121, and the CPU baseline is timed on this code)
+    std::vector<double> st_kv[4], st_ka[4], st_incv, st_inca, st_qs, st_vs, st_as;
     // ---- `contacts.model = "constraint"`: per-robot constraint registry + solver state
     jm_constraint_options copt{JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
     struct BoundCon  // JointConstraint (core/src/constraints/joint_constraint.cc)
@@ -1523,23 +1526,29 @@ void try_step(Engine & e, int solver, double dt)
 {
     const Model & m = e.mdl;
     const int nq = m.nq, nv = m.nv;
+    if ((int)e.st_incv.size() != nv || (int)e.st_qs.size() != nq)
+    {
+        for (int i = 0; i < 4; ++i) { e.st_kv[i].assign(nv, 0.0); e.st_ka[i].assign(nv, 0.0); }
+        e.st_incv.assign(nv, 0.0); e.st_inca.assign(nv, 0.0); e.st_vs.assign(nv, 0.0); e.st_as.assign(nv, 0.0);
+        e.st_qs.assign(nq, 0.0);
+    }
+    std::vector<double> & incv = e.st_incv, & inca = e.st_inca, & qs = e.st_qs, & vs = e.st_vs, & as = e.st_as;
     if (solver == JM_SOLVER_EULER_EXPLICIT)
     {
         // state.sumInPlace(stateDerivative, dt): q = integrate(q, dt*v); v = v + dt*a
-        std::vector<double> inc_v(nv), qn(nq);
-        for (int i = 0; i < nv; ++i) inc_v[i] = dt * e.v[i];
-        integrate(m, e.q.data(), inc_v.data(), qn.data());
+        for (int i = 0; i < nv; ++i) incv[i] = dt * e.v[i];
+        integrate(m, e.q.data(), incv.data(), qs.data());
         for (int i = 0; i < nv; ++i) e.v[i] = e.v[i] + dt * e.a[i];
-        e.q = qn;
+        std::copy(qs.begin(), qs.end(), e.q.begin());
         dynamics(e, e.q.data(), e.v.data(), e.a.data());
     }
     else
     {
         static const double A[4][4] = {{0, 0, 0, 0}, {0.5, 0, 0, 0}, {0, 0.5, 0, 0}, {0, 0, 1.0, 0}};
         static const double b[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
-        std::vector<double> kv[4], ka[4];
-        kv[0] = e.v; ka[0] = e.a;
-        std::vector<double> incv(nv), inca(nv), qs(nq), vs(nv), as(nv);
+        std::vector<double> * kv = e.st_kv, * ka = e.st_ka;
+        std::copy(e.v.begin(), e.v.end(), kv[0].begin());
+        std::copy(e.a.begin(), e.a.end(), ka[0].begin());
         for (int i = 1; i < 4; ++i)
         {
             std::fill(incv.begin(), incv.end(), 0.0);
@@ -1552,7 +1561,8 @@ void try_step(Engine & e, int solver, double dt)
             integrate(m, e.q.data(), incv.data(), qs.data());
             for (int k = 0; k < nv; ++k) vs[k] = e.v[k] + inca[k];
             dynamics(e, qs.data(), vs.data(), as.data());
-            kv[i] = vs; ka[i] = as;
+            std::copy(vs.begin(), vs.end(), kv[i].begin());
+            std::copy(as.begin(), as.end(), ka[i].begin());
         }
         std::fill(incv.begin(), incv.end(), 0.0);
         std::fill(inca.begin(), inca.end(), 0.0);
@@ -1563,7 +1573,7 @@ void try_step(Engine & e, int solver, double dt)
         }
         integrate(m, e.q.data(), incv.data(), qs.data());
         for (int k = 0; k < nv; ++k) e.v[k] = e.v[k] + inca[k];
-        e.q = qs;
+        std::copy(qs.begin(), qs.end(), e.q.begin());
         dynamics(e, e.q.data(), e.v.data(), e.a.data());  // not FSAL
     }
     extra_terms(e);

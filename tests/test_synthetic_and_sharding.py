@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from jiminy_amd import load_builtin
-from jiminy_amd.distributed import all_gather_observations, pack_observations, shard_range
+from jiminy_amd.distributed import ObservationGather, all_gather_observations, pack_observations, shard_range
 from jiminy_amd.synthetic import lowest_contact_height, sample_states
 
 
@@ -64,6 +64,21 @@ def _worker(rank, world, port, ret):
                              torch.arange(4 * B, dtype=torch.float64).reshape(4, B) - 1000 * r])
             ok = ok and torch.equal(gathered[r], ref)
         ok = ok and (lo, hi) == (rank * B, (rank + 1) * B)
+        # asynchronous, double-buffered form (what bench.py --gather-obs uses): three launches in flight order,
+        # the result of the last one is the last block that was packed
+        g = ObservationGather()
+        for k in range(3):
+            g.launch([imu + k, enc])
+        last = g.result()
+        for r in range(world):
+            ok = ok and torch.equal(last[r][:6], torch.arange(6 * B, dtype=torch.float64).reshape(6, B) + 1000 * r + 2)
+        g.drain()
+        # ragged shards are refused up front instead of hanging inside the collective
+        try:
+            all_gather_observations([imu[:, : B - rank], enc[:, : B - rank]])
+            ok = False
+        except ValueError:
+            pass
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -81,3 +96,25 @@ def test_observation_all_gather_world_size_2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_launcher_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher around it must start 2 ranks by itself, check the
+    process-group size and print ONE JSON line from rank 0 (dry run: gloo on CPU tensors, no physics)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--gather-obs",
+                          "--model", "atlas", "--batch", "32768", "--strong", "--steps", "4"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["n_ranks_rccl"] == 2 and rec["gather_ok"] and rec["scaling"] == "strong"
+    # a world size that contradicts --gpus is refused, not silently run on one rank
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0
