@@ -124,49 +124,40 @@ struct DelayParams
     double delay[JM_NOISE_MAX_ROWS];     // [sensor]
     float jitter[JM_NOISE_MAX_ROWS];     // [sensor]
 };
-// index of the sample to read (and the interpolation ratio towards the next one) for the desired time
+// Which stored sample a lane reads for `t_read = t_now - delay` (and the interpolation weight towards the
+// next one), same answers as the reference's history lookup (abstract_sensor.hxx:305-429) in a form that
+// suits the device: the sample times are lane-uniform kernel parameters (at most 64 of them, scalar
+// registers), so the position of `t_read` among them is a branch-free COUNT of the samples not younger than
+// it -- no per-lane bisection, no divergent loop.  Cases, in the reference's order:
+//   * zero-order hold adds 1e-10 s to `t_read`, so that a delay equal to a whole number of periods always
+//     lands on the same sample;
+//   * `t_read` inside the recorded history: the newest sample with time <= t_read (linear interpolation
+//     towards its successor when order == 1); older than everything recorded -> the oldest sample (the
+//     engine sizes the ring so that this does not occur; the reference raises there);
+//   * `t_read` < 0 or ahead of the newest sample while a delay is configured (the ring is still filling up
+//     after a start / reset): the newest sample taken at t <= 0, i.e. the initial measurement;
+//   * no delay at all: the current sample.
 JM_RDEV void delay_lookup(const DelayParams & p, int s, double delay, int & idx, double & ratio)
 {
     const int n = p.n_hist;
-    const double EPS = 2.220446049250313e-16;
-    double timeDesired = p.times[n - 1] - delay;
-    // zero-order hold: bias the comparison so that a delay equal to a multiple of the period always
-    // picks the same side (abstract_sensor.hxx:322-330)
-    if (p.order == 0) timeDesired += 1.0e-10;
-    // bisectLeft (abstract_sensor.hxx:334-375)
-    long left = 0, right = n - 1, mid = 0, idxLeft;
-    if (timeDesired >= p.times[n - 1]) idxLeft = right;
-    else if (timeDesired < p.times[0]) idxLeft = -1;
-    else
+    const double t_read = p.times[n - 1] - delay + (p.order == 0 ? 1.0e-10 : 0.0);
+    int not_younger = 0, not_positive = 0;
+    for (int i = 0; i < n; ++i)
     {
-        bool found = false;
-        idxLeft = 0;
-        while (left < right)
-        {
-            mid = (left + right) / 2;
-            if (timeDesired < p.times[mid]) right = mid;
-            else if (timeDesired > p.times[mid]) left = mid + 1;
-            else { idxLeft = mid; found = true; break; }
-        }
-        if (!found) idxLeft = (timeDesired < p.times[mid]) ? mid - 1 : mid;
+        not_younger += (p.times[i] <= t_read) ? 1 : 0;
+        not_positive += (p.times[i] <= 0.0) ? 1 : 0;
     }
+    const int newest_before = not_younger - 1;                 // -1: nothing that old was recorded
+    const bool inside = t_read >= 0.0 && newest_before + 1 < n;
+    const bool delayed = p.delay[s] > 2.220446049250313e-16 || (double)p.jitter[s] > 2.220446049250313e-16;
+    const int initial = not_positive > 0 ? not_positive - 1 : 0;
+    idx = inside ? (newest_before < 0 ? 0 : newest_before) : (delayed ? initial : n - 1);
     ratio = 0.0;
-    if (timeDesired >= 0.0 && idxLeft + 1 < n)
+    if (inside && p.order == 1 && newest_before >= 0)
     {
-        // the reference raises "No data old enough is available" for idxLeft < 0: the caller sizes the
-        // history so that this cannot happen; the oldest sample is the graceful answer
-        idx = idxLeft < 0 ? 0 : (int)idxLeft;
-        if (p.order == 1 && idxLeft >= 0)
-            ratio = (timeDesired - p.times[idxLeft]) / (p.times[idxLeft + 1] - p.times[idxLeft]);
+        const double t0 = p.times[newest_before], t1 = p.times[newest_before + 1];
+        ratio = (t_read - t0) / (t1 - t0);
     }
-    else if (p.delay[s] > EPS || (double)p.jitter[s] > EPS)
-    {
-        // buffer not fully initialised yet: the oldest value (abstract_sensor.hxx:405-421)
-        idx = n - 1;
-        for (int i = 0; i < n; ++i)
-            if (p.times[i] > 0.0) { idx = i - 1 > 0 ? i - 1 : 0; break; }
-    }
-    else idx = n - 1;
 }
 
 #ifndef JM_HOST_EMU

@@ -393,6 +393,7 @@ class BatchedEngine:
         self._sensor_noise: Dict[str, Dict[str, Any]] = {}
         self.adaptive_attempts = 0   # device attempts of the last `step` with the adaptive solver
         self._apply_options()
+        self._apply_hardware_sensor_options()
 
     # ------------------------------------------------------------------ memory
     def _alloc(self, name: str) -> torch.Tensor:
@@ -878,6 +879,27 @@ class BatchedEngine:
             else:
                 entry["bias"] = b
         self._sensor_noise[sensor_type] = entry
+
+    def _apply_hardware_sensor_options(self) -> None:
+        """Measurement options that came with the robot's hardware description file (`noiseStd`, `bias`,
+        `delay`, `jitter`, `delayInterpolationOrder` per sensor; model.load_hardware_description_file)."""
+        for stype, recs in self.model.sensors.items():
+            if stype not in self._SENSOR_FIELDS or not any("options" in r for r in recs):
+                continue
+            nf = self._SENSOR_FIELDS[stype][1]
+            nb = 9 if stype == "ImuSensor" else nf
+
+            def table(key, cols):
+                rows = [np.asarray(r.get("options", {}).get(key, np.zeros(cols)), dtype=np.float64) for r in recs]
+                rows = [np.broadcast_to(x, (cols,)) if x.size in (1, cols) else x for x in rows]
+                t = np.stack(rows)
+                return t if np.any(t != 0.0) else None
+            scal = lambda key: np.array([float(np.asarray(r.get("options", {}).get(key, 0.0)).reshape(-1)[0])  # noqa: E731
+                                         for r in recs])
+            orders = {int(r["options"].get("delayInterpolationOrder", 0)) for r in recs if "options" in r}
+            self.set_sensor_options(stype, noise_std=table("noiseStd", nf), bias=table("bias", nb),
+                                    delay=scal("delay"), jitter=scal("jitter"),
+                                    delay_interpolation_order=max(orders) if orders else 0)
 
     def seed_sensors(self, seeds: Any) -> None:
         """Seed the per-(sensor, lane) PCG32 generators, ≙ `AbstractSensorTpl::resetAll(seed)`

@@ -158,6 +158,12 @@ class VecJiminyEnv:
         q, v = self._sample_state(self.num_envs)
         self._on_reset(lane_mask)
         self._randomise_ground(lane_mask)
+        # a fresh episode starts from a zero command like `reset()` (for the PD pipeline it IS the controller's
+        # output at the reset state: target = measured position, zero velocity), not from the last command of the
+        # finished episode.  With sensor noise / delay configured the first observation of the re-initialised lanes
+        # is the raw measurement (their generators and histories restart at the next sensor refresh).
+        cmd = self.engine.field("command")
+        cmd.copy_(torch.where(lane_mask[None, :], torch.zeros_like(cmd), cmd))
         self.engine.reset_lanes(lane_mask, q, v)
         self.num_steps[lane_mask] = 0
         self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
@@ -228,6 +234,10 @@ class WalkerVecEnv(VecJiminyEnv):
         m = self.model
         lim = torch.tensor([mo.effort_limit * mo.velocity_limit for mo in m.motors], dtype=self.dtype)
         self._power_consumption_max = float(lim.sum())  # locomotion.py:230-236
+        # encoder of every motor (the reference indexes the encoder data through `encoder_to_motor_map`)
+        enc_of = {e.get("motor_index", -1): i for i, e in enumerate(m.sensors.get("EncoderSensor", []))}
+        self._motor_enc_idx = (torch.tensor([enc_of[i] for i in range(m.nmotors)], device=self.device)
+                               if all(i in enc_of for i in range(m.nmotors)) and m.nmotors else None)
 
     def has_terminated(self) -> Tuple[torch.Tensor, torch.Tensor]:
         terminated, truncated = super().has_terminated()
@@ -239,8 +249,10 @@ class WalkerVecEnv(VecJiminyEnv):
         if "survival" in self.reward_mixture:
             total += self.reward_mixture["survival"]
         if "energy" in self.reward_mixture:
-            enc = self.engine.sensor_measurements["EncoderSensor"]  # (2, n, B)
-            power = torch.clamp_min(self.engine.command * enc[1], 0.0).sum(0)
+            if self._motor_enc_idx is None:
+                raise RuntimeError("the 'energy' reward needs one motor-side encoder per motor")
+            enc = self.engine.sensor_measurements["EncoderSensor"]  # (2, n_enc, B), encoder order
+            power = torch.clamp_min(self.engine.command * enc[1][self._motor_enc_idx], 0.0).sum(0)
             total -= self.reward_mixture["energy"] * power / self._power_consumption_max
         if "failure" in self.reward_mixture:
             total -= self.reward_mixture["failure"] * terminated.to(self.dtype)
@@ -259,8 +271,8 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
 
     def __init__(self, model: CompiledModel, num_envs: int, step_dt: float, control_dt: float,
                  kp: Any, kd: Any, mahony_kp: float = 1.0, mahony_ki: float = 0.1,
-                 target_velocity_limit: float = 100.0, target_acceleration_limit: float = 10000.0,
-                 **kw: Any) -> None:
+                 joint_position_margin: float = 0.0, joint_velocity_limit: float = float("inf"),
+                 joint_acceleration_limit: Optional[float] = None, **kw: Any) -> None:
         opts = kw.pop("engine_options", None) or {}
         st = dict(opts.get("stepper", {}))
         st.setdefault("controllerUpdatePeriod", control_dt)
@@ -281,10 +293,21 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         self.kp = torch.as_tensor(kp, dtype=dt_, device=dev)
         self.kd = torch.as_tensor(kd, dtype=dt_, device=dev)
         self.effort_limit = torch.tensor([m.effort_limit for m in model.motors], dtype=dt_, device=dev)
-        lo = torch.tensor([[model.position_lower[m.idx_q] * m.reduction for m in model.motors],
-                           [-target_velocity_limit] * M, [-target_acceleration_limit] * M], dtype=dt_, device=dev)
-        hi = torch.tensor([[model.position_upper[m.idx_q] * m.reduction for m in model.motors],
-                           [target_velocity_limit] * M, [target_acceleration_limit] * M], dtype=dt_, device=dev)
+        # command-state bounds of `PDController.__init__` (proportional_derivative_controller.py:405-437):
+        # motor-side position limits shrunk by the margin, velocity min(motor limit, reduction * joint limit),
+        # acceleration reduction * joint limit -- or, without one, the largest that still allows bang-bang control
+        red = np.array([m.reduction for m in model.motors])
+        p_lo = np.array([model.position_lower[m.idx_q] * m.reduction for m in model.motors]) + red * joint_position_margin
+        p_hi = np.array([model.position_upper[m.idx_q] * m.reduction for m in model.motors]) - red * joint_position_margin
+        v_lim = np.minimum(np.array([m.velocity_limit for m in model.motors]), red * joint_velocity_limit)
+        if joint_acceleration_limit is None:
+            kp_, kd_ = np.broadcast_to(np.asarray(kp, dtype=float), (M,)), np.broadcast_to(np.asarray(kd, dtype=float), (M,))
+            eff = np.array([m.effort_limit for m in model.motors])
+            a_lim = np.minimum(2.0 * v_lim / step_dt, eff / (kp_ * step_dt * np.maximum(step_dt, kd_)))
+        else:
+            a_lim = red * float(joint_acceleration_limit)
+        lo = torch.tensor(np.stack([p_lo, -v_lim, -a_lim]), dtype=dt_, device=dev)
+        hi = torch.tensor(np.stack([p_hi, v_lim, a_lim]), dtype=dt_, device=dev)
         self.command_state_lower, self.command_state_upper = lo, hi
         self.command_state = torch.zeros((3, M, B), dtype=dt_, device=dev)
         self._accel = torch.zeros((M, B), dtype=dt_, device=dev)
@@ -317,12 +340,19 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
             self.imu_quat.zero_(); self.imu_quat[3] = 1.0
             self._bias.zero_()
         else:
-            keep = ~lane_mask
-            self.command_state *= keep
-            self.command_state[0] += target * lane_mask
-            self.imu_quat *= keep
-            self.imu_quat[3] += lane_mask.to(self.dtype)
-            self._bias *= keep
+            # by selection, never by arithmetic: a lane truncated for JM_LANE_NAN carries NaN in its controller /
+            # observer state, and NaN * 0 stays NaN
+            m = lane_mask[None, None, :]
+            fresh = torch.zeros_like(self.command_state)
+            fresh[0] = target
+            self.command_state.copy_(torch.where(m, fresh, self.command_state))
+            unit = torch.zeros_like(self.imu_quat)
+            unit[3] = 1.0
+            self.imu_quat.copy_(torch.where(m, unit, self.imu_quat))
+            for t in (self._bias, self._omega, self._cf):
+                t.copy_(torch.where(m, torch.zeros_like(t), t))
+            for t in (self._accel, self._torque):
+                t.copy_(torch.where(lane_mask[None, :], torch.zeros_like(t), t))
 
     def _step_engine(self, action: torch.Tensor) -> None:
         a = action.to(self.dtype).T
@@ -362,6 +392,9 @@ ANYMAL_CONTROL_DT = 0.005
 ANYMAL_PD_KP = (1500.0,) * 12
 ANYMAL_PD_KD = (0.01,) * 12
 ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI = 1.0, 0.1
+ANYMAL_MOTOR_VELOCITY_MAX = 4.0
+ANYMAL_MOTOR_ACCELERATION_MAX = 30.0
+ANYMAL_SIMULATION_DURATION = 20.0
 
 
 def make_anymal_env(num_envs: int, dtype: torch.dtype = torch.float64,
@@ -376,9 +409,13 @@ def make_anymal_env(num_envs: int, dtype: torch.dtype = torch.float64,
                         "controllerUpdatePeriod": ANYMAL_CONTROL_DT,
                         "sensorsUpdatePeriod": ANYMAL_CONTROL_DT},
             "contacts": {"model": contact_model}}
+    kw.setdefault("simulation_duration_max", ANYMAL_SIMULATION_DURATION)
     if pd_pipeline:
         return PDControlledWalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, ANYMAL_CONTROL_DT,
                                         ANYMAL_PD_KP, ANYMAL_PD_KD, ANYMAL_MAHONY_KP, ANYMAL_MAHONY_KI,
+                                        joint_position_margin=0.0,
+                                        joint_velocity_limit=ANYMAL_MOTOR_VELOCITY_MAX,
+                                        joint_acceleration_limit=ANYMAL_MOTOR_ACCELERATION_MAX,
                                         engine_options=opts, dtype=dtype, device=device, **kw)
     return WalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, engine_options=opts, dtype=dtype,
                         device=device, **kw)

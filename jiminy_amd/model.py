@@ -727,10 +727,15 @@ def load_hardware_description_file(model: CompiledModel, hardware_path: str,
             if fname is not None and fname not in model.frames:
                 pose = np.array(kw.pop("frame_pose"), dtype=np.float64)
                 add_frame(model, fname, kw.pop("body_name"), rpy_to_matrix(pose[3:]), pose[:3])
-            if any(np.any(np.asarray(d.get(k, 0.0)) != 0.0)
-                   for k in ("noiseStd", "bias", "delay", "jitter")):
-                raise NotImplementedError("sensor noise/bias/delay are outside the hot path")
             add_sensor(model, sensor_type, sensor_name, **kw)
+            # measurement options of the hardware file (abstract_sensor.h:66-100): kept with the sensor record
+            # and applied by BatchedEngine at construction (`set_sensor_options`)
+            opt = {k: np.asarray(d[k], dtype=np.float64).reshape(-1).tolist()
+                   for k in ("noiseStd", "bias", "delay", "jitter") if k in d and np.any(np.asarray(d[k]) != 0.0)}
+            if opt:
+                if "delayInterpolationOrder" in d:
+                    opt["delayInterpolationOrder"] = int(d["delayInterpolationOrder"])
+                model.sensors[sensor_type][-1]["options"] = opt
     return extra
 
 

@@ -63,6 +63,39 @@ def test_auto_reset_of_failed_lanes(gpu_device):
     assert n_reset >= B // 2
 
 
+def test_pd_env_recovers_from_a_nan_lane(gpu_device):
+    """A lane that fails numerically (JM_LANE_NAN) poisons its controller / observer state with NaN; the
+    auto-reset must hand back a clean lane (reset by selection: NaN * 0 would stay NaN), and the lane
+    must keep working afterwards."""
+    B = 32
+    env = make_anymal_env(B, dt_max=5e-4)
+    env.reset(seed=0)
+    action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
+    env.step(action)
+    env.engine.field("v")[7, 5] = float("nan")
+    obs, reward, terminated, truncated, info = env.step(action)
+    assert bool(truncated[5]) and int(truncated.sum()) == 1
+    assert bool(info["reset_mask"][5])
+    flat = torch.cat([obs["states"]["agent"]["q"], obs["states"]["agent"]["v"], obs["features"]["mahony_filter"].flatten(1),
+                      obs["actions"]["pd_controller"].flatten(1)] + [m.flatten(1) for m in obs["measurements"].values()], dim=1)
+    assert bool(torch.isfinite(flat).all())
+    assert bool(torch.isfinite(env.engine.field("command")).all())
+    for _ in range(3):
+        obs, reward, terminated, truncated, info = env.step(action)
+        assert not bool(truncated.any()) and not bool(terminated.any())
+    assert bool(torch.isfinite(obs["features"]["mahony_filter"]).all())
+    # the re-initialised lane follows the same trajectory as a lane of a fresh episode would: compare with lane 0
+    # three steps after ITS start (all lanes are identical copies under a zero action)
+    env2 = make_anymal_env(B, dt_max=5e-4)
+    env2.reset(seed=0)
+    for _ in range(3):
+        obs2, *_ = env2.step(action)
+    assert torch.allclose(obs["states"]["agent"]["q"][5], obs2["states"]["agent"]["q"][0], rtol=0, atol=1e-12)
+    # reference constants of ANYmalPDControlJiminyEnv (gym_jiminy/envs/anymal.py:13-24, 93-96)
+    assert env.simulation_duration_max == 20.0
+    assert float(env.command_state_upper[1].max()) == 4.0 and float(env.command_state_upper[2].max()) == 30.0
+
+
 def test_hip_pipeline_blocks_match_the_tensor_programs(gpu_device, monkeypatch):
     """`jm_block_pd_controller` / `jm_block_mahony_filter` (one HIP launch each) against the tensor
     programs of jiminy_amd/blocks.py (themselves pinned to the scalar restatement of the reference's

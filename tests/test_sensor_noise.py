@@ -5,6 +5,7 @@ CPU part: the oracle (oracle/oracle_random.cpp) against independent restatements
 ziggurat against the normal distribution (moments, Kolmogorov-Smirnov, tail mass).
 GPU part (`-m gpu`): jm_block_sensor_noise / jm_sensor_rng_seed through the C ABI against the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -309,6 +310,51 @@ def test_oracle_delay_zero_order_hold_and_linear_interpolation():
     # early in the simulation: t = 5 ms, delay 12 ms -> desired time < 0 -> the oldest sample
     oracle_py.sensor_delay(data, hist, slots[:2], times[:2], None, n, nf, delay=[0.012, 0.012], order=0)
     assert np.allclose(data, 100 * times[0] + base, atol=1e-12)
+
+
+def test_device_delay_lookup_matches_the_oracle_on_the_host():
+    """The sample selection of the device kernel (`delay_lookup`, jm_random.h: a branch-free count over the
+    lane-uniform sample times) compiled for the host, against the oracle's literal restatement of
+    `interpolateData` (bisection): random histories in every regime -- ring still filling up after a start,
+    delays equal to whole periods, delays older than the ring, no delay, both interpolation orders."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "jiminy_amd", "csrc", "build", "libemu_random.so")
+    src = os.path.join(here, "hostemu", "emu_random.cpp")
+    hdr = os.path.join(here, "..", "jiminy_amd", "csrc", "jm_random.h")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(out):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", out])
+    L = C.CDLL(out)
+    dp = C.POINTER(C.c_double)
+    L.emu_delay_lookup.argtypes = [C.c_int, dp, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), dp]
+    L.emu_delay_lookup.restype = None
+    rg = np.random.default_rng(3)
+    n_cases = 0
+    for trial in range(400):
+        n = int(rg.integers(1, 40))
+        period = float(rg.choice([1e-3, 5e-3, 1.3e-3]))
+        t_first = float(rg.choice([0.0, 0.0, period * rg.integers(1, 50)]))
+        times = t_first + period * np.arange(n)
+        order = int(trial % 2)
+        cfg_delay = float(rg.choice([0.0, period * rg.integers(0, 6), rg.uniform(0, 8 * period)]))
+        jitter = float(rg.choice([0.0, rg.uniform(0, 2 * period)]))
+        delay = cfg_delay + jitter * float(rg.random())
+        idx, ratio = C.c_int(-7), C.c_double(-7.0)
+        L.emu_delay_lookup(n, times.ctypes.data_as(dp), order, cfg_delay, jitter, delay, C.byref(idx), C.byref(ratio))
+        # oracle: one sensor, one field, one lane, history value = a distinct number per sample
+        hist = (100.0 + 7.0 * np.arange(n)).reshape(n, 1, 1)
+        data = np.array([[hist[-1, 0, 0]]])
+        # the oracle takes the configured delay and draws the jitter itself: feed it the total as the delay, no rng
+        oracle_py.sensor_delay(data, hist, np.arange(n), times, None, 1, 1, delay=[delay],
+                               jitter=[1.0 if (jitter > 0 and cfg_delay == 0.0 and delay > 0) else 0.0], order=order)
+        a = hist[idx.value, 0, 0]
+        got = a + ratio.value * (hist[min(idx.value + 1, n - 1), 0, 0] - a) if ratio.value != 0.0 else a
+        assert 0 <= idx.value < n
+        assert abs(got - data[0, 0]) <= 1e-9 * abs(data[0, 0]), (trial, n, order, cfg_delay, jitter, delay, idx.value, ratio.value)
+        n_cases += 1
+    assert n_cases == 400
 
 
 def test_oracle_jitter_takes_one_uniform_draw_per_sensor_and_call():
