@@ -288,7 +288,7 @@ def write_header(model: CompiledModel) -> str:
 def _sources() -> List[str]:
     return [os.path.join(CSRC, n) for n in ("jm_lib.cpp", "jm_kernels.h", "jm_math.h", "jm_quad.h",
                                             "jm_pack.h", "jm_adaptive.h", "jm_blocks.h", "jm_random.h",
-                                            "jm_constraint.h", "jm_lib_constraint.cpp")] + \
+                                            "jm_constraint.h", "jm_qcon.h", "jm_lib_constraint.cpp")] + \
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 

@@ -458,6 +458,38 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
     (void)ix;
 }
 
+// ---- where the forces on the contact points come from, and what else acts on the joints ------------
+// CFM = 0: spring-damper contact law (the spring-damper contact model: everything below is unused)
+// CFM = 1: no contact forces at all (free evaluation of the constraint contact model)
+// CFM = 2: contact forces = stored multipliers of the enabled FrameConstraints (constraint contact model:
+//          the evaluation that applies the solved multipliers; jm_qcon.h)
+// With CFM != 0 joint position bounds are constraints, not a lane failure, `tau_*` are extra joint efforts
+// of the dynamics (bound multipliers, signed) and `uemit_*` what is added to the emitted RobotState::u
+// (the reference adds the bound multipliers with a plus sign whatever the direction, engine.cc:3786-3790).
+template<class T, class Tp> struct QExtra
+{
+    T tau_l[Tp::QN], tau_b[Tp::QT], uemit_l[Tp::QN], uemit_b[Tp::QT];
+    bool motors_on;              // false: Engine::start's first pass, RobotState::u still zero
+    const int32_t * flags;       // [NF][B] constraint flags (bit 0 enabled), rows of the contacts start at `nb`
+    const T * lam;               // [NR][B] multipliers, rows of the contacts start at `nb`
+    int nb;
+};
+// what a free evaluation leaves behind for the bias-free solves of the constraint model (per lane)
+struct NoKeep { static constexpr bool ON = false; };
+template<class T, class Tp> struct TrunkStore;
+template<class T, class Tp> struct QKeep
+{
+    static constexpr bool ON = true;
+    V3<T> ps[Tp::QN], as[Tp::QN];    // limb joint origins / axes, root coordinates
+    Sp<T> Us[Tp::QN];
+    T dinv[Tp::QN];
+    M3<T> Rt;                        // rotation of the limb tip body (its origin is ps[N-1])
+    Sp<T> vtip, atip;                // tip velocity / spatial acceleration (gravity field included)
+    M3<T> R1; V3<T> p1;              // root placement in the world
+    Sp<T> agf1;                      // gravity field in root coordinates
+    T rootL[6][6], rootdinv[6];      // LDL^T factor of the root block (chol6_solve)
+};
+
 // a = f(q, v) for one robot spread over a quad; lane k evaluates limb k.
 //   qb[NQB], vb[NVB] : trunk-tree configuration / velocity (identical in the 4 lanes)
 //   ql[N], vl[N], cmdl[N] : this limb's joints;  cmdb[NT] : commands of the trunk-tree motors
@@ -465,10 +497,11 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
 // derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
 // if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
 // has to stay in registers for a separate output phase.
-template<class T, class Tp, class X, bool EMIT, class SB>
+template<class T, class Tp, class X, bool EMIT, class SB, int CFM = 0, class KEEP = NoKeep>
 JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
                       const SB & S_, const T * qb, const T * vb_, const T * ql, const T * vl_, const T * cmdb_, const T * cmdl_,
-                      bool sensors, T * ddqb, T * ddq, int & status)
+                      bool sensors, T * ddqb, T * ddq, int & status, const QExtra<T, Tp> * ex = nullptr, KEEP * keep = nullptr,
+                      TrunkStore<T, Tp> * ts_out = nullptr)
 {
     // velocities / commands: registers for short limbs, re-read from the stage buffer for long ones
     using RW = QRows<Tp>;
@@ -538,6 +571,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     V3<T> ps[N];
     Sp<T> vtip;
     limb_fk<T, Tp>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status);
+    if constexpr (CFM != 0) status &= ~JM_LANE_OUT_OF_BOUNDS;  // bounds are constraints there, not failures
     // ---- contact points on the limb tip (engine.cc:3117-3238, 3394-3425)
     Sp<T> fext = zero6<T>();   // total external force on the tip body, root coordinates
     {
@@ -553,20 +587,48 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
             const bool active = c < ix.nc;
             Sp<T> fl = zero6<T>();
-            if (active && depth < T(0))
+            if constexpr (CFM == 0)
             {
-                const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
-                const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
-                const V3<T> fR = tmul(R1, fW);
-                fext.l = fext.l + fR;
-                fext.a = fext.a + cross(pc, fR);
-                fmax2 = fmax_(fmax2, dot(fW, fW));
-                if (emit)
+                if (active && depth < T(0))
                 {
-                    fl.l = tmul(Rt, fR);
-                    fl.a = cross(fr.p, fl.l);
+                    const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
+                    const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
+                    const V3<T> fR = tmul(R1, fW);
+                    fext.l = fext.l + fR;
+                    fext.a = fext.a + cross(pc, fR);
+                    fmax2 = fmax_(fmax2, dot(fW, fW));
+                    if (emit)
+                    {
+                        fl.l = tmul(Rt, fR);
+                        fl.a = cross(fr.p, fl.l);
+                    }
                 }
             }
+            else if constexpr (CFM == 2)
+            {
+                // multipliers of the enabled FrameConstraint (x, y, z, torsion about z; world aligned) applied at
+                // the contact point: convertForceGlobalFrameToJoint (utilities/pinocchio.cc:794-809)
+                (void)depth;
+                if (active)
+                {
+                    const unsigned ci = (unsigned)(int)LT(oc + Q::C_IDX);
+                    if (ex->flags[((unsigned)ex->nb + ci) * B32 + r32] & 1)
+                    {
+                        const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
+                        const V3<T> fW = {ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]};
+                        const V3<T> fR = tmul(R1, fW);
+                        const V3<T> tR = ex->lam[o + 3 * B32] * V3<T>{R1.m20, R1.m21, R1.m22};
+                        fext.l = fext.l + fR;
+                        fext.a = fext.a + cross(pc, fR) + tR;
+                        if (emit)
+                        {
+                            fl.l = tmul(Rt, fR);
+                            fl.a = cross(fr.p, fl.l) + tmul(Rt, tR);
+                        }
+                    }
+                }
+            }
+            else { (void)depth; }
             if (emit && active)
             {
                 fext_loc = fext_loc + fl;
@@ -589,7 +651,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 #pragma nounroll
             for (int c = 0; c < Tp::QCL; ++c) one_contact(c);
         }
-        if constexpr (EMIT)
+        if constexpr (EMIT && CFM == 0)
             if ((A.mode == MODE_START || A.mode == MODE_RESET) && fmax2 > T(1e10)) status |= JM_LANE_FORCE_OVERFLOW;
         if (emit)
         {
@@ -624,10 +686,16 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         T um, ue;
         motor_law<T, FL>([&](int i) { return LT(o + i); }, cmdlq(s), vlq(s), um, ue);
         u[s] = ue;
+        T ue_out = ue;
+        if constexpr (CFM != 0)
+        {
+            u[s] = (ex->motors_on ? ue : T(0)) + ex->tau_l[s];
+            ue_out = ue + ex->uemit_l[s];
+        }
         if (emit && ix.has[s])
         {
             if (A.u_motor) A.u_motor[(unsigned)ix.rm[s] * B32 + r32] = um;
-            if (A.u) A.u[(unsigned)ix.rv[s] * B32 + r32] = ue;
+            if (A.u) A.u[(unsigned)ix.rv[s] * B32 + r32] = ue_out;
             if constexpr (Tp::QHAS_EFF)
                 if (sensors && A.effort)
                 {
@@ -644,10 +712,16 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         T um, ue;
         motor_law<T, FL>([&](int i) { return P[o + i]; }, cmdbq(t), vbq(5 + t), um, ue);
         ut[t] = ue;
+        T ue_out = ue;
+        if constexpr (CFM != 0)
+        {
+            ut[t] = (ex->motors_on ? ue : T(0)) + ex->tau_b[t];
+            ue_out = ue + ex->uemit_b[t];
+        }
         if (emit && lead)
         {
             if (A.u_motor) A.u_motor[(unsigned)m * B32 + r32] = um;
-            if (A.u) A.u[(unsigned)Tp::idx_v[Tp::trunk_joint[t]] * B32 + r32] = ue;
+            if (A.u) A.u[(unsigned)Tp::idx_v[Tp::trunk_joint[t]] * B32 + r32] = ue_out;
             if constexpr (Tp::QHAS_EFF)
                 if (sensors && A.effort) A.effort[(unsigned)Tp::trunk_eff[t] * B32 + r32] = um;
         }
@@ -703,6 +777,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             Us[s] = U; dinv[s] = di; u[s] = uj;
             if constexpr (KEEP_SC) { Ss[s] = S; cs[s] = c; }
             else as[s] = a;
+            if constexpr (KEEP::ON) { keep->ps[s] = ps[s]; keep->as[s] = a; keep->Us[s] = U; keep->dinv[s] = di; }
         });
     }
     // ---- child -> parent reduction over the 4 limbs (the only cross-lane step of the dynamics)
@@ -784,6 +859,17 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         chol6_solve(M, b);
 #pragma unroll
         for (int i = 0; i < 6; ++i) ddqb[i] = b[i];
+        if constexpr (KEEP::ON)
+        {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+            {
+#pragma unroll
+                for (int c = 0; c <= i; ++c) keep->rootL[i][c] = M[i][c];
+                keep->rootdinv[i] = rcp_(M[i][i]);
+            }
+            keep->Rt = Rs[N - 1]; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1; keep->agf1 = agf1;
+        }
     }
     if (want_energy)
     {
@@ -880,6 +966,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             vp = vp + vj;
         }
     });
+    if constexpr (KEEP::ON)
+    {
+        keep->atip = ap;
+        if (ts_out) *ts_out = TS;
+    }
     {
         bool bad = false;
         static_for<0, I::NVB>([&](auto ic) { bad |= (ddqb[decltype(ic)::value] != ddqb[decltype(ic)::value]); });
@@ -893,9 +984,10 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 // from the state here so that nothing of the dynamics evaluation has to stay live for it.
 // Root coordinates again: body forces add up along the tree, each joint's wrench is rotated into
 // its own frame only when it is stored.
-template<class T, class Tp, class X>
+template<class T, class Tp, class X, int CFM = 0>
 JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r32, int k, const QIdx<Tp> & ix,
-                             const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq)
+                             const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq,
+                             const QExtra<T, Tp> * ex = nullptr)
 {
     using L = Layout<Tp>;
     using Q = QLayout<Tp>;
@@ -938,12 +1030,27 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     {
         auto one_contact = [&](int c) {
             const V3<T> pc = Rs[N - 1] * LT.v3(Q::CONTACT + c * Q::QC + 9) + ps[N - 1];
-            const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
-            if (c < ix.nc && depth < T(0))
+            if constexpr (CFM == 0)
             {
-                const V3<T> fR = tmul(R1, contact_law<T, Tp>(P, depth, R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc))));
-                fext.l = fext.l + fR;
-                fext.a = fext.a + cross(pc, fR);
+                const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+                if (c < ix.nc && depth < T(0))
+                {
+                    const V3<T> fR = tmul(R1, contact_law<T, Tp>(P, depth, R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc))));
+                    fext.l = fext.l + fR;
+                    fext.a = fext.a + cross(pc, fR);
+                }
+            }
+            else if (c < ix.nc)
+            {
+                // constraint contact model: the multipliers of the enabled contact constraints
+                const unsigned ci = (unsigned)(int)LT(Q::CONTACT + c * Q::QC + Q::C_IDX);
+                if (ex->flags[((unsigned)ex->nb + ci) * B32 + r32] & 1)
+                {
+                    const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
+                    const V3<T> fR = tmul(R1, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
+                    fext.l = fext.l + fR;
+                    fext.a = fext.a + cross(pc, fR) + ex->lam[o + 3 * B32] * V3<T>{R1.m20, R1.m21, R1.m22};
+                }
             }
         };
         if constexpr (Tp::QCL <= 2)
@@ -1064,9 +1171,27 @@ template<class T> JM_DEV void integrate_freeflyer(const T * q, const T * d, T * 
     qo[3] = x * al; qo[4] = y * al; qo[5] = z * al; qo[6] = ww * al;
 }
 
-// one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.
-template<class T, class Tp, class X, int SL, int SB>
-JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S)
+// constraint contact model on this decomposition (jm_qcon.h)
+template<class Tp> constexpr int qcon_first_contact_row()   // = number of bounded joints (ConRows<Tp>::NB)
+{
+    int n = 0;
+    for (int j = 1; j < Tp::NJ; ++j) n += jt_bounded(Tp::jtype[j]) ? 1 : 0;
+    return n;
+}
+template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_contact_row<Tp>(); }   // ConRows<Tp>::LAM
+template<class T> struct QConArgs;
+template<class T> struct QStore;
+template<class T, class Tp, class X, bool EMIT, class SB>
+JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
+                          unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
+                          const T * vl, const T * cmdb, const T * cmdl, bool sensors, T * ddqb, T * ddq, int & status,
+                          int start_passes);
+
+// one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.  QCON: every evaluation is the
+// constrained one (`C` / `V`: constraint state and the robot's solver region).
+template<class T, class Tp, class X, int SL, int SB, bool QCON = false>
+JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S,
+                          const QConArgs<T> * C = nullptr, const QStore<T> * V = nullptr)
 {
     using Q = QLayout<Tp>;
     using R = QRows<Tp>;
@@ -1246,6 +1371,17 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             }
         }
     };
+    const int start_passes = (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0);
+    auto evaluate = [&](auto emit_c, unsigned rr, bool sens) {
+        constexpr bool EM = decltype(emit_c)::value;
+        if constexpr (QCON)
+            quad_eval_con<T, Tp, X, EM>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, sens, ddqb, ddq, status, start_passes);
+        else
+        {
+            (void)start_passes;
+            quad_eval<T, Tp, X, EM>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, sens, ddqb, ddq, status);
+        }
+    };
     // The n-1 output-free evaluations run in the hot loop; the last one (outputs, sensors, optional
     // extra terms) is peeled off so that its register pressure does not leak into the loop.
 #pragma nounroll
@@ -1258,7 +1394,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         unsigned rr = r32;
         JM_OPAQUE(rr);
         advance(st, false, rr);
-        quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        evaluate(std::false_type{}, rr, false);
     }
     {
         const int e = n_evals - 1;
@@ -1268,10 +1404,9 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         JM_OPAQUE(rr);
         advance(st, true, rr);
         if (A.mode != MODE_DYNAMICS)
-            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
-                                      (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
+            evaluate(std::true_type{}, rr, (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0);
         else
-            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+            evaluate(std::false_type{}, rr, false);
         T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
         if (lead) static_for<0, NVB>([&](auto ic) { adst[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = ddqb[decltype(ic)::value]; });
         static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) adst[(unsigned)ix.rv[decltype(sc)::value] * B32 + rr] = ddq[decltype(sc)::value]; });
@@ -1286,7 +1421,15 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                 static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
                 static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
                 static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-                quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
+                if constexpr (QCON)
+                {
+                    QExtra<T, Tp> ex;
+                    ex.flags = C->flags;
+                    ex.nb = qcon_first_contact_row<Tp>();
+                    ex.lam = C->data + (size_t)qcon_first_lambda_row<Tp>() * B32;
+                    quad_extra_terms<T, Tp, X, 2>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq, &ex);
+                }
+                else quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
             }
         }
     }

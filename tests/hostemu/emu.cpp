@@ -12,6 +12,7 @@
 #include JM_TOPO_HEADER
 #include "../../jiminy_amd/csrc/jm_kernels.h"
 #include "../../jiminy_amd/csrc/jm_constraint.h"
+#include "../../jiminy_amd/csrc/jm_qcon.h"
 #include "../../jiminy_amd/csrc/jm_pack.h"
 
 extern "C"
@@ -90,6 +91,39 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
     else { (void)A; (void)P; }
 }
 
+// branch-parallel kernel with the constraint contact model (jm_qcon.h): the robot's solver region is split
+// between a small "on-chip" array and overflow rows, so that both homes of QStore are exercised
+template<class T, class Tp> static void run_quad_con(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
+{
+    if constexpr (Tp::QUAD)
+    {
+        QuadShared sh;
+        pthread_barrier_init(&sh.bar, nullptr, 4);
+        const T * table = P.data() + jm::QLayout<Tp>::OFFSET;
+        constexpr int CAP = 37;
+        const int rows = jm::QConRows<Tp>::ws_rows(CAP);
+        std::vector<T> lds((size_t)(CAP + 1) * A.B, (T)std::nan("")), hbm((size_t)(rows + 1) * A.B, (T)std::nan(""));
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k]() {
+                HostQuad::sh = &sh;
+                HostQuad::k = k;
+                std::vector<T> sl(jm::QRows<Tp>::NL + 1), sb(jm::QRows<Tp>::NB + 1);
+                const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};
+                for (long long r = 0; r < A.B; ++r)
+                {
+                    jm::QConArgs<T> C = C0;
+                    C.ws = hbm.data();
+                    const jm::QStore<T> V{lds.data() + (size_t)r * CAP, hbm.data() + r, (unsigned)A.B, CAP};
+                    jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true>(A, r, k, table, S, &C, &V);
+                }
+            });
+        for (auto & t : th) t.join();
+        pthread_barrier_destroy(&sh.bar);
+    }
+    else { (void)A; (void)P; (void)C0; }
+}
+
 // constraint contact model: options + per-lane state rows (flags int32 [NF][B], data [ND][B]); the
 // delassus workspace is allocated here
 static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
@@ -136,7 +170,18 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.update_sensors = update_sensors; A.dt = (T)dt;
     if (g_variant == 1 && Topo::QUAD)
     {
-        run_quad<T, Topo>(A, P);
+        if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
+        {
+            jm::QConArgs<T> C;
+            C.flags = (int32_t *)g_con_flags; C.data = (T *)g_con_data; C.ws = nullptr;
+            C.friction = (const T *)g_friction;
+            const double omega = 2.0 * 3.14159265358979323846 * g_copt.stabilization_freq;
+            C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
+            C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
+            C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
+            run_quad_con<T, Topo>(A, P, C);
+        }
+        else run_quad<T, Topo>(A, P);
         return 0;
     }
     std::vector<T> sb(jm::stage_rows<Topo>() + 1);
