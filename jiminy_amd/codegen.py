@@ -166,6 +166,7 @@ def topology_header(model: CompiledModel) -> str:
         "// GENERATED by jiminy_amd/codegen.py -- robot topology traits (no numeric parameters).",
         f"// model: {model.name}",
         "#pragma once",
+        f"#define JM_TOPO_QUAD {1 if quad_structure(model) is not None else 0}",
         "// The struct name carries the topology hash so that two topology libraries loaded in the",
         "// same process never share (STB_GNU_UNIQUE / weak) template instantiations.",
         f"struct Topo_{model.topology_hash()}",
@@ -313,15 +314,16 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
         raise RuntimeError(
             f"hipcc not found ({HIPCC}); cannot build the HIP library for topology "
             f"{model.topology_hash()} and no prebuilt {lib} exists")
-    # two translation units compiled in parallel (the constraint-model kernel is the longest single compile
+    # three translation units compiled in parallel (the constraint-model kernels are the longest single compiles
     # of a large topology), then linked into one shared library
     common = [f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"]
     common += list(BUILD_VARIANTS[v])
     common += extra_flags or []
-    objs = [lib + ".main.o", lib + ".con.o"]
+    objs = [lib + ".main.o", lib + ".con.o", lib + ".qcon.o"]
     cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]],
-            [HIPCC] + common + ["-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[1]]]
+            [HIPCC] + common + ["-DJM_CON_PART=1", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[1]],
+            [HIPCC] + common + ["-DJM_CON_PART=2", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[2]]]
     if verbose:
         for c in cmds:
             print(" ".join(c))

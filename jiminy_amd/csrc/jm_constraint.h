@@ -125,8 +125,20 @@ template<int NW> struct RowMaskN
 #pragma unroll
         for (int i = 0; i < NW; ++i) w[i] = 0ull;
     }
-    JM_DEV bool test(int r) const { return (w[r >> 6] >> (r & 63)) & 1ull; }
-    JM_DEV void set(int r) { w[r >> 6] |= 1ull << (r & 63); }
+    // (value-level selects over the words: a run-time index would turn the mask into a private-memory array)
+    JM_DEV bool test(int r) const
+    {
+        unsigned long long x = w[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) x = (r >> 6) == i ? w[i] : x;
+        return (x >> (r & 63)) & 1ull;
+    }
+    JM_DEV void set(int r)
+    {
+        const unsigned long long bit = 1ull << (r & 63);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] |= (NW == 1 || (r >> 6) == i) ? bit : 0ull;
+    }
     JM_DEV bool any() const
     {
         unsigned long long o = 0ull;

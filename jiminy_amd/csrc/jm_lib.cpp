@@ -24,6 +24,7 @@
 
 #include "jm_kernels.h"
 #include "jm_constraint.h"
+#include "jm_qcon.h"
 #include "jm_pack.h"
 #include "jm_blocks.h"
 #include "jm_adaptive.h"
@@ -36,6 +37,9 @@
 namespace jm
 {
 extern template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
+#if JM_TOPO_QUAD
+extern template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+#endif
 }
 #endif
 
@@ -113,6 +117,20 @@ int32_t upload_params(jm_batch * b)
     return JM_OK;
 }
 
+// rows of the caller-owned constraint workspace: overflow of the per-robot solver region (branch-parallel
+// kernel) or the dense per-lane delassus workspace (one-robot-per-lane kernel)
+template<class Tp> int32_t constraint_ws_rows_of(const jm_batch * b)
+{
+    if constexpr (Tp::QUAD)
+        if (b->variant == VARIANT_QUAD)
+        {
+            const int rows = jm::qcon_ws_rows<double, Tp>();
+            return rows > 0 ? rows : 1;
+        }
+    return jm::ConRows<Tp>::WTOTAL;
+}
+int32_t constraint_ws_rows(const jm_batch * b) { return constraint_ws_rows_of<Topo>(b); }
+
 template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
 {
     jm::BatchArgs<T> A;
@@ -152,6 +170,22 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
     else { (void)b; (void)A; (void)s; }
 }
 
+// constraint contact model on the branch-parallel decomposition (jm_qcon.h)
+template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A, const jm::ConArgs<double> & C0, hipStream_t s)
+{
+    if constexpr (Tp::QUAD)
+    {
+        jm::QConArgs<double> C;
+        C.flags = C0.flags; C.data = C0.data; C.ws = C0.ws; C.friction = C0.friction;
+        C.kp = C0.kp; C.kd = C0.kd; C.torsion = C0.torsion; C.reg = C0.reg; C.tol_abs = C0.tol_abs; C.tol_rel = C0.tol_rel;
+        C.iter_max = C0.iter_max;
+        constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
+        const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
+        hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+    }
+    else { (void)b; (void)A; (void)C0; (void)s; }
+}
+
 template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stream)
 {
     HIP_TRY(hipSetDevice(b->device));
@@ -188,7 +222,8 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             C.xl = nullptr; C.xstride = 0;  // set by the kernel (LDS)
             C.yl = nullptr; C.ystride = 0; C.yrows = 0;
             C.park = nullptr; C.park_rows = 0;
-            hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
+            if (Topo::QUAD && b->variant == VARIANT_QUAD && R::NR > 0) launch_quad_con<Topo>(b, A, C, s);
+            else hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
         }
         else return fail(JM_ENOTIMPL, "contacts.model = 'constraint' needs a float64 batch");
     }
@@ -405,7 +440,7 @@ int32_t jm_batch_set_options(jm_batch * b, const jm_options * o)
 }
 int32_t jm_batch_workspace_rows(const jm_batch * b)
 {
-    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? jm::ConRows<Topo>::WTOTAL : 0;
+    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? constraint_ws_rows(b) : 0;
 }
 int32_t jm_batch_set_constraint_options(jm_batch * b, const jm_constraint_options * o)
 {
@@ -429,7 +464,7 @@ int32_t jm_batch_constraint_rows(const jm_batch * b, int32_t * n_flag_rows, int3
     using R = jm::ConRows<Topo>;
     if (n_flag_rows) *n_flag_rows = R::NF;
     if (n_data_rows) *n_data_rows = R::ND;
-    if (n_workspace_rows) *n_workspace_rows = R::WTOTAL;
+    if (n_workspace_rows) *n_workspace_rows = constraint_ws_rows(b);
     return JM_OK;
 }
 int32_t jm_batch_bind(jm_batch * b, int32_t field, void * ptr)
@@ -497,7 +532,7 @@ int32_t jm_batch_step(jm_batch * b, int32_t solver, double dt, int32_t n_substep
 // ---- adaptive Dormand-Prince stepping (jm_adaptive.h)
 int32_t jm_batch_adaptive_workspace_rows(const jm_batch * b)
 {
-    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? jm::AdaptiveRows<Topo>::TOTAL_CON
+    return (b && b->copt.contact_model == JM_CONTACT_CONSTRAINT) ? jm::AdaptiveRows<Topo>::CWS + constraint_ws_rows(b)
                                                                  : jm::AdaptiveRows<Topo>::TOTAL;
 }
 int32_t jm_batch_bind_adaptive(jm_batch * b, void * workspace, double * state_f64, int32_t * state_i32)

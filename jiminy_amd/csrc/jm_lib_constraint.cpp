@@ -1,6 +1,8 @@
-// jm_lib_constraint.cpp -- second translation unit of the per-topology HIP library: the constraint-model
-// kernel (jm_constraint.h), compiled in parallel with jm_lib.cpp (which declares the same instantiation
-// `extern` under -DJM_SPLIT_CONSTRAINT) because it is the longest single compile of a large topology.
+// jm_lib_constraint.cpp -- further translation units of the per-topology HIP library: the constraint-model
+// kernels, compiled in parallel with jm_lib.cpp (which declares the same instantiations `extern` under
+// -DJM_SPLIT_CONSTRAINT) because they are the longest single compiles of a large topology.
+//   -DJM_CON_PART=1  k_constrained (jm_constraint.h, one robot per lane: trees without the 4-limb structure)
+//   -DJM_CON_PART=2  k_quad_con    (jm_qcon.h, branch-parallel: ANYmal, Atlas, ...)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -10,8 +12,13 @@
 
 #include "jm_kernels.h"
 #include "jm_constraint.h"
+#include "jm_qcon.h"
 
 namespace jm
 {
+#if JM_CON_PART == 1
 template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
+#elif JM_CON_PART == 2 && JM_TOPO_QUAD
+template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+#endif
 }

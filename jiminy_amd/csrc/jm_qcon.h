@@ -41,6 +41,14 @@
 #include "jm_quad.h"
 #include "jm_constraint.h"
 
+#ifndef JM_QCON_SKIP
+#define JM_QCON_SKIP 0   // profiling only: bit 0 skip the PGS sweeps, 1 the delassus rounds, 2 the closing evaluation
+#endif
+#ifndef JM_QCON_DELTA
+#define JM_QCON_DELTA 0  // 1: evaluations that emit nothing apply the multipliers with one bias-free solve instead of the closing
+                         // full evaluation (cheaper arithmetic, but it keeps the free evaluation's data live across the PGS
+                         // sweeps: measured slower on ANYmal because the sweeps then spill)
+#endif
 #ifndef JM_QCON_MAXM
 #define JM_QCON_MAXM 64  // most active constraint rows solved per robot (rows beyond it are dropped and flagged)
 #endif
@@ -61,8 +69,15 @@ template<class Tp> struct QConRows
 {
     using R = ConRows<Tp>;
     static constexpr int MAXM = R::NR < JM_QCON_MAXM ? R::NR : JM_QCON_MAXM;
-    // per-robot solver region: x | b | y | packed lower triangle of A
-    static constexpr int VMAX = 3 * MAXM + MAXM * (MAXM + 1) / 2;
+    // per-robot solver region: x | b | y | 1 / diag(A) | packed lower triangle of A
+    static constexpr int VMAX = 4 * MAXM + MAXM * (MAXM + 1) / 2;
+    // largest solve that fits entirely in `cap` scalars
+    static constexpr int mfit(int cap)
+    {
+        int m = 0;
+        while (m < MAXM && 4 * (m + 1) + (m + 1) * (m + 2) / 2 <= cap) ++m;
+        return m;
+    }
     // workspace rows in HBM for a given on-chip capacity (scalars per robot)
     static constexpr int ws_rows(int cap) { return VMAX > cap ? VMAX - cap : 0; }
     // 64-bit words of the row masks
@@ -80,12 +95,24 @@ template<class Tp> struct QConRows
 // per-robot solver region: the first `cap` scalars on chip, the rest in the workspace rows
 template<class T> struct QStore
 {
+    static constexpr bool ON_CHIP = false;
+    static constexpr int NIT = 1;
     T * lds;
     T * hbm;       // already offset by the robot index
     unsigned B;
     int cap;
     JM_DEV T get(int e) const { return e < cap ? lds[e] : hbm[(unsigned)(e - cap) * B]; }
     JM_DEV void put(int e, T x) const { if (e < cap) lds[e] = x; else hbm[(unsigned)(e - cap) * B] = x; }
+};
+// the same region when the whole solve of the robot fits on chip (the common case: ANYmal with up to 16
+// active rows): no per-access branch, so that the loads of one row update are issued together
+template<class T, int NIT_> struct QStoreChip
+{
+    static constexpr bool ON_CHIP = true;
+    static constexpr int NIT = NIT_;   // quarter-sum terms per lane: the store holds solves of up to 4 * NIT rows
+    T * lds;
+    JM_DEV T get(int e) const { return lds[e]; }
+    JM_DEV void put(int e, T x) const { lds[e] = x; }
 };
 JM_DEV int tri_(int i, int c) { return i >= c ? i * (i + 1) / 2 + c : c * (c + 1) / 2 + i; }
 
@@ -266,21 +293,19 @@ JM_DEV Sp<T> limb_pull(const QKeep<T, Tp> & K, const QIdx<Tp> & ix, const T * u,
     return ap;
 }
 
-// trunk tree for ONE lane's own column: bias force `f_in` enters at trunk joint `t_in` (0 = the root), joint
-// efforts tau_b[t]; returns the spatial accelerations of the trunk joints (at[0] = root) and their joint
+// trunk tree, bias-free: bias forces `accF[t]` enter at the trunk joints (0 = the root), joint efforts tau_b[t];
+// (a lane's own delassus column: one non-zero entry; the closing solve: the quad sums of the four limbs) returns the spatial accelerations of the trunk joints (at[0] = root) and their joint
 // accelerations ddb[t].  The TrunkStore broadcasts are executed by the four lanes together (uniform code).
 template<class T, class Tp, class X>
-JM_DEV void trunk_column(CPtr<T> P, const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, int t_in, Sp<T> f_in, const T * tau_b,
+JM_DEV void trunk_column(CPtr<T> P, const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, Sp<T> * accF, const T * tau_b,
                          Sp<T> * at, T * ddb)
 {
     using QR = QConRows<Tp>;
     constexpr int NT = Tp::QT;
     T ub[NT];
     ub[0] = T(0);
-    // leaves -> root: the force travels along the chain of ancestors of t_in (plus the efforts of the joints
-    // themselves); a single running 6-vector per parent level
-    Sp<T> accF[NT];
-    static_for<0, NT>([&](auto tc) { accF[decltype(tc)::value] = mask6(t_in == decltype(tc)::value, f_in); });
+    // leaves -> root: `accF[t]` = bias force entering trunk joint t from the limbs (plus, on the way, from its
+    // trunk children and the efforts of the joints themselves)
     static_rfor<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int tp = Tp::trunk_parent[t];
@@ -320,9 +345,9 @@ JM_DEV void trunk_column(CPtr<T> P, const QKeep<T, Tp> & K, const TrunkStore<T, 
 }
 
 // ---------------------------------------------------------------- delassus matrix, four columns per round
-template<class T, class Tp, class X>
+template<class T, class Tp, class X, class VS>
 JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, int k, const QIdx<Tp> & ix,
-                          const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, const QConCtx<T, Tp> & cx, const QStore<T> & V)
+                          const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, const QConCtx<T, Tp> & cx, const VS & V)
 {
     using Q = QLayout<Tp>;
     using R = ConRows<Tp>;
@@ -330,7 +355,7 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
     using I = QInfo<Tp>;
     constexpr int N = Tp::QN, NT = Tp::QT;
     const int m = cx.m;
-    const int A0 = 3 * m;
+    const int A0 = 4 * m;
     typename QConCtx<T, Tp>::RowMask rem = cx.mine;
     // acceleration of the joint this lane's limb hangs from, out of the trunk accelerations of column lane `c`
     while (X::quad_or(rem.any() ? 1 : 0))
@@ -381,7 +406,11 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
         const Sp<T> fbase = limb_push<T, Tp>(K, tau_l, fu, ul);
         Sp<T> at[NT];
         T ddb[NT];
-        trunk_column<T, Tp, X>(P, K, TS, on_trunk ? -1 : ix.attach, mask6(!on_trunk, fbase), tau_b, at, ddb);
+        {
+            Sp<T> accF[NT];
+            static_for<0, NT>([&](auto tc) { accF[decltype(tc)::value] = mask6(!on_trunk && ix.attach == decltype(tc)::value, fbase); });
+            trunk_column<T, Tp, X>(P, K, TS, accF, tau_b, at, ddb);
+        }
         // rows of the trunk-tree joints: every lane writes the entries of ITS column
         if (r >= 0)
             static_for<1, NT>([&](auto tc) {
@@ -455,10 +484,10 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
 
 // ---------------------------------------------------------------- right-hand side and warm start
 // b = -(drift + J a_free) for the rows this lane owns (Baumgarte terms: abstract_constraint.cc:88-98), x = lambda
-template<class T, class Tp>
+template<class T, class Tp, class VS>
 JM_DEV void qcon_rhs(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k,
                      const QIdx<Tp> & ix, const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq,
-                     const QKeep<T, Tp> & K, const QConCtx<T, Tp> & cx, const QStore<T> & V)
+                     const QKeep<T, Tp> & K, const QConCtx<T, Tp> & cx, const VS & V)
 {
     using Q = QLayout<Tp>;
     using R = ConRows<Tp>;
@@ -517,9 +546,9 @@ JM_DEV void qcon_rhs(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, 
     (void)P;
 }
 // multipliers back to the per-lane constraint state (rows this lane owns)
-template<class T, class Tp>
+template<class T, class Tp, class VS>
 JM_DEV void qcon_scatter(const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k, const QIdx<Tp> & ix,
-                         const QConCtx<T, Tp> & cx, const QStore<T> & V)
+                         const QConCtx<T, Tp> & cx, const VS & V)
 {
     using Q = QLayout<Tp>;
     using R = ConRows<Tp>;
@@ -551,24 +580,49 @@ JM_DEV void qcon_scatter(const LimbTable<T> & LT, const QConArgs<T> & C, unsigne
 }
 
 // ---------------------------------------------------------------- solvers (the four lanes of the quad together)
-// sum_c A[i][c] x[c]: every lane takes the columns c = k, k+4, ... ; one butterfly adds the quarters
-template<class T, class X> JM_DEV T qcon_dot(const QStore<T> & V, int m, int i, int k)
-{
-    const int A0 = 3 * m;
-    T s = T(0);
-    for (int c = k; c < m; c += 4) s += V.get(A0 + tri_(i, c)) * V.get(c);
-    return X::quad_sum(s);
-}
 // PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333) over the m packed rows: `nb` joint
-// bounds, then blocks of `cb` rows (x, y, z[, torsion]) per active contact
-template<class T, class Tp, class X>
-JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, Tp> & cx, const QStore<T> & V)
+// bounds, then blocks of `cb` rows (x, y, z[, torsion]) per active contact.  One row update: every lane of the
+// quad sums the columns c = k, k+4, ... of `A.col(i).dot(x)`, one butterfly adds the quarters, the lead lane
+// projects and stores the multiplier.  With the on-chip store (VS::ON_CHIP: the whole solve fits in LDS, at most
+// 4 * VS::NIT rows) the quarter sums are unrolled and branch-free, so that all the LDS reads of a row update are
+// in flight together; the update uses the reciprocal of the diagonal, computed once per solve.
+template<class T, class Tp, class X, class VS>
+JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, Tp> & cx, const VS & V)
 {
-    const int m = cx.m, nb = cx.nb, cb = cx.cb, A0 = 3 * m;
+    const int m = cx.m, nb = cx.nb, cb = cx.cb, A0 = 4 * m;
     const bool lead = (k == 0);
     const T eps = Eps<T>::eps;
     const bool friction_zero = friction < eps;
     const unsigned iter_max = (unsigned)C.iter_max;
+    // 1 / diag(A), once per solve
+    X::sync();
+    for (int i = k; i < m; i += 4) V.put(3 * m + i, T(1) / V.get(A0 + tri_(i, i)));
+    X::sync();
+    constexpr int NIT = VS::NIT;
+    int tric[NIT];   // c (c + 1) / 2 of this lane's columns
+    static_for<0, NIT>([&](auto jc) { const int c = k + 4 * decltype(jc)::value; tric[decltype(jc)::value] = c * (c + 1) / 2; });
+    auto col_dot = [&](int i) {
+        T s = T(0);
+        if constexpr (VS::ON_CHIP)
+        {
+            const int rowbase = A0 + i * (i + 1) / 2;
+            T a[NIT], xv[NIT];
+            static_for<0, NIT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int c = k + 4 * j;
+                const bool valid = c < m;
+                a[j] = V.get(valid ? (c <= i ? rowbase + c : A0 + tric[j] + i) : 0);
+                xv[j] = V.get(valid ? c : 0);
+            });
+            static_for<0, NIT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                s = (k + 4 * j < m) ? s + a[j] * xv[j] : s;
+            });
+        }
+        else
+            for (int c = k; c < m; c += 4) s += V.get(A0 + tri_(i, c)) * V.get(c);
+        return X::quad_sum(s);
+    };
     for (unsigned iter = 0; iter < iter_max; ++iter)
     {
         T dmax = T(0), ymax = T(0);
@@ -581,8 +635,9 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
             if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
         }
         auto residual = [&](int i) {
-            const T y = V.get(m + i) - qcon_dot<T, X>(V, m, i, k);
+            const T y = V.get(m + i) - col_dot(i);
             dmax = fmax_(dmax, cabs_(y - V.get(2 * m + i)));
+            ymax = fmax_(ymax, cabs_(y));
             X::sync();
             if (lead) V.put(2 * m + i, y);
             return y;
@@ -592,7 +647,7 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
         {
             const int i0 = r < nb ? r : r + 2;
             const T y = residual(i0);
-            const T e = V.get(i0) + w * y / V.get(A0 + tri_(i0, i0));
+            const T e = V.get(i0) + (w * y) * V.get(3 * m + i0);
             X::sync();
             if (lead) V.put(i0, fmax_(e, T(0)));  // clamp(e, 0, inf)
             X::sync();
@@ -610,7 +665,7 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
                     continue;
                 }
                 const T y = residual(i0);
-                const T e = V.get(i0) + w * y / V.get(A0 + tri_(i0, i0));
+                const T e = V.get(i0) + (w * y) * V.get(3 * m + i0);
                 const T thr = C.torsion * V.get(r + 2);
                 X::sync();
                 if (lead) V.put(i0, clamp_(e, -thr, thr));
@@ -628,10 +683,10 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
             }
             const T y0 = residual(r);
             const T y1 = residual(r + 1);
-            const T a00 = V.get(A0 + tri_(r, r)), a11 = V.get(A0 + tri_(r + 1, r + 1));
-            const T a_max = a11 > a00 ? a11 : a00;
-            T e0 = V.get(r) + w * y0 / a_max;
-            T e1 = V.get(r + 1) + w * y1 / a_max;
+            // 1 / max(a00, a11)
+            const T ia = fmin_(V.get(3 * m + r), V.get(3 * m + r + 1));
+            T e0 = V.get(r) + (w * y0) * ia;
+            T e1 = V.get(r + 1) + (w * y1) * ia;
             const T thr = friction * V.get(r + 2);
             const T n2 = e0 * e0 + e1 * e1;
             if (n2 > thr * thr)
@@ -644,19 +699,212 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
             if (lead) { V.put(r, e0); V.put(r + 1, e1); }
             X::sync();
         }
-        // stagnation of the residuals (constraint_solvers.cc:263-278)
-        for (int r = 0; r < m; ++r) ymax = fmax_(ymax, cabs_(V.get(2 * m + r)));
+        // stagnation of the residuals (constraint_solvers.cc:263-278); a row that the sweep did not touch kept
+        // its residual of zero, so the running maxima equal the reference's sweeps over the whole vector
         const T tol = C.tol_abs + C.tol_rel * ymax + eps;
         if (dmax < tol) return true;
     }
     return false;
 }
+// The same solver for a robot whose whole solve is on chip (at most MR = 4 * NIT rows: ANYmal 16), run out of
+// REGISTERS: every lane loads its quarter of the columns of A (A[i][k + 4j], i < MR, j < NIT), and a full copy
+// of x, b, y and 1 / diag(A), once; the sweeps are unrolled on the PACKED row index, so that every operand is
+// a register with a compile-time index and the only cross-lane traffic of a row update is the quad butterfly
+// of its quarter sums -- no LDS access, no address arithmetic inside the sweeps.  Which packed rows are joint
+// bounds / normal forces, torsion rows or the first row of a friction pair is decided once per solve (three
+// bit masks); a row that is none of these for any robot of the wave is skipped by a uniform branch.
+template<class T, class Tp, class X, int NIT>
+JM_DEV bool qcon_pgs_regs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, Tp> & cx, T * Lr)
+{
+    constexpr int MR = 4 * NIT;
+    const int m = cx.m, nb = cx.nb, cb = cx.cb, A0 = 4 * m;
+    const bool lead = (k == 0);
+    const T eps = Eps<T>::eps;
+    const bool friction_zero = friction < eps, torsion_zero = C.torsion < eps;
+    const unsigned iter_max = (unsigned)C.iter_max;
+    // registers: this lane's quarter of the columns of A; x and 1 / diag(A) replicated in the four lanes; b and the
+    // residuals of the rows i = k (mod 4) only (their owner lane computes the residual and broadcasts it)
+    T Aq[MR][NIT], x[MR], invd[MR], xq[NIT], bq[NIT], yq[NIT];
+    X::sync();
+    // 1 / diag(A): every lane divides for its quarter of the rows, the quad shares them through the region
+    static_for<0, NIT>([&](auto jc) {
+        const int i = k + 4 * decltype(jc)::value;
+        if (i < m) Lr[3 * m + i] = T(1) / Lr[A0 + i * (i + 1) / 2 + i];
+    });
+    X::sync();
+    // rows that exist for some robot of the wave (scalar mask): the others cost one scalar test here, none later
+    unsigned rows_any = 0u;
+    static_for<0, MR>([&](auto ic) { rows_any |= X::wave_any(decltype(ic)::value < m) ? (1u << decltype(ic)::value) : 0u; });
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        x[i] = T(0); invd[i] = T(0);
+        static_for<0, NIT>([&](auto jc) { Aq[i][decltype(jc)::value] = T(0); });
+        if ((rows_any >> i) & 1u)
+        {
+            const bool vi = i < m;
+            const T xi = Lr[vi ? i : 0], di = Lr[vi ? 3 * m + i : 0];
+            x[i] = vi ? xi : T(0);
+            invd[i] = vi ? di : T(0);
+            const int rowbase = A0 + i * (i + 1) / 2;
+            static_for<0, NIT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int c = k + 4 * j;
+                const bool v = vi && c < m;
+                const T a = Lr[v ? (c <= i ? rowbase + c : A0 + c * (c + 1) / 2 + i) : 0];
+                Aq[i][j] = v ? a : T(0);
+            });
+        }
+    });
+    static_for<0, NIT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        xq[j] = k == 0 ? x[4 * j] : (k == 1 ? x[4 * j + 1] : (k == 2 ? x[4 * j + 2] : x[4 * j + 3]));
+        const int i = k + 4 * j;
+        const T bi = Lr[i < m ? m + i : 0];
+        bq[j] = i < m ? bi : T(0);
+        yq[j] = T(0);
+    });
+    // row kinds (bit i = packed row i): block 0 = bounds + normals, block 1 = torsion, block 2 = first row of a cone
+    unsigned mask0 = 0u, mask1 = 0u, mask2 = 0u;
+    for (int r = 0; r < m; r += (r < nb ? 1 : cb)) mask0 |= 1u << (r < nb ? r : r + 2);
+    if (cb == 4)
+        for (int r = nb; r < m; r += 4) mask1 |= 1u << (r + 3);
+    for (int r = nb; r < m; r += cb) mask2 |= 1u << r;
+    // the same three masks for the whole wave (scalars): a row position that no robot of the wave uses in a block
+    // costs one scalar bit test per sweep
+    unsigned any0 = 0u, any1 = 0u, any2 = 0u;
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        any0 |= X::wave_any((mask0 >> i) & 1u) ? (1u << i) : 0u;
+        any1 |= X::wave_any((mask1 >> i) & 1u) ? (1u << i) : 0u;
+        any2 |= X::wave_any((mask2 >> i) & 1u) ? (1u << i) : 0u;
+    });
+    const bool contacts_only = !X::wave_any(!(nb == 0 && cb == 3));
+    bool converged = false;
+#pragma nounroll
+    for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
+    {
+        T dmax = T(0), ymax = T(0);
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        auto residual = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            T s = T(0);
+            static_for<0, NIT>([&](auto jc) { s += Aq[i][decltype(jc)::value] * xq[decltype(jc)::value]; });
+            // the owner lane of row i (i mod 4) holds b and the previous residual; its result goes to the quad
+            const T mine = bq[i >> 2] - X::quad_sum(s);
+            const bool own = k == (i & 3);
+            dmax = X::max_abs(dmax, own ? mine - yq[i >> 2] : T(0));
+            ymax = X::max_abs(ymax, own ? mine : T(0));
+            yq[i >> 2] = own ? mine : yq[i >> 2];
+            return X::template bcast<(i & 3)>(mine);
+        };
+        auto set_x = [&](auto ic, T val) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            x[i] = val;
+            if (k == (i & 3)) xq[i >> 2] = val;
+        };
+        auto cone = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (friction_zero)
+            {
+                set_x(ic, x[i] * T(0));
+                set_x(std::integral_constant<int, i + 1>{}, x[i + 1] * T(0));
+            }
+            else
+            {
+                const T y0 = residual(ic);
+                const T y1 = residual(std::integral_constant<int, i + 1>{});
+                const T ia = fmin_(invd[i], invd[i + 1]);   // 1 / max(a00, a11)
+                T e0 = x[i] + (w * y0) * ia;
+                T e1 = x[i + 1] + (w * y1) * ia;
+                const T thr = friction * x[i + 2];
+                const T n2 = e0 * e0 + e1 * e1;
+                if (n2 > thr * thr)
+                {
+                    const T scale = thr / sqrt_(n2);
+                    e0 *= scale;
+                    e1 *= scale;
+                }
+                set_x(ic, e0);
+                set_x(std::integral_constant<int, i + 1>{}, e1);
+            }
+        };
+        if (contacts_only)
+        {
+            // every robot of the wave: no joint bound, 3-row contact blocks (robots standing / walking inside their
+            // joint ranges, contacts.torsion = 0): the row kinds are compile-time, no per-row mask tests
+            static_for<0, MR / 3>([&](auto jc) {
+                constexpr int i = 3 * decltype(jc)::value + 2;
+                if (i < m)
+                {
+                    const T yy = residual(std::integral_constant<int, i>{});
+                    set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+                }
+            });
+            static_for<0, MR / 3>([&](auto jc) {
+                constexpr int i = 3 * decltype(jc)::value;
+                if (i + 2 < m) cone(std::integral_constant<int, i>{});
+            });
+        }
+        else
+        {
+        // block 0
+        static_for<0, MR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any0 >> i) & 1u)
+                if ((mask0 >> i) & 1u)
+                {
+                    const T yy = residual(ic);
+                    set_x(ic, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+                }
+        });
+        // block 1: torsional friction, bounded by the normal force of the same contact (the row before)
+        static_for<1, MR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any1 >> i) & 1u)
+            if ((mask1 >> i) & 1u)
+            {
+                if (torsion_zero) set_x(ic, x[i] * T(0));
+                else
+                {
+                    const T yy = residual(ic);
+                    const T thr = C.torsion * x[i - 1];
+                    set_x(ic, clamp_(x[i] + (w * yy) * invd[i], -thr, thr));
+                }
+            }
+        });
+        // block 2: friction cone (rows i, i + 1; normal force = row i + 2)
+        static_for<0, MR - 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any2 >> i) & 1u)
+                if ((mask2 >> i) & 1u) cone(ic);
+        });
+        }
+        // (dmax / ymax: every lane saw its own rows)
+        dmax = X::max_(dmax, X::template perm_<0xB1>(dmax)); dmax = X::max_(dmax, X::template perm_<0x4E>(dmax));
+        ymax = X::max_(ymax, X::template perm_<0xB1>(ymax)); ymax = X::max_(ymax, X::template perm_<0x4E>(ymax));
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        converged = dmax < tol;
+    }
+    // multipliers back to the region (qcon_scatter reads them from there)
+    X::sync();
+    if (lead)
+        static_for<0, MR>([&](auto ic) { if (decltype(ic)::value < m) Lr[decltype(ic)::value] = x[decltype(ic)::value]; });
+    X::sync();
+    return converged;
+}
+
 // Exact solve A x = b (Engine::start's first pass, `ignoreBounds`: solveJMinvJtv): Cholesky in place in the
 // packed triangle -- the caller rebuilds the matrix afterwards.  Serial, lead lane only (start / reset only).
-template<class T, class X>
-JM_DEV bool qcon_chol(int k, int m, const QStore<T> & V)
+template<class T, class X, class VS>
+JM_DEV bool qcon_chol(int k, int m, const VS & V)
 {
-    const int A0 = 3 * m;
+    const int A0 = 4 * m;
     bool ok = true;
     X::sync();
     if (k == 0)
@@ -692,13 +940,93 @@ JM_DEV bool qcon_chol(int k, int m, const QStore<T> & V)
     return X::quad_or(ok ? 0 : 1) == 0;
 }
 
+// ---------------------------------------------------------------- multipliers applied: a += M^-1 J^T lambda
+// One bias-free solve of the whole robot by the quad (evaluations that emit nothing: the closing full
+// evaluation with the constraint forces would cost four times as much): every lane pushes the constraint forces
+// of ITS limb (bound multipliers as joint efforts, contact multipliers as a wrench on the tip) down to the
+// attachment joint, the quad sums enter the trunk tree, and the accelerations come back up.
+template<class T, class Tp, class X>
+JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k,
+                             const QIdx<Tp> & ix, const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, const QConCtx<T, Tp> & cx,
+                             T * ddqb, T * ddq, int & status)
+{
+    using Q = QLayout<Tp>;
+    using R = ConRows<Tp>;
+    using QR = QConRows<Tp>;
+    using I = QInfo<Tp>;
+    constexpr int N = Tp::QN, NT = Tp::QT;
+    auto lam = [&](int row) { return C.data[(unsigned)(R::LAM + row) * B32 + r32]; };
+    T tau_l[N], tau_b[NT];
+    static_for<0, N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const int row = sel4(k, QR::limb_row(0, s), QR::limb_row(1, s), QR::limb_row(2, s), QR::limb_row(3, s));
+        const bool on = row >= 0 && ix.has[s] && cx.act.test(row);
+        const T l = on ? lam(on ? row : 0) : T(0);
+        tau_l[s] = (on && cx.rev.test(row)) ? -l : l;
+    });
+    tau_b[0] = T(0);
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int row = QR::trunk_row(t);
+        tau_b[t] = T(0);
+        if constexpr (row >= 0)
+        {
+            const T l = cx.act.test(row) ? lam(row) : T(0);
+            tau_b[t] = cx.rev.test(row) ? -l : l;
+        }
+    });
+    Sp<T> ftip = zero6<T>();
+    auto contact = [&](int cl) {
+        if (cl >= ix.nc) return;
+        const int oc = Q::CONTACT + cl * Q::QC;
+        const int r0 = R::NB + 4 * (int)LT(oc + Q::C_IDX);
+        if (!cx.act.test(r0)) return;
+        const V3<T> pc = K.Rt * LT.v3(oc + 9) + K.ps[N - 1];
+        const V3<T> fR = tmul(K.R1, V3<T>{lam(r0), lam(r0 + 1), lam(r0 + 2)});
+        ftip.l = ftip.l + fR;
+        ftip.a = ftip.a + cross(pc, fR);
+        if (cx.cb == 4) ftip.a = ftip.a + lam(r0 + 3) * V3<T>{K.R1.m20, K.R1.m21, K.R1.m22};
+    };
+    if constexpr (Tp::QCL <= 2) static_for<0, Tp::QCL>([&](auto cc) { contact(decltype(cc)::value); });
+    else
+    {
+#pragma nounroll
+        for (int cl = 0; cl < Tp::QCL; ++cl) contact(cl);
+    }
+    T ul[N];
+    const Sp<T> fbase = limb_push<T, Tp>(K, tau_l, ftip, ul);
+    Sp<T> accF[NT];
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (I::limb_at(t))
+        {
+            if constexpr (I::uniform_attach) accF[t] = quad_sum6<T, X>(fbase);
+            else accF[t] = quad_sum6<T, X>(mask6(ix.attach == t, fbase));
+        }
+        else accF[t] = zero6<T>();
+    });
+    Sp<T> at[NT];
+    T ddb[NT];
+    trunk_column<T, Tp, X>(P, K, TS, accF, tau_b, at, ddb);
+    T dd[N];
+    (void)limb_pull<T, Tp>(K, ix, ul, true, pick_attach<T, Tp>(k, at), dd);
+    bool bad = false;
+    ddqb[0] += at[0].l.x; ddqb[1] += at[0].l.y; ddqb[2] += at[0].l.z;
+    ddqb[3] += at[0].a.x; ddqb[4] += at[0].a.y; ddqb[5] += at[0].a.z;
+    static_for<1, NT>([&](auto tc) { ddqb[5 + decltype(tc)::value] += ddb[decltype(tc)::value]; });
+    static_for<0, N>([&](auto sc) { ddq[decltype(sc)::value] += dd[decltype(sc)::value]; });
+    static_for<0, I::NVB>([&](auto ic) { bad |= (ddqb[decltype(ic)::value] != ddqb[decltype(ic)::value]); });
+    static_for<0, N>([&](auto sc) { bad |= ix.has[decltype(sc)::value] && (ddq[decltype(sc)::value] != ddq[decltype(sc)::value]); });
+    if (bad) status |= JM_LANE_NAN;
+}
+
 // ---------------------------------------------------------------- one constrained evaluation
 // `start_passes` > 0: Engine::start / reset sequence; < 0: MODE_REFRESH (re-apply the stored multipliers);
 // 0: a regular evaluation.  Leaves the constrained acceleration in ddqb / ddq.
-template<class T, class Tp, class X, bool EMIT, class SB>
+template<class T, class Tp, class X, class SB, int CAPC>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
-                          const T * vl, const T * cmdb, const T * cmdl, bool sensors, T * ddqb, T * ddq, int & status,
+                          const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
                           int start_passes)
 {
     using L = Layout<Tp>;
@@ -716,9 +1044,13 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     ex.lam = C.data + (size_t)R::LAM * B32;
     ex.nb = R::NB;
     status &= ~JM_LANE_SOLVER_FAILURE;
+    auto apply = [&]() __attribute__((always_inline)) {
+        if (emit) quad_eval<T, Tp, X, true, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, sensors, ddqb, ddq, status, &ex);
+        else quad_eval<T, Tp, X, false, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status, &ex);
+    };
     if constexpr (R::NR == 0)
     {
-        quad_eval<T, Tp, X, EMIT, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, sensors, ddqb, ddq, status, &ex);
+        apply();
         return;
     }
     const bool refresh = start_passes < 0;
@@ -751,30 +1083,46 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             any = cx.act.any();
             if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
             if (!any || refresh) break;
-            qcon_delassus<T, Tp, X>(P, LT, C, k, ix, K, TS, cx, V);
         }
-        X::sync();
-        qcon_rhs<T, Tp>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, V);
-        X::sync();
-        bool ok;
-        if (init && pass == 0)
+        // delassus matrix (first pass), right-hand side and warm start, solve, multipliers back to the lane state
+        auto phases = [&](const auto & W) __attribute__((always_inline)) {
+            using VS = std::decay_t<decltype(W)>;
+            if (pass == 0 && !(JM_QCON_SKIP & 2)) qcon_delassus<T, Tp, X, VS>(P, LT, C, k, ix, K, TS, cx, W);
+            X::sync();
+            qcon_rhs<T, Tp, VS>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
+            X::sync();
+            if (init && pass == 0)
+            {
+                const bool ok = qcon_chol<T, X, VS>(k, cx.m, W);
+                if (!ok) status |= JM_LANE_NAN;
+                X::sync();
+                qcon_scatter<T, Tp, VS>(LT, C, B32, r32, k, ix, cx, W);
+                X::sync();
+                qcon_delassus<T, Tp, X, VS>(P, LT, C, k, ix, K, TS, cx, W);   // the factorisation overwrote the matrix
+            }
+            else
+            {
+                bool ok = true;
+                if constexpr (VS::ON_CHIP)
+                {
+                    if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs_regs<T, Tp, X, VS::NIT>(C, friction, k, cx, W.lds);
+                }
+                else if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs<T, Tp, X, VS>(C, friction, k, cx, W);
+                if (ok) status &= ~JM_LANE_SOLVER_FAILURE;
+                else status |= JM_LANE_SOLVER_FAILURE;
+                if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
+                X::sync();
+                qcon_scatter<T, Tp, VS>(LT, C, B32, r32, k, ix, cx, W);
+            }
+        };
+        constexpr int MFIT = QR::mfit(CAPC);
+        if constexpr (MFIT >= 4)
         {
-            ok = qcon_chol<T, X>(k, cx.m, V);
-            if (!ok) status |= JM_LANE_NAN;
-            X::sync();
-            qcon_scatter<T, Tp>(LT, C, B32, r32, k, ix, cx, V);
-            X::sync();
-            qcon_delassus<T, Tp, X>(P, LT, C, k, ix, K, TS, cx, V);   // the factorisation overwrote the matrix
+            // the whole solve of this robot fits the on-chip part of its region (quad-uniform decision)
+            if (!init && cx.m <= MFIT) phases(QStoreChip<T, (MFIT + 3) / 4>{V.lds});
+            else phases(V);
         }
-        else
-        {
-            ok = qcon_pgs<T, Tp, X>(C, friction, k, cx, V);
-            if (ok) status &= ~JM_LANE_SOLVER_FAILURE;
-            else status |= JM_LANE_SOLVER_FAILURE;
-            if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
-            X::sync();
-            qcon_scatter<T, Tp>(LT, C, B32, r32, k, ix, cx, V);
-        }
+        else phases(V);
         X::sync();
         if (pass == n_pass - 1) break;
         // Engine::start: the next pass sees u = uInternal (bound multipliers of this pass, plus sign whatever the
@@ -791,8 +1139,13 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         });
     }
     // ---- nothing to enforce and nothing to emit: the free acceleration is the answer (engine.cc:3861-3865)
-    if constexpr (!EMIT)
-        if (!any) return;
+    if (!emit && !any && !init) return;
+    if (JM_QCON_DELTA && !emit && !init && !refresh && !(JM_QCON_SKIP & 4))
+    {
+        // nothing to emit: the free acceleration plus one bias-free solve with the multipliers
+        qcon_apply_delta<T, Tp, X>(P, LT, C, B32, r32, k, ix, K, TS, cx, ddqb, ddq, status);
+        return;
+    }
     // ---- apply the multipliers: articulated-body solve with the constraint forces; emits the outputs
     static_for<0, N>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -815,6 +1168,50 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         else { ex.tau_b[t] = uq_b[t]; ex.uemit_b[t] = T(0); }
     });
     ex.motors_on = true;
-    quad_eval<T, Tp, X, EMIT, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, sensors, ddqb, ddq, status, &ex);
+    if (!(JM_QCON_SKIP & 4)) apply();
 }
+
+#ifndef JM_HOST_EMU
+// ---------------------------------------------------------------- kernel configuration (host-visible)
+// waves per block and on-chip scalars per LANE of the per-robot solver region (a robot owns 4 lanes' worth):
+// what is left of the 160 KiB of LDS next to the limb table and the stage buffer at 4 resident waves per CU
+// (the kernel needs the whole register file: one wave per SIMD), capped by what the largest solve can use.
+template<class T, class Tp> constexpr int qcon_block_waves() { return quad_block_waves<T, Tp>(); }
+template<class T, class Tp> constexpr int qcon_lane_scalars()
+{
+    constexpr long W = 4;   // resident waves per CU
+    constexpr long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
+    constexpr long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
+    constexpr long blocks = W / qcon_block_waves<T, Tp>() > 0 ? W / qcon_block_waves<T, Tp>() : 1;
+    constexpr long left = 160L * 1024 - 2048 - blocks * table - W * per_wave;   // 2 KiB of slack (alignment, odd strides)
+    constexpr long per_lane = left > 0 ? left / (W * 64 * (long)sizeof(T)) : 0;
+    constexpr long want = (QConRows<Tp>::VMAX + 3) / 4;
+    return (int)(per_lane < want ? per_lane : want);
+}
+// on-chip scalars per robot / HBM workspace rows per robot
+template<class T, class Tp> constexpr int qcon_capacity() { return 4 * qcon_lane_scalars<T, Tp>(); }
+template<class T, class Tp> constexpr int qcon_ws_rows() { return QConRows<Tp>::ws_rows(qcon_capacity<T, Tp>()); }
+
+template<class T, class Tp>
+__global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
+{
+    using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * qcon_block_waves<T, Tp>();
+    constexpr int CAP = qcon_capacity<T, Tp>();
+    constexpr int RSTRIDE = (CAP % 2 == 0) ? CAP + 1 : CAP;   // odd: the 16 robots of a wave start in different banks
+    __shared__ T table[Q::TABLE];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+    __shared__ T con[(CAP > 0 ? RSTRIDE : 1) * (NTH / 4)];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    const QStore<T> V{con + (threadIdx.x >> 2) * RSTRIDE, C.ws + r, (unsigned)A.B, CAP};
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
+}
+#endif
 }  // namespace jm

@@ -1181,15 +1181,15 @@ template<class Tp> constexpr int qcon_first_contact_row()   // = number of bound
 template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_contact_row<Tp>(); }   // ConRows<Tp>::LAM
 template<class T> struct QConArgs;
 template<class T> struct QStore;
-template<class T, class Tp, class X, bool EMIT, class SB>
+template<class T, class Tp, class X, class SB, int CAPC>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
-                          const T * vl, const T * cmdb, const T * cmdl, bool sensors, T * ddqb, T * ddq, int & status,
+                          const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
                           int start_passes);
 
 // one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.  QCON: every evaluation is the
 // constrained one (`C` / `V`: constraint state and the robot's solver region).
-template<class T, class Tp, class X, int SL, int SB, bool QCON = false>
+template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0>
 JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S,
                           const QConArgs<T> * C = nullptr, const QStore<T> * V = nullptr)
 {
@@ -1371,17 +1371,27 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             }
         }
     };
-    const int start_passes = (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0);
-    auto evaluate = [&](auto emit_c, unsigned rr, bool sens) {
-        constexpr bool EM = decltype(emit_c)::value;
-        if constexpr (QCON)
-            quad_eval_con<T, Tp, X, EM>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, sens, ddqb, ddq, status, start_passes);
-        else
+    unsigned rr = r32;
+    if constexpr (QCON)
+    {
+        // constraint contact model: ONE call site of the (large) constrained evaluation, emitting or not at run time
+        const int start_passes = (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0);
+#pragma nounroll
+        for (int e = 0; e < n_evals; ++e)
         {
-            (void)start_passes;
-            quad_eval<T, Tp, X, EM>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, sens, ddqb, ddq, status);
+            const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+            const bool last = e == n_evals - 1;
+            JM_REFRESH();
+            rr = r32;
+            JM_OPAQUE(rr);
+            advance(st, last, rr);
+            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
+                                    (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status,
+                                    start_passes);
         }
-    };
+    }
+    else
+    {
     // The n-1 output-free evaluations run in the hot loop; the last one (outputs, sensors, optional
     // extra terms) is peeled off so that its register pressure does not leak into the loop.
 #pragma nounroll
@@ -1391,22 +1401,26 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         JM_REFRESH();
         // per-iteration opaque copy of the lane offset: the addresses of the commit stores must
         // not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
-        unsigned rr = r32;
-        JM_OPAQUE(rr);
-        advance(st, false, rr);
-        evaluate(std::false_type{}, rr, false);
+        unsigned rl = r32;
+        JM_OPAQUE(rl);
+        advance(st, false, rl);
+        quad_eval<T, Tp, X, false>(P, LT, A, rl, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
     }
     {
         const int e = n_evals - 1;
         const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
         JM_REFRESH();
-        unsigned rr = r32;
+        rr = r32;
         JM_OPAQUE(rr);
         advance(st, true, rr);
         if (A.mode != MODE_DYNAMICS)
-            evaluate(std::true_type{}, rr, (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0);
+            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
+                                      (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
         else
-            evaluate(std::false_type{}, rr, false);
+            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+    }
+    }
+    {
         T * adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
         if (lead) static_for<0, NVB>([&](auto ic) { adst[(unsigned)I::vrow(decltype(ic)::value) * B32 + rr] = ddqb[decltype(ic)::value]; });
         static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) adst[(unsigned)ix.rv[decltype(sc)::value] * B32 + rr] = ddq[decltype(sc)::value]; });
@@ -1446,6 +1460,7 @@ struct DppQuad
         return __hiloint2double(hi, lo);
     }
     template<int CTRL> static __device__ __forceinline__ float perm(float x) { return __int_as_float(mov<CTRL>(__float_as_int(x))); }
+    template<int CTRL> static __device__ __forceinline__ int perm(int x) { return mov<CTRL>(x); }
     template<class T> static __device__ __forceinline__ T quad_sum(T x)
     {
         x = x + perm<0xB1>(x);  // quad_perm [1,0,3,2]
@@ -1460,6 +1475,25 @@ struct DppQuad
         x |= mov<0x4E>(x);
         return x;
     }
+    // value of the quad lane selected by a quad_perm pattern (0xB1 = [1,0,3,2], 0x4E = [2,3,0,1])
+    template<int CTRL, class T> static __device__ __forceinline__ T perm_(T x) { return perm<CTRL>(x); }
+    // true in every lane of the WAVE when the predicate holds in any of its lanes (scalar result)
+    static __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+    // max(a, |b|) / max(a, b) in one instruction (no NaN canonicalisation: a NaN operand loses)
+    static __device__ __forceinline__ double max_abs(double a, double b)
+    {
+        double r;
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static __device__ __forceinline__ double max_(double a, double b)
+    {
+        double r;
+        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static __device__ __forceinline__ float max_abs(float a, float b) { return fmaxf(a, fabsf(b)); }
+    static __device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ void sync() {}  // lanes of a wave are already in lock-step
     static __device__ __forceinline__ void table_ready() { __syncthreads(); }
 };

@@ -55,6 +55,18 @@ struct HostQuad
         pthread_barrier_wait(&sh->bar);
         return r;
     }
+    template<int CTRL, class T> static T perm_(T x)
+    {
+        sh->buf[k] = (double)x;
+        pthread_barrier_wait(&sh->bar);
+        const int src = (CTRL >> (2 * k)) & 3;   // quad_perm: 2 bits per destination lane
+        const T r = (T)sh->buf[src];
+        pthread_barrier_wait(&sh->bar);
+        return r;
+    }
+    static bool wave_any(bool p) { return p; }   // one robot at a time: its four lanes agree on robot-level predicates
+    template<class T> static T max_abs(T a, T b) { return std::fmax(a, std::fabs(b)); }
+    template<class T> static T max_(T a, T b) { return std::fmax(a, b); }
     static void sync() { pthread_barrier_wait(&sh->bar); }
     static void table_ready() {}
     static int quad_or(int x)
@@ -100,7 +112,7 @@ template<class T, class Tp> static void run_quad_con(const jm::BatchArgs<T> & A,
         QuadShared sh;
         pthread_barrier_init(&sh.bar, nullptr, 4);
         const T * table = P.data() + jm::QLayout<Tp>::OFFSET;
-        constexpr int CAP = 37;
+        constexpr int CAP = 150;   // solves of up to 13 rows take the on-chip path, larger ones overflow
         const int rows = jm::QConRows<Tp>::ws_rows(CAP);
         std::vector<T> lds((size_t)(CAP + 1) * A.B, (T)std::nan("")), hbm((size_t)(rows + 1) * A.B, (T)std::nan(""));
         std::vector<std::thread> th;
@@ -115,7 +127,7 @@ template<class T, class Tp> static void run_quad_con(const jm::BatchArgs<T> & A,
                     jm::QConArgs<T> C = C0;
                     C.ws = hbm.data();
                     const jm::QStore<T> V{lds.data() + (size_t)r * CAP, hbm.data() + r, (unsigned)A.B, CAP};
-                    jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true>(A, r, k, table, S, &C, &V);
+                    jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, CAP>(A, r, k, table, S, &C, &V);
                 }
             });
         for (auto & t : th) t.join();

@@ -229,13 +229,20 @@ def _check(got, ref, tol, what=""):
         assert e < tol, (what, k, e)
 
 
-@pytest.mark.parametrize("name", list(_models()))
-def test_constraint_kernel_matches_oracle_on_the_host(name):
+QUAD_MODELS = ("anymal", "atlas", "crane_walker")   # served by the branch-parallel kernel (jm_qcon.h)
+
+
+@pytest.mark.parametrize("name,variant", [(n, "lane") for n in _models()] + [(n, "quad") for n in QUAD_MODELS])
+def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
+    """Both device formulations compiled for the host against the oracle (the reference's dense one):
+    `lane` = one robot per lane, sequential bias-free solves (jm_constraint.h); `quad` = four lanes per
+    robot, four delassus columns per round, packed symmetric matrix in the per-robot solver region split
+    between the on-chip part and the overflow rows, PGS dot products summed over the quad (jm_qcon.h)."""
     model = _models()[name]()
     B = 6 if name == "atlas" else 12
     ref, got = _pair(model, B, seed=7)
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
-    emu.run(model, got, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT, variant=variant)
     _check(got, ref, 1e-9, "start")
     n_active = int((ref["con_flags"] & 1).sum())
     assert n_active > 0 or _abi.constraint_rows(model)["n_rows"] == 0
@@ -243,8 +250,47 @@ def test_constraint_kernel_matches_oracle_on_the_host(name):
         for _ in range(2):
             kw = dict(solver=solver, dt=5e-4, n_substeps=n_sub, command_changed=changed)
             oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
-            emu.run(model, got, "step", constraint_options=TIGHT, **kw)
+            emu.run(model, got, "step", constraint_options=TIGHT, variant=variant, **kw)
         _check(got, ref, 1e-7, solver)
+
+
+@pytest.mark.parametrize("torsion", [0.0, 0.3])
+def test_quad_constraint_kernel_torsion_dynamics_and_reset(torsion):
+    """Branch-parallel constraint kernel on the host: with torsional friction (the 4-row contact blocks) and
+    without (3-row blocks, the torsion row left out of the solve), `compute_robots_dynamics` at another state
+    (no outputs, constraint state still switched) and `reset_lanes` (the start sequence for masked lanes)."""
+    model = load_builtin("anymal")
+    B = 8
+    copt = dict(TIGHT, torsion=torsion)
+    ref, got = _pair(model, B, seed=17)
+    oracle_batch(model, ref, "start", constraint_options=copt)
+    emu.run(model, got, "start", constraint_options=copt, variant="quad")
+    _check(got, ref, 1e-9, "start")
+    for _ in range(3):
+        kw = dict(solver="euler_explicit", dt=1e-3, n_substeps=2, command_changed=True)
+        oracle_batch(model, ref, "step", constraint_options=copt, **kw)
+        emu.run(model, got, "step", constraint_options=copt, variant="quad", **kw)
+    _check(got, ref, 1e-7, "euler")
+    if torsion > 0:
+        nb = _abi.constraint_rows(model)["n_bounds"]
+        assert np.abs(ref["con_data"][2 * nb:].reshape(-1, 4, B)[:, 3]).max() > 0   # torsion multipliers at work
+    # dynamics at a perturbed state: accelerations only, but the constraint objects are switched / warm-started
+    rg = np.random.default_rng(0)
+    q_in = ref["q"].copy()
+    q_in[7:] += 1e-3 * rg.standard_normal(q_in[7:].shape)
+    v_in = ref["v"] + 1e-2 * rg.standard_normal(ref["v"].shape)
+    for arr in (ref, got):
+        arr["q_in"], arr["v_in"], arr["a_out"] = q_in.copy(), v_in.copy(), np.zeros_like(ref["a"])
+    from oracle.oracle_py import OracleEngine
+    e = OracleEngine(model)
+    e.set_constraint_options(**copt)
+    e.bind_constraints(ref["con_flags"], ref["con_data"])
+    io = {"q": ref["q_in"], "v": ref["v_in"], "a": ref["a_out"], "command": ref["command"], "status": ref["status"].reshape(-1)}
+    e.batch_run("dynamics", io)
+    emu.run(model, got, "dynamics", constraint_options=copt, variant="quad")
+    assert rel_err(got["a_out"], ref["a_out"]) < 1e-8
+    assert np.array_equal(got["con_flags"], ref["con_flags"])
+    assert rel_err(got["con_data"], ref["con_data"]) < 1e-8
 
 
 def test_default_tolerances_follow_the_oracle_iterates():
