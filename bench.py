@@ -364,7 +364,7 @@ def main() -> None:
             rows = _abi_rows(model)
             alg_bytes_per_launch += 2 * (rows["con_flags"] * 4 + rows["con_data"] * sz) * B
             achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-            kernel_name = "jm::k_constrained"
+            kernel_name = "jm::k_quad_con" if kernel_name == "jm::k_quad" else "jm::k_constrained"
             pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json")
         if os.path.exists(pmc_path):
             try:

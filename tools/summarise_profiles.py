@@ -110,7 +110,9 @@ def main():
     latest["valu_insts_per_wave"] = summary.get("SQ_INSTS_VALU_per_wave")
     latest["waves_per_launch"] = c.get("SQ_WAVES")
     latest["from"] = f"profiles/{name}_pmc.json"
-    with open(os.path.join(out_dir, "pmc_latest.json"), "w") as f:
+    # fourth argument: name of the "latest" file bench.py reads (pmc_latest.json / pmc_con_latest.json)
+    latest_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_latest.json"
+    with open(os.path.join(out_dir, latest_name), "w") as f:
         json.dump(latest, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1))
 
