@@ -38,18 +38,19 @@ SOLVER_IDS = {"euler_explicit": _abi.JM_SOLVER_EULER_EXPLICIT,
               "runge_kutta_dopri": _abi.JM_SOLVER_RUNGE_KUTTA_DOPRI}
 
 
-def default_options() -> Dict[str, Dict[str, Any]]:
-    """Hot-path subset of `Engine::getDefaultEngineOptions` (reference engine.h:260-481),
-    same names and defaults (`odeSolver` = "runge_kutta_dopri": adaptive, every lane carries its
-    own step size), except `contacts.model`: the reference default "constraint" is available with
-    the fixed-step solvers only, so the default here stays "spring_damper" (the north-star config)."""
+def default_options(dtype: torch.dtype = torch.float64) -> Dict[str, Dict[str, Any]]:
+    """Hot-path subset of `Engine::getDefaultEngineOptions` (reference engine.h:260-481), same names
+    and defaults: `odeSolver` = "runge_kutta_dopri" (adaptive, every lane carries its own step size) and
+    `contacts.model` = "constraint" (engine.h:273).  The constraint solver is float64 only (the reference
+    has no float32 mode to mirror): a float32 engine starts with "spring_damper"."""
     return {
         "world": {"gravity": [0.0, 0.0, -9.81, 0.0, 0.0, 0.0]},
         "stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1.0e-5, "tolRel": 1.0e-4,
                     "dtMax": SIMULATION_MAX_TIMESTEP, "dtRestoreThresholdRel": 0.2,
                     "successiveIterFailedMax": 1000, "iterMax": 0,
                     "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
-        "contacts": {"model": "spring_damper", "stiffness": 1.0e6, "damping": 2.0e3,
+        "contacts": {"model": "constraint" if dtype == torch.float64 else "spring_damper",
+                     "stiffness": 1.0e6, "damping": 2.0e3,
                      "friction": 1.0, "torsion": 0.0, "transitionEps": 1.0e-3,
                      "transitionVelocity": 1.0e-2, "stabilizationFreq": 20.0},
         "constraints": {"solver": "PGS", "regularization": 1.0e-3},
@@ -224,7 +225,8 @@ def _library_self_test(model: CompiledModel, variant: int, dtype: torch.dtype, d
     for changed in (False, True):
         probe = BatchedEngine(model, n, dtype=dtype, device=device, extra_outputs=(), _lib_variant=variant)
         probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt,
-                                       "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0}})
+                                       "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
+                           "contacts": {"model": "spring_damper"}})
         if model.nmotors:
             probe.set_command(cmd)
         probe.start(q, v)
@@ -372,7 +374,7 @@ class BatchedEngine:
             self._model_h, self.batch_size,
             _abi.JM_F64 if dtype == torch.float64 else _abi.JM_F32, dev_index,
             C.byref(self._batch_h)))
-        self._options = default_options()
+        self._options = default_options(dtype)
         self._rows = _abi.field_rows(model)
         B = self.batch_size
         mandatory = ("q", "v", "a", "command", "u_motor", "u", "imu", "force", "contact",

@@ -19,6 +19,11 @@ def test_default_options_follow_the_reference_names():
     assert o["contacts"]["stiffness"] == 1.0e6 and o["contacts"]["damping"] == 2.0e3
     assert o["contacts"]["transitionEps"] == 1.0e-3 and o["contacts"]["transitionVelocity"] == 1.0e-2
     assert o["stepper"]["dtMax"] == 0.02
+    # reference defaults (engine.h:273, :307): the constraint contact model and the adaptive stepper; float32
+    # engines have no constraint solver and start with the spring-damper model
+    import torch
+    assert o["contacts"]["model"] == "constraint" and o["stepper"]["odeSolver"] == "runge_kutta_dopri"
+    assert E.default_options(torch.float32)["contacts"]["model"] == "spring_damper"
 
 
 def test_plan_gym_style_step():

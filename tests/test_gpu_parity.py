@@ -19,7 +19,7 @@ EXTRA = ("contact_forces", "energy", "f_external", "joint_forces", "centroidal")
 def _engine(model, B, dtype, solver, dt):
     eng = BatchedEngine(model, B, dtype=dtype, extra_outputs=EXTRA)
     eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": dt,
-                                 "sensorsUpdatePeriod": dt}})
+                                 "sensorsUpdatePeriod": dt}, "contacts": {"model": "spring_damper"}})
     return eng
 
 
@@ -385,7 +385,7 @@ def test_multi_substep_launches_match_oracle(gpu_device, name, solver):
     oracle_batch(model, ref, "start")
     eng = BatchedEngine(model, B, dtype=torch.float64, extra_outputs=EXTRA)
     eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
-                                 "sensorsUpdatePeriod": n_sub * dt}})
+                                 "sensorsUpdatePeriod": n_sub * dt}, "contacts": {"model": "spring_damper"}})
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     rng = np.random.default_rng(0)
@@ -421,7 +421,7 @@ def _dopri_pair(model, B, st, step_dt, n_steps, tol_rel, tol_abs, dt_max=0.02, c
     ad = adaptive_state(B)
     eng = BatchedEngine(model, B, dtype=torch.float64, extra_outputs=EXTRA)
     eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolRel": tol_rel, "tolAbs": tol_abs,
-                                 "dtMax": dt_max, "controllerUpdatePeriod": ctrl, "sensorsUpdatePeriod": ctrl}})
+                                 "dtMax": dt_max, "controllerUpdatePeriod": ctrl, "sensorsUpdatePeriod": ctrl}, "contacts": {"model": "spring_damper"}})
     if model.nmotors:
         eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))

@@ -87,7 +87,7 @@ def test_hip_path_matches_the_reference_binary(gpu_device, name):
     dt = float(g["dt"])
     eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
     eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
-                                 "sensorsUpdatePeriod": dt}})
+                                 "sensorsUpdatePeriod": dt}, "contacts": {"model": "spring_damper"}})
     if model.nmotors:
         eng.set_command(torch.from_numpy(g["in_command"]))
     eng.start(torch.from_numpy(g["in_q"]), torch.from_numpy(g["in_v"]))

@@ -239,7 +239,7 @@ def test_engine_sensor_noise_at_sensor_breakpoints(gpu_device):
     def run(noise, seed=3):
         eng = BatchedEngine(model, B, dtype=torch.float64)
         eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 2 * dt,
-                                     "sensorsUpdatePeriod": 2 * dt}})
+                                     "sensorsUpdatePeriod": 2 * dt}, "contacts": {"model": "spring_damper"}})
         if noise:
             eng.set_sensor_options("ImuSensor", noise_std=[0.01, 0.01, 0.01, 0.1, 0.1, 0.1],
                                    bias=[0.0, 0.0, 0.1, 0.001, 0.002, 0.003, 0.0, 0.0, 0.05])
@@ -430,7 +430,7 @@ def test_engine_encoder_delay_reads_the_past(gpu_device):
     def run(delay):
         eng = BatchedEngine(model, B, dtype=torch.float64)
         eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
-                                     "sensorsUpdatePeriod": dt}})
+                                     "sensorsUpdatePeriod": dt}, "contacts": {"model": "spring_damper"}})
         if delay:
             eng.set_sensor_options("EncoderSensor", delay=delay)
         eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
@@ -458,7 +458,7 @@ def test_engine_delay_history_of_reset_lanes_starts_afresh(gpu_device):
     B, dt = 6, 1e-3
     eng = BatchedEngine(model, B, dtype=torch.float64)
     eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
-                                 "sensorsUpdatePeriod": dt}})
+                                 "sensorsUpdatePeriod": dt}, "contacts": {"model": "spring_damper"}})
     eng.set_sensor_options("EncoderSensor", delay=3e-3)
     eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
     q0 = torch.linspace(0.1, 0.6, B, dtype=torch.float64)[None, :]

@@ -32,7 +32,7 @@ def main():
     st = sample_states(model, B, seed=0)
     eng = BatchedEngine(model, B, dtype=torch.float64, device=dev)
     eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": args.tol_abs, "tolRel": args.tol_rel,
-                                 "controllerUpdatePeriod": args.interval, "sensorsUpdatePeriod": args.interval}})
+                                 "controllerUpdatePeriod": args.interval, "sensorsUpdatePeriod": args.interval}, "contacts": {"model": "spring_damper"}})
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     eng.step(args.interval)  # leaves the 1 us initial step size behind
