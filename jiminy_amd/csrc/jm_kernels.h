@@ -224,12 +224,12 @@ template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> v
     const T vDepth = vW.z;
     const T fN = -fmin_(k * depth + c * vDepth, T(0));
     const V3<T> vT = {vW.x, vW.y, vW.z - vDepth};
-    const T ratio = fmin_(sqrt_(dot(vT, vT)) / vt, T(1));
+    const T ratio = fmin_(sqrt_(dot(vT, vT)) * rcp_(vt), T(1));
     const T fT = mu * ratio * fN;
     V3<T> f = {-fT * vT.x, -fT * vT.y, fN - fT * vT.z};
     if (eps > Eps<T>::eps)
     {
-        const T blend = tanh_(T(2) * (-depth / eps));
+        const T blend = tanh_(T(2) * (-depth * rcp_(eps)));
         f = blend * f;
     }
     return f;

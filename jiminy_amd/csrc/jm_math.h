@@ -358,11 +358,14 @@ template<class T> JM_DEV SE3<T> exp6(Sp<T> nu)
     T st, ct;
     sincos_(t, &st, &ct);
     const bool small = t < Eps<T>::taylor;
-    const T inv_t2 = T(1) / (small ? T(1) : t2);
-    const T a_wxv = small ? T(0.5) - t2 / T(24) : (T(1) - ct) * inv_t2;
-    const T a_v = small ? T(1) - t2 / T(6) : st / (small ? T(1) : t);
-    const T a_w = small ? T(1) / T(6) - t2 / T(120) : (T(1) - a_v) * inv_t2;
-    const T dg = small ? T(1) - t2 / T(2) : ct;
+    // (reciprocals by rcp_: the IEEE division sequence is 2-3x the instructions, and both sides of every select
+    // below are evaluated)
+    const T inv_t = rcp_(small ? T(1) : t);
+    const T inv_t2 = inv_t * inv_t;
+    const T a_wxv = small ? T(0.5) - t2 * T(1.0 / 24.0) : (T(1) - ct) * inv_t2;
+    const T a_v = small ? T(1) - t2 * T(1.0 / 6.0) : st * inv_t;
+    const T a_w = small ? T(1.0 / 6.0) - t2 * T(1.0 / 120.0) : (T(1) - a_v) * inv_t2;
+    const T dg = small ? T(1) - t2 * T(0.5) : ct;
     SE3<T> M;
     M.p = a_v * v + (a_w * dot(w, v)) * w + a_wxv * cross(w, v);
     M.R = {a_wxv * w.x * w.x + dg, a_wxv * w.x * w.y - a_v * w.z, a_wxv * w.x * w.z + a_v * w.y,
@@ -378,7 +381,7 @@ template<class T> JM_DEV void matrix_to_quat(const M3<T> & R, T & x, T & y, T & 
     {
         t = sqrt_(t + T(1));
         w = T(0.5) * t;
-        t = T(0.5) / t;
+        t = T(0.5) * rcp_(t);
         x = (R.m21 - R.m12) * t;
         y = (R.m02 - R.m20) * t;
         z = (R.m10 - R.m01) * t;
@@ -387,7 +390,7 @@ template<class T> JM_DEV void matrix_to_quat(const M3<T> & R, T & x, T & y, T & 
     {
         t = sqrt_(R.m00 - R.m11 - R.m22 + T(1));
         x = T(0.5) * t;
-        t = T(0.5) / t;
+        t = T(0.5) * rcp_(t);
         w = (R.m21 - R.m12) * t;
         y = (R.m10 + R.m01) * t;
         z = (R.m20 + R.m02) * t;
@@ -396,7 +399,7 @@ template<class T> JM_DEV void matrix_to_quat(const M3<T> & R, T & x, T & y, T & 
     {
         t = sqrt_(R.m11 - R.m22 - R.m00 + T(1));
         y = T(0.5) * t;
-        t = T(0.5) / t;
+        t = T(0.5) * rcp_(t);
         w = (R.m02 - R.m20) * t;
         z = (R.m21 + R.m12) * t;
         x = (R.m01 + R.m10) * t;
@@ -405,7 +408,7 @@ template<class T> JM_DEV void matrix_to_quat(const M3<T> & R, T & x, T & y, T & 
     {
         t = sqrt_(R.m22 - R.m00 - R.m11 + T(1));
         z = T(0.5) * t;
-        t = T(0.5) / t;
+        t = T(0.5) * rcp_(t);
         w = (R.m10 - R.m01) * t;
         x = (R.m02 + R.m20) * t;
         y = (R.m12 + R.m21) * t;

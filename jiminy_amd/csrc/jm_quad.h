@@ -184,7 +184,7 @@ template<class T, int FL, class MP> JM_DEV void motor_law(MP && mp, T cmd, T vjn
             const T vdelta = elim * islope;
             const bool on = vdelta > T(0);
             const T vthr = fmax_(vlim - vdelta, T(0));
-            const T inv = T(1) / (on ? vlim - vthr : T(1));
+            const T inv = rcp_(on ? vlim - vthr : T(1));
             emin *= on ? clamp_((vlim + vmot) * inv, T(0), T(1)) : T(1);
             emax *= on ? clamp_((vlim - vmot) * inv, T(0), T(1)) : T(1);
         }
