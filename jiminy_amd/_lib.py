@@ -47,6 +47,7 @@ ABI_SYMBOLS = (
     "jm_batch_adaptive_workspace_rows", "jm_batch_bind_adaptive", "jm_batch_step_adaptive",
     "jm_block_sensor_noise", "jm_sensor_rng_seed",
     "jm_batch_set_constraint_options", "jm_batch_constraint_rows", "jm_block_sensor_delay",
+    "jm_batch_set_ground", "jm_batch_set_applied_frames",
 )
 
 
@@ -90,6 +91,8 @@ class HipLibrary:
                                             dp, dp, C.c_int32, vp]
         L.jm_batch_set_constraint_options.argtypes = [vp, C.POINTER(_abi.ConstraintOptions)]
         L.jm_batch_constraint_rows.argtypes = [vp, ip, ip, ip]
+        L.jm_batch_set_ground.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.jm_batch_set_applied_frames.argtypes = [vp, C.c_int32, dp]
         for name in ABI_SYMBOLS:
             getattr(L, name)  # AttributeError if a declared symbol is not exported
             if name not in ("jm_topology_signature",):

@@ -314,16 +314,17 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
         raise RuntimeError(
             f"hipcc not found ({HIPCC}); cannot build the HIP library for topology "
             f"{model.topology_hash()} and no prebuilt {lib} exists")
-    # three translation units compiled in parallel (the constraint-model kernels are the longest single compiles
+    # up to five translation units compiled in parallel (the constraint-model kernels are the longest single compiles
     # of a large topology), then linked into one shared library
     common = [f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"]
     common += list(BUILD_VARIANTS[v])
     common += extra_flags or []
-    objs = [lib + ".main.o", lib + ".con.o", lib + ".qcon.o"]
-    cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]],
-            [HIPCC] + common + ["-DJM_CON_PART=1", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[1]],
-            [HIPCC] + common + ["-DJM_CON_PART=2", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", objs[2]]]
+    parts = [1, 2, 3, 4] if quad_structure(model) is not None else [1]
+    objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]
+    cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]]]
+    cmds += [[HIPCC] + common + [f"-DJM_CON_PART={p}", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", o]
+             for p, o in zip(parts, objs[1:])]
     if verbose:
         for c in cmds:
             print(" ".join(c))

@@ -111,6 +111,19 @@ template<class T> struct BatchArgs
     long long B;
     int mode, solver, n_sub, command_changed, update_sensors;
     T dt;
+    // ---- optional per-environment variation (branch-parallel kernels, GEN instantiation; all null / 0 otherwise)
+    // per-lane body parameters, rows per joint: mass | com 3 | inertia xx xy xz yy yz zz | joint placement
+    // translation 3 = `[13 * NJ][B]` (Model::addBiasedToExtendedModel, model.cc:1166-1236)
+    const T * model_lane;
+    // world.groundProfile as a height map `[ny][nx]` at (x0 + ix dx, y0 + iy dy), bilinear patches (engine.h:292-302)
+    const T * ground_h;
+    int ground_nx, ground_ny;
+    T ground_x0, ground_y0, ground_dx, ground_dy;
+    // impulse / profile forces on frames of the root joint (engine.cc:1838-2016): world-aligned (force, moment)
+    // `[6 K][B]` at the frame offsets `applied_p` (root joint frame), K <= 4
+    const T * applied;
+    int applied_k;
+    T applied_p[12];
 };
 // MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
 // the lane status into the existing one: the closing launch of an adaptive-step interval
@@ -233,6 +246,46 @@ template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> v
         f = blend * f;
     }
     return f;
+}
+
+// the same law on a ground of unit normal n (world.groundProfile, engine.cc:3138-3142)
+template<class T, class Tp> JM_DEV V3<T> contact_law_n(CPtr<T> P, V3<T> n, T depth, V3<T> vW)
+{
+    using L = Layout<Tp>;
+    const T k = P[L::OPT + 6], c = P[L::OPT + 7], mu = P[L::OPT + 8], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    const T vDepth = dot(vW, n);
+    const T fN = -fmin_(k * depth + c * vDepth, T(0));
+    const V3<T> vT = vW - vDepth * n;
+    const T ratio = fmin_(sqrt_(dot(vT, vT)) * rcp_(vt), T(1));
+    const T fT = mu * ratio * fN;
+    V3<T> f = fN * n - fT * vT;
+    if (eps > Eps<T>::eps)
+    {
+        const T blend = tanh_(T(2) * (-depth * rcp_(eps)));
+        f = blend * f;
+    }
+    return f;
+}
+// world.groundProfile(x, y) -> height and unit normal out of the height map of the batch arguments
+template<class T> JM_DEV void ground_profile(const BatchArgs<T> & A, T x, T y, T & h, V3<T> & n)
+{
+    const int nx = A.ground_nx, ny = A.ground_ny;
+    T u = (x - A.ground_x0) / A.ground_dx, w = (y - A.ground_y0) / A.ground_dy;
+    const bool in_x = u >= T(0) && u <= T(nx - 1), in_y = w >= T(0) && w <= T(ny - 1);
+    u = fmin_(fmax_(u, T(0)), T(nx - 1));
+    w = fmin_(fmax_(w, T(0)), T(ny - 1));
+    int ix = (int)u, iy = (int)w;
+    ix = ix > nx - 2 ? nx - 2 : ix; iy = iy > ny - 2 ? ny - 2 : iy;
+    ix = ix < 0 ? 0 : ix; iy = iy < 0 ? 0 : iy;
+    const T fx = u - T(ix), fy = w - T(iy);
+    const T h00 = A.ground_h[iy * nx + ix], h10 = A.ground_h[iy * nx + ix + 1];
+    const T h01 = A.ground_h[(iy + 1) * nx + ix], h11 = A.ground_h[(iy + 1) * nx + ix + 1];
+    h = (T(1) - fy) * ((T(1) - fx) * h00 + fx * h10) + fy * ((T(1) - fx) * h01 + fx * h11);
+    // outside the grid the ground continues flat (height of the nearest edge sample, no slope across the edge)
+    const T dhdx = in_x ? ((T(1) - fy) * (h10 - h00) + fy * (h11 - h01)) / A.ground_dx : T(0);
+    const T dhdy = in_y ? ((T(1) - fx) * (h01 - h00) + fx * (h11 - h10)) / A.ground_dy : T(0);
+    const T inv = T(1) / sqrt_(dhdx * dhdx + dhdy * dhdy + T(1));
+    n = {-dhdx * inv, -dhdy * inv, inv};
 }
 
 // symmetric positive definite 6x6 solve (Ia + diag(rot)) x = b (calc_aba free-flyer,

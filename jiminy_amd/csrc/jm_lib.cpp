@@ -30,7 +30,7 @@
 #include "jm_adaptive.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 1
+#define JM_ABI_VERSION 2
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -39,6 +39,8 @@ namespace jm
 extern template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
 #if JM_TOPO_QUAD
 extern template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
+extern template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
 #endif
 }
 #endif
@@ -91,6 +93,12 @@ struct jm_batch
     int32_t * ad_count_host = nullptr;  // pinned host
     // constraint contact model (jm_constraint.h)
     jm_constraint_options copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+    // optional per-environment variation (GEN kernels): height map, frames of the applied wrenches
+    const void * ground_h = nullptr;
+    int ground_nx = 0, ground_ny = 0;
+    double ground_x0 = 0, ground_y0 = 0, ground_dx = 1, ground_dy = 1;
+    int applied_k = 0;
+    double applied_p[12] = {0};
     // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs (begin, end), ring of JM_TIMING_RING launches
@@ -155,6 +163,13 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     A.status = (int32_t *)b->field[JM_F_STATUS];
     A.ws = (T *)b->field[JM_F_WORKSPACE];
     A.B = b->B;
+    A.model_lane = (const T *)b->field[JM_F_MODEL_LANE];
+    A.ground_h = (const T *)b->ground_h;
+    A.ground_nx = b->ground_nx; A.ground_ny = b->ground_ny;
+    A.ground_x0 = (T)b->ground_x0; A.ground_y0 = (T)b->ground_y0; A.ground_dx = (T)b->ground_dx; A.ground_dy = (T)b->ground_dy;
+    A.applied = b->applied_k > 0 ? (const T *)b->field[JM_F_APPLIED] : nullptr;
+    A.applied_k = A.applied ? b->applied_k : 0;
+    for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)b->applied_p[i];
     return A;
 }
 
@@ -165,6 +180,14 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
     {
         constexpr int nth = 64 * jm::quad_block_waves<T, Tp>();  // 4 lanes per robot
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));  // A.B <= b->B (compact adaptive batches)
+        if constexpr (std::is_same<T, double>::value)
+        {
+            if (A.model_lane || A.ground_h || A.applied)
+            {
+                hipLaunchKernelGGL((jm::k_quad_gen<T, Tp>), dim3(grid), dim3(nth), 0, s, A);
+                return;
+            }
+        }
         hipLaunchKernelGGL((jm::k_quad<T, Tp>), dim3(grid), dim3(nth), 0, s, A);
     }
     else { (void)b; (void)A; (void)s; }
@@ -181,7 +204,8 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
         C.iter_max = C0.iter_max;
         constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
-        hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+        if (A.model_lane || A.applied) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+        else hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
     }
     else { (void)b; (void)A; (void)C0; (void)s; }
 }
@@ -193,6 +217,16 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     const unsigned grid = (unsigned)((A.B + 63) / 64);
     // only the step launches are timed: the roofline leg prices one pass of the hot path, not the
     // (cheaper, single-evaluation) start / reset / dynamics launches
+    if (A.model_lane || A.ground_h || A.applied)
+    {
+        if (!(Topo::QUAD && b->variant == VARIANT_QUAD) || !std::is_same<T, double>::value)
+            return fail(JM_ENOTIMPL, "per-lane body parameters, height-map ground and applied wrenches need a float64 batch of a "
+                                     "branch-parallel topology (floating base with four limbs)");
+        if (A.ground_h && b->copt.contact_model == JM_CONTACT_CONSTRAINT)
+            return fail(JM_ENOTIMPL, "the height-map ground is available with contacts.model = 'spring_damper' only");
+        if (b->ad_ws && A.B != b->B)
+            return fail(JM_ENOTIMPL, "per-lane body parameters / applied wrenches are not available with the adaptive stepper");
+    }
     const bool timed = b->timing && A.mode == jm::MODE_STEP && b->n_timed < JM_TIMING_RING;
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
     if (b->copt.contact_model == JM_CONTACT_CONSTRAINT)
@@ -465,6 +499,23 @@ int32_t jm_batch_constraint_rows(const jm_batch * b, int32_t * n_flag_rows, int3
     if (n_flag_rows) *n_flag_rows = R::NF;
     if (n_data_rows) *n_data_rows = R::ND;
     if (n_workspace_rows) *n_workspace_rows = constraint_ws_rows(b);
+    return JM_OK;
+}
+int32_t jm_batch_set_ground(jm_batch * b, const void * heights, int32_t nx, int32_t ny, double x0, double y0, double dx, double dy)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_set_ground: null batch");
+    if (heights && (nx < 2 || ny < 2 || !(dx > 0.0) || !(dy > 0.0)))
+        return fail(JM_EINVAL, "jm_batch_set_ground: the height map needs at least 2 x 2 samples and positive spacings");
+    b->ground_h = heights; b->ground_nx = nx; b->ground_ny = ny;
+    b->ground_x0 = x0; b->ground_y0 = y0; b->ground_dx = dx; b->ground_dy = dy;
+    return JM_OK;
+}
+int32_t jm_batch_set_applied_frames(jm_batch * b, int32_t k, const double * offsets)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_set_applied_frames: null batch");
+    if (k < 0 || k > 4 || (k > 0 && !offsets)) return fail(JM_EINVAL, "jm_batch_set_applied_frames: 0 <= K <= 4 frames with their offsets");
+    b->applied_k = k;
+    for (int i = 0; i < 3 * k; ++i) b->applied_p[i] = offsets[i];
     return JM_OK;
 }
 int32_t jm_batch_bind(jm_batch * b, int32_t field, void * ptr)

@@ -3,6 +3,8 @@
 // -DJM_SPLIT_CONSTRAINT) because they are the longest single compiles of a large topology.
 //   -DJM_CON_PART=1  k_constrained (jm_constraint.h, one robot per lane: trees without the 4-limb structure)
 //   -DJM_CON_PART=2  k_quad_con    (jm_qcon.h, branch-parallel: ANYmal, Atlas, ...)
+//   -DJM_CON_PART=3  k_quad_gen     (jm_quad.h with per-lane body parameters / height-map ground / applied forces)
+//   -DJM_CON_PART=4  k_quad_con_gen (the same for the constraint contact model)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -20,5 +22,9 @@ namespace jm
 template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
 #elif JM_CON_PART == 2 && JM_TOPO_QUAD
 template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+#elif JM_CON_PART == 3 && JM_TOPO_QUAD
+template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
+#elif JM_CON_PART == 4 && JM_TOPO_QUAD
+template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
 #endif
 }

@@ -1023,7 +1023,7 @@ JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<
 // ---------------------------------------------------------------- one constrained evaluation
 // `start_passes` > 0: Engine::start / reset sequence; < 0: MODE_REFRESH (re-apply the stored multipliers);
 // 0: a regular evaluation.  Leaves the constrained acceleration in ddqb / ddq.
-template<class T, class Tp, class X, class SB, int CAPC>
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1045,8 +1045,8 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     ex.nb = R::NB;
     status &= ~JM_LANE_SOLVER_FAILURE;
     auto apply = [&]() __attribute__((always_inline)) {
-        if (emit) quad_eval<T, Tp, X, true, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, sensors, ddqb, ddq, status, &ex);
-        else quad_eval<T, Tp, X, false, SB, 2>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status, &ex);
+        if (emit) quad_eval<T, Tp, X, true, SB, 2, NoKeep, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, sensors, ddqb, ddq, status, &ex);
+        else quad_eval<T, Tp, X, false, SB, 2, NoKeep, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status, &ex);
     };
     if constexpr (R::NR == 0)
     {
@@ -1075,7 +1075,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         static_for<0, N>([&](auto sc) { ex.tau_l[decltype(sc)::value] = uq_l[decltype(sc)::value]; });
         static_for<0, NT>([&](auto tc) { ex.tau_b[decltype(tc)::value] = uq_b[decltype(tc)::value]; });
         ex.motors_on = !(init && pass == 0);
-        quad_eval<T, Tp, X, false, SB, 1, QKeep<T, Tp>>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq,
+        quad_eval<T, Tp, X, false, SB, 1, QKeep<T, Tp>, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq,
                                                        status, &ex, &K, &TS);
         if (pass == 0)
         {
@@ -1212,6 +1212,27 @@ k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     const QStore<T> V{con + (threadIdx.x >> 2) * RSTRIDE, C.ws + r, (unsigned)A.B, CAP};
     quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
+}
+template<class T, class Tp>
+__global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_con_gen(const BatchArgs<T> A, const QConArgs<T> C)
+{
+    using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * qcon_block_waves<T, Tp>();
+    constexpr int CAP = qcon_capacity<T, Tp>();
+    constexpr int RSTRIDE = (CAP % 2 == 0) ? CAP + 1 : CAP;
+    __shared__ T table[Q::TABLE];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+    __shared__ T con[(CAP > 0 ? RSTRIDE : 1) * (NTH / 4)];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    const QStore<T> V{con + (threadIdx.x >> 2) * RSTRIDE, C.ws + r, (unsigned)A.B, CAP};
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP, true>(A, r, k, table, S, &C, &V);
 }
 #endif
 }  // namespace jm

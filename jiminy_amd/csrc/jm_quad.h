@@ -224,6 +224,33 @@ template<class Tp> JM_DEV QIdx<Tp> quad_indices(int k)
     return ix;
 }
 
+// ---- body parameters: the constant block / limb table, or per-lane rows (GEN kernels: model randomisation per
+// environment, Model::addBiasedToExtendedModel, model.cc:1166-1236).  `c` is the constant value, returned as is
+// by the no-op accessor so that the regular kernels compile to exactly what they were.
+struct NoModelLane
+{
+    template<class V> JM_DEV V rbi(int, const V & c) const { return c; }
+    template<class V> JM_DEV V plc_p(int, const V & c) const { return c; }
+};
+template<class T> struct ModelLane
+{
+    const T * ml;   // [13 * NJ][B] or null
+    unsigned B, r;
+    JM_DEV RBI<T> rbi(int j, const RBI<T> & c) const
+    {
+        if (!ml || j < 1) return c;
+        const unsigned o = (unsigned)(13 * j) * B + r;
+        return {ml[o], {ml[o + B], ml[o + 2 * B], ml[o + 3 * B]},
+                S3<T>{ml[o + 4 * B], ml[o + 5 * B], ml[o + 6 * B], ml[o + 7 * B], ml[o + 8 * B], ml[o + 9 * B]}};
+    }
+    JM_DEV V3<T> plc_p(int j, const V3<T> & c) const
+    {
+        if (!ml || j < 1) return c;
+        const unsigned o = (unsigned)(13 * j + 10) * B + r;
+        return {ml[o], ml[o + B], ml[o + 2 * B]};
+    }
+};
+
 // kinematics of the trunk tree in root coordinates (placements X_t, velocities v_t, joint motion
 // subspaces S_t of the 1-dof joints); element 0 is the root itself (X = identity, S unused)
 template<class T, class Tp> struct TrunkKin
@@ -246,8 +273,8 @@ template<class T, class Tp, int t> JM_DEV Sp<T> trunk_S(CPtr<T> P, const TrunkKi
     if constexpr (jt_is_rev(jt)) return {cross(K.X[t].p, a), a};
     else return {a, zero3<T>()};
 }
-template<class T, class Tp>
-JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K, int & status)
+template<class T, class Tp, class MA = NoModelLane>
+JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K, int & status, const MA & ma = MA{})
 {
     using L = Layout<Tp>;
     K.X[0] = {ident3<T>(), zero3<T>()};
@@ -256,7 +283,8 @@ JM_DEV void trunk_fk(CPtr<T> P, const T * qb, const T * vb, TrunkKin<T, Tp> & K,
         constexpr int t = decltype(tc)::value;
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t], jt = Tp::jtype[j];
         const T qj = qb[6 + t], vj = vb[5 + t];
-        const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+        SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+        plc.p = ma.plc_p(j, plc.p);
         const V3<T> n = joint_axis<T, Tp, j>(P);
         SE3<T> li;
         if constexpr (jt_is_rev(jt))
@@ -344,11 +372,12 @@ template<class T, class Tp, int t> JM_DEV Sp<T> trunk_S_at(CPtr<T> P, const SE3<
     else return {a, zero3<T>()};
 }
 // placement of trunk joint t relative to its parent joint: jointPlacement * M_j(q)
-template<class T, class Tp, int t> JM_DEV SE3<T> trunk_liMi(CPtr<T> P, T qj)
+template<class T, class Tp, int t, class MA = NoModelLane> JM_DEV SE3<T> trunk_liMi(CPtr<T> P, T qj, const MA & ma = MA{})
 {
     using L = Layout<Tp>;
     constexpr int j = Tp::trunk_joint[t], jt = Tp::jtype[j];
-    const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+    SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+    plc.p = ma.plc_p(j, plc.p);
     const V3<T> n = joint_axis<T, Tp, j>(P);
     SE3<T> li;
     if constexpr (jt_is_rev(jt))
@@ -369,9 +398,9 @@ template<class T, class Tp, int t> JM_DEV SE3<T> trunk_liMi(CPtr<T> P, T qj)
 }
 // Forward kinematics of the trunk tree into the distributed store; also hands every lane the
 // placement / velocity of the trunk joint its limb hangs from (picked up where it is computed).
-template<class T, class Tp, class Xq>
+template<class T, class Tp, class Xq, class MA = NoModelLane>
 JM_DEV void trunk_fk_store(CPtr<T> P, int k, const QIdx<Tp> & ix, const T * qb, const T * vb, TrunkStore<T, Tp> & TS,
-                           SE3<T> & Xatt, Sp<T> & vatt, int & status)
+                           SE3<T> & Xatt, Sp<T> & vatt, int & status, const MA & ma = MA{})
 {
     using L = Layout<Tp>;
     const Sp<T> v1 = {{vb[0], vb[1], vb[2]}, {vb[3], vb[4], vb[5]}};
@@ -383,7 +412,7 @@ JM_DEV void trunk_fk_store(CPtr<T> P, int k, const QIdx<Tp> & ix, const T * qb, 
         constexpr int t = decltype(tc)::value;
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
         const T qj = qb[6 + t], vj = vb[5 + t];
-        const SE3<T> li = trunk_liMi<T, Tp, t>(P, qj);
+        const SE3<T> li = trunk_liMi<T, Tp, t, MA>(P, qj, ma);
         SE3<T> Xt;
         Sp<T> vpar;
         if constexpr (tp == 0) { Xt = li; vpar = v1; }
@@ -433,9 +462,9 @@ template<class T, class Tp, class V> JM_DEV V pick_attach(int k, const V * arr)
 // limb kinematics in root coordinates. Only the placements are kept per joint; the velocities are
 // unwound from the tip in the backward sweep (v_{s-1} = v_s - S_s qd_s) and re-accumulated in the
 // forward sweep, which is cheaper than 6 more live scalars per joint.
-template<class T, class Tp>
+template<class T, class Tp, class MA = NoModelLane>
 JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> & Xp, Sp<T> vp, const T * ql, const T * vl,
-                    M3<T> * Rs, V3<T> * ps, Sp<T> & vtip, int & status)
+                    M3<T> * Rs, V3<T> * ps, Sp<T> & vtip, int & status, const MA & ma = MA{}, int k = 0)
 {
     using Q = QLayout<Tp>;
     M3<T> Rp = Xp.R;
@@ -446,7 +475,9 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
         T c, sn;
         sincos_(ql[s], &sn, &c);
         const V3<T> n = LT.v3(o + Q::J_AXIS);
-        const SE3<T> plc = LT.se3(o + Q::J_PLC);
+        SE3<T> plc = LT.se3(o + Q::J_PLC);
+        if constexpr (!std::is_same<MA, NoModelLane>::value)
+            plc.p = ma.plc_p(sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]), plc.p);
         const V3<T> a = Rp * LT.v3(o + Q::J_AXP);  // joint axis in root coordinates
         ps[s] = pp + Rp * plc.p;
         Rs[s] = Rp * (plc.R * rot_rodrigues(n, c, sn));
@@ -456,6 +487,24 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
     });
     vtip = vp;
     (void)ix;
+}
+
+// impulse / profile forces on frames of the root joint (BatchArgs::applied) as one wrench on joint 1, joint frame
+// = root coordinates (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
+template<class T> JM_DEV Sp<T> applied_root_wrench(const BatchArgs<T> & A, const M3<T> & R1, unsigned B32, unsigned r32)
+{
+    Sp<T> f = zero6<T>();
+    for (int i = 0; i < A.applied_k; ++i)
+    {
+        const unsigned o = (unsigned)(6 * i) * B32 + r32;
+        const V3<T> F = {A.applied[o], A.applied[o + B32], A.applied[o + 2 * B32]};
+        const V3<T> M = {A.applied[o + 3 * B32], A.applied[o + 4 * B32], A.applied[o + 5 * B32]};
+        const V3<T> p = {A.applied_p[3 * i], A.applied_p[3 * i + 1], A.applied_p[3 * i + 2]};
+        const V3<T> fl = tmul(R1, F);
+        f.l = f.l + fl;
+        f.a = f.a + tmul(R1, M) + cross(p, fl);
+    }
+    return f;
 }
 
 // ---- where the forces on the contact points come from, and what else acts on the joints ------------
@@ -497,7 +546,7 @@ template<class T, class Tp> struct QKeep
 // derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
 // if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
 // has to stay in registers for a separate output phase.
-template<class T, class Tp, class X, bool EMIT, class SB, int CFM = 0, class KEEP = NoKeep>
+template<class T, class Tp, class X, bool EMIT, class SB, int CFM = 0, class KEEP = NoKeep, bool GEN = false>
 JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
                       const SB & S_, const T * qb, const T * vb_, const T * ql, const T * vl_, const T * cmdb_, const T * cmdl_,
                       bool sensors, T * ddqb, T * ddq, int & status, const QExtra<T, Tp> * ex = nullptr, KEEP * keep = nullptr,
@@ -565,12 +614,21 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 #endif
     SE3<T> Xatt;
     Sp<T> vatt;
-    trunk_fk_store<T, Tp, X>(P, k, ix, qb, vb_, TS, Xatt, vatt, status);
+    // body parameters: constants, or (GEN) the per-lane rows when they are bound
+    using MA = std::conditional_t<GEN, ModelLane<T>, NoModelLane>;
+    MA ma;
+    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, B32, r32};
+    auto limb_joint_of = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        return sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
+    };
+    (void)limb_joint_of;
+    trunk_fk_store<T, Tp, X, MA>(P, k, ix, qb, vb_, TS, Xatt, vatt, status, ma);
     // ---- limb kinematics
     M3<T> Rs[N];
     V3<T> ps[N];
     Sp<T> vtip;
-    limb_fk<T, Tp>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status);
+    limb_fk<T, Tp, MA>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status, ma, k);
     if constexpr (CFM != 0) status &= ~JM_LANE_OUT_OF_BOUNDS;  // bounds are constraints there, not failures
     // ---- contact points on the limb tip (engine.cc:3117-3238, 3394-3425)
     Sp<T> fext = zero6<T>();   // total external force on the tip body, root coordinates
@@ -584,7 +642,17 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             const int oc = Q::CONTACT + c * Q::QC;
             const SE3<T> fr = LT.se3(oc);
             const V3<T> pc = Rt * fr.p + pt;
-            const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+            T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+            V3<T> nG = {T(0), T(0), T(1)};
+            if constexpr (GEN && CFM == 0)
+                if (A.ground_h)
+                {
+                    // world.groundProfile at the contact point; first-order projection (engine.cc:3138-3145)
+                    const V3<T> pW = R1 * pc + p1;
+                    T hG;
+                    ground_profile(A, pW.x, pW.y, hG, nG);
+                    depth = (pW.z - hG) * nG.z;
+                }
             const bool active = c < ix.nc;
             Sp<T> fl = zero6<T>();
             if constexpr (CFM == 0)
@@ -592,7 +660,9 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 if (active && depth < T(0))
                 {
                     const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
-                    const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
+                    V3<T> fW;
+                    if constexpr (GEN) fW = contact_law_n<T, Tp>(P, nG, depth, vW);
+                    else fW = contact_law<T, Tp>(P, depth, vW);
                     const V3<T> fR = tmul(R1, fW);
                     fext.l = fext.l + fR;
                     fext.a = fext.a + cross(pc, fR);
@@ -661,6 +731,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 {
                     put6(A.f_external, B32, r32, 0, zero6<T>());
                     static_for<0, NT>([&](auto tc) { put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[decltype(tc)::value], zero6<T>()); });
+                    if constexpr (GEN)
+                        if (A.applied_k > 0) put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[0], applied_root_wrench(A, R1, B32, r32));
                 }
                 static_for<0, N>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
@@ -750,7 +822,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         static_rfor<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int o = s * Q::QJ;
-            const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(o + Q::J_RBI));
+            const RBI<T> Y = rbi_placed(Rs[s], ps[s], ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
             const V3<T> a = Rs[s] * LT.v3(o + Q::J_AXIS);
             const Sp<T> S = {cross(ps[s], a), a};
             Sp<T> f = cross_mf(vcur, rbi_mul(Y, vcur));  // bias force v x* (I v)
@@ -812,7 +884,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         SE3<T> Xt;
         Sp<T> vt;
         TS.template get_kin<t, X>(Xt, vt);
-        const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+        const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12)));
         const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
         Sp<T> f = cross_mf(vt, rbi_mul(Y, vt));
         AI<T> It = ai_from_rbi(Y);
@@ -840,12 +912,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         }
     });
     // ---- root: u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf (free-flyer calc_aba + pass 3)
-    const RBI<T> Y1 = ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12);
+    const RBI<T> Y1 = ma.rbi(1, ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12));
     const Sp<T> agf1 = actinv_motion(SE3<T>{R1, p1}, Sp<T>{-g, -gw});  // bias v x v = 0 for the free-flyer
     {
         AI<T> I1 = ai_from_rbi(Y1);
         Sp<T> f1 = cross_mf(v1, rbi_mul(Y1, v1));
         if constexpr (I::has_child(0)) { I1 = I1 + accA[0]; f1 = f1 + accF[0]; }
+        if constexpr (GEN)
+            if (A.applied_k > 0) f1 = f1 - applied_root_wrench(A, R1, B32, r32);   // impulse / profile forces on the root body
         const Sp<T> Ya = ai_mul(I1, agf1);
         T b[6] = {-f1.l.x - Ya.l.x, -f1.l.y - Ya.l.y, -f1.l.z - Ya.l.z, -f1.a.x - Ya.a.x, -f1.a.y - Ya.a.y, -f1.a.z - Ya.a.z};
         T M[6][6];
@@ -984,7 +1058,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 // from the state here so that nothing of the dynamics evaluation has to stay live for it.
 // Root coordinates again: body forces add up along the tree, each joint's wrench is rotated into
 // its own frame only when it is stored.
-template<class T, class Tp, class X, int CFM = 0>
+template<class T, class Tp, class X, int CFM = 0, bool GEN = false>
 JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r32, int k, const QIdx<Tp> & ix,
                              const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq,
                              const QExtra<T, Tp> * ex = nullptr)
@@ -1001,8 +1075,11 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     const SE3<T> M1 = {R1, p1};
     const Sp<T> agf1 = actinv_motion(M1, Sp<T>{-g, -gw});
     int status = 0;
+    using MA = std::conditional_t<GEN, ModelLane<T>, NoModelLane>;
+    MA ma;
+    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, B32, r32};
     TrunkKin<T, Tp> K;
-    trunk_fk<T, Tp>(P, qb, vb, K, status);
+    trunk_fk<T, Tp, MA>(P, qb, vb, K, status, ma);
     // true spatial accelerations of the trunk tree (ForwardKinematicsAccelerationStep)
     Sp<T> at[NT];
     at[0] = {{ddqb[0], ddqb[1], ddqb[2]}, {ddqb[3], ddqb[4], ddqb[5]}};
@@ -1016,7 +1093,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     Sp<T> vs[N];
     {
         Sp<T> vtip;
-        limb_fk<T, Tp>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vtip, status);
+        limb_fk<T, Tp, MA>(LT, ix, pick_attach<T, Tp>(k, K.X), pick_attach<T, Tp>(k, K.v), ql, vl, Rs, ps, vtip, status, ma, k);
         Sp<T> vp = pick_attach<T, Tp>(k, K.v);
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -1032,10 +1109,23 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
             const V3<T> pc = Rs[N - 1] * LT.v3(Q::CONTACT + c * Q::QC + 9) + ps[N - 1];
             if constexpr (CFM == 0)
             {
-                const T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+                T depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+                V3<T> nG = {T(0), T(0), T(1)};
+                if constexpr (GEN)
+                    if (A.ground_h)
+                    {
+                        const V3<T> pW = R1 * pc + p1;
+                        T hG;
+                        ground_profile(A, pW.x, pW.y, hG, nG);
+                        depth = (pW.z - hG) * nG.z;
+                    }
                 if (c < ix.nc && depth < T(0))
                 {
-                    const V3<T> fR = tmul(R1, contact_law<T, Tp>(P, depth, R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc))));
+                    const V3<T> vWc = R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc));
+                    V3<T> fWc;
+                    if constexpr (GEN) fWc = contact_law_n<T, Tp>(P, nG, depth, vWc);
+                    else fWc = contact_law<T, Tp>(P, depth, vWc);
+                    const V3<T> fR = tmul(R1, fWc);
                     fext.l = fext.l + fR;
                     fext.a = fext.a + cross(pc, fR);
                 }
@@ -1078,7 +1168,8 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
         });
         static_rfor<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const RBI<T> Y = rbi_placed(Rs[s], ps[s], LT.rbi(s * Q::QJ + Q::J_RBI));
+            const RBI<T> Y = rbi_placed(Rs[s], ps[s], ma.rbi(GEN ? sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]) : 0,
+                                                            LT.rbi(s * Q::QJ + Q::J_RBI)));
             const Sp<T> h = rbi_mul(Y, vs[s]);
             const Sp<T> vxh = cross_mf(vs[s], h);
             hs = hs + h;
@@ -1118,13 +1209,15 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     static_rfor<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int j = Tp::trunk_joint[t];
-        RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+        RBI<T> Y = ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
         if constexpr (t > 0) Y = rbi_placed(K.X[t].R, K.X[t].p, Y);
         const Sp<T> h = rbi_mul(Y, K.v[t]);
         const Sp<T> vxh = cross_mf(K.v[t], h);
         hT[t] = hT[t] + h;
         fBT[t] = fBT[t] + rbi_mul(Y, at[t]) + vxh;
         fjT[t] = fjT[t] + vxh + rbi_mul(Y, at[t] + agf1);
+        if constexpr (GEN && t == 0)
+            if (A.applied_k > 0) fjT[0] = fjT[0] - applied_root_wrench(A, R1, B32, r32);
         mT[t] += Y.m;
         mcT[t] = mcT[t] + Y.m * Y.c;
         if (A.joint_forces && lead)
@@ -1181,7 +1274,7 @@ template<class Tp> constexpr int qcon_first_contact_row()   // = number of bound
 template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_contact_row<Tp>(); }   // ConRows<Tp>::LAM
 template<class T> struct QConArgs;
 template<class T> struct QStore;
-template<class T, class Tp, class X, class SB, int CAPC>
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1189,7 +1282,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
 
 // one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.  QCON: every evaluation is the
 // constrained one (`C` / `V`: constraint state and the robot's solver region).
-template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0>
+template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0, bool GEN = false>
 JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S,
                           const QConArgs<T> * C = nullptr, const QStore<T> * V = nullptr)
 {
@@ -1385,7 +1478,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             rr = r32;
             JM_OPAQUE(rr);
             advance(st, last, rr);
-            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
+            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
                                     (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status,
                                     start_passes);
         }
@@ -1404,7 +1497,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         unsigned rl = r32;
         JM_OPAQUE(rl);
         advance(st, false, rl);
-        quad_eval<T, Tp, X, false>(P, LT, A, rl, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rl, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
     }
     {
         const int e = n_evals - 1;
@@ -1414,10 +1507,10 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         JM_OPAQUE(rr);
         advance(st, true, rr);
         if (A.mode != MODE_DYNAMICS)
-            quad_eval<T, Tp, X, true>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
+            quad_eval<T, Tp, X, true, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
                                       (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
         else
-            quad_eval<T, Tp, X, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+            quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
     }
     }
     {
@@ -1441,9 +1534,9 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                     ex.flags = C->flags;
                     ex.nb = qcon_first_contact_row<Tp>();
                     ex.lam = C->data + (size_t)qcon_first_lambda_row<Tp>() * B32;
-                    quad_extra_terms<T, Tp, X, 2>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq, &ex);
+                    quad_extra_terms<T, Tp, X, 2, GEN>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq, &ex);
                 }
-                else quad_extra_terms<T, Tp, X>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
+                else quad_extra_terms<T, Tp, X, 0, GEN>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
             }
         }
     }
@@ -1538,6 +1631,25 @@ k_quad(const BatchArgs<T> A)
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4>(A, r, k, table, S);
+}
+// the same kernel with the optional per-environment variation compiled in (per-lane body parameters, height-map
+// ground, impulse / profile forces on the root body): launched instead of k_quad when one of them is bound
+template<class T, class Tp>
+__global__ void __launch_bounds__((64 * quad_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
+k_quad_gen(const BatchArgs<T> A)
+{
+    using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * quad_block_waves<T, Tp>();
+    __shared__ T table[Q::TABLE];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, false, 0, true>(A, r, k, table, S);
 }
 #endif
 }  // namespace jm

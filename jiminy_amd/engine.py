@@ -57,7 +57,8 @@ def default_options(dtype: torch.dtype = torch.float64) -> Dict[str, Dict[str, A
     }
 
 
-def _breakpoint_intervals(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
+def _breakpoint_intervals(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]],
+                          extra_breakpoints: Tuple[float, ...] = ()
                           ) -> Tuple[List[Tuple[float, float, bool, bool]], float, float]:
     """Breakpoint schedule of one `Engine::step(step_size)` call.
 
@@ -99,28 +100,32 @@ def _breakpoint_intervals(t: float, t_error: float, step_size: float, options: D
                 dt_next = t_end - t
         else:
             dt_next = t_end - t
+        # start / end of the impulse forces and refresh times of the profile forces (engine.cc:1985-2016)
+        for tb in extra_breakpoints:
+            if STEPPER_MIN_TIMESTEP <= tb - t < dt_next - STEPPER_MIN_TIMESTEP:
+                dt_next = tb - t
         t = t + dt_next
         intervals.append((t, dt_next, command_changed, hit(sens, t)))
     return intervals, t_end, t_error
 
 
-def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
-                     ) -> Tuple[List[Tuple[float, bool, bool]], float, float]:
+def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]],
+                     extra_breakpoints: Tuple[float, ...] = ()) -> Tuple[List[Tuple[float, bool, bool]], float, float]:
     """Adaptive solver: `(t_next, command_changed, update_sensors)` per breakpoint interval; the
     step sizes inside an interval are chosen per lane on the device (engine.cc:2021-2222)."""
-    intervals, t_end, t_err = _breakpoint_intervals(t, t_error, step_size, options)
+    intervals, t_end, t_err = _breakpoint_intervals(t, t_error, step_size, options, extra_breakpoints)
     return [(tn, c, s) for tn, _, c, s in intervals], t_end, t_err
 
 
-def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]]
-              ) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
+def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]],
+              extra_breakpoints: Tuple[float, ...] = ()) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
     """Fixed-step schedule of one `Engine::step(step_size)` call: the breakpoint intervals cut in
     sub-steps of `dtMax`, the last one shortened to land on the breakpoint (engine.cc:2063-2089).
     Returns (launches, t_end, t_error) where each launch is
     `(dt, n_substeps, command_changed, update_sensors)`.
     """
     dt_max = float(options["stepper"]["dtMax"])
-    intervals, t_end, t_error = _breakpoint_intervals(t, t_error, step_size, options)
+    intervals, t_end, t_error = _breakpoint_intervals(t, t_error, step_size, options, extra_breakpoints)
     launches: List[Tuple[float, int, bool, bool]] = []
     for _, dt_next, command_changed, update_sensors in intervals:
         n_full = int(math.floor((dt_next + STEPPER_MIN_TIMESTEP) / dt_max))
@@ -394,6 +399,14 @@ class BatchedEngine:
         self._adaptive: Optional[Dict[str, torch.Tensor]] = None
         self._sensor_noise: Dict[str, Dict[str, Any]] = {}
         self.adaptive_attempts = 0   # device attempts of the last `step` with the adaptive solver
+        # model biases per environment, ground profile, impulse / profile forces (section 4.9 of DESIGN.md)
+        from .randomization import default_dynamics_options
+        self._model_options: Dict[str, Dict[str, float]] = {"dynamics": default_dynamics_options()}
+        self._model_generator = torch.Generator(device="cpu")
+        self._ground: Optional[torch.Tensor] = None
+        self._force_frames: List[str] = []
+        self._impulse_forces: List[Dict[str, Any]] = []
+        self._profile_forces: List[Dict[str, Any]] = []
         self._apply_options()
         self._apply_hardware_sensor_options()
 
@@ -642,6 +655,9 @@ class BatchedEngine:
         self._t = self._t_prev = self._t_error = 0.0
         self._dt = 0.0
         self._iter = 0
+        if any(float(v) > EPS for v in self._model_options["dynamics"].values()):
+            self.sample_model_biases()   # ≙ Model::reset -> generateModelBiased at the start of every simulation
+        self._update_applied_forces(0.0)
         self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
         if self._sensor_noise:
             # `Engine::start` measures the sensors INIT_ITERATIONS times while it solves the initial
@@ -686,6 +702,9 @@ class BatchedEngine:
 
     def _step_adaptive(self, step_dt: float) -> None:
         st = self._options["stepper"]
+        if self._impulse_forces or self._profile_forces or "model_lane" in self._fields:
+            raise NotImplementedError("impulse / profile forces and per-lane model biases need a fixed-step solver "
+                                      "(the adaptive stepper re-orders the lanes)")
         intervals, t_end, t_err = plan_breakpoints(self._t, self._t_error, float(step_dt), self._options)
         o = _abi.AdaptiveOptions(float(st["tolRel"]), float(st["tolAbs"]), float(st["dtMax"]),
                                  float(st["dtRestoreThresholdRel"]), int(st["successiveIterFailedMax"]))
@@ -723,7 +742,8 @@ class BatchedEngine:
         if self._adaptive is not None:
             self._step_adaptive(step_dt)
             return
-        launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options)
+        launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options,
+                                           self._force_breakpoints(self._t))
         solver = SOLVER_IDS[self._options["stepper"]["odeSolver"]]
         stream = self._stream()
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
@@ -734,6 +754,7 @@ class BatchedEngine:
         t_now = self._t
         for dt, n, cmd_bp, sens in launches:
             for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
+                self._update_applied_forces(t_now)
                 t_now += dt * n_k
                 # a(t+) refresh at a controller breakpoint (engine.cc:2030-2042): skipped when the held
                 # command was not rewritten (the evaluation is idempotent) -- except with the constraint
@@ -815,6 +836,170 @@ class BatchedEngine:
             if e.get("hist") is not None:
                 m_ = mask.bool()
                 e["hist"][:, :, m_] = self._fields[e["field"]][:, m_].unsqueeze(0)
+
+    # ------------------------------------------------------------------ per-environment variation
+    def get_model_options(self) -> Dict[str, Dict[str, float]]:
+        """≙ `robot.get_model_options()`: the `dynamics` bias options (model.h:147-158)."""
+        return {k: dict(v) for k, v in self._model_options.items()}
+
+    def set_model_options(self, options: Dict[str, Dict[str, float]]) -> None:
+        """≙ `robot.set_model_options({"dynamics": {"massBodiesBiasStd": ..., ...}})`: standard deviations of the
+        body mass / centre of mass / inertia / relative position biases.  A biased copy of the model is drawn for
+        every lane at each `start` (`Model::reset` -> `addBiasedToExtendedModel`, model.cc:1166-1236)."""
+        if self._running:
+            raise BadControlFlow("Robot already locked, probably because a simulation is running.")
+        for k, v in options.get("dynamics", {}).items():
+            if k in self._model_options["dynamics"]:
+                if float(v) < 0.0:
+                    raise ValueError(f"'{k}' must be non-negative")
+                self._model_options["dynamics"][k] = float(v)
+        if not any(v > EPS for v in self._model_options["dynamics"].values()):
+            self.set_lane_model(None)
+
+    def seed_model(self, seed: int) -> None:
+        self._model_generator.manual_seed(int(seed))
+
+    def set_lane_model(self, model_lane: Optional[torch.Tensor]) -> None:
+        """Bind body parameters per lane (`[13 * njoints][B]`, layout of `JM_F_MODEL_LANE`), None = the model's."""
+        if model_lane is None:
+            if "model_lane" in self._fields:
+                self._fields.pop("model_lane")
+                self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["model_lane"], None))
+            return
+        rows = 13 * self.model.njoints
+        t = torch.as_tensor(model_lane, dtype=self.dtype, device=self.device)
+        if tuple(t.shape) != (rows, self.batch_size):
+            raise ValueError(f"model_lane must have shape ({rows}, B)")
+        if "model_lane" not in self._fields:
+            self._fields["model_lane"] = torch.empty((rows, self.batch_size), dtype=self.dtype, device=self.device)
+            self._bind("model_lane")
+        self._fields["model_lane"].copy_(t)
+
+    def sample_model_biases(self, lane_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Draw the biased models (all lanes, or the masked ones: episode-wise re-randomisation) and bind them."""
+        from .randomization import sample_model_lane
+        prev = self._fields.get("model_lane") if lane_mask is not None else None
+        ml = sample_model_lane(self.model, self.batch_size, self._model_options["dynamics"], self._model_generator,
+                               self.dtype, self.device, lane_mask if prev is not None else None, prev)
+        self.set_lane_model(ml)
+        return self._fields["model_lane"]
+
+    def set_ground_heightmap(self, heights: Any, x0: float = 0.0, y0: float = 0.0, dx: float = 1.0, dy: float = 1.0) -> None:
+        """≙ `engine_options["world"]["groundProfile"]` (engine.h:292-302) as a height map: `heights[iy][ix]` at
+        (x0 + ix dx, y0 + iy dy), bilinear patches (height + unit normal), flat continuation outside; None = flat
+        ground.  Spring-damper contact model."""
+        if self._running:
+            raise BadControlFlow("Please stop the simulation before updating the options.")
+        if heights is None:
+            self._ground = None
+            self._lib.check(self._L.jm_batch_set_ground(self._batch_h, None, 0, 0, 0.0, 0.0, 1.0, 1.0))
+            return
+        h = torch.as_tensor(heights, dtype=self.dtype, device=self.device).contiguous()
+        if h.dim() != 2 or min(h.shape) < 2:
+            raise ValueError("the height map needs at least 2 x 2 samples")
+        self._ground = h
+        self._lib.check(self._L.jm_batch_set_ground(self._batch_h, C.c_void_p(h.data_ptr()), int(h.shape[1]), int(h.shape[0]),
+                                                    float(x0), float(y0), float(dx), float(dy)))
+
+    def set_ground_profile(self, func: Any, x_range: Tuple[float, float], y_range: Tuple[float, float],
+                           resolution: float) -> None:
+        """Discretise a `heightmap(x, y) -> height` callable (vectorised over numpy arrays) on a regular grid
+        (≙ `discretize_heightmap`, core/src/utilities/geometry.cc) and use it as the ground profile."""
+        nx = max(int(math.ceil((x_range[1] - x_range[0]) / resolution)) + 1, 2)
+        ny = max(int(math.ceil((y_range[1] - y_range[0]) / resolution)) + 1, 2)
+        xs = x_range[0] + resolution * np.arange(nx)
+        ys = y_range[0] + resolution * np.arange(ny)
+        X, Y = np.meshgrid(xs, ys)
+        self.set_ground_heightmap(np.asarray(func(X, Y), dtype=np.float64), x_range[0], y_range[0], resolution, resolution)
+
+    def _force_frame_index(self, frame_name: str) -> int:
+        fr = self.model.frame(frame_name)
+        if fr.parent_joint != 1 or not self.model.has_freeflyer:
+            raise NotImplementedError("external forces are available on frames of the root (free-flyer) body")
+        if frame_name not in self._force_frames:
+            if len(self._force_frames) == 4:
+                raise NotImplementedError("at most 4 frames can carry external forces")
+            self._force_frames.append(frame_name)
+            offs = np.ascontiguousarray([self.model.frame(n).p for n in self._force_frames], dtype=np.float64)
+            self._lib.check(self._L.jm_batch_set_applied_frames(self._batch_h, len(self._force_frames),
+                                                                offs.ctypes.data_as(C.POINTER(C.c_double))))
+            old = self._fields.get("applied")
+            new = torch.zeros((6 * len(self._force_frames), self.batch_size), dtype=self.dtype, device=self.device)
+            if old is not None:
+                new[: old.shape[0]] = old
+            self._fields["applied"] = new
+            self._bind("applied")
+        return self._force_frames.index(frame_name)
+
+    def register_impulse_force(self, frame_name: str, t: float, dt: float, force: Any) -> None:
+        """≙ `Engine.register_impulse_force(robot_name, frame_name, t, dt, force)` (engine.cc:1838-1893): the
+        world-aligned wrench `force` (6,) -- or one per lane, (6, B) -- acts on the frame during [t, t + dt]."""
+        if self._running:
+            raise BadControlFlow("Simulation already running. Please stop it before registering new forces.")
+        if dt < STEPPER_MIN_TIMESTEP:
+            raise ValueError("Force duration cannot be smaller than 1e-10 s.")   # engine.cc:1854-1858
+        if t < 0.0:
+            raise ValueError("Force application time must be positive.")        # engine.cc:1860-1864
+        f = torch.as_tensor(force, dtype=self.dtype, device=self.device)
+        if f.dim() == 1:
+            f = f[:, None].expand(6, self.batch_size)
+        if tuple(f.shape) != (6, self.batch_size):
+            raise ValueError("force must have shape (6,) or (6, B)")
+        self._impulse_forces.append({"frame": self._force_frame_index(frame_name), "t": float(t), "dt": float(dt),
+                                     "force": f.contiguous()})
+
+    def register_profile_force(self, frame_name: str, func: Any, update_period: float = 0.0) -> None:
+        """≙ `Engine.register_profile_force(robot_name, frame_name, force_func, update_period)` (engine.cc:1895-1935):
+        `func(t, q, v) -> wrench` with `q`, `v` the `[rows][B]` state tensors and the result `(6,)` or `(6, B)`; it is
+        evaluated at every launch (update_period = 0) or held between multiples of `update_period`."""
+        if self._running:
+            raise BadControlFlow("Simulation already running. Please stop it before registering new forces.")
+        if EPS < update_period < SIMULATION_MIN_TIMESTEP:
+            raise ValueError("Cannot register external force profile with update period smaller than 1us.")
+        self._profile_forces.append({"frame": self._force_frame_index(frame_name), "func": func,
+                                     "period": float(update_period), "t_last": -math.inf, "value": None})
+
+    def remove_all_forces(self) -> None:
+        """≙ `Engine.remove_all_forces` (engine.cc:1937-1960)."""
+        if self._running:
+            raise BadControlFlow("Simulation already running. Please stop it before removing forces.")
+        self._impulse_forces.clear()
+        self._profile_forces.clear()
+        self._force_frames.clear()
+        self._fields.pop("applied", None)
+        self._lib.check(self._L.jm_batch_set_applied_frames(self._batch_h, 0, None))
+        self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["applied"], None))
+
+    @property
+    def impulse_forces(self) -> List[Dict[str, Any]]:
+        return [{"frame_name": self._force_frames[f["frame"]], "t": f["t"], "dt": f["dt"], "force": f["force"]}
+                for f in self._impulse_forces]
+
+    def _force_breakpoints(self, t: float) -> Tuple[float, ...]:
+        """Times after `t` at which an applied force changes: impulse starts / ends, profile refreshes."""
+        pts = []
+        for f in self._impulse_forces:
+            pts += [f["t"], f["t"] + f["dt"]]
+        for p in self._profile_forces:
+            if p["period"] > EPS:
+                pts.append((math.floor(t / p["period"] + 1e-9) + 1) * p["period"])
+        return tuple(sorted(x for x in pts if x > t + STEPPER_MIN_TIMESTEP))
+
+    def _update_applied_forces(self, t: float) -> None:
+        """Current value of the registered forces into the `applied` field (start of a launch at time `t`)."""
+        if "applied" not in self._fields:
+            return
+        a = self._fields["applied"]
+        a.zero_()
+        for f in self._impulse_forces:
+            if f["t"] - STEPPER_MIN_TIMESTEP <= t < f["t"] + f["dt"] - STEPPER_MIN_TIMESTEP:
+                a[6 * f["frame"]:6 * f["frame"] + 6] += f["force"]
+        for p in self._profile_forces:
+            if p["value"] is None or p["period"] <= EPS or t - p["t_last"] >= p["period"] - STEPPER_MIN_TIMESTEP:
+                w = torch.as_tensor(p["func"](t, self._fields["q"], self._fields["v"]), dtype=self.dtype, device=self.device)
+                p["value"] = w[:, None].expand(6, self.batch_size) if w.dim() == 1 else w
+                p["t_last"] = t if p["period"] <= EPS else math.floor(t / p["period"] + 1e-9) * p["period"]
+            a[6 * p["frame"]:6 * p["frame"] + 6] += p["value"]
 
     # ------------------------------------------------------------------ sensor noise and bias
     _SENSOR_FIELDS = {"ImuSensor": ("imu", 6), "ForceSensor": ("force", 6), "ContactSensor": ("contact", 3),

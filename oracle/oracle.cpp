@@ -467,7 +467,59 @@ struct Engine
     int32_t * con_flags = nullptr;
     double * con_data = nullptr;
     const double * lane_friction = nullptr;  // [B] contacts.friction of every lane, or null
+    // ---- per-lane model (Model::addBiasedToExtendedModel output, model.cc:1166-1236): rows per joint
+    // mass | com 3 | inertia xx xy xz yy yz zz | joint placement translation 3, `[13 * njoints][B]`, or null
+    const double * model_lane = nullptr;
+    // ---- world.groundProfile as a sampled height map (engine.h:292-302): heights `[ny][nx]` at
+    // (x0 + ix dx, y0 + iy dy), bilinear patches, flat continuation outside; null = flat ground at z = 0
+    const double * ground_h = nullptr;
+    int ground_nx = 0, ground_ny = 0;
+    double ground_x0 = 0, ground_y0 = 0, ground_dx = 1, ground_dy = 1;
+    // ---- external wrenches on frames of the root joint (impulse / profile forces, engine.cc:1838-2016):
+    // `[6 K][B]` world-aligned (force, moment) at frame offsets applied_p (root joint frame), K <= 4
+    const double * applied = nullptr;
+    int applied_k = 0;
+    double applied_p[12] = {0};
+    double applied_now[24] = {0};   // the current lane's wrenches
 };
+// world.groundProfile(x, y) -> height, unit normal
+inline void ground_profile(const Engine & e, double x, double y, double & h, V3 & n)
+{
+    if (!e.ground_h) { h = 0.0; n = {0, 0, 1}; return; }
+    const int nx = e.ground_nx, ny = e.ground_ny;
+    double u = (x - e.ground_x0) / e.ground_dx, w = (y - e.ground_y0) / e.ground_dy;
+    const bool in_x = u >= 0.0 && u <= (double)(nx - 1), in_y = w >= 0.0 && w <= (double)(ny - 1);
+    u = std::min(std::max(u, 0.0), (double)(nx - 1));
+    w = std::min(std::max(w, 0.0), (double)(ny - 1));
+    int ix = std::min((int)u, nx - 2), iy = std::min((int)w, ny - 2);
+    if (ix < 0) ix = 0;
+    if (iy < 0) iy = 0;
+    const double fx = u - ix, fy = w - iy;
+    const double h00 = e.ground_h[iy * nx + ix], h10 = e.ground_h[iy * nx + ix + 1];
+    const double h01 = e.ground_h[(iy + 1) * nx + ix], h11 = e.ground_h[(iy + 1) * nx + ix + 1];
+    h = (1.0 - fy) * ((1.0 - fx) * h00 + fx * h10) + fy * ((1.0 - fx) * h01 + fx * h11);
+    // outside the grid the ground continues flat (height of the nearest edge sample, no slope across the edge)
+    const double dhdx = in_x ? ((1.0 - fy) * (h10 - h00) + fy * (h11 - h01)) / e.ground_dx : 0.0;
+    const double dhdy = in_y ? ((1.0 - fx) * (h01 - h00) + fx * (h11 - h10)) / e.ground_dy : 0.0;
+    const double inv = 1.0 / std::sqrt(dhdx * dhdx + dhdy * dhdy + 1.0);
+    n = {-dhdx * inv, -dhdy * inv, inv};
+}
+// impulse / profile forces on frames of the root joint -> wrench on joint 1, joint frame
+// (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
+inline Force applied_root_wrench(const Engine & e)
+{
+    Force f;
+    for (int k = 0; k < e.applied_k; ++k)
+    {
+        const V3 F = {e.applied_now[6 * k], e.applied_now[6 * k + 1], e.applied_now[6 * k + 2]};
+        const V3 M = {e.applied_now[6 * k + 3], e.applied_now[6 * k + 4], e.applied_now[6 * k + 5]};
+        const V3 p = {e.applied_p[3 * k], e.applied_p[3 * k + 1], e.applied_p[3 * k + 2]};
+        const V3 fl = tmul(e.oMi[1].R, F);
+        f.lin = f.lin + fl;
+        f.ang = f.ang + tmul(e.oMi[1].R, M) + cross(p, fl);
+    }
+    return f;
+}
 
 V3 joint_axis(const Model & m, int j)
 {
@@ -569,8 +621,10 @@ V3 contact_law(const jm_options & o, V3 n, double depth, V3 vWorld)
 Force contact_at_frame(const Engine & e, const FrameP & fr)
 {
     const SE3 oMf = e.oMi[fr.joint] * fr.M;
-    const V3 n = {0, 0, 1};
-    const double depth = (oMf.p.z - 0.0) * n.z;
+    double hGround;
+    V3 n;
+    ground_profile(e, oMf.p.x, oMf.p.y, hGround, n);
+    const double depth = (oMf.p.z - hGround) * n.z;
     Force fl;
     if (depth < 0.0)
     {
@@ -1262,6 +1316,7 @@ void dynamics_constraint(Engine & e, const double * q, const double * v, double 
     if (e.uInternal.empty()) init_constraints(e);
     forward_kin(e, q, v);
     for (auto & f : e.fExternal) f = Force();
+    if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
     std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
     toggle_bounds(e, q);
     toggle_contacts(e);
@@ -1302,6 +1357,7 @@ void dynamics(Engine & e, const double * q, const double * v, double * a_out)
         e.fExternal[fr.joint] = e.fExternal[fr.joint] + e.contactFrameForces[i];
         e.contactForces[i] = actInv(fr.M, e.contactFrameForces[i]);
     }
+    if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
     motor_efforts(e, v);
     for (int i = 0; i < m.nv; ++i) e.u[i] = 0.0;  // uInternal + uCustom
     for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
@@ -1487,6 +1543,7 @@ void start_constraint(Engine & e)
     for (int it = 0; it < 4; ++it)
     {
         for (auto & f : e.fExternal) f = Force();
+        if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
         std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
         compute_acceleration(e, e.q.data(), e.v.data(), e.u, it == 0);
         for (int i = 0; i < m.nv; ++i)
@@ -1946,6 +2003,19 @@ void orc_engine_bind_constraints(void * h, int32_t * flags, double * data)
     e.con_data = data;
 }
 void orc_engine_bind_friction(void * h, const double * friction) { static_cast<Engine *>(h)->lane_friction = friction; }
+void orc_engine_bind_model_lane(void * h, const double * model_lane) { static_cast<Engine *>(h)->model_lane = model_lane; }
+void orc_engine_bind_ground(void * h, const double * heights, int nx, int ny, double x0, double y0, double dx, double dy)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    e.ground_h = heights; e.ground_nx = nx; e.ground_ny = ny; e.ground_x0 = x0; e.ground_y0 = y0; e.ground_dx = dx; e.ground_dy = dy;
+}
+void orc_engine_bind_applied(void * h, const double * wrenches, int k, const double * offsets)
+{
+    Engine & e = *static_cast<Engine *>(h);
+    e.applied = wrenches;
+    e.applied_k = wrenches ? k : 0;
+    for (int i = 0; i < 3 * e.applied_k; ++i) e.applied_p[i] = offsets[i];
+}
 int orc_engine_constraint_counts(void * h, int * n_bounds, int * n_contacts)
 {
     Engine & e = *static_cast<Engine *>(h);
@@ -2059,6 +2129,18 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
     for (int i = 0; i < e.mdl.nv; ++i) e.v[i] = io.v[i * B + l];
     for (int i = 0; i < e.mdl.nv; ++i) e.a[i] = io.a[i * B + l];
     for (size_t i = 0; i < e.command.size(); ++i) e.command[i] = io.command[i * B + l];
+    if (e.model_lane)
+        for (int j = 1; j < e.mdl.njoints; ++j)
+        {
+            const double * r = e.model_lane + (int64_t)(13 * j) * B + l;
+            Inertia & Y = e.mdl.inertia[j];
+            Y.mass = r[0];
+            Y.c = {r[B], r[2 * B], r[3 * B]};
+            Y.I.m[0][0] = r[4 * B]; Y.I.m[0][1] = Y.I.m[1][0] = r[5 * B]; Y.I.m[0][2] = Y.I.m[2][0] = r[6 * B];
+            Y.I.m[1][1] = r[7 * B]; Y.I.m[1][2] = Y.I.m[2][1] = r[8 * B]; Y.I.m[2][2] = r[9 * B];
+            e.mdl.placement[j].p = {r[10 * B], r[11 * B], r[12 * B]};
+        }
+    for (int k = 0; k < 6 * e.applied_k; ++k) e.applied_now[k] = e.applied ? e.applied[(int64_t)k * B + l] : 0.0;
 }
 static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {

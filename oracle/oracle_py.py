@@ -60,6 +60,12 @@ def lib() -> C.CDLL:
         L.orc_engine_bind_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.restype = None
+        L.orc_engine_bind_model_lane.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_bind_model_lane.restype = None
+        L.orc_engine_bind_ground.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_engine_bind_ground.restype = None
+        L.orc_engine_bind_applied.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_engine_bind_applied.restype = None
         L.orc_engine_constraint_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_engine_constraint_counts.restype = C.c_int
         pd = C.POINTER(C.c_double)
@@ -147,6 +153,34 @@ class OracleEngine:
         """Per-lane `contacts.friction` of the batch drivers (`[B]` float64), None = the engine option."""
         self._friction = None if friction is None else np.ascontiguousarray(friction, dtype=np.float64)
         self._L.orc_engine_bind_friction(self._h, None if friction is None else self._friction.ctypes.data)
+
+    def bind_model_lane(self, model_lane: Optional[np.ndarray]) -> None:
+        """Per-lane body parameters `[13 * njoints][B]` (mass | com | inertia xx xy xz yy yz zz | placement
+        translation per joint), None = the model's own."""
+        self._model_lane = None if model_lane is None else np.ascontiguousarray(model_lane, dtype=np.float64)
+        self._L.orc_engine_bind_model_lane(self._h, None if model_lane is None else self._model_lane.ctypes.data)
+
+    def bind_ground(self, heights: Optional[np.ndarray], x0: float = 0.0, y0: float = 0.0, dx: float = 1.0,
+                    dy: float = 1.0) -> None:
+        """Ground height map `[ny][nx]` sampled at (x0 + ix dx, y0 + iy dy), None = flat ground."""
+        if heights is None:
+            self._ground = None
+            self._L.orc_engine_bind_ground(self._h, None, 0, 0, 0.0, 0.0, 1.0, 1.0)
+            return
+        self._ground = np.ascontiguousarray(heights, dtype=np.float64)
+        ny, nx = self._ground.shape
+        self._L.orc_engine_bind_ground(self._h, self._ground.ctypes.data, nx, ny, float(x0), float(y0), float(dx), float(dy))
+
+    def bind_applied(self, wrenches: Optional[np.ndarray], offsets=None) -> None:
+        """World-aligned wrenches `[6 K][B]` applied on K <= 4 frames of the root joint at `offsets` `[K][3]`."""
+        if wrenches is None:
+            self._applied = None
+            self._L.orc_engine_bind_applied(self._h, None, 0, None)
+            return
+        self._applied = np.ascontiguousarray(wrenches, dtype=np.float64)
+        k = self._applied.shape[0] // 6
+        self._applied_p = np.ascontiguousarray(np.zeros((k, 3)) if offsets is None else offsets, dtype=np.float64)
+        self._L.orc_engine_bind_applied(self._h, self._applied.ctypes.data, k, self._applied_p.ctypes.data)
 
     @property
     def pgs_iterations(self) -> int:

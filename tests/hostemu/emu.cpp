@@ -81,7 +81,7 @@ struct HostQuad
 thread_local QuadShared * HostQuad::sh = nullptr;
 thread_local int HostQuad::k = 0;
 
-template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, const std::vector<T> & P)
+template<class T, class Tp, bool GEN = false> static void run_quad(const jm::BatchArgs<T> & A, const std::vector<T> & P)
 {
     if constexpr (Tp::QUAD)
     {
@@ -95,7 +95,7 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
                 HostQuad::k = k;
                 std::vector<T> sl(jm::QRows<Tp>::NL + 1), sb(jm::QRows<Tp>::NB + 1);
                 const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};  // private trunk rows per thread
-                for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1, 1>(A, r, k, table, S);
+                for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1, 1, false, 0, GEN>(A, r, k, table, S);
             });
         for (auto & t : th) t.join();
         pthread_barrier_destroy(&sh.bar);
@@ -105,7 +105,7 @@ template<class T, class Tp> static void run_quad(const jm::BatchArgs<T> & A, con
 
 // branch-parallel kernel with the constraint contact model (jm_qcon.h): the robot's solver region is split
 // between a small "on-chip" array and overflow rows, so that both homes of QStore are exercised
-template<class T, class Tp> static void run_quad_con(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
+template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
 {
     if constexpr (Tp::QUAD)
     {
@@ -127,7 +127,7 @@ template<class T, class Tp> static void run_quad_con(const jm::BatchArgs<T> & A,
                     jm::QConArgs<T> C = C0;
                     C.ws = hbm.data();
                     const jm::QStore<T> V{lds.data() + (size_t)r * CAP, hbm.data() + r, (unsigned)A.B, CAP};
-                    jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, CAP>(A, r, k, table, S, &C, &V);
+                    jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, CAP, GEN>(A, r, k, table, S, &C, &V);
                 }
             });
         for (auto & t : th) t.join();
@@ -152,6 +152,21 @@ extern "C" void emu_set_constraints(const jm_constraint_options * o, void * flag
 extern "C" void emu_constraint_rows(int * nf, int * nd, int * nw)
 {
     *nf = jm::ConRows<Topo>::NF; *nd = jm::ConRows<Topo>::ND; *nw = jm::ConRows<Topo>::WTOTAL;
+}
+// optional per-environment variation (GEN instantiation of the branch-parallel code)
+static const void * g_model_lane = nullptr;
+static const void * g_ground = nullptr;
+static int g_gnx = 0, g_gny = 0;
+static double g_gx0 = 0, g_gy0 = 0, g_gdx = 1, g_gdy = 1;
+static const void * g_applied = nullptr;
+static int g_applied_k = 0;
+static double g_applied_p[12] = {0};
+extern "C" void emu_set_gen(const void * model_lane, const void * ground, int nx, int ny, double x0, double y0, double dx, double dy,
+                            const void * applied, int k, const double * offsets)
+{
+    g_model_lane = model_lane; g_ground = ground; g_gnx = nx; g_gny = ny; g_gx0 = x0; g_gy0 = y0; g_gdx = dx; g_gdy = dy;
+    g_applied = applied; g_applied_k = applied ? k : 0;
+    for (int i = 0; i < 3 * g_applied_k; ++i) g_applied_p[i] = offsets[i];
 }
 static int g_variant = 0;  // 0 = one robot per lane, 1 = limb-parallel (4 lanes per robot)
 extern "C" void emu_set_variant(int v) { g_variant = v; }
@@ -180,6 +195,13 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.mask = (const unsigned char *)io->mask; A.q_init = (const T *)io->q_init; A.v_init = (const T *)io->v_init;
     A.B = io->B; A.mode = mode; A.solver = solver; A.n_sub = n_sub; A.command_changed = command_changed;
     A.update_sensors = update_sensors; A.dt = (T)dt;
+    const bool gen = g_model_lane || g_ground || g_applied;
+    A.model_lane = (const T *)g_model_lane;
+    A.ground_h = (const T *)g_ground; A.ground_nx = g_gnx; A.ground_ny = g_gny;
+    A.ground_x0 = (T)g_gx0; A.ground_y0 = (T)g_gy0; A.ground_dx = (T)g_gdx; A.ground_dy = (T)g_gdy;
+    A.applied = (const T *)g_applied; A.applied_k = g_applied_k;
+    for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)g_applied_p[i];
+    if (gen && !(g_variant == 1 && Topo::QUAD)) return JM_ENOTIMPL;
     if (g_variant == 1 && Topo::QUAD)
     {
         if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
@@ -191,8 +213,10 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
             C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
             C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
-            run_quad_con<T, Topo>(A, P, C);
+            if (gen) run_quad_con<T, Topo, true>(A, P, C);
+            else run_quad_con<T, Topo>(A, P, C);
         }
+        else if (gen) run_quad<T, Topo, true>(A, P);
         else run_quad<T, Topo>(A, P);
         return 0;
     }

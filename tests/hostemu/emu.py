@@ -42,6 +42,9 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_constraints.restype = None
     L.emu_set_friction.argtypes = [C.c_void_p]
     L.emu_set_friction.restype = None
+    L.emu_set_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                              C.c_void_p, C.c_int, C.c_void_p]
+    L.emu_set_gen.restype = None
     _CACHE[h] = L
     return L
 
@@ -53,8 +56,19 @@ SOLVERS = {"euler_explicit": 0, "runge_kutta_4": 1}
 def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=None,
         solver: str = "runge_kutta_4", dt: float = 1e-3, n_substeps: int = 1,
         command_changed: bool = True, update_sensors: bool = True, dtype=np.float64,
-        variant: str = "lane", constraint_options=None) -> None:
+        variant: str = "lane", constraint_options=None, model_lane=None, ground=None, applied=None) -> None:
+    """`model_lane` `[13 * njoints][B]`; `ground` = (heights [ny][nx], x0, y0, dx, dy); `applied` = (wrenches
+    [6 K][B], offsets [K][3]) -- the optional per-environment variation of the branch-parallel code."""
     L = _lib(model)
+    g = ground if ground is not None else (None, 0.0, 0.0, 1.0, 1.0)
+    gh = None if g[0] is None else np.ascontiguousarray(g[0], dtype=dtype)
+    ap = None if applied is None else np.ascontiguousarray(applied[0], dtype=dtype)
+    apo = None if applied is None else np.ascontiguousarray(applied[1], dtype=np.float64)
+    ml = None if model_lane is None else np.ascontiguousarray(model_lane, dtype=dtype)
+    L.emu_set_gen(None if ml is None else ml.ctypes.data, None if gh is None else gh.ctypes.data,
+                  0 if gh is None else gh.shape[1], 0 if gh is None else gh.shape[0], float(g[1]), float(g[2]), float(g[3]),
+                  float(g[4]), None if ap is None else ap.ctypes.data, 0 if ap is None else ap.shape[0] // 6,
+                  None if apo is None else apo.ctypes.data)
     if constraint_options is not None:
         co = _abi.make_constraint_options(**constraint_options)
         L.emu_set_constraints(C.byref(co), arrays["con_flags"].ctypes.data, arrays["con_data"].ctypes.data)

@@ -1,0 +1,254 @@
+"""Per-environment variation: body-parameter biases per lane
+(`Model::addBiasedToExtendedModel`, core/src/robot/model.cc:1166-1236), the ground profile as a height map
+(`world.groundProfile`, engine.h:292-302, engine.cc:3138-3145) and impulse / profile forces on the root body
+(engine.cc:1838-2016).  Layers: the oracle on laws it must obey, the kernel sources on the host against the
+oracle, and (`-m gpu`) the device build through the C ABI / BatchedEngine against the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from jiminy_amd import load_builtin
+from jiminy_amd.engine import _breakpoint_intervals, default_options
+from jiminy_amd.randomization import nominal_model_lane, sample_model_lane
+from jiminy_amd.synthetic import sample_standing_states, sample_states
+from oracle.oracle_py import OracleEngine
+from tests.helpers import alloc_constraint_state, alloc_soa, oracle_io, rel_err
+from tests.hostemu import emu
+
+OUTS = ("q", "v", "a", "u", "imu", "force", "energy", "contact_forces", "f_external", "joint_forces", "centroidal")
+TIGHT = dict(tol_abs=1e-11, tol_rel=1e-10)
+
+
+def _scene(model, B, seed, constrained):
+    """Seeded states + a biased model per lane + a bumpy ground + two wrenches on root-body frames."""
+    import torch
+    rg = np.random.default_rng(seed)
+    st = sample_standing_states(model, B, seed=seed) if constrained else sample_states(model, B, seed=seed, grounded_fraction=0.75)
+    ml = sample_model_lane(model, B, {"massBodiesBiasStd": 0.1, "inertiaBodiesBiasStd": 0.1,
+                                      "centerOfMassPositionBodiesBiasStd": 0.05, "relativePositionBodiesBiasStd": 0.02},
+                           torch.Generator().manual_seed(seed)).numpy()
+    heights = 0.02 * rg.standard_normal((7, 9))
+    ground = None if constrained else (heights, -1.0, -0.8, 0.25, 0.3)
+    applied = (rg.normal(0, 30.0, (12, B)), np.array([[0.0, 0.0, 0.0], [0.1, -0.05, 0.02]]))
+    return st, ml, ground, applied
+
+
+def _oracle(model, arr, ml, ground, applied, copt):
+    e = OracleEngine(model)
+    if copt is not None:
+        e.set_constraint_options(**copt)
+        e.bind_constraints(arr["con_flags"], arr["con_data"])
+    e.bind_model_lane(ml)
+    if ground is not None:
+        e.bind_ground(*ground)
+    if applied is not None:
+        e.bind_applied(*applied)
+    return e
+
+
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False)])
+def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, constrained):
+    model = load_builtin(name)
+    B = 16 if name == "anymal" else 4
+    st, ml, ground, applied = _scene(model, B, 5, constrained)
+    copt = TIGHT if constrained else None
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for arr in (ref, got):
+        if constrained:
+            alloc_constraint_state(model, arr, B)
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+    e = _oracle(model, ref, ml, ground, applied, copt)
+    io = oracle_io(ref)
+    kw = dict(variant="quad", constraint_options=copt, model_lane=ml, ground=ground, applied=applied)
+    e.batch_run("start", io)
+    emu.run(model, got, "start", **kw)
+    for k in OUTS:
+        assert rel_err(got[k], ref[k]) < 1e-10, ("start", k)
+    a_start = got["a"].copy()
+    in_contact = np.abs(ref["contact_forces"]).sum(axis=0) > 0
+    for solver in ("runge_kutta_4", "euler_explicit"):
+        for _ in range(2):
+            e.batch_run("step", io, solver=solver, dt=5e-4, n_substeps=2, command_changed=True)
+            emu.run(model, got, "step", solver=solver, dt=5e-4, n_substeps=2, command_changed=True, **kw)
+            in_contact |= np.abs(ref["contact_forces"]).sum(axis=0) > 0
+        ok = (ref["status"][0] & 1) == 0
+        assert ok.sum() >= B - 1
+        for k in OUTS:
+            assert rel_err(got[k], ref[k], ok) < 1e-8, (solver, k)
+    assert in_contact.sum() >= 1
+    # the variation is not a no-op: the nominal model on flat ground without wrenches gives another answer
+    plain = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, plain, B)
+    for k in ("q", "v", "command"):
+        plain[k][:] = st[k]
+    emu.run(model, plain, "start", variant="quad", constraint_options=copt)
+    assert rel_err(plain["a"], a_start) > 1e-3
+
+
+def test_oracle_ground_profile_laws():
+    """A point mass dropped on an inclined plane z = s x feels a normal force along the plane's normal and rests
+    at depth m g n_z / k along it (first-order projection, engine.cc:3138-3145); outside the grid the ground
+    continues flat."""
+    from tests import robots
+    model = robots.point_mass()
+    e = OracleEngine(model)
+    slope = 0.2
+    xs = np.arange(5) * 1.0 - 2.0
+    heights = np.tile(slope * xs[None, :], (4, 1))
+    e.bind_ground(heights, -2.0, -1.5, 1.0, 1.0)
+    q = model.neutral()
+    q[0], q[2] = 0.3, slope * 0.3 - 1e-4        # 0.1 mm below the plane
+    e.start(q, np.zeros(model.nv))
+    f = e.get("contact_forces")[:3]              # contact frame = world aligned for an upright point mass
+    n = np.array([-slope, 0.0, 1.0]) / math.hypot(slope, 1.0)
+    assert np.linalg.norm(f) > 0 and np.allclose(f / np.linalg.norm(f), n, atol=1e-9)
+    # normal force magnitude k * depth with depth = dz * n_z, times the tanh blend of the reference's law
+    depth = 1e-4 * n[2]
+    assert np.linalg.norm(f) == pytest.approx(1.0e6 * depth * math.tanh(2.0 * depth / 1.0e-3), rel=1e-9)
+    q[0] = 50.0                                  # far outside the grid: height of the last sample, zero slope
+    q[2] = slope * 2.0 - 1e-4
+    e.start(q, np.zeros(model.nv))
+    f = e.get("contact_forces")[:3]
+    assert abs(f[0]) < 1e-12 and f[2] > 0
+
+
+def test_model_bias_sampler_follows_the_reference_laws():
+    """`addBiasedToExtendedModel` (model.cc:1166-1236): multiplicative N(1, std) biases, mass floor, inertia biased
+    through its principal axes / moments (stays positive definite), translations only for the relative position."""
+    import torch
+    m = load_builtin("anymal")
+    B = 8192
+    opts = {"massBodiesBiasStd": 0.1, "inertiaBodiesBiasStd": 0.05, "centerOfMassPositionBodiesBiasStd": 0.05,
+            "relativePositionBodiesBiasStd": 0.02}
+    ml = sample_model_lane(m, B, opts, torch.Generator().manual_seed(1)).view(m.njoints, 13, B)
+    nom = nominal_model_lane(m, B).view(m.njoints, 13, B)
+    j = 3
+    r = ml[j, 0] / nom[j, 0]
+    assert float(r.mean()) == pytest.approx(1.0, abs=5e-3) and float(r.std()) == pytest.approx(0.1, rel=5e-2)
+    rc = ml[j, 1:4] / nom[j, 1:4]
+    assert float(rc.std()) == pytest.approx(0.05, rel=5e-2)
+    rp = ml[j, 10:13][nom[j, 10:13].abs() > 1e-9] / nom[j, 10:13][nom[j, 10:13].abs() > 1e-9]
+    assert float(rp.std()) == pytest.approx(0.02, rel=1e-1)
+    I = ml[j, 4:10]
+    M = torch.stack([torch.stack([I[0], I[1], I[2]]), torch.stack([I[1], I[3], I[4]]), torch.stack([I[2], I[4], I[5]])]).permute(2, 0, 1)
+    ev = torch.linalg.eigvalsh(M)
+    ev0 = torch.linalg.eigvalsh(torch.as_tensor(m.inertia[j]))
+    assert float(ev.min()) > 0.0
+    assert torch.allclose(ev.mean(0), ev0, rtol=5e-2)
+    # nothing drawn when every option is zero; only the masked lanes change on an episode-wise re-draw
+    same = sample_model_lane(m, 16, {k: 0.0 for k in opts}, torch.Generator().manual_seed(2))
+    assert torch.equal(same, nominal_model_lane(m, 16))
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[::2] = True
+    again = sample_model_lane(m, B, opts, torch.Generator().manual_seed(3), lane_mask=mask, previous=ml.view(-1, B))
+    assert torch.equal(again[:, ~mask], ml.view(-1, B)[:, ~mask]) and not torch.equal(again[:, mask], ml.view(-1, B)[:, mask])
+    # a tiny mass keeps its floor: max(m * N(1, std), min(m, 1 g))
+    light = load_builtin("anymal")
+    light.mass[4] = 5.0e-4
+    lm = sample_model_lane(light, 4096, {"massBodiesBiasStd": 0.5}, torch.Generator().manual_seed(4)).view(light.njoints, 13, -1)
+    assert float(lm[4, 0].min()) >= 5.0e-4
+
+
+def test_force_breakpoints_cut_the_launches():
+    """Impulse starts / ends are breakpoints of `Engine::step` (engine.cc:1985-2016)."""
+    o = default_options()
+    o["stepper"].update({"controllerUpdatePeriod": 0.01, "sensorsUpdatePeriod": 0.01, "dtMax": 1e-3})
+    iv, t_end, _ = _breakpoint_intervals(0.0, 0.0, 0.02, o, (0.0123, 0.0173))
+    ends = [round(x[0], 10) for x in iv]
+    assert ends == [0.01, 0.0123, 0.0173, 0.02]
+    iv, _, _ = _breakpoint_intervals(0.0, 0.0, 0.02, o, ())
+    assert [round(x[0], 10) for x in iv] == [0.01, 0.02]
+
+
+# ------------------------------------------------------------------ device build
+@pytest.mark.gpu
+@pytest.mark.parametrize("constrained", [False, True])
+def test_gpu_variation_matches_oracle(gpu_device, constrained):
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    B, dt = 96, 5e-4
+    st, ml, ground, applied = _scene(model, B, 9, constrained)
+    copt = TIGHT if constrained else None
+    ref = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, ref, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = _oracle(model, ref, ml, ground, applied, copt)
+    io = oracle_io(ref)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                        extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+    stepper = {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt}
+    if constrained:
+        stepper.update({"tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]})
+    eng.set_options({"stepper": stepper, "contacts": {"model": "constraint" if constrained else "spring_damper"}})
+    eng.set_lane_model(torch.from_numpy(ml))
+    if ground is not None:
+        eng.set_ground_heightmap(*ground)
+    # the two wrenches as profile forces on two frames of the root body (held values)
+    frames = [n for n, f in model.frames.items() if f.parent_joint == 1][:2]
+    offsets = np.array([model.frame(n).p for n in frames])
+    applied = (applied[0], offsets)
+    e.bind_applied(*applied)
+    for i, n in enumerate(frames):
+        w = torch.from_numpy(applied[0][6 * i:6 * i + 6].copy()).to(gpu_device)
+        eng.register_profile_force(n, lambda t, q, v, w=w: w)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+    for k in OUTS:
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < (1e-7 if constrained else 1e-10), ("start", k)
+    for _ in range(4):
+        eng.step(dt)
+        e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=constrained)
+    ok = (ref["status"][0] & 1) == 0
+    for k in OUTS:
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < (1e-5 if constrained else 1e-8), k
+    assert (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() > B // 8
+
+
+@pytest.mark.gpu
+def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
+    """`register_impulse_force` (engine.cc:1838-1893): the wrench acts exactly during [t, t + dt] -- the launches are
+    cut at its breakpoints -- and pushes the base; `set_model_options` draws a biased model per lane at `start`."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    B, dt = 64, 1e-3
+    st = sample_states(model, B, seed=2, base_height=(2.0, 3.0), grounded_fraction=0.0)
+    frame = next(n for n, f in model.frames.items() if f.parent_joint == 1)
+
+    def run(push, std):
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("f_external",))
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 5 * dt,
+                                     "sensorsUpdatePeriod": 5 * dt}, "contacts": {"model": "spring_damper"}})
+        if std:
+            eng.set_model_options({"dynamics": {"massBodiesBiasStd": std}})
+            eng.seed_model(7)
+        if push:
+            eng.register_impulse_force(frame, 0.0032, 0.0041, np.array([400.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+        eng.set_command(torch.from_numpy(st["command"]))
+        eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+        fx = []
+        for _ in range(3):
+            eng.step(5 * dt)
+            fx.append(float(eng.field("f_external")[6:9].abs().max()))
+        return eng.field("v").clone(), fx, eng
+    v0, fx0, _ = run(False, 0.0)
+    v1, fx1, eng = run(True, 0.0)
+    assert max(fx0) == 0.0
+    assert fx1[0] > 0.0 and fx1[1] == 0.0 and fx1[2] == 0.0     # active at t = 5 ms (inside [3.2, 7.3] ms), over by 10 ms
+    # impulse = F dt on a ~50 kg robot: the base gained about 400 * 0.0041 / 52 m/s along the push
+    dv = (v1 - v0)[0:3].norm(dim=0)
+    assert float(dv.median()) == pytest.approx(400.0 * 0.0041 / 52.1, rel=0.2)
+    assert eng.impulse_forces[0]["frame_name"] == frame
+    v2, _, eng2 = run(False, 0.1)
+    ml = eng2.field("model_lane").view(model.njoints, 13, B)
+    assert float((ml[1, 0] / model.mass[1]).std()) == pytest.approx(0.1, rel=0.5)
+    assert not torch.equal(v2, v0)
