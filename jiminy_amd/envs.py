@@ -39,19 +39,28 @@ class VecJiminyEnv:
                  engine_options: Optional[Dict[str, Dict[str, Any]]] = None,
                  dtype: torch.dtype = torch.float64, device: Optional[torch.device] = None,
                  simulation_duration_max: float = 86400.0, auto_reset: bool = True,
-                 std_ratio: Optional[Dict[str, float]] = None) -> None:
+                 std_ratio: Optional[Dict[str, float]] = None,
+                 model_options: Optional[Dict[str, Dict[str, float]]] = None) -> None:
         self.model = model
         # ≙ `WalkerJiminyEnv(std_ratio=...)` (envs/locomotion.py:100-135): scale of the episode-wise
         # randomisation.  Supported keys: 'ground' (friction coefficient of every environment, constraint
         # contact model) and 'sensors' (white noise, bias, delay and jitter of every sensor type, drawn once per
-        # `reset()` for the whole batch: the sensor options are lane-uniform kernel parameters)
+        # `reset()` for the whole batch: the sensor options are lane-uniform kernel parameters) and 'disturbance'
+        # (impulse forces on the root body, envs/locomotion.py:298-331: one random horizontal push per environment
+        # every F_IMPULSE_PERIOD seconds of ENGINE time).  `model_options` ≙ `robot.set_model_options`: standard
+        # deviations of the body mass / centre of mass / inertia / relative position biases
+        # (`{"dynamics": {"massBodiesBiasStd": ...}}`, model.h:147-158); every environment gets its own biased model,
+        # drawn again whenever it is reset
         self.std_ratio = dict(std_ratio or {})
+        self._model_options = model_options
         self.num_envs = int(num_envs)
         self.step_dt = float(step_dt)
         self.engine = BatchedEngine(model, num_envs, dtype=dtype, device=device)
         self.device, self.dtype = self.engine.device, dtype
         if engine_options:
             self.engine.set_options(engine_options)
+        if model_options:
+            self.engine.set_model_options(model_options)
         self.simulation_duration_max = float(simulation_duration_max)
         self.auto_reset = auto_reset
         self._generator = torch.Generator(device="cpu")
@@ -125,6 +134,9 @@ class VecJiminyEnv:
         self._on_reset(None)
         self._randomise_ground(None)
         self._randomise_sensors()
+        self._schedule_disturbances()
+        if self._model_options:
+            self.engine.seed_model(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._generator)))
         self.engine.start(q, v)
         self.num_steps.zero_()
         self._t0.zero_()
@@ -164,6 +176,8 @@ class VecJiminyEnv:
         # is the raw measurement (their generators and histories restart at the next sensor refresh).
         cmd = self.engine.field("command")
         cmd.copy_(torch.where(lane_mask[None, :], torch.zeros_like(cmd), cmd))
+        if self._model_options and "model_lane" in self.engine._fields:
+            self.engine.sample_model_biases(lane_mask)     # a new biased model for the new episode (Model::reset)
         self.engine.reset_lanes(lane_mask, q, v)
         self.num_steps[lane_mask] = 0
         self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
@@ -181,6 +195,33 @@ class VecJiminyEnv:
         if lane_mask is not None and "friction" in self.engine._fields:
             mu = torch.where(lane_mask, mu, self.engine.field("friction")[0])
         self.engine.set_lane_friction(mu)
+
+    # envs/locomotion.py:30-33
+    F_IMPULSE_DT, F_IMPULSE_PERIOD, F_IMPULSE_DELTA, F_IMPULSE_SCALE = 10.0e-3, 2.0, 0.25, 1000.0
+
+    def _schedule_disturbances(self) -> None:
+        """≙ the impulse part of `WalkerJiminyEnv._setup` (envs/locomotion.py:298-326): every F_IMPULSE_PERIOD
+        seconds (+- F_IMPULSE_DELTA, one offset for the batch: breakpoints are shared) a horizontal push of random
+        direction and magnitude U(0, std_ratio['disturbance'] * F_IMPULSE_SCALE) on the root body, one draw per
+        environment.  (The periodic Gaussian-process profile force of :327-331 is available through
+        `engine.register_profile_force`.)"""
+        scale = float(self.std_ratio.get("disturbance", 0.0))
+        self.engine.remove_all_forces()
+        if scale <= 0.0 or not self.model.has_freeflyer:
+            return
+        frame = next(n for n, f in self.model.frames.items() if f.parent_joint == 1)
+        g = self._generator
+        B = self.num_envs
+        t_ref = self.F_IMPULSE_PERIOD
+        while t_ref < self.simulation_duration_max:
+            t = t_ref + self.F_IMPULSE_DELTA * float(torch.rand(1, generator=g) * 2.0 - 1.0)
+            d = torch.randn(2, B, generator=g, dtype=torch.float64)
+            d = d / d.norm(dim=0, keepdim=True)
+            mag = torch.rand(B, generator=g, dtype=torch.float64) * scale * self.F_IMPULSE_SCALE
+            f = torch.zeros(6, B, dtype=torch.float64)
+            f[:2] = d * mag
+            self.engine.register_impulse_force(frame, t, self.F_IMPULSE_DT, f)
+            t_ref += self.F_IMPULSE_PERIOD
 
     # scales of envs/locomotion.py:40-61 (delay [s]; noise and bias per field)
     SENSOR_DELAY_SCALE = {"EncoderSensor": 3.0e-3, "EffortSensor": 0.0, "ContactSensor": 0.0, "ForceSensor": 0.0,

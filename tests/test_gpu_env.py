@@ -287,3 +287,32 @@ def test_env_sensor_randomisation(gpu_device):
         assert torch.isfinite(noisy[k]).all()
         assert torch.equal(noisy[k], again[k]), k
     assert not torch.equal(clean["imu"], noisy["imu"]) and not torch.equal(clean["effort"], noisy["effort"])
+
+
+def test_env_model_biases_and_disturbances(gpu_device):
+    """`model_options` (body biases per environment, re-drawn for the lanes being reset) and
+    `std_ratio={'disturbance': s}` (impulse pushes on the root body, envs/locomotion.py:298-326)."""
+    B = 64
+    env = make_anymal_env(B, device=gpu_device, dt_max=5e-4,
+                          model_options={"dynamics": {"massBodiesBiasStd": 0.05, "inertiaBodiesBiasStd": 0.05}},
+                          std_ratio={"disturbance": 0.2})
+    env.reset(seed=3)
+    ml0 = env.engine.field("model_lane").clone()
+    mass = ml0.view(env.model.njoints, 13, B)[1, 0]
+    assert float(mass.std()) > 0.0 and abs(float(mass.mean()) / env.model.mass[1] - 1.0) < 0.05
+    imp = env.engine.impulse_forces
+    assert len(imp) == 9 and all(abs(f["t"] - 2.0 * (i + 1)) <= 0.25 for i, f in enumerate(imp))
+    assert float(imp[0]["force"][:2].norm(dim=0).max()) <= 0.2 * 1000.0 and float(imp[0]["force"][2:].abs().max()) == 0.0
+    action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
+    z0 = env.observation()["states"]["agent"]["q"][:, :2].clone()
+    for _ in range(60):                      # 2.4 s: the first push has happened
+        obs, _, terminated, truncated, info = env.step(action)
+    moved = (obs["states"]["agent"]["q"][:, :2] - z0).norm(dim=1)
+    assert float(moved.max()) > 1e-3         # pushed sideways; the PD controller keeps them up
+    assert not bool(terminated.any())
+    # a reset lane gets a new biased model, the others keep theirs
+    mask = torch.zeros(B, dtype=torch.bool, device=gpu_device)
+    mask[:8] = True
+    env.reset_lanes(mask)
+    ml1 = env.engine.field("model_lane")
+    assert torch.equal(ml1[:, 8:], ml0[:, 8:]) and not torch.equal(ml1[:, :8], ml0[:, :8])

@@ -203,12 +203,18 @@ def test_gpu_variation_matches_oracle(gpu_device, constrained):
     e.batch_run("start", io)
     for k in OUTS:
         assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < (1e-7 if constrained else 1e-10), ("start", k)
+    ok = np.ones(B, dtype=bool)
     for _ in range(4):
         eng.step(dt)
         e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=constrained)
-    ok = (ref["status"][0] & 1) == 0
+        # lanes that blow up numerically (light biased shanks landing on a bump: explicit RK4 on the stiff ground,
+        # DESIGN.md section 5) leave the comparison, as in the teacher-forced test of test_gpu_parity.py
+        ok &= ((ref["status"][0] & 1) == 0) & (np.abs(ref["v"]).max(axis=0) < 1e2) & (np.abs(ref["a"]).max(axis=0) < 1e6)
+    assert ok.sum() > 0.8 * B
+    errs = {k: rel_err(eng.field(k).cpu().numpy(), ref[k], ok) for k in OUTS}
+    print("variation on the device:", {k: float("%.1e" % v) for k, v in errs.items()})
     for k in OUTS:
-        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < (1e-5 if constrained else 1e-8), k
+        assert errs[k] < (1e-5 if constrained else 1e-8), (k, errs)
     assert (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() > B // 8
 
 
