@@ -325,6 +325,23 @@ int32_t jm_block_pd_controller(int32_t dtype, int64_t batch_size, int32_t nmotor
 int32_t jm_block_mahony_filter(int32_t dtype, int64_t batch_size, int32_t n_imu, const void * imu,
                                void * quat, void * omega, void * cf, void * bias, double kp, double ki,
                                double dt, void * stream);
+/* jm_block_pd_adapter ≙ `pd_adapter` (proportional_derivative_controller.py:166-260), the `PDAdapter` block: from
+ *   the action `[M][B]` (target motor position, `order` 0, or velocity, `order` 1) to the target acceleration
+ *   `out` `[M][B]` held over `step_dt` (or, `is_instantaneous`, the command state `[3][M][B]` moved at once and a
+ *   zero acceleration); `lower` / `upper` `[3][M]`, `velocity_deadband` `[M]` or NULL (host arrays).
+ * jm_block_motor_safety_limit ≙ `apply_safety_limits` (blocks/motor_safety_limit.py:20-77), the `MotorSafetyLimit`
+ *   block: clips the command torques `[M][B]` so that they act against soft position bounds / the velocity limit;
+ *   `encoder` is the raw JM_F_ENCODER field, `encoder_index[m]` the encoder of motor m, the gains and limits are
+ *   host arrays `[M]`. */
+int32_t jm_block_pd_adapter(int32_t dtype, int64_t batch_size, int32_t nmotors, const void * action, int32_t order,
+                            void * command_state, const double * lower, const double * upper,
+                            int32_t is_instantaneous, const double * velocity_deadband, double step_dt,
+                            void * out_acceleration, void * stream);
+int32_t jm_block_motor_safety_limit(int32_t dtype, int64_t batch_size, int32_t nmotors, const void * encoder,
+                                    const int32_t * encoder_index, const void * command, const double * kp,
+                                    const double * kd, const double * soft_position_lower,
+                                    const double * soft_position_upper, const double * velocity_limit,
+                                    const double * effort_limit, void * out_command, void * stream);
 
 /* ---- Sensor white noise and bias (sensor part), batched.
  *

@@ -47,7 +47,7 @@ ABI_SYMBOLS = (
     "jm_batch_adaptive_workspace_rows", "jm_batch_bind_adaptive", "jm_batch_step_adaptive",
     "jm_block_sensor_noise", "jm_sensor_rng_seed",
     "jm_batch_set_constraint_options", "jm_batch_constraint_rows", "jm_block_sensor_delay",
-    "jm_batch_set_ground", "jm_batch_set_applied_frames",
+    "jm_batch_set_ground", "jm_batch_set_applied_frames", "jm_block_pd_adapter", "jm_block_motor_safety_limit",
 )
 
 
@@ -85,6 +85,9 @@ class HipLibrary:
                                              C.c_double, vp, vp]
         L.jm_block_mahony_filter.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, vp, vp, vp, vp,
                                              C.c_double, C.c_double, C.c_double, vp]
+        L.jm_block_pd_adapter.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, C.c_int32, vp, dp, dp, C.c_int32, dp,
+                                          C.c_double, vp, vp]
+        L.jm_block_motor_safety_limit.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, ip, vp, dp, dp, dp, dp, dp, dp, vp, vp]
         L.jm_block_sensor_noise.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, dp, dp, dp, vp]
         L.jm_sensor_rng_seed.argtypes = [C.POINTER(C.c_uint32), C.c_int64, C.c_int32, C.POINTER(C.c_uint64)]
         L.jm_block_sensor_delay.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, ip, dp, C.c_int32, vp,

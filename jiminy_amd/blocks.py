@@ -12,7 +12,8 @@ Two forms of the per-controller-tick blocks:
 * `pd_controller` / `mahony_filter` / `integrate_zoh`: the same arithmetic as elementwise tensor
   programs (scalar branches become `torch.where`), ~40 launches per block.  They run wherever their
   tensors live and serve as the readable specification the kernels are tested against.
-`pd_adapter` runs once per environment step and stays a tensor program.
+`HipBlocks.pd_adapter` / `HipBlocks.motor_safety_limit` are the `PDAdapter` / `MotorSafetyLimit` blocks as single
+launches; `pd_adapter` below is the tensor-program form.
 """
 from __future__ import annotations
 
@@ -76,6 +77,35 @@ class HipBlocks:
         self._check(self._L.jm_block_mahony_filter(
             self._dtype, self._eng.batch_size, n_imu, self._ptr(self._eng.field("imu")), self._ptr(q),
             self._ptr(omega), self._ptr(cf), self._ptr(bias_hat), float(kp), float(ki), float(dt),
+            self._eng._stream()))
+
+
+    def pd_adapter(self, action: torch.Tensor, order: int, command_state: torch.Tensor, is_instantaneous: bool,
+                   velocity_deadband, step_dt: float, out: torch.Tensor) -> None:
+        """≙ `pd_adapter` (proportional_derivative_controller.py:166-260): `action` `[M][B]` -> target
+        acceleration `out` `[M][B]` (command state `[3][M][B]` moved in place when instantaneous)."""
+        import numpy as np
+        C = self._C
+        dp = C.POINTER(C.c_double)
+        db = None
+        if velocity_deadband is not None:
+            db = np.ascontiguousarray(torch.as_tensor(velocity_deadband).cpu().numpy(), dtype=np.float64)
+        self._check(self._L.jm_block_pd_adapter(
+            self._dtype, self._eng.batch_size, self._M, self._ptr(action), int(order), self._ptr(command_state),
+            self._lo.ctypes.data_as(dp), self._hi.ctypes.data_as(dp), int(bool(is_instantaneous)),
+            None if db is None else db.ctypes.data_as(dp), float(step_dt), self._ptr(out), self._eng._stream()))
+
+    def motor_safety_limit(self, command: torch.Tensor, kp, kd, soft_position_lower, soft_position_upper,
+                           velocity_limit, out: torch.Tensor) -> None:
+        """≙ `apply_safety_limits` (blocks/motor_safety_limit.py:20-77) on the engine's raw encoder field."""
+        import numpy as np
+        C = self._C
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        arr = lambda x: np.ascontiguousarray(np.broadcast_to(np.asarray(torch.as_tensor(x).cpu().numpy(), dtype=np.float64), (self._M,)))  # noqa: E731
+        a = [arr(x) for x in (kp, kd, soft_position_lower, soft_position_upper, velocity_limit)]
+        self._check(self._L.jm_block_motor_safety_limit(
+            self._dtype, self._eng.batch_size, self._M, self._ptr(self._eng.field("encoder")), self._enc.ctypes.data_as(ip),
+            self._ptr(command), *[x.ctypes.data_as(dp) for x in a], self._lim.ctypes.data_as(dp), self._ptr(out),
             self._eng._stream()))
 
 

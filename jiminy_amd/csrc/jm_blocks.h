@@ -130,4 +130,82 @@ __global__ void __launch_bounds__(256) k_mahony(int n_imu, const T * imu, T * qu
         bias[o] -= ki * dt * mx; bias[nB + o] -= ki * dt * my; bias[2 * nB + o] -= ki * dt * mz;
     }
 }
+// ---- PDAdapter: `pd_adapter` (proportional_derivative_controller.py:166-260), once per environment step.
+// action [M][B]; command_state [3][M][B] (position, velocity, acceleration targets); out [M][B] = the target
+// acceleration the PD controller holds over the step.  deadband[m] < 0: none.
+struct PdAdapterParams
+{
+    int M, order, instantaneous;
+    double lo[3][JM_BLOCK_MAX_MOTORS], hi[3][JM_BLOCK_MAX_MOTORS], deadband[JM_BLOCK_MAX_MOTORS];
+    double dt;
+};
+template<class T>
+__global__ void __launch_bounds__(256) k_pd_adapter(const PdAdapterParams p, const T * action, T * cs, T * out, long long B)
+{
+    const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (lane >= B || fabs(p.dt) < 1e-9) return;
+    const T dt = (T)p.dt;
+    for (int m = 0; m < p.M; ++m)
+    {
+        T * ps = cs + (long long)m * B + lane;
+        T * vs = ps + (long long)p.M * B;
+        T act = action[(long long)m * B + lane];
+        const bool db = p.deadband[m] >= 0.0;
+        const T dbv = (T)p.deadband[m];
+        T res = T(0);
+        if (p.instantaneous)
+        {
+            if (p.order == 0)
+            {
+                T vel = (act - *ps) / dt;
+                vel = fmin_(fmax_(vel, (T)p.lo[1][m]), (T)p.hi[1][m]);
+                if (db && (vel < T(0) ? -vel : vel) < dbv) vel = T(0);
+                *ps += vel * dt;
+                *vs = T(0);
+            }
+            else
+            {
+                if (db) act = ((act < T(0) ? -act : act) > dbv) ? act : act * T(0);
+                T acc = (act - *vs) / dt;
+                acc = fmin_(fmax_(acc, (T)p.lo[2][m]), (T)p.hi[2][m]);
+                *vs += acc * dt;
+            }
+        }
+        else
+        {
+            T vel = p.order == 0 ? (act - *ps) / dt : act;
+            vel = fmin_(fmax_(vel, (T)p.lo[1][m]), (T)p.hi[1][m]);
+            if (db && (vel < T(0) ? -vel : vel) < dbv) vel = T(0);
+            res = (vel - *vs) / dt;
+        }
+        out[(long long)m * B + lane] = res;
+    }
+}
+
+// ---- MotorSafetyLimit: `apply_safety_limits` (blocks/motor_safety_limit.py:20-77).  encoder raw field
+// [n_enc][2][B]; command / out [M][B].
+struct SafetyParams
+{
+    int M;
+    int enc_index[JM_BLOCK_MAX_MOTORS];
+    double kp[JM_BLOCK_MAX_MOTORS], kd[JM_BLOCK_MAX_MOTORS], soft_lo[JM_BLOCK_MAX_MOTORS], soft_hi[JM_BLOCK_MAX_MOTORS],
+        vel_lim[JM_BLOCK_MAX_MOTORS], eff_lim[JM_BLOCK_MAX_MOTORS];
+};
+template<class T>
+__global__ void __launch_bounds__(256) k_motor_safety_limit(const SafetyParams p, const T * enc, const T * command, T * out, long long B)
+{
+    const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (lane >= B) return;
+    for (int m = 0; m < p.M; ++m)
+    {
+        const long long e = (long long)p.enc_index[m] * 2 * B + lane;
+        const T q = enc[e], v = enc[e + B];
+        const T kp = (T)p.kp[m], kd = (T)p.kd[m], vl = (T)p.vel_lim[m], el = (T)p.eff_lim[m];
+        const T v_lo = vl * fmin_(fmax_(-kp * (q - (T)p.soft_lo[m]), T(-1)), T(1));
+        const T v_hi = vl * fmin_(fmax_(-kp * (q - (T)p.soft_hi[m]), T(-1)), T(1));
+        const T e_lo = el * fmin_(fmax_(-kd * (v - v_lo), T(-1)), T(1));
+        const T e_hi = el * fmin_(fmax_(-kd * (v - v_hi), T(-1)), T(1));
+        out[(long long)m * B + lane] = fmin_(fmax_(command[(long long)m * B + lane], e_lo), e_hi);
+    }
+}
 }  // namespace jm

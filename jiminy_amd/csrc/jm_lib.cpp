@@ -735,6 +735,63 @@ int32_t jm_block_mahony_filter(int32_t dtype, int64_t B, int32_t n_imu, const vo
     return JM_OK;
 }
 
+int32_t jm_block_pd_adapter(int32_t dtype, int64_t B, int32_t M, const void * action, int32_t order, void * command_state,
+                            const double * lower, const double * upper, int32_t is_instantaneous, const double * velocity_deadband,
+                            double step_dt, void * out, void * stream)
+{
+    if (!action || !command_state || !lower || !upper || !out) return fail(JM_EINVAL, "jm_block_pd_adapter: null argument");
+    if (B <= 0 || M <= 0 || M > JM_BLOCK_MAX_MOTORS) return fail(JM_EINVAL, "jm_block_pd_adapter: bad sizes");
+    if (order != 0 && order != 1) return fail(JM_EINVAL, "Derivative order of the target must be either 0 or 1.");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_pd_adapter: bad dtype");
+    jm::PdAdapterParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M; p.order = order; p.instantaneous = is_instantaneous != 0; p.dt = step_dt;
+    for (int m = 0; m < M; ++m)
+    {
+        for (int k = 0; k < 3; ++k) { p.lo[k][m] = lower[k * M + m]; p.hi[k][m] = upper[k * M + m]; }
+        p.deadband[m] = velocity_deadband ? velocity_deadband[m] : -1.0;
+    }
+    const unsigned grid = (unsigned)((B + 255) / 256);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_pd_adapter<double>), dim3(grid), dim3(256), 0, s, p, (const double *)action, (double *)command_state,
+                           (double *)out, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_pd_adapter<float>), dim3(grid), dim3(256), 0, s, p, (const float *)action, (float *)command_state,
+                           (float *)out, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_block_motor_safety_limit(int32_t dtype, int64_t B, int32_t M, const void * encoder, const int32_t * encoder_index,
+                                    const void * command, const double * kp, const double * kd, const double * soft_lo,
+                                    const double * soft_hi, const double * vel_lim, const double * eff_lim, void * out, void * stream)
+{
+    if (!encoder || !encoder_index || !command || !kp || !kd || !soft_lo || !soft_hi || !vel_lim || !eff_lim || !out)
+        return fail(JM_EINVAL, "jm_block_motor_safety_limit: null argument");
+    if (B <= 0 || M <= 0 || M > JM_BLOCK_MAX_MOTORS) return fail(JM_EINVAL, "jm_block_motor_safety_limit: bad sizes");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_motor_safety_limit: bad dtype");
+    jm::SafetyParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M;
+    for (int m = 0; m < M; ++m)
+    {
+        p.enc_index[m] = encoder_index[m];
+        p.kp[m] = kp[m]; p.kd[m] = kd[m]; p.soft_lo[m] = soft_lo[m]; p.soft_hi[m] = soft_hi[m];
+        p.vel_lim[m] = vel_lim[m]; p.eff_lim[m] = eff_lim[m];
+    }
+    const unsigned grid = (unsigned)((B + 255) / 256);
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_motor_safety_limit<double>), dim3(grid), dim3(256), 0, s, p, (const double *)encoder,
+                           (const double *)command, (double *)out, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_motor_safety_limit<float>), dim3(grid), dim3(256), 0, s, p, (const float *)encoder,
+                           (const float *)command, (float *)out, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
 int32_t jm_block_sensor_noise(int32_t dtype, int64_t B, int32_t n_sensors, int32_t n_fields, void * data,
                               uint64_t * rng_state, const double * noise_std, const double * bias,
                               const double * rot_bias_inv, void * stream)

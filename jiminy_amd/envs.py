@@ -397,10 +397,13 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
 
     def _step_engine(self, action: torch.Tensor) -> None:
         a = action.to(self.dtype).T
-        blocks.pd_adapter(a, 1, self.command_state, self.command_state_lower, self.command_state_upper,
-                          False, None, self.step_dt, self._accel)
-        self.command_state[2].copy_(self._accel)
         hb = self._hip_blocks
+        if hb is not None:
+            hb.pd_adapter(a.contiguous(), 1, self.command_state, False, None, self.step_dt, self._accel)
+        else:
+            blocks.pd_adapter(a, 1, self.command_state, self.command_state_lower, self.command_state_upper,
+                              False, None, self.step_dt, self._accel)
+        self.command_state[2].copy_(self._accel)
         for _ in range(self._n_ctrl):
             if hb is not None:
                 # torques go straight into the engine's command rows

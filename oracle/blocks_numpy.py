@@ -107,3 +107,17 @@ def mahony_filter(q, omega, cf, gyro, acc, bias_hat, kp, ki, dt):
         q_w * p_w - q_x * p_x - q_y * p_y - q_z * p_z)
     q *= (3.0 - np.sum(np.square(q), 0)) / 2
     bias_hat -= ki * dt * omega_mes
+
+
+def apply_safety_limits(command, q_measured, v_measured, kp, kd, motors_soft_position_lower,
+                        motors_soft_position_upper, motors_velocity_limit, motors_effort_limit, out):
+    """blocks/motor_safety_limit.py:20-77, statement by statement."""
+    safe_velocity_lower = motors_velocity_limit * np.minimum(np.maximum(
+        -kp * (q_measured - motors_soft_position_lower), -1.0), 1.0)
+    safe_velocity_upper = motors_velocity_limit * np.minimum(np.maximum(
+        -kp * (q_measured - motors_soft_position_upper), -1.0), 1.0)
+    safe_effort_lower = motors_effort_limit * np.minimum(np.maximum(
+        -kd * (v_measured - safe_velocity_lower), -1.0), 1.0)
+    safe_effort_upper = motors_effort_limit * np.minimum(np.maximum(
+        -kd * (v_measured - safe_velocity_upper), -1.0), 1.0)
+    out[:] = np.minimum(np.maximum(command, safe_effort_lower), safe_effort_upper)

@@ -316,3 +316,54 @@ def test_env_model_biases_and_disturbances(gpu_device):
     env.reset_lanes(mask)
     ml1 = env.engine.field("model_lane")
     assert torch.equal(ml1[:, 8:], ml0[:, 8:]) and not torch.equal(ml1[:, :8], ml0[:, :8])
+
+
+def test_hip_pd_adapter_and_motor_safety_limit_match_the_oracle(gpu_device):
+    """`jm_block_pd_adapter` / `jm_block_motor_safety_limit` against oracle/blocks_numpy.py (`pd_adapter`,
+    proportional_derivative_controller.py:166-260; `apply_safety_limits`, motor_safety_limit.py:20-77): both target
+    orders, instantaneous or not, with and without a velocity deadband; shuffled encoder order."""
+    from jiminy_amd import blocks, load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    from oracle import blocks_numpy as orc
+    model = load_builtin("anymal")
+    B, M = 200, model.nmotors
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    rg = np.random.default_rng(4)
+    lo = np.stack([-1.0 - rg.random(M), -3.0 - rg.random(M), -40.0 - 20 * rg.random(M)])
+    hi = np.stack([1.0 + rg.random(M), 3.0 + rg.random(M), 40.0 + 20 * rg.random(M)])
+    enc_idx = rg.permutation(M)
+    hb = blocks.HipBlocks(eng, torch.from_numpy(enc_idx), torch.from_numpy(lo), torch.from_numpy(hi),
+                          torch.ones(M, dtype=torch.float64), torch.ones(M, dtype=torch.float64),
+                          torch.from_numpy(20 + 60 * rg.random(M)))
+    for order in (0, 1):
+        for inst in (False, True):
+            for db in (None, 0.5 * rg.random(M)):
+                action = (rg.random((M, B)) - 0.5) * 10.0
+                cs = np.stack([(rg.random((M, B)) - 0.5) * 2, (rg.random((M, B)) - 0.5) * 6, np.zeros((M, B))])
+                cs_dev = torch.from_numpy(cs).to(gpu_device)
+                out_dev = torch.full((M, B), 7.0, dtype=torch.float64, device=gpu_device)
+                hb.pd_adapter(torch.from_numpy(action).to(gpu_device), order, cs_dev, inst, db, 0.04, out_dev)
+                cs_ref, out_ref = cs.copy(), np.full((M, B), 7.0)
+                for lane in range(B):
+                    state = np.ascontiguousarray(cs_ref[:, :, lane])
+                    o = np.full(M, 7.0)
+                    orc.pd_adapter(action[:, lane].copy(), order, state, lo, hi, inst, db, 0.04, o)
+                    cs_ref[:, :, lane], out_ref[:, lane] = state, o
+                assert np.abs(cs_dev.cpu().numpy() - cs_ref).max() <= 1e-13 * max(np.abs(cs_ref).max(), 1.0), (order, inst)
+                assert np.abs(out_dev.cpu().numpy() - out_ref).max() <= 1e-12 * max(np.abs(out_ref).max(), 1.0), (order, inst)
+    # motor safety limit
+    enc = (rg.random((M, 2, B)) - 0.5) * np.array([3.0, 12.0])[None, :, None]
+    eng.field("encoder").copy_(torch.from_numpy(enc.reshape(2 * M, B)))
+    command = (rg.random((M, B)) - 0.5) * 200.0
+    kp, kd = 20.0 + 10 * rg.random(M), 0.5 + rg.random(M)
+    soft_lo, soft_hi, vlim = -1.0 - 0.2 * rg.random(M), 1.0 + 0.2 * rg.random(M), 4.0 + rg.random(M)
+    out_dev = torch.zeros((M, B), dtype=torch.float64, device=gpu_device)
+    hb.motor_safety_limit(torch.from_numpy(command).to(gpu_device), kp, kd, soft_lo, soft_hi, vlim, out_dev)
+    out_ref = np.zeros((M, B))
+    for lane in range(B):
+        o = np.zeros(M)
+        orc.apply_safety_limits(command[:, lane], enc[enc_idx, 0, lane], enc[enc_idx, 1, lane], kp, kd, soft_lo, soft_hi,
+                                vlim, hb._lim, o)
+        out_ref[:, lane] = o
+    assert np.abs(out_dev.cpu().numpy() - out_ref).max() <= 1e-13 * np.abs(out_ref).max()
+    assert (out_ref != command).mean() > 0.2      # the limits are active on a good part of the batch

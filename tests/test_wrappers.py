@@ -1,0 +1,90 @@
+"""Observation / action wrappers (reference gym_jiminy/common/wrappers: observation_stack.py, normalize.py,
+flatten.py) on a toy vectorised environment with the `VecJiminyEnv` surface (CPU tensors)."""
+import numpy as np
+import pytest
+import torch
+
+from jiminy_amd.wrappers import (FlattenObservation, NormalizeAction, NormalizeObservation, StackObservation,
+                                 flatten_with_path)
+
+
+class _Env:
+    """Observation = step counter per lane in two leaves; lane 1 is re-initialised at step 3."""
+    def __init__(self, B=3):
+        self.B, self.k = B, torch.zeros(B)
+        self.last_action = None
+
+    def observation(self):
+        return {"t": self.k.clone(), "states": {"agent": {"q": self.k[:, None] * torch.tensor([1.0, 10.0]),
+                                                           "v": -self.k[:, None].repeat(1, 3)}}}
+
+    def reset(self, seed=None, options=None):
+        self.k = torch.zeros(self.B)
+        return self.observation(), {}
+
+    def step(self, action):
+        self.last_action = action
+        self.k = self.k + 1
+        info = {}
+        if int(self.k[0]) == 3:
+            mask = torch.tensor([False, True, False])
+            self.k = torch.where(mask, torch.zeros_like(self.k), self.k)
+            info["reset_mask"] = mask
+        return self.observation(), torch.zeros(self.B), torch.zeros(self.B, dtype=torch.bool), torch.zeros(self.B, dtype=torch.bool), info
+
+
+def test_stack_observation_rolls_oldest_first_and_restarts_reset_lanes():
+    env = StackObservation(_Env(), num_stack=3, nested_filter_keys=[("states", "agent", "q")])
+    obs, _ = env.reset()
+    assert obs["states"]["agent"]["q"].shape == (3, 3, 2) and obs["states"]["agent"]["v"].shape == (3, 3)
+    assert torch.equal(obs["states"]["agent"]["q"][:, -1], torch.zeros(3, 2))
+    a = torch.zeros(3, 1)
+    for _ in range(2):
+        obs, *_ = env.step(a)
+    q = obs["states"]["agent"]["q"]
+    assert torch.equal(q[0, :, 0], torch.tensor([0.0, 1.0, 2.0]))       # oldest first, latest last
+    obs, _, _, _, info = env.step(a)                                      # lane 1 re-initialised
+    q = obs["states"]["agent"]["q"]
+    assert torch.equal(q[0, :, 0], torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.equal(q[1], torch.zeros(3, 2))                           # zero history + fresh (zero) observation
+    obs, *_ = env.step(a)
+    assert torch.equal(obs["states"]["agent"]["q"][1, :, 0], torch.tensor([0.0, 0.0, 1.0]))
+    with pytest.raises(ValueError):
+        StackObservation(_Env(), num_stack=2, nested_filter_keys=[("nothing",)]).reset()
+    # skip_frames_ratio = 1: the stack shifts every other step, the last frame is always the current value
+    env = StackObservation(_Env(), num_stack=2, nested_filter_keys=["t"], skip_frames_ratio=1)
+    env.reset()
+    seen = [env.step(a)[0]["t"][0].tolist() for _ in range(4)]
+    assert [s[-1] for s in seen] == [1.0, 2.0, 3.0, 4.0]
+    assert seen[1][0] != seen[2][0] or seen[0][0] != seen[1][0]
+
+
+def test_normalize_observation_and_action_are_affine_without_clipping():
+    env = NormalizeObservation(_Env(), {("states", "agent", "q"): ([-1.0, 0.0], [3.0, 20.0]),
+                                        ("states", "agent", "v"): (-np.inf, np.inf)})
+    env.reset()
+    obs, *_ = env.step(torch.zeros(3, 1))
+    q = obs["states"]["agent"]["q"][0]
+    assert torch.allclose(q, torch.tensor([(1.0 - 1.0) / 2.0, (10.0 - 10.0) / 10.0]))
+    assert torch.equal(obs["states"]["agent"]["v"][0], -torch.ones(3))     # unbounded: untouched
+    for _ in range(5):
+        obs, *_ = env.step(torch.zeros(3, 1))
+    assert float(obs["states"]["agent"]["q"][0, 0]) > 1.0                   # no clipping
+    with pytest.raises(ValueError):
+        NormalizeObservation(_Env(), {}, ignore_unbounded=False).reset()
+    inner = _Env()
+    act = NormalizeAction(inner, low=[-4.0, -np.inf], high=[4.0, np.inf])
+    act.reset()
+    act.step(torch.tensor([[0.5, 2.0]] * 3))
+    assert torch.allclose(inner.last_action, torch.tensor([[2.0, 2.0]] * 3))
+
+
+def test_flatten_observation_concatenates_leaves_in_sorted_key_order():
+    env = FlattenObservation(StackObservation(_Env(), num_stack=2, nested_filter_keys=[("states", "agent", "v")]),
+                             dtype=torch.float32)
+    flat, _ = env.reset()
+    assert flat.shape == (3, 2 + 2 * 3) and flat.dtype == torch.float32
+    paths = [p for p, _ in flatten_with_path(_Env().observation())]
+    assert paths == [("states", "agent", "q"), ("states", "agent", "v"), ("t",)]
+    flat, *_ = env.step(torch.zeros(3, 1))
+    assert torch.equal(flat[0], torch.tensor([1.0, 10.0, 0.0, 0.0, 0.0, -1.0, -1.0, -1.0]))
