@@ -99,6 +99,7 @@ struct jm_batch
     double ground_x0 = 0, ground_y0 = 0, ground_dx = 1, ground_dy = 1;
     int applied_k = 0;
     double applied_p[12] = {0};
+    int n_cus = 256;   // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs (begin, end), ring of JM_TIMING_RING launches
@@ -185,6 +186,17 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
             if (A.model_lane || A.ground_h || A.applied)
             {
                 hipLaunchKernelGGL((jm::k_quad_gen<T, Tp>), dim3(grid), dim3(nth), 0, s, A);
+                return;
+            }
+        }
+        // small batch: one wave per block so that the waves spread over all the CUs (the per-block limb table is
+        // a few kB, staging it four times as often is noise next to idle CUs)
+        if constexpr (jm::quad_block_waves<T, Tp>() > 1)
+        {
+            if ((long long)grid < 2LL * b->n_cus)
+            {
+                const unsigned grid1 = (unsigned)((A.B + 15) / 16);
+                hipLaunchKernelGGL((jm::k_quad<T, Tp, 1>), dim3(grid1), dim3(64), 0, s, A);
                 return;
             }
         }
@@ -433,6 +445,10 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     if (const char * v = std::getenv("JM_KERNEL_VARIANT"))
         if (std::string(v) == "lane") b->variant = VARIANT_LANE;
     hipError_t e = hipSetDevice(device);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) b->n_cus = cus;
+    }
     if (e == hipSuccess) e = hipMalloc(&b->d_params, b->params.size() * sizeof(double));
     if (e != hipSuccess)
     {

@@ -1613,12 +1613,16 @@ template<class T, class Tp> constexpr int quad_block_waves()
     }
     return best;
 }
-template<class T, class Tp>
-__global__ void __launch_bounds__((64 * quad_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
+// W = waves per block (they share one copy of the limb table).  The default, quad_block_waves(), suits large
+// batches; the library also instantiates W = 1, which it launches for SMALL batches (one GPU's share of a
+// sharded batch): four times as many blocks, so that e.g. 4096 Atlas robots = 256 waves land on 256 CUs
+// instead of 64.
+template<class T, class Tp, int W = quad_block_waves<T, Tp>()>
+__global__ void __launch_bounds__((64 * W)) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
 k_quad(const BatchArgs<T> A)
 {
     using Q = QLayout<Tp>;
-    constexpr int NTH = 64 * quad_block_waves<T, Tp>();
+    constexpr int NTH = 64 * W;
     __shared__ T table[Q::TABLE];
     __shared__ T stage_l[QRows<Tp>::NL * NTH];
     __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
