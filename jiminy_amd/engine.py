@@ -224,28 +224,104 @@ def _library_self_test(model: CompiledModel, variant: int, dtype: torch.dtype, d
     first takes the acceleration from the in-loop copy, the second from `start`; a second step
     (one more pass through the loop, from a state the kernel itself produced) must agree too.
     Returns the largest relative disagreement over (v, a)."""
+    err, _ = _library_self_test_detail(model, variant, dtype, device)
+    return err
+
+
+def _library_self_test_detail(model: CompiledModel, variant: int, dtype: torch.dtype,
+                              device: torch.device) -> Tuple[float, Dict[str, float]]:
+    """`_library_self_test` with the disagreement of every leg (solver x launch form)."""
+    n0, dt = 64, 1e-4
+    probe_state = _probe_state(model, n0)
+    # the branch-parallel step kernel has a one-wave-per-block instantiation for small batches and a
+    # several-waves-per-block one for large batches (jm_lib.cpp `launch_quad`): both are probed, and must
+    # agree with each other lane for lane
+    sizes = [n0]
+    if codegen.quad_structure(model) is not None:
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        sizes.append(2 * cus * 16 * 4)
+    err, legs = 0.0, {}
+
+    def rel(x, y, ok):
+        scale = torch.clamp(x[:, ok].abs().max(), min=1.0)
+        e = float(((x - y)[:, ok]).abs().max() / scale)
+        return e if e == e else float("inf")
+    # the explicit-Euler and the Runge-Kutta kernels are separate instantiations: both are checked (the
+    # Runge-Kutta one takes k1 from the last stage evaluation of the previous step, or from the refresh)
+    for solver in ("euler_explicit", "runge_kutta_4"):
+        small = None
+        for n in sizes:
+            q, v, cmd = (torch.as_tensor(np.tile(x, (1, n // n0)), dtype=dtype, device=device) for x in probe_state)
+            outs = []
+            for changed in (False, True):
+                probe = BatchedEngine(model, n, dtype=dtype, device=device, extra_outputs=(), _lib_variant=variant)
+                probe.set_options({"stepper": {"odeSolver": solver, "dtMax": dt,
+                                               "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
+                                   "contacts": {"model": "spring_damper"}})
+                if model.nmotors:
+                    probe.set_command(cmd)
+                probe.start(q, v)
+                res = []
+                for _ in range(2):
+                    if changed:
+                        probe.mark_command_changed()
+                    probe.step(dt)
+                    res += [probe._fields["v"].clone(), probe._fields["a"].clone()]
+                outs.append((res, probe.status.clone()))
+                probe.stop()
+            ok = ((outs[0][1] | outs[1][1]) & _abi.JM_LANE_NAN).reshape(-1) == 0
+            if not bool(ok.any()):
+                legs[f"{solver}/{n}"] = float("inf")   # a state this tame never produces NaN in a sound library
+                err = float("inf")
+                continue
+            e = max(rel(x, y, ok) for x, y in zip(outs[0][0], outs[1][0]))
+            if small is None:
+                small = (outs[0][0], ok)
+            else:   # large-batch launch form against the small-batch one, on the lanes they share
+                ok0 = small[1] & ok[:n0]
+                e = max([e] + [rel(x, y[:, :n0], ok0) for x, y in zip(small[0], outs[0][0])]) if bool(ok0.any()) else float("inf")
+            legs[f"{solver}/{n}"] = e
+            err = max(err, e)
+    return err, legs
+
+
+_GEN_VERIFIED: Dict[Tuple[str, int, str], float] = {}
+
+
+def _variation_self_test(model: CompiledModel, variant: int, device: torch.device, contact_model: str) -> float:
+    """Consistency check of the per-environment variation kernels (`k_quad_gen`, `k_quad_con_gen`: their own
+    instantiations of the evaluation) of one compiled library: with the NOMINAL body
+    parameters bound per lane, a flat height map and zero applied wrenches they must reproduce the plain kernels
+    to round-off over two Runge-Kutta steps.  Returns the largest relative disagreement over (v, a)."""
+    from .randomization import nominal_model_lane
     n, dt = 64, 1e-4
-    q, v, cmd = (torch.as_tensor(x, dtype=dtype, device=device) for x in _probe_state(model, n))
+    q, v, cmd = (torch.as_tensor(x, dtype=torch.float64, device=device) for x in _probe_state(model, n))
     outs = []
-    for changed in (False, True):
-        probe = BatchedEngine(model, n, dtype=dtype, device=device, extra_outputs=(), _lib_variant=variant)
-        probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt,
-                                       "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
-                           "contacts": {"model": "spring_damper"}})
+    for gen in (False, True):
+        probe = BatchedEngine(model, n, dtype=torch.float64, device=device, extra_outputs=(), _lib_variant=variant)
+        probe.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                       "sensorsUpdatePeriod": dt}, "contacts": {"model": contact_model}},
+                          _skip_constraint_check=True)
+        if gen:
+            probe._gen_checked = True
+            probe.set_lane_model(nominal_model_lane(model, n, torch.float64, device))
+            if contact_model == "spring_damper":
+                probe.set_ground_heightmap(np.zeros((3, 3)), -1.0, -1.0, 1.0, 1.0)
+            root = [name for name, f in model.frames.items() if f.parent_joint == 1] if model.has_freeflyer else []
+            if root:
+                probe.register_impulse_force(root[0], 0.0, 1.0, np.zeros(6))
         if model.nmotors:
             probe.set_command(cmd)
         probe.start(q, v)
         res = []
         for _ in range(2):
-            if changed:
-                probe.mark_command_changed()
             probe.step(dt)
             res += [probe._fields["v"].clone(), probe._fields["a"].clone()]
         outs.append((res, probe.status.clone()))
         probe.stop()
-    ok = (outs[0][1] & _abi.JM_LANE_NAN) == 0
+    ok = ((outs[0][1] | outs[1][1]) & _abi.JM_LANE_NAN).reshape(-1) == 0
     if not bool(ok.any()):
-        return float("inf")   # a state this tame never produces NaN in a sound library
+        return float("inf")
     err = 0.0
     for x, y in zip(outs[0][0], outs[1][0]):
         scale = torch.clamp(x[:, ok].abs().max(), min=1.0)
@@ -369,6 +445,8 @@ class BatchedEngine:
         # `_lib_variant` is internal (probe engines of the library self-test)
         self._lib: HipLibrary = (load_for(model, variant=_lib_variant) if _lib_variant is not None
                                  else _verified_library(model, dtype, self.device))
+        self._lib_variant_index = _lib_variant if _lib_variant is not None else \
+            _VERIFIED.get((model.topology_hash(), dtype), codegen.preferred_variant(model))
         self._L = self._lib.L
         self._desc, self._keep = _abi.make_model_desc(model)
         self._model_h = C.c_void_p()
@@ -514,6 +592,26 @@ class BatchedEngine:
                 "with another variant (JIMINY_AMD_BUILD_VARIANT).")
         _CON_VERIFIED[key] = err
 
+    def _check_variation_kernels(self) -> None:
+        """First use of per-lane body parameters / a height map / applied forces for this topology and contact
+        model in the process: run `_variation_self_test` and refuse to run a library that fails it."""
+        if getattr(self, "_gen_checked", False) or self.dtype != torch.float64 or \
+                os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
+            return
+        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields):
+            return
+        self._gen_checked = True
+        variant = self._lib_variant_index
+        key = (self.model.topology_hash(), variant, self._options["contacts"]["model"])
+        if key not in _GEN_VERIFIED:
+            err = _variation_self_test(self.model, variant, self.device, key[2])
+            if not err <= 1e-8:
+                raise RuntimeError(
+                    f"variation-kernel self-test failed for topology {key[0]} ({self.model.name}, build variant "
+                    f"{variant}, contact model {key[2]}): disagreement with the plain kernel {err:.3e} (toolchain "
+                    "mis-compile, DESIGN.md section 4.7); rebuild with another variant (JIMINY_AMD_BUILD_VARIANT).")
+            _GEN_VERIFIED[key] = err
+
     def _apply_options(self) -> None:
         ct = self._options["contacts"]
         o = _abi.make_options(gravity=self._options["world"]["gravity"],
@@ -658,6 +756,7 @@ class BatchedEngine:
         if any(float(v) > EPS for v in self._model_options["dynamics"].values()):
             self.sample_model_biases()   # ≙ Model::reset -> generateModelBiased at the start of every simulation
         self._update_applied_forces(0.0)
+        self._check_variation_kernels()
         self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
         if self._sensor_noise:
             # `Engine::start` measures the sensors INIT_ITERATIONS times while it solves the initial

@@ -5,6 +5,7 @@
 #include <pthread.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -33,12 +34,40 @@ struct QuadShared
     double buf[4];
     int ibuf[4];
 };
+// EMU_UNDEF_CHECK (with amdclang++ -ftrivial-auto-var-init=pattern, which turns every uninitialised floating
+// point local into the all-ones NaN): a quad exchange whose operand is uninitialised on ANY of the four lanes
+// is reported.  On the device such an operand is `undef` on those lanes to the compiler even when only the
+// source lane's value is read, and a DPP move may then read an arbitrary register.
+#ifdef EMU_UNDEF_CHECK
+#include <execinfo.h>
+#include <atomic>
+static std::atomic<int> g_undef_reports{0};
+template<class T> static inline void undef_check(T x)
+{
+    double d = (double)x;
+    unsigned long long bits;
+    std::memcpy(&bits, &d, 8);
+    bool bad = bits == 0xFFFFFFFFFFFFFFFFull;
+    if constexpr (sizeof(T) == 4) { unsigned b32; std::memcpy(&b32, &x, 4); bad = b32 == 0xFFFFFFFFu; }
+    if (bad && g_undef_reports.fetch_add(1) < 40)
+    {
+        void * bt[6];
+        const int n = backtrace(bt, 6);
+        backtrace_symbols_fd(bt, n, 2);
+        fprintf(stderr, "---- uninitialised quad operand\n");
+    }
+}
+extern "C" int emu_undef_reports() { return g_undef_reports.load(); }
+#else
+template<class T> static inline void undef_check(T) {}
+#endif
 struct HostQuad
 {
     static thread_local QuadShared * sh;
     static thread_local int k;
     template<class T> static T quad_sum(T x)
     {
+        undef_check(x);
         sh->buf[k] = (double)x;
         pthread_barrier_wait(&sh->bar);
         // same association as the DPP butterflies: (x_k + x_{k^1}) + (x_{k^2} + x_{k^3})
@@ -49,6 +78,7 @@ struct HostQuad
     }
     template<int LANE, class T> static T bcast(T x)
     {
+        undef_check(x);
         sh->buf[k] = (double)x;
         pthread_barrier_wait(&sh->bar);
         const T r = (T)sh->buf[LANE];
@@ -57,6 +87,7 @@ struct HostQuad
     }
     template<int CTRL, class T> static T perm_(T x)
     {
+        undef_check(x);
         sh->buf[k] = (double)x;
         pthread_barrier_wait(&sh->bar);
         const int src = (CTRL >> (2 * k)) & 3;   // quad_perm: 2 bits per destination lane
@@ -93,7 +124,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad(const jm::Bat
             th.emplace_back([&, k]() {
                 HostQuad::sh = &sh;
                 HostQuad::k = k;
-                std::vector<T> sl(jm::QRows<Tp>::NL + 1), sb(jm::QRows<Tp>::NB + 1);
+                // poisoned: the device LDS is not zero-initialised either
+                std::vector<T> sl(jm::QRows<Tp>::NL + 1, (T)std::nan("")), sb(jm::QRows<Tp>::NB + 1, (T)std::nan(""));
                 const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};  // private trunk rows per thread
                 for (long long r = 0; r < A.B; ++r) jm::quad_lane_run<T, Tp, HostQuad, 1, 1, false, 0, GEN>(A, r, k, table, S);
             });
@@ -120,7 +152,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
             th.emplace_back([&, k]() {
                 HostQuad::sh = &sh;
                 HostQuad::k = k;
-                std::vector<T> sl(jm::QRows<Tp>::NL + 1), sb(jm::QRows<Tp>::NB + 1);
+                // poisoned: the device LDS is not zero-initialised either
+                std::vector<T> sl(jm::QRows<Tp>::NL + 1, (T)std::nan("")), sb(jm::QRows<Tp>::NB + 1, (T)std::nan(""));
                 const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};
                 for (long long r = 0; r < A.B; ++r)
                 {
@@ -220,7 +253,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         else run_quad<T, Topo>(A, P);
         return 0;
     }
-    std::vector<T> sb(jm::stage_rows<Topo>() + 1);
+    std::vector<T> sb(jm::stage_rows<Topo>() + 1, (T)std::nan(""));
     if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
     {
         std::vector<T> wsp((size_t)(jm::ConRows<Topo>::WTOTAL + 1) * io->B, (T)std::nan(""));

@@ -28,11 +28,13 @@ def _lib(model: CompiledModel) -> C.CDLL:
     if h in _CACHE:
         return _CACHE[h]
     hdr = codegen.write_header(model)
-    out = os.path.join(codegen.BUILD, f"libemu_{h}.so")
+    # EMU_CXX / EMU_EXTRA_FLAGS / EMU_TAG: alternative host builds of the same kernel code (e.g. amdclang++ with
+    # -ftrivial-auto-var-init=pattern: every uninitialised local becomes NaN, the hunt of DESIGN.md section 4.7)
+    out = os.path.join(codegen.BUILD, f"libemu_{h}{os.environ.get('EMU_TAG', '')}.so")
     deps = [os.path.join(_HERE, "emu.cpp"), hdr] + codegen._sources()[1:] + \
            []
     if (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O1", *os.environ.get("EMU_EXTRA_FLAGS", "").split(), "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
+        subprocess.check_call([os.environ.get("EMU_CXX", "g++"), "-O1", *os.environ.get("EMU_EXTRA_FLAGS", "").split(), "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3",
                                "-ffp-contract=off", "-pthread", f"-DJM_TOPO_HEADER=\"{hdr}\"",
                                os.path.join(_HERE, "emu.cpp"), "-o", out])
     L = C.CDLL(out)
