@@ -26,7 +26,12 @@ namespace jm
 {
 namespace dopri
 {
-__device__ __constant__ const double A[7][7] = {
+#ifdef JM_HOST_EMU
+#define JM_TABLEAU static const
+#else
+#define JM_TABLEAU __device__ __constant__ const
+#endif
+JM_TABLEAU double A[7][7] = {
     {0, 0, 0, 0, 0, 0, 0},
     {1.0 / 5.0, 0, 0, 0, 0, 0, 0},
     {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0, 0},
@@ -34,7 +39,7 @@ __device__ __constant__ const double A[7][7] = {
     {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0, 0, 0},
     {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0, 0},
     {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0}};
-__device__ __constant__ const double E[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
+JM_TABLEAU double E[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
                                              187.0 / 2100.0, 1.0 / 40.0};
 constexpr double STEPPER_ORDER = 5.0, SAFETY = 0.8, ERROR_THRESHOLD = 0.5, MIN_FACTOR = 0.2, MAX_FACTOR = 5.0;
 }
@@ -157,6 +162,7 @@ template<class T, class Tp> JM_DEV void difference_q(const T * q0, const T * q1,
     });
 }
 
+#ifndef JM_HOST_EMU
 // ---- choose the step size of the next attempt (engine.cc:2021-2131, per lane)
 template<class T, class Tp>
 __global__ void __launch_bounds__(256) k_dopri_prepare(const AdaptiveArgs<T> A)
@@ -373,4 +379,5 @@ __global__ void __launch_bounds__(128) k_dopri_finish(const AdaptiveArgs<T> A)
     fs[AD_DT_LARGEST * B] = dtLargest;
     fs[AD_DT * B] = fmin(dtLargest, A.dt_max);
 }
+#endif  // JM_HOST_EMU
 }  // namespace jm

@@ -28,6 +28,7 @@
 #include "jm_pack.h"
 #include "jm_blocks.h"
 #include "jm_adaptive.h"
+#include "jm_qdopri.h"
 #include "jm_random.h"
 
 #define JM_ABI_VERSION 2
@@ -41,6 +42,7 @@ extern template __global__ void k_constrained<double, Topo>(const BatchArgs<doub
 extern template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
 extern template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
 }
 #endif
@@ -329,6 +331,37 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
     D.con_flags_c = b->ad_flags;
     if (constrained && (!D.con_flags || !D.con_data || !b->ad_flags))
         return fail(JM_ECONTROLFLOW, "contacts.model = 'constraint': bind con_flags / con_data, then jm_batch_bind_adaptive");
+    // branch-parallel topologies, spring-damper contacts, float64: ONE persistent launch per interval, every quad
+    // runs its robot's whole adaptive loop on the chip (jm_qdopri.h); the host only learns whether a robot ran
+    // into the attempt bound of a launch (then it launches again) and the largest attempt count
+    if constexpr (Topo::QUAD && std::is_same<T, double>::value)
+    {
+        if (b->variant == VARIANT_QUAD && !constrained && !b->field[JM_F_MODEL_LANE] && !b->ground_h && b->applied_k == 0)
+        {
+            auto A = make_args<T>(b);
+            A.mode = jm::MODE_DYNAMICS;
+            constexpr int nth = 64 * jm::qdopri_block_waves<T, Topo>();
+            const unsigned grid = (unsigned)((B + nth / 4 - 1) / (nth / 4));
+            const int per_launch = 4096;
+            int total = 0;
+            for (;;)
+            {
+                HIP_TRY(hipMemsetAsync(b->ad_count, 0, 2 * sizeof(int32_t), s));
+                hipLaunchKernelGGL((jm::k_quad_dopri<T, Topo>), dim3(grid), dim3(nth), 0, s, A, D, per_launch);
+                HIP_TRY(hipGetLastError());
+                D.new_step = 0;
+                HIP_TRY(hipMemcpyAsync(b->ad_count_host, b->ad_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                total += b->ad_count_host[1];
+                if (b->ad_count_host[0] == 0) break;
+                if (total >= max_attempts) return fail(JM_ERUNTIME, "adaptive stepper: too many attempts for one breakpoint interval");
+            }
+            if (attempts_out) *attempts_out = total;
+            auto Ar = make_args<T>(b);
+            Ar.mode = jm::MODE_REFRESH; Ar.update_sensors = update_sensors;
+            return launch<T>(b, Ar, stream);
+        }
+    }
     const unsigned g256 = (unsigned)((B + 255) / 256);
     int attempts = 0;
     for (;;)
@@ -609,10 +642,10 @@ int32_t jm_batch_bind_adaptive(jm_batch * b, void * workspace, double * state_f6
     if (!b->ad_count)
     {
         HIP_TRY(hipSetDevice(b->device));
-        HIP_TRY(hipMalloc((void **)&b->ad_count, sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&b->ad_count, 2 * sizeof(int32_t)));
         if (jm::ConRows<Topo>::NF > 0)
             HIP_TRY(hipMalloc((void **)&b->ad_flags, sizeof(int32_t) * (size_t)jm::ConRows<Topo>::NF * (size_t)b->B));
-        HIP_TRY(hipHostMalloc((void **)&b->ad_count_host, sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->ad_count_host, 2 * sizeof(int32_t), hipHostMallocDefault));
     }
     return JM_OK;
 }

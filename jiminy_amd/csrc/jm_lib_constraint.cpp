@@ -5,6 +5,7 @@
 //   -DJM_CON_PART=2  k_quad_con    (jm_qcon.h, branch-parallel: ANYmal, Atlas, ...)
 //   -DJM_CON_PART=3  k_quad_gen     (jm_quad.h with per-lane body parameters / height-map ground / applied forces)
 //   -DJM_CON_PART=4  k_quad_con_gen (the same for the constraint contact model)
+//   -DJM_CON_PART=5  k_quad_dopri   (jm_qdopri.h, the persistent adaptive stepper)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -15,6 +16,9 @@
 #include "jm_kernels.h"
 #include "jm_constraint.h"
 #include "jm_qcon.h"
+#if JM_CON_PART == 5
+#include "jm_qdopri.h"
+#endif
 
 namespace jm
 {
@@ -26,5 +30,7 @@ template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const
 template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
 #elif JM_CON_PART == 4 && JM_TOPO_QUAD
 template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+#elif JM_CON_PART == 5 && JM_TOPO_QUAD
+template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
 }

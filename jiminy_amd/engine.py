@@ -406,7 +406,9 @@ def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.de
     first = codegen.preferred_variant(model)
     if os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
         return load_for(model, variant=first)
-    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    # (garbage from a mis-compiled library is >= 1e-4; sound builds stay below 1e-8: the two copies of the evaluation
+    # contract their multiply-adds differently and a stiff ground contact amplifies that over the two steps)
+    tol = 1e-7 if dtype == torch.float64 else 1e-3
     tried = []
     for variant in [first] + [i for i in range(len(codegen.BUILD_VARIANTS)) if i != first]:
         err = _library_self_test(model, variant, dtype, device)

@@ -15,6 +15,7 @@
 #include "../../jiminy_amd/csrc/jm_constraint.h"
 #include "../../jiminy_amd/csrc/jm_qcon.h"
 #include "../../jiminy_amd/csrc/jm_pack.h"
+#include "../../jiminy_amd/csrc/jm_qdopri.h"
 
 extern "C"
 {
@@ -280,4 +281,55 @@ extern "C" int emu_run(const jm_model_desc * d, const jm_options * o, const emu_
 {
     if (dtype == JM_F64) return run<double>(d, o, io, mode, solver, dt, n_sub, command_changed, update_sensors);
     return run<float>(d, o, io, mode, solver, dt, n_sub, command_changed, update_sensors);
+}
+
+// persistent adaptive stepper of the branch-parallel decomposition (jm_qdopri.h), float64, spring-damper contacts
+extern "C" int emu_run_dopri(const jm_model_desc * d, const jm_options * o, const emu_io * io, double * fs, int32_t * is,
+                             double t_next, double tol_rel, double tol_abs, double dt_max, double dt_restore, int succ_failed_max,
+                             int new_step, int max_attempts, int32_t * counters)
+{
+    using T = double;
+    if constexpr (Topo::QUAD)
+    {
+        std::string why;
+        if (!jm::check_topology<Topo>(*d, why)) return JM_ETOPOLOGY;
+        std::vector<double> P = jm::pack_model<Topo>(*d);
+        jm::pack_options<Topo>(P, *o);
+        jm::pack_quad<Topo>(P, *d);
+        jm::BatchArgs<T> A;
+        std::memset(&A, 0, sizeof(A));
+        A.P = P.data();
+        A.q = (T *)io->q; A.v = (T *)io->v; A.a = (T *)io->a; A.command = (const T *)io->command;
+        A.status = (int32_t *)io->status;
+        A.B = io->B; A.mode = jm::MODE_DYNAMICS;
+        std::vector<T> ws((size_t)(jm::AdaptiveRows<Topo>::TOTAL + 1) * io->B, std::nan(""));
+        jm::AdaptiveArgs<T> D;
+        std::memset(&D, 0, sizeof(D));
+        D.P = P.data(); D.q = A.q; D.v = A.v; D.a = A.a; D.ws = ws.data(); D.command = A.command;
+        D.fs = fs; D.is = is; D.status = A.status; D.n_active = counters; D.B = io->B;
+        D.t_next = t_next; D.tol_rel = tol_rel; D.tol_abs = tol_abs; D.dt_max = dt_max; D.dt_restore_threshold_rel = dt_restore;
+        D.succ_failed_max = succ_failed_max; D.new_step = new_step;
+        counters[0] = counters[1] = 0;
+        QuadShared sh;
+        pthread_barrier_init(&sh.bar, nullptr, 4);
+        const T * table = P.data() + jm::QLayout<Topo>::OFFSET;
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k]() {
+                HostQuad::sh = &sh;
+                HostQuad::k = k;
+                std::vector<T> sl(jm::QRows<Topo>::NL + 1, std::nan("")), sb(jm::QDopriRows<Topo>::NB + 1, std::nan(""));
+                const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};
+                for (long long r = 0; r < A.B; ++r) jm::quad_dopri_run<T, Topo, HostQuad, 1, 1>(A, D, r, k, table, S, max_attempts);
+            });
+        for (auto & t : th) t.join();
+        pthread_barrier_destroy(&sh.bar);
+        return 0;
+    }
+    else
+    {
+        (void)d; (void)o; (void)io; (void)fs; (void)is; (void)t_next; (void)tol_rel; (void)tol_abs; (void)dt_max; (void)dt_restore;
+        (void)succ_failed_max; (void)new_step; (void)max_attempts; (void)counters;
+        return JM_ENOTIMPL;
+    }
 }

@@ -47,6 +47,8 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_void_p, C.c_int, C.c_void_p]
     L.emu_set_gen.restype = None
+    L.emu_run_dopri.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options), C.POINTER(EmuIO), C.c_void_p, C.c_void_p,
+                                C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _CACHE[h] = L
     return L
 
@@ -96,3 +98,44 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
                    float(dt), int(n_substeps), int(command_changed), int(update_sensors))
     if rc != 0:
         raise RuntimeError(f"emu_run failed with code {rc}")
+
+
+# rows of the per-lane stepper state (jm_adaptive.h)
+_AD_F = ("t", "dt", "dt_largest", "dt_largest_prev", "dt_try")
+_AD_I = ("iter", "iter_failed", "succ_too_large", "succ_failed", "active", "bp_reached", "map")
+
+
+def run_dopri(model: CompiledModel, arrays: Dict[str, np.ndarray], adaptive: Dict[str, np.ndarray], t_next: float,
+              tol_rel: float = 1e-4, tol_abs: float = 1e-5, dt_max: float = 0.02, dt_restore_threshold_rel: float = 0.2,
+              successive_iter_failed_max: int = 1000, new_step: bool = True, options=None, max_attempts: int = 100000):
+    """The persistent adaptive stepper (jm_qdopri.h) on the host: every robot of `arrays` to `t_next`; `adaptive` is
+    the per-lane stepper state in the oracle's form (oracle_py.adaptive_state), updated in place.  Returns
+    (robots still active, largest attempt count)."""
+    L = _lib(model)
+    B = arrays["q"].shape[-1]
+    fs = np.zeros((len(_AD_F), B))
+    isv = np.zeros((len(_AD_I), B), dtype=np.int32)
+    for i, n in enumerate(_AD_F[:4]):
+        fs[i] = adaptive[n]
+    for i, n in enumerate(_AD_I[:4]):
+        isv[i] = adaptive[n]
+    desc, keep = _abi.make_model_desc(model)
+    opts = options if options is not None else _abi.make_options()
+    io = EmuIO()
+    io.B = B
+    for n in _FIELDS:
+        a = arrays.get(n)
+        if a is not None:
+            assert a.flags.c_contiguous, n
+            setattr(io, n, a.ctypes.data)
+    counters = np.zeros(2, dtype=np.int32)
+    rc = L.emu_run_dopri(C.byref(desc), C.byref(opts), C.byref(io), fs.ctypes.data, isv.ctypes.data, float(t_next),
+                         float(tol_rel), float(tol_abs), float(dt_max), float(dt_restore_threshold_rel),
+                         int(successive_iter_failed_max), int(new_step), int(max_attempts), counters.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"emu_run_dopri failed with code {rc}")
+    for i, n in enumerate(_AD_F[:4]):
+        adaptive[n][:] = fs[i]
+    for i, n in enumerate(_AD_I[:4]):
+        adaptive[n][:] = isv[i]
+    return int(counters[0]), int(counters[1])

@@ -210,3 +210,42 @@ def test_long_horizon_sensitivity():
     assert ok.sum() >= 32
     assert np.median(err) < 1e-9
     assert (err <= 1e-5).mean() >= 0.9
+
+
+@pytest.mark.parametrize("name", ["anymal", "crane_walker"])
+def test_persistent_adaptive_stepper_matches_oracle(name):
+    """jm_qdopri.h (every quad runs its robot's whole Dormand-Prince loop to the breakpoint) against the oracle's
+    restatement of the reference's adaptive loop: robots in free flight and robots landing on the ground, three
+    breakpoint intervals.  Accept / reject decisions are discontinuous in the error estimate, so the robots that
+    follow the oracle's step sequence (all but a few) agree to round-off and the others within the tolerance."""
+    from oracle.oracle_py import OracleEngine, adaptive_state
+    from tests.helpers import oracle_io
+    model = robots.crane_walker() if name == "crane_walker" else load_builtin(name)
+    B = 16
+    st = sample_states(model, B, seed=21, base_height=(0.5, 0.7) if name == "anymal" else (0.5, 0.8), grounded_fraction=0.4)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+        got[k][:] = st[k]
+    orc = OracleEngine(model)
+    io = oracle_io(ref)
+    orc.batch_run("start", io)
+    emu.run(model, got, "start", variant="quad")
+    ad_ref, ad_got = adaptive_state(B), adaptive_state(B)
+    for k in ("iter", "iter_failed", "succ_too_large", "succ_failed"):
+        ad_got[k] = ad_got[k].astype(np.int64)
+    tol = dict(tol_rel=1e-6, tol_abs=1e-7)
+    for i, t_next in enumerate((2e-3, 4e-3, 7e-3)):
+        orc.batch_run_dopri(io, ad_ref, t_next, new_step=True, command_changed=False, update_sensors=False, **tol)
+        left, attempts = emu.run_dopri(model, got, ad_got, t_next, new_step=True, **tol)
+        assert left == 0 and attempts >= 1
+    ok = ((ref["status"][0] | got["status"][0]) & 9) == 0
+    assert ok.sum() >= B - 2
+    same = ok & (ad_got["iter"] == ad_ref["iter"]) & (ad_got["iter_failed"] == ad_ref["iter_failed"])
+    assert same.mean() > 0.8, (ad_got["iter"], ad_ref["iter"], ad_got["iter_failed"], ad_ref["iter_failed"])
+    assert np.allclose(ad_got["t"][ok], 7e-3, rtol=0, atol=1e-12)
+    for k in ("q", "v", "a"):
+        scale = max(np.abs(ref[k][:, same]).max(), 1.0)
+        assert np.abs(got[k] - ref[k])[:, same].max() / scale < 1e-7, k
+        assert np.abs(got[k] - ref[k])[:, ok].max() / scale < 1e-2, k
+    assert np.allclose(ad_got["dt_largest"][same], ad_ref["dt_largest"][same], rtol=1e-5)
