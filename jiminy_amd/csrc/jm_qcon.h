@@ -44,6 +44,13 @@
 #ifndef JM_QCON_SKIP
 #define JM_QCON_SKIP 0   // profiling only: bit 0 skip the PGS sweeps, 1 the delassus rounds, 2 the closing evaluation
 #endif
+#ifndef JM_QCON_PGS_INCR
+#define JM_QCON_PGS_INCR 1  // register-resident PGS: 1 = residuals maintained incrementally (y -= A[:, i] dx after every update,
+                            // no dot products and no quad reductions inside the sweeps), 0 = residual of a row = b - A x at its turn
+#endif
+#ifndef JM_QCON_PGS_FIXED
+#define JM_QCON_PGS_FIXED 1 // waves whose robots all fit the fixed row layout of qcon_pgs_fixed take it
+#endif
 #ifndef JM_QCON_DELTA
 #define JM_QCON_DELTA 0  // 1: evaluations that emit nothing apply the multipliers with one bias-free solve instead of the closing
                          // full evaluation (cheaper arithmetic, but it keeps the free evaluation's data live across the PGS
@@ -780,6 +787,126 @@ JM_DEV bool qcon_pgs_regs(const QConArgs<T> & C, T friction, int k, const QConCt
     });
     const bool contacts_only = !X::wave_any(!(nb == 0 && cb == 3));
     bool converged = false;
+#if JM_QCON_PGS_INCR
+    // Residual-maintaining form: y = b - A x is kept up to date for this lane's rows (i = k mod 4): a row update
+    // x_i += dx costs the lane NIT multiply-adds on its rows (column i of A = row i, the matrix is symmetric) instead
+    // of a dot product + quad butterfly per row.  At its turn the owner lane broadcasts y_i; the projection and the
+    // stagnation bookkeeping (|y_i - y_i of the previous sweep|, |y_i|: constraint_solvers.cc:263-278) then run
+    // replicated in the four lanes.  Same iterates as the dot-product form up to the rounding of the running sums.
+    T yturn[MR];   // residual of every row at its turn in the previous sweep (zero until a row is touched)
+    static_for<0, MR>([&](auto ic) { yturn[decltype(ic)::value] = T(0); });
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if ((rows_any >> i) & 1u)
+        {
+            T s = T(0);
+            static_for<0, NIT>([&](auto jc) { s += Aq[i][decltype(jc)::value] * xq[decltype(jc)::value]; });
+            const T tot = X::quad_sum(s);
+            if (k == (i & 3)) yq[i >> 2] = bq[i >> 2] - tot;
+        }
+    });
+#pragma nounroll
+    for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
+    {
+        T dmax = T(0), ymax = T(0);
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        auto residual = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T yy = X::template bcast<(i & 3)>(yq[i >> 2]);
+            dmax = X::max_abs(dmax, yy - yturn[i]);
+            ymax = X::max_abs(ymax, yy);
+            yturn[i] = yy;
+            return yy;
+        };
+        auto set_x = [&](auto ic, T val) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T dx = val - x[i];
+            x[i] = val;
+            static_for<0, NIT>([&](auto jc) { yq[decltype(jc)::value] -= Aq[i][decltype(jc)::value] * dx; });
+        };
+        auto cone = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (friction_zero)
+            {
+                set_x(ic, x[i] * T(0));
+                set_x(std::integral_constant<int, i + 1>{}, x[i + 1] * T(0));
+            }
+            else
+            {
+                const T y0 = residual(ic);
+                const T y1 = residual(std::integral_constant<int, i + 1>{});
+                const T ia = fmin_(invd[i], invd[i + 1]);   // 1 / max(a00, a11)
+                T e0 = x[i] + (w * y0) * ia;
+                T e1 = x[i + 1] + (w * y1) * ia;
+                const T thr = friction * x[i + 2];
+                const T n2 = e0 * e0 + e1 * e1;
+                if (n2 > thr * thr)
+                {
+                    const T scale = thr / sqrt_(n2);
+                    e0 *= scale;
+                    e1 *= scale;
+                }
+                set_x(ic, e0);
+                set_x(std::integral_constant<int, i + 1>{}, e1);
+            }
+        };
+        if (contacts_only)
+        {
+            static_for<0, MR / 3>([&](auto jc) {
+                constexpr int i = 3 * decltype(jc)::value + 2;
+                if (i < m)
+                {
+                    const T yy = residual(std::integral_constant<int, i>{});
+                    set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+                }
+            });
+            static_for<0, MR / 3>([&](auto jc) {
+                constexpr int i = 3 * decltype(jc)::value;
+                if (i + 2 < m) cone(std::integral_constant<int, i>{});
+            });
+        }
+        else
+        {
+        static_for<0, MR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any0 >> i) & 1u)
+                if ((mask0 >> i) & 1u)
+                {
+                    const T yy = residual(ic);
+                    set_x(ic, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+                }
+        });
+        static_for<1, MR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any1 >> i) & 1u)
+            if ((mask1 >> i) & 1u)
+            {
+                if (torsion_zero) set_x(ic, x[i] * T(0));
+                else
+                {
+                    const T yy = residual(ic);
+                    const T thr = C.torsion * x[i - 1];
+                    set_x(ic, clamp_(x[i] + (w * yy) * invd[i], -thr, thr));
+                }
+            }
+        });
+        static_for<0, MR - 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if ((any2 >> i) & 1u)
+                if ((mask2 >> i) & 1u) cone(ic);
+        });
+        }
+        // (every lane followed every row: dmax / ymax are already those of the robot)
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        converged = dmax < tol;
+    }
+#else
 #pragma nounroll
     for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
     {
@@ -891,10 +1018,167 @@ JM_DEV bool qcon_pgs_regs(const QConArgs<T> & C, T friction, int k, const QConCt
         const T tol = C.tol_abs + C.tol_rel * ymax + eps;
         converged = dmax < tol;
     }
+#endif
     // multipliers back to the region (qcon_scatter reads them from there)
     X::sync();
     if (lead)
         static_for<0, MR>([&](auto ic) { if (decltype(ic)::value < m) Lr[decltype(ic)::value] = x[decltype(ic)::value]; });
+    X::sync();
+    return converged;
+}
+
+// The register-resident solver on a FIXED row layout (robots with few contact points: ANYmal's four feet): contact
+// point c always sits at positions 3c (tangential x, y) and 3c + 2 (normal), the active joint bounds at the MR - 3 NC
+// positions behind them, whatever the packed order of the robot's solver region.  The kind of every position is
+// then known at compile time and identical for every robot of the wave: a sweep is straight-line code -- bounds,
+// normals, friction cones in the reference's order -- with no per-robot branch and no per-row mask test; a position
+// that a robot does not use holds zeros (x, its row and column of A, b, 1 / diag), whose update is the identity.
+// Residuals are maintained incrementally like in qcon_pgs_regs.  Taken when every robot of the wave has 3-row
+// contact blocks (contacts.torsion = 0), a positive friction coefficient and at most MR - 3 NC active bounds.
+template<class T, class Tp, class X, int NIT>
+JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConCtx<T, Tp> & cx, T * Lr)
+{
+    using R = ConRows<Tp>;
+    constexpr int MR = 4 * NIT, NC = R::NC, NBF = MR - 3 * NC;
+    static_assert(NBF >= 0, "fixed layout needs 3 rows per contact point on chip");
+    const int m = cx.m, nb = cx.nb, A0 = 4 * m;
+    const bool lead = (k == 0);
+    const T eps = Eps<T>::eps;
+    const unsigned iter_max = (unsigned)C.iter_max;
+    // position -> packed row of this robot's region (-1: unused)
+    int pk[MR];
+    unsigned used = 0u;
+    static_for<0, NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const bool on = cx.act.test(R::NB + 4 * c);
+        const int base = cx.act.rank(R::NB + 4 * c);
+        pk[3 * c] = on ? base : -1; pk[3 * c + 1] = on ? base + 1 : -1; pk[3 * c + 2] = on ? base + 2 : -1;
+        used |= on ? (7u << (3 * c)) : 0u;
+    });
+    static_for<0, NBF>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        pk[3 * NC + q] = q < nb ? q : -1;
+        used |= q < nb ? (1u << (3 * NC + q)) : 0u;
+    });
+    T Aq[MR][NIT], x[MR], invd[MR], yturn[MR], bq[NIT], yq[NIT], xq[NIT];
+    int pkq[NIT];
+    static_for<0, NIT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        pkq[j] = k == 0 ? pk[4 * j] : (k == 1 ? pk[4 * j + 1] : (k == 2 ? pk[4 * j + 2] : pk[4 * j + 3]));
+    });
+    X::sync();
+    static_for<0, NIT>([&](auto jc) {
+        const int i = k + 4 * decltype(jc)::value;
+        if (i < m) Lr[3 * m + i] = T(1) / Lr[A0 + i * (i + 1) / 2 + i];
+    });
+    X::sync();
+    unsigned used_any = 0u;
+    static_for<0, MR>([&](auto ic) { used_any |= X::wave_any((used >> decltype(ic)::value) & 1u) ? (1u << decltype(ic)::value) : 0u; });
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        x[i] = T(0); invd[i] = T(0); yturn[i] = T(0);
+        static_for<0, NIT>([&](auto jc) { Aq[i][decltype(jc)::value] = T(0); });
+        if ((used_any >> i) & 1u)
+        {
+            const int pi = pk[i];
+            const bool vi = pi >= 0;
+            const T xi = Lr[vi ? pi : 0], di = Lr[vi ? 3 * m + pi : 0];
+            x[i] = vi ? xi : T(0);
+            invd[i] = vi ? di : T(0);
+            static_for<0, NIT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int pc = pkq[j];
+                const bool v = vi && pc >= 0;
+                const T a = Lr[v ? A0 + tri_(pi, pc) : 0];
+                Aq[i][j] = v ? a : T(0);
+            });
+        }
+    });
+    static_for<0, NIT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        xq[j] = k == 0 ? x[4 * j] : (k == 1 ? x[4 * j + 1] : (k == 2 ? x[4 * j + 2] : x[4 * j + 3]));
+        const T bi = Lr[pkq[j] >= 0 ? m + pkq[j] : 0];
+        bq[j] = pkq[j] >= 0 ? bi : T(0);
+        yq[j] = T(0);
+    });
+    // y = b - A x for this lane's positions
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if ((used_any >> i) & 1u)
+        {
+            T sacc = T(0);
+            static_for<0, NIT>([&](auto jc) { sacc += Aq[i][decltype(jc)::value] * xq[decltype(jc)::value]; });
+            const T tot = X::quad_sum(sacc);
+            if (k == (i & 3)) yq[i >> 2] = bq[i >> 2] - tot;
+        }
+    });
+    bool converged = false;
+#pragma nounroll
+    for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
+    {
+        T dmax = T(0), ymax = T(0);
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        auto residual = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T yy = X::template bcast<(i & 3)>(yq[i >> 2]);
+            dmax = X::max_abs(dmax, yy - yturn[i]);
+            ymax = X::max_abs(ymax, yy);
+            yturn[i] = yy;
+            return yy;
+        };
+        auto set_x = [&](auto ic, T val) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T dx = val - x[i];
+            x[i] = val;
+            static_for<0, NIT>([&](auto jc) { yq[decltype(jc)::value] -= Aq[i][decltype(jc)::value] * dx; });
+        };
+        // block 0: joint bounds, then the normal forces (unilateral)
+        static_for<0, NBF>([&](auto qc) {
+            constexpr int i = 3 * NC + decltype(qc)::value;
+            if ((used_any >> i) & 1u)
+            {
+                const T yy = residual(std::integral_constant<int, i>{});
+                set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+            }
+        });
+        static_for<0, NC>([&](auto cc) {
+            constexpr int i = 3 * decltype(cc)::value + 2;
+            if ((used_any >> i) & 1u)
+            {
+                const T yy = residual(std::integral_constant<int, i>{});
+                set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
+            }
+        });
+        // block 2: friction cones (rows i, i + 1; normal force = row i + 2)
+        static_for<0, NC>([&](auto cc) {
+            constexpr int i = 3 * decltype(cc)::value;
+            if ((used_any >> i) & 1u)
+            {
+                const T y0 = residual(std::integral_constant<int, i>{});
+                const T y1 = residual(std::integral_constant<int, i + 1>{});
+                const T ia = fmin_(invd[i], invd[i + 1]);   // 1 / max(a00, a11)
+                T e0 = x[i] + (w * y0) * ia;
+                T e1 = x[i + 1] + (w * y1) * ia;
+                const T thr = friction * x[i + 2];
+                const T n2 = e0 * e0 + e1 * e1;
+                const bool out = n2 > thr * thr;
+                const T scale = out ? thr / sqrt_(out ? n2 : T(1)) : T(1);
+                set_x(std::integral_constant<int, i>{}, e0 * scale);
+                set_x(std::integral_constant<int, i + 1>{}, e1 * scale);
+            }
+        });
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        converged = dmax < tol;
+    }
+    X::sync();
+    if (lead)
+        static_for<0, MR>([&](auto ic) { if (pk[decltype(ic)::value] >= 0) Lr[pk[decltype(ic)::value]] = x[decltype(ic)::value]; });
     X::sync();
     return converged;
 }
@@ -1105,7 +1389,16 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 bool ok = true;
                 if constexpr (VS::ON_CHIP)
                 {
-                    if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs_regs<T, Tp, X, VS::NIT>(C, friction, k, cx, W.lds);
+                    if (!(JM_QCON_SKIP & 1))
+                    {
+                        bool fixed = false;
+                        if constexpr (JM_QCON_PGS_FIXED && 3 * ConRows<Tp>::NC <= 4 * VS::NIT)
+                        {
+                            fixed = !X::wave_any(cx.cb != 3 || cx.nb > 4 * VS::NIT - 3 * ConRows<Tp>::NC || friction < Eps<T>::eps);
+                            if (fixed) ok = qcon_pgs_fixed<T, Tp, X, VS::NIT>(C, friction, k, cx, W.lds);
+                        }
+                        if (!fixed) ok = qcon_pgs_regs<T, Tp, X, VS::NIT>(C, friction, k, cx, W.lds);
+                    }
                 }
                 else if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs<T, Tp, X, VS>(C, friction, k, cx, W);
                 if (ok) status &= ~JM_LANE_SOLVER_FAILURE;

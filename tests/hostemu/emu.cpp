@@ -284,9 +284,10 @@ extern "C" int emu_run(const jm_model_desc * d, const jm_options * o, const emu_
 }
 
 // persistent adaptive stepper of the branch-parallel decomposition (jm_qdopri.h), float64, spring-damper contacts
-extern "C" int emu_run_dopri(const jm_model_desc * d, const jm_options * o, const emu_io * io, double * fs, int32_t * is,
-                             double t_next, double tol_rel, double tol_abs, double dt_max, double dt_restore, int succ_failed_max,
-                             int new_step, int max_attempts, int32_t * counters)
+template<class Topo>
+static int run_dopri_impl(const jm_model_desc * d, const jm_options * o, const emu_io * io, double * fs, int32_t * is,
+                          double t_next, double tol_rel, double tol_abs, double dt_max, double dt_restore, int succ_failed_max,
+                          int new_step, int max_attempts, int32_t * counters)
 {
     using T = double;
     if constexpr (Topo::QUAD)
@@ -332,4 +333,11 @@ extern "C" int emu_run_dopri(const jm_model_desc * d, const jm_options * o, cons
         (void)succ_failed_max; (void)new_step; (void)max_attempts; (void)counters;
         return JM_ENOTIMPL;
     }
+}
+extern "C" int emu_run_dopri(const jm_model_desc * d, const jm_options * o, const emu_io * io, double * fs, int32_t * is,
+                             double t_next, double tol_rel, double tol_abs, double dt_max, double dt_restore, int succ_failed_max,
+                             int new_step, int max_attempts, int32_t * counters)
+{
+    return run_dopri_impl<::Topo>(d, o, io, fs, is, t_next, tol_rel, tol_abs, dt_max, dt_restore, succ_failed_max, new_step,
+                                  max_attempts, counters);
 }
