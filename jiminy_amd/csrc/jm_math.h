@@ -334,6 +334,19 @@ JM_DEV float rcp_(float x) { return 1.0f / x; }
 #endif
 JM_DEV double sqrt_(double x) { return ::sqrt(x); }
 JM_DEV float sqrt_(float x) { return ::sqrtf(x); }
+// 1 / sqrt(x) of a well-scaled positive number: hardware estimate + two Newton steps
+#ifdef JM_HOST_EMU
+JM_DEV double rsqrt_(double x) { return 1.0 / ::sqrt(x); }
+#else
+JM_DEV double rsqrt_(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(y, __builtin_fma(-0.5 * x * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-0.5 * x * y, y, 0.5), y);
+    return y;
+}
+#endif
+JM_DEV float rsqrt_(float x) { return 1.0f / ::sqrtf(x); }
 JM_DEV double trunc_(double x) { return ::trunc(x); }
 JM_DEV float trunc_(float x) { return ::truncf(x); }
 JM_DEV double tanh_(double x) { return ::tanh(x); }

@@ -1069,7 +1069,7 @@ JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConC
     X::sync();
     static_for<0, NIT>([&](auto jc) {
         const int i = k + 4 * decltype(jc)::value;
-        if (i < m) Lr[3 * m + i] = T(1) / Lr[A0 + i * (i + 1) / 2 + i];
+        if (i < m) Lr[3 * m + i] = rcp_(Lr[A0 + i * (i + 1) / 2 + i]);
     });
     X::sync();
     unsigned used_any = 0u;
@@ -1113,11 +1113,12 @@ JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConC
         }
     });
     bool converged = false;
+    const T ratio_den = T(1) / T(iter_max - 20u - 30u);
 #pragma nounroll
     for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
     {
         T dmax = T(0), ymax = T(0);
-        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        const T ratio = (T(iter_max - 20u) - T(iter)) * ratio_den;
         T w = T(1);
         if (ratio < T(1))
         {
@@ -1168,7 +1169,7 @@ JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConC
                 const T thr = friction * x[i + 2];
                 const T n2 = e0 * e0 + e1 * e1;
                 const bool out = n2 > thr * thr;
-                const T scale = out ? thr / sqrt_(out ? n2 : T(1)) : T(1);
+                const T scale = out ? thr * rsqrt_(out ? n2 : T(1)) : T(1);
                 set_x(std::integral_constant<int, i>{}, e0 * scale);
                 set_x(std::integral_constant<int, i + 1>{}, e1 * scale);
             }
