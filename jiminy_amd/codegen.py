@@ -293,10 +293,36 @@ def _sources() -> List[str]:
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 
+def source_digest(model: CompiledModel, variant: Optional[int] = None, extra_flags: Optional[List[str]] = None) -> str:
+    """Digest of everything a topology library is compiled from: the kernel sources, the generated topology header
+    and the flags of its build variant.  Stored next to the library (`<lib>.src`) when it is built."""
+    import hashlib
+    v = preferred_variant(model) if variant is None else variant
+    h = hashlib.sha256()
+    for path in _sources():
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(topology_header(model).encode())
+    h.update(" ".join(BUILD_VARIANTS[v]).encode() if v < len(BUILD_VARIANTS) else b"?")
+    h.update(" ".join(extra_flags or []).encode())
+    return h.hexdigest()
+
+
 def is_stale(model: CompiledModel, variant: Optional[int] = None) -> bool:
+    """A library is stale when it was built from other sources than the ones in the tree: content digest recorded at
+    build time (file times do not survive a checkout or a copy to another machine); libraries without a record fall
+    back to the file times."""
     lib = lib_path(model, variant)
     if not os.path.exists(lib):
         return True
+    try:
+        with open(lib + ".src") as f:
+            recorded = f.read().split()
+        if os.environ.get("JIMINY_AMD_LIB_TAG"):
+            return False   # experimental builds carry their own flags: never rebuilt behind the experimenter's back
+        return recorded[0] != source_digest(model, variant)
+    except (OSError, IndexError):
+        pass
     t = os.path.getmtime(lib)
     deps = _sources() + [header_path(model)]
     return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
@@ -339,4 +365,6 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
     for o in objs:
         os.remove(o)
     os.replace(lib + ".tmp", lib)
+    with open(lib + ".src", "w") as f:
+        f.write(source_digest(model, v, extra_flags) + "\n")
     return lib
