@@ -147,15 +147,19 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                         incb[d] = s0 * S.getb(R::V0B + d);
                         acc[d] = s0 * S.getb(DR::A0B + d);
                     });
-                    for (int j = 1; j < i; ++j)
-                    {
+                    // (all five earlier stages, the ones that do not exist yet with a zero operand: the reads are
+                    // issued together instead of one dependent round trip per stage)
+                    static_for<1, 6>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const bool on = j < i;
                         const T sj = dtT * (T)dopri::A[i][j];
                         static_for<0, NVB>([&](auto ic) {
                             constexpr int d = decltype(ic)::value;
-                            incb[d] += sj * S.getb(DR::KVB + (j - 1) * NVB + d);
-                            acc[d] += sj * S.getb(DR::KAB + (j - 1) * NVB + d);
+                            const T kv = S.getb(DR::KVB + (j - 1) * NVB + d), ka = S.getb(DR::KAB + (j - 1) * NVB + d);
+                            incb[d] += sj * (on ? kv : T(0));
+                            acc[d] += sj * (on ? ka : T(0));
                         });
-                    }
+                    });
                     integrate_freeflyer<T>(q0b, incb, qb);
                     static_for<1, NT>([&](auto tc) { qb[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + incb[5 + decltype(tc)::value]; });
                     static_for<0, NVB>([&](auto ic) {
@@ -169,13 +173,18 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                     constexpr int s = decltype(sc)::value;
                     const T v0 = S.getl(R::V0L + s);
                     T inc = s0 * v0, acc = s0 * S.getl(DR::A0L + s);
-                    if (ix.has[s])
-                        for (int j = 1; j < i; ++j)
-                        {
-                            const T sj = dtT * (T)dopri::A[i][j];
-                            inc += sj * kvl[krow(j, s)];
-                            acc += sj * kal[krow(j, s)];
-                        }
+                    T kvj[5], kaj[5];
+                    static_for<1, 6>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        kvj[j - 1] = kvl[krow(j, s)]; kaj[j - 1] = kal[krow(j, s)];
+                    });
+                    static_for<1, 6>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const bool on = ix.has[s] && j < i;
+                        const T sj = dtT * (T)dopri::A[i][j];
+                        inc += sj * (on ? kvj[j - 1] : T(0));
+                        acc += sj * (on ? kaj[j - 1] : T(0));
+                    });
                     ql[s] = S.getl(R::Q0L + s) + inc;
                     vl[s] = v0 + acc;
                     if (!ix.has[s]) { ql[s] = T(0); vl[s] = T(0); }   // dummy joints never move
@@ -200,11 +209,11 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                 static_for<1, NT>([&](auto tc) { sc[5 + decltype(tc)::value] = T(0) - q0b[6 + decltype(tc)::value]; });
                 static_for<0, NVB>([&](auto ic) { sc[decltype(ic)::value] = fabs_(sc[decltype(ic)::value]) * tolRel + tolAbs; });
                 static_for<0, NVB>([&](auto ic) { d[decltype(ic)::value] = e0 * S.getb(R::V0B + decltype(ic)::value); });
-                for (int j = 1; j < 7; ++j)
-                {
+                static_for<1, 7>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     const T sj = dtT * (T)dopri::E[j];
                     static_for<0, NVB>([&](auto ic) { d[decltype(ic)::value] += sj * S.getb(DR::KVB + (j - 1) * NVB + decltype(ic)::value); });
-                }
+                });
                 integrate_freeflyer<T>(q0b, d, qalt);
                 static_for<1, NT>([&](auto tc) { qalt[6 + decltype(tc)::value] = q0b[6 + decltype(tc)::value] + d[5 + decltype(tc)::value]; });
                 root_difference<T>(qb, qalt, d);
@@ -216,11 +225,11 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                 });
                 // velocity part
                 static_for<0, NVB>([&](auto ic) { d[decltype(ic)::value] = e0 * S.getb(DR::A0B + decltype(ic)::value); });
-                for (int j = 1; j < 7; ++j)
-                {
+                static_for<1, 7>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     const T sj = dtT * (T)dopri::E[j];
                     static_for<0, NVB>([&](auto ic) { d[decltype(ic)::value] += sj * S.getb(DR::KAB + (j - 1) * NVB + decltype(ic)::value); });
-                }
+                });
                 static_for<0, NVB>([&](auto ic) {
                     constexpr int c = decltype(ic)::value;
                     const T v0 = S.getb(R::V0B + c);
@@ -235,13 +244,17 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                 constexpr int s = decltype(sc_)::value;
                 const T q0 = S.getl(R::Q0L + s), v0 = S.getl(R::V0L + s);
                 T dq = e0 * v0, dv = e0 * S.getl(DR::A0L + s);
-                if (ix.has[s])
-                    for (int j = 1; j < 7; ++j)
-                    {
-                        const T sj = dtT * (T)dopri::E[j];
-                        dq += sj * kvl[krow(j, s)];
-                        dv += sj * kal[krow(j, s)];
-                    }
+                T kvj[6], kaj[6];
+                static_for<1, 7>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    kvj[j - 1] = kvl[krow(j, s)]; kaj[j - 1] = kal[krow(j, s)];
+                });
+                static_for<1, 7>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const T sj = dtT * (T)dopri::E[j];
+                    dq += sj * (ix.has[s] ? kvj[j - 1] : T(0));
+                    dv += sj * (ix.has[s] ? kaj[j - 1] : T(0));
+                });
                 const T scq = fabs_(T(0) - q0) * tolRel + tolAbs;
                 const double eq = (double)fabs_(((q0 + dq) - ql[s]) / scq);
                 const T scv = fabs_(T(0) - v0) * tolRel + tolAbs;
