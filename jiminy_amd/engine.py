@@ -866,7 +866,12 @@ class BatchedEngine:
                 if changed:
                     self._command_dirty = False
                 if sens and self._sensor_noise:
-                    self._apply_sensor_noise(t_now=t_now)
+                    # continuous sensors: the reference also measures inside every dynamics evaluation of the step
+                    # (engine.cc:3655-3667: the three Runge-Kutta stages + the derivative at the end of the step, or
+                    # Euler's one, + the a(t+) refresh) -- those measurements are overwritten by the one after the
+                    # step, but they draw from the noise streams: same number of rounds discarded here
+                    extra = ((4 if solver == SOLVER_IDS["runge_kutta_4"] else 1) + (1 if changed else 0)) if per_step_noise else 0
+                    self._apply_sensor_noise(discard_rounds=extra, t_now=t_now)
             self._iter += n
             self._dt = dt
         self._t_prev = self._t

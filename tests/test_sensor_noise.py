@@ -282,6 +282,40 @@ def test_engine_sensor_noise_at_sensor_breakpoints(gpu_device):
     assert np.array_equal(rng["ImuSensor"].cpu().numpy().view(np.uint64), st_ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,per_step", [("runge_kutta_4", 4), ("euler_explicit", 1)])
+def test_engine_continuous_sensors_draw_inside_every_evaluation(gpu_device, solver, per_step):
+    """`sensorsUpdatePeriod = 0`: the reference measures (and draws) inside every dynamics evaluation of an
+    integrator step (engine.cc:3655-3667) and once more after it; the streams must stand where the reference's
+    stand: (INIT_ITERATIONS + 1) rounds at start + (evaluations per step + 1) per step."""
+    import torch
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import INIT_ITERATIONS, BatchedEngine
+    from jiminy_amd.synthetic import sample_states
+    model = load_builtin("anymal")
+    B, dt, steps = 32, 1e-3, 3
+    st = sample_states(model, B, seed=5)
+    eng = BatchedEngine(model, B, dtype=torch.float64)
+    eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": 0.0, "sensorsUpdatePeriod": 0.0},
+                     "contacts": {"model": "spring_damper"}})
+    eng.set_sensor_options("ImuSensor", noise_std=[0.01, 0.01, 0.01, 0.1, 0.1, 0.1])
+    eng.seed_sensors(3)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    for _ in range(steps):
+        eng.step(dt)
+    rng = eng._sensor_noise["ImuSensor"]["rng"].cpu().numpy().view(np.uint64)
+    eng.stop()
+    n_imu = len(model.sensors["ImuSensor"])
+    gs = ((3 + np.arange(B, dtype=np.uint64) * 1 + 0) & 0xFFFFFFFF).astype(np.uint32)
+    st_ref = oracle_py.sensor_rng_seed(gs, n_imu)
+    scratch = np.zeros((n_imu * 6, B))
+    for _ in range(INIT_ITERATIONS + 1 + steps * (per_step + 1)):
+        oracle_py.sensor_delay(scratch, None, None, None, st_ref, n_imu, 6)
+        oracle_py.sensor_noise(scratch, st_ref, n_imu, 6, np.tile([0.01, 0.01, 0.01, 0.1, 0.1, 0.1], (n_imu, 1)), None, None)
+    assert np.array_equal(rng, st_ref)
+
+
 # ------------------------------------------------------------------ delay and jitter (interpolateData)
 def _ramp_history(n, nf, B, times, slots, n_slots):
     """history whose sample taken at time t holds the value 100 * t + row + 0.001 * lane in every row"""

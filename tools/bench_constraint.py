@@ -65,7 +65,7 @@ def main():
         "kernel_env_steps_per_s": B * n / (ms * 1e-3) if ms > 0 else None,
         "ms_per_launch": ms / max(n, 1), "batch": B, "steps": args.steps, "solver": args.solver, "dt": args.dt,
         "mean_active_constraints_start": active0, "mean_active_constraints_end": active1,
-        "constraint_rows_max": rows["n_rows"], "workspace_MB": rows["workspace"] * B * 8 / 1e6,
+        "constraint_rows_max": rows["n_rows"], "workspace_MB": eng.field("workspace").numel() * 8 / 1e6,
         "lanes_pgs_not_converged_last_eval": failed, "lanes_nan": nan}))
 
 
