@@ -178,6 +178,9 @@ class VecJiminyEnv:
         cmd.copy_(torch.where(lane_mask[None, :], torch.zeros_like(cmd), cmd))
         if self._model_options and "model_lane" in self.engine._fields:
             self.engine.sample_model_biases(lane_mask)     # a new biased model for the new episode (Model::reset)
+        if self._f_xy_profile is not None and float(self.std_ratio.get("disturbance", 0.0)) > 0.0:
+            for proc in self._f_xy_profile:
+                proc.reset(self._generator, lane_mask=lane_mask)   # `func.reset(self.np_random)` of the new episode
         self.engine.reset_lanes(lane_mask, q, v)
         self.num_steps[lane_mask] = 0
         self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
@@ -196,15 +199,16 @@ class VecJiminyEnv:
             mu = torch.where(lane_mask, mu, self.engine.field("friction")[0])
         self.engine.set_lane_friction(mu)
 
-    # envs/locomotion.py:30-33
+    # envs/locomotion.py:30-36
     F_IMPULSE_DT, F_IMPULSE_PERIOD, F_IMPULSE_DELTA, F_IMPULSE_SCALE = 10.0e-3, 2.0, 0.25, 1000.0
+    F_PROFILE_SCALE, F_PROFILE_WAVELENGTH, F_PROFILE_PERIOD = 50.0, 0.2, 1.0
+    _f_xy_profile = None
 
     def _schedule_disturbances(self) -> None:
         """≙ the impulse part of `WalkerJiminyEnv._setup` (envs/locomotion.py:298-326): every F_IMPULSE_PERIOD
         seconds (+- F_IMPULSE_DELTA, one offset for the batch: breakpoints are shared) a horizontal push of random
         direction and magnitude U(0, std_ratio['disturbance'] * F_IMPULSE_SCALE) on the root body, one draw per
-        environment.  (The periodic Gaussian-process profile force of :327-331 is available through
-        `engine.register_profile_force`.)"""
+        environment, plus the continuous Gaussian-process force of :327-359 (below)."""
         scale = float(self.std_ratio.get("disturbance", 0.0))
         self.engine.remove_all_forces()
         if scale <= 0.0 or not self.model.has_freeflyer:
@@ -222,6 +226,22 @@ class VecJiminyEnv:
             f[:2] = d * mag
             self.engine.register_impulse_force(frame, t, self.F_IMPULSE_DT, f)
             t_ref += self.F_IMPULSE_PERIOD
+        # the continuous part (envs/locomotion.py:165-167, 327-359): two periodic Gaussian processes, one realisation
+        # per environment, drive the x / y force on the root body: F_PROFILE_SCALE * std_ratio * process(episode time)
+        from .processes import PeriodicGaussianProcess
+        if self._f_xy_profile is None:
+            self._f_xy_profile = [PeriodicGaussianProcess(self.F_PROFILE_WAVELENGTH, self.F_PROFILE_PERIOD, B, self.dtype, self.device),
+                                  PeriodicGaussianProcess(self.F_PROFILE_PERIOD, self.F_PROFILE_PERIOD, B, self.dtype, self.device)]
+        for proc in self._f_xy_profile:
+            proc.reset(g)
+
+        def profile(t: float, q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+            w = torch.zeros((6, B), dtype=self.dtype, device=self.device)
+            tl = t - self._t0
+            w[0] = self.F_PROFILE_SCALE * scale * self._f_xy_profile[0](tl)
+            w[1] = self.F_PROFILE_SCALE * scale * self._f_xy_profile[1](tl)
+            return w
+        self.engine.register_profile_force(frame, profile)
 
     # scales of envs/locomotion.py:40-61 (delay [s]; noise and bias per field)
     SENSOR_DELAY_SCALE = {"EncoderSensor": 3.0e-3, "EffortSensor": 0.0, "ContactSensor": 0.0, "ForceSensor": 0.0,

@@ -303,6 +303,12 @@ def test_env_model_biases_and_disturbances(gpu_device):
     imp = env.engine.impulse_forces
     assert len(imp) == 9 and all(abs(f["t"] - 2.0 * (i + 1)) <= 0.25 for i, f in enumerate(imp))
     assert float(imp[0]["force"][:2].norm(dim=0).max()) <= 0.2 * 1000.0 and float(imp[0]["force"][2:].abs().max()) == 0.0
+    # the continuous Gaussian-process force (envs/locomotion.py:327-359) is in the applied wrench from the first launch:
+    # F_PROFILE_SCALE * std_ratio * process(t), x / y only, one realisation per environment
+    procs = env._f_xy_profile
+    w0 = env.engine.field("applied")[:6].clone()
+    assert torch.allclose(w0[0], 50.0 * 0.2 * procs[0](0.0), atol=1e-9) and torch.allclose(w0[1], 50.0 * 0.2 * procs[1](0.0), atol=1e-9)
+    assert float(w0[2:].abs().max()) == 0.0 and float(w0[0].std()) > 1.0
     action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
     z0 = env.observation()["states"]["agent"]["q"][:, :2].clone()
     for _ in range(60):                      # 2.4 s: the first push has happened
@@ -316,6 +322,13 @@ def test_env_model_biases_and_disturbances(gpu_device):
     env.reset_lanes(mask)
     ml1 = env.engine.field("model_lane")
     assert torch.equal(ml1[:, 8:], ml0[:, 8:]) and not torch.equal(ml1[:, :8], ml0[:, :8])
+    # ... and a new force process that restarts at its own episode time
+    v_before = procs[0].values.clone()
+    env.reset_lanes(mask)
+    assert torch.equal(procs[0].values[:, 8:], v_before[:, 8:]) and not torch.equal(procs[0].values[:, :8], v_before[:, :8])
+    env.step(action)
+    t_lane = env._lane_time()
+    assert float(t_lane[:8].max()) < float(t_lane[8:].min())
 
 
 def test_hip_pd_adapter_and_motor_safety_limit_match_the_oracle(gpu_device):

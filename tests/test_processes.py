@@ -1,0 +1,71 @@
+"""Batched periodic Gaussian processes (jiminy_amd/processes.py) against the scalar restatement of the reference's
+(oracle/process_numpy.py), and the properties the reference's process has by construction."""
+import numpy as np
+import pytest
+import torch
+
+from jiminy_amd.processes import PeriodicGaussianProcess, toeplitz_cholesky_lower
+from oracle import process_numpy
+
+
+@pytest.mark.parametrize("wavelength,period", [(0.2, 1.0), (1.0, 1.0), (0.35, 2.0)])
+def test_batched_process_matches_the_scalar_restatement(wavelength, period):
+    B = 5
+    ref = process_numpy.PeriodicGaussianProcess(wavelength, period)
+    proc = PeriodicGaussianProcess(wavelength, period, B)
+    assert proc.num_times == ref.num_times and abs(proc.dt - ref.dt) < 1e-15
+    assert np.allclose(proc._L.numpy(), np.tril(ref.cov_sqrt_root), rtol=0, atol=1e-7)   # (the recursion is ill-conditioned: reg = 1e-9)
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((ref.num_times, B)).astype(np.float32)
+    proc.reset(normal=torch.from_numpy(z))
+    times = np.concatenate([np.linspace(-0.7, 2.9 * period, 41), [0.0, period, ref.dt, period - 1e-12]])
+    for lane in range(B):
+        ref.reset(z[:, lane].astype(np.float64))
+        assert np.allclose(proc.values[:, lane].numpy(), ref.values, rtol=0, atol=1e-6)
+        assert np.allclose(proc.grads[:, lane].numpy(), ref.grads, rtol=1e-6, atol=1e-5)   # L is ill-conditioned by design (reg 1e-9)
+        for t in times:
+            assert abs(float(proc(float(t))[lane]) - ref(float(t))) < 1e-6
+            assert abs(float(proc.grad(float(t))[lane]) - ref.grad(float(t))) < 1e-4
+    # one time per lane
+    tl = torch.tensor([0.05, 0.3, 0.99, 1.7, -0.2], dtype=torch.float64)
+    got = proc(tl)
+    for lane in range(B):
+        ref.reset(z[:, lane].astype(np.float64))
+        assert abs(float(got[lane]) - ref(float(tl[lane]))) < 1e-6
+
+
+def test_process_is_periodic_smooth_and_standard_normal():
+    B = 4096
+    proc = PeriodicGaussianProcess(0.2, 1.0, B)
+    g = torch.Generator().manual_seed(7)
+    proc.reset(g)
+    assert torch.allclose(proc(0.013), proc(1.013), atol=1e-9) and torch.allclose(proc(0.5), proc(-0.5), atol=1e-9)
+    # unit variance at every knot (the covariance has a unit diagonal), zero mean
+    assert abs(float(proc.values.mean())) < 0.02 and abs(float(proc.values.var()) - 1.0) < 0.05
+    # covariance of neighbouring knots = the periodic squared-exponential kernel; knots half a period apart: none
+    v = proc.values
+    c1 = float((v[0] * v[1]).mean())
+    c25 = float((v[0] * v[25]).mean())
+    assert abs(c1 - float(np.exp(-2.0 * (np.sin(np.pi / 50) / 0.2) ** 2))) < 0.04 and abs(c25) < 0.1   # the kernel itself
+    # the tabulated derivative is the derivative of the interpolant
+    h = 1e-6
+    t = 0.3141
+    fd = (proc(t + h) - proc(t - h)) / (2 * h)
+    assert torch.allclose(fd, proc.grad(t), atol=1e-4)
+    # re-drawing masked lanes only
+    before = proc.values.clone()
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[:10] = True
+    proc.reset(g, lane_mask=mask)
+    assert torch.equal(proc.values[:, 10:], before[:, 10:]) and not torch.equal(proc.values[:, :10], before[:, :10])
+
+
+def test_toeplitz_factor_reproduces_the_covariance():
+    n, wl = 50, 0.2
+    i = np.arange(n)
+    c = np.exp(-2.0 * (np.sin(np.pi / n * i) / wl) ** 2)
+    L = toeplitz_cholesky_lower(c, 1e-9)
+    K = np.array([[c[abs(a - b)] for b in range(n)] for a in range(n)])
+    assert np.allclose(L @ L.T, K + 1e-9 * np.eye(n), atol=1e-7)
+    with pytest.raises(ValueError):
+        PeriodicGaussianProcess(0.2, -1.0, 2)
