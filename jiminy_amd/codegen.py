@@ -346,7 +346,7 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"]
     common += list(BUILD_VARIANTS[v])
     common += extra_flags or []
-    parts = [1, 2, 3, 4, 5] if quad_structure(model) is not None else [1]
+    parts = [1, 2, 3, 4, 5, 6] if quad_structure(model) is not None else [1]
     objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]
     cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]]]
     cmds += [[HIPCC] + common + [f"-DJM_CON_PART={p}", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", o]

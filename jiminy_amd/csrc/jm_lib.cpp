@@ -43,6 +43,7 @@ extern template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>
 extern template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
 extern template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
+extern template __global__ void k_quad_dopri_gen<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
 }
 #endif
@@ -336,8 +337,9 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
     // into the attempt bound of a launch (then it launches again) and the largest attempt count
     if constexpr (Topo::QUAD && std::is_same<T, double>::value)
     {
-        if (b->variant == VARIANT_QUAD && !constrained && !b->field[JM_F_MODEL_LANE] && !b->ground_h && b->applied_k == 0)
+        if (b->variant == VARIANT_QUAD && !constrained)
         {
+            const bool gen = b->field[JM_F_MODEL_LANE] || b->ground_h || (b->applied_k > 0 && b->field[JM_F_APPLIED]);
             auto A = make_args<T>(b);
             A.mode = jm::MODE_DYNAMICS;
             constexpr int nth = 64 * jm::qdopri_block_waves<T, Topo>();
@@ -347,7 +349,8 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
             for (;;)
             {
                 HIP_TRY(hipMemsetAsync(b->ad_count, 0, 2 * sizeof(int32_t), s));
-                hipLaunchKernelGGL((jm::k_quad_dopri<T, Topo>), dim3(grid), dim3(nth), 0, s, A, D, per_launch);
+                if (gen) hipLaunchKernelGGL((jm::k_quad_dopri_gen<T, Topo>), dim3(grid), dim3(nth), 0, s, A, D, per_launch);
+                else hipLaunchKernelGGL((jm::k_quad_dopri<T, Topo>), dim3(grid), dim3(nth), 0, s, A, D, per_launch);
                 HIP_TRY(hipGetLastError());
                 D.new_step = 0;
                 HIP_TRY(hipMemcpyAsync(b->ad_count_host, b->ad_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));

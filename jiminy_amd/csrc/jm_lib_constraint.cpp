@@ -6,6 +6,7 @@
 //   -DJM_CON_PART=3  k_quad_gen     (jm_quad.h with per-lane body parameters / height-map ground / applied forces)
 //   -DJM_CON_PART=4  k_quad_con_gen (the same for the constraint contact model)
 //   -DJM_CON_PART=5  k_quad_dopri   (jm_qdopri.h, the persistent adaptive stepper)
+//   -DJM_CON_PART=6  k_quad_dopri_gen (the same with per-lane body parameters / height map / applied forces)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -16,7 +17,7 @@
 #include "jm_kernels.h"
 #include "jm_constraint.h"
 #include "jm_qcon.h"
-#if JM_CON_PART == 5
+#if JM_CON_PART == 5 || JM_CON_PART == 6
 #include "jm_qdopri.h"
 #endif
 
@@ -32,5 +33,7 @@ template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
 template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
 #elif JM_CON_PART == 5 && JM_TOPO_QUAD
 template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
+#elif JM_CON_PART == 6 && JM_TOPO_QUAD
+template __global__ void k_quad_dopri_gen<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
 }

@@ -47,7 +47,7 @@ template<class T> JM_DEV void root_difference(const T * q0, const T * q1, T * ou
 }
 
 // one lane of a quad: robot r, limb k, from its current time to D.t_next (at most `max_attempts` attempts)
-template<class T, class Tp, class X, int SL, int SB>
+template<class T, class Tp, class X, int SL, int SB, bool GEN = false>
 JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, long long r, int k, const T * limb_table,
                            const StageBuf<T, SL, SB> & S, int max_attempts)
 {
@@ -192,7 +192,7 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                     if constexpr (R::LONG) S.putl(R::KVL + s, vl[s]);
                 });
                 int evst = 0;
-                quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>>(P, LT, A, r32, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, evst);
+                quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, r32, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, evst);
                 static_for<0, NVB>([&](auto ic) { S.putb(DR::KAB + (i - 1) * NVB + decltype(ic)::value, ddqb[decltype(ic)::value]); });
                 static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) kal[krow(i, decltype(sc)::value)] = ddq[decltype(sc)::value]; });
             }
@@ -387,6 +387,25 @@ k_quad_dopri(const BatchArgs<T> A, const AdaptiveArgs<T> D, int max_attempts)
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     quad_dopri_run<T, Tp, DppQuad, NTH, NTH / 4>(A, D, r, k, table, S, max_attempts);
+}
+// the same with the per-environment variation of DESIGN.md section 4.9 compiled in (the lanes keep their places in this
+// form of the stepper, so per-lane body parameters, the height map and applied wrenches simply follow)
+template<class T, class Tp>
+__global__ void __launch_bounds__((64 * qdopri_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_dopri_gen(const BatchArgs<T> A, const AdaptiveArgs<T> D, int max_attempts)
+{
+    using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * qdopri_block_waves<T, Tp>();
+    __shared__ T table[Q::TABLE];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QDopriRows<Tp>::NB * (NTH / 4)];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    quad_dopri_run<T, Tp, DppQuad, NTH, NTH / 4, true>(A, D, r, k, table, S, max_attempts);
 }
 #endif
 }  // namespace jm

@@ -296,11 +296,22 @@ def _variation_self_test(model: CompiledModel, variant: int, device: torch.devic
     from .randomization import nominal_model_lane
     n, dt = 64, 1e-4
     q, v, cmd = (torch.as_tensor(x, dtype=torch.float64, device=device) for x in _probe_state(model, n))
+    err = 0.0
+    # (the persistent adaptive stepper has its own variation instantiation, `k_quad_dopri_gen`: spring-damper model)
+    for solver in ("runge_kutta_4",) + (("runge_kutta_dopri",) if contact_model == "spring_damper" else ()):
+        err = max(err, _variation_self_test_leg(model, variant, device, contact_model, solver, n, dt, q, v, cmd))
+    return err
+
+
+def _variation_self_test_leg(model: CompiledModel, variant: int, device: torch.device, contact_model: str, solver: str,
+                             n: int, dt: float, q: torch.Tensor, v: torch.Tensor, cmd: torch.Tensor) -> float:
+    from .randomization import nominal_model_lane
     outs = []
     for gen in (False, True):
         probe = BatchedEngine(model, n, dtype=torch.float64, device=device, extra_outputs=(), _lib_variant=variant)
-        probe.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt,
-                                       "sensorsUpdatePeriod": dt}, "contacts": {"model": contact_model}},
+        probe.set_options({"stepper": {"odeSolver": solver, "dtMax": dt if solver != "runge_kutta_dopri" else 1e-3,
+                                       "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt, "tolAbs": 1e-8, "tolRel": 1e-7},
+                           "contacts": {"model": contact_model}},
                           _skip_constraint_check=True)
         if gen:
             probe._gen_checked = True
@@ -486,6 +497,7 @@ class BatchedEngine:
         self._ground: Optional[torch.Tensor] = None
         self._force_frames: List[str] = []
         self._impulse_forces: List[Dict[str, Any]] = []
+        self._impulse_active: List[int] = []
         self._profile_forces: List[Dict[str, Any]] = []
         self._apply_options()
         self._apply_hardware_sensor_options()
@@ -803,10 +815,10 @@ class BatchedEngine:
 
     def _step_adaptive(self, step_dt: float) -> None:
         st = self._options["stepper"]
-        if self._impulse_forces or self._profile_forces or "model_lane" in self._fields:
-            raise NotImplementedError("impulse / profile forces and per-lane model biases need a fixed-step solver "
-                                      "(the adaptive stepper re-orders the lanes)")
-        intervals, t_end, t_err = plan_breakpoints(self._t, self._t_error, float(step_dt), self._options)
+        # (impulse / profile forces and per-lane model biases: available where the stepper is the persistent kernel
+        # of jm_qdopri.h, whose lanes keep their places; the per-stage path over compacted lanes refuses them)
+        intervals, t_end, t_err = plan_breakpoints(self._t, self._t_error, float(step_dt), self._options,
+                                                   self._force_breakpoints(self._t))
         o = _abi.AdaptiveOptions(float(st["tolRel"]), float(st["tolAbs"]), float(st["dtMax"]),
                                  float(st["dtRestoreThresholdRel"]), int(st["successiveIterFailedMax"]))
         stream = self._stream()
@@ -815,12 +827,15 @@ class BatchedEngine:
         # (only discrete controllers have breakpoints: engine.cc:1919-1940)
         constraint_model = (self._options["contacts"]["model"] == "constraint"
                             and float(st["controllerUpdatePeriod"]) > EPS)
+        t_now = self._t
         for i, (t_next, cmd_bp, sens) in enumerate(intervals):
-            changed = cmd_bp and (self._command_dirty or constraint_model)
+            forces_changed = self._update_applied_forces(t_now)
+            t_now = float(t_next)
+            changed = (cmd_bp and (self._command_dirty or constraint_model)) or forces_changed
             self._lib.check(self._L.jm_batch_step_adaptive(
                 self._batch_h, float(t_next), C.byref(o), int(i == 0), int(changed), int(sens),
                 100000, C.byref(attempts), stream))
-            if changed:
+            if changed and cmd_bp:
                 self._command_dirty = False
             self.adaptive_attempts += int(attempts.value)
             if sens and self._sensor_noise:
@@ -855,15 +870,16 @@ class BatchedEngine:
         t_now = self._t
         for dt, n, cmd_bp, sens in launches:
             for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
-                self._update_applied_forces(t_now)
+                forces_changed = self._update_applied_forces(t_now)
                 t_now += dt * n_k
                 # a(t+) refresh at a controller breakpoint (engine.cc:2030-2042): skipped when the held
                 # command was not rewritten (the evaluation is idempotent) -- except with the constraint
-                # contact model, where the reference's refresh re-runs the warm-started PGS solve
-                changed = cmd_bp and (self._command_dirty or constraint_model) and k == 0
+                # contact model, where the reference's refresh re-runs the warm-started PGS solve; and whenever
+                # an applied force changed at the start of this launch
+                changed = (cmd_bp and (self._command_dirty or constraint_model) and k == 0) or forces_changed
                 self._lib.check(self._L.jm_batch_step(self._batch_h, solver, dt, n_k, int(changed),
                                                       int(sens), stream))
-                if changed:
+                if changed and cmd_bp:
                     self._command_dirty = False
                 if sens and self._sensor_noise:
                     # continuous sensors: the reference also measures inside every dynamics evaluation of the step
@@ -1070,6 +1086,7 @@ class BatchedEngine:
         if self._running:
             raise BadControlFlow("Simulation already running. Please stop it before removing forces.")
         self._impulse_forces.clear()
+        self._impulse_active = []
         self._profile_forces.clear()
         self._force_frames.clear()
         self._fields.pop("applied", None)
@@ -1091,21 +1108,32 @@ class BatchedEngine:
                 pts.append((math.floor(t / p["period"] + 1e-9) + 1) * p["period"])
         return tuple(sorted(x for x in pts if x > t + STEPPER_MIN_TIMESTEP))
 
-    def _update_applied_forces(self, t: float) -> None:
-        """Current value of the registered forces into the `applied` field (start of a launch at time `t`)."""
+    def _update_applied_forces(self, t: float) -> bool:
+        """Current value of the registered forces into the `applied` field (start of a launch at time `t`).  Returns
+        True when the held wrenches changed -- an impulse started or ended, a profile was re-evaluated -- i.e. when the
+        reference sets `hasDynamicsChanged` and recomputes a(t+) before stepping on (engine.cc:1860-1868, 1909-1912,
+        1972-1983, 2031-2042)."""
         if "applied" not in self._fields:
-            return
+            return False
         a = self._fields["applied"]
         a.zero_()
-        for f in self._impulse_forces:
+        active = []
+        changed = False
+        for i, f in enumerate(self._impulse_forces):
             if f["t"] - STEPPER_MIN_TIMESTEP <= t < f["t"] + f["dt"] - STEPPER_MIN_TIMESTEP:
                 a[6 * f["frame"]:6 * f["frame"] + 6] += f["force"]
+                active.append(i)
+        if active != self._impulse_active:
+            self._impulse_active = active
+            changed = True
         for p in self._profile_forces:
             if p["value"] is None or p["period"] <= EPS or t - p["t_last"] >= p["period"] - STEPPER_MIN_TIMESTEP:
                 w = torch.as_tensor(p["func"](t, self._fields["q"], self._fields["v"]), dtype=self.dtype, device=self.device)
                 p["value"] = w[:, None].expand(6, self.batch_size) if w.dim() == 1 else w
                 p["t_last"] = t if p["period"] <= EPS else math.floor(t / p["period"] + 1e-9) * p["period"]
+                changed = True
             a[6 * p["frame"]:6 * p["frame"] + 6] += p["value"]
+        return changed
 
     # ------------------------------------------------------------------ sensor noise and bias
     _SENSOR_FIELDS = {"ImuSensor": ("imu", 6), "ForceSensor": ("force", 6), "ContactSensor": ("contact", 3),

@@ -258,3 +258,52 @@ def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
     ml = eng2.field("model_lane").view(model.njoints, 13, B)
     assert float((ml[1, 0] / model.mass[1]).std()) == pytest.approx(0.1, rel=0.5)
     assert not torch.equal(v2, v0)
+
+
+@pytest.mark.gpu
+def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device):
+    """The persistent adaptive stepper (jm_qdopri.h) keeps every robot in its lane, so per-lane body parameters and
+    applied forces work with `runge_kutta_dopri` too (`k_quad_dopri_gen`): (a) with the NOMINAL parameters bound per
+    lane it follows the plain adaptive kernel step for step; (b) an impulse force acts during [t, t + dt] exactly --
+    its start and end are breakpoints of the adaptive loop -- and changes the base velocity by F dt / m; (c) biased
+    masses change the motion."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.randomization import nominal_model_lane
+    model = load_builtin("anymal")
+    B = 64
+    st = sample_states(model, B, seed=6, base_height=(2.0, 3.0), grounded_fraction=0.0)
+    frame = next(n for n, f in model.frames.items() if f.parent_joint == 1)
+
+    def run(nominal=False, push=False, std=0.0):
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("f_external",))
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-7, "tolRel": 1e-6, "controllerUpdatePeriod": 5e-3,
+                                     "sensorsUpdatePeriod": 5e-3}, "contacts": {"model": "spring_damper"}})
+        if nominal:
+            eng.set_lane_model(nominal_model_lane(model, B, torch.float64, gpu_device))
+        if std:
+            eng.set_model_options({"dynamics": {"massBodiesBiasStd": std}})
+            eng.seed_model(7)
+        if push:
+            eng.register_impulse_force(frame, 0.0032, 0.0041, np.array([400.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+        eng.set_command(torch.from_numpy(st["command"]))
+        eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+        fx = []
+        for _ in range(3):
+            eng.step(5e-3)
+            fx.append(float(eng.field("f_external")[6:9].abs().max()))
+        ss = eng.stepper_state
+        assert abs(ss.t - 0.015) < 1e-12 and int(eng.status.abs().sum()) == 0
+        return eng.field("q").clone(), eng.field("v").clone(), ss.iter_lanes.clone(), ss.iter_failed_lanes.clone(), fx
+    q0, v0, it0, if0, fx0 = run()
+    q1, v1, it1, if1, _ = run(nominal=True)
+    assert torch.equal(it0, it1) and torch.equal(if0, if1)
+    assert float((q1 - q0).abs().max()) < 1e-9 and float((v1 - v0).abs().max()) < 1e-8
+    q2, v2, it2, _, fx2 = run(push=True)
+    assert max(fx0) == 0.0 and fx2[0] > 0.0 and fx2[1] == 0.0 and fx2[2] == 0.0
+    dv = (v2 - v0)[0:3].norm(dim=0)
+    assert float(dv.median()) == pytest.approx(400.0 * 0.0041 / 52.1, rel=0.2)
+    assert int(it2.min()) >= int(it0.min())       # the two extra breakpoints cost steps
+    q3, v3, *_ = run(std=0.1)
+    assert not torch.equal(v3, v0)
