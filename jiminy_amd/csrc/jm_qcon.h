@@ -110,6 +110,15 @@ template<class T> struct QStore
     int cap;
     JM_DEV T get(int e) const { return e < cap ? lds[e] : hbm[(unsigned)(e - cap) * B]; }
     JM_DEV void put(int e, T x) const { if (e < cap) lds[e] = x; else hbm[(unsigned)(e - cap) * B] = x; }
+    // the same read without a branch: both homes are read at a valid address and the value is selected, so that a
+    // batch of reads is issued together instead of one dependent memory round trip per element
+    JM_DEV T get_flat(int e) const
+    {
+        const bool on = e < cap;
+        const T l = lds[on ? e : 0];
+        const T h = hbm[(unsigned)(on ? 0 : e - cap) * B];
+        return on ? l : h;
+    }
 };
 // the same region when the whole solve of the robot fits on chip (the common case: ANYmal with up to 16
 // active rows): no per-access branch, so that the loads of one row update are issued together
@@ -627,7 +636,23 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
             });
         }
         else
-            for (int c = k; c < m; c += 4) s += V.get(A0 + tri_(i, c)) * V.get(c);
+        {
+            // this lane's quarter of row i, all reads in flight at once (the overflow part of the region sits in HBM:
+            // one round trip per row instead of one per element); same summation order as the plain loop
+            constexpr int NG = (QConRows<Tp>::MAXM + 3) / 4;
+            T a[NG], xv[NG];
+            static_for<0, NG>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int c = k + 4 * j;
+                const bool valid = c < m;
+                a[j] = V.get_flat(valid ? A0 + tri_(i, c) : 0);
+                xv[j] = V.get_flat(valid ? c : 0);
+            });
+            static_for<0, NG>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                s = (k + 4 * j < m) ? s + a[j] * xv[j] : s;
+            });
+        }
         return X::quad_sum(s);
     };
     for (unsigned iter = 0; iter < iter_max; ++iter)
@@ -1470,14 +1495,39 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
 // waves per block and on-chip scalars per LANE of the per-robot solver region (a robot owns 4 lanes' worth):
 // what is left of the 160 KiB of LDS next to the limb table and the stage buffer at 4 resident waves per CU
 // (the kernel needs the whole register file: one wave per SIMD), capped by what the largest solve can use.
-template<class T, class Tp> constexpr int qcon_block_waves() { return quad_block_waves<T, Tp>(); }
+// LDS plan of the constraint kernels.  The per-robot solver region wants to be on chip at least with its four vectors
+// (x | b | y | 1 / diag: they are read and written row by row inside the Gauss-Seidel dependency chain; the matrix is only
+// read).  `WR` = waves resident per CU: 4 (one per SIMD) when the stage buffer and the limb table leave >= 3 MAXM scalars
+// per robot (ANYmal: 212, whole 16-row solves on chip), else 2 or 1 -- for Atlas the stage rows of four waves take 115 kB
+// and leave 12 scalars per robot, which puts every row update of the solver behind HBM round trips; two resident waves
+// leave 236 (Atlas, B = 32 768: 33.4 -> 28.4 ms per launch together with the batched row reads of `qcon_pgs`).
+template<class T, class Tp> constexpr long qcon_free_lds(int wr, int wb)
+{
+    const long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
+    const long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
+    return 160L * 1024 - 2048 - (long)(wr / wb) * table - (long)wr * per_wave;   // 2 KiB of slack (alignment, odd strides)
+}
+template<class T, class Tp> constexpr int qcon_resident_waves()
+{
+#ifdef JM_QCON_RESIDENT_WAVES
+    return JM_QCON_RESIDENT_WAVES;   // tuning override
+#endif
+    for (int wr = 4; wr > 1; wr /= 2)
+    {
+        const int wb = wr < quad_block_waves<T, Tp>() ? wr : quad_block_waves<T, Tp>();
+        const long per_robot = qcon_free_lds<T, Tp>(wr, wb) / ((long)wr * 16 * (long)sizeof(T));
+        if (per_robot >= 3L * QConRows<Tp>::MAXM) return wr;
+    }
+    return 1;
+}
+template<class T, class Tp> constexpr int qcon_block_waves()
+{
+    return qcon_resident_waves<T, Tp>() < quad_block_waves<T, Tp>() ? qcon_resident_waves<T, Tp>() : quad_block_waves<T, Tp>();
+}
 template<class T, class Tp> constexpr int qcon_lane_scalars()
 {
-    constexpr long W = 4;   // resident waves per CU
-    constexpr long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
-    constexpr long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
-    constexpr long blocks = W / qcon_block_waves<T, Tp>() > 0 ? W / qcon_block_waves<T, Tp>() : 1;
-    constexpr long left = 160L * 1024 - 2048 - blocks * table - W * per_wave;   // 2 KiB of slack (alignment, odd strides)
+    constexpr long W = qcon_resident_waves<T, Tp>();
+    constexpr long left = qcon_free_lds<T, Tp>((int)W, qcon_block_waves<T, Tp>());
     constexpr long per_lane = left > 0 ? left / (W * 64 * (long)sizeof(T)) : 0;
     constexpr long want = (QConRows<Tp>::VMAX + 3) / 4;
     return (int)(per_lane < want ? per_lane : want);
