@@ -635,6 +635,9 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
                 s = (k + 4 * j < m) ? s + a[j] * xv[j] : s;
             });
         }
+        else if constexpr (QConRows<Tp>::MAXM <= 32)
+            // (robots whose solves nearly always fit the chip: the plain loop keeps the kernel's register budget)
+            for (int c = k; c < m; c += 4) s += V.get(A0 + tri_(i, c)) * V.get(c);
         else
         {
             // this lane's quarter of row i, all reads in flight at once (the overflow part of the region sits in HBM:

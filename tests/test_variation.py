@@ -307,3 +307,57 @@ def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device):
     assert int(it2.min()) >= int(it0.min())       # the two extra breakpoints cost steps
     q3, v3, *_ = run(std=0.1)
     assert not torch.equal(v3, v0)
+
+
+@pytest.mark.gpu
+def test_gpu_impulse_force_launches_match_the_oracle_step_for_step(gpu_device):
+    """The whole force path against the oracle: the engine cuts its launches at the start and the end of an impulse
+    force (3.2 ms, 7.3 ms inside 5 ms controller periods), holds the wrench in between and recomputes a(t+) at the
+    launch where it changes (`hasDynamicsChanged`, engine.cc:1860-1868, 2031-2042).  The oracle is driven with the
+    same schedule (`plan_step` with the force breakpoints), the wrench bound launch by launch and the refresh flag set
+    where the wrench changed: state and outputs agree to round-off after every `step`."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, plan_step
+    model = load_builtin("anymal")
+    B, dt = 48, 1e-3
+    st = sample_states(model, B, seed=8, base_height=(1.0, 1.5), grounded_fraction=0.0)
+    frame = next(n for n, f in model.frames.items() if f.parent_joint == 1)
+    push = np.array([300.0, -150.0, 80.0, 5.0, -3.0, 2.0])
+    t_on, t_len = 0.0032, 0.0041
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                        extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+    options = {"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 5 * dt, "sensorsUpdatePeriod": 5 * dt},
+               "contacts": {"model": "spring_damper"}}
+    eng.set_options(options)
+    eng.register_impulse_force(frame, t_on, t_len, push)
+    eng.set_command(torch.from_numpy(st["command"]))
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = OracleEngine(model)
+    io = oracle_io(ref)
+    wrench = np.zeros((6, B))
+    e.bind_applied(wrench, np.array([model.frame(frame).p]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+    t, t_err, active = 0.0, 0.0, False
+    breakpoints = (t_on, t_on + t_len)
+    n_refresh = 0
+    for _ in range(3):
+        launches, t_end, t_err = plan_step(t, t_err, 5 * dt, eng.get_options(), tuple(b for b in breakpoints if b > t + 1e-10))
+        for h, n, cmd_bp, sens in launches:
+            now = t_on - 1e-10 <= t < t_on + t_len - 1e-10
+            wrench[:] = push[:, None] if now else 0.0
+            changed = now != active
+            active = now
+            n_refresh += int(changed)
+            e.bind_applied(wrench, np.array([model.frame(frame).p]))
+            e.batch_run("step", io, solver="runge_kutta_4", dt=h, n_substeps=n, command_changed=changed, update_sensors=sens)
+            t += h * n
+        t = t_end
+        eng.step(5 * dt)
+        for k in OUTS:
+            assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-9, (t, k)
+    assert n_refresh == 2 and abs(eng.stepper_state.t - 0.015) < 1e-12
+    assert float(np.abs(ref["v"][0:3] - st["v"][0:3]).max()) > 1e-3
