@@ -123,10 +123,18 @@ def load_for(model: CompiledModel, allow_build: bool = True, variant: Optional[i
     if lib is not None:
         return lib
     path = codegen.lib_path(model, v)
-    # Build only when the prebuilt library is missing (e.g. a user-supplied URDF): staleness is
-    # handled by `__graft_entry__.build()` / JIMINY_AMD_REBUILD=1, never implicitly, so that a
-    # snapshot copied to another machine does not recompile because of file timestamps.
-    rebuild = os.environ.get("JIMINY_AMD_REBUILD", "0") == "1" and codegen.is_stale(model, v)
+    # A library is (re)built when it is missing (e.g. a user-supplied URDF) or when the digest of the sources it
+    # was built from (recorded next to it, codegen.source_digest) differs from the sources in the tree -- contents,
+    # not file times, so that a snapshot copied to another machine does not recompile.  JIMINY_AMD_REBUILD=0 turns
+    # the rebuild of a stale library into a warning; libraries without a record are only rebuilt with =1.
+    stale = os.path.exists(path) and codegen.is_stale(model, v)
+    mode = os.environ.get("JIMINY_AMD_REBUILD", "")
+    has_record = os.path.exists(path + ".src")
+    rebuild = stale and (mode == "1" or (mode != "0" and has_record))
+    if stale and not rebuild:
+        import warnings
+        warnings.warn(f"{path} was built from other kernel sources than the ones in the tree "
+                      "(run `python __graft_entry__.py` or set JIMINY_AMD_REBUILD=1)")
     if allow_build and (not os.path.exists(path) or rebuild):
         path = codegen.build_library(model, variant=v)
     lib = HipLibrary(path)
