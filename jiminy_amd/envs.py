@@ -396,6 +396,7 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         q0, _ = self._sample_state(self.num_envs)
         target = torch.stack([q0[m.idx_q] * m.reduction for m in self.model.motors])
         if lane_mask is None:
+            self._graph = None      # a full reset restarts the engine: the step graph is captured again
             self.command_state.zero_()
             self.command_state[0] = target
             self.imu_quat.zero_(); self.imu_quat[3] = 1.0
@@ -415,8 +416,61 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
             for t in (self._accel, self._torque):
                 t.copy_(torch.where(lane_mask[None, :], torch.zeros_like(t), t))
 
+    # ------------------------------------------------------------------ HIP-graph replay of one environment step
+    def enable_graph(self, enable: bool = True) -> None:
+        """Replay the launches of one environment step -- PD adapter, then per controller tick PD controller -> physics
+        launch -> Mahony filter: 26 launches for ANYmal -- as ONE captured HIP graph instead of issuing them from
+        Python.  For small batches per GPU (a sharded config 4 / 5: a few thousand environments) the step is bound by
+        the host's launch rate, not by the kernels; at B = 65 536 it makes no difference.  Needs the HIP blocks, a
+        fixed-step solver, no sensor noise / delay and no applied forces (their host-side schedules run between the
+        launches).  The graph is captured at the next `step` and dropped by `reset`."""
+        if enable:
+            eng = self.engine
+            if self._hip_blocks is None or eng._adaptive is not None or eng._sensor_noise or eng._impulse_forces or eng._profile_forces:
+                raise NotImplementedError("enable_graph needs the HIP blocks, a fixed-step solver, noiseless sensors and "
+                                          "no applied forces")
+        self._graph_enabled = bool(enable)
+        self._graph = None
+
+    def _step_engine_graphed(self, action: torch.Tensor) -> None:
+        eng = self.engine
+        if self._graph is None:
+            # the launches carry no time: the breakpoint plan of a step must be the same at every step
+            plan = _plan_signature(eng, self.control_dt, self._n_ctrl)
+            self._g_action = torch.zeros((self.model.nmotors, self.num_envs), dtype=self.dtype, device=self.device)
+            host = (eng._t, eng._t_prev, eng._t_error, eng._iter, eng._dt, eng._command_dirty)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g):
+                self._issue_step(self._g_action)          # recorded, not executed
+            after = (eng._t, eng._iter, eng._dt)
+            eng._t, eng._t_prev, eng._t_error, eng._iter, eng._dt, eng._command_dirty = host
+            self._graph = (g, plan, after[0] - host[0], after[1] - host[3], after[2])
+            self._graph_replays = 0
+        g, plan, dt_total, d_iter, dt_last = self._graph
+        self._graph_replays += 1
+        if self._graph_replays % 64 == 0 and _plan_signature(eng, self.control_dt, self._n_ctrl) != plan:
+            self._graph = None                            # (never seen: the plan is periodic; re-capture if it is not)
+            return self._step_engine_graphed(action)
+        self._g_action.copy_(action.to(self.dtype).T)
+        g.replay()
+        # host-side bookkeeping of the `n_ctrl` engine steps the graph stands for (Kahan-compensated like engine.step)
+        for _ in range(self._n_ctrl):
+            corrected = self.control_dt - eng._t_error
+            t_end = eng._t + corrected
+            eng._t_error = (t_end - eng._t) - corrected
+            eng._t_prev, eng._t = eng._t, t_end
+        eng._iter += d_iter
+        eng._dt = dt_last
+        eng._command_dirty = False
+
     def _step_engine(self, action: torch.Tensor) -> None:
-        a = action.to(self.dtype).T
+        if getattr(self, "_graph_enabled", False):
+            self._step_engine_graphed(action)
+        else:
+            self._issue_step(action.to(self.dtype).T)
+
+    def _issue_step(self, a: torch.Tensor) -> None:
         hb = self._hip_blocks
         if hb is not None:
             hb.pd_adapter(a.contiguous(), 1, self.command_state, False, None, self.step_dt, self._accel)
@@ -448,6 +502,16 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         obs["features"] = {"mahony_filter": self.imu_quat.permute(2, 0, 1)}
         obs["actions"] = {"pd_controller": self.command_state[:2].permute(2, 0, 1)}
         return obs
+
+
+def _plan_signature(eng: Any, control_dt: float, n_ctrl: int) -> tuple:
+    """The launches `n_ctrl` engine steps of `control_dt` would issue from the engine's current time."""
+    from .engine import plan_step
+    t, t_err, out = eng._t, eng._t_error, []
+    for _ in range(n_ctrl):
+        launches, t, t_err = plan_step(t, t_err, control_dt, eng._options)
+        out.append(tuple((round(dt / 1e-12), n, bool(c), bool(sn)) for dt, n, c, sn in launches))
+    return tuple(out)
 
 
 # constants of the reference ANYmal environment (python/gym_jiminy/envs/gym_jiminy/envs/anymal.py:17-35)

@@ -380,3 +380,37 @@ def test_hip_pd_adapter_and_motor_safety_limit_match_the_oracle(gpu_device):
         out_ref[:, lane] = o
     assert np.abs(out_dev.cpu().numpy() - out_ref).max() <= 1e-13 * np.abs(out_ref).max()
     assert (out_ref != command).mean() > 0.2      # the limits are active on a good part of the batch
+
+
+def test_graph_replay_of_the_environment_step_is_bit_identical(gpu_device):
+    """`enable_graph`: one environment step = 26 launches replayed as one captured HIP graph.  Same launches, same
+    arguments: observations, rewards and the engine's time must equal the eager environment's bit for bit, across a
+    lane reset and a full reset."""
+    B = 256
+    envs = [make_anymal_env(B, device=gpu_device, dt_max=1e-3) for _ in range(2)]
+    envs[1].enable_graph()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for e in envs:
+        e.reset(seed=5)
+    for i in range(12):
+        action = (0.3 * torch.randn(B, 12, generator=g, dtype=torch.float64)).to(gpu_device)
+        outs = [e.step(action) for e in envs]
+        for k in ("q", "v"):
+            assert torch.equal(outs[0][0]["states"]["agent"][k], outs[1][0]["states"]["agent"][k]), (i, k)
+        assert torch.equal(outs[0][0]["features"]["mahony_filter"], outs[1][0]["features"]["mahony_filter"])
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][3], outs[1][3])
+        assert envs[0].engine.stepper_state.t == envs[1].engine.stepper_state.t
+        assert envs[0].engine.stepper_state.iter == envs[1].engine.stepper_state.iter
+        if i == 5:
+            mask = torch.zeros(B, dtype=torch.bool, device=gpu_device)
+            mask[::7] = True
+            for e in envs:
+                e.reset_lanes(mask)
+        if i == 8:
+            for e in envs:
+                e.reset(seed=6)
+    assert envs[1]._graph is not None
+    with pytest.raises(NotImplementedError):
+        e = make_anymal_env(8, device=gpu_device, dt_max=1e-3, std_ratio={"disturbance": 0.1})
+        e.reset(seed=1)
+        e.enable_graph()

@@ -24,16 +24,24 @@ def main():
     ap.add_argument("--solver", default="euler_explicit")
     ap.add_argument("--contact-model", default="spring_damper", choices=("spring_damper", "constraint"))
     ap.add_argument("--zero-action", action="store_true", help="hold the neutral stance (standing robots)")
+    ap.add_argument("--graph", action="store_true", help="replay one environment step as one captured HIP graph")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver, contact_model=args.contact_model)
     env.reset(seed=0)
+    if args.graph:
+        env.enable_graph()
     g = torch.Generator(device="cpu").manual_seed(0)
     action = ((torch.rand(args.envs, 12, generator=g, dtype=torch.float64) - 0.5) * 0.5).to(dev)
     if args.zero_action:
         action = torch.zeros_like(action)
     for _ in range(args.warmup):
         env.step(action)
+    # one untimed lane reset: the first use of the reset path loads its kernels (tens of ms, once per process)
+    warm = torch.zeros(args.envs, dtype=torch.bool, device=dev)
+    warm[:1] = True
+    env.reset_lanes(warm)
+    env.step(action)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n_reset = 0
@@ -51,7 +59,7 @@ def main():
     print(json.dumps({"metric": "gym-steps/s ANYmal PD + Mahony pipeline", "value": args.envs * args.steps / el,
                       "contact_model": args.contact_model, **extra,
                       "ms_per_env_step": 1e3 * el / args.steps, "envs": args.envs, "steps": args.steps,
-                      "integrator_steps_per_env_step": 40, "solver": args.solver, "lanes_reset": n_reset,
+                      "integrator_steps_per_env_step": 40, "solver": args.solver, "graph": bool(args.graph), "lanes_reset": n_reset,
                       "blocks": "tensor" if os.environ.get("JIMINY_AMD_TENSOR_BLOCKS") == "1" else "hip"}))
 
 
