@@ -262,10 +262,20 @@ def test_anymal_1000_steps_teacher_forced_at_the_benchmarked_step(gpu_device):
     steps in the oracle and on the device alike, and the device `sincos` is specified for |x| < 1e5
     (jm_math.h): lanes are compared while |v| <= 1e3 and |a| <= 1e9, then re-seeded from the next
     unused lane of the bench batch, like the bench's own auto-reset."""
-    model = load_builtin("anymal")
+    _teacher_forced_test(gpu_device, "anymal", 256, 1e-3, 1000, 65536, 50000)
+
+
+def test_atlas_teacher_forced_at_the_benchmarked_step(gpu_device):
+    """The same per-step comparison on BASELINE's Atlas configuration (`bench.py --model atlas --dt 2.5e-4`: 30 motors,
+    32 contact points, trunk tree + padded limbs on the branch-parallel kernel), first 64 lanes of its bench batch,
+    400 steps."""
+    _teacher_forced_test(gpu_device, "atlas", 64, 2.5e-4, 400, 4096, 2000)
+
+
+def _teacher_forced_test(gpu_device, name, B, dt, steps, pool, min_contact_steps):
+    model = load_builtin(name)
     _open_bounds(model)
-    B, dt, steps = 256, 1e-3, 1000
-    st = sample_states(model, 65536, seed=0)
+    st = sample_states(model, pool, seed=0)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     eng.set_command(torch.from_numpy(np.ascontiguousarray(st["command"][:, :B])))
     eng.start(torch.from_numpy(np.ascontiguousarray(st["q"][:, :B])), torch.from_numpy(np.ascontiguousarray(st["v"][:, :B])))
@@ -295,10 +305,10 @@ def test_anymal_1000_steps_teacher_forced_at_the_benchmarked_step(gpu_device):
         count["contact_steps"] += int((ok & (np.abs(ref["contact_forces"]).sum(axis=0) > 0)).sum())
 
     n_reseeded = _teacher_forced_run(model, st, B, dt, steps, step_and_compare)
-    print(f"teacher-forced dt=1e-3: {count['lane_steps']} lane-steps compared ({count['contact_steps']} in ground "
+    print(f"teacher-forced {name} dt={dt:g}: {count['lane_steps']} lane-steps compared ({count['contact_steps']} in ground "
           f"contact, {n_reseeded} lanes re-seeded); worst lane " + ", ".join(f"{k} {v.max():.1e}" for k, v in worst.items()))
     assert count["lane_steps"] >= 0.95 * B * steps, count
-    assert count["contact_steps"] >= 50000, count
+    assert count["contact_steps"] >= min_contact_steps, count
     for k, v in worst.items():
         assert v.max() <= 1e-5, (k, v.max())
     assert np.median(worst["a"]) <= 1e-9, np.median(worst["a"])
