@@ -57,7 +57,8 @@
                          // sweeps: measured slower on ANYmal because the sweeps then spill)
 #endif
 #ifndef JM_QCON_MAXM
-#define JM_QCON_MAXM 64  // most active constraint rows solved per robot (rows beyond it are dropped and flagged)
+#define JM_QCON_MAXM 96  // most active constraint rows solved per robot (rows beyond it are dropped and flagged); 96 = a humanoid
+                         // standing flat on two 8-vertex feet during Engine::start (16 contacts x 4 rows + joint bounds)
 #endif
 
 namespace jm
@@ -264,7 +265,25 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
         typename QConCtx<T, Tp>::RowMask lim;
         lim.clear();
         typename QConCtx<T, Tp>::RowMask tmp = en;
-        while (keep > 0 && tmp.any()) { lim.set(tmp.pop_lowest()); --keep; }
+        int last = -1;
+        while (keep > 0 && tmp.any()) { last = tmp.pop_lowest(); lim.set(last); --keep; }
+        // never keep a part of a contact block: its rows are addressed as r, r + 1, r + 2 (, r + 3) from its first
+        // packed row, a truncated block would index past the m kept rows (and past the solver region)
+        if (last >= R::NB)
+        {
+            const int b0 = R::NB + 4 * ((last - R::NB) / 4);
+            bool cut = false;
+            for (int i = 0; i < 4; ++i) cut |= en.test(b0 + i) && !lim.test(b0 + i);
+            if (cut)
+                for (int i = 0; i < 4; ++i)
+                {
+                    typename QConCtx<T, Tp>::RowMask one;
+                    one.clear();
+                    one.set(b0 + i);
+#pragma unroll
+                    for (int w = 0; w < QR::NWORDS; ++w) lim.w[w] &= ~one.w[w];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < QR::NWORDS; ++i) { en.w[i] &= lim.w[i]; own.w[i] &= lim.w[i]; }
     }
@@ -642,19 +661,26 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
         {
             // this lane's quarter of row i, all reads in flight at once (the overflow part of the region sits in HBM:
             // one round trip per row instead of one per element); same summation order as the plain loop
-            constexpr int NG = (QConRows<Tp>::MAXM + 3) / 4;
-            T a[NG], xv[NG];
-            static_for<0, NG>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int c = k + 4 * j;
-                const bool valid = c < m;
-                a[j] = V.get_flat(valid ? A0 + tri_(i, c) : 0);
-                xv[j] = V.get_flat(valid ? c : 0);
-            });
-            static_for<0, NG>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                s = (k + 4 * j < m) ? s + a[j] * xv[j] : s;
-            });
+            constexpr int NG = (QConRows<Tp>::MAXM + 3) / 4, NG0 = NG < 16 ? NG : 16;
+            auto batch = [&](auto lo_, auto hi_) __attribute__((always_inline)) {
+                constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+                T a[HI - LO > 0 ? HI - LO : 1], xv[HI - LO > 0 ? HI - LO : 1];
+                static_for<LO, HI>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int c = k + 4 * j;
+                    const bool valid = c < m;
+                    a[j - LO] = V.get_flat(valid ? A0 + tri_(i, c) : 0);
+                    xv[j - LO] = V.get_flat(valid ? c : 0);
+                });
+                static_for<LO, HI>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    s = (k + 4 * j < m) ? s + a[j - LO] * xv[j - LO] : s;
+                });
+            };
+            batch(std::integral_constant<int, 0>{}, std::integral_constant<int, NG0>{});
+            // (rows 64 and above exist during Engine::start of a robot standing on many contact points: one scalar test)
+            if constexpr (NG > NG0)
+                if (X::wave_any(m > 4 * NG0)) batch(std::integral_constant<int, NG0>{}, std::integral_constant<int, NG>{});
         }
         return X::quad_sum(s);
     };
@@ -1519,7 +1545,7 @@ template<class T, class Tp> constexpr int qcon_resident_waves()
     {
         const int wb = wr < quad_block_waves<T, Tp>() ? wr : quad_block_waves<T, Tp>();
         const long per_robot = qcon_free_lds<T, Tp>(wr, wb) / ((long)wr * 16 * (long)sizeof(T));
-        if (per_robot >= 3L * QConRows<Tp>::MAXM) return wr;
+        if (per_robot >= 3L * (QConRows<Tp>::MAXM < 64 ? QConRows<Tp>::MAXM : 64)) return wr;
     }
     return 1;
 }

@@ -12,6 +12,7 @@ instead of raising for the whole batch.
 """
 from __future__ import annotations
 
+import math
 from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
@@ -333,7 +334,8 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
     def __init__(self, model: CompiledModel, num_envs: int, step_dt: float, control_dt: float,
                  kp: Any, kd: Any, mahony_kp: float = 1.0, mahony_ki: float = 0.1,
                  joint_position_margin: float = 0.0, joint_velocity_limit: float = float("inf"),
-                 joint_acceleration_limit: Optional[float] = None, **kw: Any) -> None:
+                 joint_acceleration_limit: Optional[float] = None,
+                 safety_limit: Optional[Dict[str, float]] = None, **kw: Any) -> None:
         opts = kw.pop("engine_options", None) or {}
         st = dict(opts.get("stepper", {}))
         st.setdefault("controllerUpdatePeriod", control_dt)
@@ -387,6 +389,21 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         if os.environ.get("JIMINY_AMD_TENSOR_BLOCKS", "0") != "1":
             self._hip_blocks = blocks.HipBlocks(self.engine, self._enc_idx, lo, hi, self.kp, self.kd,
                                                 self.effort_limit)
+        # optional `MotorSafetyLimit` between the PD controller and the motors (gym_jiminy blocks/motor_safety_limit.py:
+        # 81-175; Atlas: kp = 1 / MOTOR_POSITION_MARGIN, kd = MOTOR_VELOCITY_SAFE_GAIN): motor-side soft bounds
+        self._safety = None
+        if safety_limit is not None:
+            if self._hip_blocks is None:
+                raise NotImplementedError("the motor safety limit runs as a HIP block")
+            margin = float(safety_limit.get("soft_position_margin", 0.0))
+            vmax = float(safety_limit["soft_velocity_max"])
+            if margin < 0.0 or vmax < 0.0:
+                raise ValueError("Soft position margin and soft maximum velocity must be positive.")
+            self._safety = dict(
+                kp=np.full(M, float(safety_limit["kp"])), kd=np.full(M, float(safety_limit["kd"])),
+                lo=np.array([model.position_lower[m.idx_q] * m.reduction for m in model.motors]) + red * margin,
+                hi=np.array([model.position_upper[m.idx_q] * m.reduction for m in model.motors]) - red * margin,
+                vlim=np.minimum(np.array([m.velocity_limit for m in model.motors]), red * vmax))
 
     def _encoders(self) -> torch.Tensor:
         enc = self.engine.sensor_measurements["EncoderSensor"]   # (2, n_enc, B)
@@ -482,6 +499,10 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
             if hb is not None:
                 # torques go straight into the engine's command rows
                 hb.pd_controller(self.command_state, self.control_dt, self.engine.field("command"))
+                if self._safety is not None:
+                    sf = self._safety
+                    cmd = self.engine.field("command")
+                    hb.motor_safety_limit(cmd, sf["kp"], sf["kd"], sf["lo"], sf["hi"], sf["vlim"], cmd)
                 self.engine.mark_command_changed()
             else:
                 blocks.pd_controller(self._encoders(), self.command_state, self.command_state_lower,
@@ -547,3 +568,64 @@ def make_anymal_env(num_envs: int, dtype: torch.dtype = torch.float64,
                                         engine_options=opts, dtype=dtype, device=device, **kw)
     return WalkerVecEnv(model, num_envs, ANYMAL_STEP_DT, engine_options=opts, dtype=dtype,
                         device=device, **kw)
+
+
+# constants of the reference Atlas environment (python/gym_jiminy/envs/gym_jiminy/envs/atlas.py:24-80, atlas_options.toml)
+ATLAS_STEP_DT = 0.04
+ATLAS_CONTROL_DT = 0.005
+ATLAS_SIMULATION_DURATION = 20.0
+ATLAS_NEUTRAL_SAGITTAL_HIP_ANGLE = 0.2
+ATLAS_MOTOR_POSITION_MARGIN = 0.02
+ATLAS_MOTOR_VELOCITY_SAFE_GAIN = 0.15
+ATLAS_MOTOR_VELOCITY_MAX = 4.0
+ATLAS_MOTOR_ACCELERATION_MAX = 30.0
+ATLAS_PD_REDUCED_KP = (5000.0, 5000.0, 8000.0, 4000.0, 8000.0, 5000.0) * 2      # legs: HpZ, HpX, HpY, KnY, AkY, AkX
+ATLAS_PD_REDUCED_KD = (0.01, 0.02, 0.02, 0.01, 0.025, 0.01) * 2
+ATLAS_PD_FULL_KP = ((5000.0, 8000.0, 5000.0)                                      # back: Z, Y, X
+                    + (500.0, 100.0, 200.0, 500.0, 10.0, 100.0, 10.0)             # left arm
+                    + (100.0,)                                                    # neck
+                    + (500.0, 100.0, 200.0, 500.0, 10.0, 100.0, 10.0)             # right arm
+                    + ATLAS_PD_REDUCED_KP)
+ATLAS_PD_FULL_KD = ((0.01, 0.015, 0.02) + (0.01, 0.01, 0.01, 0.02, 0.01, 0.02, 0.02) + (0.01,)
+                    + (0.01, 0.01, 0.01, 0.02, 0.01, 0.02, 0.02) + ATLAS_PD_REDUCED_KD)
+ATLAS_MAHONY_KP, ATLAS_MAHONY_KI = 0.75, 0.057
+# `AtlasJiminyEnv._neutral` (atlas.py:147-164): the arms folded along the body, a slight forward lean of the back
+ATLAS_NEUTRAL_JOINTS = {"back_bky": 0.2, "l_arm_elx": 0.2, "l_arm_shx": -math.pi / 2.0, "l_arm_shz": math.pi / 4.0,
+                        "l_arm_ely": math.pi / 4.0 + math.pi / 2.0, "r_arm_elx": -0.2, "r_arm_shx": math.pi / 2.0,
+                        "r_arm_shz": -math.pi / 4.0, "r_arm_ely": math.pi / 4.0 + math.pi / 2.0}
+
+
+class AtlasPDControlVecEnv(PDControlledWalkerVecEnv):
+    """≙ `AtlasPDControlJiminyEnv` (atlas.py:254-309): MotorSafetyLimit -> PDController -> PDAdapter (order 1) ->
+    MahonyFilter around `AtlasJiminyEnv`, whose neutral configuration folds the arms."""
+
+    def _sample_state_numpy(self) -> Tuple[np.ndarray, np.ndarray]:
+        m = self.model
+        q = m.neutral()
+        for name, value in ATLAS_NEUTRAL_JOINTS.items():
+            q[int(m.idx_q[m.joint_names.index(name)])] = value
+        mask = m.bounded_position_mask()
+        q[mask] = np.clip(q[mask], m.position_lower[mask], m.position_upper[mask])
+        q[2] -= float(lowest_contact_height(m, q)[0])
+        return q, np.zeros(m.nv)
+
+
+def make_atlas_env(num_envs: int, dtype: torch.dtype = torch.float64, device: Optional[torch.device] = None,
+                   ode_solver: str = "euler_explicit", dt_max: float = 1e-3, contact_model: str = "constraint",
+                   **kw: Any) -> AtlasPDControlVecEnv:
+    """Atlas with the reference's environment constants (atlas.py, atlas_options.toml: explicit Euler at 1 ms, 5 ms
+    controller / sensor period, constraint contact model).  All 32 box-vertex contact points of the compiled model are
+    kept (the reference environment prunes the ones off the bottom convex hull of each foot, atlas.py:99-115: they never
+    touch a flat ground)."""
+    model = load_builtin("atlas")
+    opts = {"stepper": {"odeSolver": ode_solver, "dtMax": dt_max, "controllerUpdatePeriod": ATLAS_CONTROL_DT,
+                        "sensorsUpdatePeriod": ATLAS_CONTROL_DT},
+            "contacts": {"model": contact_model}}
+    kw.setdefault("simulation_duration_max", ATLAS_SIMULATION_DURATION)
+    return AtlasPDControlVecEnv(
+        model, num_envs, ATLAS_STEP_DT, ATLAS_CONTROL_DT, ATLAS_PD_FULL_KP, ATLAS_PD_FULL_KD, ATLAS_MAHONY_KP, ATLAS_MAHONY_KI,
+        joint_position_margin=0.0, joint_velocity_limit=ATLAS_MOTOR_VELOCITY_MAX,
+        joint_acceleration_limit=ATLAS_MOTOR_ACCELERATION_MAX,
+        safety_limit={"kp": 1.0 / ATLAS_MOTOR_POSITION_MARGIN, "kd": ATLAS_MOTOR_VELOCITY_SAFE_GAIN,
+                      "soft_position_margin": 0.0, "soft_velocity_max": ATLAS_MOTOR_VELOCITY_MAX},
+        engine_options=opts, dtype=dtype, device=device, **kw)

@@ -136,6 +136,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad(const jm::Bat
     else { (void)A; (void)P; }
 }
 
+static int g_guard_violations = 0;
+extern "C" int emu_guard_violations() { return g_guard_violations; }
 // branch-parallel kernel with the constraint contact model (jm_qcon.h): the robot's solver region is split
 // between a small "on-chip" array and overflow rows, so that both homes of QStore are exercised
 template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
@@ -147,7 +149,11 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
         const T * table = P.data() + jm::QLayout<Tp>::OFFSET;
         constexpr int CAP = 150;   // solves of up to 13 rows take the on-chip path, larger ones overflow
         const int rows = jm::QConRows<Tp>::ws_rows(CAP);
-        std::vector<T> lds((size_t)(CAP + 1) * A.B, (T)std::nan("")), hbm((size_t)(rows + 1) * A.B, (T)std::nan(""));
+        // (guard rows behind the workspace: a solver that indexes past its region is caught below)
+        constexpr int GUARD = 512;
+        const T sentinel = (T)-12345.678;
+        std::vector<T> lds((size_t)(CAP + 1) * A.B, (T)std::nan("")), hbm((size_t)(rows + 1 + GUARD) * A.B, (T)std::nan(""));
+        for (size_t i = (size_t)(rows + 1) * A.B; i < hbm.size(); ++i) hbm[i] = sentinel;
         std::vector<std::thread> th;
         for (int k = 0; k < 4; ++k)
             th.emplace_back([&, k]() {
@@ -166,6 +172,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
             });
         for (auto & t : th) t.join();
         pthread_barrier_destroy(&sh.bar);
+        for (size_t i = (size_t)(rows + 1) * A.B; i < hbm.size(); ++i)
+            if (hbm[i] != sentinel) { g_guard_violations += 1; break; }
     }
     else { (void)A; (void)P; (void)C0; }
 }

@@ -254,6 +254,42 @@ def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
         _check(got, ref, 1e-7, solver)
 
 
+def test_atlas_standing_flat_on_both_feet_start_and_steps():
+    """A humanoid standing flat: the 8 bottom vertices of each foot box touch, 16 contact points = 64 rows in
+    `Engine::start`'s passes (4-row blocks) + the joints the neutral pose puts on their bounds -- the largest solve the
+    shipped robots produce, above the 64 rows the solver region was first sized for (a truncated contact block then
+    indexed past the region: the emulation keeps guard rows behind its workspace for exactly that).  Start, then
+    steps with 3-row blocks, against the oracle."""
+    from jiminy_amd.synthetic import lowest_contact_height
+    model = load_builtin("atlas")
+    B = 3
+    q = model.neutral()
+    for name, value in {"back_bky": 0.2, "l_arm_elx": 0.2, "l_arm_shx": -np.pi / 2, "l_arm_shz": np.pi / 4, "l_arm_ely": 3 * np.pi / 4,
+                        "r_arm_elx": -0.2, "r_arm_shx": np.pi / 2, "r_arm_shz": -np.pi / 4, "r_arm_ely": 3 * np.pi / 4}.items():
+        q[int(model.idx_q[model.joint_names.index(name)])] = value
+    mask = model.bounded_position_mask()
+    q[mask] = np.clip(q[mask], model.position_lower[mask], model.position_upper[mask])
+    q[2] -= float(lowest_contact_height(model, q)[0]) + 2.0e-3           # 2 mm into the ground
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for arr in (ref, got):
+        alloc_constraint_state(model, arr, B)
+        arr["q"][:] = q[:, None]
+        arr["q"][2] += 1e-4 * np.arange(B)
+    lib = emu._lib(model)
+    before = lib.emu_guard_violations()
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT, variant="quad")
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    assert int((ref["con_flags"][nb:, 0] & 1).sum()) == 16 and int((ref["con_flags"][:nb, 0] & 1).sum()) >= 3
+    _check(got, ref, 1e-8, "start")
+    for _ in range(2):
+        kw = dict(solver="euler_explicit", dt=1e-3, n_substeps=2, command_changed=True)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
+        emu.run(model, got, "step", constraint_options=TIGHT, variant="quad", **kw)
+    _check(got, ref, 1e-6, "steps")
+    assert lib.emu_guard_violations() == before
+
+
 @pytest.mark.parametrize("torsion", [0.0, 0.3])
 def test_quad_constraint_kernel_torsion_dynamics_and_reset(torsion):
     """Branch-parallel constraint kernel on the host: with torsional friction (the 4-row contact blocks) and

@@ -414,3 +414,31 @@ def test_graph_replay_of_the_environment_step_is_bit_identical(gpu_device):
         e = make_anymal_env(8, device=gpu_device, dt_max=1e-3, std_ratio={"disturbance": 0.1})
         e.reset(seed=1)
         e.enable_graph()
+
+
+def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
+    """`make_atlas_env` ≙ `AtlasPDControlJiminyEnv` (gym_jiminy envs/atlas.py): 30 motors under MotorSafetyLimit -> PD
+    controller -> PD adapter, Mahony filter, constraint contact model, Euler 1 ms / controller 5 ms.  With a zero action
+    (hold the neutral pose, arms folded) the robots keep standing for a second of simulated time, the estimated attitude
+    stays upright, and the HIP-graph replay of the step gives the same result."""
+    from jiminy_amd.envs import ATLAS_NEUTRAL_JOINTS, make_atlas_env
+    B = 64
+    envs = [make_atlas_env(B, device=gpu_device) for _ in range(2)]
+    envs[1].enable_graph()
+    for e in envs:
+        obs, _ = e.reset(seed=2)
+    m = envs[0].model
+    q0 = obs["states"]["agent"]["q"].clone()        # (the observation is a live view of the engine's state)
+    for name, value in ATLAS_NEUTRAL_JOINTS.items():
+        assert torch.allclose(q0[:, int(m.idx_q[m.joint_names.index(name)])], torch.full((B,), value, dtype=torch.float64, device=gpu_device))
+    action = torch.zeros((B, m.nmotors), dtype=torch.float64, device=gpu_device)
+    for _ in range(25):
+        outs = [e.step(action) for e in envs]
+    (obs, reward, terminated, truncated, _), (obs_g, *_rest) = outs
+    assert not bool(terminated.any()) and not bool(truncated.any())
+    z = obs["states"]["agent"]["q"][:, 2]
+    assert float((z - q0[:, 2]).abs().max()) < 0.01                     # still standing at the neutral height
+    quat = obs["features"]["mahony_filter"][:, :, 0]                      # (B, 4) first IMU
+    assert float(quat[:, 3].abs().min()) > 0.95                          # estimated attitude upright
+    assert torch.equal(obs["states"]["agent"]["q"], obs_g["states"]["agent"]["q"])
+    assert (envs[0].engine.field("con_flags")[envs[0].engine.field("con_flags").shape[0] - m.ncontacts:] & 1).sum() >= 4 * B
