@@ -748,3 +748,41 @@ def test_gpu_constraint_model_long_horizon(gpu_device):
           f"active bound constraints at the end {n_bounds}")
     assert n_bounds >= 10
     assert np.median(worst) <= 1e-9 and worst.max() <= 1e-5, (np.median(worst), worst.max())
+
+
+@pytest.mark.gpu
+def test_gpu_solver_region_stays_inside_its_workspace(gpu_device):
+    """Device twin of the guard-row check of the host emulation: Atlas standing flat on both feet (the largest solve of
+    the shipped robots: 16 contact points x 4 rows in the start passes + its joint bounds) with a workspace that carries
+    256 sentinel rows behind the rows the library asked for -- they must come back untouched, and the lanes unflagged."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.synthetic import lowest_contact_height
+    model = load_builtin("atlas")
+    B = 48
+    q = model.neutral()
+    for name, value in {"back_bky": 0.2, "l_arm_elx": 0.2, "l_arm_shx": -np.pi / 2, "l_arm_shz": np.pi / 4, "l_arm_ely": 3 * np.pi / 4,
+                        "r_arm_elx": -0.2, "r_arm_shx": np.pi / 2, "r_arm_shz": -np.pi / 4, "r_arm_ely": 3 * np.pi / 4}.items():
+        q[int(model.idx_q[model.joint_names.index(name)])] = value
+    mask = model.bounded_position_mask()
+    q[mask] = np.clip(q[mask], model.position_lower[mask], model.position_upper[mask])
+    q[2] -= float(lowest_contact_height(model, q)[0]) + 2.0e-3
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": 1e-3, "controllerUpdatePeriod": 5e-3, "sensorsUpdatePeriod": 5e-3},
+                     "contacts": {"model": "constraint"}})
+    rows = eng._fields["workspace"].shape[0]
+    guarded = torch.zeros((rows + 256, B), dtype=torch.float64, device=gpu_device)
+    guarded[rows:] = -12345.678
+    eng._fields["workspace"] = guarded
+    eng._bind("workspace")
+    eng.set_command(torch.zeros(model.nmotors, B, dtype=torch.float64))
+    eng.start(torch.from_numpy(np.tile(q[:, None], (1, B))), torch.zeros(model.nv, B, dtype=torch.float64))
+    for _ in range(4):
+        eng.mark_command_changed()
+        eng.step(5e-3)
+    torch.cuda.synchronize()
+    assert bool((guarded[rows:] == -12345.678).all())
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    assert int((eng.field("con_flags")[nb:, 0] & 1).sum()) == 16
+    assert int((eng.status & ~16).abs().sum()) == 0
