@@ -297,6 +297,8 @@ typedef struct jm_adaptive_options
     double dt_max;                      /* stepper.dtMax */
     double dt_restore_threshold_rel;    /* stepper.dtRestoreThresholdRel (0.2) */
     int32_t successive_iter_failed_max; /* stepper.successiveIterFailedMax (1000) */
+    int32_t form;                       /* 0: one persistent launch per interval where the topology has that kernel
+                                           (jm_qdopri.h), 1: always the per-stage launches over compacted lanes */
 } jm_adaptive_options;
 int32_t jm_batch_adaptive_workspace_rows(const jm_batch * batch);
 int32_t jm_batch_bind_adaptive(jm_batch * batch, void * workspace, double * state_f64, int32_t * state_i32);

@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -120,6 +120,7 @@ class AdaptiveOptions(C.Structure):
         ("dt_max", C.c_double),
         ("dt_restore_threshold_rel", C.c_double),
         ("successive_iter_failed_max", C.c_int32),
+        ("form", C.c_int32),
     ]
 
 

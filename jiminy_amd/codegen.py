@@ -11,7 +11,7 @@ import json
 import os
 import shutil
 import subprocess
-from typing import List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -264,6 +264,16 @@ def preferred_variant(model: CompiledModel) -> int:
         return 0
 
 
+def part_flags(model: CompiledModel) -> Dict[str, List[str]]:
+    """Extra flags of single translation units of a topology (build_variants.json `part_flags`: {"5": ["-O1"]} compiles
+    the persistent adaptive kernel of that topology at -O1), appended after the common flags."""
+    try:
+        with open(_VARIANT_FILE) as f:
+            return {str(k): list(v) for k, v in json.load(f).get(model.topology_hash(), {}).get("part_flags", {}).items()}
+    except (OSError, ValueError):
+        return {}
+
+
 def lib_path(model: CompiledModel, variant: Optional[int] = None) -> str:
     v = preferred_variant(model) if variant is None else variant
     # JIMINY_AMD_LIB_TAG selects an experimental build (tuning A/B runs only)
@@ -304,6 +314,7 @@ def source_digest(model: CompiledModel, variant: Optional[int] = None, extra_fla
             h.update(f.read())
     h.update(topology_header(model).encode())
     h.update(" ".join(BUILD_VARIANTS[v]).encode() if v < len(BUILD_VARIANTS) else b"?")
+    h.update(json.dumps(part_flags(model), sort_keys=True).encode())
     h.update(" ".join(extra_flags or []).encode())
     return h.hexdigest()
 
@@ -349,7 +360,8 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
     parts = [1, 2, 3, 4, 5, 6] if quad_structure(model) is not None else [1]
     objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]
     cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]]]
-    cmds += [[HIPCC] + common + [f"-DJM_CON_PART={p}", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", o]
+    pf = part_flags(model)
+    cmds += [[HIPCC] + common + pf.get(str(p), []) + [f"-DJM_CON_PART={p}", "-c", os.path.join(CSRC, "jm_lib_constraint.cpp"), "-o", o]
              for p, o in zip(parts, objs[1:])]
     if verbose:
         for c in cmds:

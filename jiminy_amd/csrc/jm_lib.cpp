@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 2
+#define JM_ABI_VERSION 3
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -337,7 +337,7 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
     // into the attempt bound of a launch (then it launches again) and the largest attempt count
     if constexpr (Topo::QUAD && std::is_same<T, double>::value)
     {
-        if (b->variant == VARIANT_QUAD && !constrained)
+        if (b->variant == VARIANT_QUAD && !constrained && o->form != 1)
         {
             const bool gen = b->field[JM_F_MODEL_LANE] || b->ground_h || (b->applied_k > 0 && b->field[JM_F_APPLIED]);
             auto A = make_args<T>(b);

@@ -299,7 +299,10 @@ def _variation_self_test(model: CompiledModel, variant: int, device: torch.devic
     err = 0.0
     # (the persistent adaptive stepper has its own variation instantiation, `k_quad_dopri_gen`: spring-damper model)
     for solver in ("runge_kutta_4",) + (("runge_kutta_dopri",) if contact_model == "spring_damper" else ()):
-        err = max(err, _variation_self_test_leg(model, variant, device, contact_model, solver, n, dt, q, v, cmd))
+        e = _variation_self_test_leg(model, variant, device, contact_model, solver, n, dt, q, v, cmd)
+        # (two adaptive runs whose evaluations round differently agree to the integration tolerance, 1e-7 here, not to
+        # round-off: that leg is weighed so that the common bar of 1e-8 means 1e-5 for it; garbage is O(1))
+        err = max(err, e * (1e-3 if solver == "runge_kutta_dopri" else 1.0))
     return err
 
 
@@ -337,6 +340,47 @@ def _variation_self_test_leg(model: CompiledModel, variant: int, device: torch.d
     for x, y in zip(outs[0][0], outs[1][0]):
         scale = torch.clamp(x[:, ok].abs().max(), min=1.0)
         e = float(((x - y)[:, ok]).abs().max() / scale)
+        err = max(err, e if e == e else float("inf"))
+    return err
+
+
+_DOPRI_FORM: Dict[Tuple[str, int], int] = {}
+
+
+def _adaptive_self_test(model: CompiledModel, variant: int, device: torch.device) -> float:
+    """Persistent adaptive kernel (jm_qdopri.h) against the per-stage launches on the probe batch: three breakpoint
+    intervals with tight tolerances.  Returns the largest relative disagreement over (q, v) on the lanes that follow the
+    same accept / reject sequence (inf when fewer than 80 % do, or when the persistent kernel flags lanes the per-stage
+    path does not)."""
+    n = 64
+    q, v, cmd = (torch.as_tensor(x, dtype=torch.float64, device=device) for x in _probe_state(model, n))
+    outs = []
+    for form in (1, 0):
+        probe = BatchedEngine(model, n, dtype=torch.float64, device=device, extra_outputs=(), _lib_variant=variant)
+        probe._adaptive_form_override = form
+        probe.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-8, "tolRel": 1e-7, "dtMax": 1e-3,
+                                       "controllerUpdatePeriod": 1e-3, "sensorsUpdatePeriod": 1e-3},
+                           "contacts": {"model": "spring_damper"}})
+        if model.nmotors:
+            probe.set_command(cmd)
+        probe.start(q, v)
+        for _ in range(3):
+            probe.step(1e-3)
+        ss = probe.stepper_state
+        outs.append((probe._fields["q"].clone(), probe._fields["v"].clone(), ss.iter_lanes.clone(), ss.iter_failed_lanes.clone(),
+                     probe.status.reshape(-1).clone()))
+        probe.stop()
+    (q1, v1, it1, if1, st1), (q0, v0, it0, if0, st0) = outs
+    bad = ((st0 & (_abi.JM_LANE_NAN | _abi.JM_LANE_STEPPER_FAILURE)) != 0) & ((st1 & (_abi.JM_LANE_NAN | _abi.JM_LANE_STEPPER_FAILURE)) == 0)
+    if bool(bad.any()):
+        return float("inf")
+    same = (it0 == it1) & (if0 == if1) & ((st1 & (_abi.JM_LANE_NAN | _abi.JM_LANE_STEPPER_FAILURE)) == 0)
+    if float(same.double().mean()) < 0.8:
+        return float("inf")
+    err = 0.0
+    for x, y in ((q0, q1), (v0, v1)):
+        scale = torch.clamp(y[:, same].abs().max(), min=1.0)
+        e = float((x - y)[:, same].abs().max() / scale)
         err = max(err, e if e == e else float("inf"))
     return err
 
@@ -820,7 +864,8 @@ class BatchedEngine:
         intervals, t_end, t_err = plan_breakpoints(self._t, self._t_error, float(step_dt), self._options,
                                                    self._force_breakpoints(self._t))
         o = _abi.AdaptiveOptions(float(st["tolRel"]), float(st["tolAbs"]), float(st["dtMax"]),
-                                 float(st["dtRestoreThresholdRel"]), int(st["successiveIterFailedMax"]))
+                                 float(st["dtRestoreThresholdRel"]), int(st["successiveIterFailedMax"]),
+                                 self._adaptive_form())
         stream = self._stream()
         attempts = C.c_int32(0)
         self.adaptive_attempts = 0
@@ -847,6 +892,29 @@ class BatchedEngine:
         self._t_prev = self._t
         self._t = t_end
         self._t_error = t_err
+
+    def _adaptive_form(self) -> int:
+        """0 = the persistent kernel where the library has one, 1 = per-stage launches.  The first adaptive step of a
+        (topology, build variant) in the process checks the persistent kernel against the per-stage path on a probe
+        batch (`_adaptive_self_test`: the per-stage path runs through the step kernels the library self-test covers)
+        and falls back to it, with a warning, when they disagree.  JIMINY_AMD_ADAPTIVE_FORM forces a form."""
+        env = os.environ.get("JIMINY_AMD_ADAPTIVE_FORM")
+        if env is not None:
+            return int(env)
+        if getattr(self, "_adaptive_form_override", None) is not None:
+            return self._adaptive_form_override
+        if self.dtype != torch.float64 or codegen.quad_structure(self.model) is None or \
+                self._options["contacts"]["model"] != "spring_damper" or os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
+            return 0
+        key = (self.model.topology_hash(), self._lib_variant_index)
+        if key not in _DOPRI_FORM:
+            _DOPRI_FORM[key] = 0       # (the probes below are engines of the same topology)
+            err = _adaptive_self_test(self.model, self._lib_variant_index, self.device)
+            if not err <= 1e-6:
+                _DOPRI_FORM[key] = 1
+                warnings.warn(f"{self.model.name}: the persistent adaptive kernel of build variant {key[1]} disagrees with the "
+                              f"per-stage path on the probe batch ({err:.3e}): using the per-stage launches (DESIGN.md section 4.7)")
+        return _DOPRI_FORM[key]
 
     def step(self, step_dt: float = -1.0) -> None:
         """≙ `Engine::step(stepSize)` (reference engine.cc:1724-2417): fixed-step solvers advance

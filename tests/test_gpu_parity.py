@@ -487,6 +487,24 @@ def test_adaptive_dopri_anymal_free_flight_and_energy(gpu_device):
     assert int(eng.stepper_state.iter) >= 20 and eng.adaptive_attempts >= 1
 
 
+def test_adaptive_dopri_atlas_long_limbs(gpu_device):
+    """The persistent stepper on a topology with long limbs and a trunk tree (Atlas: the stage velocities and commands of
+    the evaluation travel through the stage buffer): free flight and landings, tight tolerances, against the oracle."""
+    model = load_builtin("atlas")
+    B = 32
+    st = sample_states(model, B, seed=14, base_height=(1.0, 1.3), grounded_fraction=0.3, command_fraction=0.1)
+    eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 6, 1e-7, 1e-8)
+    dev_status = eng.status.cpu().numpy().reshape(-1)
+    ok = ((ref["status"][0] | dev_status) & 9) == 0
+    assert ok.mean() > 0.9, (np.unique(ref["status"][0], return_counts=True), np.unique(dev_status, return_counts=True))
+    ss = eng.stepper_state
+    same = ok & (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.mean() > 0.8
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-7, k
+    assert abs(ss.t - 0.03) < 1e-12
+
+
 def test_adaptive_dopri_with_controller_breakpoints_and_contacts(gpu_device):
     """Default tolerances (tolRel 1e-4, tolAbs 1e-5), 5 ms controller / sensor breakpoints, ANYmal
     landing on the spring-damper ground: lanes reach every breakpoint, none is lost, the state stays

@@ -165,13 +165,13 @@ def test_force_breakpoints_cut_the_launches():
 
 # ------------------------------------------------------------------ device build
 @pytest.mark.gpu
-@pytest.mark.parametrize("constrained", [False, True])
-def test_gpu_variation_matches_oracle(gpu_device, constrained):
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True)])
+def test_gpu_variation_matches_oracle(gpu_device, name, constrained):
     import torch
 
     from jiminy_amd.engine import BatchedEngine
-    model = load_builtin("anymal")
-    B, dt = 96, 5e-4
+    model = load_builtin(name)
+    B, dt = (96, 5e-4) if name == "anymal" else (24, 2.5e-4)
     st, ml, ground, applied = _scene(model, B, 9, constrained)
     copt = TIGHT if constrained else None
     ref = alloc_soa(model, B)
