@@ -487,6 +487,24 @@ def test_adaptive_dopri_anymal_free_flight_and_energy(gpu_device):
     assert int(eng.stepper_state.iter) >= 20 and eng.adaptive_attempts >= 1
 
 
+def test_adaptive_dopri_crane_walker_trunk_tree_and_ragged_limbs(gpu_device):
+    """The persistent stepper on the authored robot with a prismatic / unaligned trunk tree and limbs of 3/3/2/2 joints
+    (its library is the one that needs build variant 1): landings on the spring-damper ground, against the oracle."""
+    from tests import robots
+    model = robots.crane_walker()
+    B = 48
+    st = sample_states(model, B, seed=19, base_height=(0.5, 0.8), grounded_fraction=0.4, command_fraction=0.2)
+    eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 6, 1e-7, 1e-8)
+    dev_status = eng.status.cpu().numpy().reshape(-1)
+    ok = ((ref["status"][0] | dev_status) & 9) == 0
+    assert ok.mean() > 0.9, (np.unique(ref["status"][0], return_counts=True), np.unique(dev_status, return_counts=True))
+    ss = eng.stepper_state
+    same = ok & (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.mean() > 0.8
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-7, k
+
+
 def test_adaptive_dopri_atlas_long_limbs(gpu_device):
     """The persistent stepper on a topology with long limbs and a trunk tree (Atlas: the stage velocities and commands of
     the evaluation travel through the stage buffer): free flight and landings, tight tolerances, against the oracle."""
