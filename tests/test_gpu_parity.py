@@ -314,6 +314,27 @@ def _teacher_forced_test(gpu_device, name, B, dt, steps, pool, min_contact_steps
     assert np.median(worst["a"]) <= 1e-9, np.median(worst["a"])
 
 
+@pytest.mark.parametrize("name", ["anymal", "atlas"])
+def test_fp32_engines_of_the_branch_parallel_topologies(gpu_device, name):
+    """float32 batches of the big robots (`bench.py --dtype f32`): the library self-test accepts the float32 kernels (its
+    Runge-Kutta leg is conditioned for float64 only) and ten RK4 steps in free flight stay within float32 accuracy of the
+    float64 engine."""
+    model = load_builtin(name)
+    B, dt = 64, 2.5e-4
+    st = sample_states(model, B, seed=3, base_height=(2.0, 2.5), grounded_fraction=0.0, command_fraction=0.3)
+    out = {}
+    for dtype in (torch.float64, torch.float32):
+        eng = _engine(model, B, dtype, "runge_kutta_4", dt)
+        eng.set_command(torch.from_numpy(st["command"]).to(dtype))
+        eng.start(torch.from_numpy(st["q"]).to(dtype), torch.from_numpy(st["v"]).to(dtype))
+        for _ in range(10):
+            eng.step(dt)
+        assert int((eng.status & 1).sum()) == 0
+        out[dtype] = (eng.field("q").double().cpu().numpy(), eng.field("v").double().cpu().numpy())
+    assert rel_err(out[torch.float32][0], out[torch.float64][0]) < 1e-4
+    assert rel_err(out[torch.float32][1], out[torch.float64][1]) < 5e-3
+
+
 def test_fp32_tolerance_study_cartpole(gpu_device):
     """Config 2 of BASELINE.json: cartpole batch 4096, ABA + RK4, fp64 vs fp32."""
     model = load_builtin("cartpole")
@@ -485,6 +506,24 @@ def test_adaptive_dopri_anymal_free_flight_and_energy(gpu_device):
     e_ref = ref["energy"].sum(axis=0)
     assert np.abs(e_gpu - e_ref).max() < 1e-6 * np.abs(e_ref).max()
     assert int(eng.stepper_state.iter) >= 20 and eng.adaptive_attempts >= 1
+
+
+@pytest.mark.parametrize("B", [1, 3, 65])
+def test_adaptive_dopri_ragged_and_tiny_batches(gpu_device, B):
+    """Batches that fill neither a quad-wave (16 robots) nor a block under the persistent adaptive stepper: the tail
+    robots are integrated, the padding lanes stay out of memory (the engine's fields carry no slack: a stray write would
+    land in a neighbouring tensor and show up in the comparison with the oracle)."""
+    model = load_builtin("anymal")
+    st = sample_states(model, B, seed=23, base_height=(0.5, 0.7), grounded_fraction=0.5, command_fraction=0.2)
+    eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 4, 1e-7, 1e-8)
+    dev_status = eng.status.cpu().numpy().reshape(-1)
+    ok = ((ref["status"][0] | dev_status) & 9) == 0
+    ss = eng.stepper_state
+    same = ok & (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.sum() >= max(1, int(0.7 * B)), (ss.iter_lanes.cpu().numpy(), ad["iter"])
+    for k in ("q", "v", "a"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-6, k
+    assert abs(ss.t - 0.02) < 1e-12
 
 
 def test_adaptive_dopri_crane_walker_trunk_tree_and_ragged_limbs(gpu_device):
