@@ -442,3 +442,33 @@ def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
     assert float(quat[:, 3].abs().min()) > 0.95                          # estimated attitude upright
     assert torch.equal(obs["states"]["agent"]["q"], obs_g["states"]["agent"]["q"])
     assert (envs[0].engine.field("con_flags")[envs[0].engine.field("con_flags").shape[0] - m.ncontacts:] & 1).sum() >= 4 * B
+
+
+@pytest.mark.parametrize("contact_model", ["spring_damper", "constraint"])
+def test_env_with_every_randomisation_switched_on(gpu_device, contact_model):
+    """Everything the reference's locomotion environment randomises, at once: ground friction (constraint model), sensor
+    noise / bias / delay, body-parameter biases, impulse pushes and the Gaussian-process force, with random actions and
+    auto-resets in flight: 40 environment steps (1.6 s) run through, observations and rewards stay finite, finished
+    lanes restart, and a second run from the same seed reproduces the first bit for bit."""
+    B = 128
+    std = {"sensors": 0.3, "disturbance": 0.3}
+    if contact_model == "constraint":
+        std["ground"] = 0.5
+
+    def run():
+        env = make_anymal_env(B, device=gpu_device, contact_model=contact_model, std_ratio=std,
+                              model_options={"dynamics": {"massBodiesBiasStd": 0.05, "centerOfMassPositionBodiesBiasStd": 0.02}})
+        env.reset(seed=11)
+        g = torch.Generator(device="cpu").manual_seed(4)
+        n_reset, last = 0, None
+        for i in range(40):
+            action = (1.5 * torch.randn(B, 12, generator=g, dtype=torch.float64)).to(gpu_device)
+            obs, reward, terminated, truncated, info = env.step(action)
+            n_reset += int(info["reset_mask"].sum()) if "reset_mask" in info else 0
+            for leaf in (obs["states"]["agent"]["q"], obs["states"]["agent"]["v"], obs["features"]["mahony_filter"], reward):
+                assert bool(torch.isfinite(leaf).all()), i
+            last = (obs["states"]["agent"]["q"].clone(), reward.clone())
+        return n_reset, last
+    n1, a = run()
+    n2, b = run()
+    assert n1 == n2 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
