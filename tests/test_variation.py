@@ -361,3 +361,60 @@ def test_gpu_impulse_force_launches_match_the_oracle_step_for_step(gpu_device):
             assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-9, (t, k)
     assert n_refresh == 2 and abs(eng.stepper_state.t - 0.015) < 1e-12
     assert float(np.abs(ref["v"][0:3] - st["v"][0:3]).max()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_adaptive_stepper_with_a_periodic_profile_force_matches_the_oracle(gpu_device):
+    """`register_profile_force(..., update_period)` under the adaptive solver: the force is re-evaluated every 2 ms, those
+    times are breakpoints of the per-robot step-size loops, a(t+) is recomputed when the held value changes.  The oracle's
+    adaptive loop is driven with the same schedule interval by interval; robots that follow the same accept / reject
+    sequence (nearly all) agree to the integration tolerance."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, plan_breakpoints
+    from oracle.oracle_py import adaptive_state
+    model = load_builtin("anymal")
+    B = 40
+    st = sample_states(model, B, seed=9, base_height=(1.0, 1.5), grounded_fraction=0.0)
+    frame = next(n for n, f in model.frames.items() if f.parent_joint == 1)
+    period = 2e-3
+
+    def wrench_at(t):
+        return np.array([80.0 * math.sin(2 * math.pi * t / 0.01), 40.0 * math.cos(2 * math.pi * t / 0.01), 0.0, 0.0, 0.0, 3.0])
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("f_external",))
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-8, "tolRel": 1e-7, "controllerUpdatePeriod": 4e-3,
+                                 "sensorsUpdatePeriod": 4e-3}, "contacts": {"model": "spring_damper"}})
+    eng.register_profile_force(frame, lambda t, q, v: torch.as_tensor(wrench_at(t), device=gpu_device), update_period=period)
+    eng.set_command(torch.from_numpy(st["command"]))
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = OracleEngine(model)
+    io = oracle_io(ref)
+    wrench = np.tile(wrench_at(0.0)[:, None], (1, B))
+    e.bind_applied(wrench, np.array([model.frame(frame).p]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+    ad = adaptive_state(B)
+    t, t_err, held_t = 0.0, 0.0, 0.0
+    for _ in range(3):
+        extra = tuple(period * k for k in range(1, 20) if period * k > t + 1e-10)
+        intervals, t_end, t_err = plan_breakpoints(t, t_err, 4e-3, eng.get_options(), extra)
+        for i, (t_next, cmd_bp, sens) in enumerate(intervals):
+            refresh = False
+            if t - held_t >= period - 1e-10:            # re-evaluated at this interval's start
+                held_t = math.floor(t / period + 1e-9) * period
+                wrench[:] = wrench_at(t)[:, None]
+                refresh = True
+            e.bind_applied(wrench, np.array([model.frame(frame).p]))
+            e.batch_run_dopri(io, ad, t_next, tol_rel=1e-7, tol_abs=1e-8, new_step=(i == 0), command_changed=refresh, update_sensors=sens)
+            t = t_next
+        t = t_end
+        eng.step(4e-3)
+    ss = eng.stepper_state
+    assert abs(ss.t - 0.012) < 1e-12 and int(eng.status.abs().sum()) == 0
+    same = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.mean() > 0.8, (ss.iter_lanes.cpu().numpy(), ad["iter"])
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-7, k
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-4, k
