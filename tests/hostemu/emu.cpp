@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -45,11 +46,11 @@ struct QuadShared
 static std::atomic<int> g_undef_reports{0};
 template<class T> static inline void undef_check(T x)
 {
-    double d = (double)x;
-    unsigned long long bits;
-    std::memcpy(&bits, &d, 8);
-    bool bad = bits == 0xFFFFFFFFFFFFFFFFull;
-    if constexpr (sizeof(T) == 4) { unsigned b32; std::memcpy(&b32, &x, 4); bad = b32 == 0xFFFFFFFFu; }
+    // clang's pattern: all-ones for floating point (a NaN), 0xAA bytes for integers
+    bool bad;
+    if constexpr (std::is_integral<T>::value) { unsigned b32; std::memcpy(&b32, &x, 4); bad = b32 == 0xAAAAAAAAu; }
+    else if constexpr (sizeof(T) == 4) { unsigned b32; std::memcpy(&b32, &x, 4); bad = b32 == 0xFFFFFFFFu; }
+    else { unsigned long long bits; std::memcpy(&bits, &x, 8); bad = bits == 0xFFFFFFFFFFFFFFFFull; }
     if (bad && g_undef_reports.fetch_add(1) < 40)
     {
         void * bt[6];
