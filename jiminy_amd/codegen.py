@@ -183,6 +183,7 @@ def topology_header(model: CompiledModel) -> str:
         f"    static constexpr int NEFF = {len(eff)};",
         _arr("parent", parents),
         _arr("jtype", model.jtypes),
+        _arr("axis_signed", model.signed_axes()),   # +-(i + 1): the joint axis is exactly +-e_i; 0: general
         _arr("idx_q", model.idx_q),
         _arr("idx_v", model.idx_v),
         _arr("nchildren", nchildren),

@@ -14,6 +14,9 @@
 #define JM_DEV inline
 #define JM_REFRESH() ((void)0)
 #define JM_OPAQUE(x) ((void)0)
+#define JM_OPAQUE_S(x) ((void)0)
+#define JM_K(c, kz) (c)
+#define JM_KZ(dep) 0
 #else
 #include <hip/hip_runtime.h>
 #define JM_DEV __device__ __forceinline__
@@ -23,6 +26,15 @@
 // Opaque re-definition of a per-lane integer: address arithmetic that depends on it cannot be
 // hoisted out of the evaluation loop (LICM otherwise pins one 64-bit VGPR address per store).
 #define JM_OPAQUE(x) asm volatile("" : "+v"(x))
+// the same for a wave-uniform value (scalar register): re-defining the parameter-block pointer inside the evaluation
+// loop keeps its scalar loads inside the loop -- hoisted, they overflow the SGPR file and come back as v_readlane
+#define JM_OPAQUE_S(x) asm volatile("" : "+s"(x))
+// Literal constant `c` made data-dependent on the (loop-variant) value `dep`: the constant is materialised
+// into a scalar register pair next to its use (2 SALU moves) instead of being hoisted out of the evaluation
+// loop into a VGPR pair by LICM -- where the polynomial coefficients of sincos / tanh ended up in scratch as
+// soon as the kernel is built for two waves per SIMD (256 VGPRs).
+#define JM_KZ(dep) jm::kzero_(dep)
+#define JM_K(c, kz) __hiloint2double((int)(__builtin_bit_cast(unsigned long long, (double)(c)) >> 32) | (kz), (int)__builtin_bit_cast(unsigned long long, (double)(c)) | (kz))
 #ifndef JM_NO_REFRESH
 #define JM_REFRESH() asm volatile("" ::: "memory")
 #else
@@ -32,6 +44,10 @@
 
 namespace jm
 {
+#ifndef JM_HOST_EMU
+// a uniform zero the compiler cannot see through, defined after `dep` is (see JM_K)
+__device__ __forceinline__ int kzero_(double dep) { int z; asm("s_mov_b32 %0, 0" : "=s"(z) : "v"(dep)); return z; }
+#endif
 template<class T> struct V3
 {
     T x, y, z;
@@ -289,6 +305,18 @@ template<class T> JM_DEV M3<T> quat_to_matrix(T x, T y, T z, T w)
 // accelerations after an integrate step, GPU only).  Cody-Waite reduction by pi/2 in three FMA
 // steps + the fdlibm kernel polynomials (< 2 ulp for |x| < 1e5; larger arguments give NaN).
 JM_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// a * b + k with the constant k (JM_K) read straight from its scalar register pair (VOP3 form; the compiler's own
+// choice is `v_fmac` with the addend copied into a VGPR pair first: two more VALU moves per coefficient)
+#ifdef JM_HOST_EMU
+JM_DEV double fmak_(double a, double b, double k) { return __builtin_fma(a, b, k); }
+#else
+JM_DEV double fmak_(double a, double b, double k)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+#endif
 JM_DEV void sincos_(double x, double * s, double * c)
 {
     // Branch-free: |x| >= 1e5 is never a valid joint angle or dt * omega; it yields NaN, which
@@ -300,11 +328,20 @@ JM_DEV void sincos_(double x, double * s, double * c)
     r = fma_(-fn, 6.123233995736766e-17, r);
     r = fma_(-fn, -1.4973849048591698e-33, r);
     const double z = r * r;
-    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
-                      + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    const double sk = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
-    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
-                      + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const int kz = JM_KZ(z);
+    (void)kz;
+    // Horner chains with the addends in scalar registers (JM_K): `v_fma_f64 d, z, p, s[c]`
+    double ps = fmak_(z, JM_K(1.58969099521155010221e-10, kz), JM_K(-2.50507602534068634195e-08, kz));
+    ps = fmak_(z, ps, JM_K(2.75573137070700676789e-06, kz));
+    ps = fmak_(z, ps, JM_K(-1.98412698298579493134e-04, kz));
+    ps = fmak_(z, ps, JM_K(8.33333333332248946124e-03, kz));
+    const double sk = fma_(z * r, fmak_(z, ps, JM_K(-1.66666666666666324348e-01, kz)), r);
+    double pc = fmak_(z, JM_K(-1.13596475577881948265e-11, kz), JM_K(2.08757232129817482790e-09, kz));
+    pc = fmak_(z, pc, JM_K(-2.75573143513906633035e-07, kz));
+    pc = fmak_(z, pc, JM_K(2.48015872894767294178e-05, kz));
+    pc = fmak_(z, pc, JM_K(-1.38888888888741095749e-03, kz));
+    pc = fmak_(z, pc, JM_K(4.16666666666666019037e-02, kz));
+    pc = z * pc;
     const double ck = 1.0 - (0.5 * z - z * pc);
     const int n = (int)fn & 3;
     const double s0 = (n & 1) ? ck : sk, c0 = (n & 1) ? sk : ck;
@@ -349,7 +386,34 @@ JM_DEV double rsqrt_(double x)
 JM_DEV float rsqrt_(float x) { return 1.0f / ::sqrtf(x); }
 JM_DEV double trunc_(double x) { return ::trunc(x); }
 JM_DEV float trunc_(float x) { return ::truncf(x); }
-JM_DEV double tanh_(double x) { return ::tanh(x); }
+// tanh(x) = e / (e + 2), e = expm1(2 |x|) = 2^n (expm1(r) + 1) - 1 with 2|x| = n ln2 + r, |r| <= ln2 / 2 (degree-13
+// Taylor polynomial of expm1, truncation 4e-18 relative); |x| >= 20 saturates.  <= 2 ulp; replaces ocml's
+// extended-precision tanh (3x the instructions, a dozen coefficients hoisted into VGPRs by LICM).
+JM_DEV double tanh_(double x)
+{
+    const double ax = __builtin_fabs(x);
+    const double y = __builtin_fmin(ax + ax, 40.0);
+    const double fn = __builtin_rint(y * 1.4426950408889634074);
+    double r = fma_(-fn, 6.93147180369123816490e-01, y);
+    r = fma_(-fn, 1.90821492927058770002e-10, r);
+    const int kz = JM_KZ(r);
+    double p = fmak_(r, JM_K(1.0 / 6227020800.0, kz), JM_K(1.0 / 479001600.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 39916800.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 3628800.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 362880.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 40320.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 5040.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 720.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 120.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 24.0, kz));
+    p = fmak_(r, p, JM_K(1.0 / 6.0, kz));
+    p = fma_(r, p, 0.5);
+    p = fma_(r * r, p, r);                        // expm1(r)
+    const double s = __builtin_ldexp(1.0, (int)fn);   // 2^n, n in 0..58
+    const double e = fma_(s, p, s - 1.0);        // expm1(y)
+    const double t = e * rcp_(e + 2.0);
+    return __builtin_copysign(x != x ? x : t, x);
+}
 JM_DEV float tanh_(float x) { return ::tanhf(x); }
 JM_DEV double atan2_(double y, double x) { return ::atan2(y, x); }
 JM_DEV float atan2_(float y, float x) { return ::atan2f(y, x); }

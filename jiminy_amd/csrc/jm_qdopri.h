@@ -69,7 +69,7 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
     });
     cmdb[0] = T(0);
     static_for<1, NT>([&](auto tc) { cmdb[decltype(tc)::value] = A.command[(unsigned)Tp::trunk_motor[decltype(tc)::value] * B32 + r32]; });
-    if constexpr (R::LONG)
+    if constexpr (R::CMD_LDS)
     {
         static_for<0, N>([&](auto sc) { S.putl(R::CMDL + decltype(sc)::value, cmdl[decltype(sc)::value]); });
         static_for<0, NT>([&](auto tc) { S.putb(R::CMDB + decltype(tc)::value, cmdb[decltype(tc)::value]); });

@@ -80,6 +80,44 @@ template<class Tp> struct QInfo
     static constexpr int vrow(int i) { return i < 6 ? Tp::idx_v[1] + i : Tp::idx_v[Tp::trunk_joint[i - 5]]; }
 };
 
+// Joint s of the four limbs turns about the same coordinate axis of its own frame, up to the sign (Topo::axis_signed:
+// ANYmal's joints all turn about +x or -x; dummy padding joints turn about +x): the joint rotation is then a
+// two-column update instead of a Rodrigues matrix + 3x3 product, and the axis in root coordinates is a (signed)
+// column of the joint's rotation.  -1: mixed or general axes, general form.
+template<class Tp> constexpr int limb_axis_uniform(int s)
+{
+    int ax = -2;
+    for (int k = 0; k < 4; ++k)
+    {
+        const int c = s < Tp::limb_len[k] ? Tp::axis_signed[Tp::limb_joint[k][s]] : 1;
+        if (c == 0) return -1;
+        const int a = (c < 0 ? -c : c) - 1;
+        if (ax == -2) ax = a;
+        else if (ax != a) return -1;
+    }
+    return ax;
+}
+// some limb has the NEGATIVE coordinate axis at joint s: the sign is read from the limb table (its axis entry is +-1)
+template<class Tp> constexpr bool limb_axis_negative(int s)
+{
+    for (int k = 0; k < 4; ++k)
+        if (s < Tp::limb_len[k] && Tp::axis_signed[Tp::limb_joint[k][s]] < 0) return true;
+    return false;
+}
+template<class T> JM_DEV V3<T> mcol(const M3<T> & R, int ax)
+{
+    return ax == 0 ? V3<T>{R.m00, R.m10, R.m20} : (ax == 1 ? V3<T>{R.m01, R.m11, R.m21} : V3<T>{R.m02, R.m12, R.m22});
+}
+// R * rot(axis ax, c, s): the two other columns rotate into each other
+template<class T> JM_DEV M3<T> mul_rot_axis(const M3<T> & R, int ax, T c, T s)
+{
+    if (ax == 0) return {R.m00, c * R.m01 + s * R.m02, c * R.m02 - s * R.m01, R.m10, c * R.m11 + s * R.m12, c * R.m12 - s * R.m11,
+                         R.m20, c * R.m21 + s * R.m22, c * R.m22 - s * R.m21};
+    if (ax == 1) return {c * R.m00 - s * R.m02, R.m01, c * R.m02 + s * R.m00, c * R.m10 - s * R.m12, R.m11, c * R.m12 + s * R.m10,
+                         c * R.m20 - s * R.m22, R.m21, c * R.m22 + s * R.m20};
+    return {c * R.m00 + s * R.m01, c * R.m01 - s * R.m00, R.m02, c * R.m10 + s * R.m11, c * R.m11 - s * R.m10, R.m12,
+            c * R.m20 + s * R.m21, c * R.m21 - s * R.m20, R.m22};
+}
 // limb table accessor: element `off` of limb k
 template<class T> struct LimbTable
 {
@@ -90,6 +128,17 @@ template<class T> struct LimbTable
     JM_DEV SE3<T> se3(int o) const { return {m3(o), v3(o + 9)}; }
     JM_DEV RBI<T> rbi(int o) const { return {base[o], v3(o + 1), S3<T>{base[o + 4], base[o + 5], base[o + 6], base[o + 7], base[o + 8], base[o + 9]}}; }
 };
+// joint axis of limb joint s in root coordinates, from the joint's rotation Rs (root coordinates)
+template<class T, class Tp, int s> JM_DEV V3<T> limb_axis_root(const LimbTable<T> & LT, const M3<T> & Rs_)
+{
+    constexpr int ax = limb_axis_uniform<Tp>(s);
+    if constexpr (ax >= 0)
+    {
+        if constexpr (limb_axis_negative<Tp>(s)) return LT(s * QLayout<Tp>::QJ + QLayout<Tp>::J_AXIS + ax) * mcol(Rs_, ax);
+        else return mcol(Rs_, ax);
+    }
+    else return Rs_ * LT.v3(s * QLayout<Tp>::QJ + QLayout<Tp>::J_AXIS);
+}
 
 template<class T, class X> JM_DEV Sp<T> quad_sum6(Sp<T> a)
 {
@@ -155,8 +204,11 @@ template<class Tp> struct QRows
 #else
     static constexpr bool LONG = N > 4;
 #endif
-    static constexpr int CMDL = 5 * N, NL = LONG ? 6 * N : 5 * N;
-    static constexpr int CMDB = KVB + NVB, NB = LONG ? CMDB + Tp::QT : CMDB;
+    // The held commands always live in the stage buffer: in registers they are three to seven loop-invariant
+    // pairs per lane that the two-waves-per-SIMD build (256 VGPRs) spills to scratch.
+    static constexpr bool CMD_LDS = true;
+    static constexpr int CMDL = 5 * N, NL = CMD_LDS ? 6 * N : 5 * N;
+    static constexpr int CMDB = KVB + NVB, NB = CMD_LDS ? CMDB + Tp::QT : CMDB;
 };
 
 // All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
@@ -474,19 +526,105 @@ JM_DEV void limb_fk(const LimbTable<T> & LT, const QIdx<Tp> & ix, const SE3<T> &
         constexpr int o = s * Q::QJ;
         T c, sn;
         sincos_(ql[s], &sn, &c);
-        const V3<T> n = LT.v3(o + Q::J_AXIS);
         SE3<T> plc = LT.se3(o + Q::J_PLC);
         if constexpr (!std::is_same<MA, NoModelLane>::value)
             plc.p = ma.plc_p(sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]), plc.p);
-        const V3<T> a = Rp * LT.v3(o + Q::J_AXP);  // joint axis in root coordinates
         ps[s] = pp + Rp * plc.p;
-        Rs[s] = Rp * (plc.R * rot_rodrigues(n, c, sn));
+        V3<T> a;   // joint axis in root coordinates
+        constexpr int ax = limb_axis_uniform<Tp>(s);
+        if constexpr (ax >= 0)
+        {
+            if constexpr (limb_axis_negative<Tp>(s))
+            {
+                const T sg = LT(o + Q::J_AXIS + ax);   // +-1: rotation by q about -e = rotation by -q about e
+                Rs[s] = mul_rot_axis(Rp * plc.R, ax, c, sg * sn);
+                a = sg * mcol(Rs[s], ax);
+            }
+            else
+            {
+                Rs[s] = mul_rot_axis(Rp * plc.R, ax, c, sn);
+                a = mcol(Rs[s], ax);
+            }
+        }
+        else
+        {
+            a = Rp * LT.v3(o + Q::J_AXP);
+            Rs[s] = Rp * (plc.R * rot_rodrigues(LT.v3(o + Q::J_AXIS), c, sn));
+        }
         vp = {vp.l + vl[s] * cross(ps[s], a), vp.a + vl[s] * a};
         if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
         Rp = Rs[s]; pp = ps[s];
     });
     vtip = vp;
     (void)ix;
+}
+
+// Long limbs (register-bound kernels): the forward kinematics keep only cos / sin of every joint angle and the tip
+// placement; the backward ABA sweep UNWINDS the placements joint by joint on its way to the trunk
+// (R_{s-1} = R_s rot(-q_s) plc_s.R^T, p_{s-1} = p_s - R_{s-1} plc_s.p: 48 more operations per joint) instead of 12
+// live scalars per joint across the contact and motor code -- 84 doubles per lane for Atlas' arms, which the
+// compiler otherwise shuffles through AGPRs and scratch all along the sweep (profiles/r02_atlas_v1_*).
+template<class T, class Tp, class MA = NoModelLane>
+JM_DEV void limb_fk_tip(const LimbTable<T> & LT, const SE3<T> & Xp, Sp<T> vp, const T * ql, const T * vl,
+                        T * cq, T * sq, M3<T> & Rtip, V3<T> & ptip, Sp<T> & vtip, int & status, const MA & ma = MA{}, int k = 0)
+{
+    using Q = QLayout<Tp>;
+    M3<T> Rp = Xp.R;
+    V3<T> pp = Xp.p;
+    static_for<0, Tp::QN>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int o = s * Q::QJ;
+        T c, sn;
+        sincos_(ql[s], &sn, &c);
+        SE3<T> plc = LT.se3(o + Q::J_PLC);
+        if constexpr (!std::is_same<MA, NoModelLane>::value)
+            plc.p = ma.plc_p(sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]), plc.p);
+        const V3<T> pj = pp + Rp * plc.p;
+        V3<T> a;
+        M3<T> Rj;
+        constexpr int ax = limb_axis_uniform<Tp>(s);
+        if constexpr (ax >= 0)
+        {
+            if constexpr (limb_axis_negative<Tp>(s))
+            {
+                const T sg = LT(o + Q::J_AXIS + ax);
+                sn = sg * sn;   // rotation by q about -e = rotation by -q about e: the signed sine is what is kept
+                Rj = mul_rot_axis(Rp * plc.R, ax, c, sn);
+                a = sg * mcol(Rj, ax);
+            }
+            else
+            {
+                Rj = mul_rot_axis(Rp * plc.R, ax, c, sn);
+                a = mcol(Rj, ax);
+            }
+        }
+        else
+        {
+            a = Rp * LT.v3(o + Q::J_AXP);
+            Rj = Rp * (plc.R * rot_rodrigues(LT.v3(o + Q::J_AXIS), c, sn));
+        }
+        cq[s] = c; sq[s] = sn;
+        vp = {vp.l + vl[s] * cross(pj, a), vp.a + vl[s] * a};
+        if (LT(o + Q::J_QHI) < ql[s] || ql[s] < LT(o + Q::J_QLO)) status |= JM_LANE_OUT_OF_BOUNDS;
+        Rp = Rj; pp = pj;
+    });
+    Rtip = Rp; ptip = pp; vtip = vp;
+}
+// placement of the parent of limb joint s from the placement (R, p) of joint s itself (see limb_fk_tip)
+template<class T, class Tp, int s, class MA = NoModelLane>
+JM_DEV void limb_unwind(const LimbTable<T> & LT, T c, T sn, M3<T> & R, V3<T> & p, const MA & ma = MA{}, int k = 0)
+{
+    using Q = QLayout<Tp>;
+    constexpr int o = s * Q::QJ;
+    SE3<T> plc = LT.se3(o + Q::J_PLC);
+    if constexpr (!std::is_same<MA, NoModelLane>::value)
+        plc.p = ma.plc_p(sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]), plc.p);
+    constexpr int ax = limb_axis_uniform<Tp>(s);
+    M3<T> Rq;   // parent rotation times the joint placement
+    if constexpr (ax >= 0) Rq = mul_rot_axis(R, ax, c, -sn);
+    else Rq = R * rot_rodrigues(LT.v3(o + Q::J_AXIS), c, -sn);
+    R = mul_bt(Rq, plc.R);
+    p = p - R * plc.p;
 }
 
 // impulse / profile forces on frames of the root joint (BatchArgs::applied) as one wrench on joint 1, joint frame
@@ -546,7 +684,11 @@ template<class T, class Tp> struct QKeep
 // derive from this evaluation (RobotState::u / uMotor / fExternal, contact forces, energies and,
 // if `sensors`, the sensor rows) are written right where their inputs are live, so that nothing
 // has to stay in registers for a separate output phase.
-template<class T, class Tp, class X, bool EMIT, class SB, int CFM = 0, class KEEP = NoKeep, bool GEN = false>
+// DYN = false (with EMIT): the OUTPUT PASS of the step kernels -- kinematics, contact forces, motors and sensors at
+// a state whose accelerations `ddqb` / `ddq` are already known (inputs then), without the three ABA sweeps: the
+// dynamics evaluations themselves carry no output code at all, so that their register footprint is the same
+// everywhere (two waves per SIMD), and the outputs cost about a third of an evaluation once per launch.
+template<class T, class Tp, class X, bool EMIT, class SB, int CFM = 0, class KEEP = NoKeep, bool GEN = false, bool DYN = true>
 JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, unsigned r, int k, const QIdx<Tp> & ix,
                       const SB & S_, const T * qb, const T * vb_, const T * ql, const T * vl_, const T * cmdb_, const T * cmdl_,
                       bool sensors, T * ddqb, T * ddq, int & status, const QExtra<T, Tp> * ex = nullptr, KEEP * keep = nullptr,
@@ -556,8 +698,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     using RW = QRows<Tp>;
     auto vlq = [&](int s) -> T { if constexpr (RW::LONG) return S_.getl(RW::KVL + s); else return vl_[s]; };
     auto vbq = [&](int i) -> T { if constexpr (RW::LONG) return S_.getb(RW::KVB + i); else return vb_[i]; };
-    auto cmdlq = [&](int s) -> T { if constexpr (RW::LONG) return S_.getl(RW::CMDL + s); else return cmdl_[s]; };
-    auto cmdbq = [&](int t) -> T { if constexpr (RW::LONG) return S_.getb(RW::CMDB + t); else return cmdb_[t]; };
+    auto cmdlq = [&](int s) -> T { if constexpr (RW::CMD_LDS) return S_.getl(RW::CMDL + s); else return cmdl_[s]; };
+    auto cmdbq = [&](int t) -> T { if constexpr (RW::CMD_LDS) return S_.getb(RW::CMDB + t); else return cmdb_[t]; };
     // compile-time: the three non-emitting evaluations of an RK4 step carry no output code at all,
     // which keeps their basic blocks large (LDS reads of the limb table get batched ahead of use)
     constexpr bool emit = EMIT;
@@ -607,6 +749,9 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     const V3<T> p1 = {qb[0], qb[1], qb[2]};
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     const Sp<T> v1 = {{vb_[0], vb_[1], vb_[2]}, {vb_[3], vb_[4], vb_[5]}};
+    // gravity field in root coordinates (bias v x v = 0 for the free-flyer), taken here so that the root placement
+    // is not live across the sweeps (the contact code below is its last reader in the evaluations without outputs)
+    const Sp<T> agf1 = actinv_motion(SE3<T>{R1, p1}, Sp<T>{-g, -gw});
     // every lane keeps only "its" trunk joints (see TrunkStore: first write of a slot is unconditional)
     TrunkStore<T, Tp> TS;
 #ifdef JM_HOST_EMU
@@ -624,17 +769,26 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     };
     (void)limb_joint_of;
     trunk_fk_store<T, Tp, X, MA>(P, k, ix, qb, vb_, TS, Xatt, vatt, status, ma);
-    // ---- limb kinematics
-    M3<T> Rs[N];
+    // ---- limb kinematics (long limbs: cos / sin per joint + the tip placement only, see limb_fk_tip)
+    constexpr bool UNWIND = QRows<Tp>::LONG;
+    M3<T> Rs[UNWIND ? 1 : N];
     V3<T> ps[N];
+    T cq[UNWIND ? N : 1], sq[UNWIND ? N : 1];
+    M3<T> Rtip;
+    V3<T> ptip;
     Sp<T> vtip;
-    limb_fk<T, Tp, MA>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status, ma, k);
+    if constexpr (UNWIND) limb_fk_tip<T, Tp, MA>(LT, Xatt, vatt, ql, vl_, cq, sq, Rtip, ptip, vtip, status, ma, k);
+    else
+    {
+        limb_fk<T, Tp, MA>(LT, ix, Xatt, vatt, ql, vl_, Rs, ps, vtip, status, ma, k);
+        Rtip = Rs[N - 1]; ptip = ps[N - 1];
+    }
     if constexpr (CFM != 0) status &= ~JM_LANE_OUT_OF_BOUNDS;  // bounds are constraints there, not failures
     // ---- contact points on the limb tip (engine.cc:3117-3238, 3394-3425)
     Sp<T> fext = zero6<T>();   // total external force on the tip body, root coordinates
     {
-        const M3<T> Rt = Rs[N - 1];
-        const V3<T> pt = ps[N - 1];
+        const M3<T> Rt = Rtip;
+        const V3<T> pt = ptip;
         const Sp<T> vt = vtip;
         Sp<T> fext_loc = zero6<T>(), fsens = zero6<T>();
         T fmax2 = T(0);
@@ -750,18 +904,20 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 }
         }
     }
-    // ---- motors (one per movable joint, uniform flags; basic_motors.cc:83-143)
+    // ---- motors (one per movable joint, uniform flags; basic_motors.cc:83-143).  Long limbs without output code
+    // evaluate each motor where the backward sweep consumes its effort instead of keeping N + NT efforts live across
+    // the contact code (MOTORS_IN_SWEEP).
+    constexpr bool MOTORS_IN_SWEEP = QRows<Tp>::LONG && !EMIT && DYN;
     T u[N], ut[NT];
-    static_for<0, N>([&](auto sc) {
+    auto limb_motor = [&](auto sc) -> T {
         constexpr int s = decltype(sc)::value;
         constexpr int o = s * Q::QJ + Q::J_MOTOR;
         T um, ue;
         motor_law<T, FL>([&](int i) { return LT(o + i); }, cmdlq(s), vlq(s), um, ue);
-        u[s] = ue;
-        T ue_out = ue;
+        T ueff = ue, ue_out = ue;
         if constexpr (CFM != 0)
         {
-            u[s] = (ex->motors_on ? ue : T(0)) + ex->tau_l[s];
+            ueff = (ex->motors_on ? ue : T(0)) + ex->tau_l[s];
             ue_out = ue + ex->uemit_l[s];
         }
         if (emit && ix.has[s])
@@ -775,19 +931,18 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     A.effort[(unsigned)si * B32 + r32] = um;
                 }
         }
-    });
-    ut[0] = T(0);
-    static_for<1, NT>([&](auto tc) {
+        return ueff;
+    };
+    auto trunk_motor = [&](auto tc) -> T {
         constexpr int t = decltype(tc)::value;
         constexpr int m = Tp::trunk_motor[t];
         constexpr int o = L::MOTOR + JM_MOTOR_NPARAMS * m;
         T um, ue;
         motor_law<T, FL>([&](int i) { return P[o + i]; }, cmdbq(t), vbq(5 + t), um, ue);
-        ut[t] = ue;
-        T ue_out = ue;
+        T ueff = ue, ue_out = ue;
         if constexpr (CFM != 0)
         {
-            ut[t] = (ex->motors_on ? ue : T(0)) + ex->tau_b[t];
+            ueff = (ex->motors_on ? ue : T(0)) + ex->tau_b[t];
             ue_out = ue + ex->uemit_b[t];
         }
         if (emit && lead)
@@ -797,7 +952,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             if constexpr (Tp::QHAS_EFF)
                 if (sensors && A.effort) A.effort[(unsigned)Tp::trunk_eff[t] * B32 + r32] = um;
         }
-    });
+        return ueff;
+    };
+    if constexpr (!MOTORS_IN_SWEEP)
+    {
+        static_for<0, N>([&](auto sc) { u[decltype(sc)::value] = limb_motor(sc); });
+        ut[0] = T(0);
+        static_for<1, NT>([&](auto tc) { ut[decltype(tc)::value] = trunk_motor(tc); });
+    }
     if (emit && A.u && lead)
     {
 #pragma unroll
@@ -819,12 +981,32 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     V3<T> mc = zero3<T>();
     {
         Sp<T> vcur = vtip;
+        M3<T> Rcur = Rtip;   // long limbs: placement of the joint being processed, unwound towards the trunk
+        V3<T> pcur = ptip;
         static_rfor<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int o = s * Q::QJ;
-            const RBI<T> Y = rbi_placed(Rs[s], ps[s], ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
-            const V3<T> a = Rs[s] * LT.v3(o + Q::J_AXIS);
-            const Sp<T> S = {cross(ps[s], a), a};
+            if constexpr (!UNWIND) { Rcur = Rs[s]; pcur = ps[s]; }
+            else ps[s] = pcur;
+            if constexpr (!DYN)
+            {
+                // output pass: only the energy sums need the bodies (velocities unwound from the tip like below)
+                if (want_energy)
+                {
+                    const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
+                    const V3<T> a = limb_axis_root<T, Tp, s>(LT, Rcur);
+                    kin += rbi_vtiv(Y, vcur);
+                    mc = mc + Y.m * Y.c;
+                    msum += Y.m;
+                    rot += LT(o + Q::J_ROTOR) * vlq(s) * vlq(s);
+                    vcur = vcur - vlq(s) * Sp<T>{cross(pcur, a), a};
+                    if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
+                }
+                return;
+            }
+            const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
+            const V3<T> a = limb_axis_root<T, Tp, s>(LT, Rcur);
+            const Sp<T> S = {cross(pcur, a), a};
             Sp<T> f = cross_mf(vcur, rbi_mul(Y, vcur));  // bias force v x* (I v)
             if constexpr (s == N - 1) { f = f - fext; Ia = ai_from_rbi(Y); }
             else { f = f + pa; Ia = ai_from_rbi(Y) + Ia; }
@@ -838,6 +1020,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             const Sp<T> vj = vlq(s) * S;
             vcur = vcur - vj;                              // velocity of the parent joint
             const Sp<T> c = cross_mm(vcur, vj);            // bias acceleration v x S qd (S x S = 0)
+            if constexpr (MOTORS_IN_SWEEP) u[s] = limb_motor(sc);
             const T uj = u[s] - dot6(S, f);
             const Sp<T> U = ai_mul(Ia, S);
             const T D = dot6(S, U) + LT(o + Q::J_ROTOR);
@@ -849,7 +1032,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             Us[s] = U; dinv[s] = di; u[s] = uj;
             if constexpr (KEEP_SC) { Ss[s] = S; cs[s] = c; }
             else as[s] = a;
-            if constexpr (KEEP::ON) { keep->ps[s] = ps[s]; keep->as[s] = a; keep->Us[s] = U; keep->dinv[s] = di; }
+            if constexpr (KEEP::ON) { keep->ps[s] = pcur; keep->as[s] = a; keep->Us[s] = U; keep->dinv[s] = di; }
+            if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
         });
     }
     // ---- child -> parent reduction over the 4 limbs (the only cross-lane step of the dynamics)
@@ -858,6 +1042,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
 #ifdef JM_HOST_EMU
     std::memset(accA, 0xFF, sizeof(accA)); std::memset(accF, 0xFF, sizeof(accF));
 #endif
+    if constexpr (DYN)
     static_for<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         if constexpr (I::limb_at(t))
@@ -883,6 +1068,19 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
         SE3<T> Xt;
         Sp<T> vt;
+        if constexpr (!DYN)
+        {
+            if (want_energy)
+            {
+                TS.template get_kin<t, X>(Xt, vt);
+                const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12)));
+                kin += rbi_vtiv(Y, vt);
+                mc = mc + Y.m * Y.c;
+                msum += Y.m;
+                rot += P[L::ROTOR + Tp::idx_v[j]] * vbq(5 + t) * vbq(5 + t);
+            }
+            return;
+        }
         TS.template get_kin<t, X>(Xt, vt);
         const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12)));
         const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
@@ -891,6 +1089,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         if constexpr (I::has_child(t)) { f = f + accF[t]; It = It + accA[t]; }
         const Sp<T> vj = vbq(5 + t) * S;
         const Sp<T> c = cross_mm(vt - vj, vj);   // parent velocity x S qd
+        if constexpr (MOTORS_IN_SWEEP) ut[t] = trunk_motor(tc);
         const T uj = ut[t] - dot6(S, f);
         const Sp<T> U = ai_mul(It, S);
         const T rotor = P[L::ROTOR + Tp::idx_v[j]];
@@ -913,10 +1112,12 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     });
     // ---- root: u -= S^T f ; (Ia + Im) ddq = u - Ia a_gf (free-flyer calc_aba + pass 3)
     const RBI<T> Y1 = ma.rbi(1, ld_rbi<T>(P, L::JOINT + 1 * L::JSTRIDE + 12));
-    const Sp<T> agf1 = actinv_motion(SE3<T>{R1, p1}, Sp<T>{-g, -gw});  // bias v x v = 0 for the free-flyer
+    // root velocity: long limbs re-read it from the stage buffer (6 scalars less across the sweeps)
+    const Sp<T> v1r = {{vbq(0), vbq(1), vbq(2)}, {vbq(3), vbq(4), vbq(5)}};
+    if constexpr (DYN)
     {
         AI<T> I1 = ai_from_rbi(Y1);
-        Sp<T> f1 = cross_mf(v1, rbi_mul(Y1, v1));
+        Sp<T> f1 = cross_mf(v1r, rbi_mul(Y1, v1r));
         if constexpr (I::has_child(0)) { I1 = I1 + accA[0]; f1 = f1 + accF[0]; }
         if constexpr (GEN)
             if (A.applied_k > 0) f1 = f1 - applied_root_wrench(A, R1, B32, r32);   // impulse / profile forces on the root body
@@ -942,13 +1143,13 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 for (int c = 0; c <= i; ++c) keep->rootL[i][c] = M[i][c];
                 keep->rootdinv[i] = rcp_(M[i][i]);
             }
-            keep->Rt = Rs[N - 1]; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1; keep->agf1 = agf1;
+            keep->Rt = Rtip; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1; keep->agf1 = agf1;
         }
     }
     if (want_energy)
     {
         // Engine::computeExtraTerms energies (engine.cc:806-815, overload .h:54-55)
-        kin += rbi_vtiv(Y1, v1);
+        kin += rbi_vtiv(Y1, v1r);
         mc = mc + Y1.m * Y1.c;
         msum += Y1.m;
 #pragma unroll
@@ -986,14 +1187,15 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     }
                 });
     };
-    imu_at(std::integral_constant<int, 0>{}, SE3<T>{ident3<T>(), zero3<T>()}, v1, at0);
+    imu_at(std::integral_constant<int, 0>{}, SE3<T>{ident3<T>(), zero3<T>()}, v1r, at0);
     Sp<T> ap = at0;   // acceleration / velocity of the trunk joint this lane's limb hangs from
-    Sp<T> vp = v1;
+    Sp<T> vp = v1r;
     {
         // accelerations of trunk joints with a non-adjacent, non-root parent are re-fetched from
         // the store; chains (the common case) carry them in `aprev`
         Sp<T> atst[TrunkStore<T, Tp>::SLOTS];
         Sp<T> aprev = at0;
+        if constexpr (DYN || Tp::NIMU > 0)
         static_for<1, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int tp = Tp::trunk_parent[t];
@@ -1001,7 +1203,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             Sp<T> vt, Ut;
             T di, uj;
             TS.template get_kin<t, X>(Xt, vt);
-            TS.template get_aba<t, X>(Ut, di, uj);
+            if constexpr (DYN) TS.template get_aba<t, X>(Ut, di, uj);
             const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
             const Sp<T> vj = vbq(5 + t) * S;
             Sp<T> apar;
@@ -1009,8 +1211,9 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             else if constexpr (tp == t - 1) apar = aprev;
             else apar = qbcast<T, X, TrunkStore<T, Tp>::template lane<tp>()>(atst[TrunkStore<T, Tp>::template slot<tp>()]);
             const Sp<T> ag = apar + cross_mm(vt - vj, vj);
-            const T dd = di * (uj - dot6(Ut, ag));
-            ddqb[5 + t] = dd;
+            T dd;
+            if constexpr (DYN) { dd = di * (uj - dot6(Ut, ag)); ddqb[5 + t] = dd; }
+            else dd = ddqb[5 + t];
             const Sp<T> att = ag + dd * S;
             if (TrunkStore<T, Tp>::template first_fwd<t>() || k == TrunkStore<T, Tp>::template lane<t>())
                 atst[TrunkStore<T, Tp>::template slot<t>()] = att;
@@ -1020,6 +1223,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             imu_at(tc, Xt, vt, att);
         });
     }
+    if constexpr (DYN)
     static_for<0, N>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (KEEP_SC)
@@ -1045,6 +1249,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         keep->atip = ap;
         if (ts_out) *ts_out = TS;
     }
+    if constexpr (DYN)
     {
         bool bad = false;
         static_for<0, I::NVB>([&](auto ic) { bad |= (ddqb[decltype(ic)::value] != ddqb[decltype(ic)::value]); });
@@ -1303,7 +1508,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     });
     cmdb[0] = T(0);
     static_for<1, NT>([&](auto tc) { cmdb[decltype(tc)::value] = A.command[(unsigned)Tp::trunk_motor[decltype(tc)::value] * B32 + r32]; });
-    if constexpr (R::LONG)
+    if constexpr (R::CMD_LDS)
     {
         static_for<0, N>([&](auto sc) { S.putl(R::CMDL + decltype(sc)::value, cmdl[decltype(sc)::value]); });
         static_for<0, NT>([&](auto tc) { S.putb(R::CMDB + decltype(tc)::value, cmdb[decltype(tc)::value]); });
@@ -1383,8 +1588,12 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             // explicit Euler = a single "final" stage with b = 1.  (kv, ka) = derivative of the
             // previous stage; the increments are summed in the tangent space and applied once
             // from the step-start configuration (abstract_runge_kutta_stepper.cc:51-56).
-            const T bw = rk4 ? ((st == 0 || st == 3) ? dt * T(1.0 / 6.0) : dt * T(1.0 / 3.0)) : dt;
-            const T aw = (st == 2) ? dt : dt * T(0.5);
+            // (step size through a per-iteration opaque copy: otherwise dt/6, dt/3 and dt/2 are hoisted out of the
+            // evaluation loop as three more live register pairs)
+            T dtl = dt;
+            JM_OPAQUE(dtl);
+            const T bw = dtl * (rk4 ? ((st == 0 || st == 3) ? T(1.0 / 6.0) : T(1.0 / 3.0)) : T(1));
+            const T aw = dtl * ((st == 2) ? T(1) : T(0.5));
             T incb[NVB], q0b[NQB], v0b[NVB], incl[N], v0l[N];
             static_for<0, NQB>([&](auto ic) { q0b[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
             static_for<0, NVB>([&](auto ic) {
@@ -1485,32 +1694,48 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     }
     else
     {
-    // The n-1 output-free evaluations run in the hot loop; the last one (outputs, sensors, optional
-    // extra terms) is peeled off so that its register pressure does not leak into the loop.
+    // Dynamics evaluations carry no output code.  Stepping runs all of them in ONE loop (one copy of the evaluation);
+    // the single evaluation of `start` / `reset` / `dynamics` / `refresh` is a second, separately optimised copy --
+    // the library self-test (engine._library_self_test) compares what the two produce.  The outputs of the launch
+    // (RobotState::u / uMotor / fExternal, contact forces, energies, sensors) are then written by the output pass
+    // (quad_eval<EMIT, DYN = false>) at the committed state with the accelerations of the last evaluation.
+    if (stepping)
+    {
 #pragma nounroll
-    for (int e = 0; e < n_evals - 1; ++e)
-    {
-        const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
-        JM_REFRESH();
-        // per-iteration opaque copy of the lane offset: the addresses of the commit stores must
-        // not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
-        unsigned rl = r32;
-        JM_OPAQUE(rl);
-        advance(st, false, rl);
-        quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rl, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        for (int e = 0; e < n_evals; ++e)
+        {
+            const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+            JM_REFRESH();
+            // per-iteration opaque copy of the lane offset: the addresses of the commit stores must
+            // not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
+            rr = r32;
+            JM_OPAQUE(rr);
+            CPtr<T> Pl = P;
+            JM_OPAQUE_S(Pl);
+            advance(st, e == n_evals - 1, rr);
+            quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(Pl, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        }
     }
+    else
     {
-        const int e = n_evals - 1;
-        const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
         JM_REFRESH();
         rr = r32;
         JM_OPAQUE(rr);
-        advance(st, true, rr);
-        if (A.mode != MODE_DYNAMICS)
-            quad_eval<T, Tp, X, true, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
-                                      (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
-        else
-            quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+        advance(-1, true, rr);
+        quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
+    }
+    if (A.mode != MODE_DYNAMICS)
+    {
+        JM_REFRESH();
+        rr = r32;
+        JM_OPAQUE(rr);
+        // the (committed) state is re-read from the stage buffer: kept in registers it would be live across the
+        // whole evaluation loop
+        static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
+        static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
+        static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
+        quad_eval<T, Tp, X, true, StageBuf<T, SL, SB>, 0, NoKeep, GEN, false>(P, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl,
+                                  (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status);
     }
     }
     {
@@ -1591,9 +1816,6 @@ struct DppQuad
     static __device__ __forceinline__ void table_ready() { __syncthreads(); }
 };
 
-#ifndef JM_QUAD_WAVES_PER_EU
-#define JM_QUAD_WAVES_PER_EU 1
-#endif
 // waves per block: they share one copy of the limb table. Pick the block size that keeps the most
 // waves resident per CU under the 160 KiB of LDS (a CU runs at most 2 such waves per SIMD).
 template<class T, class Tp> constexpr int quad_block_waves()
@@ -1613,12 +1835,27 @@ template<class T, class Tp> constexpr int quad_block_waves()
     }
     return best;
 }
+// Resident waves per SIMD the step kernels are compiled for.  Two (256 registers per lane) when a short-limbed
+// robot's stage buffer leaves room for eight waves per CU in the 160 KiB of LDS: the evaluation carries no output
+// code and keeps neither the held commands nor polynomial coefficients in registers, so that it fits without
+// scratch traffic, and the second wave fills the LDS / dependency stalls of the first (ANYmal, MI355X: 0.158 ->
+// 0.125 ms per launch at B = 65 536; profiles/r03_quad_*).  Long limbs (Atlas: 137 KiB of LDS per block) stay at one.
+// The per-environment variation kernels (GEN) and robots with a trunk tree spill at 256 registers: one wave.
+template<class T, class Tp, int W, bool GEN = false> constexpr int quad_waves_per_eu()
+{
+#ifdef JM_QUAD_WAVES_PER_EU
+    return JM_QUAD_WAVES_PER_EU;   // tuning override
+#endif
+    constexpr long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
+    constexpr long block = (long)sizeof(T) * QLayout<Tp>::TABLE + W * per_wave;
+    return (!GEN && !QRows<Tp>::LONG && Tp::QT == 1 && Tp::QCL <= 2 && (8 / W) * block <= 160L * 1024) ? 2 : 1;
+}
 // W = waves per block (they share one copy of the limb table).  The default, quad_block_waves(), suits large
 // batches; the library also instantiates W = 1, which it launches for SMALL batches (one GPU's share of a
 // sharded batch): four times as many blocks, so that e.g. 4096 Atlas robots = 256 waves land on 256 CUs
 // instead of 64.
 template<class T, class Tp, int W = quad_block_waves<T, Tp>()>
-__global__ void __launch_bounds__((64 * W)) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
+__global__ void __launch_bounds__((64 * W)) __attribute__((amdgpu_waves_per_eu(quad_waves_per_eu<T, Tp, W>())))
 k_quad(const BatchArgs<T> A)
 {
     using Q = QLayout<Tp>;
@@ -1639,7 +1876,7 @@ k_quad(const BatchArgs<T> A)
 // the same kernel with the optional per-environment variation compiled in (per-lane body parameters, height-map
 // ground, impulse / profile forces on the root body): launched instead of k_quad when one of them is bound
 template<class T, class Tp>
-__global__ void __launch_bounds__((64 * quad_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(JM_QUAD_WAVES_PER_EU)))
+__global__ void __launch_bounds__((64 * quad_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(quad_waves_per_eu<T, Tp, quad_block_waves<T, Tp>(), true>())))
 k_quad_gen(const BatchArgs<T> A)
 {
     using Q = QLayout<Tp>;

@@ -387,7 +387,29 @@ class CompiledModel:
                           for s in self.sensors.get("EncoderSensor", [])),
             "U", ",".join(str(s["motor_index"]) for s in self.sensors.get("EffortSensor", [])),
         ]
+        # "unaligned" 1-dof joints whose axis is the NEGATIVE of a coordinate axis (ANYmal: every other joint turns
+        # about -x): structural like RX / RY / RZ, and the branch-parallel kernel specialises on it (jm_quad.h
+        # limb_axis_uniform).  Appended only when there is such a joint, so that other topologies keep their hash.
+        sa = self.signed_axes()
+        if any(int(self.jtypes[j]) in (JT_RU, JT_PU) and sa[j] != 0 for j in range(self.njoints)):
+            parts += ["AX", ",".join(str(int(x)) for x in sa)]
         return "|".join(parts)
+
+    def signed_axes(self) -> np.ndarray:
+        """Per joint: +-(i + 1) when the axis of a 1-dof joint is exactly +-e_i, else 0."""
+        out = np.zeros(self.njoints, dtype=np.int32)
+        for j in range(1, self.njoints):
+            if JT_NV.get(int(self.jtypes[j]), 0) != 1:
+                continue
+            a = np.asarray(self.axes[j], dtype=np.float64)
+            for i in range(3):
+                e = np.zeros(3)
+                e[i] = 1.0
+                if np.array_equal(a, e):
+                    out[j] = i + 1
+                elif np.array_equal(a, -e):
+                    out[j] = -(i + 1)
+        return out
 
     def topology_hash(self) -> str:
         return hashlib.sha1(self.topology_signature().encode()).hexdigest()[:12]

@@ -47,7 +47,7 @@ def _oracle(model, arr, ml, ground, applied, copt):
     return e
 
 
-@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False)])
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True)])
 def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, constrained):
     model = load_builtin(name)
     B = 16 if name == "anymal" else 4
@@ -214,7 +214,9 @@ def test_gpu_variation_matches_oracle(gpu_device, name, constrained):
     errs = {k: rel_err(eng.field(k).cpu().numpy(), ref[k], ok) for k in OUTS}
     print("variation on the device:", {k: float("%.1e" % v) for k, v in errs.items()})
     for k in OUTS:
-        assert errs[k] < (1e-5 if constrained else 1e-8), (k, errs)
+        # (observed on the MI355X: <= 1.1e-13 with the constraint model, PGS tolerances 1e-11 -- the solves converge
+        # to the same fixed point; the bar leaves room for one more PGS sweep on either side)
+        assert errs[k] < (1e-9 if constrained else 1e-8), (k, errs)
     assert (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() > B // 8
 
 
