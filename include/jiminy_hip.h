@@ -370,6 +370,28 @@ int32_t jm_block_sensor_noise(int32_t dtype, int64_t batch_size, int32_t n_senso
 int32_t jm_sensor_rng_seed(const uint32_t * group_seed, int64_t batch_size, int32_t n_sensors,
                            uint64_t * state_out);
 
+/* ---- Model biases per environment (model part), batched, drawn on the device.
+ *
+ * jm_block_model_bias ≙ `Model::addBiasedToExtendedModel(g)` (core/src/robot/model.cc:1166-1236) for every
+ *   lane: for the mechanical joints in index order (`first_joint`..njoints-1: the free-flyer root is not one of
+ *   them, model.cc:337-341) and in the reference's field order -- centre of mass (3 normals), mass (1), inertia
+ *   (3 for the rotation vector of the principal axes, 3 for the principal moments), joint placement translation
+ *   (3), each group only when its standard deviation is > EPS -- the lane's engine generator `rng_state[lane]`
+ *   (device, uint64 `[B]`: the PCG32 stream of `Engine::generator_`) is advanced exactly as the reference advances
+ *   it, the float normals are `normal(g, mean, std)` of core/src/utilities/random.cc:52-167, and the biased body
+ *   parameters are written to the rows of `model_lane` (device, `[13 * njoints][B]`, JM_F_MODEL_LANE layout).
+ *   `nominal` (device, float64 `[njoints][25]`): mass | com 3 | inertia xx xy xz yy yz zz | placement translation 3
+ *   | principal moments 3 (ascending) | principal axes 9 (row-major, columns = axes) of the unbiased model.
+ *   `std4` (host): inertia, mass, centre of mass, relative position standard deviations.  `mask` (device, uint8
+ *   `[B]`) or NULL: only the masked lanes draw (episode-wise re-randomisation of the lanes being reset).
+ * jm_engine_rng_seed ≙ `generator_.seed(std::seed_seq(randomSeedSeq))` (core/src/engine/engine.cc:756-757,
+ *   random.hxx:20-51) with one seed word per lane: PCG32 state `(w0 | w1 << 32) | 3` of the two words
+ *   `std::seed_seq{seed[lane]}` generates.  Host arrays. */
+int32_t jm_block_model_bias(int32_t dtype, int64_t batch_size, int32_t njoints, int32_t first_joint,
+                            const double * nominal, const float * std4, uint64_t * rng_state,
+                            const uint8_t * mask, void * model_lane, void * stream);
+int32_t jm_engine_rng_seed(const uint32_t * seed, int64_t batch_size, uint64_t * state_out);
+
 /* ---- Sensor delay and jitter, batched.
  * jm_block_sensor_delay ≙ `AbstractSensorTpl<T>::interpolateData`
  *   (core/include/jiminy/core/hardware/abstract_sensor.hxx:305-429), the first half of `measureDataAll`: call it

@@ -48,6 +48,7 @@ ABI_SYMBOLS = (
     "jm_block_sensor_noise", "jm_sensor_rng_seed",
     "jm_batch_set_constraint_options", "jm_batch_constraint_rows", "jm_block_sensor_delay",
     "jm_batch_set_ground", "jm_batch_set_applied_frames", "jm_block_pd_adapter", "jm_block_motor_safety_limit",
+    "jm_block_model_bias", "jm_engine_rng_seed",
 )
 
 
@@ -90,6 +91,8 @@ class HipLibrary:
         L.jm_block_motor_safety_limit.argtypes = [C.c_int32, C.c_int64, C.c_int32, vp, ip, vp, dp, dp, dp, dp, dp, dp, vp, vp]
         L.jm_block_sensor_noise.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, dp, dp, dp, vp]
         L.jm_sensor_rng_seed.argtypes = [C.POINTER(C.c_uint32), C.c_int64, C.c_int32, C.POINTER(C.c_uint64)]
+        L.jm_block_model_bias.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, C.POINTER(C.c_float), vp, vp, vp, vp]
+        L.jm_engine_rng_seed.argtypes = [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint64)]
         L.jm_block_sensor_delay.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, ip, dp, C.c_int32, vp,
                                             dp, dp, C.c_int32, vp]
         L.jm_batch_set_constraint_options.argtypes = [vp, C.POINTER(_abi.ConstraintOptions)]

@@ -124,6 +124,9 @@ template<class T> struct BatchArgs
     const T * applied;
     int applied_k;
     T applied_p[12];
+    // `[1][B]` ground friction coefficient of every lane (spring-damper model; the constraint model reads its own
+    // copy, QConArgs / ConArgs), or null: `contacts.friction` randomised per environment (envs/locomotion.py:257-262)
+    const T * friction;
 };
 // MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
 // the lane status into the existing one: the closing launch of an adaptive-step interval
@@ -234,6 +237,7 @@ template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> v
 {
     using L = Layout<Tp>;
     const T k = P[L::OPT + 6], c = P[L::OPT + 7], mu = P[L::OPT + 8], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    // (per-lane friction goes through contact_law_n, the form of the per-environment variation kernels)
     const T vDepth = vW.z;
     const T fN = -fmin_(k * depth + c * vDepth, T(0));
     const V3<T> vT = {vW.x, vW.y, vW.z - vDepth};
@@ -249,10 +253,12 @@ template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> v
 }
 
 // the same law on a ground of unit normal n (world.groundProfile, engine.cc:3138-3142)
-template<class T, class Tp> JM_DEV V3<T> contact_law_n(CPtr<T> P, V3<T> n, T depth, V3<T> vW)
+// `mu_lane` >= 0: the lane's own friction coefficient (BatchArgs::friction) instead of the option
+template<class T, class Tp> JM_DEV V3<T> contact_law_n(CPtr<T> P, V3<T> n, T depth, V3<T> vW, T mu_lane = T(-1))
 {
     using L = Layout<Tp>;
-    const T k = P[L::OPT + 6], c = P[L::OPT + 7], mu = P[L::OPT + 8], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    const T k = P[L::OPT + 6], c = P[L::OPT + 7], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    const T mu = mu_lane >= T(0) ? mu_lane : P[L::OPT + 8];
     const T vDepth = dot(vW, n);
     const T fN = -fmin_(k * depth + c * vDepth, T(0));
     const V3<T> vT = vW - vDepth * n;
@@ -267,7 +273,8 @@ template<class T, class Tp> JM_DEV V3<T> contact_law_n(CPtr<T> P, V3<T> n, T dep
     return f;
 }
 // world.groundProfile(x, y) -> height and unit normal out of the height map of the batch arguments
-template<class T> JM_DEV void ground_profile(const BatchArgs<T> & A, T x, T y, T & h, V3<T> & n)
+// (`A`: anything with the height-map fields of BatchArgs -- the batch arguments or the constraint arguments)
+template<class T, class G> JM_DEV void ground_profile(const G & A, T x, T y, T & h, V3<T> & n)
 {
     const int nx = A.ground_nx, ny = A.ground_ny;
     T u = (x - A.ground_x0) / A.ground_dx, w = (y - A.ground_y0) / A.ground_dy;
@@ -286,6 +293,35 @@ template<class T> JM_DEV void ground_profile(const BatchArgs<T> & A, T x, T y, T
     const T dhdy = in_y ? ((T(1) - fx) * (h01 - h00) + fx * (h11 - h10)) / A.ground_dy : T(0);
     const T inv = T(1) / sqrt_(dhdx * dhdx + dhdy * dhdy + T(1));
     n = {-dhdx * inv, -dhdy * inv, inv};
+}
+// Local frame of a contact constraint on the ground surface, in ROOT coordinates: the reference expresses the rows
+// of a FrameConstraint (x, y, z, rotation about z) in `rotationLocal_` = [t0 t1 n] built from the ground normal n under
+// the contact point (FrameConstraint::setNormal, frame_constraint.cc:62-68: t1 = normalize(n x e_x), t0 = t1 x n), and
+// takes the penetration depth to first order, (z - height) n_z (engine.cc:3133-3141).  Returns M = rotationLocal^T R1:
+// `M * x` are the local components of a root-coordinate vector, `M^T * lambda` the root coordinates of a local one;
+// the third row of M is the normal.  Flat ground (no height map bound): M = R1, depth = world height.
+// GND = false: kernels without the variation code, flat ground at compile time.
+template<bool GND, class T, class G> JM_DEV M3<T> contact_frame(const G & g, const M3<T> & R1, V3<T> p1, V3<T> pc, T & depth)
+{
+    bool flat = true;
+    if constexpr (GND) flat = !g.ground_h;
+    if (flat)
+    {
+        depth = p1.z + dot(V3<T>{R1.m20, R1.m21, R1.m22}, pc);
+        return R1;
+    }
+    const V3<T> pW = R1 * pc + p1;
+    T hG;
+    V3<T> n;
+    ground_profile(g, pW.x, pW.y, hG, n);
+    depth = (pW.z - hG) * n.z;
+    // t1 = normalize(n x e_x) = (0, n.z, -n.y) / |.|, t0 = t1 x n
+    const T inv = rsqrt_(n.z * n.z + n.y * n.y);
+    const V3<T> t1 = {T(0), n.z * inv, -n.y * inv};
+    const V3<T> t0 = cross(t1, n);
+    return {t0.x * R1.m00 + t0.y * R1.m10 + t0.z * R1.m20, t0.x * R1.m01 + t0.y * R1.m11 + t0.z * R1.m21, t0.x * R1.m02 + t0.y * R1.m12 + t0.z * R1.m22,
+            t1.x * R1.m00 + t1.y * R1.m10 + t1.z * R1.m20, t1.x * R1.m01 + t1.y * R1.m11 + t1.z * R1.m21, t1.x * R1.m02 + t1.y * R1.m12 + t1.z * R1.m22,
+            n.x * R1.m00 + n.y * R1.m10 + n.z * R1.m20, n.x * R1.m01 + n.y * R1.m11 + n.z * R1.m21, n.x * R1.m02 + n.y * R1.m12 + n.z * R1.m22};
 }
 
 // symmetric positive definite 6x6 solve (Ia + diag(rot)) x = b (calc_aba free-flyer,

@@ -174,6 +174,8 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     A.applied = b->applied_k > 0 ? (const T *)b->field[JM_F_APPLIED] : nullptr;
     A.applied_k = A.applied ? b->applied_k : 0;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)b->applied_p[i];
+    // spring-damper model: the lane's own friction coefficient when the field is bound (variation kernels)
+    A.friction = b->copt.contact_model == JM_CONTACT_CONSTRAINT ? nullptr : (const T *)b->field[JM_F_FRICTION];
     return A;
 }
 
@@ -186,7 +188,7 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));  // A.B <= b->B (compact adaptive batches)
         if constexpr (std::is_same<T, double>::value)
         {
-            if (A.model_lane || A.ground_h || A.applied)
+            if (A.model_lane || A.ground_h || A.applied || A.friction)
             {
                 hipLaunchKernelGGL((jm::k_quad_gen<T, Tp>), dim3(grid), dim3(nth), 0, s, A);
                 return;
@@ -217,9 +219,11 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
         C.flags = C0.flags; C.data = C0.data; C.ws = C0.ws; C.friction = C0.friction;
         C.kp = C0.kp; C.kd = C0.kd; C.torsion = C0.torsion; C.reg = C0.reg; C.tol_abs = C0.tol_abs; C.tol_rel = C0.tol_rel;
         C.iter_max = C0.iter_max;
+        C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
+        C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
         constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
-        if (A.model_lane || A.applied) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+        if (A.model_lane || A.applied || A.ground_h) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
         else hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
     }
     else { (void)b; (void)A; (void)C0; (void)s; }
@@ -232,13 +236,11 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     const unsigned grid = (unsigned)((A.B + 63) / 64);
     // only the step launches are timed: the roofline leg prices one pass of the hot path, not the
     // (cheaper, single-evaluation) start / reset / dynamics launches
-    if (A.model_lane || A.ground_h || A.applied)
+    if (A.model_lane || A.ground_h || A.applied || A.friction)
     {
         if (!(Topo::QUAD && b->variant == VARIANT_QUAD) || !std::is_same<T, double>::value)
-            return fail(JM_ENOTIMPL, "per-lane body parameters, height-map ground and applied wrenches need a float64 batch of a "
-                                     "branch-parallel topology (floating base with four limbs)");
-        if (A.ground_h && b->copt.contact_model == JM_CONTACT_CONSTRAINT)
-            return fail(JM_ENOTIMPL, "the height-map ground is available with contacts.model = 'spring_damper' only");
+            return fail(JM_ENOTIMPL, "per-lane body parameters / friction, height-map ground and applied wrenches need a float64 "
+                                     "batch of a branch-parallel topology (floating base with four limbs)");
         if (b->ad_ws && A.B != b->B)
             return fail(JM_ENOTIMPL, "per-lane body parameters / applied wrenches are not available with the adaptive stepper");
     }
@@ -844,6 +846,29 @@ int32_t jm_block_motor_safety_limit(int32_t dtype, int64_t B, int32_t M, const v
     return JM_OK;
 }
 
+// ziggurat tables: computed once on the host (random.cc:66-96), one copy per device
+static int32_t ziggurat_tables_on_device(jm::rnd::ZigguratTables ** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::mutex mtx;
+    static std::map<int, jm::rnd::ZigguratTables *> tables;
+    std::lock_guard<std::mutex> lock(mtx);
+    auto it = tables.find(dev);
+    if (it == tables.end())
+    {
+        jm::rnd::ZigguratTables host;
+        jm::rnd::ziggurat_tables(host);
+        jm::rnd::ZigguratTables * tab = nullptr;
+        HIP_TRY(hipMalloc((void **)&tab, sizeof(host)));
+        HIP_TRY(hipMemcpy(tab, &host, sizeof(host), hipMemcpyHostToDevice));
+        tables[dev] = tab;
+        *out = tab;
+    }
+    else *out = it->second;
+    return JM_OK;
+}
+
 int32_t jm_block_sensor_noise(int32_t dtype, int64_t B, int32_t n_sensors, int32_t n_fields, void * data,
                               uint64_t * rng_state, const double * noise_std, const double * bias,
                               const double * rot_bias_inv, void * stream)
@@ -872,24 +897,10 @@ int32_t jm_block_sensor_noise(int32_t dtype, int64_t B, int32_t n_sensors, int32
     if (rot_bias_inv)
         for (int s = 0; s < n_sensors; ++s)
             for (int k = 0; k < 9; ++k) p.rot[s][k] = rot_bias_inv[9 * s + k];
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    // ziggurat tables: computed once on the host (random.cc:66-96), one copy per device
-    static std::mutex mtx;
-    static std::map<int, jm::rnd::ZigguratTables *> tables;
     jm::rnd::ZigguratTables * tab = nullptr;
     {
-        std::lock_guard<std::mutex> lock(mtx);
-        auto it = tables.find(dev);
-        if (it == tables.end())
-        {
-            jm::rnd::ZigguratTables host;
-            jm::rnd::ziggurat_tables(host);
-            HIP_TRY(hipMalloc((void **)&tab, sizeof(host)));
-            HIP_TRY(hipMemcpy(tab, &host, sizeof(host), hipMemcpyHostToDevice));
-            tables[dev] = tab;
-        }
-        else tab = it->second;
+        const int32_t rc = ziggurat_tables_on_device(&tab);
+        if (rc != JM_OK) return rc;
     }
     const dim3 grid((unsigned)((B + 255) / 256), (unsigned)n_sensors);
     const hipStream_t s = (hipStream_t)stream;
@@ -937,6 +948,44 @@ int32_t jm_block_sensor_delay(int32_t dtype, int64_t B, int32_t n_sensors, int32
     else
         hipLaunchKernelGGL((jm::k_sensor_delay<float>), grid, dim3(256), 0, s, p, (float *)data, (const float *)history, rng_state, (long long)B);
     HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_block_model_bias(int32_t dtype, int64_t B, int32_t njoints, int32_t first_joint, const double * nominal,
+                            const float * std4, uint64_t * rng_state, const uint8_t * mask, void * model_lane, void * stream)
+{
+    if (!nominal || !std4 || !rng_state || !model_lane) return fail(JM_EINVAL, "jm_block_model_bias: null argument");
+    if (B <= 0 || njoints < 1 || first_joint < 1 || first_joint > njoints) return fail(JM_EINVAL, "jm_block_model_bias: bad sizes");
+    if (dtype != JM_F64 && dtype != JM_F32) return fail(JM_EINVAL, "jm_block_model_bias: bad dtype");
+    for (int i = 0; i < 4; ++i)
+        if (!(std4[i] >= 0.0f)) return fail(JM_EINVAL, "jm_block_model_bias: negative standard deviation");
+    jm::BiasParams p{};
+    p.njoints = njoints; p.first = first_joint;
+    p.inertia_std = std4[0]; p.mass_std = std4[1]; p.com_std = std4[2]; p.pos_std = std4[3];
+    jm::rnd::ZigguratTables * tab = nullptr;
+    const int32_t rc = ziggurat_tables_on_device(&tab);
+    if (rc != JM_OK) return rc;
+    const dim3 grid((unsigned)((B + 255) / 256));
+    const hipStream_t s = (hipStream_t)stream;
+    if (dtype == JM_F64)
+        hipLaunchKernelGGL((jm::k_model_bias<double>), grid, dim3(256), 0, s, p, tab, nominal, rng_state, mask, (double *)model_lane, (long long)B);
+    else
+        hipLaunchKernelGGL((jm::k_model_bias<float>), grid, dim3(256), 0, s, p, tab, nominal, rng_state, mask, (float *)model_lane, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return JM_OK;
+}
+
+int32_t jm_engine_rng_seed(const uint32_t * seed, int64_t B, uint64_t * state_out)
+{
+    if (!seed || !state_out || B <= 0) return fail(JM_EINVAL, "jm_engine_rng_seed: bad arguments");
+    for (int64_t lane = 0; lane < B; ++lane)
+    {
+        // internal::generateState (random.hxx:20-44): two 32-bit words of the sequence, low word first
+        std::seed_seq seq{seed[lane]};
+        uint32_t w[2];
+        seq.generate(w, w + 2);
+        state_out[lane] = jm::rnd::pcg32_init((uint64_t)w[0] | ((uint64_t)w[1] << 32));
+    }
     return JM_OK;
 }
 

@@ -71,6 +71,11 @@ template<class T> struct QConArgs
     const T * friction;   // [B] per-lane contacts.friction, or null
     T kp, kd, torsion, reg, tol_abs, tol_rel;
     int iter_max;
+    // world.groundProfile as a height map (variation kernels; fields of BatchArgs): contact rows live in the local
+    // frame of the ground surface under every contact point (contact_frame, jm_kernels.h); null = flat ground
+    const T * ground_h;
+    int ground_nx, ground_ny;
+    T ground_x0, ground_y0, ground_dx, ground_dy;
 };
 
 template<class Tp> struct QConRows
@@ -157,7 +162,7 @@ template<class T, class Tp> struct QConCtx
 
 // ---------------------------------------------------------------- switching
 // `init`: Engine::start (every constraint enabled first, engine.cc:1266-1308); `readonly`: MODE_REFRESH.
-template<class T, class Tp, class X>
+template<class T, class Tp, class X, bool GND = false>
 JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k,
                         const QIdx<Tp> & ix, const T * qb, const T * ql, const QKeep<T, Tp> & K, bool init, bool readonly,
                         QConCtx<T, Tp> & cx)
@@ -224,7 +229,8 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
         const int oc = Q::CONTACT + c * Q::QC;
         const int ci = (int)LT(oc + Q::C_IDX);
         const V3<T> pc = K.Rt * LT.v3(oc + 9) + K.ps[N - 1];
-        const T d = K.p1.z + dot(V3<T>{K.R1.m20, K.R1.m21, K.R1.m22}, pc);
+        T d;
+        (void)contact_frame<GND>(C, K.R1, K.p1, pc, d);
         const unsigned of = (unsigned)(R::NB + ci) * B32 + r32;
         int32_t f = init ? 1 : C.flags[of];
         if (!readonly)
@@ -380,7 +386,7 @@ JM_DEV void trunk_column(CPtr<T> P, const QKeep<T, Tp> & K, const TrunkStore<T, 
 }
 
 // ---------------------------------------------------------------- delassus matrix, four columns per round
-template<class T, class Tp, class X, class VS>
+template<class T, class Tp, class X, class VS, bool GND = false>
 JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, int k, const QIdx<Tp> & ix,
                           const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, const QConCtx<T, Tp> & cx, const VS & V)
 {
@@ -430,9 +436,12 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
 #pragma nounroll
                 for (int c = 0; c < Tp::QCL; ++c) find(c);
             }
-            // unit force along world x / y / z at the contact point, or unit torque about world z
-            const V3<T> col = d == 0 ? V3<T>{K.R1.m00, K.R1.m01, K.R1.m02}
-                            : d == 1 ? V3<T>{K.R1.m10, K.R1.m11, K.R1.m12} : V3<T>{K.R1.m20, K.R1.m21, K.R1.m22};
+            // unit force along the local x / y / normal of the ground surface at the contact point, or unit torque about
+            // the normal (world x / y / z on a flat ground)
+            T dep_;
+            const M3<T> Mc = contact_frame<GND>(C, K.R1, K.p1, pc, dep_);
+            const V3<T> col = d == 0 ? V3<T>{Mc.m00, Mc.m01, Mc.m02}
+                            : d == 1 ? V3<T>{Mc.m10, Mc.m11, Mc.m12} : V3<T>{Mc.m20, Mc.m21, Mc.m22};
             if (d < 3) fu = {col, cross(pc, col)};
             else fu = {zero3<T>(), col};
         }
@@ -501,9 +510,11 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
                     const int r0 = R::NB + 4 * (int)LT(oc + Q::C_IDX);
                     if (!cx.act.test(r0)) return;
                     const V3<T> pc = K.Rt * LT.v3(oc + 9) + K.ps[N - 1];
-                    const V3<T> lin = K.R1 * (atip.l + cross(atip.a, pc));
+                    T dep_;
+                    const M3<T> Mc = contact_frame<GND>(C, K.R1, K.p1, pc, dep_);
+                    const V3<T> lin = Mc * (atip.l + cross(atip.a, pc));
                     store(r0, lin.x); store(r0 + 1, lin.y); store(r0 + 2, lin.z);
-                    if (cx.cb == 4) store(r0 + 3, dot(V3<T>{K.R1.m20, K.R1.m21, K.R1.m22}, atip.a));
+                    if (cx.cb == 4) store(r0 + 3, dot(V3<T>{Mc.m20, Mc.m21, Mc.m22}, atip.a));
                 };
                 if constexpr (Tp::QCL <= 2) static_for<0, Tp::QCL>([&](auto c2) { rows_of(decltype(c2)::value); });
                 else
@@ -519,7 +530,7 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
 
 // ---------------------------------------------------------------- right-hand side and warm start
 // b = -(drift + J a_free) for the rows this lane owns (Baumgarte terms: abstract_constraint.cc:88-98), x = lambda
-template<class T, class Tp, class VS>
+template<class T, class Tp, class VS, bool GND = false>
 JM_DEV void qcon_rhs(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k,
                      const QIdx<Tp> & ix, const T * qb, const T * vb, const T * ql, const T * vl, const T * ddqb, const T * ddq,
                      const QKeep<T, Tp> & K, const QConCtx<T, Tp> & cx, const VS & V)
@@ -555,11 +566,15 @@ JM_DEV void qcon_rhs(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, 
         const int r0 = R::NB + 4 * (int)LT(oc + Q::C_IDX);
         if (!cx.act.test(r0)) return;
         const V3<T> pc = K.Rt * LT.v3(oc + 9) + K.ps[N - 1];
-        const T depth = K.p1.z + dot(V3<T>{K.R1.m20, K.R1.m21, K.R1.m22}, pc);
-        const V3<T> vlin = K.R1 * (K.vtip.l + cross(K.vtip.a, pc));
-        const V3<T> vang = K.R1 * K.vtip.a;
-        V3<T> alin = K.R1 * (sa.l + cross(sa.a, pc));
-        const V3<T> aang = K.R1 * sa.a;
+        // velocity / drift acceleration in the local frame of the ground surface (LOCAL_WORLD_ALIGNED rotated by
+        // rotationLocal^T, frame_constraint.cc:151-174; a rotation commutes with the cross product); the Baumgarte
+        // position term is depth * n, i.e. (0, 0, depth) there
+        T depth;
+        const M3<T> Mc = contact_frame<GND>(C, K.R1, K.p1, pc, depth);
+        const V3<T> vlin = Mc * (K.vtip.l + cross(K.vtip.a, pc));
+        const V3<T> vang = Mc * K.vtip.a;
+        V3<T> alin = Mc * (sa.l + cross(sa.a, pc));
+        const V3<T> aang = Mc * sa.a;
         alin = alin + cross(vang, vlin);
         const int p0 = cx.act.rank(r0);
         V.put(m + p0, -(alin.x + C.kd * vlin.x));
@@ -1284,7 +1299,7 @@ JM_DEV bool qcon_chol(int k, int m, const VS & V)
 // evaluation with the constraint forces would cost four times as much): every lane pushes the constraint forces
 // of ITS limb (bound multipliers as joint efforts, contact multipliers as a wrench on the tip) down to the
 // attachment joint, the quad sums enter the trunk tree, and the accelerations come back up.
-template<class T, class Tp, class X>
+template<class T, class Tp, class X, bool GND = false>
 JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, unsigned B32, unsigned r32, int k,
                              const QIdx<Tp> & ix, const QKeep<T, Tp> & K, const TrunkStore<T, Tp> & TS, const QConCtx<T, Tp> & cx,
                              T * ddqb, T * ddq, int & status)
@@ -1321,10 +1336,12 @@ JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<
         const int r0 = R::NB + 4 * (int)LT(oc + Q::C_IDX);
         if (!cx.act.test(r0)) return;
         const V3<T> pc = K.Rt * LT.v3(oc + 9) + K.ps[N - 1];
-        const V3<T> fR = tmul(K.R1, V3<T>{lam(r0), lam(r0 + 1), lam(r0 + 2)});
+        T dep_;
+        const M3<T> Mc = contact_frame<GND>(C, K.R1, K.p1, pc, dep_);
+        const V3<T> fR = tmul(Mc, V3<T>{lam(r0), lam(r0 + 1), lam(r0 + 2)});
         ftip.l = ftip.l + fR;
         ftip.a = ftip.a + cross(pc, fR);
-        if (cx.cb == 4) ftip.a = ftip.a + lam(r0 + 3) * V3<T>{K.R1.m20, K.R1.m21, K.R1.m22};
+        if (cx.cb == 4) ftip.a = ftip.a + lam(r0 + 3) * V3<T>{Mc.m20, Mc.m21, Mc.m22};
     };
     if constexpr (Tp::QCL <= 2) static_for<0, Tp::QCL>([&](auto cc) { contact(decltype(cc)::value); });
     else
@@ -1418,7 +1435,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                                                        status, &ex, &K, &TS);
         if (pass == 0)
         {
-            qcon_switch<T, Tp, X>(P, LT, C, B32, r32, k, ix, qb, ql, K, init, refresh, cx);
+            qcon_switch<T, Tp, X, GEN>(P, LT, C, B32, r32, k, ix, qb, ql, K, init, refresh, cx);
             any = cx.act.any();
             if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
             if (!any || refresh) break;
@@ -1426,9 +1443,9 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         // delassus matrix (first pass), right-hand side and warm start, solve, multipliers back to the lane state
         auto phases = [&](const auto & W) __attribute__((always_inline)) {
             using VS = std::decay_t<decltype(W)>;
-            if (pass == 0 && !(JM_QCON_SKIP & 2)) qcon_delassus<T, Tp, X, VS>(P, LT, C, k, ix, K, TS, cx, W);
+            if (pass == 0 && !(JM_QCON_SKIP & 2)) qcon_delassus<T, Tp, X, VS, GEN>(P, LT, C, k, ix, K, TS, cx, W);
             X::sync();
-            qcon_rhs<T, Tp, VS>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
+            qcon_rhs<T, Tp, VS, GEN>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
             X::sync();
             if (init && pass == 0)
             {
@@ -1437,7 +1454,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 X::sync();
                 qcon_scatter<T, Tp, VS>(LT, C, B32, r32, k, ix, cx, W);
                 X::sync();
-                qcon_delassus<T, Tp, X, VS>(P, LT, C, k, ix, K, TS, cx, W);   // the factorisation overwrote the matrix
+                qcon_delassus<T, Tp, X, VS, GEN>(P, LT, C, k, ix, K, TS, cx, W);   // the factorisation overwrote the matrix
             }
             else
             {
@@ -1491,7 +1508,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     if (JM_QCON_DELTA && !emit && !init && !refresh && !(JM_QCON_SKIP & 4))
     {
         // nothing to emit: the free acceleration plus one bias-free solve with the multipliers
-        qcon_apply_delta<T, Tp, X>(P, LT, C, B32, r32, k, ix, K, TS, cx, ddqb, ddq, status);
+        qcon_apply_delta<T, Tp, X, GEN>(P, LT, C, B32, r32, k, ix, K, TS, cx, ddqb, ddq, status);
         return;
     }
     // ---- apply the multipliers: articulated-body solve with the constraint forces; emits the outputs

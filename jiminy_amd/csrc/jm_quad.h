@@ -610,6 +610,31 @@ JM_DEV void limb_fk_tip(const LimbTable<T> & LT, const SE3<T> & Xp, Sp<T> vp, co
     });
     Rtip = Rp; ptip = pp; vtip = vp;
 }
+// placement of limb joint s and its axis (root coordinates) from the parent's placement and the kept cos / signed
+// sin of the joint angle: the forward ABA sweep of long limbs walks the kinematics a second time instead of keeping
+// origin + axis of every joint (6 scalars each) from the backward sweep
+template<class T, class Tp, int s, class MA = NoModelLane>
+JM_DEV void limb_rewind(const LimbTable<T> & LT, T c, T sn, M3<T> & R, V3<T> & p, V3<T> & a, const MA & ma = MA{}, int k = 0)
+{
+    using Q = QLayout<Tp>;
+    constexpr int o = s * Q::QJ;
+    SE3<T> plc = LT.se3(o + Q::J_PLC);
+    if constexpr (!std::is_same<MA, NoModelLane>::value)
+        plc.p = ma.plc_p(sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]), plc.p);
+    p = p + R * plc.p;
+    constexpr int ax = limb_axis_uniform<Tp>(s);
+    if constexpr (ax >= 0)
+    {
+        R = mul_rot_axis(R * plc.R, ax, c, sn);
+        if constexpr (limb_axis_negative<Tp>(s)) a = LT(o + Q::J_AXIS + ax) * mcol(R, ax);
+        else a = mcol(R, ax);
+    }
+    else
+    {
+        a = R * LT.v3(o + Q::J_AXP);
+        R = R * (plc.R * rot_rodrigues(LT.v3(o + Q::J_AXIS), c, sn));
+    }
+}
 // placement of the parent of limb joint s from the placement (R, p) of joint s itself (see limb_fk_tip)
 template<class T, class Tp, int s, class MA = NoModelLane>
 JM_DEV void limb_unwind(const LimbTable<T> & LT, T c, T sn, M3<T> & R, V3<T> & p, const MA & ma = MA{}, int k = 0)
@@ -771,6 +796,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     trunk_fk_store<T, Tp, X, MA>(P, k, ix, qb, vb_, TS, Xatt, vatt, status, ma);
     // ---- limb kinematics (long limbs: cos / sin per joint + the tip placement only, see limb_fk_tip)
     constexpr bool UNWIND = QRows<Tp>::LONG;
+    constexpr bool REWIND = UNWIND;   // ... and the forward sweep re-derives joint origins / axes (limb_rewind)
     M3<T> Rs[UNWIND ? 1 : N];
     V3<T> ps[N];
     T cq[UNWIND ? N : 1], sq[UNWIND ? N : 1];
@@ -815,7 +841,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 {
                     const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
                     V3<T> fW;
-                    if constexpr (GEN) fW = contact_law_n<T, Tp>(P, nG, depth, vW);
+                    if constexpr (GEN) fW = contact_law_n<T, Tp>(P, nG, depth, vW, A.friction ? A.friction[r32] : T(-1));
                     else fW = contact_law<T, Tp>(P, depth, vW);
                     const V3<T> fR = tmul(R1, fW);
                     fext.l = fext.l + fR;
@@ -839,9 +865,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     if (ex->flags[((unsigned)ex->nb + ci) * B32 + r32] & 1)
                     {
                         const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
-                        const V3<T> fW = {ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]};
-                        const V3<T> fR = tmul(R1, fW);
-                        const V3<T> tR = ex->lam[o + 3 * B32] * V3<T>{R1.m20, R1.m21, R1.m22};
+                        // (multipliers live in the local frame of the ground surface under the point: contact_frame)
+                        T dep_;
+                        const M3<T> Mc = contact_frame<GEN>(A, R1, p1, pc, dep_);
+                        const V3<T> fR = tmul(Mc, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
+                        const V3<T> tR = ex->lam[o + 3 * B32] * V3<T>{Mc.m20, Mc.m21, Mc.m22};
                         fext.l = fext.l + fR;
                         fext.a = fext.a + cross(pc, fR) + tR;
                         if (emit)
@@ -987,7 +1015,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             constexpr int s = decltype(sc)::value;
             constexpr int o = s * Q::QJ;
             if constexpr (!UNWIND) { Rcur = Rs[s]; pcur = ps[s]; }
-            else ps[s] = pcur;
+            else if constexpr (!REWIND) ps[s] = pcur;
             if constexpr (!DYN)
             {
                 // output pass: only the energy sums need the bodies (velocities unwound from the tip like below)
@@ -1031,7 +1059,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             pa = {f.l + Ya.l + ud * U.l, f.a + Ya.a + ud * U.a};
             Us[s] = U; dinv[s] = di; u[s] = uj;
             if constexpr (KEEP_SC) { Ss[s] = S; cs[s] = c; }
-            else as[s] = a;
+            else if constexpr (!REWIND) as[s] = a;
             if constexpr (KEEP::ON) { keep->ps[s] = pcur; keep->as[s] = a; keep->Us[s] = U; keep->dinv[s] = di; }
             if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
         });
@@ -1188,8 +1216,10 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 });
     };
     imu_at(std::integral_constant<int, 0>{}, SE3<T>{ident3<T>(), zero3<T>()}, v1r, at0);
-    Sp<T> ap = at0;   // acceleration / velocity of the trunk joint this lane's limb hangs from
+    Sp<T> ap = at0;   // acceleration / velocity (/ placement) of the trunk joint this lane's limb hangs from
     Sp<T> vp = v1r;
+    M3<T> Rw = ident3<T>();
+    V3<T> pw = zero3<T>();
     {
         // accelerations of trunk joints with a non-adjacent, non-root parent are re-fetched from
         // the store; chains (the common case) carry them in `aprev`
@@ -1219,7 +1249,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 atst[TrunkStore<T, Tp>::template slot<t>()] = att;
             aprev = att;
             if constexpr (I::limb_at(t))
-                if (ix.attach == t) { ap = att; vp = vt; }
+                if (ix.attach == t)
+                {
+                    ap = att; vp = vt;
+                    if constexpr (REWIND) { Rw = Xt.R; pw = Xt.p; }
+                }
             imu_at(tc, Xt, vt, att);
         });
     }
@@ -1235,7 +1269,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         }
         else
         {
-            const Sp<T> S = {cross(ps[s], as[s]), as[s]};
+            V3<T> a_s, p_s;
+            if constexpr (REWIND)
+            {
+                limb_rewind<T, Tp, s, MA>(LT, cq[s], sq[s], Rw, pw, a_s, ma, k);
+                p_s = pw;
+            }
+            else { a_s = as[s]; p_s = ps[s]; }
+            const Sp<T> S = {cross(p_s, a_s), a_s};
             const Sp<T> vj = vlq(s) * S;
             const Sp<T> ag = ap + cross_mm(vp, vj);
             const T dd = ix.has[s] ? dinv[s] * (u[s] - dot6(Us[s], ag)) : T(0);  // dummy joints never move
@@ -1328,7 +1369,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
                 {
                     const V3<T> vWc = R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc));
                     V3<T> fWc;
-                    if constexpr (GEN) fWc = contact_law_n<T, Tp>(P, nG, depth, vWc);
+                    if constexpr (GEN) fWc = contact_law_n<T, Tp>(P, nG, depth, vWc, A.friction ? A.friction[r32] : T(-1));
                     else fWc = contact_law<T, Tp>(P, depth, vWc);
                     const V3<T> fR = tmul(R1, fWc);
                     fext.l = fext.l + fR;
@@ -1342,9 +1383,11 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
                 if (ex->flags[((unsigned)ex->nb + ci) * B32 + r32] & 1)
                 {
                     const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
-                    const V3<T> fR = tmul(R1, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
+                    T dep_;
+                    const M3<T> Mc = contact_frame<GEN>(A, R1, p1, pc, dep_);
+                    const V3<T> fR = tmul(Mc, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
                     fext.l = fext.l + fR;
-                    fext.a = fext.a + cross(pc, fR) + ex->lam[o + 3 * B32] * V3<T>{R1.m20, R1.m21, R1.m22};
+                    fext.a = fext.a + cross(pc, fR) + ex->lam[o + 3 * B32] * V3<T>{Mc.m20, Mc.m21, Mc.m22};
                 }
             }
         };
@@ -1710,8 +1753,10 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             // not be hoisted out of the loop (each would pin or spill a 64-bit VGPR pair)
             rr = r32;
             JM_OPAQUE(rr);
+            // (long limbs / trunk trees only: re-read the parameter block inside the loop; its scalar loads hoisted out
+            // of the loop overflow the SGPR file and come back as v_readlane -- 300 per Atlas evaluation)
             CPtr<T> Pl = P;
-            JM_OPAQUE_S(Pl);
+            if constexpr (R::LONG) JM_OPAQUE_S(Pl);
             advance(st, e == n_evals - 1, rr);
             quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(Pl, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
         }

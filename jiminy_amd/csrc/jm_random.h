@@ -200,6 +200,104 @@ __global__ void __launch_bounds__(256) k_sensor_delay(const DelayParams p, T * d
 }
 #endif
 
+// ---- model biases: Model::addBiasedToExtendedModel (model.cc:1166-1236) for one robot, generator state in / out.
+// `nom`: the 25 nominal scalars of the joint (jiminy_hip.h jm_block_model_bias), `out`: its 13 biased scalars.
+struct BiasParams
+{
+    int njoints, first;
+    float inertia_std, mass_std, com_std, pos_std;
+};
+namespace rnd
+{
+// pinocchio::exp3 (explog.hpp, v2.7.0): Rodrigues formula, Taylor expansion below eps^(1/4)
+JM_RDEV void exp3_rowmajor(const double * v, double * R)
+{
+    const double t2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double t = sqrt(t2);
+    double a_vxvx, a_vx, dg;
+    if (t > 1.220703125e-4)
+    {
+        const double ct = cos(t), st = sin(t);
+        a_vxvx = (1.0 - ct) / t2; a_vx = st / t; dg = ct;
+    }
+    else
+    {
+        a_vxvx = 0.5 - t2 / 24.0; a_vx = 1.0 - t2 / 6.0; dg = 1.0 - t2 / 2.0;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = a_vxvx * v[i] * v[j];
+    R[1] -= a_vx * v[2]; R[3] += a_vx * v[2];
+    R[2] += a_vx * v[1]; R[6] -= a_vx * v[1];
+    R[5] -= a_vx * v[0]; R[7] += a_vx * v[0];
+    R[0] += dg; R[4] += dg; R[8] += dg;
+}
+template<class Tab> JM_RDEV void bias_one_joint(const BiasParams & p, const double * nom, uint64_t & st, const Tab & kn,
+                                                const float * fn, const float * wn, double * out)
+{
+    // `normal(g, mean, std)` = normal01(g) * std + mean in float, two roundings (random.cc:162-167)
+#pragma clang fp contract(off)
+    const double eps = 2.220446049250313e-16;
+    for (int i = 0; i < 13; ++i) out[i] = nom[i];
+    if ((double)p.com_std > eps)
+        for (int i = 0; i < 3; ++i) out[1 + i] *= (double)(normal01(st, kn, fn, wn) * p.com_std + 1.0f);
+    if ((double)p.mass_std > eps)
+    {
+        const double m = out[0];
+        const double mb = m * (double)(normal01(st, kn, fn, wn) * p.mass_std + 1.0f);
+        const double lo = m < 1.0e-3 ? m : 1.0e-3;
+        out[0] = mb > lo ? mb : lo;
+    }
+    if ((double)p.inertia_std > eps)
+    {
+        // principal axes rotated by exp3(N(0, std)^3), principal moments scaled by N(1, std)^3, I = A diag(M) A^T
+        // (the reference goes through Eigen::Quaterniond(exp3(.)): the same rotation up to rounding)
+        double ra[3], R[9], A[9], M[3];
+        for (int i = 0; i < 3; ++i) ra[i] = (double)(normal01(st, kn, fn, wn) * p.inertia_std + 0.0f);
+        exp3_rowmajor(ra, R);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                A[3 * i + j] = nom[16 + 3 * i] * R[j] + nom[16 + 3 * i + 1] * R[3 + j] + nom[16 + 3 * i + 2] * R[6 + j];
+        for (int i = 0; i < 3; ++i) M[i] = nom[13 + i] * (double)(normal01(st, kn, fn, wn) * p.inertia_std + 1.0f);
+        int o = 4;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 3; ++j)
+                out[o++] = A[3 * i] * M[0] * A[3 * j] + A[3 * i + 1] * M[1] * A[3 * j + 1] + A[3 * i + 2] * M[2] * A[3 * j + 2];
+    }
+    if ((double)p.pos_std > eps)
+        for (int i = 0; i < 3; ++i) out[10 + i] *= (double)(normal01(st, kn, fn, wn) * p.pos_std + 1.0f);
+}
+}  // namespace rnd
+
+#ifndef JM_HOST_EMU
+// one thread per lane: the mechanical joints in index order, the lane's engine generator advanced like the reference's
+template<class T>
+__global__ void __launch_bounds__(256) k_model_bias(const BiasParams p, const rnd::ZigguratTables * tables, const double * nominal,
+                                                    uint64_t * rng, const uint8_t * mask, T * model_lane, long long B)
+{
+    __shared__ uint32_t kn[128];
+    __shared__ float fn[128], wn[128];
+    if (threadIdx.x < 128)
+    {
+        kn[threadIdx.x] = tables->kn[threadIdx.x];
+        fn[threadIdx.x] = tables->fn[threadIdx.x];
+        wn[threadIdx.x] = tables->wn[threadIdx.x];
+    }
+    __syncthreads();
+    const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (lane >= B) return;
+    if (mask && !mask[lane]) return;
+    uint64_t st = rng[lane];
+    for (int j = p.first; j < p.njoints; ++j)
+    {
+        double nom[25], out[13];
+        for (int i = 0; i < 25; ++i) nom[i] = nominal[25 * j + i];
+        rnd::bias_one_joint(p, nom, st, kn, fn, wn, out);
+        for (int i = 0; i < 13; ++i) model_lane[(long long)(13 * j + i) * B + lane] = (T)out[i];
+    }
+    rng[lane] = st;
+}
+#endif
+
 #ifndef JM_HOST_EMU
 // data: [n_sensors * n_fields][B] (row = sensor * n_fields + field), rng: [n_sensors][B]
 template<class T>

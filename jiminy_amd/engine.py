@@ -542,7 +542,8 @@ class BatchedEngine:
         # model biases per environment, ground profile, impulse / profile forces (section 4.9 of DESIGN.md)
         from .randomization import default_dynamics_options
         self._model_options: Dict[str, Dict[str, float]] = {"dynamics": default_dynamics_options()}
-        self._model_generator = torch.Generator(device="cpu")
+        self._model_rng: Optional[torch.Tensor] = None      # PCG32 state of every lane's engine generator
+        self._bias_table: Optional[torch.Tensor] = None     # nominal body parameters + principal axes (device)
         self._ground: Optional[torch.Tensor] = None
         self._force_frames: List[str] = []
         self._impulse_forces: List[Dict[str, Any]] = []
@@ -661,7 +662,8 @@ class BatchedEngine:
         if getattr(self, "_gen_checked", False) or self.dtype != torch.float64 or \
                 os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
             return
-        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields):
+        lane_mu = "friction" in self._fields and self._options["contacts"]["model"] != "constraint"
+        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu):
             return
         self._gen_checked = True
         variant = self._lib_variant_index
@@ -703,13 +705,16 @@ class BatchedEngine:
     def set_lane_friction(self, friction: Optional[Any]) -> None:
         """Ground friction coefficient of every lane (`contacts.friction` randomised per environment as
         `WalkerJiminyEnv._setup` does per episode, gym_jiminy envs/locomotion.py:257-262).  `(B,)` values, or
-        None to go back to the batch-wide option.  Constraint contact model, fixed-step solvers."""
+        None to go back to the batch-wide option.  Both contact models (the spring-damper law reads it in the
+        per-environment variation kernels: float64 batches of branch-parallel topologies); fixed-step solvers."""
         if friction is None:
             self._fields.pop("friction", None)
             self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["friction"], None))
             return
-        if self._options["contacts"]["model"] != "constraint":
-            raise NotImplementedError("per-lane friction needs contacts.model='constraint'")
+        if self._options["contacts"]["model"] != "constraint" and \
+                (codegen.quad_structure(self.model) is None or self.dtype != torch.float64):
+            raise NotImplementedError("per-lane friction with the spring-damper model needs a float64 batch of a "
+                                      "branch-parallel topology (floating base with four limbs)")
         f = torch.as_tensor(friction, dtype=self.dtype, device=self.device).reshape(1, -1)
         if f.shape[1] != self.batch_size or bool((f < 0).any()):
             raise ValueError("friction must hold one non-negative value per lane")
@@ -818,6 +823,12 @@ class BatchedEngine:
         self._iter = 0
         if any(float(v) > EPS for v in self._model_options["dynamics"].values()):
             self.sample_model_biases()   # ≙ Model::reset -> generateModelBiased at the start of every simulation
+        # a new simulation re-evaluates every profile force and forgets the impulses that were active when the last
+        # one stopped (the reference evaluates all external forces in Engine::start, engine.cc:1311-1330): a held
+        # value with `t_last` from the previous simulation would otherwise survive until t exceeds that time again
+        for pf in self._profile_forces:
+            pf["value"], pf["t_last"] = None, -math.inf
+        self._impulse_active = []
         self._update_applied_forces(0.0)
         self._check_variation_kernels()
         self._lib.check(self._L.jm_batch_start(self._batch_h, self._stream()))
@@ -937,12 +948,16 @@ class BatchedEngine:
         stream = self._stream()
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step
         per_step_noise = bool(self._sensor_noise) and float(self._options["stepper"]["sensorsUpdatePeriod"]) <= 0.0
+        # continuous profile forces (update_period = 0) are functions of (t, q, v): the reference evaluates them inside
+        # every dynamics evaluation (computeExternalForces, engine.cc:3481-3492).  Here they are re-evaluated at the
+        # start of every integrator step (launches cut to one step): piecewise constant over dtMax at most.
+        per_step_forces = any(p["period"] <= EPS for p in self._profile_forces)
         # (only discrete controllers have breakpoints: engine.cc:1919-1940)
         constraint_model = (self._options["contacts"]["model"] == "constraint"
                             and float(self._options["stepper"]["controllerUpdatePeriod"]) > EPS)
         t_now = self._t
         for dt, n, cmd_bp, sens in launches:
-            for k, n_k in enumerate([1] * n if (per_step_noise and sens) else [n]):
+            for k, n_k in enumerate([1] * n if ((per_step_noise and sens) or per_step_forces) else [n]):
                 forces_changed = self._update_applied_forces(t_now)
                 t_now += dt * n_k
                 # a(t+) refresh at a controller breakpoint (engine.cc:2030-2042): skipped when the held
@@ -1051,8 +1066,24 @@ class BatchedEngine:
         if not any(v > EPS for v in self._model_options["dynamics"].values()):
             self.set_lane_model(None)
 
-    def seed_model(self, seed: int) -> None:
-        self._model_generator.manual_seed(int(seed))
+    def seed_model(self, seed: Any) -> None:
+        """Seed the engine generator of every lane, ≙ `stepper.randomSeedSeq = [seed]` of one reference engine per lane
+        (`generator_.seed(std::seed_seq(...))`, engine.cc:756-757): the PCG32 stream the model biases are drawn from
+        (`Model::addBiasedToExtendedModel`).  `seed`: `(B,)` uint32 words, or an `int` -- lane l gets `seed + l`."""
+        B = self.batch_size
+        if isinstance(seed, (int, np.integer)):
+            words = ((int(seed) + np.arange(B, dtype=np.uint64)) & 0xFFFFFFFF).astype(np.uint32)
+        else:
+            words = np.ascontiguousarray(np.broadcast_to(np.asarray(seed, dtype=np.uint32), (B,)))
+        out = np.empty(B, dtype=np.uint64)
+        self._lib.check(self._L.jm_engine_rng_seed(words.ctypes.data_as(C.POINTER(C.c_uint32)), B,
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        self._model_rng = torch.from_numpy(out.view(np.int64)).to(self.device)
+
+    @property
+    def model_rng_state(self) -> torch.Tensor:
+        """PCG32 state of every lane's engine generator (`(B,)`, int64 view of the uint64 states)."""
+        return self._model_rng
 
     def set_lane_model(self, model_lane: Optional[torch.Tensor]) -> None:
         """Bind body parameters per lane (`[13 * njoints][B]`, layout of `JM_F_MODEL_LANE`), None = the model's."""
@@ -1071,18 +1102,34 @@ class BatchedEngine:
         self._fields["model_lane"].copy_(t)
 
     def sample_model_biases(self, lane_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Draw the biased models (all lanes, or the masked ones: episode-wise re-randomisation) and bind them."""
-        from .randomization import sample_model_lane
-        prev = self._fields.get("model_lane") if lane_mask is not None else None
-        ml = sample_model_lane(self.model, self.batch_size, self._model_options["dynamics"], self._model_generator,
-                               self.dtype, self.device, lane_mask if prev is not None else None, prev)
-        self.set_lane_model(ml)
+        """Draw the biased models (all lanes, or the masked ones: episode-wise re-randomisation) on the device and bind
+        them: `jm_block_model_bias` ≙ `Model::addBiasedToExtendedModel` per lane, from the lane's engine generator
+        (`seed_model`), whose stream advances exactly like the reference's."""
+        from .randomization import DYNAMICS_OPTION_NAMES, nominal_bias_table, nominal_model_lane
+        B = self.batch_size
+        if "model_lane" not in self._fields:
+            self.set_lane_model(nominal_model_lane(self.model, B, self.dtype, self.device))
+        if self._model_rng is None:
+            self.seed_model(0)
+        if self._bias_table is None:
+            self._bias_table = torch.from_numpy(nominal_bias_table(self.model)).to(self.device)
+        std4 = (C.c_float * 4)(*[float(self._model_options["dynamics"][k]) for k in DYNAMICS_OPTION_NAMES])
+        mask = None
+        if lane_mask is not None:
+            mask = lane_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        first = 2 if self.model.has_freeflyer else 1   # mechanicalJointNames_ excludes the free-flyer (model.cc:337-341)
+        self._lib.check(self._L.jm_block_model_bias(
+            _abi.JM_F64 if self.dtype == torch.float64 else _abi.JM_F32, B, self.model.njoints, first,
+            C.c_void_p(self._bias_table.data_ptr()), std4, C.c_void_p(self._model_rng.data_ptr()),
+            C.c_void_p(mask.data_ptr()) if mask is not None else None,
+            C.c_void_p(self._fields["model_lane"].data_ptr()), self._stream()))
         return self._fields["model_lane"]
 
     def set_ground_heightmap(self, heights: Any, x0: float = 0.0, y0: float = 0.0, dx: float = 1.0, dy: float = 1.0) -> None:
         """≙ `engine_options["world"]["groundProfile"]` (engine.h:292-302) as a height map: `heights[iy][ix]` at
         (x0 + ix dx, y0 + iy dy), bilinear patches (height + unit normal), flat continuation outside; None = flat
-        ground.  Spring-damper contact model."""
+        ground.  Both contact models: with `contacts.model = "constraint"` the rows of a contact constraint live in the
+        local frame of the surface under the contact point (`FrameConstraint::setNormal`, engine.cc:3184-3193)."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before updating the options.")
         if heights is None:
@@ -1098,14 +1145,21 @@ class BatchedEngine:
 
     def set_ground_profile(self, func: Any, x_range: Tuple[float, float], y_range: Tuple[float, float],
                            resolution: float) -> None:
-        """Discretise a `heightmap(x, y) -> height` callable (vectorised over numpy arrays) on a regular grid
-        (≙ `discretize_heightmap`, core/src/utilities/geometry.cc) and use it as the ground profile."""
+        """Discretise a `heightmap(x, y) -> height` callable on a regular grid (≙ `discretize_heightmap`,
+        core/src/utilities/geometry.cc) and use it as the ground profile.  The callable is tried on device tensors
+        first (e.g. `jiminy_amd.terrain.random_tile_ground`: the map is then generated on the GPU), then on numpy arrays."""
         nx = max(int(math.ceil((x_range[1] - x_range[0]) / resolution)) + 1, 2)
         ny = max(int(math.ceil((y_range[1] - y_range[0]) / resolution)) + 1, 2)
-        xs = x_range[0] + resolution * np.arange(nx)
-        ys = y_range[0] + resolution * np.arange(ny)
-        X, Y = np.meshgrid(xs, ys)
-        self.set_ground_heightmap(np.asarray(func(X, Y), dtype=np.float64), x_range[0], y_range[0], resolution, resolution)
+        xs = x_range[0] + resolution * torch.arange(nx, dtype=torch.float64, device=self.device)
+        ys = y_range[0] + resolution * torch.arange(ny, dtype=torch.float64, device=self.device)
+        Y, X = torch.meshgrid(ys, xs, indexing="ij")
+        try:
+            h = func(X, Y)
+            if not isinstance(h, torch.Tensor):
+                raise TypeError
+        except (TypeError, RuntimeError):
+            h = np.asarray(func(X.cpu().numpy(), Y.cpu().numpy()), dtype=np.float64)
+        self.set_ground_heightmap(h, x_range[0], y_range[0], resolution, resolution)
 
     def _force_frame_index(self, frame_name: str) -> int:
         fr = self.model.frame(frame_name)
@@ -1142,6 +1196,20 @@ class BatchedEngine:
             raise ValueError("force must have shape (6,) or (6, B)")
         self._impulse_forces.append({"frame": self._force_frame_index(frame_name), "t": float(t), "dt": float(dt),
                                      "force": f.contiguous()})
+
+    def _schedule_impulse_force(self, frame_name: str, t: float, dt: float, force: torch.Tensor) -> None:
+        """Internal (environments): append an impulse while the simulation runs -- its start must lie at or after the
+        current time, so that the breakpoint schedule of the steps to come sees it -- and drop the impulses that are
+        over.  The vectorised environments keep only the NEXT push of their periodic schedule registered instead of
+        one (6, B) tensor per push of the whole horizon."""
+        if t < self._t - STEPPER_MIN_TIMESTEP:
+            raise ValueError("cannot schedule an impulse in the past")
+        alive = [i for i, f in enumerate(self._impulse_forces) if f["t"] + f["dt"] > self._t - STEPPER_MIN_TIMESTEP]
+        remap = {old: new for new, old in enumerate(alive)}
+        self._impulse_forces = [self._impulse_forces[i] for i in alive]
+        self._impulse_active = [remap[i] for i in self._impulse_active if i in remap]
+        self._impulse_forces.append({"frame": self._force_frames.index(frame_name), "t": float(t), "dt": float(dt),
+                                     "force": force.to(dtype=self.dtype, device=self.device).contiguous()})
 
     def register_profile_force(self, frame_name: str, func: Any, update_period: float = 0.0) -> None:
         """≙ `Engine.register_profile_force(robot_name, frame_name, force_func, update_period)` (engine.cc:1895-1935):

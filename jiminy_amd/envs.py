@@ -41,8 +41,12 @@ class VecJiminyEnv:
                  dtype: torch.dtype = torch.float64, device: Optional[torch.device] = None,
                  simulation_duration_max: float = 86400.0, auto_reset: bool = True,
                  std_ratio: Optional[Dict[str, float]] = None,
-                 model_options: Optional[Dict[str, Dict[str, float]]] = None) -> None:
+                 model_options: Optional[Dict[str, Dict[str, float]]] = None,
+                 ground_profile: Optional[Tuple[Any, Tuple[float, float], Tuple[float, float], float]] = None) -> None:
         self.model = model
+        # ≙ `engine_options["world"]["groundProfile"]`: `(heightmap(x, y), x_range, y_range, resolution)`, e.g. a
+        # `jiminy_amd.terrain.random_tile_ground` generator; sampled on the device at every `reset()`, shared by the batch
+        self._ground_profile = ground_profile
         # ≙ `WalkerJiminyEnv(std_ratio=...)` (envs/locomotion.py:100-135): scale of the episode-wise
         # randomisation.  Supported keys: 'ground' (friction coefficient of every environment, constraint
         # contact model) and 'sensors' (white noise, bias, delay and jitter of every sensor type, drawn once per
@@ -133,6 +137,8 @@ class VecJiminyEnv:
         self._q0, self._v0 = q, v
         self.engine.field("command").zero_()
         self._on_reset(None)
+        if self._ground_profile is not None:
+            self.engine.set_ground_profile(*self._ground_profile)
         self._randomise_ground(None)
         self._randomise_sensors()
         self._schedule_disturbances()
@@ -165,7 +171,35 @@ class VecJiminyEnv:
 
     def _step_engine(self, action: torch.Tensor) -> None:
         self.engine.set_command(self.compute_command(action))
+        self._refill_impulses(self.step_dt)
         self.engine.step(self.step_dt)
+
+    def _refill_impulses(self, horizon: float) -> None:
+        """Keep the pushes that start within the next `horizon` seconds of engine time registered (see
+        `_schedule_disturbances`); a push is drawn once, when it enters the horizon."""
+        if getattr(self, "_impulse_frame", None) is None:
+            return
+        scale = float(self.std_ratio.get("disturbance", 0.0))
+        g, B = self._generator, self.num_envs
+        t_now = float(self.engine._t)    # (host-side clock: no device synchronisation)
+        while True:
+            t_ref = self._impulse_index * self.F_IMPULSE_PERIOD
+            if t_ref - self.F_IMPULSE_DELTA > t_now + horizon + self.F_IMPULSE_DT:
+                break
+            t = t_ref + self.F_IMPULSE_DELTA * float(torch.rand(1, generator=g) * 2.0 - 1.0)
+            t = max(t, t_now, self._impulse_end)
+            d = torch.randn(2, B, generator=g, dtype=torch.float64)
+            d = d / d.norm(dim=0, keepdim=True)
+            mag = torch.rand(B, generator=g, dtype=torch.float64) * scale * self.F_IMPULSE_SCALE
+            f = torch.zeros(6, B, dtype=torch.float64)
+            f[:2] = d * mag
+            f = f.to(self.device)
+            # environments whose episode is younger than the first push of the reference's schedule are spared
+            young = (t - self._t0) < (self.F_IMPULSE_PERIOD - self.F_IMPULSE_DELTA)
+            f = torch.where(young[None, :], torch.zeros_like(f), f)
+            self.engine._schedule_impulse_force(self._impulse_frame, t, self.F_IMPULSE_DT, f)
+            self._impulse_end = t + self.F_IMPULSE_DT
+            self._impulse_index += 1
 
     def reset_lanes(self, lane_mask: torch.Tensor) -> None:
         q, v = self._sample_state(self.num_envs)
@@ -206,27 +240,29 @@ class VecJiminyEnv:
     _f_xy_profile = None
 
     def _schedule_disturbances(self) -> None:
-        """≙ the impulse part of `WalkerJiminyEnv._setup` (envs/locomotion.py:298-326): every F_IMPULSE_PERIOD
-        seconds (+- F_IMPULSE_DELTA, one offset for the batch: breakpoints are shared) a horizontal push of random
-        direction and magnitude U(0, std_ratio['disturbance'] * F_IMPULSE_SCALE) on the root body, one draw per
-        environment, plus the continuous Gaussian-process force of :327-359 (below)."""
+        """≙ the disturbance part of `WalkerJiminyEnv._setup` (envs/locomotion.py:298-326): every F_IMPULSE_PERIOD
+        seconds (+- F_IMPULSE_DELTA) a horizontal push of random direction and magnitude
+        U(0, std_ratio['disturbance'] * F_IMPULSE_SCALE) on the root body, one draw per environment, plus the
+        continuous Gaussian-process force of :327-359 (below).
+
+        The reference draws the pushes of a whole episode in episode time at every `_setup`.  Here the environments
+        of a batch share the engine clock and its breakpoints while their episodes start at different times
+        (auto-reset), so the schedule is periodic in ENGINE time and generated lazily -- only the next push is
+        registered (`_refill_impulses`, called before every engine step), whatever `simulation_duration_max` -- and an
+        environment is spared by the pushes of the first F_IMPULSE_PERIOD - F_IMPULSE_DELTA seconds of its own
+        episode, in which the reference schedules none."""
         scale = float(self.std_ratio.get("disturbance", 0.0))
         self.engine.remove_all_forces()
+        self._impulse_frame = None
         if scale <= 0.0 or not self.model.has_freeflyer:
             return
         frame = next(n for n, f in self.model.frames.items() if f.parent_joint == 1)
         g = self._generator
         B = self.num_envs
-        t_ref = self.F_IMPULSE_PERIOD
-        while t_ref < self.simulation_duration_max:
-            t = t_ref + self.F_IMPULSE_DELTA * float(torch.rand(1, generator=g) * 2.0 - 1.0)
-            d = torch.randn(2, B, generator=g, dtype=torch.float64)
-            d = d / d.norm(dim=0, keepdim=True)
-            mag = torch.rand(B, generator=g, dtype=torch.float64) * scale * self.F_IMPULSE_SCALE
-            f = torch.zeros(6, B, dtype=torch.float64)
-            f[:2] = d * mag
-            self.engine.register_impulse_force(frame, t, self.F_IMPULSE_DT, f)
-            t_ref += self.F_IMPULSE_PERIOD
+        self.engine._force_frame_index(frame)    # binds the `applied` field while no simulation is running
+        self._impulse_frame = frame
+        self._impulse_index = 1                  # the push of period k starts at k * F_IMPULSE_PERIOD +- delta
+        self._impulse_end = 0.0
         # the continuous part (envs/locomotion.py:165-167, 327-359): two periodic Gaussian processes, one realisation
         # per environment, drive the x / y force on the root body: F_PROFILE_SCALE * std_ratio * process(episode time)
         from .processes import PeriodicGaussianProcess
@@ -485,6 +521,7 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         if getattr(self, "_graph_enabled", False):
             self._step_engine_graphed(action)
         else:
+            self._refill_impulses(self.step_dt)
             self._issue_step(action.to(self.dtype).T)
 
     def _issue_step(self, a: torch.Tensor) -> None:

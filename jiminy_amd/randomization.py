@@ -12,8 +12,11 @@ once, with the model options of `Model::getDefaultDynamicsOptions` (core/include
 * `relativePositionBodiesBiasStd`: every component of the joint placement translation times N(1, std)
   (rotation excluded).
 
-The draws come from a `torch.Generator` (the reference draws from the robot's PCG32 stream in joint order; it
-holds no golden vectors for these biases, and they are statistical by nature: the laws are what is mirrored).
+The engine draws on the device with `jm_block_model_bias` (csrc/jm_random.h): one PCG32 stream per lane, consumed in
+the reference's joint and field order, generator states bit-identical to `oracle/oracle_random.cpp`
+(`BatchedEngine.sample_model_biases`).  `sample_model_lane` below is the tensor-program statement of the same laws
+from a `torch.Generator`: host-side use and the statistical tests of tests/test_variation.py.  The free-flyer root is
+not a "mechanical joint" (model.cc:337-341): its body is never biased.
 """
 from __future__ import annotations
 
@@ -47,6 +50,25 @@ def nominal_model_lane(model: CompiledModel, batch_size: int, dtype: torch.dtype
         rows[13 * j + 10:13 * j + 13] = model.placement_p[j]
     t = torch.as_tensor(rows, dtype=dtype, device=device)
     return t[:, None].expand(-1, batch_size).contiguous()
+
+
+def nominal_bias_table(model: CompiledModel) -> np.ndarray:
+    """`[njoints][25]` float64: mass | com 3 | inertia xx xy xz yy yz zz | placement translation 3 | principal moments 3
+    (ascending) | principal axes 9 (row-major, columns = axes) of the unbiased bodies: the `nominal` argument of
+    `jm_block_model_bias`.  (The reference decomposes with Eigen::SelfAdjointEigenSolver, model.cc:1204-1206; the sign
+    and, for equal moments, the choice of the axes are the solver's, not part of the law.)"""
+    nj = model.njoints
+    t = np.zeros((nj, 25))
+    for j in range(1, nj):
+        I = np.asarray(model.inertia[j], dtype=np.float64)
+        t[j, 0] = model.mass[j]
+        t[j, 1:4] = model.com[j]
+        t[j, 4:10] = (I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2])
+        t[j, 10:13] = model.placement_p[j]
+        w, A = np.linalg.eigh(0.5 * (I + I.T))
+        t[j, 13:16] = w
+        t[j, 16:25] = A.reshape(9)
+    return np.ascontiguousarray(t)
 
 
 def _exp3(w: torch.Tensor) -> torch.Tensor:
@@ -84,7 +106,7 @@ def sample_model_lane(model: CompiledModel, batch_size: int, options: Dict[str, 
     inertia_std = float(options.get("inertiaBodiesBiasStd", 0.0))
     pos_std = float(options.get("relativePositionBodiesBiasStd", 0.0))
     eps = float(np.finfo(np.float64).eps)
-    for j in range(1, nj):
+    for j in range(2 if model.has_freeflyer else 1, nj):   # mechanical joints: the free-flyer root is not one
         if com_std > eps:
             out[j, 1:4] *= normal((3, B), 1.0, com_std)
         if mass_std > eps:

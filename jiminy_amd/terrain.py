@@ -1,0 +1,107 @@
+"""Random terrain generators on the device: `random_tile_ground` ≙ `jiminy.random_tile_ground` / `tiles`
+(reference core/src/utilities/random.cc:488-656; core/include/jiminy/core/utilities/random.h:588).
+
+The reference's generator is a pure function of the position: every tile (i, j) of a rotated, offset grid gets the
+height `heightMax * u(i, j)`, `u` = XXH32 of the two int32 tile indices with the seed (random.cc:200-256, 488-501: kept
+only when `hash % sparsity == 0`, else 0), and a band of width `interpDelta` on either side of a tile edge blends
+linearly into the neighbouring tile.  Here the same function is evaluated for whole tensors of positions with integer
+tensor arithmetic (wrap-around uint32 products carried in int64), on whatever device the positions live on, e.g. to
+fill the height map of `BatchedEngine.set_ground_profile` from a seed without leaving the GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Sequence, Tuple
+
+import torch
+
+_P1, _P2, _P3, _P4, _P5 = 2654435761, 2246822519, 3266489917, 668265263, 374761393
+_M32 = 0xFFFFFFFF
+
+
+def _u32(x: torch.Tensor) -> torch.Tensor:
+    return x & _M32
+
+
+def _rotl(x: torch.Tensor, r: int) -> torch.Tensor:
+    return _u32((x << r) | (x >> (32 - r)))
+
+
+def xxh32_words(words: Sequence[torch.Tensor], seed: int) -> torch.Tensor:
+    """XXH32 (random.cc:200-256) of a short key given as 32-bit little-endian words (fewer than four: the
+    `len < 16` branch), one hash per tensor element; int64 tensors holding values in [0, 2^32)."""
+    n = 4 * len(words)
+    assert n < 16
+    h = torch.full_like(words[0], (int(seed) + _P5 + n) & _M32)
+    for w in words:
+        h = _u32(h + _u32(_u32(w) * _P3))
+        h = _u32(_rotl(h, 17) * _P4)
+    h = h ^ (h >> 15)
+    h = _u32(h * _P2)
+    h = h ^ (h >> 13)
+    h = _u32(h * _P3)
+    h = h ^ (h >> 16)
+    return h
+
+
+def _uniform_sparse(ix: torch.Tensor, iy: torch.Tensor, sparsity: int, seed: int) -> torch.Tensor:
+    """`uniformSparseFromState(Vector2<int32>{ix, iy}, sparsity, seed)` (random.cc:488-509): float32 in [0, 1]."""
+    h = xxh32_words([ix & _M32, iy & _M32], seed)
+    # float(hash) / float(UINT32_MAX): the divisor rounds to 2^32 in float32, so the quotient is an exact scaling --
+    # written as one, it is bit-identical on every device (a float32 division is not correctly rounded everywhere)
+    u = h.to(torch.float32) * (1.0 / 4294967296.0)
+    return torch.where(h % int(sparsity) == 0, u, torch.zeros_like(u))
+
+
+def random_tile_ground(size: Tuple[float, float], height_max: float, interp_delta: Tuple[float, float],
+                       sparsity: int, orientation: float, seed: int) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `tiles(size, heightMax, interpDelta, sparsity, orientation, seed)` (random.cc:552-656): returns
+    `heightmap(x, y) -> height` for float64 tensors `x`, `y` of any (equal) shape and device."""
+    sx, sy = float(size[0]), float(size[1])
+    thr = [min(max(float(interp_delta[0]), 0.01), sx / 2.0) / sx, min(max(float(interp_delta[1]), 0.01), sy / 2.0) / sy]
+    sizes = (sx, sy)
+    c, s = math.cos(float(orientation)), math.sin(float(orientation))
+
+    def offset(i: int) -> float:   # size[i] * uniformSparseFromState(Vector1<Eigen::Index>{i}, 1, seed): an int64 key
+        k = torch.tensor([i], dtype=torch.int64)
+        h = xxh32_words([k, torch.zeros_like(k)], seed)
+        return sizes[i] * float(h.to(torch.float32) * (1.0 / 4294967296.0))
+    off = (offset(0), offset(1))
+
+    def z_of(ix: torch.Tensor, iy: torch.Tensor) -> torch.Tensor:
+        return float(height_max) * _uniform_sparse(ix, iy, sparsity, seed).to(torch.float64)
+
+    def interp1d(ix, iy, rel, dim):
+        """`tile2dInterp1d` (random.cc:511-550): height blended along `dim` where the point lies in an edge band."""
+        z = z_of(ix, iy)
+        dm = (-1, 0) if dim == 0 else (0, -1)
+        z_m = z_of(ix + dm[0], iy + dm[1])
+        z_p = z_of(ix - dm[0], iy - dm[1])
+        t = thr[dim]
+        lo, hi = rel < t, (1.0 - rel) < t
+        h_lo = z + (z_m - z) * ((1.0 - rel / t) / 2.0)
+        h_hi = z + (z_p - z) * ((1.0 + (rel - 1.0) / t) / 2.0)
+        return torch.where(lo, h_lo, torch.where(hi, h_hi, z))
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        y = torch.as_tensor(y, dtype=torch.float64, device=x.device)
+        px, py = x + off[0], y + off[1]
+        rx, ry = (c * px - s * py) / sx, (s * px + c * py) / sy
+        fx, fy = torch.floor(rx), torch.floor(ry)
+        ix, iy = fx.to(torch.int64), fy.to(torch.int64)      # (int32 in the reference: same values for |index| < 2^31)
+        rx, ry = rx - fx, ry - fy
+        ex = (rx < thr[0]) | ((1.0 - rx) < thr[0])
+        ey = (ry < thr[1]) | ((1.0 - ry) < thr[1])
+        h_x = interp1d(ix, iy, rx, 0)            # edge along x only (or no edge at all: the tile's own height)
+        h_y = interp1d(ix, iy, ry, 1)            # edge along y only
+        # corner: the x-blended heights of this row of tiles and of the neighbouring row, blended along y
+        t = thr[1]
+        lo = ry < t
+        h_0 = h_x
+        h_n = torch.where(lo, interp1d(ix, iy - 1, rx, 0), interp1d(ix, iy + 1, rx, 0))
+        ratio = torch.where(lo, (1.0 - ry / t) / 2.0, (1.0 + (ry - 1.0) / t) / 2.0)
+        h_xy = h_0 + (h_n - h_0) * ratio
+        return torch.where(ex & ey, h_xy, torch.where(ey, h_y, h_x))
+
+    return heightmap

@@ -458,6 +458,10 @@ struct Engine
     {
         bool enabled = false;
         double lambda[4] = {0, 0, 0, 0};
+        // FrameConstraint::rotationLocal_ (frame_constraint.cc:62-68: columns t0, t1, n from the ground normal) and the
+        // penetration depth, both refreshed at every evaluation while the constraint is enabled (engine.cc:3184-3193)
+        M3 Rloc = M3::identity();
+        double depth = 0.0;
     };
     std::vector<BoundCon> bcon;
     std::vector<FrameCon> fcon;
@@ -950,7 +954,10 @@ void toggle_bounds(Engine & e, const double * q)
     }
 }
 
-// computeContactDynamicsAtFrame, CONSTRAINT branch, flat ground (engine.cc:3145-3193)
+// computeContactDynamicsAtFrame, CONSTRAINT branch (engine.cc:3133-3193): height and normal of world.groundProfile
+// under the frame, first-order depth, hysteresis, and -- while enabled -- the constraint's local frame from the
+// normal (FrameConstraint::setNormal, frame_constraint.cc:62-68); the reference transform moved to the surface shows up
+// as deltaPosition = depth * n in the Baumgarte term (compute_acceleration)
 void toggle_contacts(Engine & e)
 {
     const Model & m = e.mdl;
@@ -958,12 +965,29 @@ void toggle_contacts(Engine & e)
     {
         const FrameP & fr = m.contacts[i];
         const SE3 oMf = e.oMi[fr.joint] * fr.M;
-        const double depth = (oMf.p.z - 0.0) * 1.0;
+        double heightGround;
+        V3 normalGround;
+        ground_profile(e, oMf.p.x, oMf.p.y, heightGround, normalGround);
+        const double depth = (oMf.p.z - heightGround) * normalGround.z;
         if (depth < 0.0) e.fcon[i].enabled = true;
         else if (depth > e.opt.contact_transition_eps)
         {
             for (double & l : e.fcon[i].lambda) l = 0.0;
             e.fcon[i].enabled = false;
+        }
+        if (e.fcon[i].enabled)
+        {
+            const V3 n = normalGround;
+            V3 c1 = cross(n, V3{1.0, 0.0, 0.0});
+            const double inv = 1.0 / std::sqrt(dot(c1, c1));
+            c1 = {c1.x * inv, c1.y * inv, c1.z * inv};
+            const V3 c0 = cross(c1, n);
+            M3 R;
+            R.m[0][0] = c0.x; R.m[1][0] = c0.y; R.m[2][0] = c0.z;
+            R.m[0][1] = c1.x; R.m[1][1] = c1.y; R.m[2][1] = c1.z;
+            R.m[0][2] = n.x; R.m[1][2] = n.y; R.m[2][2] = n.z;
+            e.fcon[i].Rloc = R;
+            e.fcon[i].depth = depth;
         }
         // contactFrameForces stay zero with this model; contactForces_ = actInv(0) (engine.cc:3417-3424)
         e.contactFrameForces[i] = Force();
@@ -1203,13 +1227,16 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         if (!e.fcon[i].enabled) continue;
         const FrameP & fr = m.contacts[i];
         const SE3 oMf = e.oMi[fr.joint] * fr.M;
-        const double depth = oMf.p.z;
-        // frame Jacobian in (rotationLocal = identity, frame translation): transformLocal.actInv(data.J col)
+        const double depth = e.fcon[i].depth;
+        const M3 & Rloc = e.fcon[i].Rloc;
+        const V3 nG = Rloc * V3{0.0, 0.0, 1.0};
+        // frame Jacobian in (rotationLocal, frame translation): transformLocal.actInv(data.J col)
+        // (frame_constraint.cc:136-146)
         for (int a = 0; a < nv; ++a)
         {
             if (!supports(fr.joint, a)) continue;
-            const V3 lin = Jw[a].lin - cross(oMf.p, Jw[a].ang);
-            J(r + 0, a) = lin.x; J(r + 1, a) = lin.y; J(r + 2, a) = lin.z; J(r + 3, a) = Jw[a].ang.z;
+            const V3 lin = tmul(Rloc, Jw[a].lin - cross(oMf.p, Jw[a].ang));
+            J(r + 0, a) = lin.x; J(r + 1, a) = lin.y; J(r + 2, a) = lin.z; J(r + 3, a) = dot(nG, Jw[a].ang);
         }
         // velocity and drift acceleration, LOCAL_WORLD_ALIGNED
         const Motion vl = actInv(fr.M, e.dv[fr.joint]);
@@ -1219,9 +1246,11 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         dlin = dlin + cross(vang, vlin);
         // Baumgarte: reference transform moved to the ground surface every evaluation
         // (engine.cc:3186-3193) -> deltaPosition = depth * n, deltaRotation = 0
-        dlin = dlin + kp * V3{0.0, 0.0, depth} + kd * vlin;
+        dlin = dlin + kp * (depth * nG) + kd * vlin;
         dang = dang + kd * vang;
-        gamma[r] = dlin.x; gamma[r + 1] = dlin.y; gamma[r + 2] = dlin.z; gamma[r + 3] = dang.z;
+        // drift in the local frame (frame_constraint.cc:172-174)
+        dlin = tmul(Rloc, dlin);
+        gamma[r] = dlin.x; gamma[r + 1] = dlin.y; gamma[r + 2] = dlin.z; gamma[r + 3] = dot(nG, dang);
         for (int k = 0; k < 4; ++k) lambda[r + k] = e.fcon[i].lambda[k];
         r += 4;
     }
@@ -1296,8 +1325,9 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         for (int k = 0; k < 4; ++k) e.fcon[i].lambda[k] = lambda[r + k];
         const FrameP & fr = m.contacts[i];
         const SE3 oMf = e.oMi[fr.joint] * fr.M;
-        const V3 fW = {lambda[r], lambda[r + 1], lambda[r + 2]};
-        const V3 tW = {0.0, 0.0, lambda[r + 3]};
+        // multipliers live in the constraint's local frame: fextInGlobal = rotationLocal * fextInLocal (engine.cc:3805-3815)
+        const V3 fW = e.fcon[i].Rloc * V3{lambda[r], lambda[r + 1], lambda[r + 2]};
+        const V3 tW = e.fcon[i].Rloc * V3{0.0, 0.0, lambda[r + 3]};
         e.contactForces[i].lin = tmul(oMf.R, fW);
         e.contactForces[i].ang = tmul(oMf.R, tW);
         Force fl;  // convertForceGlobalFrameToJoint

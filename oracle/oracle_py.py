@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
         L.orc_ziggurat_tables.argtypes = [u32p, fp, fp]
         L.orc_seed_seq.argtypes = [C.c_uint32, C.c_int32, u32p]
         L.orc_sensor_rng_seed.argtypes = [u32p, C.c_int64, C.c_int32, u64p]
+        L.orc_engine_rng_seed.argtypes = [u32p, C.c_int64, u64p]
+        L.orc_model_bias.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, C.POINTER(C.c_float), u64p, C.c_void_p, pd]
         L.orc_sensor_noise.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, u64p, pd, pd, pd]
         L.orc_sensor_delay.argtypes = [C.c_int64, C.c_int32, C.c_int32, pd, pd, C.POINTER(C.c_int32), pd, C.c_int32,
                                        u64p, pd, pd, C.c_int32]
@@ -323,6 +325,27 @@ def sensor_rng_seed(group_seed: np.ndarray, n_sensors: int) -> np.ndarray:
     lib().orc_sensor_rng_seed(gs.ctypes.data_as(C.POINTER(C.c_uint32)), gs.shape[0], n_sensors,
                               out.ctypes.data_as(C.POINTER(C.c_uint64)))
     return out
+
+
+def engine_rng_seed(seed: np.ndarray) -> np.ndarray:
+    """PCG32 states of `Engine::generator_` seeded with `std::seed_seq{seed[lane]}` (engine.cc:756-757)."""
+    sd = np.ascontiguousarray(seed, dtype=np.uint32)
+    out = np.empty(sd.shape[0], dtype=np.uint64)
+    lib().orc_engine_rng_seed(sd.ctypes.data_as(C.POINTER(C.c_uint32)), sd.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
+
+
+def model_bias(nominal: np.ndarray, first_joint: int, std4, rng: np.ndarray, out: np.ndarray, mask=None) -> None:
+    """`Model::addBiasedToExtendedModel` per lane: `nominal` `[njoints][25]`, `std4` (inertia, mass, com, position),
+    `rng` `[B]` uint64 in / out, `out` `[13 * njoints][B]` float64 (rows of the masked-out lanes / of the joints
+    before `first_joint` are left as they are)."""
+    nom = np.ascontiguousarray(nominal, dtype=np.float64)
+    s4 = np.ascontiguousarray(std4, dtype=np.float32)
+    assert rng.dtype == np.uint64 and rng.flags.c_contiguous and out.dtype == np.float64 and out.flags.c_contiguous
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_model_bias(out.shape[1], nom.shape[0], first_joint, nom.ctypes.data_as(C.POINTER(C.c_double)),
+                         s4.ctypes.data_as(C.POINTER(C.c_float)), rng.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         None if m is None else m.ctypes.data, out.ctypes.data_as(C.POINTER(C.c_double)))
 
 
 def sensor_noise(data: np.ndarray, rng: np.ndarray, n_sensors: int, n_fields: int, noise_std=None, bias=None,

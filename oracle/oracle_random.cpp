@@ -9,6 +9,8 @@
 //   normal()             normal(g, mean, stddev)               random.cc:164-167
 //   orc_sensor_noise     AbstractSensorBase::measureData       core/src/hardware/abstract_sensor.cc:71-85
 //                        ImuSensor::measureData                core/src/hardware/basic_sensors.cc:166-187
+//   orc_model_bias       Model::addBiasedToExtendedModel       core/src/robot/model.cc:1166-1236
+//   orc_engine_rng_seed  Engine::generator_ seeding            core/src/engine/engine.cc:756-757, utilities/random.hxx:20-51
 //   orc_sensor_rng_seed  AbstractSensorTpl<T>::resetAll        core/include/jiminy/core/hardware/abstract_sensor.hxx:213-226
 //                        -- std::seed_seq is the real libstdc++ class, as in the reference build
 // Parity status: the reference holds no golden vectors for its generators (core/unit/random_test.cc
@@ -151,6 +153,86 @@ void orc_seed_seq(uint32_t seed, int32_t n, uint32_t * out)
     std::vector<uint32_t> w((size_t)n);
     seq.generate(w.begin(), w.end());
     for (int32_t i = 0; i < n; ++i) out[i] = w[i];
+}
+// ---- model biases: Model::addBiasedToExtendedModel (core/src/robot/model.cc:1166-1236), one robot per lane.
+// The engine generator of a lane: PCG32(std::seed_seq{seed}) through internal::generateState
+// (core/include/jiminy/core/utilities/random.hxx:20-51: two 32-bit words, low word first; engine.cc:756-757)
+void orc_engine_rng_seed(const uint32_t * seed, int64_t B, uint64_t * state_out)
+{
+    for (int64_t l = 0; l < B; ++l)
+    {
+        std::seed_seq seq{seed[l]};
+        std::array<uint32_t, 2> buffer;
+        seq.generate(buffer.begin(), buffer.end());
+        uint64_t value = 0;
+        uint32_t shift = 0;
+        for (std::size_t j = 0; j < 2; ++j)
+        {
+            value |= static_cast<uint64_t>(buffer[j]) << shift;
+            shift += 32;
+        }
+        state_out[l] = Pcg32(value).state();
+    }
+}
+// nominal [njoints][25]: mass | com 3 | inertia xx xy xz yy yz zz | placement translation 3 | principal moments 3 |
+// principal axes 9 (row-major, columns = eigenvectors) -- the eigen-decomposition is an input because its sign /
+// ordering conventions are the solver's (Eigen::SelfAdjointEigenSolver in the reference), not part of the law.
+// std4: inertia, mass, com, relative position.  out [13 * njoints][B]; rng [B] in / out; mask [B] or null.
+void orc_model_bias(int64_t B, int32_t njoints, int32_t first_joint, const double * nominal, const float * std4,
+                    uint64_t * rng, const uint8_t * mask, double * out)
+{
+    const double EPS = std::numeric_limits<double>::epsilon();
+    const float inertiaBiasStd = std4[0], massBiasStd = std4[1], comBiasStd = std4[2], relativeBodyPosBiasStd = std4[3];
+    for (int64_t l = 0; l < B; ++l)
+    {
+        if (mask && !mask[l]) continue;
+        Pcg32 g(rng[l]);
+        for (int32_t j = first_joint; j < njoints; ++j)   // mechanicalJointNames_: every joint but the free-flyer root
+        {
+            const double * nom = nominal + 25 * j;
+            double mass = nom[0], com[3] = {nom[1], nom[2], nom[3]}, I[6] = {nom[4], nom[5], nom[6], nom[7], nom[8], nom[9]};
+            double pos[3] = {nom[10], nom[11], nom[12]};
+            if (comBiasStd > EPS)
+                for (int i = 0; i < 3; ++i) com[i] *= static_cast<double>(normal(g, 1.0F, comBiasStd));
+            if (massBiasStd > EPS)
+                mass = std::max(mass * normal(g, 1.0F, massBiasStd), std::min(mass, 1.0e-3));
+            if (inertiaBiasStd > EPS)
+            {
+                double randAxis[3];
+                for (int i = 0; i < 3; ++i) randAxis[i] = static_cast<double>(normal(g, 0.0F, inertiaBiasStd));
+                // pinocchio::exp3 (explog.hpp)
+                const double t2 = randAxis[0] * randAxis[0] + randAxis[1] * randAxis[1] + randAxis[2] * randAxis[2];
+                const double t = std::sqrt(t2);
+                double alpha_vxvx, alpha_vx, diag;
+                if (t > 1.220703125e-4) { alpha_vxvx = (1.0 - std::cos(t)) / t2; alpha_vx = std::sin(t) / t; diag = std::cos(t); }
+                else { alpha_vxvx = 0.5 - t2 / 24.0; alpha_vx = 1.0 - t2 / 6.0; diag = 1.0 - t2 / 2.0; }
+                double R[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) R[a][b] = alpha_vxvx * randAxis[a] * randAxis[b];
+                R[0][1] -= alpha_vx * randAxis[2]; R[1][0] += alpha_vx * randAxis[2];
+                R[0][2] += alpha_vx * randAxis[1]; R[2][0] -= alpha_vx * randAxis[1];
+                R[1][2] -= alpha_vx * randAxis[0]; R[2][1] += alpha_vx * randAxis[0];
+                for (int a = 0; a < 3; ++a) R[a][a] += diag;
+                // inertiaBodyAxes = inertiaBodyAxes * Quaterniond(exp3(randAxis)); moments *= normal(3, 1, g, 1, std)
+                double A[3][3], M[3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        A[a][b] = nom[16 + 3 * a] * R[0][b] + nom[16 + 3 * a + 1] * R[1][b] + nom[16 + 3 * a + 2] * R[2][b];
+                for (int i = 0; i < 3; ++i) M[i] = nom[13 + i] * static_cast<double>(normal(g, 1.0F, inertiaBiasStd));
+                int o = 0;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a; b < 3; ++b) I[o++] = A[a][0] * M[0] * A[b][0] + A[a][1] * M[1] * A[b][1] + A[a][2] * M[2] * A[b][2];
+            }
+            if (relativeBodyPosBiasStd > EPS)
+                for (int i = 0; i < 3; ++i) pos[i] *= static_cast<double>(normal(g, 1.0F, relativeBodyPosBiasStd));
+            double * o = out + (size_t)(13 * j) * B + l;
+            o[0] = mass;
+            for (int i = 0; i < 3; ++i) o[(size_t)(1 + i) * B] = com[i];
+            for (int i = 0; i < 6; ++i) o[(size_t)(4 + i) * B] = I[i];
+            for (int i = 0; i < 3; ++i) o[(size_t)(10 + i) * B] = pos[i];
+        }
+        rng[l] = g.state();
+    }
 }
 // states [n_sensors][B] of AbstractSensorTpl::resetAll(group_seed[lane]) for every lane
 void orc_sensor_rng_seed(const uint32_t * group_seed, int64_t B, int32_t n_sensors, uint64_t * state_out)

@@ -1,0 +1,99 @@
+"""Scalar restatement of the reference's random tile terrain. TEST INFRASTRUCTURE ONLY (same rules as oracle.cpp).
+
+Follows core/src/utilities/random.cc line by line: `xxHash` (:200-256), `uniformSparseFromStateImpl` (:488-501),
+`tile2dInterp1d` (:511-550), `tiles` (:552-656).  Pinned in tests/test_terrain.py: the hash against the independent
+`xxhash` package (XXH32 reference implementation), the generator on its structural laws (constant tile interiors,
+continuity across the blend bands, sparsity)."""
+import math
+import struct
+
+import numpy as np
+
+P1, P2, P3, P4, P5 = 2654435761, 2246822519, 3266489917, 668265263, 374761393
+M = 0xFFFFFFFF
+
+
+def rotl32(x, r):
+    return ((x << r) | (x >> (32 - r))) & M
+
+
+def xx_hash(data: bytes, seed: int) -> int:
+    n, i = len(data), 0
+    if n >= 16:
+        v1, v2, v3, v4 = (seed + P1 + P2) & M, (seed + P2) & M, seed & M, (seed - P1) & M
+        rnd = lambda acc, w: (rotl32((acc + w * P2) & M, 13) * P1) & M  # noqa: E731
+        while i <= n - 16:
+            w = struct.unpack_from("<4I", data, i)
+            v1, v2, v3, v4 = rnd(v1, w[0]), rnd(v2, w[1]), rnd(v3, w[2]), rnd(v4, w[3])
+            i += 16
+        h = (rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18)) & M
+    else:
+        h = (seed + P5) & M
+    h = (h + n) & M
+    while n - i >= 4:
+        h = (h + struct.unpack_from("<I", data, i)[0] * P3) & M
+        h = (rotl32(h, 17) * P4) & M
+        i += 4
+    while i < n:
+        h = (h + data[i] * P5) & M
+        h = (rotl32(h, 11) * P1) & M
+        i += 1
+    h ^= h >> 15
+    h = (h * P2) & M
+    h ^= h >> 13
+    h = (h * P3) & M
+    h ^= h >> 16
+    return h
+
+
+def uniform_sparse(data: bytes, sparsity: int, seed: int) -> float:
+    h = xx_hash(data, seed)
+    if h % sparsity == 0:
+        return float(np.float32(h) / np.float32(M))
+    return 0.0
+
+
+def tile_2d_interp_1d(idx, rel, dim, size, sparsity, height_max, thr, seed):
+    key = lambda ij: struct.pack("<2i", *ij)  # noqa: E731
+    idx = list(idx)
+    z = height_max * uniform_sparse(key(idx), sparsity, seed)
+    if rel[dim] < thr[dim]:
+        idx[dim] -= 1
+        z_m = height_max * uniform_sparse(key(idx), sparsity, seed)
+        idx[dim] += 1
+        ratio = (1.0 - rel[dim] / thr[dim]) / 2.0
+        return z + (z_m - z) * ratio, (z - z_m) / (2.0 * size[dim] * thr[dim])
+    if 1.0 - rel[dim] < thr[dim]:
+        idx[dim] += 1
+        z_p = height_max * uniform_sparse(key(idx), sparsity, seed)
+        idx[dim] -= 1
+        ratio = (1.0 + (rel[dim] - 1.0) / thr[dim]) / 2.0
+        return z + (z_p - z) * ratio, (z_p - z) / (2.0 * size[dim] * thr[dim])
+    return z, 0.0
+
+
+def tiles(size, height_max, interp_delta, sparsity, orientation, seed):
+    size = [float(size[0]), float(size[1])]
+    thr = [min(max(float(interp_delta[i]), 0.01), size[i] / 2.0) / size[i] for i in range(2)]
+    offset = [size[i] * uniform_sparse(struct.pack("<q", i), 1, seed) for i in range(2)]
+    c, s = math.cos(orientation), math.sin(orientation)
+
+    def heightmap(x, y):
+        px, py = x + offset[0], y + offset[1]
+        rel = [(c * px - s * py) / size[0], (s * px + c * py) / size[1]]
+        idx = [int(math.floor(rel[0])), int(math.floor(rel[1]))]
+        rel = [rel[0] - idx[0], rel[1] - idx[1]]
+        edge = [rel[i] < thr[i] or 1.0 - rel[i] < thr[i] for i in range(2)]
+        if edge[0] and not edge[1]:
+            return tile_2d_interp_1d(idx, rel, 0, size, sparsity, height_max, thr, seed)[0]
+        if not edge[0] and edge[1]:
+            return tile_2d_interp_1d(idx, rel, 1, size, sparsity, height_max, thr, seed)[0]
+        if edge[0] and edge[1]:
+            h0, _ = tile_2d_interp_1d(idx, rel, 0, size, sparsity, height_max, thr, seed)
+            if rel[1] < thr[1]:
+                hm, _ = tile_2d_interp_1d([idx[0], idx[1] - 1], rel, 0, size, sparsity, height_max, thr, seed)
+                return h0 + (hm - h0) * ((1.0 - rel[1] / thr[1]) / 2.0)
+            hp, _ = tile_2d_interp_1d([idx[0], idx[1] + 1], rel, 0, size, sparsity, height_max, thr, seed)
+            return h0 + (hp - h0) * ((1.0 + (rel[1] - 1.0) / thr[1]) / 2.0)
+        return height_max * uniform_sparse(struct.pack("<2i", *idx), sparsity, seed)
+    return heightmap

@@ -33,8 +33,8 @@ def oracle_batch(model: CompiledModel, arr: Dict[str, np.ndarray], mode: str, op
     if constraint_options is not None:
         e.set_constraint_options(**constraint_options)
         e.bind_constraints(arr["con_flags"], arr["con_data"])
-        if arr.get("friction") is not None:
-            e.bind_friction(arr["friction"])
+    if arr.get("friction") is not None:     # per-lane contacts.friction, either contact model
+        e.bind_friction(arr["friction"])
     e.batch_run(mode, oracle_io(arr), **kw)
 
 

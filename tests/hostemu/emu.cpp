@@ -238,7 +238,8 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.mask = (const unsigned char *)io->mask; A.q_init = (const T *)io->q_init; A.v_init = (const T *)io->v_init;
     A.B = io->B; A.mode = mode; A.solver = solver; A.n_sub = n_sub; A.command_changed = command_changed;
     A.update_sensors = update_sensors; A.dt = (T)dt;
-    const bool gen = g_model_lane || g_ground || g_applied;
+    A.friction = g_copt.contact_model == JM_CONTACT_CONSTRAINT ? nullptr : (const T *)g_friction;
+    const bool gen = g_model_lane || g_ground || g_applied || A.friction;
     A.model_lane = (const T *)g_model_lane;
     A.ground_h = (const T *)g_ground; A.ground_nx = g_gnx; A.ground_ny = g_gny;
     A.ground_x0 = (T)g_gx0; A.ground_y0 = (T)g_gy0; A.ground_dx = (T)g_gdx; A.ground_dy = (T)g_gdy;
@@ -256,6 +257,8 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
             C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
             C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
+            C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
+            C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
             if (gen) run_quad_con<T, Topo, true>(A, P, C);
             else run_quad_con<T, Topo>(A, P, C);
         }

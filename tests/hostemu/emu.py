@@ -76,11 +76,11 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     if constraint_options is not None:
         co = _abi.make_constraint_options(**constraint_options)
         L.emu_set_constraints(C.byref(co), arrays["con_flags"].ctypes.data, arrays["con_data"].ctypes.data)
-        fr = arrays.get("friction")
-        L.emu_set_friction(fr.ctypes.data if fr is not None else None)
     else:
         co = _abi.make_constraint_options(model="spring_damper")
         L.emu_set_constraints(C.byref(co), None, None)
+    fr = arrays.get("friction")
+    L.emu_set_friction(fr.ctypes.data if fr is not None else None)
     if variant == "quad" and not L.emu_has_quad():
         raise RuntimeError("this topology has no limb-parallel variant")
     L.emu_set_variant(1 if variant == "quad" else 0)

