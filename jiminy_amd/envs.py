@@ -71,6 +71,10 @@ class VecJiminyEnv:
         self._generator = torch.Generator(device="cpu")
         self.num_steps = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)
         self._t0 = torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
+        # engine time on the device (set from the host clock around every step, never read back): episode times,
+        # truncation and the reset bookkeeping are tensor programs that a captured graph can replay
+        self._clock = torch.zeros((), dtype=self.dtype, device=self.device)
+        self._state_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._q0 = None
         self._v0 = None
         q_neutral, _ = self._sample_state_numpy()
@@ -117,7 +121,7 @@ class VecJiminyEnv:
 
     # ------------------------------------------------------------------ gym surface
     def _lane_time(self) -> torch.Tensor:
-        return self.engine.stepper_state.t - self._t0
+        return self._clock - self._t0
 
     def observation(self) -> ObsType:
         rs = self.engine.robot_state
@@ -147,6 +151,7 @@ class VecJiminyEnv:
         self.engine.start(q, v)
         self.num_steps.zero_()
         self._t0.zero_()
+        self._clock.zero_()
         return self.observation(), {}
 
     def step(self, action: torch.Tensor
@@ -157,17 +162,22 @@ class VecJiminyEnv:
         if tuple(action.shape) != (self.num_envs, self.model.nmotors):
             raise ValueError(f"action must have shape ({self.num_envs}, {self.model.nmotors})")
         self._step_engine(action)
-        self.num_steps += 1
-        terminated, truncated = self.has_terminated()
-        reward = self.compute_reward(terminated)
+        self._clock.fill_(float(self.engine._t))
+        reward, terminated, truncated, done = self._after_step()
         info: Dict[str, Any] = {}
-        done = terminated | truncated
         if self.auto_reset and bool(done.any()):
             # gymnasium "next-step" autoreset would cost a launch per step; lanes are reset in
             # place here and the final observation of the finished lanes is not returned
             info["reset_mask"] = done
             self.reset_lanes(done)
         return self.observation(), reward, terminated, truncated, info
+
+    def _after_step(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Episode bookkeeping after the engine advanced (tensor programs only, no host read-back)."""
+        self.num_steps += 1
+        terminated, truncated = self.has_terminated()
+        reward = self.compute_reward(terminated)
+        return reward, terminated, truncated, terminated | truncated
 
     def _step_engine(self, action: torch.Tensor) -> None:
         self.engine.set_command(self.compute_command(action))
@@ -202,7 +212,7 @@ class VecJiminyEnv:
             self._impulse_index += 1
 
     def reset_lanes(self, lane_mask: torch.Tensor) -> None:
-        q, v = self._sample_state(self.num_envs)
+        q, v = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)
         self._on_reset(lane_mask)
         self._randomise_ground(lane_mask)
         # a fresh episode starts from a zero command like `reset()` (for the PD pipeline it IS the controller's
@@ -215,10 +225,19 @@ class VecJiminyEnv:
             self.engine.sample_model_biases(lane_mask)     # a new biased model for the new episode (Model::reset)
         if self._f_xy_profile is not None and float(self.std_ratio.get("disturbance", 0.0)) > 0.0:
             for proc in self._f_xy_profile:
-                proc.reset(self._generator, lane_mask=lane_mask)   # `func.reset(self.np_random)` of the new episode
+                # `func.reset(self.np_random)` of the new episode; drawn by the device generator (all lanes, the masked
+                # ones keep the draw): no host normals, no host -> device copy on the auto-reset path
+                proc.reset(self._device_generator(), lane_mask=lane_mask)
         self.engine.reset_lanes(lane_mask, q, v)
-        self.num_steps[lane_mask] = 0
-        self._t0 = torch.where(lane_mask, torch.full_like(self._t0, self.engine.stepper_state.t), self._t0)
+        self.num_steps.masked_fill_(lane_mask, 0)
+        self._t0.copy_(torch.where(lane_mask, self._clock.expand_as(self._t0), self._t0))
+
+    def _device_generator(self) -> torch.Generator:
+        g = getattr(self, "_dev_gen", None)
+        if g is None:
+            g = self._dev_gen = torch.Generator(device=self.device)
+            g.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._generator)))
+        return g
 
     def _randomise_ground(self, lane_mask: Optional[torch.Tensor]) -> None:
         """Ground friction of the environments being reset, ≙ `sample(*GROUND_FRICTION_RANGE,
@@ -269,6 +288,7 @@ class VecJiminyEnv:
         if self._f_xy_profile is None:
             self._f_xy_profile = [PeriodicGaussianProcess(self.F_PROFILE_WAVELENGTH, self.F_PROFILE_PERIOD, B, self.dtype, self.device),
                                   PeriodicGaussianProcess(self.F_PROFILE_PERIOD, self.F_PROFILE_PERIOD, B, self.dtype, self.device)]
+        self._dev_gen = None          # re-seeded from the (just re-seeded) host generator at its next use
         for proc in self._f_xy_profile:
             proc.reset(g)
 
@@ -446,8 +466,10 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         return enc[:, self._enc_idx]
 
     def _on_reset(self, lane_mask: Optional[torch.Tensor]) -> None:
-        q0, _ = self._sample_state(self.num_envs)
-        target = torch.stack([q0[m.idx_q] * m.reduction for m in self.model.motors])
+        q0, _ = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)
+        if lane_mask is None or getattr(self, "_target_cache", None) is None:
+            self._target_cache = torch.stack([q0[m.idx_q] * m.reduction for m in self.model.motors])
+        target = self._target_cache
         if lane_mask is None:
             self._graph = None      # a full reset restarts the engine: the step graph is captured again
             self.command_state.zero_()
@@ -470,19 +492,30 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
                 t.copy_(torch.where(lane_mask[None, :], torch.zeros_like(t), t))
 
     # ------------------------------------------------------------------ HIP-graph replay of one environment step
-    def enable_graph(self, enable: bool = True) -> None:
+    def enable_graph(self, enable: bool = True, whole_step: bool = False) -> None:
         """Replay the launches of one environment step -- PD adapter, then per controller tick PD controller -> physics
         launch -> Mahony filter: 26 launches for ANYmal -- as ONE captured HIP graph instead of issuing them from
         Python.  For small batches per GPU (a sharded config 4 / 5: a few thousand environments) the step is bound by
         the host's launch rate, not by the kernels; at B = 65 536 it makes no difference.  Needs the HIP blocks, a
         fixed-step solver, no sensor noise / delay and no applied forces (their host-side schedules run between the
-        launches).  The graph is captured at the next `step` and dropped by `reset`."""
+        launches).  The graph is captured at the next `step` and dropped by `reset`.
+
+        `whole_step=True` captures the WHOLE `env.step`: the physics chain, the episode clock, termination / truncation,
+        the reward and an unconditional masked auto-reset (`reset_lanes` with the `done` mask: lanes that are not done
+        leave its launches at once) -- no host read-back at all (`bool(done.any())` of the eager step is the one
+        synchronisation per environment step).  `step` then returns static tensors (`reward`, `terminated`, `truncated`,
+        `info["reset_mask"]`) that the next `step` overwrites.  Additionally needs `auto_reset`, no ground-friction
+        randomisation and the deterministic default state sampler (model biases are fine: drawn on the device)."""
         if enable:
             eng = self.engine
-            if self._hip_blocks is None or eng._adaptive is not None or eng._sensor_noise or eng._impulse_forces or eng._profile_forces:
+            if self._hip_blocks is None or eng._adaptive is not None or eng._sensor_noise or eng._impulse_forces or eng._profile_forces \
+                    or getattr(self, "_impulse_frame", None) is not None:
                 raise NotImplementedError("enable_graph needs the HIP blocks, a fixed-step solver, noiseless sensors and "
                                           "no applied forces")
+            if whole_step and (not self.auto_reset or float(self.std_ratio.get("ground", 0.0)) > 0.0):
+                raise NotImplementedError("whole-step graphs need auto_reset and no ground-friction randomisation")
         self._graph_enabled = bool(enable)
+        self._graph_whole = bool(enable and whole_step)
         self._graph = None
 
     def _step_engine_graphed(self, action: torch.Tensor) -> None:
@@ -494,8 +527,14 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
             host = (eng._t, eng._t_prev, eng._t_error, eng._iter, eng._dt, eng._command_dirty)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
+            if self._graph_whole:
+                self._state_cache = self._sample_state(self.num_envs)    # (host -> device copies are not capturable)
             with torch.cuda.graph(g):
                 self._issue_step(self._g_action)          # recorded, not executed
+                if self._graph_whole:
+                    reward, terminated, truncated, done = self._after_step()
+                    self._g_out = (reward, terminated, truncated, done)
+                    self.reset_lanes(done)
             after = (eng._t, eng._iter, eng._dt)
             eng._t, eng._t_prev, eng._t_error, eng._iter, eng._dt, eng._command_dirty = host
             self._graph = (g, plan, after[0] - host[0], after[1] - host[3], after[2])
@@ -506,16 +545,29 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
             self._graph = None                            # (never seen: the plan is periodic; re-capture if it is not)
             return self._step_engine_graphed(action)
         self._g_action.copy_(action.to(self.dtype).T)
-        g.replay()
-        # host-side bookkeeping of the `n_ctrl` engine steps the graph stands for (Kahan-compensated like engine.step)
+        # host-side bookkeeping of the `n_ctrl` engine steps the graph stands for (Kahan-compensated like engine.step);
+        # the device clock gets the end time before the replay: the captured episode bookkeeping reads it
         for _ in range(self._n_ctrl):
             corrected = self.control_dt - eng._t_error
             t_end = eng._t + corrected
             eng._t_error = (t_end - eng._t) - corrected
             eng._t_prev, eng._t = eng._t, t_end
+        self._clock.fill_(float(eng._t))
+        g.replay()
         eng._iter += d_iter
         eng._dt = dt_last
         eng._command_dirty = False
+
+    def step(self, action: torch.Tensor):
+        if not getattr(self, "_graph_whole", False):
+            return super().step(action)
+        if not self.engine.is_simulation_running:
+            raise RuntimeError("No simulation running. Please call `reset` before `step`.")
+        if tuple(action.shape) != (self.num_envs, self.model.nmotors):
+            raise ValueError(f"action must have shape ({self.num_envs}, {self.model.nmotors})")
+        self._step_engine_graphed(action)
+        reward, terminated, truncated, done = self._g_out
+        return self.observation(), reward, terminated, truncated, {"reset_mask": done}
 
     def _step_engine(self, action: torch.Tensor) -> None:
         if getattr(self, "_graph_enabled", False):

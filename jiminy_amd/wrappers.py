@@ -55,7 +55,12 @@ class _Wrapper:
         return obs
 
     def observation(self) -> Any:
-        return self.transform(self.env.observation())
+        """Current observation.  Read-only with respect to the wrapper's own state: wrappers that accumulate (the
+        observation stack) update in `reset` / `step` only and answer here from what they hold (`peek`)."""
+        return self.peek(self.env.observation())
+
+    def peek(self, obs: Any) -> Any:
+        return self.transform(obs)
 
     def reset(self, *args: Any, **kw: Any):
         obs, info = self.env.reset(*args, **kw)
@@ -116,12 +121,23 @@ class StackObservation(_Wrapper):
             elif shift and self.num_stack > 1:
                 st[:, :-1] = st[:, 1:].clone()
             st[:, -1] = x
-            out = _set_path(out, path, st)
+            # (a copy: the ring buffer is rewritten by the next step, a rollout buffer that keeps the returned
+            # observation must not see that)
+            out = _set_path(out, path, st.clone())
         self._n_since_shift = 0 if shift else self._n_since_shift + 1
         return out
 
-    def step(self, action: torch.Tensor):
-        return super().step(action)
+    def peek(self, obs: Any) -> Any:
+        """The stack as it stands (copies), without shifting it: `observation()` between two steps."""
+        out = obs
+        for path, x in flatten_with_path(obs):
+            if self._selected(path):
+                st = self._stack.get(path)
+                if st is None:   # nothing stacked yet: zeros and the current frame, like the first `transform`
+                    st = torch.zeros((x.shape[0], self.num_stack) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                    st[:, -1] = x
+                out = _set_path(out, path, st.clone())
+        return out
 
 
 class NormalizeObservation(_Wrapper):

@@ -435,6 +435,46 @@ def test_graph_replay_of_the_environment_step_is_bit_identical(gpu_device):
         e.enable_graph()
 
 
+def test_whole_environment_step_as_one_graph_matches_the_eager_step(gpu_device):
+    """`enable_graph(whole_step=True)`: physics chain + episode clock + termination / truncation + reward + the masked
+    auto-reset (with per-environment model biases re-drawn on the device for the lanes that restart) captured as ONE graph,
+    no host read-back per step.  Wild actions make robots fall: observations, rewards, termination flags, reset masks and
+    episode counters must equal the eager environment's bit for bit over many auto-resets."""
+    B = 512
+    mo = {"dynamics": {"massBodiesBiasStd": 0.05}}
+    envs = [make_anymal_env(B, device=gpu_device, dt_max=1e-3, model_options=mo, simulation_duration_max=0.6) for _ in range(2)]
+    for e in envs:
+        e.reset(seed=9)
+    envs[1].enable_graph(whole_step=True)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    n_reset = 0
+    for i in range(30):
+        action = (6.0 * torch.randn(B, 12, generator=g, dtype=torch.float64)).to(gpu_device)
+        o0, r0, te0, tr0, i0 = envs[0].step(action)
+        o1, r1, te1, tr1, i1 = envs[1].step(action)
+        done0 = i0.get("reset_mask", torch.zeros_like(te0))
+        assert torch.equal(done0, i1["reset_mask"]), i
+        n_reset += int(done0.sum())
+        for k in ("q", "v"):
+            assert torch.equal(o0["states"]["agent"][k], o1["states"]["agent"][k]), (i, k)
+        assert torch.equal(o0["t"], o1["t"]) and torch.equal(o0["features"]["mahony_filter"], o1["features"]["mahony_filter"])
+        assert torch.equal(r0, r1) and torch.equal(te0, te1) and torch.equal(tr0, tr1)
+        assert torch.equal(envs[0].num_steps, envs[1].num_steps)
+        assert torch.equal(envs[0].engine.field("model_lane"), envs[1].engine.field("model_lane"))
+    assert n_reset > B // 4 and envs[1]._graph is not None
+    # a full reset drops the graph; the next step captures it again
+    for e in envs:
+        e.reset(seed=10)
+    assert envs[1]._graph is None
+    action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
+    a, b = envs[0].step(action), envs[1].step(action)
+    assert torch.equal(a[0]["states"]["agent"]["q"], b[0]["states"]["agent"]["q"]) and envs[1]._graph is not None
+    with pytest.raises(NotImplementedError):
+        e = make_anymal_env(8, device=gpu_device, dt_max=1e-3, contact_model="constraint", std_ratio={"ground": 0.2})
+        e.reset(seed=1)
+        e.enable_graph(whole_step=True)
+
+
 def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
     """`make_atlas_env` ≙ `AtlasPDControlJiminyEnv` (gym_jiminy envs/atlas.py): 30 motors under MotorSafetyLimit -> PD
     controller -> PD adapter, Mahony filter, constraint contact model, Euler 1 ms / controller 5 ms.  With a zero action

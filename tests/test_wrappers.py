@@ -49,6 +49,14 @@ def test_stack_observation_rolls_oldest_first_and_restarts_reset_lanes():
     assert torch.equal(q[1], torch.zeros(3, 2))                           # zero history + fresh (zero) observation
     obs, *_ = env.step(a)
     assert torch.equal(obs["states"]["agent"]["q"][1, :, 0], torch.tensor([0.0, 0.0, 1.0]))
+    # `observation()` between two steps reads the stack without shifting it, and what a step returned is a copy that
+    # later steps do not rewrite (a rollout buffer may keep it)
+    kept = obs["states"]["agent"]["q"].clone()
+    peek1, peek2 = env.observation(), env.observation()
+    assert torch.equal(peek1["states"]["agent"]["q"], kept) and torch.equal(peek2["states"]["agent"]["q"], kept)
+    nxt, *_ = env.step(a)
+    assert torch.equal(obs["states"]["agent"]["q"], kept) and not torch.equal(nxt["states"]["agent"]["q"], kept)
+    assert torch.equal(nxt["states"]["agent"]["q"][0, :, 0], torch.tensor([3.0, 4.0, 5.0]))
     with pytest.raises(ValueError):
         StackObservation(_Env(), num_stack=2, nested_filter_keys=[("nothing",)]).reset()
     # skip_frames_ratio = 1: the stack shifts every other step, the last frame is always the current value
