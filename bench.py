@@ -357,7 +357,8 @@ def main() -> None:
                                        os.environ.get("JM_KERNEL_VARIANT") != "lane") else "jm::k_batch"
         traffic = None
         valu = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        # counters of the latest committed profile of this workload (tools/gpu_profile.sh -> profiles/)
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.model == "anymal" else f"pmc_{args.model}_latest.json")
         if constrained:
             # + the per-lane constraint state read and written once per step (flags int32, reference
             # configurations + multipliers); the delassus workspace is scratch, not algorithmic traffic
