@@ -170,15 +170,15 @@ enum {
     JM_F_CON_DATA = 19,    /* [n_data_rows] in/out: JointConstraint::configurationRef_ per bounded joint, then
                               the Lagrange multipliers `lambda_` of every constraint row (PGS warm start) */
     JM_F_FRICTION = 20,    /* [1] in, optional: contacts.friction of every lane (domain randomisation of the ground
-                              friction, gym_jiminy envs/locomotion.py:257-262); constraint contact model only,
-                              unbound = the batch-wide contacts.friction option */
+                              friction, gym_jiminy envs/locomotion.py:257-262); both contact models (spring-damper:
+                              branch-parallel topologies), unbound = the batch-wide contacts.friction option */
     JM_F_MODEL_LANE = 21,  /* [13 * njoints] in, optional: body parameters of every lane, rows per joint
                               mass | com 3 | inertia xx xy xz yy yz zz | joint placement translation 3 -- the
                               output of Model::addBiasedToExtendedModel (core/src/robot/model.cc:1166-1236: mass,
                               centre of mass, inertia and relative body position biases), one model per
                               environment; branch-parallel topologies, float64; unbound = the model's own */
-    JM_F_APPLIED = 22,     /* [6 * K] in, optional: world-aligned (force, moment) applied at K <= 4 frames of the
-                              ROOT joint (jm_batch_set_applied_frames), i.e. the current value of the impulse /
+    JM_F_APPLIED = 22,     /* [6 * K] in, optional: world-aligned (force, moment) applied at K <= 4 frames of any
+                              joint (jm_batch_set_applied_frames), i.e. the current value of the impulse /
                               profile forces of core/src/engine/engine.cc:1838-2016 (the caller owns their time
                               schedule and cuts the launches at their breakpoints); branch-parallel topologies */
     JM_F_COUNT = 23
@@ -236,13 +236,16 @@ int32_t jm_batch_constraint_rows(const jm_batch * batch, int32_t * n_flag_rows, 
 /* world.groundProfile (core/include/jiminy/core/engine/engine.h:292-302, used by
  * computeContactDynamicsAtFrame, core/src/engine/engine.cc:3138-3145) as a height map: `heights` is a device
  * array `[ny][nx]` in the batch dtype, sampled at (x0 + ix dx, y0 + iy dy) with bilinear patches (height and
- * unit normal), flat continuation outside the grid; NULL = flat ground at z = 0.  Spring-damper contact
- * model, branch-parallel topologies. */
+ * unit normal), flat continuation outside the grid; NULL = flat ground at z = 0.  Both contact models (the rows of
+ * a contact constraint live in the local frame of the surface, FrameConstraint::setNormal), branch-parallel topologies. */
 int32_t jm_batch_set_ground(jm_batch * batch, const void * heights, int32_t nx, int32_t ny, double x0, double y0,
                             double dx, double dy);
-/* Frames of the root joint that carry the JM_F_APPLIED wrenches: `offsets` = K x 3 frame positions in the
- * root joint frame (K <= 4; K = 0 disables). */
-int32_t jm_batch_set_applied_frames(jm_batch * batch, int32_t k, const double * offsets);
+/* Frames that carry the JM_F_APPLIED wrenches (`Engine::registerImpulseForce` / `registerProfileForce`,
+ * core/src/engine/engine.cc:1838-1935, accept any frame of the model): `offsets` = K x 3 frame positions in the frame of
+ * their parent joint, `joints` = the K parent joint indices (NULL = all on the root joint); K <= 4, K = 0 disables.
+ * Every dynamics evaluation adds the wrench to `fext[parent joint]` in the joint frame, like
+ * `Engine::computeExternalForces` (engine.cc:3481-3560) through `convertForceGlobalFrameToJoint`. */
+int32_t jm_batch_set_applied_frames(jm_batch * batch, int32_t k, const double * offsets, const int32_t * joints);
 /* Lend a device pointer for one field; NULL unbinds an optional output. */
 int32_t jm_batch_bind(jm_batch * batch, int32_t field, void * device_ptr);
 

@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3

@@ -98,7 +98,7 @@ class HipLibrary:
         L.jm_batch_set_constraint_options.argtypes = [vp, C.POINTER(_abi.ConstraintOptions)]
         L.jm_batch_constraint_rows.argtypes = [vp, ip, ip, ip]
         L.jm_batch_set_ground.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
-        L.jm_batch_set_applied_frames.argtypes = [vp, C.c_int32, dp]
+        L.jm_batch_set_applied_frames.argtypes = [vp, C.c_int32, dp, ip]
         for name in ABI_SYMBOLS:
             getattr(L, name)  # AttributeError if a declared symbol is not exported
             if name not in ("jm_topology_signature",):

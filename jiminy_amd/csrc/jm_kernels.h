@@ -124,6 +124,7 @@ template<class T> struct BatchArgs
     const T * applied;
     int applied_k;
     T applied_p[12];
+    int applied_joint[4];   // parent joint of every frame: the wrench goes to that joint (engine.cc:3481-3560)
     // `[1][B]` ground friction coefficient of every lane (spring-damper model; the constraint model reads its own
     // copy, QConArgs / ConArgs), or null: `contacts.friction` randomised per environment (envs/locomotion.py:257-262)
     const T * friction;

@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 3
+#define JM_ABI_VERSION 4
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -102,6 +102,7 @@ struct jm_batch
     double ground_x0 = 0, ground_y0 = 0, ground_dx = 1, ground_dy = 1;
     int applied_k = 0;
     double applied_p[12] = {0};
+    int applied_joint[4] = {1, 1, 1, 1};
     int n_cus = 256;   // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     // per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg)
     bool timing = false;
@@ -174,6 +175,7 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     A.applied = b->applied_k > 0 ? (const T *)b->field[JM_F_APPLIED] : nullptr;
     A.applied_k = A.applied ? b->applied_k : 0;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)b->applied_p[i];
+    for (int i = 0; i < 4; ++i) A.applied_joint[i] = b->applied_joint[i];
     // spring-damper model: the lane's own friction coefficient when the field is bound (variation kernels)
     A.friction = b->copt.contact_model == JM_CONTACT_CONSTRAINT ? nullptr : (const T *)b->field[JM_F_FRICTION];
     return A;
@@ -564,12 +566,15 @@ int32_t jm_batch_set_ground(jm_batch * b, const void * heights, int32_t nx, int3
     b->ground_x0 = x0; b->ground_y0 = y0; b->ground_dx = dx; b->ground_dy = dy;
     return JM_OK;
 }
-int32_t jm_batch_set_applied_frames(jm_batch * b, int32_t k, const double * offsets)
+int32_t jm_batch_set_applied_frames(jm_batch * b, int32_t k, const double * offsets, const int32_t * joints)
 {
     if (!b) return fail(JM_EINVAL, "jm_batch_set_applied_frames: null batch");
     if (k < 0 || k > 4 || (k > 0 && !offsets)) return fail(JM_EINVAL, "jm_batch_set_applied_frames: 0 <= K <= 4 frames with their offsets");
+    for (int i = 0; i < k; ++i)
+        if (joints && (joints[i] < 1 || joints[i] >= Topo::NJ)) return fail(JM_EINVAL, "jm_batch_set_applied_frames: parent joint out of range");
     b->applied_k = k;
     for (int i = 0; i < 3 * k; ++i) b->applied_p[i] = offsets[i];
+    for (int i = 0; i < 4; ++i) b->applied_joint[i] = (joints && i < k) ? joints[i] : 1;
     return JM_OK;
 }
 int32_t jm_batch_bind(jm_batch * b, int32_t field, void * ptr)

@@ -214,6 +214,12 @@ template<class Tp> struct QRows
 // All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
 // that they select the `saddr + voffset` addressing form instead of pinning a 64-bit VGPR address
 // per access (the batch size is bounded accordingly in jm_batch_create).
+template<class T> JM_DEV void add6(T * base, unsigned B, unsigned r, unsigned row0, Sp<T> f)
+{
+    const unsigned o = row0 * B + r;
+    base[o] += f.l.x; base[o + B] += f.l.y; base[o + 2 * B] += f.l.z;
+    base[o + 3 * B] += f.a.x; base[o + 4 * B] += f.a.y; base[o + 5 * B] += f.a.z;
+}
 template<class T> JM_DEV void put6(T * base, unsigned B, unsigned r, unsigned row0, Sp<T> f)
 {
     const unsigned o = row0 * B + r;
@@ -652,22 +658,35 @@ JM_DEV void limb_unwind(const LimbTable<T> & LT, T c, T sn, M3<T> & R, V3<T> & p
     p = p - R * plc.p;
 }
 
-// impulse / profile forces on frames of the root joint (BatchArgs::applied) as one wrench on joint 1, joint frame
-// = root coordinates (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
-template<class T> JM_DEV Sp<T> applied_root_wrench(const BatchArgs<T> & A, const M3<T> & R1, unsigned B32, unsigned r32)
+// impulse / profile forces (BatchArgs::applied: world-aligned wrenches at frames of any joint): the wrenches whose frame
+// hangs from joint `jq`, summed, as a wrench about the ROOT origin in root coordinates.  (Rj, pj) = placement of that joint in
+// root coordinates.  ≙ convertForceGlobalFrameToJoint (utilities/pinocchio.cc:794-809) followed by the joint -> root
+// transform: lin = R1^T F, ang = R1^T M + (pj + Rj p_frame) x lin.
+template<class T> JM_DEV Sp<T> applied_wrench_on(const BatchArgs<T> & A, int jq, const M3<T> & R1, const M3<T> & Rj, V3<T> pj,
+                                                 unsigned B32, unsigned r32)
 {
     Sp<T> f = zero6<T>();
     for (int i = 0; i < A.applied_k; ++i)
     {
+        if (A.applied_joint[i] != jq) continue;
         const unsigned o = (unsigned)(6 * i) * B32 + r32;
         const V3<T> F = {A.applied[o], A.applied[o + B32], A.applied[o + 2 * B32]};
         const V3<T> M = {A.applied[o + 3 * B32], A.applied[o + 4 * B32], A.applied[o + 5 * B32]};
-        const V3<T> p = {A.applied_p[3 * i], A.applied_p[3 * i + 1], A.applied_p[3 * i + 2]};
+        const V3<T> p = pj + Rj * V3<T>{A.applied_p[3 * i], A.applied_p[3 * i + 1], A.applied_p[3 * i + 2]};
         const V3<T> fl = tmul(R1, F);
         f.l = f.l + fl;
         f.a = f.a + tmul(R1, M) + cross(p, fl);
     }
     return f;
+}
+template<class T> JM_DEV Sp<T> applied_root_wrench(const BatchArgs<T> & A, const M3<T> & R1, unsigned B32, unsigned r32)
+{
+    return applied_wrench_on(A, 1, R1, ident3<T>(), zero3<T>(), B32, r32);
+}
+// a wrench about the root origin (root coordinates) expressed in the frame of a joint placed at (Rj, pj)
+template<class T> JM_DEV Sp<T> wrench_to_joint(const M3<T> & Rj, V3<T> pj, Sp<T> w)
+{
+    return {tmul(Rj, w.l), tmul(Rj, w.a - cross(pj, w.l))};
 }
 
 // ---- where the forces on the contact points come from, and what else acts on the joints ------------
@@ -1018,7 +1037,18 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             else if constexpr (!REWIND) ps[s] = pcur;
             if constexpr (!DYN)
             {
-                // output pass: only the energy sums need the bodies (velocities unwound from the tip like below)
+                // output pass: the energy sums and RobotState::fExternal of joints that carry an applied wrench need the
+                // bodies (velocities / placements unwound from the tip like below)
+                bool applied_out = false;
+                if constexpr (GEN && EMIT) applied_out = A.applied_k > 0 && A.f_external;
+                if constexpr (GEN && EMIT)
+                    if (applied_out && ix.has[s])
+                        add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc),
+                             wrench_to_joint(Rcur, pcur, applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, B32, r32)));
+                if (applied_out && !want_energy)
+                {
+                    if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
+                }
                 if (want_energy)
                 {
                     const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
@@ -1038,6 +1068,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             Sp<T> f = cross_mf(vcur, rbi_mul(Y, vcur));  // bias force v x* (I v)
             if constexpr (s == N - 1) { f = f - fext; Ia = ai_from_rbi(Y); }
             else { f = f + pa; Ia = ai_from_rbi(Y) + Ia; }
+            if constexpr (GEN)
+                if (A.applied_k > 0)
+                {
+                    const Sp<T> w = applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, B32, r32);
+                    f = f - w;
+                    if constexpr (EMIT)   // (evaluations that emit their own outputs: the constraint contact model)
+                        if (A.f_external && ix.has[s]) add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc), wrench_to_joint(Rcur, pcur, w));
+                }
             if (want_energy)
             {
                 kin += rbi_vtiv(Y, vcur);
@@ -1098,6 +1136,12 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         Sp<T> vt;
         if constexpr (!DYN)
         {
+            if constexpr (GEN && EMIT)
+                if (A.applied_k > 0 && A.f_external)
+                {
+                    TS.template get_kin<t, X>(Xt, vt);
+                    if (lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, applied_wrench_on(A, j, R1, Xt.R, Xt.p, B32, r32)));
+                }
             if (want_energy)
             {
                 TS.template get_kin<t, X>(Xt, vt);
@@ -1115,6 +1159,14 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         Sp<T> f = cross_mf(vt, rbi_mul(Y, vt));
         AI<T> It = ai_from_rbi(Y);
         if constexpr (I::has_child(t)) { f = f + accF[t]; It = It + accA[t]; }
+        if constexpr (GEN)
+            if (A.applied_k > 0)
+            {
+                const Sp<T> w = applied_wrench_on(A, j, R1, Xt.R, Xt.p, B32, r32);
+                f = f - w;
+                if constexpr (EMIT)
+                    if (A.f_external && lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, w));
+            }
         const Sp<T> vj = vbq(5 + t) * S;
         const Sp<T> c = cross_mm(vt - vj, vj);   // parent velocity x S qd
         if constexpr (MOTORS_IN_SWEEP) ut[t] = trunk_motor(tc);
@@ -1424,6 +1476,10 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
             fBs = fBs + rbi_mul(Y, al[s]) + vxh;
             fjs = fjs + vxh + rbi_mul(Y, al[s] + agf1);
             if constexpr (s == N - 1) fjs = fjs - fext;
+            if constexpr (GEN)
+                if (A.applied_k > 0)
+                    fjs = fjs - applied_wrench_on(A, sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]),
+                                                  R1, Rs[s], ps[s], B32, r32);
             ms += Y.m;
             mcs = mcs + Y.m * Y.c;
             if (A.joint_forces && ix.has[s])
@@ -1464,8 +1520,12 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
         hT[t] = hT[t] + h;
         fBT[t] = fBT[t] + rbi_mul(Y, at[t]) + vxh;
         fjT[t] = fjT[t] + vxh + rbi_mul(Y, at[t] + agf1);
-        if constexpr (GEN && t == 0)
-            if (A.applied_k > 0) fjT[0] = fjT[0] - applied_root_wrench(A, R1, B32, r32);
+        if constexpr (GEN)
+            if (A.applied_k > 0)
+            {
+                if constexpr (t == 0) fjT[0] = fjT[0] - applied_root_wrench(A, R1, B32, r32);
+                else fjT[t] = fjT[t] - applied_wrench_on(A, j, R1, K.X[t].R, K.X[t].p, B32, r32);
+            }
         mT[t] += Y.m;
         mcT[t] = mcT[t] + Y.m * Y.c;
         if (A.joint_forces && lead)
@@ -1756,7 +1816,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             // (long limbs / trunk trees only: re-read the parameter block inside the loop; its scalar loads hoisted out
             // of the loop overflow the SGPR file and come back as v_readlane -- 300 per Atlas evaluation)
             CPtr<T> Pl = P;
-            if constexpr (R::LONG) JM_OPAQUE_S(Pl);
+            if constexpr (R::LONG && !GEN) JM_OPAQUE_S(Pl);
             advance(st, e == n_evals - 1, rr);
             quad_eval<T, Tp, X, false, StageBuf<T, SL, SB>, 0, NoKeep, GEN>(Pl, LT, A, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq, status);
         }

@@ -1162,16 +1162,21 @@ class BatchedEngine:
         self.set_ground_heightmap(h, x_range[0], y_range[0], resolution, resolution)
 
     def _force_frame_index(self, frame_name: str) -> int:
+        """Slot of the frame among the (at most four) frames that carry applied wrenches.  Any frame of the model: the
+        wrench goes to the frame's parent joint, like `Engine::computeExternalForces` (engine.cc:3481-3560)."""
         fr = self.model.frame(frame_name)
-        if fr.parent_joint != 1 or not self.model.has_freeflyer:
-            raise NotImplementedError("external forces are available on frames of the root (free-flyer) body")
+        if codegen.quad_structure(self.model) is None or self.dtype != torch.float64:
+            raise NotImplementedError("external forces need a float64 batch of a branch-parallel topology "
+                                      "(floating base with four limbs)")
         if frame_name not in self._force_frames:
             if len(self._force_frames) == 4:
                 raise NotImplementedError("at most 4 frames can carry external forces")
             self._force_frames.append(frame_name)
             offs = np.ascontiguousarray([self.model.frame(n).p for n in self._force_frames], dtype=np.float64)
+            joints = np.ascontiguousarray([self.model.frame(n).parent_joint for n in self._force_frames], dtype=np.int32)
             self._lib.check(self._L.jm_batch_set_applied_frames(self._batch_h, len(self._force_frames),
-                                                                offs.ctypes.data_as(C.POINTER(C.c_double))))
+                                                                offs.ctypes.data_as(C.POINTER(C.c_double)),
+                                                                joints.ctypes.data_as(C.POINTER(C.c_int32))))
             old = self._fields.get("applied")
             new = torch.zeros((6 * len(self._force_frames), self.batch_size), dtype=self.dtype, device=self.device)
             if old is not None:
@@ -1231,7 +1236,7 @@ class BatchedEngine:
         self._profile_forces.clear()
         self._force_frames.clear()
         self._fields.pop("applied", None)
-        self._lib.check(self._L.jm_batch_set_applied_frames(self._batch_h, 0, None))
+        self._lib.check(self._L.jm_batch_set_applied_frames(self._batch_h, 0, None, None))
         self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["applied"], None))
 
     @property

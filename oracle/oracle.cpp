@@ -484,6 +484,7 @@ struct Engine
     const double * applied = nullptr;
     int applied_k = 0;
     double applied_p[12] = {0};
+    int applied_joint[4] = {1, 1, 1, 1};   // parent joint of every frame (1 = the root joint)
     double applied_now[24] = {0};   // the current lane's wrenches
 };
 // world.groundProfile(x, y) -> height, unit normal
@@ -508,21 +509,21 @@ inline void ground_profile(const Engine & e, double x, double y, double & h, V3 
     const double inv = 1.0 / std::sqrt(dhdx * dhdx + dhdy * dhdy + 1.0);
     n = {-dhdx * inv, -dhdy * inv, inv};
 }
-// impulse / profile forces on frames of the root joint -> wrench on joint 1, joint frame
-// (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
-inline Force applied_root_wrench(const Engine & e)
+// impulse / profile forces (Engine::computeExternalForces, engine.cc:3481-3560): the world-aligned wrench applied at a
+// frame goes to the frame's PARENT JOINT, in the joint frame (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
+inline void add_applied_wrenches(Engine & e)
 {
-    Force f;
     for (int k = 0; k < e.applied_k; ++k)
     {
+        const int j = e.applied_joint[k];
         const V3 F = {e.applied_now[6 * k], e.applied_now[6 * k + 1], e.applied_now[6 * k + 2]};
         const V3 M = {e.applied_now[6 * k + 3], e.applied_now[6 * k + 4], e.applied_now[6 * k + 5]};
         const V3 p = {e.applied_p[3 * k], e.applied_p[3 * k + 1], e.applied_p[3 * k + 2]};
-        const V3 fl = tmul(e.oMi[1].R, F);
-        f.lin = f.lin + fl;
-        f.ang = f.ang + tmul(e.oMi[1].R, M) + cross(p, fl);
+        Force f;
+        f.lin = tmul(e.oMi[j].R, F);
+        f.ang = tmul(e.oMi[j].R, M) + cross(p, f.lin);
+        e.fExternal[j] = e.fExternal[j] + f;
     }
-    return f;
 }
 
 V3 joint_axis(const Model & m, int j)
@@ -1346,7 +1347,7 @@ void dynamics_constraint(Engine & e, const double * q, const double * v, double 
     if (e.uInternal.empty()) init_constraints(e);
     forward_kin(e, q, v);
     for (auto & f : e.fExternal) f = Force();
-    if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
+    if (e.applied_k > 0) add_applied_wrenches(e);
     std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
     toggle_bounds(e, q);
     toggle_contacts(e);
@@ -1387,7 +1388,7 @@ void dynamics(Engine & e, const double * q, const double * v, double * a_out)
         e.fExternal[fr.joint] = e.fExternal[fr.joint] + e.contactFrameForces[i];
         e.contactForces[i] = actInv(fr.M, e.contactFrameForces[i]);
     }
-    if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
+    if (e.applied_k > 0) add_applied_wrenches(e);
     motor_efforts(e, v);
     for (int i = 0; i < m.nv; ++i) e.u[i] = 0.0;  // uInternal + uCustom
     for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
@@ -1573,7 +1574,7 @@ void start_constraint(Engine & e)
     for (int it = 0; it < 4; ++it)
     {
         for (auto & f : e.fExternal) f = Force();
-        if (e.applied_k > 0) e.fExternal[1] = e.fExternal[1] + applied_root_wrench(e);
+        if (e.applied_k > 0) add_applied_wrenches(e);
         std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
         compute_acceleration(e, e.q.data(), e.v.data(), e.u, it == 0);
         for (int i = 0; i < m.nv; ++i)
@@ -2039,12 +2040,13 @@ void orc_engine_bind_ground(void * h, const double * heights, int nx, int ny, do
     Engine & e = *static_cast<Engine *>(h);
     e.ground_h = heights; e.ground_nx = nx; e.ground_ny = ny; e.ground_x0 = x0; e.ground_y0 = y0; e.ground_dx = dx; e.ground_dy = dy;
 }
-void orc_engine_bind_applied(void * h, const double * wrenches, int k, const double * offsets)
+void orc_engine_bind_applied(void * h, const double * wrenches, int k, const double * offsets, const int * joints)
 {
     Engine & e = *static_cast<Engine *>(h);
     e.applied = wrenches;
     e.applied_k = wrenches ? k : 0;
     for (int i = 0; i < 3 * e.applied_k; ++i) e.applied_p[i] = offsets[i];
+    for (int i = 0; i < e.applied_k; ++i) e.applied_joint[i] = joints ? joints[i] : 1;
 }
 int orc_engine_constraint_counts(void * h, int * n_bounds, int * n_contacts)
 {

@@ -64,7 +64,7 @@ def lib() -> C.CDLL:
         L.orc_engine_bind_model_lane.restype = None
         L.orc_engine_bind_ground.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_engine_bind_ground.restype = None
-        L.orc_engine_bind_applied.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_engine_bind_applied.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_engine_bind_applied.restype = None
         L.orc_engine_constraint_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_engine_constraint_counts.restype = C.c_int
@@ -173,16 +173,18 @@ class OracleEngine:
         ny, nx = self._ground.shape
         self._L.orc_engine_bind_ground(self._h, self._ground.ctypes.data, nx, ny, float(x0), float(y0), float(dx), float(dy))
 
-    def bind_applied(self, wrenches: Optional[np.ndarray], offsets=None) -> None:
-        """World-aligned wrenches `[6 K][B]` applied on K <= 4 frames of the root joint at `offsets` `[K][3]`."""
+    def bind_applied(self, wrenches: Optional[np.ndarray], offsets=None, joints=None) -> None:
+        """World-aligned wrenches `[6 K][B]` applied on K <= 4 frames: `offsets` `[K][3]` in the frame's parent joint,
+        `joints` `[K]` the parent joints (default: the root joint)."""
         if wrenches is None:
             self._applied = None
-            self._L.orc_engine_bind_applied(self._h, None, 0, None)
+            self._L.orc_engine_bind_applied(self._h, None, 0, None, None)
             return
         self._applied = np.ascontiguousarray(wrenches, dtype=np.float64)
         k = self._applied.shape[0] // 6
         self._applied_p = np.ascontiguousarray(np.zeros((k, 3)) if offsets is None else offsets, dtype=np.float64)
-        self._L.orc_engine_bind_applied(self._h, self._applied.ctypes.data, k, self._applied_p.ctypes.data)
+        self._applied_j = np.ascontiguousarray(np.ones(k) if joints is None else joints, dtype=np.int32)
+        self._L.orc_engine_bind_applied(self._h, self._applied.ctypes.data, k, self._applied_p.ctypes.data, self._applied_j.ctypes.data)
 
     @property
     def pgs_iterations(self) -> int:

@@ -204,12 +204,14 @@ static double g_gx0 = 0, g_gy0 = 0, g_gdx = 1, g_gdy = 1;
 static const void * g_applied = nullptr;
 static int g_applied_k = 0;
 static double g_applied_p[12] = {0};
+static int g_applied_joint[4] = {1, 1, 1, 1};
 extern "C" void emu_set_gen(const void * model_lane, const void * ground, int nx, int ny, double x0, double y0, double dx, double dy,
-                            const void * applied, int k, const double * offsets)
+                            const void * applied, int k, const double * offsets, const int * joints)
 {
     g_model_lane = model_lane; g_ground = ground; g_gnx = nx; g_gny = ny; g_gx0 = x0; g_gy0 = y0; g_gdx = dx; g_gdy = dy;
     g_applied = applied; g_applied_k = applied ? k : 0;
     for (int i = 0; i < 3 * g_applied_k; ++i) g_applied_p[i] = offsets[i];
+    for (int i = 0; i < 4; ++i) g_applied_joint[i] = (joints && i < g_applied_k) ? joints[i] : 1;
 }
 static int g_variant = 0;  // 0 = one robot per lane, 1 = limb-parallel (4 lanes per robot)
 extern "C" void emu_set_variant(int v) { g_variant = v; }
@@ -245,6 +247,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.ground_x0 = (T)g_gx0; A.ground_y0 = (T)g_gy0; A.ground_dx = (T)g_gdx; A.ground_dy = (T)g_gdy;
     A.applied = (const T *)g_applied; A.applied_k = g_applied_k;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)g_applied_p[i];
+    for (int i = 0; i < 4; ++i) A.applied_joint[i] = g_applied_joint[i];
     if (gen && !(g_variant == 1 && Topo::QUAD)) return JM_ENOTIMPL;
     if (g_variant == 1 && Topo::QUAD)
     {

@@ -45,7 +45,7 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_friction.argtypes = [C.c_void_p]
     L.emu_set_friction.restype = None
     L.emu_set_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
-                              C.c_void_p, C.c_int, C.c_void_p]
+                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.emu_set_gen.restype = None
     L.emu_run_dopri.argtypes = [C.POINTER(_abi.ModelDesc), C.POINTER(_abi.Options), C.POINTER(EmuIO), C.c_void_p, C.c_void_p,
                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -68,11 +68,13 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     gh = None if g[0] is None else np.ascontiguousarray(g[0], dtype=dtype)
     ap = None if applied is None else np.ascontiguousarray(applied[0], dtype=dtype)
     apo = None if applied is None else np.ascontiguousarray(applied[1], dtype=np.float64)
+    # optional third entry: the parent joint of every frame (default: the root joint)
+    apj = None if (applied is None or len(applied) < 3) else np.ascontiguousarray(applied[2], dtype=np.int32)
     ml = None if model_lane is None else np.ascontiguousarray(model_lane, dtype=dtype)
     L.emu_set_gen(None if ml is None else ml.ctypes.data, None if gh is None else gh.ctypes.data,
                   0 if gh is None else gh.shape[1], 0 if gh is None else gh.shape[0], float(g[1]), float(g[2]), float(g[3]),
                   float(g[4]), None if ap is None else ap.ctypes.data, 0 if ap is None else ap.shape[0] // 6,
-                  None if apo is None else apo.ctypes.data)
+                  None if apo is None else apo.ctypes.data, None if apj is None else apj.ctypes.data)
     if constraint_options is not None:
         co = _abi.make_constraint_options(**constraint_options)
         L.emu_set_constraints(C.byref(co), arrays["con_flags"].ctypes.data, arrays["con_data"].ctypes.data)
