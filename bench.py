@@ -366,6 +366,10 @@ def main() -> None:
             alg_bytes_per_launch += 2 * (rows["con_flags"] * 4 + rows["con_data"] * sz) * B
             achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
             kernel_name = "jm::k_quad_con" if kernel_name == "jm::k_quad" else "jm::k_constrained"
+            from jiminy_amd.codegen import qcon_split
+            if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
+                # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
+                kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
             pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json")
         if os.path.exists(pmc_path):
             try:

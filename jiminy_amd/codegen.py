@@ -167,6 +167,8 @@ def topology_header(model: CompiledModel) -> str:
         f"// model: {model.name}",
         "#pragma once",
         f"#define JM_TOPO_QUAD {1 if quad_structure(model) is not None else 0}",
+        "// constraint contact model: solves of more than 32 rows step through pre | solve | post launches (jm_qcon.h)",
+        f"#define JM_TOPO_QCON_SPLIT {1 if qcon_split(model) else 0}",
         "// The struct name carries the topology hash so that two topology libraries loaded in the",
         "// same process never share (STB_GNU_UNIQUE / weak) template instantiations.",
         f"struct Topo_{model.topology_hash()}",
@@ -265,6 +267,15 @@ def preferred_variant(model: CompiledModel) -> int:
         return 0
 
 
+def qcon_split(model: CompiledModel) -> bool:
+    """`jm::qcon_split<Topo>()` (jm_qcon.h): branch-parallel topology whose constraint solves can exceed 32 rows
+    (bounded joints + 4 per contact point, capped at JM_QCON_MAXM = 96)."""
+    if quad_structure(model) is None:
+        return False
+    nb = sum(1 for t in model.jtypes[1:] if 1 <= int(t) <= 8)
+    return min(nb + 4 * model.ncontacts, 96) > 32
+
+
 def part_flags(model: CompiledModel) -> Dict[str, List[str]]:
     """Extra flags of single translation units of a topology (build_variants.json `part_flags`: {"5": ["-O1"]} compiles
     the persistent adaptive kernel of that topology at -O1), appended after the common flags."""
@@ -359,6 +370,8 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
     common += list(BUILD_VARIANTS[v])
     common += extra_flags or []
     parts = [1, 2, 3, 4, 5, 6] if quad_structure(model) is not None else [1]
+    if qcon_split(model):
+        parts += [7, 8, 9]
     objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]
     cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]]]
     pf = part_flags(model)

@@ -45,6 +45,12 @@ extern template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<dou
 extern template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 extern template __global__ void k_quad_dopri_gen<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
+#if JM_TOPO_QCON_SPLIT
+extern template __global__ void k_quad_con_split<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
+extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
+#endif
 }
 #endif
 
@@ -85,6 +91,7 @@ struct jm_batch
     void * d_params = nullptr;
     void * field[JM_F_COUNT] = {};
     bool started = false;
+    bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
     // adaptive stepper: caller-owned workspace / per-lane state, library-owned active-lane counter
     void * ad_ws = nullptr;
     double * ad_fs = nullptr;
@@ -137,7 +144,9 @@ template<class Tp> int32_t constraint_ws_rows_of(const jm_batch * b)
     if constexpr (Tp::QUAD)
         if (b->variant == VARIANT_QUAD)
         {
-            const int rows = jm::qcon_ws_rows<double, Tp>();
+            int rows = jm::qcon_ws_rows<double, Tp>();
+            if constexpr (jm::qcon_split<Tp>())
+                if (jm::qcon_split_ws_rows<double, Tp>() > rows) rows = jm::qcon_split_ws_rows<double, Tp>();
             return rows > 0 ? rows : 1;
         }
     return jm::ConRows<Tp>::WTOTAL;
@@ -223,8 +232,31 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
         C.iter_max = C0.iter_max;
         C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
         C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
+        C.stage = nullptr; C.split_e = 0;
         constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
+        if constexpr (jm::qcon_split<Tp>())
+        {
+            // robots whose solves live in the workspace: step launches go through pre | solve | post per evaluation (jm_qcon.h)
+            if (b->qcon_split && A.mode == jm::MODE_STEP && !(A.model_lane || A.applied || A.ground_h) && (A.B & 15) == 0 && !b->ov_flags)
+            {
+                C.stage = C.ws + (size_t)jm::qcon_split_region_rows<double, Tp>() * (size_t)A.B;
+                const int pre = A.command_changed ? 1 : 0;
+                const int n_evals = pre + A.n_sub * (A.solver == JM_SOLVER_RUNGE_KUTTA_4 ? 4 : 1);
+                const unsigned g64 = (unsigned)((A.B + 63) / 64);
+                for (int e = 0; e < n_evals; ++e)
+                {
+                    C.split_e = e;
+                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
+                    // (solves of up to 64 rows, then the waves that hold a larger one)
+                    hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
+                    if constexpr (jm::QConRows<Tp>::MAXM > 64)
+                        hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 12, 64, JM_QCON_PGS_DEPTH - 1>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
+                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, s, A, C);
+                }
+                return;
+            }
+        }
         if (A.model_lane || A.applied || A.ground_h) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
         else hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
     }
@@ -482,6 +514,7 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     // kernel variant: limb-parallel when the topology allows it; JM_KERNEL_VARIANT=lane forces the
     // generic one-robot-per-lane kernel (A/B measurements)
     b->variant = (Topo::QUAD && model->root_at_origin) ? VARIANT_QUAD : VARIANT_LANE;
+    if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT")) b->qcon_split = e[0] != '0';
     if (const char * v = std::getenv("JM_KERNEL_VARIANT"))
         if (std::string(v) == "lane") b->variant = VARIANT_LANE;
     hipError_t e = hipSetDevice(device);

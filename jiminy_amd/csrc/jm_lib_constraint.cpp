@@ -7,6 +7,8 @@
 //   -DJM_CON_PART=4  k_quad_con_gen (the same for the constraint contact model)
 //   -DJM_CON_PART=5  k_quad_dopri   (jm_qdopri.h, the persistent adaptive stepper)
 //   -DJM_CON_PART=6  k_quad_dopri_gen (the same with per-lane body parameters / height map / applied forces)
+//   -DJM_CON_PART=7 / 8  k_quad_con_split<1 / 2>  (jm_qcon.h, split stepping of robots with large solves: before / after the solve)
+//   -DJM_CON_PART=9  k_qcon_pgs     (the solve of the split form)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -35,5 +37,12 @@ template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, c
 template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #elif JM_CON_PART == 6 && JM_TOPO_QUAD
 template __global__ void k_quad_dopri_gen<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
+#elif JM_CON_PART == 7 && JM_TOPO_QCON_SPLIT
+template __global__ void k_quad_con_split<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
+#elif JM_CON_PART == 8 && JM_TOPO_QCON_SPLIT
+template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArgs<double>, const QConArgs<double>);
+#elif JM_CON_PART == 9 && JM_TOPO_QCON_SPLIT
+template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
+template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
 #endif
 }

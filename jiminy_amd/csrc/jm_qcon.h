@@ -56,6 +56,19 @@
                          // full evaluation (cheaper arithmetic, but it keeps the free evaluation's data live across the PGS
                          // sweeps: measured slower on ANYmal because the sweeps then spill)
 #endif
+#ifndef JM_QCON_REGS_NIT
+#define JM_QCON_REGS_NIT 4  // on-chip solves of up to 4 * JM_QCON_REGS_NIT rows run out of registers (qcon_pgs_regs / _fixed), larger
+                            // ones out of LDS (qcon_pgs with the on-chip store): a quarter of a 40-row matrix is 400 registers
+#endif
+#ifndef JM_QCON_WS_TILED
+#define JM_QCON_WS_TILED 1  // workspace rows tiled per wave (qcon_store)
+#endif
+#ifndef JM_QCON_PGS_WAVES
+#define JM_QCON_PGS_WAVES 2  // waves per SIMD of the split form's solve kernel (k_qcon_pgs)
+#endif
+#ifndef JM_QCON_PGS_DEPTH
+#define JM_QCON_PGS_DEPTH 4  // rows in flight per robot in k_qcon_pgs (ring of row buffers)
+#endif
 #ifndef JM_QCON_MAXM
 #define JM_QCON_MAXM 96  // most active constraint rows solved per robot (rows beyond it are dropped and flagged); 96 = a humanoid
                          // standing flat on two 8-vertex feet during Engine::start (16 contacts x 4 rows + joint bounds)
@@ -76,6 +89,9 @@ template<class T> struct QConArgs
     const T * ground_h;
     int ground_nx, ground_ny;
     T ground_x0, ground_y0, ground_dx, ground_dy;
+    // split stepping (k_quad_con_pre / k_qcon_pgs / k_quad_con_post): stage buffer in HBM, evaluation of this launch
+    T * stage;
+    int split_e;
 };
 
 template<class Tp> struct QConRows
@@ -116,6 +132,8 @@ template<class T> struct QStore
     int cap;
     JM_DEV T get(int e) const { return e < cap ? lds[e] : hbm[(unsigned)(e - cap) * B]; }
     JM_DEV void put(int e, T x) const { if (e < cap) lds[e] = x; else hbm[(unsigned)(e - cap) * B] = x; }
+    // entry (pr, pc), pr >= pc, of the matrix of an m-row solve (packed lower triangle)
+    JM_DEV void put_a(int m, int pr, int pc, T x) const { put(4 * m + pr * (pr + 1) / 2 + pc, x); }
     // the same read without a branch: both homes are read at a valid address and the value is selected, so that a
     // batch of reads is issued together instead of one dependent memory round trip per element
     JM_DEV T get_flat(int e) const
@@ -135,8 +153,30 @@ template<class T, int NIT_> struct QStoreChip
     T * lds;
     JM_DEV T get(int e) const { return lds[e]; }
     JM_DEV void put(int e, T x) const { lds[e] = x; }
+    JM_DEV void put_a(int m, int pr, int pc, T x) const { put(4 * m + pr * (pr + 1) / 2 + pc, x); }
+};
+// the region of the split form (k_quad_con_split / k_qcon_pgs): one contiguous block of the workspace per robot ([robot][row]: the
+// sweeps of the solve stream the matrix of every robot that has not converged yet, and only those), the matrix SQUARE with
+// rows padded to a multiple of four entries (row i at 4 m + i ms: a row update reads consecutive, 32-byte aligned entries,
+// no triangle index per element), both halves written
+template<class T> struct QStoreSq
+{
+    static constexpr bool ON_CHIP = false;
+    static constexpr int NIT = 1;
+    T * hbm;
+    static JM_DEV int row_stride(int m) { return (m + 3) & ~3; }
+    JM_DEV T get(int e) const { return hbm[e]; }
+    JM_DEV void put(int e, T x) const { hbm[e] = x; }
+    JM_DEV void put_a(int m, int pr, int pc, T x) const
+    {
+        const int ms = row_stride(m);
+        put(4 * m + pr * ms + pc, x);
+        if (pr != pc) put(4 * m + pc * ms + pr, x);
+    }
 };
 JM_DEV int tri_(int i, int c) { return i >= c ? i * (i + 1) / 2 + c : c * (c + 1) / 2 + i; }
+template<class T> JM_DEV T bits_as(unsigned long long u) { static_assert(sizeof(T) == 8, "64-bit scalars"); return __builtin_bit_cast(T, u); }
+JM_DEV unsigned long long as_bits(double x) { return __builtin_bit_cast(unsigned long long, x); }
 
 template<class X, int NW> JM_DEV void quad_or_mask(RowMaskN<NW> & m)
 {
@@ -148,6 +188,15 @@ template<class X, int NW> JM_DEV void quad_or_mask(RowMaskN<NW> & m)
         m.w[i] = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
     }
 }
+
+// scalars of the robot's region of the split form: x | b | y | 1 / diag | square matrix (rows padded to a multiple of 4) | 32
+// entries of slack (a row read runs up to 31 entries past the end of the matrix) | header (rows, bounds, rows per contact
+// block) | verdict of the solve
+template<class Tp> struct QSplitRegion
+{
+    static constexpr int MAXM = QConRows<Tp>::MAXM;
+    static constexpr int HDR = 4 * MAXM + MAXM * MAXM + 32, OK = HDR + 1, ROWS = OK + 1;
+};
 
 // everything one constrained evaluation shares between its phases (per lane)
 template<class T, class Tp> struct QConCtx
@@ -468,7 +517,7 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
                         {
                             T val = cx.rev.test(row) ? -ddb[t] : ddb[t];
                             if (pr == pcol) val += fmax_(val * C.reg, T(1.0e-11));  // regularisation, constraint_solvers.cc:376-387
-                            V.put(A0 + tri_(pr, pcol), val);
+                            V.put_a(cx.m, pr, pcol, val);
                         }
                     }
             });
@@ -496,7 +545,7 @@ JM_DEV void qcon_delassus(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> 
                     if (pr >= pc_)
                     {
                         if (pr == pc_) val += fmax_(val * C.reg, T(1.0e-11));
-                        V.put(A0 + tri_(pr, pc_), val);
+                        V.put_a(cx.m, pr, pc_, val);
                     }
                 };
                 static_for<0, N>([&](auto sc) {
@@ -1379,7 +1428,10 @@ JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<
 // ---------------------------------------------------------------- one constrained evaluation
 // `start_passes` > 0: Engine::start / reset sequence; < 0: MODE_REFRESH (re-apply the stored multipliers);
 // 0: a regular evaluation.  Leaves the constrained acceleration in ddqb / ddq.
-template<class T, class Tp, class X, class SB, int CAPC, bool GEN>
+// PH = 1 / 2 (split stepping, regular evaluations only): the part before the solve (free acceleration, switching, delassus
+// matrix, right-hand side and warm start into the workspace; constraint context into the stage buffer) / after it (multipliers
+// back to the lane state, evaluation that applies them).
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1424,6 +1476,60 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     static_for<0, N>([&](auto sc) { uq_l[decltype(sc)::value] = T(0); });
     static_for<0, NT>([&](auto tc) { uq_b[decltype(tc)::value] = T(0); });
     bool any = false;
+    if constexpr (PH != 0)
+    {
+        using SR = QSplitRows<Tp>;
+        static_assert(3 * QR::NWORDS + 1 <= SR::NCX, "context rows of the split stage buffer");
+        auto mask_io = [&](typename QConCtx<T, Tp>::RowMask & mk, int row0, bool save) {
+            static_for<0, QR::NWORDS>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                if (save) S_.putl(row0 + w, bits_as<T>(mk.w[w]));
+                else mk.w[w] = as_bits(S_.getl(row0 + w));
+            });
+        };
+        if constexpr (PH == 1)
+        {
+            quad_eval<T, Tp, X, false, SB, 1, QKeep<T, Tp>, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq,
+                                                           status, &ex, &K, &TS);
+            qcon_switch<T, Tp, X, GEN>(P, LT, C, B32, r32, k, ix, qb, ql, K, false, false, cx);
+            any = cx.act.any();
+            if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
+            const QStoreSq<T> W{V.hbm};
+            if (any)
+            {
+                qcon_delassus<T, Tp, X, QStoreSq<T>, GEN>(P, LT, C, k, ix, K, TS, cx, W);
+                X::sync();
+                qcon_rhs<T, Tp, QStoreSq<T>, GEN>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
+            }
+            // header of the solve: rows | joint bounds | rows per contact block (0 rows: nothing to solve)
+            if (k == 0) W.put(QSplitRegion<Tp>::HDR, (T)(any ? (cx.m | (cx.nb << 8) | (cx.cb << 16)) : 0));
+            mask_io(cx.act, SR::CXL, true);
+            mask_io(cx.rev, SR::CXL + QR::NWORDS, true);
+            mask_io(cx.mine, SR::CXL + 2 * QR::NWORDS, true);
+            S_.putl(SR::CXL + 3 * QR::NWORDS, (T)(cx.m | (cx.nb << 8) | (cx.cb << 16) | (cx.overflow ? (1 << 24) : 0)));
+            return;
+        }
+        else
+        {
+            mask_io(cx.act, SR::CXL, false);
+            mask_io(cx.rev, SR::CXL + QR::NWORDS, false);
+            mask_io(cx.mine, SR::CXL + 2 * QR::NWORDS, false);
+            const int hdr = (int)S_.getl(SR::CXL + 3 * QR::NWORDS);
+            cx.m = hdr & 0xff; cx.nb = (hdr >> 8) & 0xff; cx.cb = (hdr >> 16) & 0xff; cx.overflow = (hdr >> 24) & 1;
+            any = cx.act.any();
+            if (any)
+            {
+                const QStoreSq<T> W{V.hbm};
+                if (W.get(QSplitRegion<Tp>::OK) != T(0)) status &= ~JM_LANE_SOLVER_FAILURE;
+                else status |= JM_LANE_SOLVER_FAILURE;
+                if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
+                qcon_scatter<T, Tp, QStoreSq<T>>(LT, C, B32, r32, k, ix, cx, W);
+                X::sync();
+            }
+        }
+    }
+    else
+    {
 #pragma nounroll
     for (int pass = 0; pass < n_pass; ++pass)
     {
@@ -1459,7 +1565,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             else
             {
                 bool ok = true;
-                if constexpr (VS::ON_CHIP)
+                if constexpr (VS::ON_CHIP && VS::NIT <= JM_QCON_REGS_NIT)
                 {
                     if (!(JM_QCON_SKIP & 1))
                     {
@@ -1503,8 +1609,9 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             if constexpr (row >= 0) uq_b[t] = cx.act.test(row) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
         });
     }
+    }
     // ---- nothing to enforce and nothing to emit: the free acceleration is the answer (engine.cc:3861-3865)
-    if (!emit && !any && !init) return;
+    if (PH == 0 && !emit && !any && !init) return;
     if (JM_QCON_DELTA && !emit && !init && !refresh && !(JM_QCON_SKIP & 4))
     {
         // nothing to emit: the free acceleration plus one bias-free solve with the multipliers
@@ -1582,6 +1689,19 @@ template<class T, class Tp> constexpr int qcon_lane_scalars()
 template<class T, class Tp> constexpr int qcon_capacity() { return 4 * qcon_lane_scalars<T, Tp>(); }
 template<class T, class Tp> constexpr int qcon_ws_rows() { return QConRows<Tp>::ws_rows(qcon_capacity<T, Tp>()); }
 
+// The robot's solver region.  Workspace rows of the 16 robots of a wave are one contiguous tile ([B / 16][rows][16]:
+// a row update reads `m` consecutive 128-byte lines) whenever the batch is a multiple of 16, robot-minor rows
+// ([rows][B]: every entry of a robot's matrix 8 B bytes apart, i.e. on its own page) otherwise.
+template<class T, class Tp> JM_DEV QStore<T> qcon_store(T * lds, T * ws, long long r, unsigned B)
+{
+    constexpr int CAP = qcon_capacity<T, Tp>();
+#if JM_QCON_WS_TILED
+    if ((B & 15u) == 0)
+        return {lds, ws + (size_t)(r >> 4) * (size_t)(qcon_ws_rows<T, Tp>() * 16) + (size_t)(r & 15), 16u, CAP};
+#endif
+    return {lds, ws + r, B, CAP};
+}
+
 template<class T, class Tp>
 __global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
 k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
@@ -1600,9 +1720,242 @@ k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
     const int k = threadIdx.x & 3;
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
-    const QStore<T> V{con + (threadIdx.x >> 2) * RSTRIDE, C.ws + r, (unsigned)A.B, CAP};
+    const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
     quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
 }
+// ---------------------------------------------------------------- split stepping: pre | solve | post
+// Robots whose solves do not fit the chip (Atlas: 27-52 rows standing, up to JM_QCON_MAXM) step through THREE launches per
+// evaluation instead of one kernel that holds the whole evaluation in 512 registers while it waits on workspace rows:
+//   k_quad_con_pre   RK stage update, free acceleration, switching, delassus matrix, right-hand side -> workspace
+//   k_qcon_pgs       the projected Gauss-Seidel sweeps alone: ~100 registers, x on chip, 8-12 waves per CU, so that the
+//                    round trips of the row reads of one robot overlap with the sweeps of the others
+//   k_quad_con_post  multipliers -> lane state, evaluation that applies them (and emits the outputs of the launch)
+// The RK stage buffer, the state of the evaluation in flight and the constraint context live in HBM between the launches
+// (QSplitRows, one tile per wave).  Same functions, same arithmetic, same order as the single kernel; `start` / `reset` /
+// `refresh` / `dynamics` launches and the variation kernels keep the single kernel.
+template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > 32; }
+#ifdef JM_TOPO_QCON_SPLIT
+static_assert(qcon_split<Topo>() == (JM_TOPO_QCON_SPLIT != 0), "codegen.qcon_split and jm::qcon_split disagree");
+#endif
+// workspace rows ([rows][B] scalars) of the split form: solver region + header + verdict, then the stage tiles
+template<class T, class Tp> constexpr int qcon_split_region_rows() { return QSplitRegion<Tp>::ROWS; }
+template<class T, class Tp> constexpr int qcon_split_ws_rows()
+{
+    return qcon_split_region_rows<T, Tp>() + (QSplitRows<Tp>::TILE + 15) / 16;
+}
+template<class T, class Tp> JM_DEV QStore<T> qcon_split_store(T * ws, long long r)
+{
+    return {nullptr, ws + (size_t)r * (size_t)qcon_split_region_rows<T, Tp>(), 1u, 0};
+}
+
+template<class T, class Tp, int PH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
+{
+    using Q = QLayout<Tp>;
+    using SR = QSplitRows<Tp>;
+    __shared__ T table[Q::TABLE];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += 256) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    T * tile = C.stage + (size_t)(r >> 4) * (size_t)SR::TILE;
+    const StageBuf<T, 64, 16> S{tile + (threadIdx.x & 63), tile + SR::NL * 64 + ((threadIdx.x >> 2) & 15), k == 0};
+    const QStore<T> V = qcon_split_store<T, Tp>(C.ws, r);
+    quad_lane_run<T, Tp, DppQuad, 64, 16, true, 0, false, PH>(A, r, k, table, S, &C, &V);
+}
+
+// The solve.  Four lanes per robot as everywhere, 16 robots per wave; the multipliers `x` of the robot on chip (zero beyond
+// its m rows), everything else (b, residuals of the previous sweep, 1 / diag, the square matrix) read from the robot's block
+// of the workspace with the row: lane k of the quad reads entries 8 j + 2 k, 8 j + 2 k + 1 of the row (16-byte loads, 64
+// contiguous bytes per quad), all the loads of a row issued together at immediate offsets from one address.
+// The sweep is ONE sequence of m row visits in the reference's order (block 0 of every constraint: joint bounds, then the
+// normal force of every contact; block 1: torsion rows {3, 2}; block 2: friction cones {0, 1, 2}, the two tangential rows
+// one after the other, both updated at the second), and the rows of the next D - 1 visits -- of the next sweep after the
+// last one -- are in flight while the current one is worked on (a ring of D row buffers, the loop unrolled D times so that
+// every buffer is a fixed set of registers): the Gauss-Seidel dependency chain does not wait for the workspace.
+// NJ = 16-byte loads per lane and row: the kernel is built for solves of up to 8 NJ rows; a wave whose largest solve needs
+// another instantiation leaves at once (LO < largest m <= 8 NJ is this one's job).
+// PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333), statement by statement the sweep of `qcon_pgs`.
+template<class T, class Tp, int NJ, int LO, int D>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JM_QCON_PGS_WAVES)))
+k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned B)
+{
+    using L = Layout<Tp>;
+    using RG = QSplitRegion<Tp>;
+    using X = DppQuad;
+    struct alignas(16) T2 { T a, b; };
+    constexpr int XS = 8 * NJ + 2;               // (stride in scalars: even, so that the pairs stay 16-byte aligned)
+    __shared__ T2 xs2[XS / 2 * 64];
+    T * const xs = (T *)xs2;
+    const unsigned r = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= B) return;
+    // uniform base (the 64 robots of the block) + unsigned 32-bit BYTE offset per lane
+    char * const ws = (char *)(C.ws + (size_t)blockIdx.x * (size_t)(64 * RG::ROWS));
+    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
+    const int hdr = (int)G(RG::HDR);
+    const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff, A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
+    {
+        const bool big = X::wave_any(m > 8 * NJ), mine = X::wave_any(m > LO);
+        if (big || !mine) return;   // (uniform over the wave)
+    }
+    if (m == 0) return;   // (uniform over the quad)
+    T * x = xs + (threadIdx.x >> 2) * XS;
+    const bool lead = (k == 0);
+    const T eps = Eps<T>::eps;
+    const T friction = C.friction ? C.friction[r] : P[L::OPT + 8];
+    const bool friction_zero = friction < eps, torsion_zero = C.torsion < eps;
+    const unsigned iter_max = (unsigned)C.iter_max;
+    for (int i = k; i < 8 * NJ; i += 4) x[i] = i < m ? G(i) : T(0);
+    for (int i = k; i < m; i += 4)
+    {
+        G(3 * m + i) = T(1) / G(A0 + i * ms + i);
+        for (int c = m; c < ms; ++c) G(A0 + i * ms + c) = T(0);   // padding of the row
+    }
+    for (int i = k; i < 32; i += 4) G(A0 + m * ms + i) = T(0);    // what the reads of the last rows find past the matrix
+    // how many groups of 8 * GJ columns exist in this wave (scalar tests around the loads of a row)
+    constexpr int GJ = 4, NGR = (NJ + GJ - 1) / GJ;
+    bool wide[NGR];
+    static_for<0, NGR>([&](auto gc) { wide[decltype(gc)::value] = X::wave_any(m > 8 * GJ * decltype(gc)::value); });
+    __threadfence_block();   // (1 / diag and the padding were written by one lane of the quad, every lane reads them)
+    // visit t of a sweep -> row and kind (0 clamp at zero, 1 torsion, 2 / 3 first / second tangential row)
+    const int nc = cb > 0 ? (m - nb) / cb : 0;
+    auto visit = [&](int t, int & kind) __attribute__((always_inline)) {
+        kind = 0;
+        if (t < nb) return t;
+        int u = t - nb;
+        if (u < nc) return nb + cb * u + 2;
+        u -= nc;
+        if (cb == 4)
+        {
+            kind = 1;
+            if (u < nc) return nb + 4 * u + 3;
+            u -= nc;
+        }
+        kind = 2 + (u & 1);
+        return nb + cb * (u >> 1) + (u & 1);
+    };
+    struct Row { T2 a[NJ]; T b, yp, invd; int i, kind; };
+    // row of visit t: this lane's quarter (entries (i, 8 j + 2 k), (i, 8 j + 2 k + 1)), right-hand side, previous residual
+    // (used by the lead lane, which alone writes and reads those), 1 / diag; loads only
+    auto fetch = [&](int t, Row & R_) __attribute__((always_inline)) {
+        R_.i = visit(t, R_.kind);
+        const char * row = ws + (g0 + (unsigned)(A0 + R_.i * ms + 2 * k) * (unsigned)sizeof(T));
+        static_for<0, NGR>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (wide[g])
+                static_for<GJ * g, (GJ * g + GJ < NJ ? GJ * g + GJ : NJ)>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    R_.a[j] = *(const T2 *)(row + (unsigned)(8 * j) * (unsigned)sizeof(T));
+                });
+        });
+        R_.b = G(m + R_.i); R_.yp = G(2 * m + R_.i); R_.invd = G(3 * m + R_.i);
+    };
+    // A.col(i).dot(x) from the fetched quarter (x is zero beyond m: the entries read past the end of a row drop out);
+    // four partial sums, then the quad butterfly
+    auto dot_row = [&](const T2 * a) __attribute__((always_inline)) {
+        T s[4] = {T(0), T(0), T(0), T(0)};
+        static_for<0, NGR>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (wide[g])
+                static_for<GJ * g, (GJ * g + GJ < NJ ? GJ * g + GJ : NJ)>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const T2 xv = *(const T2 *)(x + 8 * j + 2 * k);
+                    s[(2 * j) & 3] += a[j].a * xv.a;
+                    s[(2 * j + 1) & 3] += a[j].b * xv.b;
+                });
+        });
+        return X::quad_sum((s[0] + s[1]) + (s[2] + s[3]));
+    };
+    // under-relaxation schedule (constraint_solvers.cc:248-258)
+    auto relaxation = [&](unsigned iter) {
+        const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        return w;
+    };
+    Row ring[D];
+    int tp = 0;   // next visit to fetch
+    static_for<0, D - 1>([&](auto dc) { fetch(tp, ring[decltype(dc)::value]); tp = tp + 1 < m ? tp + 1 : 0; });
+    bool ok = false, done = iter_max == 0;
+    unsigned iter = 0;
+    int tt = 0;   // visit being worked on
+    T w = relaxation(0), dmax = T(0), ymax = T(0);
+    T y0 = T(0), id0 = T(0);   // first tangential row of the cone being worked on
+    while (!done)
+    {
+        static_for<0, D>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if (done) return;
+            fetch(tp, ring[(d + D - 1) % D]);
+            tp = tp + 1 < m ? tp + 1 : 0;
+            const Row & cur = ring[d];
+            const int i = cur.i, kind = cur.kind;
+            if ((kind == 1 && torsion_zero) || (kind >= 2 && friction_zero))
+            {
+                // (rows the reference zeroes without looking at their residual)
+                if (lead) x[i] = x[i] * T(0);
+            }
+            else
+            {
+                // residual of the row (kept by the lead lane for the stagnation test of the next sweep), stagnation maxima
+                const T y = cur.b - dot_row(cur.a);
+                const T yp = X::template bcast<0>(cur.yp);
+                dmax = fmax_(dmax, cabs_(y - yp));
+                ymax = fmax_(ymax, cabs_(y));
+                if (lead) G(2 * m + i) = y;
+                // (solves of fewer rows than the ring: the row is already in flight again, with its residual of the sweep before)
+                static_for<0, D>([&](auto ec) { if (decltype(ec)::value != d && ring[decltype(ec)::value].i == i) ring[decltype(ec)::value].yp = y; });
+                if (kind == 0)
+                {
+                    const T e = x[i] + (w * y) * cur.invd;
+                    if (lead) x[i] = fmax_(e, T(0));  // clamp(e, 0, inf)
+                }
+                else if (kind == 1)
+                {
+                    const T e = x[i] + (w * y) * cur.invd;
+                    const T thr = C.torsion * x[i - 1];
+                    if (lead) x[i] = clamp_(e, -thr, thr);
+                }
+                else if (kind == 2) { y0 = y; id0 = cur.invd; }
+                else
+                {
+                    const T ia = fmin_(id0, cur.invd);   // 1 / max(a00, a11)
+                    T e0 = x[i - 1] + (w * y0) * ia;
+                    T e1 = x[i] + (w * y) * ia;
+                    const T thr = friction * x[i + 1];
+                    const T n2 = e0 * e0 + e1 * e1;
+                    if (n2 > thr * thr)
+                    {
+                        const T scale = thr / sqrt_(n2);
+                        e0 *= scale;
+                        e1 *= scale;
+                    }
+                    if (lead) { x[i - 1] = e0; x[i] = e1; }
+                }
+            }
+            if (++tt == m)
+            {
+                // end of the sweep: stagnation of the residuals (constraint_solvers.cc:263-278)
+                tt = 0;
+                const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+                if (dmax < tol) { ok = true; done = true; }
+                else if (++iter == iter_max) done = true;
+                else { w = relaxation(iter); dmax = T(0); ymax = T(0); }
+            }
+        });
+    }
+    for (int i = k; i < m; i += 4) G(i) = x[i];
+    if (lead) G(RG::OK) = ok ? T(1) : T(0);
+}
+
 template<class T, class Tp>
 __global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
 k_quad_con_gen(const BatchArgs<T> A, const QConArgs<T> C)
@@ -1621,7 +1974,7 @@ k_quad_con_gen(const BatchArgs<T> A, const QConArgs<T> C)
     const int k = threadIdx.x & 3;
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
-    const QStore<T> V{con + (threadIdx.x >> 2) * RSTRIDE, C.ws + r, (unsigned)A.B, CAP};
+    const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
     quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP, true>(A, r, k, table, S, &C, &V);
 }
 #endif

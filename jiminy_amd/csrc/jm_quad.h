@@ -211,6 +211,21 @@ template<class Tp> struct QRows
     static constexpr int CMDB = KVB + NVB, NB = CMD_LDS ? CMDB + Tp::QT : CMDB;
 };
 
+// Split constrained stepping (jm_qcon.h: one evaluation = three launches, pre | solve | post): the stage buffer lives in
+// HBM between the launches (one tile per wave: [tile][row][64] limb rows, [tile][row][16] trunk rows) and carries, on top
+// of the rows above, the state of the evaluation in flight, the acceleration of the previous one, the lane status and the
+// constraint context of the evaluation.
+template<class Tp> struct QSplitRows
+{
+    using R = QRows<Tp>;
+    static constexpr int N = Tp::QN, NQB = QInfo<Tp>::NQB, NVB = QInfo<Tp>::NVB;
+    static constexpr int CURQL = R::NL, CURVL = CURQL + N, DDQL = CURVL + N, STATUSL = DDQL + N, CXL = STATUSL + 1, NCX = 12;
+    static constexpr int NL = CXL + NCX;
+    static constexpr int CURQB = R::NB, CURVB = CURQB + NQB, DDQB = CURVB + NVB, NB = DDQB + NVB;
+    // scalars per tile of 16 robots
+    static constexpr int TILE = NL * 64 + NB * 16;
+};
+
 // All global accesses use a uniform base pointer + an unsigned 32-bit per-lane element offset, so
 // that they select the `saddr + voffset` addressing form instead of pinning a 64-bit VGPR address
 // per access (the batch size is bounded accordingly in jm_batch_create).
@@ -1582,7 +1597,7 @@ template<class Tp> constexpr int qcon_first_contact_row()   // = number of bound
 template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_contact_row<Tp>(); }   // ConRows<Tp>::LAM
 template<class T> struct QConArgs;
 template<class T> struct QStore;
-template<class T, class Tp, class X, class SB, int CAPC, bool GEN>
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH = 0>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1590,10 +1605,13 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
 
 // one lane of a quad: robot r, limb k. `S` = stage buffer views of this lane.  QCON: every evaluation is the
 // constrained one (`C` / `V`: constraint state and the robot's solver region).
-template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0, bool GEN = false>
+// PH (QCON only): 0 = every evaluation of the launch in this kernel; 1 / 2 = split stepping, the part of evaluation
+// `C->split_e` before / after the multipliers are solved (k_quad_con_pre / k_quad_con_post, jm_qcon.h).
+template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0, bool GEN = false, int PH = 0>
 JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S,
                           const QConArgs<T> * C = nullptr, const QStore<T> * V = nullptr)
 {
+    using SR = QSplitRows<Tp>;
     using Q = QLayout<Tp>;
     using R = QRows<Tp>;
     using I = QInfo<Tp>;
@@ -1636,6 +1654,9 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     // Stage-buffer invariant at the start of every integrator step: q0/v0 = state, kv = v0,
     // accumulators = 0, ddq(b) registers = a(state).  Every stage update is then the same
     // straight-line code (no per-element `first stage ?` branches around the LDS reads).
+    int split_e = 0;
+    if constexpr (PH != 0) split_e = C->split_e;
+    if (PH == 0 || (PH == 1 && split_e == 0))
     {
         bool bad = false;
         static_for<0, NQB>([&](auto ic) {
@@ -1669,6 +1690,25 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         });
         // NaN guard on the incoming state (engine.cc:1737-1747)
         if (bad && stepping) status |= JM_LANE_NAN;
+    }
+    else
+    {
+        // split stepping: what the previous launch left in the stage buffer
+        status = (int)S.getl(SR::STATUSL);
+        if constexpr (PH == 1)
+        {
+            static_for<0, NVB>([&](auto ic) { ddqb[decltype(ic)::value] = S.getb(SR::DDQB + decltype(ic)::value); });
+            static_for<0, N>([&](auto sc) { ddq[decltype(sc)::value] = S.getl(SR::DDQL + decltype(sc)::value); });
+        }
+        else
+        {
+            static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(SR::CURQB + decltype(ic)::value); });
+            static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(SR::CURVB + decltype(ic)::value); });
+            static_for<0, N>([&](auto sc) {
+                ql[decltype(sc)::value] = S.getl(SR::CURQL + decltype(sc)::value);
+                vl[decltype(sc)::value] = S.getl(SR::CURVL + decltype(sc)::value);
+            });
+        }
     }
     // The 4 lanes of a quad execute in lock-step on the GPU, so every lane has read the trunk
     // rows of q/v/a before the lead lane overwrites them at commit time; the host emulation
@@ -1781,6 +1821,37 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     {
         // constraint contact model: ONE call site of the (large) constrained evaluation, emitting or not at run time
         const int start_passes = (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0);
+        if constexpr (PH != 0)
+        {
+            // one part of one evaluation of a step launch (MODE_STEP only)
+            const int e = split_e;
+            const int st = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
+            const bool last = e == n_evals - 1;
+            if constexpr (PH == 1)
+            {
+                advance(st, last, rr);
+                static_for<0, NQB>([&](auto ic) { S.putb(SR::CURQB + decltype(ic)::value, qb[decltype(ic)::value]); });
+                static_for<0, NVB>([&](auto ic) { S.putb(SR::CURVB + decltype(ic)::value, vb[decltype(ic)::value]); });
+                static_for<0, N>([&](auto sc) {
+                    S.putl(SR::CURQL + decltype(sc)::value, ql[decltype(sc)::value]);
+                    S.putl(SR::CURVL + decltype(sc)::value, vl[decltype(sc)::value]);
+                });
+            }
+            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN, PH>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last,
+                                    A.update_sensors != 0, ddqb, ddq, status, 0);
+            if (PH == 1 || !last)
+            {
+                S.putl(SR::STATUSL, (T)status);
+                if constexpr (PH == 2)
+                {
+                    static_for<0, NVB>([&](auto ic) { S.putb(SR::DDQB + decltype(ic)::value, ddqb[decltype(ic)::value]); });
+                    static_for<0, N>([&](auto sc) { S.putl(SR::DDQL + decltype(sc)::value, ddq[decltype(sc)::value]); });
+                }
+                return;
+            }
+        }
+        else
+        {
 #pragma nounroll
         for (int e = 0; e < n_evals; ++e)
         {
@@ -1793,6 +1864,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
                                     (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status,
                                     start_passes);
+        }
         }
     }
     else

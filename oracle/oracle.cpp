@@ -38,6 +38,8 @@
 // For ANYmal/Atlas-sized floating-base models against the real binary: "parity unpinned".
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -1299,6 +1301,7 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         e.pgsIterLast = 0;
     }
     else ok = pgs_solve(e, rs, A, b, lambda, e.pgsIterLast);
+    if (std::getenv("ORC_PGS_TRACE")) std::fprintf(stderr, "pgs rows=%d sweeps=%d\n", (int)b.size(), (int)e.pgsIterLast);   // debugging aid
     if (!ok) e.status |= JM_LANE_SOLVER_FAILURE;
     // ---- ddq = M^-1 J^T lambda + torque_residual
     std::vector<double> ddq(nv, 0.0);

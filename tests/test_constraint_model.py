@@ -419,6 +419,51 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver,n_sub", [("runge_kutta_4", 1), ("runge_kutta_4", 3), ("euler_explicit", 2)])
+def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_sub):
+    """Atlas-sized solves step through three launches per evaluation (k_quad_con_split<1> | k_qcon_pgs |
+    k_quad_con_split<2>, jm_qcon.h) when the batch is a multiple of 16: same states, multipliers, flags and outputs
+    as the single kernel (JIMINY_AMD_QCON_SPLIT=0) and as the oracle."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = _models()["atlas"]()
+    B = 48
+    ref, _ = _pair(model, B, seed=23)
+    dt = 2.5e-4
+    engines = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("JIMINY_AMD_QCON_SPLIT", split)
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                            extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+        eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
+                                     "sensorsUpdatePeriod": n_sub * dt, "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]},
+                         "contacts": {"model": "constraint"}})
+        eng.set_command(torch.from_numpy(ref["command"]))
+        eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+        engines.append(eng)
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    for i in range(3):
+        for eng in engines:
+            eng.step(n_sub * dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver=solver, dt=dt, n_substeps=n_sub, command_changed=True)
+    torch.cuda.synchronize()
+    split, single = engines
+    assert np.array_equal(split.field("con_flags").cpu().numpy(), single.field("con_flags").cpu().numpy())
+    assert np.array_equal(split.status.cpu().numpy(), single.status.cpu().numpy())
+    assert np.array_equal(split.field("con_flags").cpu().numpy(), ref["con_flags"])
+    worst = {}
+    for k in OUTS:
+        if k in split._fields and split._rows.get(k, 1) > 0:
+            a, b = split.field(k).cpu().numpy(), single.field(k).cpu().numpy()
+            worst[k] = rel_err(a, b)
+            assert worst[k] < 1e-9, (k, worst[k])
+            if k in ref and ref[k].size:
+                assert rel_err(a, ref[k]) < 1e-7, (k, rel_err(a, ref[k]))
+    print("split vs single kernel:", ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.gpu
 def test_gpu_anymal_stands_still_under_the_constraint_model(gpu_device):
     """Reference acceptance for its quadrupeds / bipeds (gym_jiminy unit_py/test_pipeline_control.py:46-133):
     the robot keeps standing.  Here: ANYmal at its neutral stance with the shipped options

@@ -32,5 +32,5 @@ if __name__ == "__main__":
     for lib in sys.argv[1:]:
         print(lib)
         for r in resources(lib):
-            if any(k in r["kernel"] for k in ("k_quad", "k_constrained", "k_batch")):
+            if any(k in r["kernel"] for k in ("k_quad", "k_qcon", "k_constrained", "k_batch")):
                 print("  ", r)
