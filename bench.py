@@ -370,7 +370,7 @@ def main() -> None:
             if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
                 # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
                 kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json")
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json" if args.model == "anymal" else f"pmc_{args.model}_con_latest.json")
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:

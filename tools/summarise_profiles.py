@@ -44,23 +44,9 @@ def step_launch_filter(db, kernel_like):
     return {i for i, d in rows if d > 0.6 * med}
 
 
-def main():
-    src, name = sys.argv[1], sys.argv[2]
-    # optional third argument: output directory (the GPU box summarises in place, the rocpd
-    # databases themselves are too large to travel back)
-    out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
-    os.makedirs(out_dir, exist_ok=True)
-    stats_db = glob.glob(os.path.join(src, "stats", "*.db"))[0]
-    rows, regs = kernel_rows(stats_db)
-    total = sum(r[2] for r in rows)
-    with open(os.path.join(out_dir, f"{name}_kernel_stats.csv"), "w") as f:
-        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,pct,arch_vgpr,accum_vgpr,sgpr,lds_bytes,scratch_bytes\n")
-        for r in rows:
-            g = regs.get(r[0], ("",) * 5)
-            f.write('"%s",%d,%d,%.1f,%d,%d,%.2f,%s,%s,%s,%s,%s\n' % (r[0], r[1], r[2], r[3], r[4], r[5],
-                                                                   100.0 * r[2] / total, *g))
-    dominant = rows[0][0]
-    like = dominant
+def summarise_kernel(src, stats_db, like):
+    """Step-launch durations and per-launch counter medians of one kernel."""
+    dominant = like
     db = sqlite3.connect(stats_db)
     keep = step_launch_filter(db, like)
     durs = [d for i, d in db.execute("select dispatch_id, duration from kernels where name like ?", (like,))
@@ -95,6 +81,40 @@ def main():
                 summary[k + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         summary["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
+    return summary
+
+
+def main():
+    src, name = sys.argv[1], sys.argv[2]
+    # optional third argument: output directory (the GPU box summarises in place, the rocpd
+    # databases themselves are too large to travel back)
+    out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats_db = glob.glob(os.path.join(src, "stats", "*.db"))[0]
+    rows, regs = kernel_rows(stats_db)
+    total = sum(r[2] for r in rows)
+    with open(os.path.join(out_dir, f"{name}_kernel_stats.csv"), "w") as f:
+        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,pct,arch_vgpr,accum_vgpr,sgpr,lds_bytes,scratch_bytes\n")
+        for r in rows:
+            g = regs.get(r[0], ("",) * 5)
+            f.write('"%s",%d,%d,%.1f,%d,%d,%.2f,%s,%s,%s,%s,%s\n' % (r[0], r[1], r[2], r[3], r[4], r[5],
+                                                                   100.0 * r[2] / total, *g))
+    # JM_PROFILE_DOMINANT: LIKE pattern of the kernel to summarise instead of the one with the largest total
+    # (launches made of several kernels: the reset launches of a short run can outweigh the step kernels);
+    # JM_PROFILE_KERNELS: comma-separated LIKE patterns of further kernels summarised under "other_kernels".
+    dominant = rows[0][0]
+    pat = os.environ.get("JM_PROFILE_DOMINANT")
+    if pat:
+        dominant = next((r[0] for r in rows if sqlite3.connect(":memory:").execute("select ? like ?", (r[0], pat)).fetchone()[0]), dominant)
+    summary = summarise_kernel(src, stats_db, dominant)
+    c = summary["counters_per_launch_median"]
+    others = [x for x in os.environ.get("JM_PROFILE_KERNELS", "").split(",") if x]
+    if others:
+        summary["other_kernels"] = {}
+        for o in others:
+            name_o = next((r[0] for r in rows if sqlite3.connect(":memory:").execute("select ? like ?", (r[0], o)).fetchone()[0]), None)
+            if name_o:
+                summary["other_kernels"][name_o] = summarise_kernel(src, stats_db, name_o)
     try:
         with open(os.path.join(src, "bench.json")) as f:
             b = json.loads(f.read().strip().splitlines()[-1])
