@@ -92,6 +92,10 @@ struct jm_batch
     void * field[JM_F_COUNT] = {};
     bool started = false;
     bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
+    int split_chunks = 1;     // ... as this many independent chunks on streams of their own (JIMINY_AMD_QCON_SPLIT_CHUNKS; measured: no gain)
+    hipStream_t split_stream[8] = {};
+    hipEvent_t split_fork = nullptr, split_join[8] = {};
+    bool split_streams_made = false;
     // adaptive stepper: caller-owned workspace / per-lane state, library-owned active-lane counter
     void * ad_ws = nullptr;
     double * ad_fs = nullptr;
@@ -221,6 +225,20 @@ template<class T, class Tp> void launch_quad(jm_batch * b, jm::BatchArgs<T> & A,
     else { (void)b; (void)A; (void)s; }
 }
 
+// streams / events of the chunked split stepping, made on first use (non-blocking streams: no implicit ordering with the
+// legacy default stream; the fork / join events order them with the caller's stream)
+bool split_streams(jm_batch * b)
+{
+    if (b->split_streams_made) return true;
+    if (hipEventCreateWithFlags(&b->split_fork, hipEventDisableTiming) != hipSuccess) return false;
+    for (int c = 0; c < b->split_chunks; ++c)
+        if (hipStreamCreateWithFlags(&b->split_stream[c], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&b->split_join[c], hipEventDisableTiming) != hipSuccess)
+            return false;
+    b->split_streams_made = true;
+    return true;
+}
+
 // constraint contact model on the branch-parallel decomposition (jm_qcon.h)
 template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A, const jm::ConArgs<double> & C0, hipStream_t s)
 {
@@ -232,7 +250,7 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
         C.iter_max = C0.iter_max;
         C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
         C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
-        C.stage = nullptr; C.split_e = 0;
+        C.stage = nullptr; C.split_e = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
         constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
         if constexpr (jm::qcon_split<Tp>())
@@ -243,17 +261,47 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                 C.stage = C.ws + (size_t)jm::qcon_split_region_rows<double, Tp>() * (size_t)A.B;
                 const int pre = A.command_changed ? 1 : 0;
                 const int n_evals = pre + A.n_sub * (A.solver == JM_SOLVER_RUNGE_KUTTA_4 ? 4 : 1);
-                const unsigned g64 = (unsigned)((A.B + 63) / 64);
-                for (int e = 0; e < n_evals; ++e)
+                // The solve launch lasts as long as its slowest robot (a few of 32 768 run into the iteration cap) while
+                // most of the chip idles.  Option (JIMINY_AMD_QCON_SPLIT_CHUNKS = n > 1, off by default): the batch steps as n
+                // independent chunks, each through its own chain of launches on a stream of its own, so that the tail of one
+                // chunk could overlap the work of the others.  Measured on the MI355X (Atlas, B = 32 768): 9.2 ms per launch
+                // with one chain, 8.8 with two chunks, 12.2 with four, 15.9 with eight -- the chains mostly serialise.
+                // (Never while the caller's stream is being captured into a graph.)
+                int n_chunks = 1;
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (b->split_chunks > 1 && A.B >= 64LL * 8 * b->split_chunks && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+                    cap == hipStreamCaptureStatusNone && split_streams(b))
+                    n_chunks = b->split_chunks;
+                const long long per = (((A.B + n_chunks - 1) / n_chunks) + 63) / 64 * 64;
+                if (n_chunks > 1)
                 {
-                    C.split_e = e;
-                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
-                    // (solves of up to 64 rows, then the waves that hold a larger one)
-                    hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
-                    if constexpr (jm::QConRows<Tp>::MAXM > 64)
-                        hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 12, 64, JM_QCON_PGS_DEPTH - 1>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
-                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, s, A, C);
+                    hipEventRecord(b->split_fork, s);
+                    for (int c = 0; c < n_chunks; ++c) hipStreamWaitEvent(b->split_stream[c], b->split_fork, 0);
                 }
+                for (int c = 0; c < n_chunks; ++c)
+                {
+                    const hipStream_t sc = n_chunks > 1 ? b->split_stream[c] : s;
+                    C.split_r0 = (int)(c * per);
+                    C.split_r1 = (int)((c + 1) * per < A.B ? (c + 1) * per : A.B);
+                    if (C.split_r1 <= C.split_r0) continue;
+                    const unsigned g64 = (unsigned)((C.split_r1 - C.split_r0 + 63) / 64);
+                    for (int e = 0; e < n_evals; ++e)
+                    {
+                        C.split_e = e;
+                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, sc, A, C);
+                        // (solves of up to 64 rows, then the waves that hold a larger one)
+                        hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
+                        if constexpr (jm::QConRows<Tp>::MAXM > 64)
+                            hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 12, 64, JM_QCON_PGS_DEPTH - 1>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
+                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, sc, A, C);
+                    }
+                }
+                if (n_chunks > 1)
+                    for (int c = 0; c < n_chunks; ++c)
+                    {
+                        hipEventRecord(b->split_join[c], b->split_stream[c]);
+                        hipStreamWaitEvent(s, b->split_join[c], 0);
+                    }
                 return;
             }
         }
@@ -515,6 +563,11 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     // generic one-robot-per-lane kernel (A/B measurements)
     b->variant = (Topo::QUAD && model->root_at_origin) ? VARIANT_QUAD : VARIANT_LANE;
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT")) b->qcon_split = e[0] != '0';
+    if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT_CHUNKS"))
+    {
+        const int n = std::atoi(e);
+        b->split_chunks = n < 1 ? 1 : (n > 8 ? 8 : n);
+    }
     if (const char * v = std::getenv("JM_KERNEL_VARIANT"))
         if (std::string(v) == "lane") b->variant = VARIANT_LANE;
     hipError_t e = hipSetDevice(device);
@@ -546,6 +599,9 @@ int32_t jm_batch_destroy(jm_batch * b)
     if (b->ad_flags) (void)hipFree(b->ad_flags);
     if (b->ad_count_host) (void)hipHostFree(b->ad_count_host);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+    if (b->split_fork) (void)hipEventDestroy(b->split_fork);
+    for (hipEvent_t e : b->split_join) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : b->split_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     delete b;
     return JM_OK;
 }

@@ -92,6 +92,7 @@ template<class T> struct QConArgs
     // split stepping (k_quad_con_pre / k_qcon_pgs / k_quad_con_post): stage buffer in HBM, evaluation of this launch
     T * stage;
     int split_e;
+    int split_r0, split_r1;   // robots [r0, r1) of this launch (chunks of the batch step on streams of their own, jm_lib.cpp)
 };
 
 template<class Tp> struct QConRows
@@ -152,6 +153,7 @@ template<class T, int NIT_> struct QStoreChip
     static constexpr int NIT = NIT_;   // quarter-sum terms per lane: the store holds solves of up to 4 * NIT rows
     T * lds;
     JM_DEV T get(int e) const { return lds[e]; }
+    JM_DEV T get_flat(int e) const { return lds[e]; }
     JM_DEV void put(int e, T x) const { lds[e] = x; }
     JM_DEV void put_a(int m, int pr, int pc, T x) const { put(4 * m + pr * (pr + 1) / 2 + pc, x); }
 };
@@ -166,6 +168,7 @@ template<class T> struct QStoreSq
     T * hbm;
     static JM_DEV int row_stride(int m) { return (m + 3) & ~3; }
     JM_DEV T get(int e) const { return hbm[e]; }
+    JM_DEV T get_flat(int e) const { return hbm[e]; }
     JM_DEV void put(int e, T x) const { hbm[e] = x; }
     JM_DEV void put_a(int m, int pr, int pc, T x) const
     {
@@ -1303,41 +1306,67 @@ JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConC
 }
 
 // Exact solve A x = b (Engine::start's first pass, `ignoreBounds`: solveJMinvJtv): Cholesky in place in the
-// packed triangle -- the caller rebuilds the matrix afterwards.  Serial, lead lane only (start / reset only).
+// packed triangle -- the caller rebuilds the matrix afterwards (start / reset only).  Left-looking, by the four lanes of the
+// quad: the diagonal entry of column j is computed by every lane (no exchange), the rows below it are dealt round-robin; the
+// dot products of two rows of the factor read their entries in batches of eight pairs, branch-free (`get_flat`), so that a
+// batch costs one round trip to the workspace instead of sixteen.  (Atlas, `reset` of 32 768 robots standing on sixteen
+// contact points, 94 rows: 82 -> 68 ms per launch against the serial lead-lane form; the rest is the three start passes
+// of the general Gauss-Seidel form at 94 rows.)
 template<class T, class X, class VS>
 JM_DEV bool qcon_chol(int k, int m, const VS & V)
 {
     const int A0 = 4 * m;
     bool ok = true;
     X::sync();
-    if (k == 0)
+    // sum over c in [c0, n) step `step` of F(i, c) F(j, c), rows i, j of the packed factor
+    auto rowdot = [&](int i, int j, int c0, int n, int step) {
+        const int bi = A0 + i * (i + 1) / 2, bj = A0 + j * (j + 1) / 2;
+        T s = T(0);
+        int c = c0;
+        for (; c + 7 * step < n; c += 8 * step)
+        {
+            T a[8], b[8];
+            static_for<0, 8>([&](auto uc) { constexpr int u = decltype(uc)::value; a[u] = V.get_flat(bi + c + u * step); b[u] = V.get_flat(bj + c + u * step); });
+            static_for<0, 8>([&](auto uc) { constexpr int u = decltype(uc)::value; s += a[u] * b[u]; });
+        }
+        for (; c < n; c += step) s += V.get_flat(bi + c) * V.get_flat(bj + c);
+        return s;
+    };
+    for (int j = 0; j < m; ++j)
     {
-        for (int j = 0; j < m; ++j)
+        const T sj = V.get_flat(A0 + tri_(j, j)) - rowdot(j, j, 0, j, 1);
+        ok &= sj > T(0);
+        const T d = sqrt_(sj);
+        X::sync();   // (every lane has read the diagonal entry before the lead lane overwrites it)
+        if (k == 0) V.put(A0 + tri_(j, j), d);
+        for (int i = j + 1 + k; i < m; i += 4)
         {
-            T s = V.get(A0 + tri_(j, j));
-            for (int c = 0; c < j; ++c) { const T l = V.get(A0 + tri_(j, c)); s -= l * l; }
-            ok &= s > T(0);
-            const T d = sqrt_(s);
-            V.put(A0 + tri_(j, j), d);
-            for (int i = j + 1; i < m; ++i)
-            {
-                T t = V.get(A0 + tri_(i, j));
-                for (int c = 0; c < j; ++c) t -= V.get(A0 + tri_(i, c)) * V.get(A0 + tri_(j, c));
-                V.put(A0 + tri_(i, j), t / d);
-            }
+            const T t = V.get_flat(A0 + tri_(i, j)) - rowdot(i, j, 0, j, 1);
+            V.put(A0 + tri_(i, j), t / d);
         }
-        for (int i = 0; i < m; ++i)
-        {
-            T s = V.get(m + i);
-            for (int c = 0; c < i; ++c) s -= V.get(A0 + tri_(i, c)) * V.get(c);
-            V.put(i, s / V.get(A0 + tri_(i, i)));
-        }
-        for (int i = m - 1; i >= 0; --i)
-        {
-            T s = V.get(i);
-            for (int c = i + 1; c < m; ++c) s -= V.get(A0 + tri_(c, i)) * V.get(c);
-            V.put(i, s / V.get(A0 + tri_(i, i)));
-        }
+        X::fence();   // the next column reads rows written by the other lanes of the quad
+    }
+    // forward and backward substitution: the lanes share the sum of a row, every lane holds the result
+    for (int i = 0; i < m; ++i)
+    {
+        const int bi = A0 + i * (i + 1) / 2;
+        T s = T(0);
+        for (int c = k; c < i; c += 4) s += V.get_flat(bi + c) * V.get_flat(c);
+        s = V.get_flat(m + i) - X::quad_sum(s);
+        const T xi = s / V.get_flat(bi + i);
+        X::sync();
+        if (k == 0) V.put(i, xi);
+        X::fence();
+    }
+    for (int i = m - 1; i >= 0; --i)
+    {
+        T s = T(0);
+        for (int c = i + 1 + k; c < m; c += 4) s += V.get_flat(A0 + tri_(c, i)) * V.get_flat(c);
+        s = V.get_flat(i) - X::quad_sum(s);
+        const T xi = s / V.get_flat(A0 + tri_(i, i));
+        X::sync();
+        if (k == 0) V.put(i, xi);
+        X::fence();
     }
     X::sync();
     return X::quad_or(ok ? 0 : 1) == 0;
@@ -1757,9 +1786,9 @@ k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
     __shared__ T table[Q::TABLE];
 #pragma nounroll
     for (int i = threadIdx.x; i < Q::TABLE; i += 256) table[i] = A.P[Q::OFFSET + i];
-    const long long r = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const long long r = (long long)C.split_r0 + (long long)blockIdx.x * 64 + (threadIdx.x >> 2);   // (r0: a multiple of 64)
     const int k = threadIdx.x & 3;
-    if (r >= A.B) return;
+    if (r >= C.split_r1) return;
     T * tile = C.stage + (size_t)(r >> 4) * (size_t)SR::TILE;
     const StageBuf<T, 64, 16> S{tile + (threadIdx.x & 63), tile + SR::NL * 64 + ((threadIdx.x >> 2) & 15), k == 0};
     const QStore<T> V = qcon_split_store<T, Tp>(C.ws, r);
@@ -1780,20 +1809,22 @@ k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
 // PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333), statement by statement the sweep of `qcon_pgs`.
 template<class T, class Tp, int NJ, int LO, int D>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JM_QCON_PGS_WAVES)))
-k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned B)
+k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
 {
     using L = Layout<Tp>;
     using RG = QSplitRegion<Tp>;
     using X = DppQuad;
     struct alignas(16) T2 { T a, b; };
     constexpr int XS = 8 * NJ + 2;               // (stride in scalars: even, so that the pairs stay 16-byte aligned)
+    constexpr int VS_ = 8 * NJ + 4;              // visit table of a robot: one 16-bit word per row visit (+ 4: quads in different banks)
     __shared__ T2 xs2[XS / 2 * 64];
+    __shared__ unsigned short vis[VS_ * 64];
     T * const xs = (T *)xs2;
-    const unsigned r = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
     const int k = threadIdx.x & 3;
-    if (r >= B) return;
+    if (r >= (unsigned)C.split_r1) return;
     // uniform base (the 64 robots of the block) + unsigned 32-bit BYTE offset per lane
-    char * const ws = (char *)(C.ws + (size_t)blockIdx.x * (size_t)(64 * RG::ROWS));
+    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
     const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
     auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
     const int hdr = (int)G(RG::HDR);
@@ -1838,11 +1869,20 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned B)
         kind = 2 + (u & 1);
         return nb + cb * (u >> 1) + (u & 1);
     };
+    // (the table of the sweep, built once per solve: row | kind << 8)
+    unsigned short * const vt = vis + (threadIdx.x >> 2) * VS_;
+    for (int t = k; t < m; t += 4)
+    {
+        int kind;
+        const int row = visit(t, kind);
+        vt[t] = (unsigned short)(row | (kind << 8));
+    }
     struct Row { T2 a[NJ]; T b, yp, invd; int i, kind; };
     // row of visit t: this lane's quarter (entries (i, 8 j + 2 k), (i, 8 j + 2 k + 1)), right-hand side, previous residual
     // (used by the lead lane, which alone writes and reads those), 1 / diag; loads only
     auto fetch = [&](int t, Row & R_) __attribute__((always_inline)) {
-        R_.i = visit(t, R_.kind);
+        const int v = vt[t];
+        R_.i = v & 0xff; R_.kind = v >> 8;
         const char * row = ws + (g0 + (unsigned)(A0 + R_.i * ms + 2 * k) * (unsigned)sizeof(T));
         static_for<0, NGR>([&](auto gc) {
             constexpr int g = decltype(gc)::value;

@@ -101,6 +101,7 @@ struct HostQuad
     template<class T> static T max_abs(T a, T b) { return std::fmax(a, std::fabs(b)); }
     template<class T> static T max_(T a, T b) { return std::fmax(a, b); }
     static void sync() { pthread_barrier_wait(&sh->bar); }
+    static void fence() { pthread_barrier_wait(&sh->bar); }   // device: memory fence within the wave; here the lanes are threads
     static void table_ready() {}
     static int quad_or(int x)
     {

@@ -419,21 +419,25 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver,n_sub", [("runge_kutta_4", 1), ("runge_kutta_4", 3), ("euler_explicit", 2)])
-def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_sub):
+@pytest.mark.parametrize("solver,n_sub,B", [("runge_kutta_4", 1, 48), ("runge_kutta_4", 3, 48), ("euler_explicit", 2, 48),
+                                            ("runge_kutta_4", 2, 2048 + 80)])
+def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_sub, B):
     """Atlas-sized solves step through three launches per evaluation (k_quad_con_split<1> | k_qcon_pgs |
     k_quad_con_split<2>, jm_qcon.h) when the batch is a multiple of 16: same states, multipliers, flags and outputs
-    as the single kernel (JIMINY_AMD_QCON_SPLIT=0) and as the oracle."""
+    as the single kernel (JIMINY_AMD_QCON_SPLIT=0) and as the oracle.  The large batch steps as four chunks on streams of
+    their own (the JIMINY_AMD_QCON_SPLIT_CHUNKS option of jm_lib.cpp, launch_quad_con; last chunk ragged): compared with the
+    single kernel."""
     import torch
 
     from jiminy_amd.engine import BatchedEngine
     model = _models()["atlas"]()
-    B = 48
+    with_oracle = B <= 64
     ref, _ = _pair(model, B, seed=23)
     dt = 2.5e-4
     engines = []
     for split in ("1", "0"):
         monkeypatch.setenv("JIMINY_AMD_QCON_SPLIT", split)
+        monkeypatch.setenv("JIMINY_AMD_QCON_SPLIT_CHUNKS", "4" if B > 64 else "1")
         eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
                             extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
         eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
@@ -442,23 +446,26 @@ def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_s
         eng.set_command(torch.from_numpy(ref["command"]))
         eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
         engines.append(eng)
-    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    if with_oracle:
+        oracle_batch(model, ref, "start", constraint_options=TIGHT)
     for i in range(3):
         for eng in engines:
             eng.step(n_sub * dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver=solver, dt=dt, n_substeps=n_sub, command_changed=True)
+        if with_oracle:
+            oracle_batch(model, ref, "step", constraint_options=TIGHT, solver=solver, dt=dt, n_substeps=n_sub, command_changed=True)
     torch.cuda.synchronize()
     split, single = engines
     assert np.array_equal(split.field("con_flags").cpu().numpy(), single.field("con_flags").cpu().numpy())
     assert np.array_equal(split.status.cpu().numpy(), single.status.cpu().numpy())
-    assert np.array_equal(split.field("con_flags").cpu().numpy(), ref["con_flags"])
+    if with_oracle:
+        assert np.array_equal(split.field("con_flags").cpu().numpy(), ref["con_flags"])
     worst = {}
     for k in OUTS:
         if k in split._fields and split._rows.get(k, 1) > 0:
             a, b = split.field(k).cpu().numpy(), single.field(k).cpu().numpy()
             worst[k] = rel_err(a, b)
             assert worst[k] < 1e-9, (k, worst[k])
-            if k in ref and ref[k].size:
+            if with_oracle and k in ref and ref[k].size:
                 assert rel_err(a, ref[k]) < 1e-7, (k, rel_err(a, ref[k]))
     print("split vs single kernel:", ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
 

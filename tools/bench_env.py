@@ -18,6 +18,7 @@ from jiminy_amd.envs import make_anymal_env  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="anymal", choices=("anymal", "atlas"))
     ap.add_argument("--envs", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -29,12 +30,17 @@ def main():
                     "termination, reward, masked auto-reset): no host read-back per step")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver, contact_model=args.contact_model)
+    if args.model == "atlas":
+        from jiminy_amd.envs import make_atlas_env
+        env = make_atlas_env(args.envs, device=dev, ode_solver=args.solver, contact_model=args.contact_model)
+    else:
+        env = make_anymal_env(args.envs, device=dev, ode_solver=args.solver, contact_model=args.contact_model)
     env.reset(seed=0)
     if args.graph:
         env.enable_graph(whole_step=args.whole_step)
     g = torch.Generator(device="cpu").manual_seed(0)
-    action = ((torch.rand(args.envs, 12, generator=g, dtype=torch.float64) - 0.5) * 0.5).to(dev)
+    n_act = env.engine.model.nmotors
+    action = ((torch.rand(args.envs, n_act, generator=g, dtype=torch.float64) - 0.5) * 0.5).to(dev)
     if args.zero_action:
         action = torch.zeros_like(action)
     for _ in range(args.warmup):
@@ -60,7 +66,7 @@ def main():
         extra = {"mean_active_constraints": (eng.field("con_flags") & 1).sum(0).double().mean().item(),
                  "mean_base_height": eng.field("q")[2].mean().item(),
                  "lanes_pgs_not_converged_last_eval": ((eng.status & 16) != 0).double().mean().item()}
-    print(json.dumps({"metric": "gym-steps/s ANYmal PD + Mahony pipeline", "value": args.envs * args.steps / el,
+    print(json.dumps({"metric": f"gym-steps/s {args.model} PD + Mahony pipeline", "value": args.envs * args.steps / el,
                       "contact_model": args.contact_model, **extra,
                       "ms_per_env_step": 1e3 * el / args.steps, "envs": args.envs, "steps": args.steps,
                       "integrator_steps_per_env_step": 40, "solver": args.solver, "graph": bool(args.graph), "whole_step": bool(args.whole_step), "lanes_reset": n_reset,
