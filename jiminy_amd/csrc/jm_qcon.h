@@ -198,8 +198,14 @@ template<class X, int NW> JM_DEV void quad_or_mask(RowMaskN<NW> & m)
 template<class Tp> struct QSplitRegion
 {
     static constexpr int MAXM = QConRows<Tp>::MAXM;
-    static constexpr int HDR = 4 * MAXM + MAXM * MAXM + 32, OK = HDR + 1, ROWS = OK + 1;
+    static constexpr int HDR = 4 * MAXM + MAXM * MAXM + 32, OK = HDR + 1, ROWS = (OK + 2) & ~1;   // (even: 16-byte aligned regions)
 };
+
+// which topologies step in the split form (jm_qcon.h, bottom): solves of more than 32 rows
+template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > 32; }
+#ifdef JM_TOPO_QCON_SPLIT
+static_assert(qcon_split<Topo>() == (JM_TOPO_QCON_SPLIT != 0), "codegen.qcon_split and jm::qcon_split disagree");
+#endif
 
 // everything one constrained evaluation shares between its phases (per lane)
 template<class T, class Tp> struct QConCtx
@@ -1672,129 +1678,6 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     if (!(JM_QCON_SKIP & 4)) apply();
 }
 
-#ifndef JM_HOST_EMU
-// ---------------------------------------------------------------- kernel configuration (host-visible)
-// waves per block and on-chip scalars per LANE of the per-robot solver region (a robot owns 4 lanes' worth):
-// what is left of the 160 KiB of LDS next to the limb table and the stage buffer at 4 resident waves per CU
-// (the kernel needs the whole register file: one wave per SIMD), capped by what the largest solve can use.
-// LDS plan of the constraint kernels.  The per-robot solver region wants to be on chip at least with its four vectors
-// (x | b | y | 1 / diag: they are read and written row by row inside the Gauss-Seidel dependency chain; the matrix is only
-// read).  `WR` = waves resident per CU: 4 (one per SIMD) when the stage buffer and the limb table leave >= 3 MAXM scalars
-// per robot (ANYmal: 212, whole 16-row solves on chip), else 2 or 1 -- for Atlas the stage rows of four waves take 115 kB
-// and leave 12 scalars per robot, which puts every row update of the solver behind HBM round trips; two resident waves
-// leave 236 (Atlas, B = 32 768: 33.4 -> 28.4 ms per launch together with the batched row reads of `qcon_pgs`).
-template<class T, class Tp> constexpr long qcon_free_lds(int wr, int wb)
-{
-    const long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
-    const long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
-    return 160L * 1024 - 2048 - (long)(wr / wb) * table - (long)wr * per_wave;   // 2 KiB of slack (alignment, odd strides)
-}
-template<class T, class Tp> constexpr int qcon_resident_waves()
-{
-#ifdef JM_QCON_RESIDENT_WAVES
-    return JM_QCON_RESIDENT_WAVES;   // tuning override
-#endif
-    for (int wr = 4; wr > 1; wr /= 2)
-    {
-        const int wb = wr < quad_block_waves<T, Tp>() ? wr : quad_block_waves<T, Tp>();
-        const long per_robot = qcon_free_lds<T, Tp>(wr, wb) / ((long)wr * 16 * (long)sizeof(T));
-        if (per_robot >= 3L * (QConRows<Tp>::MAXM < 64 ? QConRows<Tp>::MAXM : 64)) return wr;
-    }
-    return 1;
-}
-template<class T, class Tp> constexpr int qcon_block_waves()
-{
-    return qcon_resident_waves<T, Tp>() < quad_block_waves<T, Tp>() ? qcon_resident_waves<T, Tp>() : quad_block_waves<T, Tp>();
-}
-template<class T, class Tp> constexpr int qcon_lane_scalars()
-{
-    constexpr long W = qcon_resident_waves<T, Tp>();
-    constexpr long left = qcon_free_lds<T, Tp>((int)W, qcon_block_waves<T, Tp>());
-    constexpr long per_lane = left > 0 ? left / (W * 64 * (long)sizeof(T)) : 0;
-    constexpr long want = (QConRows<Tp>::VMAX + 3) / 4;
-    return (int)(per_lane < want ? per_lane : want);
-}
-// on-chip scalars per robot / HBM workspace rows per robot
-template<class T, class Tp> constexpr int qcon_capacity() { return 4 * qcon_lane_scalars<T, Tp>(); }
-template<class T, class Tp> constexpr int qcon_ws_rows() { return QConRows<Tp>::ws_rows(qcon_capacity<T, Tp>()); }
-
-// The robot's solver region.  Workspace rows of the 16 robots of a wave are one contiguous tile ([B / 16][rows][16]:
-// a row update reads `m` consecutive 128-byte lines) whenever the batch is a multiple of 16, robot-minor rows
-// ([rows][B]: every entry of a robot's matrix 8 B bytes apart, i.e. on its own page) otherwise.
-template<class T, class Tp> JM_DEV QStore<T> qcon_store(T * lds, T * ws, long long r, unsigned B)
-{
-    constexpr int CAP = qcon_capacity<T, Tp>();
-#if JM_QCON_WS_TILED
-    if ((B & 15u) == 0)
-        return {lds, ws + (size_t)(r >> 4) * (size_t)(qcon_ws_rows<T, Tp>() * 16) + (size_t)(r & 15), 16u, CAP};
-#endif
-    return {lds, ws + r, B, CAP};
-}
-
-template<class T, class Tp>
-__global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
-k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
-{
-    using Q = QLayout<Tp>;
-    constexpr int NTH = 64 * qcon_block_waves<T, Tp>();
-    constexpr int CAP = qcon_capacity<T, Tp>();
-    constexpr int RSTRIDE = (CAP % 2 == 0) ? CAP + 1 : CAP;   // odd: the 16 robots of a wave start in different banks
-    __shared__ T table[Q::TABLE];
-    __shared__ T stage_l[QRows<Tp>::NL * NTH];
-    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
-    __shared__ T con[(CAP > 0 ? RSTRIDE : 1) * (NTH / 4)];
-#pragma nounroll
-    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
-    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
-    const int k = threadIdx.x & 3;
-    if (r >= A.B) return;
-    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
-    const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
-    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
-}
-// ---------------------------------------------------------------- split stepping: pre | solve | post
-// Robots whose solves do not fit the chip (Atlas: 27-52 rows standing, up to JM_QCON_MAXM) step through THREE launches per
-// evaluation instead of one kernel that holds the whole evaluation in 512 registers while it waits on workspace rows:
-//   k_quad_con_pre   RK stage update, free acceleration, switching, delassus matrix, right-hand side -> workspace
-//   k_qcon_pgs       the projected Gauss-Seidel sweeps alone: ~100 registers, x on chip, 8-12 waves per CU, so that the
-//                    round trips of the row reads of one robot overlap with the sweeps of the others
-//   k_quad_con_post  multipliers -> lane state, evaluation that applies them (and emits the outputs of the launch)
-// The RK stage buffer, the state of the evaluation in flight and the constraint context live in HBM between the launches
-// (QSplitRows, one tile per wave).  Same functions, same arithmetic, same order as the single kernel; `start` / `reset` /
-// `refresh` / `dynamics` launches and the variation kernels keep the single kernel.
-template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > 32; }
-#ifdef JM_TOPO_QCON_SPLIT
-static_assert(qcon_split<Topo>() == (JM_TOPO_QCON_SPLIT != 0), "codegen.qcon_split and jm::qcon_split disagree");
-#endif
-// workspace rows ([rows][B] scalars) of the split form: solver region + header + verdict, then the stage tiles
-template<class T, class Tp> constexpr int qcon_split_region_rows() { return QSplitRegion<Tp>::ROWS; }
-template<class T, class Tp> constexpr int qcon_split_ws_rows()
-{
-    return qcon_split_region_rows<T, Tp>() + (QSplitRows<Tp>::TILE + 15) / 16;
-}
-template<class T, class Tp> JM_DEV QStore<T> qcon_split_store(T * ws, long long r)
-{
-    return {nullptr, ws + (size_t)r * (size_t)qcon_split_region_rows<T, Tp>(), 1u, 0};
-}
-
-template<class T, class Tp, int PH>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1)))
-k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
-{
-    using Q = QLayout<Tp>;
-    using SR = QSplitRows<Tp>;
-    __shared__ T table[Q::TABLE];
-#pragma nounroll
-    for (int i = threadIdx.x; i < Q::TABLE; i += 256) table[i] = A.P[Q::OFFSET + i];
-    const long long r = (long long)C.split_r0 + (long long)blockIdx.x * 64 + (threadIdx.x >> 2);   // (r0: a multiple of 64)
-    const int k = threadIdx.x & 3;
-    if (r >= C.split_r1) return;
-    T * tile = C.stage + (size_t)(r >> 4) * (size_t)SR::TILE;
-    const StageBuf<T, 64, 16> S{tile + (threadIdx.x & 63), tile + SR::NL * 64 + ((threadIdx.x >> 2) & 15), k == 0};
-    const QStore<T> V = qcon_split_store<T, Tp>(C.ws, r);
-    quad_lane_run<T, Tp, DppQuad, 64, 16, true, 0, false, PH>(A, r, k, table, S, &C, &V);
-}
-
 // The solve.  Four lanes per robot as everywhere, 16 robots per wave; the multipliers `x` of the robot on chip (zero beyond
 // its m rows), everything else (b, residuals of the previous sweep, 1 / diag, the square matrix) read from the robot's block
 // of the workspace with the row: lane k of the quad reads entries 8 j + 2 k, 8 j + 2 k + 1 of the row (16-byte loads, 64
@@ -1807,37 +1690,25 @@ k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
 // NJ = 16-byte loads per lane and row: the kernel is built for solves of up to 8 NJ rows; a wave whose largest solve needs
 // another instantiation leaves at once (LO < largest m <= 8 NJ is this one's job).
 // PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333), statement by statement the sweep of `qcon_pgs`.
-template<class T, class Tp, int NJ, int LO, int D>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JM_QCON_PGS_WAVES)))
-k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
+template<class T> struct alignas(16) QPair { T a, b; };
+// `x` / `vt`: the robot's multipliers (8 NJ + 2 scalars, 16-byte aligned) and visit table (8 NJ + 4 words) on chip; `ws` + `g0`:
+// the robot's region of the workspace as uniform base + byte offset.  Returns false when the wave belongs to another
+// instantiation (nothing touched).
+template<class T, class Tp, class X, int NJ, int LO, int D>
+JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsigned short * vt, char * ws, unsigned g0)
 {
-    using L = Layout<Tp>;
     using RG = QSplitRegion<Tp>;
-    using X = DppQuad;
-    struct alignas(16) T2 { T a, b; };
-    constexpr int XS = 8 * NJ + 2;               // (stride in scalars: even, so that the pairs stay 16-byte aligned)
-    constexpr int VS_ = 8 * NJ + 4;              // visit table of a robot: one 16-bit word per row visit (+ 4: quads in different banks)
-    __shared__ T2 xs2[XS / 2 * 64];
-    __shared__ unsigned short vis[VS_ * 64];
-    T * const xs = (T *)xs2;
-    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
-    const int k = threadIdx.x & 3;
-    if (r >= (unsigned)C.split_r1) return;
-    // uniform base (the 64 robots of the block) + unsigned 32-bit BYTE offset per lane
-    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
-    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    using T2 = QPair<T>;
     auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
     const int hdr = (int)G(RG::HDR);
     const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff, A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
     {
         const bool big = X::wave_any(m > 8 * NJ), mine = X::wave_any(m > LO);
-        if (big || !mine) return;   // (uniform over the wave)
+        if (big || !mine) return false;   // (uniform over the wave)
     }
-    if (m == 0) return;   // (uniform over the quad)
-    T * x = xs + (threadIdx.x >> 2) * XS;
+    if (m == 0) return true;   // (uniform over the quad)
     const bool lead = (k == 0);
     const T eps = Eps<T>::eps;
-    const T friction = C.friction ? C.friction[r] : P[L::OPT + 8];
     const bool friction_zero = friction < eps, torsion_zero = C.torsion < eps;
     const unsigned iter_max = (unsigned)C.iter_max;
     for (int i = k; i < 8 * NJ; i += 4) x[i] = i < m ? G(i) : T(0);
@@ -1851,7 +1722,7 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
     constexpr int GJ = 4, NGR = (NJ + GJ - 1) / GJ;
     bool wide[NGR];
     static_for<0, NGR>([&](auto gc) { wide[decltype(gc)::value] = X::wave_any(m > 8 * GJ * decltype(gc)::value); });
-    __threadfence_block();   // (1 / diag and the padding were written by one lane of the quad, every lane reads them)
+    X::fence();   // (1 / diag, the padding and the visit table were written by one lane of the quad, every lane reads them)
     // visit t of a sweep -> row and kind (0 clamp at zero, 1 torsion, 2 / 3 first / second tangential row)
     const int nc = cb > 0 ? (m - nb) / cb : 0;
     auto visit = [&](int t, int & kind) __attribute__((always_inline)) {
@@ -1870,13 +1741,13 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
         return nb + cb * (u >> 1) + (u & 1);
     };
     // (the table of the sweep, built once per solve: row | kind << 8)
-    unsigned short * const vt = vis + (threadIdx.x >> 2) * VS_;
     for (int t = k; t < m; t += 4)
     {
         int kind;
         const int row = visit(t, kind);
         vt[t] = (unsigned short)(row | (kind << 8));
     }
+    X::sync();
     struct Row { T2 a[NJ]; T b, yp, invd; int i, kind; };
     // row of visit t: this lane's quarter (entries (i, 8 j + 2 k), (i, 8 j + 2 k + 1)), right-hand side, previous residual
     // (used by the lead lane, which alone writes and reads those), 1 / diag; loads only
@@ -1981,6 +1852,7 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
                     if (lead) { x[i - 1] = e0; x[i] = e1; }
                 }
             }
+            X::sync();   // (the lead lane's multiplier is in place before the next row's dot product reads it)
             if (++tt == m)
             {
                 // end of the sweep: stagnation of the residuals (constraint_solvers.cc:263-278)
@@ -1994,6 +1866,145 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
     }
     for (int i = k; i < m; i += 4) G(i) = x[i];
     if (lead) G(RG::OK) = ok ? T(1) : T(0);
+    return true;
+}
+
+#ifndef JM_HOST_EMU
+// ---------------------------------------------------------------- kernel configuration (host-visible)
+// waves per block and on-chip scalars per LANE of the per-robot solver region (a robot owns 4 lanes' worth):
+// what is left of the 160 KiB of LDS next to the limb table and the stage buffer at 4 resident waves per CU
+// (the kernel needs the whole register file: one wave per SIMD), capped by what the largest solve can use.
+// LDS plan of the constraint kernels.  The per-robot solver region wants to be on chip at least with its four vectors
+// (x | b | y | 1 / diag: they are read and written row by row inside the Gauss-Seidel dependency chain; the matrix is only
+// read).  `WR` = waves resident per CU: 4 (one per SIMD) when the stage buffer and the limb table leave >= 3 MAXM scalars
+// per robot (ANYmal: 212, whole 16-row solves on chip), else 2 or 1 -- for Atlas the stage rows of four waves take 115 kB
+// and leave 12 scalars per robot, which puts every row update of the solver behind HBM round trips; two resident waves
+// leave 236 (Atlas, B = 32 768: 33.4 -> 28.4 ms per launch together with the batched row reads of `qcon_pgs`).
+template<class T, class Tp> constexpr long qcon_free_lds(int wr, int wb)
+{
+    const long per_wave = (long)sizeof(T) * (QRows<Tp>::NL * 64 + QRows<Tp>::NB * 16);
+    const long table = (long)sizeof(T) * QLayout<Tp>::TABLE;
+    return 160L * 1024 - 2048 - (long)(wr / wb) * table - (long)wr * per_wave;   // 2 KiB of slack (alignment, odd strides)
+}
+template<class T, class Tp> constexpr int qcon_resident_waves()
+{
+#ifdef JM_QCON_RESIDENT_WAVES
+    return JM_QCON_RESIDENT_WAVES;   // tuning override
+#endif
+    for (int wr = 4; wr > 1; wr /= 2)
+    {
+        const int wb = wr < quad_block_waves<T, Tp>() ? wr : quad_block_waves<T, Tp>();
+        const long per_robot = qcon_free_lds<T, Tp>(wr, wb) / ((long)wr * 16 * (long)sizeof(T));
+        if (per_robot >= 3L * (QConRows<Tp>::MAXM < 64 ? QConRows<Tp>::MAXM : 64)) return wr;
+    }
+    return 1;
+}
+template<class T, class Tp> constexpr int qcon_block_waves()
+{
+    return qcon_resident_waves<T, Tp>() < quad_block_waves<T, Tp>() ? qcon_resident_waves<T, Tp>() : quad_block_waves<T, Tp>();
+}
+template<class T, class Tp> constexpr int qcon_lane_scalars()
+{
+    constexpr long W = qcon_resident_waves<T, Tp>();
+    constexpr long left = qcon_free_lds<T, Tp>((int)W, qcon_block_waves<T, Tp>());
+    constexpr long per_lane = left > 0 ? left / (W * 64 * (long)sizeof(T)) : 0;
+    constexpr long want = (QConRows<Tp>::VMAX + 3) / 4;
+    return (int)(per_lane < want ? per_lane : want);
+}
+// on-chip scalars per robot / HBM workspace rows per robot
+template<class T, class Tp> constexpr int qcon_capacity() { return 4 * qcon_lane_scalars<T, Tp>(); }
+template<class T, class Tp> constexpr int qcon_ws_rows() { return QConRows<Tp>::ws_rows(qcon_capacity<T, Tp>()); }
+
+// The robot's solver region.  Workspace rows of the 16 robots of a wave are one contiguous tile ([B / 16][rows][16]:
+// a row update reads `m` consecutive 128-byte lines) whenever the batch is a multiple of 16, robot-minor rows
+// ([rows][B]: every entry of a robot's matrix 8 B bytes apart, i.e. on its own page) otherwise.
+template<class T, class Tp> JM_DEV QStore<T> qcon_store(T * lds, T * ws, long long r, unsigned B)
+{
+    constexpr int CAP = qcon_capacity<T, Tp>();
+#if JM_QCON_WS_TILED
+    if ((B & 15u) == 0)
+        return {lds, ws + (size_t)(r >> 4) * (size_t)(qcon_ws_rows<T, Tp>() * 16) + (size_t)(r & 15), 16u, CAP};
+#endif
+    return {lds, ws + r, B, CAP};
+}
+
+template<class T, class Tp>
+__global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
+{
+    using Q = QLayout<Tp>;
+    constexpr int NTH = 64 * qcon_block_waves<T, Tp>();
+    constexpr int CAP = qcon_capacity<T, Tp>();
+    constexpr int RSTRIDE = (CAP % 2 == 0) ? CAP + 1 : CAP;   // odd: the 16 robots of a wave start in different banks
+    __shared__ T table[Q::TABLE];
+    __shared__ T stage_l[QRows<Tp>::NL * NTH];
+    __shared__ T stage_b[QRows<Tp>::NB * (NTH / 4)];
+    __shared__ T con[(CAP > 0 ? RSTRIDE : 1) * (NTH / 4)];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += NTH) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)blockIdx.x * (NTH / 4) + (threadIdx.x >> 2);
+    const int k = threadIdx.x & 3;
+    if (r >= A.B) return;
+    const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
+    const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
+}
+// ---------------------------------------------------------------- split stepping: pre | solve | post
+// Robots whose solves do not fit the chip (Atlas: 27-52 rows standing, up to JM_QCON_MAXM) step through THREE launches per
+// evaluation instead of one kernel that holds the whole evaluation in 512 registers while it waits on workspace rows:
+//   k_quad_con_pre   RK stage update, free acceleration, switching, delassus matrix, right-hand side -> workspace
+//   k_qcon_pgs       the projected Gauss-Seidel sweeps alone: ~100 registers, x on chip, 8-12 waves per CU, so that the
+//                    round trips of the row reads of one robot overlap with the sweeps of the others
+//   k_quad_con_post  multipliers -> lane state, evaluation that applies them (and emits the outputs of the launch)
+// The RK stage buffer, the state of the evaluation in flight and the constraint context live in HBM between the launches
+// (QSplitRows, one tile per wave).  Same functions, same arithmetic, same order as the single kernel; `start` / `reset` /
+// `refresh` / `dynamics` launches and the variation kernels keep the single kernel.
+// workspace rows ([rows][B] scalars) of the split form: solver region + header + verdict, then the stage tiles
+template<class T, class Tp> constexpr int qcon_split_region_rows() { return QSplitRegion<Tp>::ROWS; }
+template<class T, class Tp> constexpr int qcon_split_ws_rows()
+{
+    return qcon_split_region_rows<T, Tp>() + (QSplitRows<Tp>::TILE + 15) / 16;
+}
+template<class T, class Tp> JM_DEV QStore<T> qcon_split_store(T * ws, long long r)
+{
+    return {nullptr, ws + (size_t)r * (size_t)qcon_split_region_rows<T, Tp>(), 1u, 0};
+}
+
+template<class T, class Tp, int PH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1)))
+k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
+{
+    using Q = QLayout<Tp>;
+    using SR = QSplitRows<Tp>;
+    __shared__ T table[Q::TABLE];
+#pragma nounroll
+    for (int i = threadIdx.x; i < Q::TABLE; i += 256) table[i] = A.P[Q::OFFSET + i];
+    const long long r = (long long)C.split_r0 + (long long)blockIdx.x * 64 + (threadIdx.x >> 2);   // (r0: a multiple of 64)
+    const int k = threadIdx.x & 3;
+    if (r >= C.split_r1) return;
+    T * tile = C.stage + (size_t)(r >> 4) * (size_t)SR::TILE;
+    const StageBuf<T, 64, 16> S{tile + (threadIdx.x & 63), tile + SR::NL * 64 + ((threadIdx.x >> 2) & 15), k == 0};
+    const QStore<T> V = qcon_split_store<T, Tp>(C.ws, r);
+    quad_lane_run<T, Tp, DppQuad, 64, 16, true, 0, false, PH>(A, r, k, table, S, &C, &V);
+}
+
+template<class T, class Tp, int NJ, int LO, int D>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JM_QCON_PGS_WAVES)))
+k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
+{
+    using L = Layout<Tp>;
+    using RG = QSplitRegion<Tp>;
+    constexpr int XS = 8 * NJ + 2;               // (stride in scalars: even, so that the pairs stay 16-byte aligned)
+    constexpr int VS_ = 8 * NJ + 4;              // visit table of a robot: one 16-bit word per row visit (+ 4: quads in different banks)
+    __shared__ QPair<T> xs2[XS / 2 * 64];
+    __shared__ unsigned short vis[VS_ * 64];
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
+    if (r >= (unsigned)C.split_r1) return;
+    // uniform base (the 64 robots of the block) + unsigned 32-bit BYTE offset per lane
+    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
+    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    qcon_pgs_lean<T, Tp, DppQuad, NJ, LO, D>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
+                                             (T *)xs2 + (threadIdx.x >> 2) * XS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
 }
 
 template<class T, class Tp>

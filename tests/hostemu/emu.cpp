@@ -180,6 +180,66 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
     else { (void)A; (void)P; (void)C0; }
 }
 
+// the same launch in the split form of robots with large solves (jm_qcon.h: k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>
+// per evaluation, stage buffer and solver region persistent between the parts): one robot at a time, its four lanes as threads
+static int g_split = 0;
+extern "C" void emu_set_split(int on) { g_split = on; }
+extern "C" int emu_has_split() { return jm::qcon_split<Topo>() ? 1 : 0; }
+template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
+{
+    if constexpr (jm::qcon_split<Tp>())
+    {
+        using SR = jm::QSplitRows<Tp>;
+        using RG = jm::QSplitRegion<Tp>;
+        QuadShared sh;
+        pthread_barrier_init(&sh.bar, nullptr, 4);
+        const T * table = P.data() + jm::QLayout<Tp>::OFFSET;
+        const int pre = A.command_changed ? 1 : 0;
+        const int n_evals = pre + A.n_sub * (A.solver == JM_SOLVER_RUNGE_KUTTA_4 ? 4 : 1);
+        constexpr int GUARD = 512;
+        const T sentinel = (T)-12345.678;
+        std::vector<T> region((size_t)RG::ROWS * A.B + GUARD, (T)std::nan(""));
+        for (size_t i = (size_t)RG::ROWS * A.B; i < region.size(); ++i) region[i] = sentinel;
+        // on-chip arrays of the solve, shared by the four lanes of the robot
+        std::vector<jm::QPair<T>> xs(8 * 12 / 2 + 2);
+        std::vector<unsigned short> vis(8 * 12 + 8);
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k]() {
+                HostQuad::sh = &sh;
+                HostQuad::k = k;
+                std::vector<T> sl(SR::NL + 1, (T)std::nan("")), sb(SR::NB + 1, (T)std::nan(""));
+                const jm::StageBuf<T, 1, 1> S{sl.data(), sb.data(), true};   // private trunk rows per thread
+                for (long long r = 0; r < A.B; ++r)
+                {
+                    jm::QConArgs<T> C = C0;
+                    C.ws = region.data();
+                    C.stage = nullptr; C.split_r0 = 0; C.split_r1 = (int)A.B;
+                    const jm::QStore<T> V{nullptr, region.data() + (size_t)r * RG::ROWS, 1u, 0};
+                    const T friction = C.friction ? C.friction[r] : P[jm::Layout<Tp>::OPT + 8];
+                    for (int e = 0; e < n_evals; ++e)
+                    {
+                        C.split_e = e;
+                        jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 1>(A, r, k, table, S, &C, &V);
+                        HostQuad::sync();
+                        char * ws = (char *)region.data();
+                        const unsigned g0 = (unsigned)((size_t)r * RG::ROWS * sizeof(T));
+                        if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
+                            jm::qcon_pgs_lean<T, Tp, HostQuad, 12, 64, JM_QCON_PGS_DEPTH - 1>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0);
+                        HostQuad::sync();
+                        jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 2>(A, r, k, table, S, &C, &V);
+                        HostQuad::sync();
+                    }
+                }
+            });
+        for (auto & t : th) t.join();
+        pthread_barrier_destroy(&sh.bar);
+        for (size_t i = (size_t)RG::ROWS * A.B; i < region.size(); ++i)
+            if (region[i] != sentinel) { g_guard_violations += 1; break; }
+    }
+    else { (void)A; (void)P; (void)C0; }
+}
+
 // constraint contact model: options + per-lane state rows (flags int32 [NF][B], data [ND][B]); the
 // delassus workspace is allocated here
 static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
@@ -263,7 +323,16 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
             C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
             C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
-            if (gen) run_quad_con<T, Topo, true>(A, P, C);
+            C.stage = nullptr; C.split_e = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
+            bool split = false;
+            if constexpr (std::is_same<T, double>::value)
+                if (!gen && g_split && jm::qcon_split<Topo>() && mode == jm::MODE_STEP)
+                {
+                    run_quad_con_split<T, Topo>(A, P, C);
+                    split = true;
+                }
+            if (split) {}
+            else if (gen) run_quad_con<T, Topo, true>(A, P, C);
             else run_quad_con<T, Topo>(A, P, C);
         }
         else if (gen) run_quad<T, Topo, true>(A, P);

@@ -44,6 +44,9 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_constraints.restype = None
     L.emu_set_friction.argtypes = [C.c_void_p]
     L.emu_set_friction.restype = None
+    L.emu_set_split.argtypes = [C.c_int]
+    L.emu_set_split.restype = None
+    L.emu_has_split.restype = C.c_int
     L.emu_set_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.emu_set_gen.restype = None
@@ -60,8 +63,9 @@ SOLVERS = {"euler_explicit": 0, "runge_kutta_4": 1}
 def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=None,
         solver: str = "runge_kutta_4", dt: float = 1e-3, n_substeps: int = 1,
         command_changed: bool = True, update_sensors: bool = True, dtype=np.float64,
-        variant: str = "lane", constraint_options=None, model_lane=None, ground=None, applied=None) -> None:
-    """`model_lane` `[13 * njoints][B]`; `ground` = (heights [ny][nx], x0, y0, dx, dy); `applied` = (wrenches
+        variant: str = "lane", constraint_options=None, model_lane=None, ground=None, applied=None, split: bool = False) -> None:
+    """`split`: step launches of the constraint model in the pre | solve | post form of robots with large solves
+    (jm_qcon.h; ignored for topologies that do not have it).  `model_lane` `[13 * njoints][B]`; `ground` = (heights [ny][nx], x0, y0, dx, dy); `applied` = (wrenches
     [6 K][B], offsets [K][3]) -- the optional per-environment variation of the branch-parallel code."""
     L = _lib(model)
     g = ground if ground is not None else (None, 0.0, 0.0, 1.0, 1.0)
@@ -86,6 +90,7 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     if variant == "quad" and not L.emu_has_quad():
         raise RuntimeError("this topology has no limb-parallel variant")
     L.emu_set_variant(1 if variant == "quad" else 0)
+    L.emu_set_split(1 if split else 0)
     desc, keep = _abi.make_model_desc(model)
     opts = options if options is not None else _abi.make_options()
     io = EmuIO()

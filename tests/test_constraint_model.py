@@ -232,12 +232,16 @@ def _check(got, ref, tol, what=""):
 QUAD_MODELS = ("anymal", "atlas", "crane_walker")   # served by the branch-parallel kernel (jm_qcon.h)
 
 
-@pytest.mark.parametrize("name,variant", [(n, "lane") for n in _models()] + [(n, "quad") for n in QUAD_MODELS])
+@pytest.mark.parametrize("name,variant", [(n, "lane") for n in _models()] + [(n, "quad") for n in QUAD_MODELS] + [("atlas", "split")])
 def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
     """Both device formulations compiled for the host against the oracle (the reference's dense one):
     `lane` = one robot per lane, sequential bias-free solves (jm_constraint.h); `quad` = four lanes per
     robot, four delassus columns per round, packed symmetric matrix in the per-robot solver region split
-    between the on-chip part and the overflow rows, PGS dot products summed over the quad (jm_qcon.h)."""
+    between the on-chip part and the overflow rows, PGS dot products summed over the quad (jm_qcon.h); `split` = the step
+    launches of robots with large solves as pre | solve | post per evaluation (stage buffer, constraint context and the
+    square solver region persistent between the parts, `qcon_pgs_lean` with its ring of prefetched rows)."""
+    split = variant == "split"
+    variant = "quad" if split else variant
     model = _models()[name]()
     B = 6 if name == "atlas" else 12
     ref, got = _pair(model, B, seed=7)
@@ -250,16 +254,18 @@ def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
         for _ in range(2):
             kw = dict(solver=solver, dt=5e-4, n_substeps=n_sub, command_changed=changed)
             oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
-            emu.run(model, got, "step", constraint_options=TIGHT, variant=variant, **kw)
+            emu.run(model, got, "step", constraint_options=TIGHT, variant=variant, split=split, **kw)
         _check(got, ref, 1e-7, solver)
 
 
-def test_atlas_standing_flat_on_both_feet_start_and_steps():
+@pytest.mark.parametrize("split", [False, True])
+def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
     """A humanoid standing flat: the 8 bottom vertices of each foot box touch, 16 contact points = 64 rows in
     `Engine::start`'s passes (4-row blocks) + the joints the neutral pose puts on their bounds -- the largest solve the
     shipped robots produce, above the 64 rows the solver region was first sized for (a truncated contact block then
     indexed past the region: the emulation keeps guard rows behind its workspace for exactly that).  Start, then
-    steps with 3-row blocks, against the oracle."""
+    steps with 3-row blocks, against the oracle (`split`: the steps in the pre | solve | post form, whose solves of more than
+    64 rows take the 12-loads-per-row instantiation of `qcon_pgs_lean`)."""
     from jiminy_amd.synthetic import lowest_contact_height
     model = load_builtin("atlas")
     B = 3
@@ -285,7 +291,7 @@ def test_atlas_standing_flat_on_both_feet_start_and_steps():
     for _ in range(2):
         kw = dict(solver="euler_explicit", dt=1e-3, n_substeps=2, command_changed=True)
         oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
-        emu.run(model, got, "step", constraint_options=TIGHT, variant="quad", **kw)
+        emu.run(model, got, "step", constraint_options=TIGHT, variant="quad", split=split, **kw)
     _check(got, ref, 1e-6, "steps")
     assert lib.emu_guard_violations() == before
 
