@@ -181,7 +181,11 @@ enum {
                               joint (jm_batch_set_applied_frames), i.e. the current value of the impulse /
                               profile forces of core/src/engine/engine.cc:1838-2016 (the caller owns their time
                               schedule and cuts the launches at their breakpoints); branch-parallel topologies */
-    JM_F_COUNT = 23
+    JM_F_GROUND_OFFSET = 23, /* [2] in, optional: (x, y) added to the world position at which every lane samples the height map
+                              of jm_batch_set_ground -- every environment its own patch of one large terrain, the batched
+                              form of one `world.groundProfile` per environment instance (gym_jiminy: a new random
+                              ground per episode); unbound = (0, 0) */
+    JM_F_COUNT = 24
 };
 
 /* ---- `contacts.model = "constraint"` (the reference's default contact model, engine.h:273) and the

@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -26,7 +26,7 @@ CONTACT_MODELS = {"spring_damper": JM_CONTACT_SPRING_DAMPER, "constraint": JM_CO
 (JM_F_Q, JM_F_V, JM_F_A, JM_F_COMMAND, JM_F_U_MOTOR, JM_F_U, JM_F_F_EXTERNAL,
  JM_F_CONTACT_FORCES, JM_F_IMU, JM_F_FORCE, JM_F_CONTACT, JM_F_ENCODER, JM_F_EFFORT,
  JM_F_ENERGY, JM_F_JOINT_FORCES, JM_F_CENTROIDAL, JM_F_STATUS, JM_F_WORKSPACE,
- JM_F_CON_FLAGS, JM_F_CON_DATA, JM_F_FRICTION, JM_F_MODEL_LANE, JM_F_APPLIED, JM_F_COUNT) = range(24)
+ JM_F_CON_FLAGS, JM_F_CON_DATA, JM_F_FRICTION, JM_F_MODEL_LANE, JM_F_APPLIED, JM_F_GROUND_OFFSET, JM_F_COUNT) = range(25)
 
 FIELD_NAMES = {
     "q": JM_F_Q, "v": JM_F_V, "a": JM_F_A, "command": JM_F_COMMAND, "u_motor": JM_F_U_MOTOR,
@@ -35,7 +35,7 @@ FIELD_NAMES = {
     "effort": JM_F_EFFORT, "energy": JM_F_ENERGY, "joint_forces": JM_F_JOINT_FORCES,
     "centroidal": JM_F_CENTROIDAL, "status": JM_F_STATUS, "workspace": JM_F_WORKSPACE,
     "con_flags": JM_F_CON_FLAGS, "con_data": JM_F_CON_DATA, "friction": JM_F_FRICTION,
-    "model_lane": JM_F_MODEL_LANE, "applied": JM_F_APPLIED,
+    "model_lane": JM_F_MODEL_LANE, "applied": JM_F_APPLIED, "ground_offset": JM_F_GROUND_OFFSET,
 }
 
 _pi = C.POINTER(C.c_int32)

@@ -128,6 +128,7 @@ template<class T> struct BatchArgs
     // `[1][B]` ground friction coefficient of every lane (spring-damper model; the constraint model reads its own
     // copy, QConArgs / ConArgs), or null: `contacts.friction` randomised per environment (envs/locomotion.py:257-262)
     const T * friction;
+    const T * ground_off;        // [2][B] per-lane (x, y) offset of the height-map queries (JM_F_GROUND_OFFSET), or null
 };
 // MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
 // the lane status into the existing one: the closing launch of an adaptive-step interval

@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 4
+#define JM_ABI_VERSION 5
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -185,6 +185,7 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     A.ground_h = (const T *)b->ground_h;
     A.ground_nx = b->ground_nx; A.ground_ny = b->ground_ny;
     A.ground_x0 = (T)b->ground_x0; A.ground_y0 = (T)b->ground_y0; A.ground_dx = (T)b->ground_dx; A.ground_dy = (T)b->ground_dy;
+    A.ground_off = b->ground_h ? (const T *)b->field[JM_F_GROUND_OFFSET] : nullptr;
     A.applied = b->applied_k > 0 ? (const T *)b->field[JM_F_APPLIED] : nullptr;
     A.applied_k = A.applied ? b->applied_k : 0;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)b->applied_p[i];

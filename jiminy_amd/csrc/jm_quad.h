@@ -731,7 +731,7 @@ template<class T, class Tp> struct QKeep
     T dinv[Tp::QN];
     M3<T> Rt;                        // rotation of the limb tip body (its origin is ps[N-1])
     Sp<T> vtip, atip;                // tip velocity / spatial acceleration (gravity field included)
-    M3<T> R1; V3<T> p1;              // root placement in the world
+    M3<T> R1; V3<T> p1;              // root placement in the world (position: as the height map sees it, JM_F_GROUND_OFFSET)
     Sp<T> agf1;                      // gravity field in root coordinates
     T rootL[6][6], rootdinv[6];      // LDL^T factor of the root block (chol6_solve)
 };
@@ -806,6 +806,10 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     // ---- root (free-flyer at the world origin, checked by jm_model_create) and trunk tree
     const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
     const V3<T> p1 = {qb[0], qb[1], qb[2]};
+    // root position as the height map sees it: every lane samples the map at its own (x, y) offset (JM_F_GROUND_OFFSET)
+    V3<T> p1g = p1;
+    if constexpr (GEN)
+        if (A.ground_off) { p1g.x += A.ground_off[r32]; p1g.y += A.ground_off[B32 + r32]; }
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     const Sp<T> v1 = {{vb_[0], vb_[1], vb_[2]}, {vb_[3], vb_[4], vb_[5]}};
     // gravity field in root coordinates (bias v x v = 0 for the free-flyer), taken here so that the root placement
@@ -862,7 +866,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 if (A.ground_h)
                 {
                     // world.groundProfile at the contact point; first-order projection (engine.cc:3138-3145)
-                    const V3<T> pW = R1 * pc + p1;
+                    const V3<T> pW = R1 * pc + p1g;
                     T hG;
                     ground_profile(A, pW.x, pW.y, hG, nG);
                     depth = (pW.z - hG) * nG.z;
@@ -901,7 +905,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                         const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
                         // (multipliers live in the local frame of the ground surface under the point: contact_frame)
                         T dep_;
-                        const M3<T> Mc = contact_frame<GEN>(A, R1, p1, pc, dep_);
+                        const M3<T> Mc = contact_frame<GEN>(A, R1, p1g, pc, dep_);
                         const V3<T> fR = tmul(Mc, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
                         const V3<T> tR = ex->lam[o + 3 * B32] * V3<T>{Mc.m20, Mc.m21, Mc.m22};
                         fext.l = fext.l + fR;
@@ -1238,7 +1242,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 for (int c = 0; c <= i; ++c) keep->rootL[i][c] = M[i][c];
                 keep->rootdinv[i] = rcp_(M[i][i]);
             }
-            keep->Rt = Rtip; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1; keep->agf1 = agf1;
+            keep->Rt = Rtip; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1g; keep->agf1 = agf1;
         }
     }
     if (want_energy)
@@ -1386,6 +1390,10 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
     const V3<T> p1 = {qb[0], qb[1], qb[2]};
     const SE3<T> M1 = {R1, p1};
+    // root position as the height map sees it: every lane samples the map at its own (x, y) offset (JM_F_GROUND_OFFSET)
+    V3<T> p1g = p1;
+    if constexpr (GEN)
+        if (A.ground_off) { p1g.x += A.ground_off[r32]; p1g.y += A.ground_off[B32 + r32]; }
     const Sp<T> agf1 = actinv_motion(M1, Sp<T>{-g, -gw});
     int status = 0;
     using MA = std::conditional_t<GEN, ModelLane<T>, NoModelLane>;
@@ -1427,7 +1435,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
                 if constexpr (GEN)
                     if (A.ground_h)
                     {
-                        const V3<T> pW = R1 * pc + p1;
+                        const V3<T> pW = R1 * pc + p1g;
                         T hG;
                         ground_profile(A, pW.x, pW.y, hG, nG);
                         depth = (pW.z - hG) * nG.z;
@@ -1451,7 +1459,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
                 {
                     const unsigned o = ((unsigned)ex->nb + 4u * ci) * B32 + r32;
                     T dep_;
-                    const M3<T> Mc = contact_frame<GEN>(A, R1, p1, pc, dep_);
+                    const M3<T> Mc = contact_frame<GEN>(A, R1, p1g, pc, dep_);
                     const V3<T> fR = tmul(Mc, V3<T>{ex->lam[o], ex->lam[o + B32], ex->lam[o + 2 * B32]});
                     fext.l = fext.l + fR;
                     fext.a = fext.a + cross(pc, fR) + ex->lam[o + 3 * B32] * V3<T>{Mc.m20, Mc.m21, Mc.m22};

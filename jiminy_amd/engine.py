@@ -1140,8 +1140,42 @@ class BatchedEngine:
         if h.dim() != 2 or min(h.shape) < 2:
             raise ValueError("the height map needs at least 2 x 2 samples")
         self._ground = h
+        self._ground_grid = (float(x0), float(y0), float(dx), float(dy))
         self._lib.check(self._L.jm_batch_set_ground(self._batch_h, C.c_void_p(h.data_ptr()), int(h.shape[1]), int(h.shape[0]),
                                                     float(x0), float(y0), float(dx), float(dy)))
+
+    def ground_height_around(self, xy: torch.Tensor, radius: float) -> torch.Tensor:
+        """Largest height of the bound height map within `radius` of the world points `xy` (`(2, N)`, device tensor):
+        where to put a robot down on a patch of terrain without burying its feet (flat continuation outside the map)."""
+        if self._ground is None:
+            return torch.zeros(xy.shape[1], dtype=self.dtype, device=self.device)
+        x0, y0, dx, dy = self._ground_grid
+        H = self._ground
+        ny, nx = H.shape
+        kx, ky = int(math.ceil(radius / dx)), int(math.ceil(radius / dy))
+        Hmax = torch.nn.functional.max_pool2d(H[None, None].to(torch.float64), (2 * ky + 1, 2 * kx + 1), stride=1, padding=(ky, kx))[0, 0]
+        ix = torch.clamp(torch.round((xy[0] - x0) / dx).long(), 0, nx - 1)
+        iy = torch.clamp(torch.round((xy[1] - y0) / dy).long(), 0, ny - 1)
+        return Hmax[iy, ix].to(self.dtype)
+
+    def set_ground_offsets(self, offsets: Optional[Any]) -> None:
+        """Every lane samples the height map at its own (x, y) offset: `(B, 2)` (or `(2, B)`) values added to the world
+        position of the height-map queries, None = no offsets.  One large terrain, every environment its own patch of
+        it -- the batched form of one `world.groundProfile` per environment instance.  May be changed while the
+        simulation runs (the environments re-draw the offsets of the lanes they reset)."""
+        if offsets is None:
+            self._fields.pop("ground_offset", None)
+            self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["ground_offset"], None))
+            return
+        o = torch.as_tensor(offsets, dtype=self.dtype, device=self.device)
+        if o.shape == (self.batch_size, 2):
+            o = o.t()
+        if o.shape != (2, self.batch_size):
+            raise ValueError("ground offsets: one (x, y) pair per lane")
+        if "ground_offset" not in self._fields:
+            self._fields["ground_offset"] = torch.zeros((2, self.batch_size), dtype=self.dtype, device=self.device)
+            self._bind("ground_offset")
+        self._fields["ground_offset"].copy_(o)
 
     def set_ground_profile(self, func: Any, x_range: Tuple[float, float], y_range: Tuple[float, float],
                            resolution: float) -> None:

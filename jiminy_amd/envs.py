@@ -42,8 +42,13 @@ class VecJiminyEnv:
                  simulation_duration_max: float = 86400.0, auto_reset: bool = True,
                  std_ratio: Optional[Dict[str, float]] = None,
                  model_options: Optional[Dict[str, Dict[str, float]]] = None,
-                 ground_profile: Optional[Tuple[Any, Tuple[float, float], Tuple[float, float], float]] = None) -> None:
+                 ground_profile: Optional[Tuple[Any, Tuple[float, float], Tuple[float, float], float]] = None,
+                 ground_patch_extent: Optional[Tuple[float, float]] = None) -> None:
         self.model = model
+        # every environment its own patch of the ground profile: at every (lane) reset a new (x, y) offset of its
+        # height-map queries, uniform in +- extent (`BatchedEngine.set_ground_offsets`) -- the batched form of a new random
+        # `groundProfile` per environment instance and episode
+        self._ground_patch_extent = ground_patch_extent
         # ≙ `engine_options["world"]["groundProfile"]`: `(heightmap(x, y), x_range, y_range, resolution)`, e.g. a
         # `jiminy_amd.terrain.random_tile_ground` generator; sampled on the device at every `reset()`, shared by the batch
         self._ground_profile = ground_profile
@@ -110,8 +115,16 @@ class VecJiminyEnv:
         # a PGS solve that hit its iteration cap is not fatal (the reference only counts it,
         # engine.cc:3755-3768)
         status = self.engine.status & ~_abi.JM_LANE_SOLVER_FAILURE
-        truncated = (status != 0) | (self._lane_time() >= self.simulation_duration_max)
+        # (a state that turned non-finite in the last integrator step of the launch is flagged by the kernel at the NEXT
+        # launch: look at it directly, so that the lane restarts now and no NaN reaches the observation)
+        rs = self.engine.robot_state
+        finite = torch.isfinite(rs.q).all(0) & torch.isfinite(rs.v).all(0) & torch.isfinite(rs.a).all(0) & self._pipeline_finite()
+        truncated = (status != 0) | ~finite | (self._lane_time() >= self.simulation_duration_max)
         return torch.zeros_like(truncated), truncated
+
+    def _pipeline_finite(self) -> torch.Tensor:
+        """Lanes whose controller / observer state is finite (hook of the pipeline environments)."""
+        return torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
 
     def compute_reward(self, terminated: torch.Tensor) -> torch.Tensor:
         return torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
@@ -144,6 +157,9 @@ class VecJiminyEnv:
         if self._ground_profile is not None:
             self.engine.set_ground_profile(*self._ground_profile)
         self._randomise_ground(None)
+        if self._spawn_dz is not None:
+            q = q.clone()
+            q[2] += self._spawn_dz.to(q.dtype).to(q.device)
         self._randomise_sensors()
         self._schedule_disturbances()
         if self._model_options:
@@ -176,7 +192,7 @@ class VecJiminyEnv:
         """Episode bookkeeping after the engine advanced (tensor programs only, no host read-back)."""
         self.num_steps += 1
         terminated, truncated = self.has_terminated()
-        reward = self.compute_reward(terminated)
+        reward = torch.nan_to_num(self.compute_reward(terminated), nan=0.0, posinf=0.0, neginf=0.0)   # (numerically failed lanes)
         return reward, terminated, truncated, terminated | truncated
 
     def _step_engine(self, action: torch.Tensor) -> None:
@@ -215,6 +231,9 @@ class VecJiminyEnv:
         q, v = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)
         self._on_reset(lane_mask)
         self._randomise_ground(lane_mask)
+        if self._spawn_dz is not None:
+            q = q.clone()
+            q[2] += self._spawn_dz.to(q.dtype).to(q.device)
         # a fresh episode starts from a zero command like `reset()` (for the PD pipeline it IS the controller's
         # output at the reset state: target = measured position, zero velocity), not from the last command of the
         # finished episode.  With sensor noise / delay configured the first observation of the re-initialised lanes
@@ -239,10 +258,21 @@ class VecJiminyEnv:
             g.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._generator)))
         return g
 
+    GROUND_FOOTPRINT_RADIUS = 0.6
+    _spawn_dz: Optional[torch.Tensor] = None
+
     def _randomise_ground(self, lane_mask: Optional[torch.Tensor]) -> None:
         """Ground friction of the environments being reset, ≙ `sample(*GROUND_FRICTION_RANGE,
         scale=std_ratio['ground'], enable_log_scale=True)` (envs/locomotion.py:28, 257-262 with
         utils/misc.py:178-219: 10 ** (mean + dev * U(-1, 1)), mean = 1.1, dev = 0.9 * scale)."""
+        if self._ground_patch_extent is not None and self._ground_profile is not None:
+            ext = torch.tensor(self._ground_patch_extent, dtype=torch.float64, device=self.device)[:, None]
+            off = (torch.rand((2, self.num_envs), generator=self._device_generator(), dtype=torch.float64, device=self.device) * 2.0 - 1.0) * ext
+            if lane_mask is not None and "ground_offset" in self.engine._fields:
+                off = torch.where(lane_mask[None, :], off, self.engine.field("ground_offset").to(torch.float64))
+            self.engine.set_ground_offsets(off)
+            # put the robots down ON their patch: base height raised by the highest ground under the footprint
+            self._spawn_dz = self.engine.ground_height_around(self._q0[0:2].to(self.device) + off, self.GROUND_FOOTPRINT_RADIUS)
         scale = float(self.std_ratio.get("ground", 0.0))
         if scale <= 0.0:
             return
@@ -464,6 +494,10 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
     def _encoders(self) -> torch.Tensor:
         enc = self.engine.sensor_measurements["EncoderSensor"]   # (2, n_enc, B)
         return enc[:, self._enc_idx]
+
+    def _pipeline_finite(self) -> torch.Tensor:
+        # (an infinite IMU sample of a lane that is about to fail poisons its attitude estimate one step before its state)
+        return torch.isfinite(self.imu_quat).all(0).all(0) & torch.isfinite(self.command_state).all(0).all(0)
 
     def _on_reset(self, lane_mask: Optional[torch.Tensor]) -> None:
         q0, _ = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)

@@ -473,6 +473,10 @@ struct Engine
     int32_t * con_flags = nullptr;
     double * con_data = nullptr;
     const double * lane_friction = nullptr;  // [B] contacts.friction of every lane, or null
+    // per-lane (x, y) offset of the ground-profile queries ([2][B], batch drivers; JM_F_GROUND_OFFSET): every environment its
+    // own patch of the terrain
+    const double * lane_ground_offset = nullptr;
+    double ground_ox = 0, ground_oy = 0;
     // ---- per-lane model (Model::addBiasedToExtendedModel output, model.cc:1166-1236): rows per joint
     // mass | com 3 | inertia xx xy xz yy yz zz | joint placement translation 3, `[13 * njoints][B]`, or null
     const double * model_lane = nullptr;
@@ -494,6 +498,7 @@ inline void ground_profile(const Engine & e, double x, double y, double & h, V3 
 {
     if (!e.ground_h) { h = 0.0; n = {0, 0, 1}; return; }
     const int nx = e.ground_nx, ny = e.ground_ny;
+    x += e.ground_ox; y += e.ground_oy;
     double u = (x - e.ground_x0) / e.ground_dx, w = (y - e.ground_y0) / e.ground_dy;
     const bool in_x = u >= 0.0 && u <= (double)(nx - 1), in_y = w >= 0.0 && w <= (double)(ny - 1);
     u = std::min(std::max(u, 0.0), (double)(nx - 1));
@@ -2037,6 +2042,7 @@ void orc_engine_bind_constraints(void * h, int32_t * flags, double * data)
     e.con_data = data;
 }
 void orc_engine_bind_friction(void * h, const double * friction) { static_cast<Engine *>(h)->lane_friction = friction; }
+void orc_engine_bind_ground_offset(void * h, const double * offsets) { static_cast<Engine *>(h)->lane_ground_offset = offsets; }
 void orc_engine_bind_model_lane(void * h, const double * model_lane) { static_cast<Engine *>(h)->model_lane = model_lane; }
 void orc_engine_bind_ground(void * h, const double * heights, int nx, int ny, double x0, double y0, double dx, double dy)
 {
@@ -2143,6 +2149,8 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
     const int64_t B = io.B;
     if (e.lane_friction) e.opt.contact_friction = e.lane_friction[l];
+    if (e.lane_ground_offset) { e.ground_ox = e.lane_ground_offset[l]; e.ground_oy = e.lane_ground_offset[B + l]; }
+    else { e.ground_ox = 0; e.ground_oy = 0; }
     if (e.con_flags && e.con_data)
     {
         if (e.uInternal.empty()) init_constraints(e);

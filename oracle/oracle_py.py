@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
         L.orc_engine_bind_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.restype = None
+        L.orc_engine_bind_ground_offset.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_bind_ground_offset.restype = None
         L.orc_engine_bind_model_lane.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_bind_model_lane.restype = None
         L.orc_engine_bind_ground.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -161,6 +163,11 @@ class OracleEngine:
         translation per joint), None = the model's own."""
         self._model_lane = None if model_lane is None else np.ascontiguousarray(model_lane, dtype=np.float64)
         self._L.orc_engine_bind_model_lane(self._h, None if model_lane is None else self._model_lane.ctypes.data)
+
+    def bind_ground_offset(self, offsets: Optional[np.ndarray]) -> None:
+        """Per-lane (x, y) added to the position at which the ground profile is sampled (`[2][B]` float64, batch drivers)."""
+        self._ground_offset = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        self._L.orc_engine_bind_ground_offset(self._h, None if offsets is None else self._ground_offset.ctypes.data)
 
     def bind_ground(self, heights: Optional[np.ndarray], x0: float = 0.0, y0: float = 0.0, dx: float = 1.0,
                     dy: float = 1.0) -> None:

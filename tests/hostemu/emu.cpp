@@ -260,6 +260,8 @@ extern "C" void emu_constraint_rows(int * nf, int * nd, int * nw)
 // optional per-environment variation (GEN instantiation of the branch-parallel code)
 static const void * g_model_lane = nullptr;
 static const void * g_ground = nullptr;
+static const void * g_ground_off = nullptr;
+extern "C" void emu_set_ground_offset(const void * off) { g_ground_off = off; }
 static int g_gnx = 0, g_gny = 0;
 static double g_gx0 = 0, g_gy0 = 0, g_gdx = 1, g_gdy = 1;
 static const void * g_applied = nullptr;
@@ -305,6 +307,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     const bool gen = g_model_lane || g_ground || g_applied || A.friction;
     A.model_lane = (const T *)g_model_lane;
     A.ground_h = (const T *)g_ground; A.ground_nx = g_gnx; A.ground_ny = g_gny;
+    A.ground_off = g_ground ? (const T *)g_ground_off : nullptr;
     A.ground_x0 = (T)g_gx0; A.ground_y0 = (T)g_gy0; A.ground_dx = (T)g_gdx; A.ground_dy = (T)g_gdy;
     A.applied = (const T *)g_applied; A.applied_k = g_applied_k;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)g_applied_p[i];

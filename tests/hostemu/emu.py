@@ -44,6 +44,8 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_constraints.restype = None
     L.emu_set_friction.argtypes = [C.c_void_p]
     L.emu_set_friction.restype = None
+    L.emu_set_ground_offset.argtypes = [C.c_void_p]
+    L.emu_set_ground_offset.restype = None
     L.emu_set_split.argtypes = [C.c_int]
     L.emu_set_split.restype = None
     L.emu_has_split.restype = C.c_int
@@ -85,6 +87,8 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     else:
         co = _abi.make_constraint_options(model="spring_damper")
         L.emu_set_constraints(C.byref(co), None, None)
+    go = arrays.get("ground_offset")
+    L.emu_set_ground_offset(go.ctypes.data if (go is not None and gh is not None) else None)
     fr = arrays.get("friction")
     L.emu_set_friction(fr.ctypes.data if fr is not None else None)
     if variant == "quad" and not L.emu_has_quad():

@@ -505,7 +505,8 @@ def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
 
 @pytest.mark.parametrize("contact_model", ["spring_damper", "constraint"])
 def test_env_with_every_randomisation_switched_on(gpu_device, contact_model):
-    """Everything the reference's locomotion environment randomises, at once: ground friction, a random tile terrain, sensor
+    """Everything the reference's locomotion environment randomises, at once: ground friction, a random tile terrain (every
+    environment on its own patch of it), sensor
     noise / bias / delay, body-parameter biases, impulse pushes and the Gaussian-process force, with random actions and
     auto-resets in flight: 40 environment steps (1.6 s) run through, observations and rewards stay finite, finished
     lanes restart, and a second run from the same seed reproduces the first bit for bit."""
@@ -517,18 +518,23 @@ def test_env_with_every_randomisation_switched_on(gpu_device, contact_model):
 
     def run():
         env = make_anymal_env(B, device=gpu_device, contact_model=contact_model, std_ratio=std, ground_profile=terrain,
+                              ground_patch_extent=(2.0, 2.0),
                               model_options={"dynamics": {"massBodiesBiasStd": 0.05, "centerOfMassPositionBodiesBiasStd": 0.02}})
         assert env.engine._ground is None
         env.reset(seed=11)
         assert env.engine._ground is not None and float(env.engine._ground.max()) > 0.0 and "friction" in env.engine._fields
+        # every environment on its own patch of the terrain
+        off = env.engine.field("ground_offset")
+        assert off.shape == (2, B) and float(off.abs().max()) <= 2.0 and float(off.std()) > 0.5
         g = torch.Generator(device="cpu").manual_seed(4)
         n_reset, last = 0, None
         for i in range(40):
             action = (1.5 * torch.randn(B, 12, generator=g, dtype=torch.float64)).to(gpu_device)
             obs, reward, terminated, truncated, info = env.step(action)
             n_reset += int(info["reset_mask"].sum()) if "reset_mask" in info else 0
-            for leaf in (obs["states"]["agent"]["q"], obs["states"]["agent"]["v"], obs["features"]["mahony_filter"], reward):
-                assert bool(torch.isfinite(leaf).all()), i
+            for name, leaf in (("q", obs["states"]["agent"]["q"]), ("v", obs["states"]["agent"]["v"]),
+                               ("mahony_filter", obs["features"]["mahony_filter"]), ("reward", reward)):
+                assert bool(torch.isfinite(leaf).all()), (i, name, int((~torch.isfinite(leaf)).sum()))
             last = (obs["states"]["agent"]["q"].clone(), reward.clone())
         return n_reset, last
     n1, a = run()

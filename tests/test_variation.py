@@ -137,6 +137,61 @@ def test_applied_forces_on_frames_of_any_joint_on_the_host(name, constrained):
     assert rel_err(plain["a"], ref["a"]) > 1e-3
 
 
+@pytest.mark.parametrize("constrained", [False, True])
+def test_per_lane_ground_patches_on_the_host(constrained):
+    """JM_F_GROUND_OFFSET: every lane samples the height map at its own (x, y) offset.  The kernel sources against the
+    oracle, and the law that defines the feature: a lane with offset (ox, oy) behaves exactly like a lane WITHOUT offset
+    whose robot stands at (x + ox, y + oy) on the same map."""
+    model = load_builtin("anymal")
+    B = 12
+    st, _, ground, _ = _scene(model, B, 13, constrained)
+    rg = np.random.default_rng(3)
+    off = np.ascontiguousarray(rg.uniform(-0.6, 0.6, (2, B)))
+    copt = TIGHT if constrained else None
+    arrs = [alloc_soa(model, B) for _ in range(3)]   # oracle with offsets | emulation with offsets | emulation, robots moved
+    for arr in arrs:
+        if constrained:
+            alloc_constraint_state(model, arr, B)
+        for k in ("q", "v", "command"):
+            arr[k][:] = st[k]
+    ref, got, moved = arrs
+    moved["q"][0:2] += off
+    got["ground_offset"] = off
+    e = OracleEngine(model)
+    if copt is not None:
+        e.set_constraint_options(**copt)
+        e.bind_constraints(ref["con_flags"], ref["con_data"])
+    e.bind_ground(*ground)
+    e.bind_ground_offset(off)
+    io = oracle_io(ref)
+    kw = dict(variant="quad", constraint_options=copt, ground=ground)
+    e.batch_run("start", io)
+    emu.run(model, got, "start", **kw)
+    emu.run(model, moved, "start", **kw)
+    a_start = got["a"].copy()
+    for _ in range(3):
+        e.batch_run("step", io, solver="runge_kutta_4", dt=5e-4, n_substeps=1, command_changed=True)
+        emu.run(model, got, "step", solver="runge_kutta_4", dt=5e-4, n_substeps=1, command_changed=True, **kw)
+        emu.run(model, moved, "step", solver="runge_kutta_4", dt=5e-4, n_substeps=1, command_changed=True, **kw)
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.sum() >= B - 1 and (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() >= 2
+    for k in OUTS:
+        assert rel_err(got[k], ref[k], ok) < 1e-8, k
+    back = moved["q"].copy()
+    back[0:2] -= off
+    assert rel_err(back, got["q"], ok) < 1e-12
+    for k in ("v", "a", "contact_forces", "u"):
+        assert rel_err(moved[k], got[k], ok) < 1e-9, k
+    # ... and the offsets matter: the same lanes without them see another ground
+    plain = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, plain, B)
+    for k in ("q", "v", "command"):
+        plain[k][:] = st[k]
+    emu.run(model, plain, "start", **kw)
+    assert rel_err(plain["a"], a_start) > 1e-6
+
+
 def test_per_lane_friction_with_the_spring_damper_law_on_the_host():
     """`contacts.friction` per environment (envs/locomotion.py:257-262 randomises it whatever the contact model): the
     spring-damper law of the variation kernels reads the lane's own coefficient; sliding robots, kernel sources on the
@@ -362,6 +417,59 @@ def test_gpu_applied_forces_on_frames_of_any_joint(gpu_device, name, constrained
         assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
     fe = ref["f_external"].reshape(model.njoints, 6, B)
     assert np.abs(fe[2]).max() > 1.0 and np.abs(fe[model.njoints - 1]).max() > 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", True)])
+def test_gpu_per_lane_ground_patches(gpu_device, name, constrained):
+    """`BatchedEngine.set_ground_offsets` (JM_F_GROUND_OFFSET) on the device against the oracle."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin(name)
+    B, dt = (64, 5e-4) if name == "anymal" else (16, 2.5e-4)
+    st, _, ground, _ = _scene(model, B, 17, constrained)
+    off = np.ascontiguousarray(np.random.default_rng(4).uniform(-0.6, 0.6, (2, B)))
+    copt = TIGHT if constrained else None
+    ref = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, ref, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = OracleEngine(model)
+    if copt is not None:
+        e.set_constraint_options(**copt)
+        e.bind_constraints(ref["con_flags"], ref["con_data"])
+    e.bind_ground(*ground)
+    e.bind_ground_offset(off)
+    io = oracle_io(ref)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces", "f_external", "energy"))
+    stepper = {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt}
+    if constrained:
+        stepper.update({"tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]})
+    eng.set_options({"stepper": stepper, "contacts": {"model": "constraint" if constrained else "spring_damper"}})
+    eng.set_ground_heightmap(*ground)
+    eng.set_ground_offsets(torch.from_numpy(off.T.copy()))   # (B, 2)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+    ok = np.ones(B, dtype=bool)
+    for _ in range(3):
+        eng.step(dt)
+        e.batch_run("step", io, solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=constrained)
+        ok &= ((ref["status"][0] & 1) == 0) & (np.abs(ref["v"]).max(axis=0) < 1e2) & (np.abs(ref["a"]).max(axis=0) < 1e6)
+    assert ok.sum() > 0.8 * B and (np.abs(ref["contact_forces"]).sum(axis=0) > 0).sum() >= B // 16
+    for k in OUTS:
+        if k in eng._fields and ref[k].size:
+            assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
+    # the same engine without offsets sees another ground
+    eng.stop()
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    a_off = eng.field("a").clone()
+    eng.stop()
+    eng.set_ground_offsets(None)
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    assert rel_err(eng.field("a").cpu().numpy(), a_off.cpu().numpy()) > 1e-6
 
 
 @pytest.mark.gpu
