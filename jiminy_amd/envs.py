@@ -117,14 +117,15 @@ class VecJiminyEnv:
         status = self.engine.status & ~_abi.JM_LANE_SOLVER_FAILURE
         # (a state that turned non-finite in the last integrator step of the launch is flagged by the kernel at the NEXT
         # launch: look at it directly, so that the lane restarts now and no NaN reaches the observation)
-        rs = self.engine.robot_state
-        finite = torch.isfinite(rs.q).all(0) & torch.isfinite(rs.v).all(0) & torch.isfinite(rs.a).all(0) & self._pipeline_finite()
+        # (the acceleration of the end state stands for the state: a non-finite q or v makes it non-finite; one column sum)
+        finite = torch.isfinite(self.engine.robot_state.a.sum(0) + self._pipeline_sum())
         truncated = (status != 0) | ~finite | (self._lane_time() >= self.simulation_duration_max)
         return torch.zeros_like(truncated), truncated
 
-    def _pipeline_finite(self) -> torch.Tensor:
-        """Lanes whose controller / observer state is finite (hook of the pipeline environments)."""
-        return torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+    def _pipeline_sum(self) -> Any:
+        """Per-lane sum of the controller / observer state (hook of the pipeline environments): non-finite where that
+        state is."""
+        return 0.0
 
     def compute_reward(self, terminated: torch.Tensor) -> torch.Tensor:
         return torch.zeros(self.num_envs, dtype=self.dtype, device=self.device)
@@ -495,9 +496,9 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         enc = self.engine.sensor_measurements["EncoderSensor"]   # (2, n_enc, B)
         return enc[:, self._enc_idx]
 
-    def _pipeline_finite(self) -> torch.Tensor:
+    def _pipeline_sum(self) -> Any:
         # (an infinite IMU sample of a lane that is about to fail poisons its attitude estimate one step before its state)
-        return torch.isfinite(self.imu_quat).all(0).all(0) & torch.isfinite(self.command_state).all(0).all(0)
+        return self.imu_quat.sum((0, 1))
 
     def _on_reset(self, lane_mask: Optional[torch.Tensor]) -> None:
         q0, _ = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)
