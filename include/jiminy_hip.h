@@ -166,7 +166,11 @@ enum {
     JM_F_STATUS = 16,      /* [1] int32 per lane, JM_LANE_* bits */
     JM_F_WORKSPACE = 17,   /* scratch, jm_batch_workspace_rows() rows */
     JM_F_CON_FLAGS = 18,   /* [n_flag_rows] int32 in/out: per constraint, bit 0 = enabled, bit 1 = reversed
-                              (AbstractConstraintBase::isEnabled_, JointConstraint::isReversed_) */
+                              (AbstractConstraintBase::isEnabled_, JointConstraint::isReversed_); joint rows, bit 2
+                              (set by the caller, kept by the library): a user-registered JointConstraint holds the
+                              joint (Model::addConstraint, core/src/robot/model.cc:926-936) -- the row is bilateral,
+                              always enabled, its reference configuration taken at jm_batch_start; branch-parallel
+                              topologies */
     JM_F_CON_DATA = 19,    /* [n_data_rows] in/out: JointConstraint::configurationRef_ per bounded joint, then
                               the Lagrange multipliers `lambda_` of every constraint row (PGS warm start) */
     JM_F_FRICTION = 20,    /* [1] in, optional: contacts.friction of every lane (domain randomisation of the ground

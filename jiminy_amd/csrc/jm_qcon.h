@@ -198,7 +198,8 @@ template<class X, int NW> JM_DEV void quad_or_mask(RowMaskN<NW> & m)
 template<class Tp> struct QSplitRegion
 {
     static constexpr int MAXM = QConRows<Tp>::MAXM;
-    static constexpr int HDR = 4 * MAXM + MAXM * MAXM + 32, OK = HDR + 1, ROWS = (OK + 2) & ~1;   // (even: 16-byte aligned regions)
+    // (LOCK: the packed joint rows that are user-registered JointConstraints, as an integer-valued scalar < 2^53)
+    static constexpr int HDR = 4 * MAXM + MAXM * MAXM + 32, OK = HDR + 1, LOCK = HDR + 2, ROWS = (LOCK + 2) & ~1;   // (even: 16-byte aligned regions)
 };
 
 // which topologies step in the split form (jm_qcon.h, bottom): solves of more than 32 rows
@@ -213,6 +214,8 @@ template<class T, class Tp> struct QConCtx
     using QR = QConRows<Tp>;
     using RowMask = RowMaskN<QR::NWORDS>;
     RowMask act, rev, mine;   // active rows of the robot (solved), reversed bounds, active rows this lane owns
+    RowMask lock;             // joint rows that are user-registered JointConstraints (bit 2 of the flag: bilateral, solved first)
+    unsigned long long lockp; // the same over the PACKED joint rows of the solve (bit p: packed row p)
     int m, nb;                // packed sizes: rows, of which joint bounds
     int cb;                   // rows per contact block of the solve (4, or 3 when contacts.torsion == 0)
     bool overflow;            // more active rows than JM_QCON_MAXM: the excess was dropped
@@ -236,12 +239,22 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
     // (constraint_solvers.cc:164-170), so that row is left out of the solve -- except in Engine::start, whose first
     // pass is an exact solve of ALL rows (`ignoreBounds`)
     const bool torsion_zero = C.torsion < Eps<T>::eps && !init;
-    typename QConCtx<T, Tp>::RowMask en, rv, own;
-    en.clear(); rv.clear(); own.clear();
+    typename QConCtx<T, Tp>::RowMask en, rv, own, lk;
+    en.clear(); rv.clear(); own.clear(); lk.clear();
     auto bound = [&](int row, T qj, T lo, T hi, bool writer, bool mine_) {
         const unsigned of = (unsigned)row * B32 + r32, ol = (unsigned)(R::LAM + row) * B32 + r32;
-        int32_t f = init ? 1 : C.flags[of];
-        if (!readonly)
+        const int32_t f0 = C.flags[of];
+        int32_t f = init ? (1 | (f0 & 4)) : f0;
+        if (f & 4)
+        {
+            // user-registered JointConstraint on this joint (Model::addConstraint, model.cc:926-936): always enabled, never
+            // reversed, reference configuration = the configuration at Engine::start (JointConstraint::reset) or what the
+            // caller stored; the joint's own bound constraint is not switched while the lock holds
+            f = 5;
+            if (!readonly && init && writer) { C.flags[of] = f; C.data[of] = qj; C.data[ol] = T(0); }
+            lk.set(row);
+        }
+        else if (!readonly)
         {
             T ref = init ? qj : C.data[of];
             bool clear = init;
@@ -319,6 +332,8 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
     }
     quad_or_mask<X>(en);
     quad_or_mask<X>(rv);
+    quad_or_mask<X>(lk);
+    cx.lock = lk;
     // row cap: the highest rows are dropped (and the lane flagged) when a robot has more active rows than the
     // solver region was sized for
     cx.overflow = false;
@@ -355,6 +370,16 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
     cx.m = en.count();
     cx.nb = en.rank(R::NB);
     cx.cb = torsion_zero ? 3 : 4;
+    static_assert(R::NB <= 64, "packed joint rows of a solve as one 64-bit mask");
+    cx.lockp = 0ull;
+    {
+        typename QConCtx<T, Tp>::RowMask tmp = lk;
+        while (tmp.any())
+        {
+            const int row = tmp.pop_lowest();
+            if (en.test(row)) cx.lockp |= 1ull << en.rank(row);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- bias-free sweeps, root coordinates
@@ -776,9 +801,22 @@ JM_DEV bool qcon_pgs(const QConArgs<T> & C, T friction, int k, const QConCtx<T, 
             if (lead) V.put(2 * m + i, y);
             return y;
         };
+        // unbounded constraints first (user-registered JointConstraints: constraint_solvers.cc:112-128, no relaxation
+        // factor, no projection)
+        if (cx.lockp)
+            for (int r = 0; r < nb; ++r)
+            {
+                if (!((cx.lockp >> r) & 1ull)) continue;
+                const T y = residual(r);
+                const T e = V.get(r) + y * V.get(3 * m + r);
+                X::sync();
+                if (lead) V.put(r, e);
+                X::sync();
+            }
         // block 0 of every constraint: joint bounds, then the normal force of every contact
         for (int r = 0; r < m; r += (r < nb ? 1 : cb))
         {
+            if (r < nb && ((cx.lockp >> r) & 1ull)) continue;
             const int i0 = r < nb ? r : r + 2;
             const T y = residual(i0);
             const T e = V.get(i0) + (w * y) * V.get(3 * m + i0);
@@ -1507,6 +1545,8 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
 #endif
     QConCtx<T, Tp> cx;
     cx.m = 0;
+    cx.lockp = 0ull;
+    cx.lock.clear();
     T uq_l[N], uq_b[NT];   // RobotState::u of the previous start pass minus the motor efforts (bound multipliers, + sign)
     static_for<0, N>([&](auto sc) { uq_l[decltype(sc)::value] = T(0); });
     static_for<0, NT>([&](auto tc) { uq_b[decltype(tc)::value] = T(0); });
@@ -1514,7 +1554,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     if constexpr (PH != 0)
     {
         using SR = QSplitRows<Tp>;
-        static_assert(3 * QR::NWORDS + 1 <= SR::NCX, "context rows of the split stage buffer");
+        static_assert(4 * QR::NWORDS + 2 <= SR::NCX, "context rows of the split stage buffer");
         auto mask_io = [&](typename QConCtx<T, Tp>::RowMask & mk, int row0, bool save) {
             static_for<0, QR::NWORDS>([&](auto wc) {
                 constexpr int w = decltype(wc)::value;
@@ -1537,11 +1577,16 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 qcon_rhs<T, Tp, QStoreSq<T>, GEN>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
             }
             // header of the solve: rows | joint bounds | rows per contact block (0 rows: nothing to solve)
-            if (k == 0) W.put(QSplitRegion<Tp>::HDR, (T)(any ? (cx.m | (cx.nb << 8) | (cx.cb << 16)) : 0));
+            if (k == 0)
+            {
+                W.put(QSplitRegion<Tp>::HDR, (T)(any ? (cx.m | (cx.nb << 8) | (cx.cb << 16)) : 0));
+                W.put(QSplitRegion<Tp>::LOCK, (T)cx.lockp);
+            }
             mask_io(cx.act, SR::CXL, true);
             mask_io(cx.rev, SR::CXL + QR::NWORDS, true);
             mask_io(cx.mine, SR::CXL + 2 * QR::NWORDS, true);
-            S_.putl(SR::CXL + 3 * QR::NWORDS, (T)(cx.m | (cx.nb << 8) | (cx.cb << 16) | (cx.overflow ? (1 << 24) : 0)));
+            mask_io(cx.lock, SR::CXL + 3 * QR::NWORDS, true);
+            S_.putl(SR::CXL + 4 * QR::NWORDS, (T)(cx.m | (cx.nb << 8) | (cx.cb << 16) | (cx.overflow ? (1 << 24) : 0)));
             return;
         }
         else
@@ -1549,7 +1594,9 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             mask_io(cx.act, SR::CXL, false);
             mask_io(cx.rev, SR::CXL + QR::NWORDS, false);
             mask_io(cx.mine, SR::CXL + 2 * QR::NWORDS, false);
-            const int hdr = (int)S_.getl(SR::CXL + 3 * QR::NWORDS);
+            mask_io(cx.lock, SR::CXL + 3 * QR::NWORDS, false);
+            cx.lockp = 0ull;   // (only the solve needs the packed form)
+            const int hdr = (int)S_.getl(SR::CXL + 4 * QR::NWORDS);
             cx.m = hdr & 0xff; cx.nb = (hdr >> 8) & 0xff; cx.cb = (hdr >> 16) & 0xff; cx.overflow = (hdr >> 24) & 1;
             any = cx.act.any();
             if (any)
@@ -1602,7 +1649,9 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 bool ok = true;
                 if constexpr (VS::ON_CHIP && VS::NIT <= JM_QCON_REGS_NIT)
                 {
-                    if (!(JM_QCON_SKIP & 1))
+                    // (robots with user-registered JointConstraints: the general form knows the unbounded rows)
+                    if (X::wave_any(cx.lockp != 0ull)) { if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs<T, Tp, X, VS>(C, friction, k, cx, W); }
+                    else if (!(JM_QCON_SKIP & 1))
                     {
                         bool fixed = false;
                         if constexpr (JM_QCON_PGS_FIXED && 3 * ConRows<Tp>::NC <= 4 * VS::NIT)
@@ -1636,12 +1685,12 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         static_for<0, N>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             const int row = sel4(k, QR::limb_row(0, s), QR::limb_row(1, s), QR::limb_row(2, s), QR::limb_row(3, s));
-            uq_l[s] = (row >= 0 && ix.has[s] && cx.act.test(row)) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
+            uq_l[s] = (row >= 0 && ix.has[s] && cx.act.test(row) && !cx.lock.test(row)) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
         });
         static_for<1, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int row = QR::trunk_row(t);
-            if constexpr (row >= 0) uq_b[t] = cx.act.test(row) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
+            if constexpr (row >= 0) uq_b[t] = (cx.act.test(row) && !cx.lock.test(row)) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
         });
     }
     }
@@ -1660,7 +1709,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         const bool on = any && row >= 0 && ix.has[s] && cx.act.test(row);
         const T lam = on ? C.data[(unsigned)(R::LAM + (on ? row : 0)) * B32 + r32] : T(0);
         ex.tau_l[s] = uq_l[s] + ((on && cx.rev.test(row)) ? -lam : lam);
-        ex.uemit_l[s] = lam;
+        ex.uemit_l[s] = (on && cx.lock.test(row)) ? T(0) : lam;   // (a user constraint's multiplier is not restored into RobotState::u)
     });
     static_for<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -1670,7 +1719,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             const bool on = any && cx.act.test(row);
             const T lam = on ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
             ex.tau_b[t] = uq_b[t] + ((on && cx.rev.test(row)) ? -lam : lam);
-            ex.uemit_b[t] = lam;
+            ex.uemit_b[t] = (on && cx.lock.test(row)) ? T(0) : lam;
         }
         else { ex.tau_b[t] = uq_b[t]; ex.uemit_b[t] = T(0); }
     });
@@ -1740,12 +1789,27 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
         kind = 2 + (u & 1);
         return nb + cb * (u >> 1) + (u & 1);
     };
-    // (the table of the sweep, built once per solve: row | kind << 8)
-    for (int t = k; t < m; t += 4)
+    // (the table of the sweep, built once per solve: row | kind << 8; kind 4 = unbounded row, no relaxation, no projection:
+    // the user-registered JointConstraints, visited FIRST, constraint_solvers.cc:112-128)
+    const unsigned long long lockp = (unsigned long long)G(RG::LOCK);
+    if (lockp == 0ull)
+        for (int t = k; t < m; t += 4)
+        {
+            int kind;
+            const int row = visit(t, kind);
+            vt[t] = (unsigned short)(row | (kind << 8));
+        }
+    else if (lead)
     {
-        int kind;
-        const int row = visit(t, kind);
-        vt[t] = (unsigned short)(row | (kind << 8));
+        int t = 0;
+        for (int r = 0; r < nb; ++r) if ((lockp >> r) & 1ull) vt[t++] = (unsigned short)(r | (4 << 8));
+        for (int r = 0; r < nb; ++r) if (!((lockp >> r) & 1ull)) vt[t++] = (unsigned short)r;
+        for (; t < m; ++t)
+        {
+            int kind;
+            const int row = visit(t, kind);
+            vt[t] = (unsigned short)(row | (kind << 8));
+        }
     }
     X::sync();
     struct Row { T2 a[NJ]; T b, yp, invd; int i, kind; };
@@ -1809,7 +1873,7 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
             tp = tp + 1 < m ? tp + 1 : 0;
             const Row & cur = ring[d];
             const int i = cur.i, kind = cur.kind;
-            if ((kind == 1 && torsion_zero) || (kind >= 2 && friction_zero))
+            if ((kind == 1 && torsion_zero) || ((kind == 2 || kind == 3) && friction_zero))
             {
                 // (rows the reference zeroes without looking at their residual)
                 if (lead) x[i] = x[i] * T(0);
@@ -1828,6 +1892,10 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
                 {
                     const T e = x[i] + (w * y) * cur.invd;
                     if (lead) x[i] = fmax_(e, T(0));  // clamp(e, 0, inf)
+                }
+                else if (kind == 4)
+                {
+                    if (lead) x[i] = x[i] + y * cur.invd;
                 }
                 else if (kind == 1)
                 {

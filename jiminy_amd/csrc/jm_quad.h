@@ -219,7 +219,7 @@ template<class Tp> struct QSplitRows
 {
     using R = QRows<Tp>;
     static constexpr int N = Tp::QN, NQB = QInfo<Tp>::NQB, NVB = QInfo<Tp>::NVB;
-    static constexpr int CURQL = R::NL, CURVL = CURQL + N, DDQL = CURVL + N, STATUSL = DDQL + N, CXL = STATUSL + 1, NCX = 12;
+    static constexpr int CURQL = R::NL, CURVL = CURQL + N, DDQL = CURVL + N, STATUSL = DDQL + N, CXL = STATUSL + 1, NCX = 16;
     static constexpr int NL = CXL + NCX;
     static constexpr int CURQB = R::NB, CURVB = CURQB + NQB, DDQB = CURVB + NVB, NB = DDQB + NVB;
     // scalars per tile of 16 robots

@@ -156,6 +156,14 @@ class RobotState:
 
 
 @dataclass
+class JointConstraint:
+    """≙ `jiminy.JointConstraint(joint_name)` (core/src/constraints/joint_constraint.cc): the joint held at a reference
+    configuration (the configuration at `start`, `JointConstraint::reset`) by a bilateral kinematic constraint with the
+    Baumgarte stabilisation of the contact model.  Registered with `BatchedEngine.add_constraint`."""
+    joint_name: str
+
+
+@dataclass
 class StepperState:
     """≙ `struct StepperState` (reference engine.h:216-250); time is shared by all lanes."""
     iter: int
@@ -546,6 +554,7 @@ class BatchedEngine:
         self._bias_table: Optional[torch.Tensor] = None     # nominal body parameters + principal axes (device)
         self._ground: Optional[torch.Tensor] = None
         self._force_frames: List[str] = []
+        self._user_constraints: Dict[str, Any] = {}
         self._impulse_forces: List[Dict[str, Any]] = []
         self._impulse_active: List[int] = []
         self._profile_forces: List[Dict[str, Any]] = []
@@ -701,6 +710,46 @@ class BatchedEngine:
             self._fields["workspace"] = torch.zeros((max(nw.value, 1), B), dtype=self.dtype, device=self.device)
             for name in ("con_flags", "con_data", "workspace"):
                 self._bind(name)
+
+    # ------------------------------------------------------------------ user-registered constraints
+    def add_constraint(self, name: str, constraint: Any, lane_mask: Optional[torch.Tensor] = None) -> None:
+        """≙ `Model::addConstraint(name, constraint)` (core/src/robot/model.cc:926-936), user registry.  `JointConstraint`s of
+        joints with position bounds, constraint contact model, float64 batches of branch-parallel topologies: the row of
+        the joint's own bound constraint becomes bilateral (bit 2 of its flag), is solved first in every Gauss-Seidel
+        sweep without projection (constraint_solvers.cc:112-128) and its multiplier is not restored into
+        `RobotState::u` (engine.cc:3771-3790); the bound of a locked joint is not switched while the lock holds.
+        `lane_mask`: the environments that get it (default: all).  Other constraint types (`FrameConstraint`,
+        `DistanceConstraint`, `SphereConstraint`, `WheelConstraint`) are not built."""
+        if self._running:
+            raise BadControlFlow("Please stop the simulation before adding constraints.")   # model.cc:866-872
+        if not isinstance(constraint, JointConstraint):
+            raise NotImplementedError("only JointConstraint can be registered")
+        if name in self._user_constraints:
+            raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
+        if self._options["contacts"]["model"] != "constraint" or codegen.quad_structure(self.model) is None or \
+                self.dtype != torch.float64 or os.environ.get("JM_KERNEL_VARIANT") == "lane":
+            raise NotImplementedError("user constraints need the constraint contact model on a float64 batch of a "
+                                      "branch-parallel topology (floating base with four limbs)")
+        if "con_flags" not in self._fields:
+            self._apply_options()
+        row = self.model.bound_row(constraint.joint_name)
+        if any(r == row for r, _ in self._user_constraints.values()):
+            raise ValueError(f"joint '{constraint.joint_name}' already carries a user constraint")
+        mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if lane_mask is None else \
+            lane_mask.to(self.device).bool()
+        self._fields["con_flags"][row] |= torch.where(mask, 4, 0).to(torch.int32)
+        self._user_constraints[name] = (row, constraint)
+
+    def remove_constraint(self, name: str) -> None:
+        """≙ `Model::removeConstraint(name)` (model.cc:1010-1013)."""
+        if self._running:
+            raise BadControlFlow("Please stop the simulation before removing constraints.")
+        row, _ = self._user_constraints.pop(name)
+        self._fields["con_flags"][row] &= ~4
+
+    @property
+    def user_constraints(self) -> Dict[str, Any]:
+        return {k: c for k, (_, c) in self._user_constraints.items()}
 
     def set_lane_friction(self, friction: Optional[Any]) -> None:
         """Ground friction coefficient of every lane (`contacts.friction` randomised per environment as

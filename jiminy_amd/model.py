@@ -365,6 +365,14 @@ class CompiledModel:
                 m[int(self.idx_q[j])] = True
         return m
 
+    def bound_row(self, joint_name: str) -> int:
+        """Row of the joint's `JointConstraint` in the per-lane constraint state (`con_flags` / `con_data`: one row per
+        bounded 1-dof joint, model joint order).  LookupError for joints without position bounds."""
+        j = self.joint_names.index(joint_name)
+        if not 1 <= int(self.jtypes[j]) <= 8:
+            raise LookupError(f"joint '{joint_name}' has no position bounds: no constraint row")
+        return int(sum(1 for i in range(1, j) if 1 <= int(self.jtypes[i]) <= 8))
+
     # ---- sensors bookkeeping: fixed layout of the observation vector
     def sensor_names(self, sensor_type: str) -> List[str]:
         return [s["name"] for s in self.sensors.get(sensor_type, [])]

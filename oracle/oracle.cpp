@@ -455,6 +455,11 @@ struct Engine
         int joint = 0;
         bool enabled = false, reversed = false;
         double ref = 0.0, lambda = 0.0;
+        // a user-registered JointConstraint on the same joint (Model::addConstraint, model.cc:926-936; flag bit 2 of the batch
+        // state): bilateral, always enabled, no direction; solved first in every sweep (constraint_solvers.cc:112-128); its
+        // multiplier is not restored into RobotState::u (engine.cc:3771-3790 restores the bounds only).  While it holds, the
+        // joint's own bound constraint is not switched (the device shares the row).
+        bool locked = false;
     };
     struct FrameCon  // FrameConstraint with dofsFixed = {x, y, z, rot z} (core/src/robot/model.cc:817-823)
     {
@@ -927,7 +932,7 @@ void reset_constraints(Engine & e)
     init_constraints(e);
     for (auto & b : e.bcon)
     {
-        b.ref = e.q[e.mdl.idx_q[b.joint]];  // JointConstraint::reset: configurationRef_ = q
+        b.ref = e.q[e.mdl.idx_q[b.joint]];  // JointConstraint::reset: configurationRef_ = q (bounds and user locks alike)
         b.lambda = 0.0;
         b.reversed = false;
         b.enabled = true;
@@ -946,6 +951,7 @@ void toggle_bounds(Engine & e, const double * q)
     const double eps = e.opt.contact_transition_eps;
     for (auto & b : e.bcon)
     {
+        if (b.locked) { b.enabled = true; b.reversed = false; continue; }
         const int iq = m.idx_q[b.joint];
         const double qj = q[iq], lo = m.qlo[iq], hi = m.qhi[iq];
         if (hi < qj || qj < lo)
@@ -1038,6 +1044,16 @@ bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const st
         {
             w = 0.01;
             if (ratio > 0.0) w += (1.0 - 0.01) * std::pow(ratio, 2.0);
+        }
+        // first, the unbounded constraints, coefficient by coefficient (constraint_solvers.cc:112-128)
+        for (const auto & c : rs.cons)
+        {
+            if (c.nblocks != 0) continue;
+            for (int i = c.start; i < c.start + c.dim; ++i)
+            {
+                y[i] = b[i] - col_dot(i);
+                x[i] += y[i] / A(i, i);
+            }
         }
         for (int blk = 0; blk < 3; ++blk)
             for (const auto & c : rs.cons)
@@ -1215,7 +1231,7 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     const double kp = omega * omega, kd = 2.0 * omega;
     PgsRowSet rs;
     int rows = 0;
-    for (const auto & b : e.bcon) if (b.enabled) { rs.cons.push_back({rows, 1, 1}); rows += 1; }
+    for (const auto & b : e.bcon) if (b.enabled) { rs.cons.push_back({rows, 1, b.locked ? 0 : 1}); rows += 1; }
     for (const auto & f : e.fcon) if (f.enabled) { rs.cons.push_back({rows, 4, 3}); rows += 4; }
     Dense J(rows, nv);
     std::vector<double> gamma(rows, 0.0), lambda(rows, 0.0);
@@ -1324,6 +1340,7 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     {
         if (!bc.enabled) continue;
         bc.lambda = lambda[r++];
+        if (bc.locked) continue;   // (user constraints: the multiplier acts through ddq only)
         const int iv = m.idx_v[bc.joint];
         e.uInternal[iv] += bc.lambda;
         u[iv] += bc.lambda;
@@ -2158,7 +2175,7 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
         for (int64_t k = 0; k < nb; ++k)
         {
             const int32_t f = e.con_flags[k * B + l];
-            e.bcon[k].enabled = f & 1; e.bcon[k].reversed = (f & 2) != 0;
+            e.bcon[k].enabled = f & 1; e.bcon[k].reversed = (f & 2) != 0; e.bcon[k].locked = (f & 4) != 0;
             e.bcon[k].ref = e.con_data[k * B + l];
             e.bcon[k].lambda = e.con_data[(nb + k) * B + l];
         }
@@ -2193,7 +2210,7 @@ static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
         const int64_t nb = (int64_t)e.bcon.size(), nc = (int64_t)e.fcon.size();
         for (int64_t k = 0; k < nb; ++k)
         {
-            e.con_flags[k * B + l] = (e.bcon[k].enabled ? 1 : 0) | (e.bcon[k].reversed ? 2 : 0);
+            e.con_flags[k * B + l] = (e.bcon[k].enabled ? 1 : 0) | (e.bcon[k].reversed ? 2 : 0) | (e.bcon[k].locked ? 4 : 0);
             e.con_data[k * B + l] = e.bcon[k].ref;
             e.con_data[(nb + k) * B + l] = e.bcon[k].lambda;
         }

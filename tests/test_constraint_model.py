@@ -258,6 +258,50 @@ def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
         _check(got, ref, 1e-7, solver)
 
 
+LOCKS = {"anymal": ("LF_KFE", "RH_HAA", "RH_HFE"), "atlas": ("l_arm_elx", "r_arm_shx", "back_bky", "l_leg_kny")}
+
+
+@pytest.mark.parametrize("name,split", [("anymal", False), ("atlas", False), ("atlas", True)])
+def test_user_joint_constraints_on_the_host(name, split):
+    """User-registered `JointConstraint`s (`Model::addConstraint`, model.cc:926-936: bit 2 of the joint's constraint flag):
+    bilateral rows solved first in every sweep, no projection (constraint_solvers.cc:112-128), multipliers not restored
+    into RobotState::u.  Kernel sources on the host against the oracle, some lanes locked and some not; the locked
+    joints stay where `Engine::start` found them."""
+    model = _models()[name]()
+    B = 8 if name == "anymal" else 4
+    ref, got = _pair(model, B, seed=31)
+    rows = [model.bound_row(j) for j in LOCKS[name]]
+    lanes = np.arange(B) % 2 == 0     # every other lane carries the locks
+    for arr in (ref, got):
+        for r in rows:
+            arr["con_flags"][r, lanes] |= 4
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT, variant="quad")
+    _check(got, ref, 1e-8, "start")
+    assert all(int(ref["con_flags"][r, 0]) == 5 and (int(ref["con_flags"][r, 1]) & 4) == 0 for r in rows)
+    q_lock = np.array([ref["q"][int(model.idx_q[model.joint_names.index(j)])].copy() for j in LOCKS[name]])
+    for solver, n_sub in (("euler_explicit", 4), ("runge_kutta_4", 2)):
+        for _ in range(2):
+            kw = dict(solver=solver, dt=5e-4, n_substeps=n_sub, command_changed=True)
+            oracle_batch(model, ref, "step", constraint_options=TIGHT, **kw)
+            emu.run(model, got, "step", constraint_options=TIGHT, variant="quad", split=split, **kw)
+        _check(got, ref, 1e-7, solver)
+    # the constraint equation of every lock at the end state: a + kp (q - q_ref) + kd v = 0 (JointConstraint drift with the
+    # Baumgarte gains of abstract_constraint.cc:88-98); q_ref = the configuration at start
+    omega = 2.0 * np.pi * 20.0
+    for j, r, q0 in zip(LOCKS[name], rows, q_lock):
+        jj = model.joint_names.index(j)
+        iq, iv = int(model.idx_q[jj]), int(model.idx_v[jj])
+        assert np.array_equal(ref["con_data"][r, lanes], q0[lanes])
+        res = ref["a"][iv] + omega ** 2 * (ref["q"][iq] - q0) + 2.0 * omega * ref["v"][iv]
+        # (to the regularisation of the solve: (A + 1e-3 diag A) lambda = b leaves 1e-3 A_ii lambda_i, constraint_solvers.cc:376-387)
+        assert np.abs(res[lanes]).max() < 5e-3 * max(1.0, np.abs(ref["a"][iv]).max()), (j, np.abs(res[lanes]).max())
+        assert np.abs(res[~lanes]).max() > 20.0 * np.abs(res[lanes]).max()
+    # the multipliers of the locks are there (con_data) and do not appear in RobotState::u
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    assert np.abs(ref["con_data"][[nb + r for r in rows]][:, lanes]).max() > 1e-3
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
     """A humanoid standing flat: the 8 bottom vertices of each foot box touch, 16 contact points = 64 rows in
@@ -474,6 +518,52 @@ def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_s
             if with_oracle and k in ref and ref[k].size:
                 assert rel_err(a, ref[k]) < 1e-7, (k, rel_err(a, ref[k]))
     print("split vs single kernel:", ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("anymal", 96), ("atlas", 48), ("atlas", 40)])
+def test_gpu_user_joint_constraints(gpu_device, name, B):
+    """`BatchedEngine.add_constraint(name, JointConstraint(joint))` on the device against the oracle: every other lane
+    locked (ANYmal: the general Gauss-Seidel form out of LDS; Atlas, 48 lanes: the split form with the unbounded rows first
+    in its visit table; 40 lanes: the single kernel), RK4 and Euler steps; `remove_constraint` gives the joints back."""
+    import torch
+
+    from jiminy_amd.engine import BadControlFlow, BatchedEngine, JointConstraint
+    model = _models()[name]()
+    ref, _ = _pair(model, B, seed=37)
+    lanes = np.arange(B) % 2 == 0
+    rows = [model.bound_row(j) for j in LOCKS[name]]
+    for r in rows:
+        ref["con_flags"][r, lanes] |= 4
+    dt = 5e-4 if name == "anymal" else 2.5e-4
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces", "f_external", "energy"))
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 2 * dt, "sensorsUpdatePeriod": 2 * dt,
+                                 "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]}, "contacts": {"model": "constraint"}})
+    mask = torch.from_numpy(lanes).to(gpu_device)
+    for j in LOCKS[name]:
+        eng.add_constraint("lock_" + j, JointConstraint(j), lane_mask=mask)
+    with pytest.raises(ValueError):
+        eng.add_constraint("lock_" + LOCKS[name][0], JointConstraint(LOCKS[name][1]))
+    eng.set_command(torch.from_numpy(ref["command"]))
+    eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+    with pytest.raises(BadControlFlow):
+        eng.remove_constraint("lock_" + LOCKS[name][0])
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    for _ in range(3):
+        eng.step(2 * dt)
+        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt, n_substeps=2, command_changed=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
+    for k in OUTS:
+        if k in eng._fields and eng._rows.get(k, 1) > 0 and ref[k].size:
+            # (ANYmal's solves run close to the iteration cap at these tolerances, see test_gpu_constraint_model_matches_oracle)
+            assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < (1e-4 if name == "anymal" else 1e-7), k
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    assert np.abs(ref["con_data"][[nb + r for r in rows]][:, lanes]).max() > 1e-3
+    eng.stop()
+    for j in LOCKS[name]:
+        eng.remove_constraint("lock_" + j)
+    assert not eng.user_constraints and int((eng.field("con_flags") & 4).sum()) == 0
 
 
 @pytest.mark.gpu
