@@ -248,6 +248,12 @@ int32_t jm_batch_constraint_rows(const jm_batch * batch, int32_t * n_flag_rows, 
  * a contact constraint live in the local frame of the surface, FrameConstraint::setNormal), branch-parallel topologies. */
 int32_t jm_batch_set_ground(jm_batch * batch, const void * heights, int32_t nx, int32_t ny, double x0, double y0,
                             double dx, double dy);
+/* User-registered JointConstraints (`Model::addConstraint(name, JointConstraint)`, core/src/robot/model.cc:926-936;
+ * python/jiminy_pywrap/src/robot.cc:215 `add_constraint`): tell the batch that joint rows of JM_F_CON_FLAGS may carry
+ * bit 2, so that its launches take kernels built with the unbounded rows (the plain kernels of robots with
+ * register-resident solves ignore the bit).  Branch-parallel topologies, constraint contact model; 0 = none any more. */
+int32_t jm_batch_set_joint_locks(jm_batch * batch, int32_t on);
+
 /* Frames that carry the JM_F_APPLIED wrenches (`Engine::registerImpulseForce` / `registerProfileForce`,
  * core/src/engine/engine.cc:1838-1935, accept any frame of the model): `offsets` = K x 3 frame positions in the frame of
  * their parent joint, `joints` = the K parent joint indices (NULL = all on the root joint); K <= 4, K = 0 disables.

@@ -47,7 +47,7 @@ ABI_SYMBOLS = (
     "jm_batch_adaptive_workspace_rows", "jm_batch_bind_adaptive", "jm_batch_step_adaptive",
     "jm_block_sensor_noise", "jm_sensor_rng_seed",
     "jm_batch_set_constraint_options", "jm_batch_constraint_rows", "jm_block_sensor_delay",
-    "jm_batch_set_ground", "jm_batch_set_applied_frames", "jm_block_pd_adapter", "jm_block_motor_safety_limit",
+    "jm_batch_set_ground", "jm_batch_set_applied_frames", "jm_batch_set_joint_locks", "jm_block_pd_adapter", "jm_block_motor_safety_limit",
     "jm_block_model_bias", "jm_engine_rng_seed",
 )
 
@@ -99,6 +99,7 @@ class HipLibrary:
         L.jm_batch_constraint_rows.argtypes = [vp, ip, ip, ip]
         L.jm_batch_set_ground.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
         L.jm_batch_set_applied_frames.argtypes = [vp, C.c_int32, dp, ip]
+        L.jm_batch_set_joint_locks.argtypes = [vp, C.c_int32]
         for name in ABI_SYMBOLS:
             getattr(L, name)  # AttributeError if a declared symbol is not exported
             if name not in ("jm_topology_signature",):

@@ -92,6 +92,7 @@ struct jm_batch
     void * field[JM_F_COUNT] = {};
     bool started = false;
     bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
+    bool joint_locks = false; // the batch carries user-registered JointConstraints (jm_batch_set_joint_locks)
     int split_chunks = 1;     // ... as this many independent chunks on streams of their own (JIMINY_AMD_QCON_SPLIT_CHUNKS; measured: no gain)
     hipStream_t split_stream[8] = {};
     hipEvent_t split_fork = nullptr, split_join[8] = {};
@@ -306,7 +307,9 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                 return;
             }
         }
-        if (A.model_lane || A.applied || A.ground_h) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+        // (user-registered JointConstraints: kernels built with them -- the variation kernel, or any kernel of a split topology)
+        if (A.model_lane || A.applied || A.ground_h || (b->joint_locks && !jm::qcon_split<Tp>()))
+            hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
         else hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
     }
     else { (void)b; (void)A; (void)C0; (void)s; }
@@ -604,6 +607,14 @@ int32_t jm_batch_destroy(jm_batch * b)
     for (hipEvent_t e : b->split_join) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : b->split_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     delete b;
+    return JM_OK;
+}
+int32_t jm_batch_set_joint_locks(jm_batch * b, int32_t on)
+{
+    if (!b) return fail(JM_EINVAL, "jm_batch_set_joint_locks: null batch");
+    if (on && !(Topo::QUAD && b->variant == VARIANT_QUAD))
+        return fail(JM_ENOTIMPL, "user-registered joint constraints need a branch-parallel topology (floating base with four limbs)");
+    b->joint_locks = on != 0;
     return JM_OK;
 }
 int32_t jm_batch_set_options(jm_batch * b, const jm_options * o)

@@ -204,6 +204,11 @@ template<class Tp> struct QSplitRegion
 
 // which topologies step in the split form (jm_qcon.h, bottom): solves of more than 32 rows
 template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > 32; }
+// which kernels know user-registered JointConstraints (bit 2 of a joint row's flag): the variation kernels, and every
+// constraint kernel of the topologies that step in the split form (their solves run out of the workspace anyway); the plain
+// kernels of robots with register-resident solves (ANYmal) stay free of it -- the host launches the variation kernel for a
+// batch that carries locks (jm_batch_set_joint_locks)
+template<class Tp, bool GEN> constexpr bool qcon_locks() { return GEN || qcon_split<Tp>(); }
 #ifdef JM_TOPO_QCON_SPLIT
 static_assert(qcon_split<Topo>() == (JM_TOPO_QCON_SPLIT != 0), "codegen.qcon_split and jm::qcon_split disagree");
 #endif
@@ -245,7 +250,7 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
         const unsigned of = (unsigned)row * B32 + r32, ol = (unsigned)(R::LAM + row) * B32 + r32;
         const int32_t f0 = C.flags[of];
         int32_t f = init ? (1 | (f0 & 4)) : f0;
-        if (f & 4)
+        if (qcon_locks<Tp, GND>() && (f & 4))
         {
             // user-registered JointConstraint on this joint (Model::addConstraint, model.cc:926-936): always enabled, never
             // reversed, reference configuration = the configuration at Engine::start (JointConstraint::reset) or what the
@@ -332,7 +337,7 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
     }
     quad_or_mask<X>(en);
     quad_or_mask<X>(rv);
-    quad_or_mask<X>(lk);
+    if constexpr (qcon_locks<Tp, GND>()) quad_or_mask<X>(lk);
     cx.lock = lk;
     // row cap: the highest rows are dropped (and the lane flagged) when a robot has more active rows than the
     // solver region was sized for
@@ -372,6 +377,7 @@ JM_DEV void qcon_switch(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & 
     cx.cb = torsion_zero ? 3 : 4;
     static_assert(R::NB <= 64, "packed joint rows of a solve as one 64-bit mask");
     cx.lockp = 0ull;
+    if constexpr (qcon_locks<Tp, GND>())
     {
         typename QConCtx<T, Tp>::RowMask tmp = lk;
         while (tmp.any())
@@ -1650,7 +1656,9 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 if constexpr (VS::ON_CHIP && VS::NIT <= JM_QCON_REGS_NIT)
                 {
                     // (robots with user-registered JointConstraints: the general form knows the unbounded rows)
-                    if (X::wave_any(cx.lockp != 0ull)) { if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs<T, Tp, X, VS>(C, friction, k, cx, W); }
+                    bool general = false;
+                    if constexpr (qcon_locks<Tp, GEN>()) general = X::wave_any(cx.lockp != 0ull);
+                    if (general) { if (!(JM_QCON_SKIP & 1)) ok = qcon_pgs<T, Tp, X, VS>(C, friction, k, cx, W); }
                     else if (!(JM_QCON_SKIP & 1))
                     {
                         bool fixed = false;

@@ -672,7 +672,8 @@ class BatchedEngine:
                 os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
             return
         lane_mu = "friction" in self._fields and self._options["contacts"]["model"] != "constraint"
-        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu):
+        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu or
+                self._user_constraints):
             return
         self._gen_checked = True
         variant = self._lib_variant_index
@@ -737,6 +738,7 @@ class BatchedEngine:
             raise ValueError(f"joint '{constraint.joint_name}' already carries a user constraint")
         mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if lane_mask is None else \
             lane_mask.to(self.device).bool()
+        self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 1))
         self._fields["con_flags"][row] |= torch.where(mask, 4, 0).to(torch.int32)
         self._user_constraints[name] = (row, constraint)
 
@@ -746,6 +748,8 @@ class BatchedEngine:
             raise BadControlFlow("Please stop the simulation before removing constraints.")
         row, _ = self._user_constraints.pop(name)
         self._fields["con_flags"][row] &= ~4
+        if not self._user_constraints:
+            self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 0))
 
     @property
     def user_constraints(self) -> Dict[str, Any]:

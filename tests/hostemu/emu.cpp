@@ -327,6 +327,11 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
             C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
             C.stage = nullptr; C.split_e = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
+            // user-registered JointConstraints (bit 2 of a joint row): kernels built with them (jm::qcon_locks)
+            bool locks = false;
+            if (!jm::qcon_split<Topo>() && g_con_flags)
+                for (long long i = 0; i < (long long)jm::ConRows<Topo>::NB * A.B && !locks; ++i) locks = (((const int32_t *)g_con_flags)[i] & 4) != 0;
+            const bool gen_ = gen || locks;
             bool split = false;
             if constexpr (std::is_same<T, double>::value)
                 if (!gen && g_split && jm::qcon_split<Topo>() && mode == jm::MODE_STEP)
@@ -335,7 +340,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
                     split = true;
                 }
             if (split) {}
-            else if (gen) run_quad_con<T, Topo, true>(A, P, C);
+            else if (gen_) run_quad_con<T, Topo, true>(A, P, C);
             else run_quad_con<T, Topo>(A, P, C);
         }
         else if (gen) run_quad<T, Topo, true>(A, P);
