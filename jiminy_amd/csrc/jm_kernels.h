@@ -129,6 +129,10 @@ template<class T> struct BatchArgs
     // copy, QConArgs / ConArgs), or null: `contacts.friction` randomised per environment (envs/locomotion.py:257-262)
     const T * friction;
     const T * ground_off;        // [2][B] per-lane (x, y) offset of the height-map queries (JM_F_GROUND_OFFSET), or null
+    // compact batches of the per-stage adaptive stepper (jm_adaptive.h): lane c of the launch is lane lane_map[c] of the
+    // batch of B_full lanes -- the per-lane OPTIONAL inputs (model_lane, friction, applied, ground_off) stay in batch order
+    const int32_t * lane_map;
+    long long B_full;
 };
 // MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
 // the lane status into the existing one: the closing launch of an adaptive-step interval

@@ -327,8 +327,6 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
         if (!(Topo::QUAD && b->variant == VARIANT_QUAD) || !std::is_same<T, double>::value)
             return fail(JM_ENOTIMPL, "per-lane body parameters / friction, height-map ground and applied wrenches need a float64 "
                                      "batch of a branch-parallel topology (floating base with four limbs)");
-        if (b->ad_ws && A.B != b->B)
-            return fail(JM_ENOTIMPL, "per-lane body parameters / applied wrenches are not available with the adaptive stepper");
     }
     const bool timed = b->timing && A.mode == jm::MODE_STEP && b->n_timed < JM_TIMING_RING;
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
@@ -345,11 +343,8 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             C.flags = b->ov_flags ? b->ov_flags : (int32_t *)b->field[JM_F_CON_FLAGS];
             C.data = b->ov_data ? (T *)b->ov_data : (T *)b->field[JM_F_CON_DATA];
             C.ws = b->ov_ws ? (T *)b->ov_ws : (T *)b->field[JM_F_WORKSPACE];
-            // per-lane friction: bound field, except in the compact batches of the adaptive stepper (lane order
-            // differs there: not supported together)
-            C.friction = b->ov_flags ? nullptr : (const T *)b->field[JM_F_FRICTION];
-            if (b->ov_flags && b->field[JM_F_FRICTION])
-                return fail(JM_ENOTIMPL, "per-lane friction is not available with the adaptive stepper");
+            // per-lane friction: bound field (compact batches of the adaptive stepper read it through BatchArgs::lane_map)
+            C.friction = (const T *)b->field[JM_F_FRICTION];
             const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
             C.kp = (T)(omega * omega);
             C.kd = (T)(2.0 * omega);
@@ -490,6 +485,9 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
                 A.q_in = ws + (long long)R::QS * n;
                 A.v_in = ws + (long long)(R::KV + (i - 1) * Topo::NV) * n;
                 A.a_out = ws + (long long)(R::KA + (i - 1) * Topo::NV) * n;
+                // (per-lane optional inputs -- body parameters, friction, applied wrenches, terrain patch -- stay in batch order)
+                A.lane_map = b->ad_is + (long long)jm::AD_MAP * b->B;
+                A.B_full = b->B;
                 if (constrained)
                 {
                     b->ov_flags = b->ad_flags;

@@ -1543,7 +1543,8 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     const bool refresh = start_passes < 0;
     const bool init = start_passes > 0;
     const int n_pass = init ? start_passes : 1;
-    const T friction = C.friction ? C.friction[r32] : P[L::OPT + 8];
+    // (compact batches of the per-stage adaptive stepper: the per-lane friction stays in batch order, BatchArgs::lane_map)
+    const T friction = C.friction ? C.friction[A.lane_map ? (unsigned)A.lane_map[r32] : r32] : P[L::OPT + 8];
     QKeep<T, Tp> K;
     TrunkStore<T, Tp> TS;
 #ifdef JM_HOST_EMU

@@ -770,6 +770,10 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     const unsigned B32 = (unsigned)A.B;
     unsigned r32 = r;
     JM_OPAQUE(r32);
+    // where the per-lane optional inputs of this lane sit (compact batches of the per-stage adaptive stepper: batch order)
+    unsigned Bg = B32, rg = r32;
+    if constexpr (GEN)
+        if (A.lane_map) { rg = (unsigned)A.lane_map[r32]; Bg = (unsigned)A.B_full; }
     const bool lead = (k == 0);
     const bool emit_sens = emit && sensors;
     const bool want_energy = emit && A.energy;
@@ -809,7 +813,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     // root position as the height map sees it: every lane samples the map at its own (x, y) offset (JM_F_GROUND_OFFSET)
     V3<T> p1g = p1;
     if constexpr (GEN)
-        if (A.ground_off) { p1g.x += A.ground_off[r32]; p1g.y += A.ground_off[B32 + r32]; }
+        if (A.ground_off) { p1g.x += A.ground_off[rg]; p1g.y += A.ground_off[Bg + rg]; }
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     const Sp<T> v1 = {{vb_[0], vb_[1], vb_[2]}, {vb_[3], vb_[4], vb_[5]}};
     // gravity field in root coordinates (bias v x v = 0 for the free-flyer), taken here so that the root placement
@@ -825,7 +829,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     // body parameters: constants, or (GEN) the per-lane rows when they are bound
     using MA = std::conditional_t<GEN, ModelLane<T>, NoModelLane>;
     MA ma;
-    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, B32, r32};
+    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, Bg, rg};
     auto limb_joint_of = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         return sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]);
@@ -879,7 +883,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 {
                     const V3<T> vW = R1 * (vt.l + cross(vt.a, pc));
                     V3<T> fW;
-                    if constexpr (GEN) fW = contact_law_n<T, Tp>(P, nG, depth, vW, A.friction ? A.friction[r32] : T(-1));
+                    if constexpr (GEN) fW = contact_law_n<T, Tp>(P, nG, depth, vW, A.friction ? A.friction[rg] : T(-1));
                     else fW = contact_law<T, Tp>(P, depth, vW);
                     const V3<T> fR = tmul(R1, fW);
                     fext.l = fext.l + fR;
@@ -952,7 +956,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                     put6(A.f_external, B32, r32, 0, zero6<T>());
                     static_for<0, NT>([&](auto tc) { put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[decltype(tc)::value], zero6<T>()); });
                     if constexpr (GEN)
-                        if (A.applied_k > 0) put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[0], applied_root_wrench(A, R1, B32, r32));
+                        if (A.applied_k > 0) put6(A.f_external, B32, r32, 6 * Tp::trunk_joint[0], applied_root_wrench(A, R1, Bg, rg));
                 }
                 static_for<0, N>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
@@ -1063,7 +1067,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 if constexpr (GEN && EMIT)
                     if (applied_out && ix.has[s])
                         add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc),
-                             wrench_to_joint(Rcur, pcur, applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, B32, r32)));
+                             wrench_to_joint(Rcur, pcur, applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, Bg, rg)));
                 if (applied_out && !want_energy)
                 {
                     if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
@@ -1090,7 +1094,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             if constexpr (GEN)
                 if (A.applied_k > 0)
                 {
-                    const Sp<T> w = applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, B32, r32);
+                    const Sp<T> w = applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, Bg, rg);
                     f = f - w;
                     if constexpr (EMIT)   // (evaluations that emit their own outputs: the constraint contact model)
                         if (A.f_external && ix.has[s]) add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc), wrench_to_joint(Rcur, pcur, w));
@@ -1159,7 +1163,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
                 if (A.applied_k > 0 && A.f_external)
                 {
                     TS.template get_kin<t, X>(Xt, vt);
-                    if (lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, applied_wrench_on(A, j, R1, Xt.R, Xt.p, B32, r32)));
+                    if (lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, applied_wrench_on(A, j, R1, Xt.R, Xt.p, Bg, rg)));
                 }
             if (want_energy)
             {
@@ -1181,7 +1185,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         if constexpr (GEN)
             if (A.applied_k > 0)
             {
-                const Sp<T> w = applied_wrench_on(A, j, R1, Xt.R, Xt.p, B32, r32);
+                const Sp<T> w = applied_wrench_on(A, j, R1, Xt.R, Xt.p, Bg, rg);
                 f = f - w;
                 if constexpr (EMIT)
                     if (A.f_external && lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, w));
@@ -1219,7 +1223,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         Sp<T> f1 = cross_mf(v1r, rbi_mul(Y1, v1r));
         if constexpr (I::has_child(0)) { I1 = I1 + accA[0]; f1 = f1 + accF[0]; }
         if constexpr (GEN)
-            if (A.applied_k > 0) f1 = f1 - applied_root_wrench(A, R1, B32, r32);   // impulse / profile forces on the root body
+            if (A.applied_k > 0) f1 = f1 - applied_root_wrench(A, R1, Bg, rg);   // impulse / profile forces on the root body
         const Sp<T> Ya = ai_mul(I1, agf1);
         T b[6] = {-f1.l.x - Ya.l.x, -f1.l.y - Ya.l.y, -f1.l.z - Ya.l.z, -f1.a.x - Ya.a.x, -f1.a.y - Ya.a.y, -f1.a.z - Ya.a.z};
         T M[6][6];
@@ -1385,6 +1389,10 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     using I = QInfo<Tp>;
     constexpr int N = Tp::QN, NT = Tp::QT;
     const unsigned B32 = (unsigned)A.B;
+    // where the per-lane optional inputs of this lane sit (compact batches of the per-stage adaptive stepper: batch order)
+    unsigned Bg = B32, rg = r32;
+    if constexpr (GEN)
+        if (A.lane_map) { rg = (unsigned)A.lane_map[r32]; Bg = (unsigned)A.B_full; }
     const bool lead = (k == 0);
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
     const M3<T> R1 = quat_to_matrix(qb[3], qb[4], qb[5], qb[6]);
@@ -1393,12 +1401,12 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
     // root position as the height map sees it: every lane samples the map at its own (x, y) offset (JM_F_GROUND_OFFSET)
     V3<T> p1g = p1;
     if constexpr (GEN)
-        if (A.ground_off) { p1g.x += A.ground_off[r32]; p1g.y += A.ground_off[B32 + r32]; }
+        if (A.ground_off) { p1g.x += A.ground_off[rg]; p1g.y += A.ground_off[Bg + rg]; }
     const Sp<T> agf1 = actinv_motion(M1, Sp<T>{-g, -gw});
     int status = 0;
     using MA = std::conditional_t<GEN, ModelLane<T>, NoModelLane>;
     MA ma;
-    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, B32, r32};
+    if constexpr (GEN) ma = ModelLane<T>{A.model_lane, Bg, rg};
     TrunkKin<T, Tp> K;
     trunk_fk<T, Tp, MA>(P, qb, vb, K, status, ma);
     // true spatial accelerations of the trunk tree (ForwardKinematicsAccelerationStep)
@@ -1444,7 +1452,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
                 {
                     const V3<T> vWc = R1 * (vs[N - 1].l + cross(vs[N - 1].a, pc));
                     V3<T> fWc;
-                    if constexpr (GEN) fWc = contact_law_n<T, Tp>(P, nG, depth, vWc, A.friction ? A.friction[r32] : T(-1));
+                    if constexpr (GEN) fWc = contact_law_n<T, Tp>(P, nG, depth, vWc, A.friction ? A.friction[rg] : T(-1));
                     else fWc = contact_law<T, Tp>(P, depth, vWc);
                     const V3<T> fR = tmul(R1, fWc);
                     fext.l = fext.l + fR;
@@ -1502,7 +1510,7 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
             if constexpr (GEN)
                 if (A.applied_k > 0)
                     fjs = fjs - applied_wrench_on(A, sel4(k, Tp::limb_joint[0][s], Tp::limb_joint[1][s], Tp::limb_joint[2][s], Tp::limb_joint[3][s]),
-                                                  R1, Rs[s], ps[s], B32, r32);
+                                                  R1, Rs[s], ps[s], Bg, rg);
             ms += Y.m;
             mcs = mcs + Y.m * Y.c;
             if (A.joint_forces && ix.has[s])
@@ -1546,8 +1554,8 @@ JM_DEV void quad_extra_terms(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs
         if constexpr (GEN)
             if (A.applied_k > 0)
             {
-                if constexpr (t == 0) fjT[0] = fjT[0] - applied_root_wrench(A, R1, B32, r32);
-                else fjT[t] = fjT[t] - applied_wrench_on(A, j, R1, K.X[t].R, K.X[t].p, B32, r32);
+                if constexpr (t == 0) fjT[0] = fjT[0] - applied_root_wrench(A, R1, Bg, rg);
+                else fjT[t] = fjT[t] - applied_wrench_on(A, j, R1, K.X[t].R, K.X[t].p, Bg, rg);
             }
         mT[t] += Y.m;
         mcT[t] = mcT[t] + Y.m * Y.c;

@@ -559,9 +559,12 @@ def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
 
 
 @pytest.mark.gpu
-def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device):
+@pytest.mark.parametrize("form", ["persistent", "per_stage"])
+def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device, monkeypatch, form):
     """The persistent adaptive stepper (jm_qdopri.h) keeps every robot in its lane, so per-lane body parameters and
-    applied forces work with `runge_kutta_dopri` too (`k_quad_dopri_gen`): (a) with the NOMINAL parameters bound per
+    applied forces work with `runge_kutta_dopri` too (`k_quad_dopri_gen`); the per-stage form (JIMINY_AMD_ADAPTIVE_FORM=1)
+    evaluates compact batches of the active lanes, whose per-lane optional inputs are read through the lane map of the
+    compaction (`BatchArgs::lane_map`).  Both: (a) with the NOMINAL parameters bound per
     lane it follows the plain adaptive kernel step for step; (b) an impulse force acts during [t, t + dt] exactly --
     its start and end are breakpoints of the adaptive loop -- and changes the base velocity by F dt / m; (c) biased
     masses change the motion."""
@@ -571,6 +574,7 @@ def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device):
     from jiminy_amd.randomization import nominal_model_lane
     model = load_builtin("anymal")
     B = 64
+    monkeypatch.setenv("JIMINY_AMD_ADAPTIVE_FORM", "1" if form == "per_stage" else "0")
     st = sample_states(model, B, seed=6, base_height=(2.0, 3.0), grounded_fraction=0.0)
     frame = next(n for n, f in model.frames.items() if f.parent_joint == 1)
 
@@ -605,6 +609,49 @@ def test_gpu_adaptive_stepper_with_per_lane_models_and_forces(gpu_device):
     assert int(it2.min()) >= int(it0.min())       # the two extra breakpoints cost steps
     q3, v3, *_ = run(std=0.1)
     assert not torch.equal(v3, v0)
+
+
+@pytest.mark.gpu
+def test_gpu_per_stage_adaptive_stepper_with_the_constraint_model_and_variation(gpu_device):
+    """The reference's two defaults together (`runge_kutta_dopri` + constraint contacts: per-stage launches over compact
+    batches) with per-lane friction, body parameters and a terrain patch per lane: (a) nominal parameters / the batch-wide
+    friction bound per lane / zero offsets reproduce the plain run step for step; (b) the varied inputs change the motion;
+    (c) the lanes' step counts differ, i.e. the compact batches really re-order the lanes."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.randomization import nominal_model_lane
+    model = load_builtin("anymal")
+    B = 64
+    st = sample_standing_states(model, B, seed=8)
+    rg = np.random.default_rng(8)
+    heights = 0.004 * rg.standard_normal((9, 9))
+
+    def run(vary):
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+        eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-7, "tolRel": 1e-6, "controllerUpdatePeriod": 5e-3,
+                                     "sensorsUpdatePeriod": 5e-3}, "contacts": {"model": "constraint", "friction": 0.8}})
+        eng.set_ground_heightmap(heights, -1.0, -1.0, 0.25, 0.25)
+        if vary is not None:
+            eng.set_lane_model(nominal_model_lane(model, B, torch.float64, gpu_device))
+            eng.set_lane_friction(torch.full((B,), 0.8, dtype=torch.float64) if not vary else torch.linspace(0.2, 1.4, B, dtype=torch.float64))
+            eng.set_ground_offsets(torch.zeros(B, 2, dtype=torch.float64) if not vary else torch.from_numpy(rg.uniform(-0.5, 0.5, (B, 2))))
+            if vary:
+                eng.set_model_options({"dynamics": {"massBodiesBiasStd": 0.1}})
+                eng.seed_model(3)
+        eng.set_command(torch.from_numpy(st["command"]))
+        eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+        for _ in range(3):
+            eng.step(5e-3)
+        ss = eng.stepper_state
+        assert abs(ss.t - 0.015) < 1e-12
+        return eng.field("q").clone(), eng.field("v").clone(), ss.iter_lanes.clone()
+    q0, v0, it0 = run(None)
+    q1, v1, it1 = run(False)
+    assert torch.equal(it0, it1) and float((q1 - q0).abs().max()) < 1e-9 and float((v1 - v0).abs().max()) < 1e-7
+    q2, v2, it2 = run(True)
+    assert float((v2 - v0).abs().max()) > 1e-4
+    assert int(it0.max()) > int(it0.min())
 
 
 @pytest.mark.gpu
