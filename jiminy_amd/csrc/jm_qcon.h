@@ -66,6 +66,12 @@
 #ifndef JM_QCON_PGS_WAVES
 #define JM_QCON_PGS_WAVES 2  // waves per SIMD of the split form's solve kernel (k_qcon_pgs)
 #endif
+#ifndef JM_QCON_PRE_WAVES
+#define JM_QCON_PRE_WAVES 1   // waves per SIMD of k_quad_con_split<1> / <2> (tuning)
+#endif
+#ifndef JM_QCON_POST_WAVES
+#define JM_QCON_POST_WAVES 1
+#endif
 #ifndef JM_QCON_PGS_DEPTH
 #define JM_QCON_PGS_DEPTH 4  // rows in flight per robot in k_qcon_pgs (ring of row buffers)
 #endif
@@ -2048,7 +2054,7 @@ template<class T, class Tp> JM_DEV QStore<T> qcon_split_store(T * ws, long long 
 }
 
 template<class T, class Tp, int PH>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PH == 1 ? JM_QCON_PRE_WAVES : JM_QCON_POST_WAVES)))
 k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
 {
     using Q = QLayout<Tp>;
