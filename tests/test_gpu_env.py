@@ -475,6 +475,29 @@ def test_whole_environment_step_as_one_graph_matches_the_eager_step(gpu_device):
         e.enable_graph(whole_step=True)
 
 
+def test_atlas_environment_step_graphs_with_the_split_constraint_stepping(gpu_device):
+    """The Atlas environment (constraint contacts: step launches in the pre | solve | post form, three kernels per
+    evaluation) replayed as a captured graph -- the physics chain and the whole step -- against the eager step."""
+    from jiminy_amd.envs import make_atlas_env
+    B = 64
+    envs = [make_atlas_env(B, device=gpu_device) for _ in range(3)]
+    for e in envs:
+        e.reset(seed=5)
+    envs[1].enable_graph()
+    envs[2].enable_graph(whole_step=True)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    n_act = envs[0].engine.model.nmotors
+    for i in range(4):
+        action = (0.2 * torch.randn(B, n_act, generator=g, dtype=torch.float64)).to(gpu_device)
+        outs = [e.step(action) for e in envs]
+        for o in outs[1:]:
+            for k in ("q", "v"):
+                assert torch.equal(outs[0][0]["states"]["agent"][k], o[0]["states"]["agent"][k]), (i, k)
+            assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+    assert envs[1]._graph is not None and envs[2]._graph is not None
+    assert bool(torch.isfinite(envs[0].engine.field("q")).all())
+
+
 def test_atlas_pd_environment_stands_with_the_reference_constants(gpu_device):
     """`make_atlas_env` ≙ `AtlasPDControlJiminyEnv` (gym_jiminy envs/atlas.py): 30 motors under MotorSafetyLimit -> PD
     controller -> PD adapter, Mahony filter, constraint contact model, Euler 1 ms / controller 5 ms.  With a zero action
