@@ -547,8 +547,9 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
                     or getattr(self, "_impulse_frame", None) is not None:
                 raise NotImplementedError("enable_graph needs the HIP blocks, a fixed-step solver, noiseless sensors and "
                                           "no applied forces")
-            if whole_step and (not self.auto_reset or float(self.std_ratio.get("ground", 0.0)) > 0.0):
-                raise NotImplementedError("whole-step graphs need auto_reset and no ground-friction randomisation")
+            if whole_step and (not self.auto_reset or float(self.std_ratio.get("ground", 0.0)) > 0.0 or
+                               self._ground_patch_extent is not None):
+                raise NotImplementedError("whole-step graphs need auto_reset and no ground-friction / terrain-patch randomisation")
         self._graph_enabled = bool(enable)
         self._graph_whole = bool(enable and whole_step)
         self._graph = None
