@@ -751,6 +751,16 @@ class BatchedEngine:
         if not self._user_constraints:
             self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 0))
 
+    def set_constraint_reference(self, name: str, reference: Any) -> None:
+        """≙ `JointConstraint.reference_configuration = ...` (joint_constraint.cc `setReferenceConfiguration`): where the
+        constraint holds its joint, one value per lane or one for all.  `start` / `reset_lanes` take the reference from the
+        state again (`JointConstraint::reset`): call it after them."""
+        row, _ = self._user_constraints[name]
+        ref = torch.as_tensor(reference, dtype=self.dtype, device=self.device).reshape(-1)
+        if ref.numel() not in (1, self.batch_size):
+            raise ValueError("one reference per lane (or one for all)")
+        self._fields["con_data"][row] = ref.expand(self.batch_size)
+
     @property
     def user_constraints(self) -> Dict[str, Any]:
         return {k: c for k, (_, c) in self._user_constraints.items()}

@@ -567,6 +567,34 @@ def test_gpu_user_joint_constraints(gpu_device, name, B):
 
 
 @pytest.mark.gpu
+def test_gpu_joint_constraint_follows_its_reference(gpu_device):
+    """`set_constraint_reference`: the Baumgarte-stabilised lock (20 Hz, critically damped) pulls its joint to a new
+    reference within a few periods; robots in free fall, so that nothing else acts on the joint."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, JointConstraint
+    from jiminy_amd.synthetic import sample_states
+    model = _models()["anymal"]()
+    B = 32
+    st = sample_states(model, B, seed=3, base_height=(3.0, 4.0), grounded_fraction=0.0)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": 5e-4, "controllerUpdatePeriod": 5e-3, "sensorsUpdatePeriod": 5e-3},
+                     "contacts": {"model": "constraint"}})
+    eng.add_constraint("knee", JointConstraint("LF_KFE"))
+    eng.set_command(torch.zeros(model.nmotors, B, dtype=torch.float64))
+    eng.start(torch.from_numpy(st["q"]), torch.zeros_like(torch.from_numpy(st["v"])))
+    iq = int(model.idx_q[model.joint_names.index("LF_KFE")])
+    q0 = eng.field("q")[iq].clone()
+    target = q0 + torch.linspace(-0.1, 0.1, B, dtype=torch.float64, device=gpu_device)
+    eng.set_constraint_reference("knee", target)
+    for _ in range(20):
+        eng.step(5e-3)
+    err = (eng.field("q")[iq] - target).abs()
+    assert float(err.max()) < 2e-3, float(err.max())
+    assert float((eng.field("q")[iq] - q0).abs().max()) > 0.09
+
+
+@pytest.mark.gpu
 def test_gpu_anymal_stands_still_under_the_constraint_model(gpu_device):
     """Reference acceptance for its quadrupeds / bipeds (gym_jiminy unit_py/test_pipeline_control.py:46-133):
     the robot keeps standing.  Here: ANYmal at its neutral stance with the shipped options
