@@ -243,7 +243,7 @@ def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
     split = variant == "split"
     variant = "quad" if split else variant
     model = _models()[name]()
-    B = 6 if name == "atlas" else 12
+    B = (3 if variant == "lane" else 6) if name == "atlas" else (8 if variant == "lane" else 12)   # (sized for the CPU suite)
     ref, got = _pair(model, B, seed=7)
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
     emu.run(model, got, "start", constraint_options=TIGHT, variant=variant)
@@ -312,7 +312,7 @@ def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
     64 rows take the 12-loads-per-row instantiation of `qcon_pgs_lean`)."""
     from jiminy_amd.synthetic import lowest_contact_height
     model = load_builtin("atlas")
-    B = 3
+    B = 2
     q = model.neutral()
     for name, value in {"back_bky": 0.2, "l_arm_elx": 0.2, "l_arm_shx": -np.pi / 2, "l_arm_shz": np.pi / 4, "l_arm_ely": 3 * np.pi / 4,
                         "r_arm_elx": -0.2, "r_arm_shx": np.pi / 2, "r_arm_shz": -np.pi / 4, "r_arm_ely": 3 * np.pi / 4}.items():
