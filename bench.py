@@ -146,6 +146,236 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0, solver: str =
     }
 
 
+FULL_EXTRA_OUTPUTS = ("contact_forces", "f_external", "energy", "joint_forces", "centroidal")
+
+
+class _Ctx:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: str, dt: float, steps: int, warmup: int,
+            episode: int, extra_terms: str, gather_obs: bool = False, strong: bool = False, headline: bool = False):
+    """One timed workload on this rank's GPU: `warmup` untimed steps, then exactly `steps` steps between barriers
+    (wall clock, max over ranks -> `value`) with every step launch timed by HIP events on the launch stream inside the
+    library (-> `roofline`).  Returns (JSON dict, the seeded states, the model)."""
+    import torch
+    import torch.distributed as dist
+
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.synthetic import sample_standing_states, sample_states
+
+    rank, world, device = ctx.rank, ctx.world, ctx.device
+    model = load_builtin(model_name)
+    constrained = contact_model == "constraint"
+    dname = "f64" if dtype == torch.float64 else "f32"
+    if constrained:
+        # robots standing on all their feet (lowest contact point 5-6 mm into the ground, small joint /
+        # attitude noise), 5 % of the lanes with joints beyond a position limit
+        states = sample_standing_states(model, B, seed=rank, joint_noise=0.01, base_angle_max=0.004,
+                                        depth_range=(-6e-3, -5e-3), twist_std=0.02, joint_vel_std=0.05,
+                                        command_fraction=0.1, out_of_bounds_fraction=0.05)
+    else:
+        states = sample_states(model, B, seed=rank)
+    # extra_terms = "full": every optional output of the step is bound, so that the launch runs the whole of
+    # Engine::computeExtraTerms (energies, subtree / centroidal quantities, the RNEA joint-wrench backward sweep)
+    outputs = FULL_EXTRA_OUTPUTS if extra_terms == "full" else ("contact_forces",)
+    eng = BatchedEngine(model, B, dtype=dtype, device=device, extra_outputs=outputs)
+    eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt,
+                                 "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt},
+                     "contacts": {"model": contact_model}})
+    eng.set_command(torch.from_numpy(states["command"]).to(dtype))
+    eng.start(torch.from_numpy(states["q"]).to(dtype), torch.from_numpy(states["v"]).to(dtype))
+
+    obs_rows = [eng.field(k) for k in ("imu", "force", "encoder", "effort") if eng._rows[k] > 0]
+    gather = None
+    if gather_obs and world > 1:
+        from jiminy_amd.distributed import ObservationGather
+        gather = ObservationGather()
+    q_seed = torch.from_numpy(states["q"]).to(dtype).to(device)
+    v_seed = torch.from_numpy(states["v"]).to(dtype).to(device)
+    all_lanes = torch.ones(B, dtype=torch.uint8, device=device)
+    ok_min = torch.ones((), dtype=torch.float64, device=device)   # worst valid-lane fraction (device)
+    nan_max = torch.zeros((), dtype=torch.float64, device=device)
+    oob_max = torch.zeros((), dtype=torch.float64, device=device)
+    n_done = 0
+
+    def one_step() -> None:
+        nonlocal n_done
+        eng.step(dt)
+        n_done += 1
+        if episode > 0 and n_done % episode == 0:
+            st = eng.status & ~16  # JM_LANE_SOLVER_FAILURE is not a lane failure
+            torch.minimum(ok_min, (st == 0).double().mean(), out=ok_min)
+            torch.maximum(nan_max, ((st & 1) != 0).double().mean(), out=nan_max)
+            torch.maximum(oob_max, ((st & 2) != 0).double().mean(), out=oob_max)
+            eng.reset_lanes(all_lanes, q_seed, v_seed)
+        if gather is not None:
+            # asynchronous: RCCL runs on the process group's stream behind an event of this stream; the
+            # next step's launches overlap with it (the learner would call gather.result() where it reads)
+            gather.launch(obs_rows)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier(device_ids=[ctx.local_rank])
+        torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        one_step()
+    if episode > 0:
+        # one untimed pass through the episode-boundary code (lazy torch kernels, reset launch)
+        torch.minimum(ok_min, ((eng.status & ~16) == 0).double().mean(), out=ok_min)
+        eng.reset_lanes(all_lanes, q_seed, v_seed)
+        n_done = 0
+    barrier()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    if gather is not None:
+        gather.drain()     # the timed region ends when the last gathered block has landed
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_launch, kernel_ms = eng.timing_summary()
+    eng.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    status = eng.status.cpu().numpy()
+    pgs_fail = float(((status & 16) != 0).mean())
+    active = float((eng.field("con_flags") & 1).sum(0).double().mean().item()) if constrained else None
+    status = status & ~16
+    ok_frac = min(float((status == 0).mean()), float(ok_min.item()))
+    nan_frac = max(float(((status & 1) != 0).mean()), float(nan_max.item()))
+    oob_frac = max(float(((status & 2) != 0).mean()), float(oob_max.item()))
+    # sanity of what the launch claims to compute: the full extra terms were written by the last step
+    extras_written = None
+    if extra_terms == "full":
+        ok_l = torch.from_numpy(status == 0).to(device)
+        e = eng.field("energy")[:, ok_l]
+        jf = eng.field("joint_forces")[:, ok_l]
+        extras_written = bool(ok_l.any().item() and torch.isfinite(e).all().item() and torch.isfinite(jf).all().item()
+                              and float(e[0].abs().max().item()) > 0.0 and float(jf.abs().max().item()) > 0.0)
+    del eng
+    if rank != 0:
+        return None, states, model
+
+    value = world * B * steps / elapsed
+    scal = algorithmic_scalars(model)
+    sz = 8 if dname == "f64" else 4
+    alg_bytes_per_launch = scal * sz * B
+    avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
+    from jiminy_amd.codegen import quad_structure
+    kernel_name = "jm::k_quad" if (quad_structure(model) is not None and
+                                   os.environ.get("JM_KERNEL_VARIANT") != "lane") else "jm::k_batch"
+    traffic = None
+    valu = None
+    # counters of the latest committed profile of this workload (tools/gpu_profile.sh -> profiles/)
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json" if model_name == "anymal" else f"pmc_{model_name}_latest.json")
+    if constrained:
+        # + the per-lane constraint state read and written once per step (flags int32, reference
+        # configurations + multipliers); the delassus workspace is scratch, not algorithmic traffic
+        rows = _abi_rows(model)
+        alg_bytes_per_launch += 2 * (rows["con_flags"] * 4 + rows["con_data"] * sz) * B
+        kernel_name = "jm::k_quad_con" if kernel_name == "jm::k_quad" else "jm::k_constrained"
+        from jiminy_amd.codegen import qcon_split
+        if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
+            # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
+            kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json" if model_name == "anymal" else f"pmc_{model_name}_con_latest.json")
+    achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            if pmc.get("batch") == B and pmc.get("model") == model_name and pmc.get("dtype") == dname \
+                    and pmc.get("extra_terms", "sensors") == extra_terms:
+                traffic = pmc.get("hbm_bytes_per_launch")
+                # the roof that actually binds (DESIGN.md section 4): VALU issue. Floor = every
+                # VALU instruction of the profiled build issued back to back, waves spread
+                # evenly over the 1024 SIMDs
+                ipw, waves = pmc.get("valu_insts_per_wave"), pmc.get("waves_per_launch")
+                if ipw and waves:
+                    cyc = 4 if dname == "f64" else 2
+                    floor_s = ipw * cyc * -(-int(waves) // SIMDS) / CLOCK_HZ
+                    valu = {"bound": "valu-issue", "insts_per_wave_per_launch": ipw, "waves": waves,
+                            "cycles_per_inst": cyc, "floor_ms": 1e3 * floor_s,
+                            "frac": floor_s / avg_launch_s if avg_launch_s else None,
+                            "from": pmc.get("from")}
+        except Exception:
+            traffic = None
+    what_ran = ("4 dynamics evaluations (FK + contacts + motors + ABA)" if solver == "runge_kutta_4" else
+                "1 dynamics evaluation (FK + contacts + motors + " + ("CRBA-free constrained ABA + PGS" if constrained else "ABA") + ")")
+    extras_txt = ("full computeExtraTerms (energies, centroidal momentum and its derivative, RNEA joint wrenches, "
+                  "fExternal, contact forces) + sensors" if extra_terms == "full"
+                  else "sensor-level extra terms only (no energy / centroidal / joint-wrench sweep) + sensors")
+    out = {
+        "metric": ("env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak"
+                   if model_name == "anymal" and not constrained
+                   else f"env-steps/s (whole node) {model_name} batch {B}"
+                        + (" constraint contact model" if constrained else "")),
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "n_ranks_rccl": ctx.n_ranks,
+        "dtype": dname, "data": "synthetic",
+        "config": {"workload": f"{model_name} nq{model.nq} nv{model.nv} {model.nmotors} motors "
+                               f"{model.ncontacts} {'constraint (PGS)' if constrained else 'spring-damper'} contact points, "
+                               f"{solver} dt={dt} command held: {what_ran}, then {extras_txt}",
+                   "extra_terms": extra_terms, "extra_terms_written": extras_written,
+                   "lanes_per_gpu": B, "global_batch": world * B,
+                   "parallelism": f"batch-sharded x{world}, no data-path collective"
+                                  + (" + async obs all-gather (RCCL)" if gather is not None else ""),
+                   "episode_steps": episode,
+                   "lanes_ok_min": ok_frac, "lanes_nan_max": nan_frac,
+                   "lanes_out_of_joint_bounds_max": oob_frac,
+                   **({"mean_active_constraints": active, "lanes_pgs_iteration_cap_last_eval": pgs_fail}
+                      if constrained else {})},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": kernel_name, "launches_timed": n_launch,
+                     "avg_launch_ms": 1e3 * avg_launch_s,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                     "secondary": valu},
+    }
+    if not headline:
+        # compact form of a secondary workload
+        out = {"workload": out["config"]["workload"], "model": model_name, "batch": B, "solver": solver, "dt": dt,
+               "contact_model": contact_model, "extra_terms": extra_terms, "value": value, "unit": "env-steps/s",
+               "steps": steps, "warmup": warmup, "ms_per_step": out["ms_per_step"],
+               "ms_per_launch": 1e3 * avg_launch_s, "launches_timed": n_launch, "kernel": kernel_name,
+               "algorithmic_bytes_per_launch": alg_bytes_per_launch, "achieved_GBps": achieved,
+               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue": valu,
+               "lanes_ok_min": ok_frac, "extra_terms_written": extras_written,
+               **({"mean_active_constraints": active, "lanes_pgs_iteration_cap_last_eval": pgs_fail} if constrained else {})}
+    return out, states, model
+
+
+# secondary workloads of the driver-run line (N = 1): the reference's SHIPPED configuration (anymal_options.toml:5,24 /
+# atlas_options.toml: euler_explicit + contacts.model = "constraint") and BASELINE.json configs[3]'s robot
+SECONDARY = (
+    dict(model_name="anymal", B=65536, solver="euler_explicit", contact_model="constraint", dt=1e-3, steps=20, warmup=3),
+    dict(model_name="atlas", B=32768, solver="runge_kutta_4", contact_model="spring_damper", dt=2.5e-4, steps=20, warmup=3),
+    dict(model_name="atlas", B=32768, solver="euler_explicit", contact_model="constraint", dt=5e-4, steps=8, warmup=2),
+)
+
+
+def secondary_workloads(ctx, args):
+    import torch
+    res = []
+    for cfg in SECONDARY:
+        try:
+            out, _, _ = measure(ctx, dtype=torch.float64, episode=args.episode, extra_terms=args.extra_terms, **cfg)
+            res.append(out)
+        except Exception as e:  # a secondary workload must never take the headline down with it
+            res.append({"workload": f"{cfg['model_name']} {cfg['contact_model']} {cfg['solver']}", "error": repr(e)[:300]})
+        torch.cuda.empty_cache()
+    return res
+
+
+
 def dry_run(args, rank: int, world: int) -> None:
     """The N > 1 control path without a GPU: rendezvous, barrier, the asynchronous observation gather and
     the max-over-ranks timing on CPU tensors over gloo; prints the same JSON shape with `value` null."""
@@ -222,6 +452,14 @@ def main() -> None:
                          "the bench re-seeds like the vectorised env's auto-reset does, inside the timed "
                          "region, and reports the worst fraction of valid lanes seen before a reset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-terms", default="full", choices=["full", "sensors"],
+                    help="'full' (default): energy, joint wrenches (the RNEA backward sweep), centroidal quantities, "
+                         "fExternal and the contact forces are bound, so every launch runs the whole of "
+                         "Engine::computeExtraTerms (engine.cc:800-905) like the reference does after every step; "
+                         "'sensors': only what the sensors need (the round-3 headline)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (ANYmal euler + constraint model, Atlas spring-damper, "
+                         "Atlas constraint model) appended as `secondary` to the JSON line at N = 1")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_spawn_ranks(args.gpus))
@@ -257,7 +495,6 @@ def main() -> None:
         if n_ranks != args.gpus:
             raise SystemExit(f"process group has {n_ranks} ranks, --gpus {args.gpus} requested")
 
-    model = load_builtin(args.model)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     if args.strong:
         from jiminy_amd.distributed import shard_range
@@ -267,157 +504,14 @@ def main() -> None:
         B = hi - lo
     else:
         B = args.batch
-    if constrained:
-        # robots standing on all their feet (lowest contact point 5-6 mm into the ground, small joint /
-        # attitude noise), 5 % of the lanes with joints beyond a position limit
-        states = sample_standing_states(model, B, seed=rank, joint_noise=0.01, base_angle_max=0.004,
-                                        depth_range=(-6e-3, -5e-3), twist_std=0.02, joint_vel_std=0.05,
-                                        command_fraction=0.1, out_of_bounds_fraction=0.05)
-    else:
-        states = sample_states(model, B, seed=rank)
-    eng = BatchedEngine(model, B, dtype=dtype, device=device, extra_outputs=("contact_forces",))
-    eng.set_options({"stepper": {"odeSolver": args.solver, "dtMax": args.dt,
-                                 "controllerUpdatePeriod": args.dt, "sensorsUpdatePeriod": args.dt},
-                     "contacts": {"model": args.contact_model}})
-    eng.set_command(torch.from_numpy(states["command"]).to(dtype))
-    eng.start(torch.from_numpy(states["q"]).to(dtype), torch.from_numpy(states["v"]).to(dtype))
-
-    obs_rows = [eng.field(k) for k in ("imu", "force", "encoder", "effort") if eng._rows[k] > 0]
-    gather = None
-    if args.gather_obs and world > 1:
-        from jiminy_amd.distributed import ObservationGather
-        gather = ObservationGather()
-    q_seed = torch.from_numpy(states["q"]).to(dtype).to(device)
-    v_seed = torch.from_numpy(states["v"]).to(dtype).to(device)
-    all_lanes = torch.ones(B, dtype=torch.uint8, device=device)
-    ok_min = torch.ones((), dtype=torch.float64, device=device)   # worst valid-lane fraction (device)
-    nan_max = torch.zeros((), dtype=torch.float64, device=device)
-    oob_max = torch.zeros((), dtype=torch.float64, device=device)
-    n_done = 0
-
-    def one_step() -> None:
-        nonlocal n_done
-        eng.step(args.dt)
-        n_done += 1
-        if args.episode > 0 and n_done % args.episode == 0:
-            st = eng.status & ~16  # JM_LANE_SOLVER_FAILURE is not a lane failure
-            torch.minimum(ok_min, (st == 0).double().mean(), out=ok_min)
-            torch.maximum(nan_max, ((st & 1) != 0).double().mean(), out=nan_max)
-            torch.maximum(oob_max, ((st & 2) != 0).double().mean(), out=oob_max)
-            eng.reset_lanes(all_lanes, q_seed, v_seed)
-        if gather is not None:
-            # asynchronous: RCCL runs on the process group's stream behind an event of this stream; the
-            # next step's launches overlap with it (the learner would call gather.result() where it reads)
-            gather.launch(obs_rows)
-
-    def barrier() -> None:
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        one_step()
-    if args.episode > 0:
-        # one untimed pass through the episode-boundary code (lazy torch kernels, reset launch)
-        torch.minimum(ok_min, ((eng.status & ~16) == 0).double().mean(), out=ok_min)
-        eng.reset_lanes(all_lanes, q_seed, v_seed)
-        n_done = 0
-    barrier()
-    eng.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    if gather is not None:
-        gather.drain()     # the timed region ends when the last gathered block has landed
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = eng.timing_summary()
-    eng.enable_timing(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    status = eng.status.cpu().numpy()
-    pgs_fail = float(((status & 16) != 0).mean())
-    active = float((eng.field("con_flags") & 1).sum(0).double().mean().item()) if constrained else None
-    status = status & ~16
-    ok_frac = min(float((status == 0).mean()), float(ok_min.item()))
-    nan_frac = max(float(((status & 1) != 0).mean()), float(nan_max.item()))
-    oob_frac = max(float(((status & 2) != 0).mean()), float(oob_max.item()))
-
+    ctx = _Ctx(rank=rank, world=world, local_rank=local_rank, device=device, n_ranks=n_ranks)
+    out, states, model = measure(ctx, model_name=args.model, B=B, dtype=dtype, solver=args.solver,
+                                 contact_model=args.contact_model, dt=args.dt, steps=args.steps, warmup=args.warmup,
+                                 episode=args.episode, extra_terms=args.extra_terms, gather_obs=args.gather_obs,
+                                 strong=args.strong, headline=True)
     if rank == 0:
-        value = world * B * args.steps / elapsed
-        scal = algorithmic_scalars(model)
-        sz = 8 if args.dtype == "f64" else 4
-        alg_bytes_per_launch = scal * sz * B
-        avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
-        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-        from jiminy_amd.codegen import quad_structure
-        kernel_name = "jm::k_quad" if (quad_structure(model) is not None and
-                                       os.environ.get("JM_KERNEL_VARIANT") != "lane") else "jm::k_batch"
-        traffic = None
-        valu = None
-        # counters of the latest committed profile of this workload (tools/gpu_profile.sh -> profiles/)
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.model == "anymal" else f"pmc_{args.model}_latest.json")
-        if constrained:
-            # + the per-lane constraint state read and written once per step (flags int32, reference
-            # configurations + multipliers); the delassus workspace is scratch, not algorithmic traffic
-            rows = _abi_rows(model)
-            alg_bytes_per_launch += 2 * (rows["con_flags"] * 4 + rows["con_data"] * sz) * B
-            achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-            kernel_name = "jm::k_quad_con" if kernel_name == "jm::k_quad" else "jm::k_constrained"
-            from jiminy_amd.codegen import qcon_split
-            if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
-                # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
-                kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json" if args.model == "anymal" else f"pmc_{args.model}_con_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    pmc = json.load(f)
-                if pmc.get("batch") == B and pmc.get("model") == args.model and pmc.get("dtype") == args.dtype:
-                    traffic = pmc.get("hbm_bytes_per_launch")
-                    # the roof that actually binds: VALU issue. Floor = every
-                    # VALU instruction of the profiled build issued back to back, waves spread
-                    # evenly over the 1024 SIMDs
-                    ipw, waves = pmc.get("valu_insts_per_wave"), pmc.get("waves_per_launch")
-                    if ipw and waves:
-                        cyc = 4 if args.dtype == "f64" else 2
-                        floor_s = ipw * cyc * -(-int(waves) // SIMDS) / CLOCK_HZ
-                        valu = {"bound": "valu-issue", "insts_per_wave_per_launch": ipw, "waves": waves,
-                                "cycles_per_inst": cyc, "floor_ms": 1e3 * floor_s,
-                                "frac": floor_s / avg_launch_s if avg_launch_s else None,
-                                "from": pmc.get("from")}
-            except Exception:
-                traffic = None
-        out = {
-            "metric": ("env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak"
-                       if args.model == "anymal" and not constrained
-                       else f"env-steps/s (whole node) {args.model} batch {B}"
-                            + (" constraint contact model" if constrained else "")),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "n_ranks_rccl": n_ranks,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} nq{model.nq} nv{model.nv} {model.nmotors} motors "
-                                   f"{model.ncontacts} {'constraint (PGS)' if constrained else 'spring-damper'} contact points, "
-                                   f"{args.solver} dt={args.dt} command held, extra terms + sensors",
-                       "lanes_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective"
-                                      + (" + async obs all-gather (RCCL)" if gather is not None else ""),
-                       "episode_steps": args.episode,
-                       "lanes_ok_min": ok_frac, "lanes_nan_max": nan_frac,
-                       "lanes_out_of_joint_bounds_max": oob_frac,
-                       **({"mean_active_constraints": active, "lanes_pgs_iteration_cap_last_eval": pgs_fail}
-                          if constrained else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": kernel_name, "launches_timed": n_launch,
-                         "avg_launch_ms": 1e3 * avg_launch_s,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "secondary": valu},
-        }
+        if world == 1 and not args.no_secondary and args.model == "anymal" and not constrained and args.dtype == "f64":
+            out["secondary"] = secondary_workloads(ctx, args)
         if world == 1 and not args.no_cpu_baseline and args.model == "anymal":
             out["cpu_baseline"] = cpu_baseline(model, states, args.dt, solver=args.solver,
                                                constraint_options={} if constrained else None)

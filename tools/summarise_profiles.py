@@ -121,11 +121,12 @@ def main():
         summary["bench_line"] = b
         summary["model"], summary["batch"], summary["dtype"] = (
             b["config"]["workload"].split()[0], b["config"]["lanes_per_gpu"], b["dtype"])
+        summary["extra_terms"] = b["config"].get("extra_terms", "sensors")
     except Exception as e:  # noqa: BLE001
         summary["bench_line"] = f"unavailable: {e}"
     with open(os.path.join(out_dir, f"{name}_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    latest = {k: summary.get(k) for k in ("model", "batch", "dtype", "hbm_bytes_per_launch",
+    latest = {k: summary.get(k) for k in ("model", "batch", "dtype", "extra_terms", "hbm_bytes_per_launch",
                                           "hbm_bytes_per_launch_uncorrected", "dominant_kernel", "source")}
     latest["valu_insts_per_wave"] = summary.get("SQ_INSTS_VALU_per_wave")
     latest["waves_per_launch"] = c.get("SQ_WAVES")
