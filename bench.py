@@ -146,7 +146,7 @@ def cpu_baseline(model, states, dt: float, budget_s: float = 12.0, solver: str =
     }
 
 
-FULL_EXTRA_OUTPUTS = ("contact_forces", "f_external", "energy", "joint_forces", "centroidal")
+FULL_EXTRA_OUTPUTS = ("contact_forces", "energy", "joint_forces", "centroidal")
 
 
 class _Ctx:
@@ -192,7 +192,8 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
     gather = None
     if gather_obs and world > 1:
         from jiminy_amd.distributed import ObservationGather
-        gather = ObservationGather()
+        gather = ObservationGather(dtype=torch.float32 if ctx.gather_dtype == "f32" else None, every=ctx.gather_every)
+    gather_wait_s = 0.0
     q_seed = torch.from_numpy(states["q"]).to(dtype).to(device)
     v_seed = torch.from_numpy(states["v"]).to(dtype).to(device)
     all_lanes = torch.ones(B, dtype=torch.uint8, device=device)
@@ -234,7 +235,13 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
     for _ in range(steps):
         one_step()
     if gather is not None:
-        gather.drain()     # the timed region ends when the last gathered block has landed
+        # the timed region ends when the last gathered block has landed; how long that takes once the physics is done
+        # is the part of the collectives the stepping did not hide (reported separately as `gather.exposed_ms`)
+        torch.cuda.synchronize(device)
+        tg = time.perf_counter()
+        gather.drain()
+        torch.cuda.synchronize(device)
+        gather_wait_s = time.perf_counter() - tg
     barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = eng.timing_summary()
@@ -308,8 +315,8 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
             traffic = None
     what_ran = ("4 dynamics evaluations (FK + contacts + motors + ABA)" if solver == "runge_kutta_4" else
                 "1 dynamics evaluation (FK + contacts + motors + " + ("CRBA-free constrained ABA + PGS" if constrained else "ABA") + ")")
-    extras_txt = ("full computeExtraTerms (energies, centroidal momentum and its derivative, RNEA joint wrenches, "
-                  "fExternal, contact forces) + sensors" if extra_terms == "full"
+    extras_txt = ("full computeExtraTerms (energies, subtree masses / centroidal momentum and its derivative, RNEA joint "
+                  "wrenches; + contact forces) + sensors" if extra_terms == "full"
                   else "sensor-level extra terms only (no energy / centroidal / joint-wrench sweep) + sensors")
     out = {
         "metric": ("env-steps/s (whole node) ANYmal 18-DoF batch 65536; achieved HBM GB/s vs peak"
@@ -340,6 +347,12 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "secondary": valu},
     }
+    if gather is not None:
+        out["gather"] = {"dtype": ctx.gather_dtype, "every": ctx.gather_every, "collectives": gather.launched,
+                         "bytes_per_rank_per_collective": gather.bytes_per_rank,
+                         "exposed_ms": 1e3 * gather_wait_s,
+                         "note": "asynchronous all-gather on RCCL's stream, overlapped with the next steps; exposed_ms = "
+                                 "wait for the collectives still in flight when the last step has finished"}
     if not headline:
         # compact form of a secondary workload
         out = {"workload": out["config"]["workload"], "model": model_name, "batch": B, "solver": solver, "dt": dt,
@@ -394,7 +407,8 @@ def dry_run(args, rank: int, world: int) -> None:
     B = (shard_range(args.batch, rank, world)[1] - shard_range(args.batch, rank, world)[0]) if args.strong else args.batch
     B = min(B, 512)
     rows = [torch.full((6, B), float(rank), dtype=torch.float64), torch.full((2 * model.nmotors, B), float(rank), dtype=torch.float64)]
-    gather = ObservationGather() if (args.gather_obs and world > 1) else None
+    gather = ObservationGather(dtype=torch.float32 if args.gather_dtype == "f32" else None,
+                               every=args.gather_every) if (args.gather_obs and world > 1) else None
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -439,6 +453,10 @@ def main() -> None:
     ap.add_argument("--gather-obs", action="store_true",
                     help="all-gather the observation block over RCCL every step (config 4 topology); asynchronous, "
                          "overlapped with the next step")
+    ap.add_argument("--gather-dtype", default="f64", choices=["f64", "f32"],
+                    help="type of the packed observation block of --gather-obs (f32 halves the bytes over xGMI)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="--gather-obs: gather only every k-th step (a learner acting every k physics steps)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, sharded over the ranks (config 4: "
                          "--model atlas --batch 32768 --strong --gather-obs)")
@@ -504,7 +522,8 @@ def main() -> None:
         B = hi - lo
     else:
         B = args.batch
-    ctx = _Ctx(rank=rank, world=world, local_rank=local_rank, device=device, n_ranks=n_ranks)
+    ctx = _Ctx(rank=rank, world=world, local_rank=local_rank, device=device, n_ranks=n_ranks,
+               gather_dtype=args.gather_dtype, gather_every=args.gather_every)
     out, states, model = measure(ctx, model_name=args.model, B=B, dtype=dtype, solver=args.solver,
                                  contact_model=args.contact_model, dt=args.dt, steps=args.steps, warmup=args.warmup,
                                  episode=args.episode, extra_terms=args.extra_terms, gather_obs=args.gather_obs,

@@ -422,7 +422,9 @@ template<class T> int32_t step_adaptive(jm_batch * b, double t_next, const jm_ad
     {
         if (b->variant == VARIANT_QUAD && !constrained && o->form != 1)
         {
-            const bool gen = b->field[JM_F_MODEL_LANE] || b->ground_h || (b->applied_k > 0 && b->field[JM_F_APPLIED]);
+            // (per-lane friction alone also needs the variation kernel: only its contact law reads A.friction)
+            const bool gen = b->field[JM_F_MODEL_LANE] || b->ground_h || (b->applied_k > 0 && b->field[JM_F_APPLIED]) ||
+                             b->field[JM_F_FRICTION];
             auto A = make_args<T>(b);
             A.mode = jm::MODE_DYNAMICS;
             constexpr int nth = 64 * jm::qdopri_block_waves<T, Topo>();

@@ -837,7 +837,12 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     (void)limb_joint_of;
     trunk_fk_store<T, Tp, X, MA>(P, k, ix, qb, vb_, TS, Xatt, vatt, status, ma);
     // ---- limb kinematics (long limbs: cos / sin per joint + the tip placement only, see limb_fk_tip)
+#ifdef JM_OUTPUT_KEEP_KIN
     constexpr bool UNWIND = QRows<Tp>::LONG;
+#else
+    // (the output pass always takes the register-lean form: its sweep carries the momentum / wrench accumulators instead)
+    constexpr bool UNWIND = QRows<Tp>::LONG || !DYN;
+#endif
     constexpr bool REWIND = UNWIND;   // ... and the forward sweep re-derives joint origins / axes (limb_rewind)
     M3<T> Rs[UNWIND ? 1 : N];
     V3<T> ps[N];
@@ -1058,33 +1063,8 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             constexpr int o = s * Q::QJ;
             if constexpr (!UNWIND) { Rcur = Rs[s]; pcur = ps[s]; }
             else if constexpr (!REWIND) ps[s] = pcur;
-            if constexpr (!DYN)
-            {
-                // output pass: the energy sums and RobotState::fExternal of joints that carry an applied wrench need the
-                // bodies (velocities / placements unwound from the tip like below)
-                bool applied_out = false;
-                if constexpr (GEN && EMIT) applied_out = A.applied_k > 0 && A.f_external;
-                if constexpr (GEN && EMIT)
-                    if (applied_out && ix.has[s])
-                        add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc),
-                             wrench_to_joint(Rcur, pcur, applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, Bg, rg)));
-                if (applied_out && !want_energy)
-                {
-                    if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
-                }
-                if (want_energy)
-                {
-                    const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
-                    const V3<T> a = limb_axis_root<T, Tp, s>(LT, Rcur);
-                    kin += rbi_vtiv(Y, vcur);
-                    mc = mc + Y.m * Y.c;
-                    msum += Y.m;
-                    rot += LT(o + Q::J_ROTOR) * vlq(s) * vlq(s);
-                    vcur = vcur - vlq(s) * Sp<T>{cross(pcur, a), a};
-                    if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
-                }
-                return;
-            }
+            // (output pass: the bodies are walked once, by the output sweep after the accelerations -- see below)
+            if constexpr (!DYN) return;
             const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
             const V3<T> a = limb_axis_root<T, Tp, s>(LT, Rcur);
             const Sp<T> S = {cross(pcur, a), a};
@@ -1145,6 +1125,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             }
         }
     });
+    if constexpr (DYN)
     if (want_energy)
     {
         kin = X::quad_sum(kin); rot = X::quad_sum(rot); msum = X::quad_sum(msum);
@@ -1157,25 +1138,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
         constexpr int j = Tp::trunk_joint[t], tp = Tp::trunk_parent[t];
         SE3<T> Xt;
         Sp<T> vt;
-        if constexpr (!DYN)
-        {
-            if constexpr (GEN && EMIT)
-                if (A.applied_k > 0 && A.f_external)
-                {
-                    TS.template get_kin<t, X>(Xt, vt);
-                    if (lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, applied_wrench_on(A, j, R1, Xt.R, Xt.p, Bg, rg)));
-                }
-            if (want_energy)
-            {
-                TS.template get_kin<t, X>(Xt, vt);
-                const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12)));
-                kin += rbi_vtiv(Y, vt);
-                mc = mc + Y.m * Y.c;
-                msum += Y.m;
-                rot += P[L::ROTOR + Tp::idx_v[j]] * vbq(5 + t) * vbq(5 + t);
-            }
-            return;
-        }
+        if constexpr (!DYN) return;
         TS.template get_kin<t, X>(Xt, vt);
         const RBI<T> Y = rbi_placed(Xt.R, Xt.p, ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12)));
         const Sp<T> S = trunk_S_at<T, Tp, t>(P, Xt);
@@ -1249,6 +1212,7 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             keep->Rt = Rtip; keep->vtip = vtip; keep->R1 = R1; keep->p1 = p1g; keep->agf1 = agf1;
         }
     }
+    if constexpr (DYN)
     if (want_energy)
     {
         // Engine::computeExtraTerms energies (engine.cc:806-815, overload .h:54-55)
@@ -1295,12 +1259,11 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
     Sp<T> vp = v1r;
     M3<T> Rw = ident3<T>();
     V3<T> pw = zero3<T>();
+    // accelerations of trunk joints with a non-adjacent, non-root parent are re-fetched from
+    // the store; chains (the common case) carry them in `aprev`
+    Sp<T> atst[TrunkStore<T, Tp>::SLOTS];
     {
-        // accelerations of trunk joints with a non-adjacent, non-root parent are re-fetched from
-        // the store; chains (the common case) carry them in `aprev`
-        Sp<T> atst[TrunkStore<T, Tp>::SLOTS];
         Sp<T> aprev = at0;
-        if constexpr (DYN || Tp::NIMU > 0)
         static_for<1, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int tp = Tp::trunk_parent[t];
@@ -1360,6 +1323,168 @@ JM_DEV void quad_eval(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A
             vp = vp + vj;
         }
     });
+    // ---- output pass: Engine::computeExtraTerms (engine.cc:800-905) in ONE walk over the bodies, tip -> root, at the
+    // committed state with the accelerations of the last evaluation: energies (:806-815, overload .h:54-55), body momenta
+    // and net body forces (:870-877), the RNEA joint wrenches data.f (:878-887: gravity field included, external forces
+    // removed), subtree masses / first moments (:817-832) and the centroidal momentum and its derivative (:900-904);
+    // RobotState::fExternal of the joints that carry an applied wrench.  Root coordinates: body quantities add up along
+    // the tree, a joint's wrench is rotated into its own frame where it is stored.  Only the running velocity and TRUE
+    // spatial acceleration are carried: they are wound up to the tip first and unwound joint by joint on the way back
+    // (v_{s-1} = v_s - S qd, a_{s-1} = a_s - v_{s-1} x S qd - S qdd), so that nothing per joint stays live.
+    if constexpr (!DYN && EMIT)
+    {
+        bool applied_out = false;
+        if constexpr (GEN) applied_out = A.applied_k > 0 && A.f_external;
+        const bool want_rnea = A.joint_forces || A.centroidal;
+        if (want_energy || want_rnea || applied_out)
+        {
+            // Accelerations are carried WITH the gravity field (a_gf = a + agf1, one constant spatial vector for every body
+            // in root coordinates): data.f needs Y a_gf.  The net body forces, which only enter the centroidal derivative
+            // as their total, follow from  sum_bodies (Y a + v x* h) = f_root + sum f_ext - sum_bodies Y agf1,  and the
+            // last sum is (m_tot agf1.l, mc_tot x agf1.l) unless the gravity has an angular part (uniform test).
+            const bool has_gw = gw.x != T(0) || gw.y != T(0) || gw.z != T(0);
+            // limb: wind the acceleration up to the tip
+            Sp<T> acur = ap;
+            {
+                Sp<T> vrun = vp;
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    V3<T> a_s, p_s;
+                    if constexpr (REWIND)
+                    {
+                        limb_rewind<T, Tp, s, MA>(LT, cq[s], sq[s], Rw, pw, a_s, ma, k);
+                        p_s = pw;
+                    }
+                    else { a_s = limb_axis_root<T, Tp, s>(LT, Rs[s]); p_s = ps[s]; }
+                    const Sp<T> S = {cross(p_s, a_s), a_s};
+                    const Sp<T> vj = vlq(s) * S;
+                    acur = acur + cross_mm(vrun, vj) + ddq[s] * S;
+                    vrun = vrun + vj;
+                });
+            }
+            // per lane: momentum, joint wrench (external forces removed), what was removed, gravity term (has_gw only)
+            Sp<T> hs = zero6<T>(), fjs = zero6<T>(), fxs = fext, Gs = zero6<T>();
+            T ms = T(0), ekin = T(0), erot = T(0);
+            V3<T> mcs = zero3<T>();
+            {
+                Sp<T> vcur = vtip;
+                M3<T> Rcur = Rtip;
+                V3<T> pcur = ptip;
+                static_rfor<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    constexpr int o = s * Q::QJ;
+                    if constexpr (!UNWIND) { Rcur = Rs[s]; pcur = ps[s]; }
+                    const RBI<T> Y = rbi_placed(Rcur, pcur, ma.rbi(GEN ? limb_joint_of(sc) : 0, LT.rbi(o + Q::J_RBI)));
+                    const V3<T> a = limb_axis_root<T, Tp, s>(LT, Rcur);
+                    const Sp<T> S = {cross(pcur, a), a};
+                    const Sp<T> h = rbi_mul(Y, vcur);
+                    hs = hs + h;
+                    fjs = fjs + cross_mf(vcur, h) + rbi_mul(Y, acur);
+                    if (has_gw) Gs = Gs + rbi_mul(Y, agf1);
+                    if constexpr (s == N - 1) fjs = fjs - fext;
+                    if constexpr (GEN)
+                        if (A.applied_k > 0)
+                        {
+                            const Sp<T> w = applied_wrench_on(A, limb_joint_of(sc), R1, Rcur, pcur, Bg, rg);
+                            fjs = fjs - w;
+                            fxs = fxs + w;
+                            if (applied_out && ix.has[s]) add6(A.f_external, B32, r32, 6u * (unsigned)limb_joint_of(sc), wrench_to_joint(Rcur, pcur, w));
+                        }
+                    ms += Y.m;
+                    mcs = mcs + Y.m * Y.c;
+                    ekin += dot6(vcur, h);
+                    erot += LT(o + Q::J_ROTOR) * vlq(s) * vlq(s);
+                    if (A.joint_forces && ix.has[s])
+                        put6(A.joint_forces, B32, r32, 6 * (unsigned)limb_joint_of(sc), actinv_force(SE3<T>{Rcur, pcur}, fjs));
+                    const Sp<T> vj = vlq(s) * S;
+                    vcur = vcur - vj;
+                    acur = acur - cross_mm(vcur, vj) - ddq[s] * S;
+                    if constexpr (UNWIND && s > 0) limb_unwind<T, Tp, s, MA>(LT, cq[s], sq[s], Rcur, pcur, ma, k);
+                });
+            }
+            // totals over the bodies (plain sums: one coordinate frame); only the joint wrenches follow the tree
+            Sp<T> htot = quad_sum6<T, X>(hs), fxtot = quad_sum6<T, X>(fxs), Gtot = zero6<T>();
+            if (has_gw) Gtot = quad_sum6<T, X>(Gs);
+            T mtot = X::quad_sum(ms);
+            V3<T> mctot = {X::quad_sum(mcs.x), X::quad_sum(mcs.y), X::quad_sum(mcs.z)};
+            ekin = X::quad_sum(ekin); erot = X::quad_sum(erot);
+            Sp<T> fjT[NT];
+            static_for<0, NT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (I::limb_at(t))
+                {
+                    if constexpr (I::uniform_attach) fjT[t] = quad_sum6<T, X>(fjs);
+                    else fjT[t] = quad_sum6<T, X>(mask6(ix.attach == t, fjs));
+                }
+                else fjT[t] = zero6<T>();
+            });
+            static_rfor<0, NT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int j = Tp::trunk_joint[t];
+                SE3<T> Xt = {ident3<T>(), zero3<T>()};
+                Sp<T> vt = v1r, att = at0;
+                RBI<T> Y = ma.rbi(j, ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+                if constexpr (t > 0)
+                {
+                    TS.template get_kin<t, X>(Xt, vt);
+                    att = qbcast<T, X, TrunkStore<T, Tp>::template lane<t>()>(atst[TrunkStore<T, Tp>::template slot<t>()]);
+                    Y = rbi_placed(Xt.R, Xt.p, Y);
+                }
+                const Sp<T> h = rbi_mul(Y, vt);
+                htot = htot + h;
+                fjT[t] = fjT[t] + cross_mf(vt, h) + rbi_mul(Y, att);
+                if (has_gw) Gtot = Gtot + rbi_mul(Y, agf1);
+                if constexpr (GEN)
+                    if (A.applied_k > 0)
+                    {
+                        Sp<T> w;
+                        if constexpr (t == 0) w = applied_root_wrench(A, R1, Bg, rg);
+                        else
+                        {
+                            w = applied_wrench_on(A, j, R1, Xt.R, Xt.p, Bg, rg);
+                            if (applied_out && lead) put6(A.f_external, B32, r32, 6 * j, wrench_to_joint(Xt.R, Xt.p, w));
+                        }
+                        fjT[t] = fjT[t] - w;
+                        fxtot = fxtot + w;
+                    }
+                mtot += Y.m;
+                mctot = mctot + Y.m * Y.c;
+                ekin += dot6(vt, h);
+                if constexpr (t > 0) erot += P[L::ROTOR + Tp::idx_v[j]] * vbq(5 + t) * vbq(5 + t);
+                if (A.joint_forces && lead)
+                {
+                    if constexpr (t > 0) put6(A.joint_forces, B32, r32, 6 * j, actinv_force(Xt, fjT[t]));
+                    else put6(A.joint_forces, B32, r32, 6 * j, fjT[t]);
+                }
+                if constexpr (t > 0) fjT[Tp::trunk_parent[t]] = fjT[Tp::trunk_parent[t]] + fjT[t];
+            });
+            if (lead)
+            {
+                if (A.joint_forces) put6(A.joint_forces, B32, r32, 0, zero6<T>());
+                if (want_energy)
+                {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) erot += P[L::ROTOR + Tp::idx_v[1] + i] * vb_[i] * vb_[i];
+                    A.energy[r32] = T(0.5) * ekin + T(0.5) * erot;
+                    A.energy[B32 + r32] = -(dot(R1 * mctot, g) + mtot * dot(p1, g));
+                }
+                if (A.centroidal)
+                {
+                    if (!has_gw) Gtot = {mtot * agf1.l, cross(mctot, agf1.l)};
+                    const Sp<T> fBtot = fjT[0] + fxtot - Gtot;
+                    const SE3<T> M1 = {R1, p1};
+                    const V3<T> c1 = rcp_(mtot) * mctot;
+                    const V3<T> com0 = R1 * c1 + p1;
+                    Sp<T> hg = act_force(M1, htot), dhg = act_force(M1, fBtot);
+                    hg.a = hg.a + cross(hg.l, com0);
+                    dhg.a = dhg.a + cross(dhg.l, com0);
+                    A.centroidal[r32] = com0.x; A.centroidal[B32 + r32] = com0.y; A.centroidal[2 * B32 + r32] = com0.z;
+                    put6(A.centroidal, B32, r32, 3, hg);
+                    put6(A.centroidal, B32, r32, 9, dhg);
+                }
+            }
+        }
+    }
     if constexpr (KEEP::ON)
     {
         keep->atip = ap;
@@ -1939,6 +2064,8 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         {
             const int stq = X::quad_or(status);
             if (A.status && lead) A.status[rr] = (A.mode == MODE_REFRESH) ? (A.status[rr] | stq) : stq;
+            // (spring-damper kernels: the output pass above has written the extra terms already)
+            if constexpr (QCON)
             if (A.joint_forces || A.centroidal)
             {
                 // the (committed) state sits in the stage buffer
@@ -1946,15 +2073,11 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                 static_for<0, NQB>([&](auto ic) { qb[decltype(ic)::value] = S.getb(R::Q0B + decltype(ic)::value); });
                 static_for<0, NVB>([&](auto ic) { vb[decltype(ic)::value] = S.getb(R::V0B + decltype(ic)::value); });
                 static_for<0, N>([&](auto sc) { ql[decltype(sc)::value] = S.getl(R::Q0L + decltype(sc)::value); vl[decltype(sc)::value] = S.getl(R::V0L + decltype(sc)::value); });
-                if constexpr (QCON)
-                {
-                    QExtra<T, Tp> ex;
-                    ex.flags = C->flags;
-                    ex.nb = qcon_first_contact_row<Tp>();
-                    ex.lam = C->data + (size_t)qcon_first_lambda_row<Tp>() * B32;
-                    quad_extra_terms<T, Tp, X, 2, GEN>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq, &ex);
-                }
-                else quad_extra_terms<T, Tp, X, 0, GEN>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq);
+                QExtra<T, Tp> ex;
+                ex.flags = C->flags;
+                ex.nb = qcon_first_contact_row<Tp>();
+                ex.lam = C->data + (size_t)qcon_first_lambda_row<Tp>() * B32;
+                quad_extra_terms<T, Tp, X, 2, GEN>(P, LT, A, rr, k, ix, qb, vb, ql, vl, ddqb, ddq, &ex);
             }
         }
     }

@@ -117,26 +117,56 @@ def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[s
     return [(tn, c, s) for tn, _, c, s in intervals], t_end, t_err
 
 
+def substep_sizes(dt_next: float, dt_max: float) -> List[float]:
+    """Integrator step sizes of a fixed-step solver over one breakpoint interval of length `dt_next`: the inner loop
+    of `Engine::step` (engine.cc:2021-2222) for a stepper whose `tryStep` always succeeds and returns `dtLargest = INF`
+    (euler_explicit_stepper.cc:19, abstract_runge_kutta_stepper.cc:74-76), i.e. `dt = min(INF, dtMax)` before every try:
+
+      * the step is stretched to land exactly on the breakpoint when what would be left after it is below
+        `clamp(0.1 dt, STEPPER_MIN_TIMESTEP, SIMULATION_MIN_TIMESTEP)` -- a residual of less than a microsecond is
+        merged into the last step instead of being integrated on its own (:2063-2073);
+      * a step longer than a microsecond that is not a whole number of microseconds is shortened to one (:2080-2089),
+        so a `dtMax` that is not a multiple of 1 us advances in microsecond multiples and the last step takes the rest.
+
+    Deviation, documented in DESIGN.md section 1: the reference starts every simulation with ONE probe step of
+    `SIMULATION_MIN_TIMESTEP` (`stepperState_.reset(SIMULATION_MIN_TIMESTEP, ...)`, engine.cc:1176) before it settles on
+    `dtMax`; a batch whose lanes restart individually inside a running launch schedule has one step size per launch,
+    so the batched engine integrates the first interval after `start` like every other one."""
+    sizes: List[float] = []
+    t, t_next = 0.0, float(dt_next)
+    while t_next - t > STEPPER_MIN_TIMESTEP:
+        dt = dt_max
+        thr = min(max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP)
+        if t_next - t < dt + thr:
+            dt = t_next - t
+        if dt > SIMULATION_MIN_TIMESTEP:
+            res = math.fmod(dt, SIMULATION_MIN_TIMESTEP)
+            if STEPPER_MIN_TIMESTEP < res < SIMULATION_MIN_TIMESTEP - STEPPER_MIN_TIMESTEP and dt - res > STEPPER_MIN_TIMESTEP:
+                dt -= res
+        sizes.append(dt)
+        t += dt
+    if not sizes:
+        sizes.append(float(dt_next))
+    return sizes
+
+
 def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]],
               extra_breakpoints: Tuple[float, ...] = ()) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
-    """Fixed-step schedule of one `Engine::step(step_size)` call: the breakpoint intervals cut in
-    sub-steps of `dtMax`, the last one shortened to land on the breakpoint (engine.cc:2063-2089).
-    Returns (launches, t_end, t_error) where each launch is
-    `(dt, n_substeps, command_changed, update_sensors)`.
-    """
+    """Fixed-step schedule of one `Engine::step(step_size)` call: the breakpoint intervals cut in sub-steps of
+    `dtMax` by the reference's rule (`substep_sizes`: residual merge and microsecond snapping, engine.cc:2063-2089).
+    Returns (launches, t_end, t_error) where each launch is `(dt, n_substeps, command_changed, update_sensors)`:
+    consecutive sub-steps of the same size share a launch."""
     dt_max = float(options["stepper"]["dtMax"])
     intervals, t_end, t_error = _breakpoint_intervals(t, t_error, step_size, options, extra_breakpoints)
     launches: List[Tuple[float, int, bool, bool]] = []
     for _, dt_next, command_changed, update_sensors in intervals:
-        n_full = int(math.floor((dt_next + STEPPER_MIN_TIMESTEP) / dt_max))
-        rem = dt_next - n_full * dt_max
-        groups: List[Tuple[float, int]] = []
-        if n_full > 0:
-            groups.append((dt_max, n_full))
-        if rem > STEPPER_MIN_TIMESTEP:
-            groups.append((rem, 1))
-        elif not groups:
-            groups.append((dt_next, 1))
+        groups: List[List[Any]] = []
+        for dt in substep_sizes(dt_next, dt_max):
+            # (steps that differ by the round-off of the time accumulation -- below 1e-14 s -- share a launch)
+            if groups and abs(groups[-1][0] - dt) <= 1.0e-14:
+                groups[-1][1] += 1
+            else:
+                groups.append([dt, 1])
         for i, (dt, n) in enumerate(groups):
             launches.append((dt, n, command_changed and i == 0,
                              update_sensors and i == len(groups) - 1))
@@ -644,6 +674,10 @@ class BatchedEngine:
                                  "must be multiple of each other.")  # engine.cc:2724-2733
         if len(new["world"]["gravity"]) != 6:
             raise ValueError("The size of the gravity force vector must be 6.")
+        if self._user_constraints and ct["model"] != "constraint":
+            # (they would stay registered and silently inactive: only the constraint contact model solves for them)
+            raise ValueError("user constraints are registered: remove them before switching away from "
+                             "contacts.model='constraint'")
         self._options = new
         self._apply_options()
         if ct["model"] == "constraint" and not _skip_constraint_check:
@@ -733,6 +767,9 @@ class BatchedEngine:
                                       "branch-parallel topology (floating base with four limbs)")
         if "con_flags" not in self._fields:
             self._apply_options()
+        # Deviation from the reference, where a user constraint is a row of its own next to the joint's bound constraint
+        # (model.cc:884-905): here it REUSES the bound row of the joint (flag bit 2), so only bounded 1-dof joints can be
+        # locked and the bound does not switch while the lock holds -- the lock is the tighter constraint anyway.
         row = self.model.bound_row(constraint.joint_name)
         if any(r == row for r, _ in self._user_constraints.values()):
             raise ValueError(f"joint '{constraint.joint_name}' already carries a user constraint")
@@ -1135,7 +1172,8 @@ class BatchedEngine:
         (`Model::addBiasedToExtendedModel`).  `seed`: `(B,)` uint32 words, or an `int` -- lane l gets `seed + l`."""
         B = self.batch_size
         if isinstance(seed, (int, np.integer)):
-            words = ((int(seed) + np.arange(B, dtype=np.uint64)) & 0xFFFFFFFF).astype(np.uint32)
+            # (Python integers: a negative seed wraps modulo 2^32 instead of overflowing a uint64 array)
+            words = np.array([(int(seed) + l) & 0xFFFFFFFF for l in range(B)], dtype=np.uint32)
         else:
             words = np.ascontiguousarray(np.broadcast_to(np.asarray(seed, dtype=np.uint32), (B,)))
         out = np.empty(B, dtype=np.uint64)
@@ -1195,6 +1233,7 @@ class BatchedEngine:
         local frame of the surface under the contact point (`FrameConstraint::setNormal`, engine.cc:3184-3193)."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before updating the options.")
+        self._ground_pool = None
         if heights is None:
             self._ground = None
             self._lib.check(self._L.jm_batch_set_ground(self._batch_h, None, 0, 0, 0.0, 0.0, 1.0, 1.0))
@@ -1215,8 +1254,15 @@ class BatchedEngine:
         x0, y0, dx, dy = self._ground_grid
         H = self._ground
         ny, nx = H.shape
-        kx, ky = int(math.ceil(radius / dx)), int(math.ceil(radius / dy))
-        Hmax = torch.nn.functional.max_pool2d(H[None, None].to(torch.float64), (2 * ky + 1, 2 * kx + 1), stride=1, padding=(ky, kx))[0, 0]
+        # (+ 1 cell: the query is rounded to the nearest node, i.e. it can sit half a cell away from the point)
+        kx, ky = int(math.ceil(radius / dx)) + 1, int(math.ceil(radius / dy)) + 1
+        cache = getattr(self, "_ground_pool", None)
+        if cache is None or cache[0] != (kx, ky):
+            # pooled once per height map and radius (invalidated by set_ground_heightmap): it is asked for at every auto-reset
+            pooled = torch.nn.functional.max_pool2d(H[None, None].to(torch.float64), (2 * ky + 1, 2 * kx + 1), stride=1,
+                                                    padding=(ky, kx))[0, 0]
+            cache = self._ground_pool = ((kx, ky), pooled)
+        Hmax = cache[1]
         ix = torch.clamp(torch.round((xy[0] - x0) / dx).long(), 0, nx - 1)
         iy = torch.clamp(torch.round((xy[1] - y0) / dy).long(), 0, ny - 1)
         return Hmax[iy, ix].to(self.dtype)

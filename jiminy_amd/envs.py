@@ -48,6 +48,8 @@ class VecJiminyEnv:
         # every environment its own patch of the ground profile: at every (lane) reset a new (x, y) offset of its
         # height-map queries, uniform in +- extent (`BatchedEngine.set_ground_offsets`) -- the batched form of a new random
         # `groundProfile` per environment instance and episode
+        if ground_patch_extent is not None and ground_profile is None:
+            raise ValueError("ground_patch_extent needs a ground_profile to take the patches from")
         self._ground_patch_extent = ground_patch_extent
         # ≙ `engine_options["world"]["groundProfile"]`: `(heightmap(x, y), x_range, y_range, resolution)`, e.g. a
         # `jiminy_amd.terrain.random_tile_ground` generator; sampled on the device at every `reset()`, shared by the batch
@@ -150,6 +152,12 @@ class VecJiminyEnv:
         """≙ `BaseJiminyEnv.reset(seed, options)` for the whole batch."""
         if seed is not None:
             self._generator.manual_seed(int(seed))
+        # the device-side stream (terrain-patch offsets, spawn heights, masked re-draws) is re-seeded from the host
+        # generator at its next use: `reset(seed=s)` reproduces all of them, whatever the disturbance settings
+        self._dev_gen = None
+        # cached reset states / PD targets of a previous graph capture do not outlive the episode batch
+        self._state_cache = None
+        self._target_cache = None
         self.engine.stop()
         q, v = self._sample_state(self.num_envs)
         self._q0, self._v0 = q, v
@@ -553,10 +561,26 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         self._graph_enabled = bool(enable)
         self._graph_whole = bool(enable and whole_step)
         self._graph = None
+        self._state_cache = None
+        self._target_cache = None
+
+    def _graph_preconditions(self) -> None:
+        """Checked again when the graph is captured: `reset()` may have registered disturbance forces (or the user sensor
+        noise) after `enable_graph` was called, and their host-side schedules do not run inside a replay."""
+        eng = self.engine
+        if eng._adaptive is not None or eng._sensor_noise or eng._impulse_forces or eng._profile_forces \
+                or getattr(self, "_impulse_frame", None) is not None:
+            raise NotImplementedError("enable_graph needs a fixed-step solver, noiseless sensors and no applied forces "
+                                      "(std_ratio['disturbance'] registers forces at reset())")
+        if self._graph_whole:
+            a, b = self._sample_state(self.num_envs), self._sample_state(self.num_envs)
+            if not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])):
+                raise NotImplementedError("whole-step graphs need a deterministic reset-state sampler")
 
     def _step_engine_graphed(self, action: torch.Tensor) -> None:
         eng = self.engine
         if self._graph is None:
+            self._graph_preconditions()
             # the launches carry no time: the breakpoint plan of a step must be the same at every step
             plan = _plan_signature(eng, self.control_dt, self._n_ctrl)
             self._g_action = torch.zeros((self.model.nmotors, self.num_envs), dtype=self.dtype, device=self.device)

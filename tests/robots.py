@@ -61,6 +61,24 @@ def crane_walker() -> CompiledModel:
                        has_freeflyer=True, name="crane_walker")
 
 
+def hanging_pendulum() -> CompiledModel:
+    """The reference's `simple_pendulum` fixture restated (tests/data/hanging_pendulum.urdf): bob welded 1 m below the
+    pivot, motor without limits or armature (unit_py/utilities.py:18-59 `load_urdf_default`), IMU on the bob."""
+    m = build_model_from_urdf(os.path.join(DATA, "hanging_pendulum.urdf"), name="hanging_pendulum")
+    add_motor(m, "pivot", "pivot", enableVelocityLimit=False, enableEffortLimit=False, enableArmature=False)
+    add_sensor(m, "ImuSensor", "bob", frame_name="bob")
+    m.position_lower[:] = -1e9   # (the reference tests run it without position limits)
+    m.position_upper[:] = 1e9
+    return m
+
+
+def foot_pendulum() -> CompiledModel:
+    """The reference's `foot_pendulum` fixture restated (tests/data/foot_pendulum.urdf + hardware file): free-flying
+    inverted pendulum on a square foot whose 8 box vertices are contact points."""
+    return build_robot(os.path.join(DATA, "foot_pendulum.urdf"), os.path.join(DATA, "foot_pendulum_hardware.toml"),
+                       has_freeflyer=True, name="foot_pendulum")
+
+
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
             tree_arm(True), crane_walker()]

@@ -106,6 +106,33 @@ def test_quad_kernel_matches_oracle(name, solver):
     assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
 
 
+@pytest.mark.parametrize("name", ["anymal", "atlas"])
+def test_quad_extra_terms_with_a_general_gravity_field(name):
+    """`world.gravity` is a 6-vector (engine.h:291); the output sweep of the branch-parallel kernel takes the total of
+    Y * a_gravity over the bodies from the subtree mass and first moment when the angular part is zero and sums it body
+    by body otherwise: both branches against the oracle (energy, joint wrenches, centroidal momentum derivative)."""
+    from jiminy_amd import _abi
+    model = load_builtin(name)
+    kw_states, dt = QUAD_CASES[name]
+    B = 8
+    st = sample_states(model, B, seed=11, **kw_states)
+    for grav in ((0.4, -0.3, -9.81, 0.0, 0.0, 0.0), (0.4, -0.3, -9.81, 0.05, -0.02, 0.03)):
+        ref, got = alloc_soa(model, B), alloc_soa(model, B)
+        for k in ("q", "v", "command"):
+            ref[k][:] = st[k]
+            got[k][:] = st[k]
+        oracle_batch(model, ref, "start", options=dict(gravity=grav))
+        emu.run(model, got, "start", variant="quad", options=_abi.make_options(gravity=grav))
+        _check(got, ref, 2e-11, what=f"start {grav}")
+        for _ in range(2):
+            oracle_batch(model, ref, "step", options=dict(gravity=grav), solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+            emu.run(model, got, "step", variant="quad", options=_abi.make_options(gravity=grav), solver="runge_kutta_4", dt=dt,
+                    n_substeps=1, command_changed=False)
+        ok = (ref["status"][0] & 1) == 0
+        _check(got, ref, 1e-8, ok, what=f"steps {grav}")
+        assert np.abs(ref["centroidal"][9:]).max() > 1e-3
+
+
 @pytest.mark.parametrize("variant", ["lane", "quad"])
 def test_sensors_are_only_refreshed_on_request(variant):
     model = load_builtin("anymal")

@@ -247,3 +247,169 @@ def test_integrate_keeps_the_manifold():
             assert abs(np.hypot(q[iq], q[iq + 1]) - 1.0) < 1e-12
     # zero increment is the identity
     assert np.allclose(e.integrate(q, np.zeros(model.nv)), q, atol=1e-15)
+
+
+# =====================================================================================================================
+# The reference's remaining law-pins, with the reference's own settings (adaptive Dormand-Prince stepper, impulse
+# forces, the fixtures of unit_py/data restated under tests/data): tests/oracle_sim.py is the simulation loop.
+from tests.oracle_sim import OracleSim  # noqa: E402
+
+
+# ---- (1) core/unit/engine_sanity_check.cc:45-165 with its OWN solver: runge_kutta_dopri, tolAbs = tolRel = 1e-11,
+# continuous time over 10 s; then the default tolerances with 1 kHz controller / sensor updates.  Bar: 1e-9.
+@pytest.mark.parametrize("mode", ["continuous", "discrete"])
+def test_double_pendulum_energy_is_conserved_by_the_adaptive_stepper(mode):
+    s = OracleSim(robots.double_pendulum())
+    s.start(np.array([1.0, 0.0]), np.zeros(2))
+    if mode == "continuous":
+        log = s.run(10.0, tol_abs=1e-11, tol_rel=1e-11, log_dt=0.02)
+    else:
+        log = s.run(10.0, period=1e-3)
+    assert log["status"] == 0 and abs(log["t"][-1] - 10.0) < 1e-12
+    en = log["energy"].sum(axis=1)
+    assert en.max() - en.min() < 1e-9
+    assert np.abs(log["v"]).max() > 1.0   # it did swing
+
+
+# ---- (2) unit_py/test_simple_pendulum.py:240-267 as the reference runs it: DEFAULT tolAbs / tolRel of the adaptive
+# stepper (engine.h:307-325), x0 = (0.1, 0), 2 s, against an independent integration (there: scipy dopri5), 1e-7.
+def test_hanging_pendulum_with_the_default_adaptive_stepper():
+    m = robots.hanging_pendulum()
+    assert m.njoints == 2 and abs(m.mass[1] - 5.0) < 1e-15          # the bob is lumped through the fixed joint
+    s = OracleSim(m)
+    s.start([0.1], [0.0])
+    log = s.run(2.0, log_dt=0.02)
+    sol = solve_ivp(lambda t, x: [x[1], -G * np.sin(x[0])], (0.0, 2.0), [0.1, 0.0], method="DOP853", rtol=1e-13,
+                    atol=1e-13, t_eval=log["t"])
+    assert np.abs(log["q"][:, 0] - sol.y[0]).max() < 1e-7
+    assert np.abs(log["v"][:, 0] - sol.y[1]).max() < 1e-7
+    assert int(s.ad["iter"][0]) < 250      # dtMax-sized steps, not a crawl
+
+
+# ---- (5) unit_py/test_simple_pendulum.py:540-660: impulse-momentum theorem.  The reference's eight impulses on the
+# frame at the bob (world-aligned wrenches, overlapping pairs, durations down to 1 us), no gravity, continuous and
+# 1 kHz discrete; compared with the exact piecewise model  m l^2 q'' = F . t(q) + M_y  (t = tangent of the bob's
+# circle), and with the theorem itself on the first impulse.  Pins convertForceGlobalFrameToJoint and the breakpoints.
+_IMPULSES = [(0.0, 2e-3, [1e3, 0, 0, 0, 0, 0]), (0.1, 1e-3, [0, 1e3, 0, 0, 0, 0]), (0.2, 2e-5, [-1e5, 0, 0, 0, 0, 0]),
+             (0.2, 2e-4, [0, 0, 1e4, 0, 0, 0]), (0.4, 1e-5, [0, 0, 0, 0, 2e4, 0]), (0.4, 1e-5, [1e3, 1e4, 3e4, 0, 0, 0]),
+             (0.6, 1e-6, (2.0 * (np.random.RandomState(0).rand(6) - 0.5)) * 4e6), (0.8, 2e-6, [0, 0, 2e5, 0, 0, 0])]
+
+
+@pytest.mark.parametrize("period", [0.0, 1e-3])
+def test_impulse_momentum_on_the_hanging_pendulum(period):
+    m = robots.hanging_pendulum()
+    s = OracleSim(m, options=dict(gravity=(0, 0, 0, 0, 0, 0)))
+    for t, dt, w in _IMPULSES:
+        s.register_impulse_force("bob", t, dt, w)
+    s.start([0.0], [0.0])
+    log = s.run(1.0, period=period, log_dt=None if period else 0.01)
+    assert log["status"] == 0
+    tl = log["t"]
+    # every start / end of an impulse is a breakpoint of the simulation (reference :612-622)
+    for t, dt, _ in _IMPULSES:
+        assert np.abs(tl - t).min() < 1e-12 and np.abs(tl - (t + dt)).min() < 1e-12
+    # exact piecewise model, integrated from breakpoint to breakpoint
+    pts = sorted({x for t, dt, _ in _IMPULSES for x in (t, t + dt)} | {0.0, 1.0})
+    x = np.zeros(2)
+    worst = 0.0
+    for a, b in zip(pts[:-1], pts[1:]):
+        w = sum((np.asarray(ww, float) for t, dt, ww in _IMPULSES if t - 1e-10 <= a < t + dt - 1e-10), np.zeros(6))
+        te = [t for t in tl if a + 1e-12 < t <= b + 1e-12]
+        sol = solve_ivp(lambda t, y: [y[1], (w[:3] @ np.array([-np.cos(y[0]), 0.0, np.sin(y[0])]) + w[4]) / 5.0],
+                        (a, b), x, method="DOP853", rtol=1e-13, atol=1e-15, t_eval=te)
+        for t, y in zip(sol.t, sol.y.T):
+            i = int(np.argmin(np.abs(tl - t)))
+            worst = max(worst, abs(log["q"][i, 0] - y[0]), abs(log["v"][i, 0] - y[1]))
+        x = sol.y[:, -1]
+    assert abs(sol.t[-1] - 1.0) < 1e-12
+    assert worst < 1e-9
+    # the theorem on the first impulse: m l^2 dw = F . t(q = 0) dt  with t(0) = (-1, 0, 0)
+    i = int(np.argmin(np.abs(tl - 2e-3)))
+    assert abs(log["v"][i, 0] - (-1e3 * 2e-3 / 5.0)) < 1e-6
+    assert np.abs(log["v"][:, 0]).max() > 0.3
+
+
+# ---- (8) unit_py/test_simple_mass.py:243-328: the friction law through a pushed point mass -- mu = 2, transition
+# velocity 5e-2, transitionEps 1e-6, 5 N for 0.8 s from t = 0.05 s, controller period = 1e-5 s (DOPRI in between).
+# Checked as there: (a) the acceleration has a kink exactly where the force switches and where the sliding velocity
+# crosses the transition velocity (stiction break times), (b) the energy only grows while the push lasts, (c) steady
+# sliding at v = Fx / (mu m g) to 1e-7 with a vanishing acceleration.
+def test_pushed_point_mass_stiction_breaks_and_steady_sliding():
+    m = robots.point_mass()
+    mass, mu, vt, h = 1.0, 2.0, 5.0e-2, 1.0e-5
+    m.mass[1] = mass      # the reference's fixture weighs 1 kg: critically damped on k = 1e6, c = 2e3 (no rebound)
+    weight = mass * G
+    s = OracleSim(m, options=dict(stiffness=1.0e6, damping=2.0e3, friction=mu, transition_eps=1.0e-6,
+                                  transition_velocity=vt))
+    t0, dur, fx = 0.05, 0.8, 5.0
+    s.register_impulse_force("body", t0, dur, [fx, 0, 0, 0, 0, 0])
+    q, v = _ff_state(0.0)
+    s.start(q, v)
+    log = s.run(1.5, period=h)
+    assert log["status"] == 0
+    t, vx, ax = log["t"], log["v"][:, 0], log["a"][:, 0]
+    # (a) discontinuities of the third difference of the acceleration
+    jerk = np.diff(ax) / np.diff(t)
+    snap = np.diff(jerk) / np.diff(t[1:])
+    rel = np.abs(snap / np.abs(snap).max())
+    found = t[1:-1][rel > 1.0e-5]
+    found = found[np.concatenate(([False], np.diff(found) > 2 * h))]
+    crossing = t[(vx > vt - 2.0e-5) & (vx < vt + 2.0e-5)]
+    expected = np.sort(np.concatenate((crossing, [t0, t0 + h, t0 + dur, t0 + dur + h])))
+    expected = expected[np.concatenate(([False], np.diff(expected) > 2 * h))]
+    assert len(crossing) > 0 and len(found) == len(expected)
+    assert np.abs(found - expected).max() <= 2 * h + 1e-12
+    # (b) energy increases only while the force is applied
+    en = log["energy"].sum(axis=1)
+    dE = np.concatenate((np.diff(en) / np.diff(t), [0.0]))
+    rising = t[np.where(dE > 1e-9)[0][[0, -1]]]
+    assert np.abs(rising - [t0, t0 + dur - h]).max() < 1e-9
+    # (c) steady state of the law (engine.cc:3218-3222: f_t = mu * min(|vT| / vt, 1) * fN * vT)
+    i = int(np.argmin(np.abs(t - (t0 + dur))))
+    assert abs(vx[i] - fx / (mu * weight)) < 1e-7
+    assert abs(ax[i - 1]) < 1e-6
+
+
+# ---- (10) unit_py/test_foot_pendulum.py:25-95: inverted pendulum on a square foot, initialised at its unstable
+# equilibrium: RK4 at dtMax = 1e-5 for 1 s, constraint contact model (stabilizationFreq 0, regularization 1e-9).
+# Start: |a| small, IMU = (0, -g), force sensor = total weight, the four sole corners share the load; it has not moved
+# after 1 s.  The reference's bar is 1e-5; 1e-6 here (the residual acceleration, 3.8e-7, is the regularisation of the
+# solve acting on 1491 N of multipliers: it is there in the reference too).  Then the spring-damper model.
+def test_foot_pendulum_static_equilibrium_constraint_model():
+    m = robots.foot_pendulum()
+    assert m.ncontacts == 8 and abs(m.mass[1:].sum() - 152.0) < 1e-12
+    s = OracleSim(m, constraint_options=dict(regularization=1e-9, stabilization_freq=0.0))
+    q0 = np.array([0.0, 0.0, 0.005, 0.0, 0.0, 0.0, 1.0, 0.0])
+    s.start(q0, np.zeros(m.nv))
+    tol = 1e-6
+    r = s.row()
+    assert np.abs(r["a"]).max() < tol
+    imu = r["imu"].reshape(-1, 6)
+    i_foot = m.sensor_names("ImuSensor").index("foot")
+    assert np.abs(imu[i_foot][:3]).max() < tol and np.abs(imu[i_foot][3:] - [0.0, 0.0, G]).max() < tol
+    assert np.abs(r["force"] - np.array([0.0, 0.0, 152.0 * G, 0.0, 0.0, 0.0])).max() < 152.0 * G * tol
+    cs = r["contact"].reshape(-1, 3)                      # vertices 0, 2, 4, 6 of the box
+    for i in range(3):
+        # (the reference: np.allclose(..., atol=1e-5) with numpy's default rtol = 1e-5, i.e. 3.7e-3 N on these 373 N)
+        assert np.abs(cs[i] - cs[i + 1]).max() < 1e-5 + 1e-6 * np.abs(cs[i]).max()
+    sole = cs[[i for i, n in enumerate(m.sensor_names("ContactSensor")) if m.frame(n).p[2] < 0.0]]
+    log = s.run(1.0, solver="runge_kutta_4", period=1e-3, dt_max=1e-5)
+    assert log["status"] == 0
+    assert np.abs(log["v"][-1]).max() < tol and np.abs(log["a"][-1]).max() < tol
+    assert np.abs(log["q"][-1] - q0).max() < tol
+    assert len(sole) >= 1 and sole[:, 2].min() > 0.0
+
+
+def test_foot_pendulum_static_equilibrium_spring_damper_model():
+    m = robots.foot_pendulum()
+    k = 1.0e6
+    s = OracleSim(m, options=dict(stiffness=k, damping=2.0e3, transition_eps=1.0e-9))
+    depth = 152.0 * G / (4.0 * k)                        # four sole corners carry the weight
+    q0 = np.array([0.0, 0.0, 0.005 - depth, 0.0, 0.0, 0.0, 1.0, 0.0])
+    s.start(q0, np.zeros(m.nv))
+    r = s.row()
+    assert np.abs(r["a"]).max() < 1e-7
+    assert np.abs(r["force"] - np.array([0.0, 0.0, 152.0 * G, 0.0, 0.0, 0.0])).max() < 1e-6
+    log = s.run(0.2, solver="runge_kutta_4", period=1e-3, dt_max=1e-5)
+    assert log["status"] == 0
+    assert np.abs(log["v"][-1]).max() < 1e-7 and np.abs(log["q"][-1] - q0).max() < 1e-7

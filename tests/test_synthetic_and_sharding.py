@@ -73,6 +73,20 @@ def _worker(rank, world, port, ret):
         for r in range(world):
             ok = ok and torch.equal(last[r][:6], torch.arange(6 * B, dtype=torch.float64).reshape(6, B) + 1000 * r + 2)
         g.drain()
+        # packed in float32 (half the bytes over the links): values that are exact in float32 round-trip exactly, the
+        # others to single precision; gathered every 2nd launch only: calls in between return at once and result()
+        # keeps the last gathered block
+        g32 = ObservationGather(dtype=torch.float32, every=2)
+        started = [g32.launch([imu + k + 0.1, enc]) for k in range(4)]      # gathers k = 0 and k = 2
+        last32 = g32.result()
+        ok = ok and started == [True, False, True, False] and g32.launched == 2
+        ok = ok and last32.dtype == torch.float32 and g32.bytes_per_rank == 10 * B * 4
+        for r in range(world):
+            want = torch.arange(6 * B, dtype=torch.float64).reshape(6, B) + 1000 * r + 2 + 0.1
+            ok = ok and torch.equal(last32[r][:6], want.to(torch.float32))
+            ok = ok and float((last32[r][:6].double() - want).abs().max()) < 1e-3
+            ok = ok and torch.equal(last32[r][6:].double(), torch.arange(4 * B, dtype=torch.float64).reshape(4, B) - 1000 * r)
+        g32.drain()
         # ragged shards are refused up front instead of hanging inside the collective
         try:
             all_gather_observations([imu[:, : B - rank], enc[:, : B - rank]])

@@ -516,6 +516,54 @@ def test_gpu_per_lane_friction_with_the_spring_damper_law(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["persistent", "per_stage"])
+def test_gpu_per_lane_friction_with_the_adaptive_stepper(gpu_device, monkeypatch, form):
+    """Per-lane friction as the ONLY per-lane input, spring-damper law, `runge_kutta_dopri`: the persistent kernel must
+    be the variation one (`k_quad_dopri_gen` -- the plain kernel never reads the friction field and would silently use
+    the batch-wide coefficient).  Against the oracle's adaptive loop on sliding robots."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    from oracle.oracle_py import OracleEngine, adaptive_state
+    model = load_builtin("anymal")
+    monkeypatch.setenv("JIMINY_AMD_ADAPTIVE_FORM", "1" if form == "per_stage" else "0")
+    B, T = 32, 2e-3
+    st = sample_states(model, B, seed=32, grounded_fraction=1.0)
+    st["v"][:2] += 0.5
+    mu = np.linspace(0.1, 1.6, B)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    ref["friction"] = mu.copy()
+    tol = dict(tolAbs=1e-8, tolRel=1e-8)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces",))
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "controllerUpdatePeriod": T, "sensorsUpdatePeriod": T, **tol},
+                     "contacts": {"model": "spring_damper"}})
+    eng.set_lane_friction(mu)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    orc = OracleEngine(model)
+    orc.bind_friction(ref["friction"])
+    from tests.helpers import oracle_io
+    orc.batch_run("start", oracle_io(ref))
+    ad = adaptive_state(B)
+    for i in range(3):
+        eng.step(T)
+        orc.batch_run_dopri(ref, ad, (i + 1) * T, tol_rel=1e-8, tol_abs=1e-8, new_step=True, command_changed=(i == 0))
+    ok = (ref["status"][0] == 0) & (eng.status.cpu().numpy() == 0)
+    assert ok.sum() >= B // 2
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-6, k
+    # the coefficient matters: the same run with the batch-wide friction differs
+    eng.stop()
+    eng.set_lane_friction(None)
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    for i in range(3):
+        eng.step(T)
+    assert rel_err(eng.field("v").cpu().numpy(), ref["v"], ok) > 1e-4
+
+
+@pytest.mark.gpu
 def test_gpu_impulse_force_schedule_and_model_options(gpu_device):
     """`register_impulse_force` (engine.cc:1838-1893): the wrench acts exactly during [t, t + dt] -- the launches are
     cut at its breakpoints -- and pushes the base; `set_model_options` draws a biased model per lane at `start`."""
