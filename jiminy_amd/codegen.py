@@ -278,7 +278,10 @@ def qcon_split(model: CompiledModel) -> bool:
 
 def part_flags(model: CompiledModel) -> Dict[str, List[str]]:
     """Extra flags of single translation units of a topology (build_variants.json `part_flags`: {"5": ["-O1"]} compiles
-    the persistent adaptive kernel of that topology at -O1), appended after the common flags."""
+    the persistent adaptive kernel of that topology at -O1), appended after the common flags.
+    JIMINY_AMD_NO_PART_FLAGS=1 ignores them (re-testing whether a pinned unit still needs its flags)."""
+    if os.environ.get("JIMINY_AMD_NO_PART_FLAGS") == "1":
+        return {}
     try:
         with open(_VARIANT_FILE) as f:
             return {str(k): list(v) for k, v in json.load(f).get(model.topology_hash(), {}).get("part_flags", {}).items()}
@@ -311,7 +314,7 @@ def write_header(model: CompiledModel) -> str:
 def _sources() -> List[str]:
     return [os.path.join(CSRC, n) for n in ("jm_lib.cpp", "jm_kernels.h", "jm_math.h", "jm_quad.h",
                                             "jm_pack.h", "jm_adaptive.h", "jm_blocks.h", "jm_random.h",
-                                            "jm_constraint.h", "jm_qcon.h", "jm_qdopri.h", "jm_lib_constraint.cpp")] + \
+                                            "jm_constraint.h", "jm_qcon.h", "jm_qtip.h", "jm_qdopri.h", "jm_lib_constraint.cpp")] + \
            [os.path.join(CSRC, "..", "..", "include", "jiminy_hip.h")]
 
 
@@ -322,6 +325,9 @@ def source_digest(model: CompiledModel, variant: Optional[int] = None, extra_fla
     v = preferred_variant(model) if variant is None else variant
     h = hashlib.sha256()
     for path in _sources():
+        # (jm_qtip.h only reaches the code of topologies that step in the split form: the others are not rebuilt for it)
+        if os.path.basename(path) == "jm_qtip.h" and not qcon_split(model):
+            continue
         with open(path, "rb") as f:
             h.update(f.read())
     h.update(topology_header(model).encode())
@@ -371,7 +377,7 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
     common += extra_flags or []
     parts = [1, 2, 3, 4, 5, 6] if quad_structure(model) is not None else [1]
     if qcon_split(model):
-        parts += [7, 8, 9]
+        parts += [7, 8, 9, 10]
     objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]
     cmds = [[HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(CSRC, "jm_lib.cpp"), "-o", objs[0]]]
     pf = part_flags(model)

@@ -50,6 +50,7 @@ extern template __global__ void k_quad_con_split<double, Topo, 1>(const BatchArg
 extern template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
+extern template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
 #endif
 }
 #endif
@@ -295,6 +296,9 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                         hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
                         if constexpr (jm::QConRows<Tp>::MAXM > 64)
                             hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 12, 64, JM_QCON_PGS_DEPTH - 1>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
+                        // (the waves whose robots all have few active joint rows: operational-space form, jm_qtip.h)
+                        if constexpr (jm::QTip<Tp>::ON)
+                            hipLaunchKernelGGL((jm::k_qtip_pgs<double, Tp>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
                         hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, sc, A, C);
                     }
                 }
@@ -722,8 +726,11 @@ int32_t jm_batch_step(jm_batch * b, int32_t solver, double dt, int32_t n_substep
         return fail(JM_ECONTROLFLOW, "No simulation running. Please start one before using step method.");  // engine.cc:1727-1731
     if (solver != JM_SOLVER_EULER_EXPLICIT && solver != JM_SOLVER_RUNGE_KUTTA_4)
         return fail(JM_ENOTIMPL, "only 'euler_explicit' and 'runge_kutta_4' are available on the batched path");
-    if (!(dt >= 1e-6) || !(dt <= 0.02 + 1e-12))
-        return fail(JM_EINVAL, "Step size out of bounds.");  // engine.cc:1750-1753, constants.h:18-20
+    // (`dt` is the step of the integrator -- the inner loop of Engine::step, which goes down to STEPPER_MIN_TIMESTEP when what
+    // is left of a breakpoint interval is that short, engine.cc:2047-2089 --, not the user-level step size, whose bound
+    // SIMULATION_MIN_TIMESTEP <= step (engine.cc:1750-1753) is checked where the schedule is planned)
+    if (!(dt >= 1e-10) || !(dt <= 0.02 + 1e-12))
+        return fail(JM_EINVAL, "Step size out of bounds.");  // constants.h:18-20
     if (n_substeps < 1) return fail(JM_EINVAL, "n_substeps must be >= 1");
     int32_t rc = check_bound(b, true);
     if (rc != JM_OK) return rc;

@@ -9,6 +9,7 @@
 //   -DJM_CON_PART=6  k_quad_dopri_gen (the same with per-lane body parameters / height map / applied forces)
 //   -DJM_CON_PART=7 / 8  k_quad_con_split<1 / 2>  (jm_qcon.h, split stepping of robots with large solves: before / after the solve)
 //   -DJM_CON_PART=9  k_qcon_pgs     (the solve of the split form)
+//   -DJM_CON_PART=10 k_qtip_pgs     (the solve of the split form in the operational space of the tip bodies, jm_qtip.h)
 #include <hip/hip_runtime.h>
 
 #ifndef JM_TOPO_HEADER
@@ -44,5 +45,7 @@ template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArgs<doubl
 #elif JM_CON_PART == 9 && JM_TOPO_QCON_SPLIT
 template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
+#elif JM_CON_PART == 10 && JM_TOPO_QCON_SPLIT
+template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
 #endif
 }

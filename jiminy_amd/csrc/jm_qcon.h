@@ -1510,6 +1510,10 @@ JM_DEV void qcon_apply_delta(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<
     if (bad) status |= JM_LANE_NAN;
 }
 
+}  // namespace jm
+#include "jm_qtip.h"
+namespace jm
+{
 // ---------------------------------------------------------------- one constrained evaluation
 // `start_passes` > 0: Engine::start / reset sequence; < 0: MODE_REFRESH (re-apply the stored multipliers);
 // 0: a regular evaluation.  Leaves the constrained acceleration in ddqb / ddq.
@@ -1583,16 +1587,25 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
             any = cx.act.any();
             if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
             const QStoreSq<T> W{V.hbm};
+            // which form the solve of this WAVE takes: the operational space of the contact-bearing tip bodies (jm_qtip.h)
+            // when every robot of the wave has few active joint rows, else the delassus matrix row by row
+            bool tipform = false;
+            if constexpr (QTip<Tp>::ON && !GEN) tipform = !X::wave_any(cx.nb > QTip<Tp>::NBX);
             if (any)
             {
-                qcon_delassus<T, Tp, X, QStoreSq<T>, GEN>(P, LT, C, k, ix, K, TS, cx, W);
+                if constexpr (QTip<Tp>::ON && !GEN)
+                {
+                    if (tipform) qtip_build<T, Tp, X, QStoreSq<T>>(P, LT, C, k, ix, K, TS, cx, W);
+                    else qcon_delassus<T, Tp, X, QStoreSq<T>, GEN>(P, LT, C, k, ix, K, TS, cx, W);
+                }
+                else qcon_delassus<T, Tp, X, QStoreSq<T>, GEN>(P, LT, C, k, ix, K, TS, cx, W);
                 X::sync();
                 qcon_rhs<T, Tp, QStoreSq<T>, GEN>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
             }
-            // header of the solve: rows | joint bounds | rows per contact block (0 rows: nothing to solve)
+            // header of the solve: rows | joint bounds | rows per contact block | form (0 rows: nothing to solve)
             if (k == 0)
             {
-                W.put(QSplitRegion<Tp>::HDR, (T)(any ? (cx.m | (cx.nb << 8) | (cx.cb << 16)) : 0));
+                W.put(QSplitRegion<Tp>::HDR, (T)((any ? (cx.m | (cx.nb << 8) | (cx.cb << 16)) : 0) | (tipform ? (1 << 24) : 0)));
                 W.put(QSplitRegion<Tp>::LOCK, (T)cx.lockp);
             }
             mask_io(cx.act, SR::CXL, true);
@@ -1742,6 +1755,51 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
     if (!(JM_QCON_SKIP & 4)) apply();
 }
 
+// Visit table of one Gauss-Seidel sweep over the m packed rows of a solve (`nb` joint rows, then blocks of `cb` rows per
+// contact), in the reference's order (constraint_solvers.cc:107-333): block 0 of every constraint -- joint bounds, then the
+// normal force of every contact --, block 1: torsion rows, block 2: friction cones, the two tangential rows one after the
+// other (both updated at the second).  Entry = row | kind << 8 with kind 0 clamp at zero, 1 torsion, 2 / 3 first / second
+// tangential row, 4 unbounded row (a user-registered JointConstraint: visited FIRST, no relaxation, no projection,
+// constraint_solvers.cc:112-128; `lockp` = those among the packed joint rows).  Filled by the four lanes of the quad.
+JM_DEV void qcon_visit_table(int k, int m, int nb, int cb, unsigned long long lockp, unsigned short * vt)
+{
+    const int nc = cb > 0 ? (m - nb) / cb : 0;
+    auto visit = [&](int t, int & kind) __attribute__((always_inline)) {
+        kind = 0;
+        if (t < nb) return t;
+        int u = t - nb;
+        if (u < nc) return nb + cb * u + 2;
+        u -= nc;
+        if (cb == 4)
+        {
+            kind = 1;
+            if (u < nc) return nb + 4 * u + 3;
+            u -= nc;
+        }
+        kind = 2 + (u & 1);
+        return nb + cb * (u >> 1) + (u & 1);
+    };
+    if (lockp == 0ull)
+        for (int t = k; t < m; t += 4)
+        {
+            int kind;
+            const int row = visit(t, kind);
+            vt[t] = (unsigned short)(row | (kind << 8));
+        }
+    else if (k == 0)
+    {
+        int t = 0;
+        for (int r = 0; r < nb; ++r) if ((lockp >> r) & 1ull) vt[t++] = (unsigned short)(r | (4 << 8));
+        for (int r = 0; r < nb; ++r) if (!((lockp >> r) & 1ull)) vt[t++] = (unsigned short)r;
+        for (; t < m; ++t)
+        {
+            int kind;
+            const int row = visit(t, kind);
+            vt[t] = (unsigned short)(row | (kind << 8));
+        }
+    }
+}
+
 // The solve.  Four lanes per robot as everywhere, 16 robots per wave; the multipliers `x` of the robot on chip (zero beyond
 // its m rows), everything else (b, residuals of the previous sweep, 1 / diag, the square matrix) read from the robot's block
 // of the workspace with the row: lane k of the quad reads entries 8 j + 2 k, 8 j + 2 k + 1 of the row (16-byte loads, 64
@@ -1765,6 +1823,7 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
     using T2 = QPair<T>;
     auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
     const int hdr = (int)G(RG::HDR);
+    if (X::wave_any(((hdr >> 24) & 1) != 0)) return false;   // (the wave solves in the operational-space form, jm_qtip.h)
     const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff, A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
     {
         const bool big = X::wave_any(m > 8 * NJ), mine = X::wave_any(m > LO);
@@ -1787,45 +1846,8 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
     bool wide[NGR];
     static_for<0, NGR>([&](auto gc) { wide[decltype(gc)::value] = X::wave_any(m > 8 * GJ * decltype(gc)::value); });
     X::fence();   // (1 / diag, the padding and the visit table were written by one lane of the quad, every lane reads them)
-    // visit t of a sweep -> row and kind (0 clamp at zero, 1 torsion, 2 / 3 first / second tangential row)
-    const int nc = cb > 0 ? (m - nb) / cb : 0;
-    auto visit = [&](int t, int & kind) __attribute__((always_inline)) {
-        kind = 0;
-        if (t < nb) return t;
-        int u = t - nb;
-        if (u < nc) return nb + cb * u + 2;
-        u -= nc;
-        if (cb == 4)
-        {
-            kind = 1;
-            if (u < nc) return nb + 4 * u + 3;
-            u -= nc;
-        }
-        kind = 2 + (u & 1);
-        return nb + cb * (u >> 1) + (u & 1);
-    };
-    // (the table of the sweep, built once per solve: row | kind << 8; kind 4 = unbounded row, no relaxation, no projection:
-    // the user-registered JointConstraints, visited FIRST, constraint_solvers.cc:112-128)
     const unsigned long long lockp = (unsigned long long)G(RG::LOCK);
-    if (lockp == 0ull)
-        for (int t = k; t < m; t += 4)
-        {
-            int kind;
-            const int row = visit(t, kind);
-            vt[t] = (unsigned short)(row | (kind << 8));
-        }
-    else if (lead)
-    {
-        int t = 0;
-        for (int r = 0; r < nb; ++r) if ((lockp >> r) & 1ull) vt[t++] = (unsigned short)(r | (4 << 8));
-        for (int r = 0; r < nb; ++r) if (!((lockp >> r) & 1ull)) vt[t++] = (unsigned short)r;
-        for (; t < m; ++t)
-        {
-            int kind;
-            const int row = visit(t, kind);
-            vt[t] = (unsigned short)(row | (kind << 8));
-        }
-    }
+    qcon_visit_table(k, m, nb, cb, lockp, vt);
     X::sync();
     struct Row { T2 a[NJ]; T b, yp, invd; int i, kind; };
     // row of visit t: this lane's quarter (entries (i, 8 j + 2 k), (i, 8 j + 2 k + 1)), right-hand side, previous residual
@@ -2088,6 +2110,29 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
     const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
     qcon_pgs_lean<T, Tp, DppQuad, NJ, LO, D>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
                                              (T *)xs2 + (threadIdx.x >> 2) * XS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
+}
+
+// the solve in the operational-space form (jm_qtip.h): multipliers, z and the visit table of the block's 64 robots on chip
+template<class T, class Tp>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JM_QTIP_WAVES)))
+k_qtip_pgs(const QConArgs<T> C, const T * P, unsigned)
+{
+    using L = Layout<Tp>;
+    using RG = QSplitRegion<Tp>;
+    using TP = QTip<Tp>;
+    constexpr int XS = QConRows<Tp>::MAXM + 3;    // (odd strides: the 16 robots of a wave start in different banks)
+    constexpr int ZS = TP::ZPAD + 1 - (TP::ZPAD & 1) + 2;
+    constexpr int VS_ = QConRows<Tp>::MAXM + 4;
+    __shared__ T xs[XS * 64];
+    __shared__ T zs[ZS * 64];
+    __shared__ unsigned short vis[VS_ * 64];
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
+    if (r >= (unsigned)C.split_r1) return;
+    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
+    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    if constexpr (TP::ON)
+        qtip_pgs<T, Tp, DppQuad, JM_QTIP_DEPTH>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
+                                                xs + (threadIdx.x >> 2) * XS, zs + (threadIdx.x >> 2) * ZS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
 }
 
 template<class T, class Tp>

@@ -63,6 +63,10 @@ extern "C" int emu_undef_reports() { return g_undef_reports.load(); }
 #else
 template<class T> static inline void undef_check(T) {}
 #endif
+#ifdef JM_HOST_EMU_TRACE
+static thread_local long long g_bar_count = 0;
+#define pthread_barrier_wait(b) (++g_bar_count, (pthread_barrier_wait)(b))
+#endif
 struct HostQuad
 {
     static thread_local QuadShared * sh;
@@ -183,6 +187,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
 // the same launch in the split form of robots with large solves (jm_qcon.h: k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>
 // per evaluation, stage buffer and solver region persistent between the parts): one robot at a time, its four lanes as threads
 static int g_split = 0;
+static long long g_tip_solves = 0;   // solves that took the operational-space form (jm_qtip.h)
+extern "C" long long emu_tip_solves() { return g_tip_solves; }
 extern "C" void emu_set_split(int on) { g_split = on; }
 extern "C" int emu_has_split() { return jm::qcon_split<Topo>() ? 1 : 0; }
 template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T> & A, const std::vector<T> & P, const jm::QConArgs<T> & C0)
@@ -202,6 +208,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
         for (size_t i = (size_t)RG::ROWS * A.B; i < region.size(); ++i) region[i] = sentinel;
         // on-chip arrays of the solve, shared by the four lanes of the robot
         std::vector<jm::QPair<T>> xs(8 * 12 / 2 + 2);
+        std::vector<T> zs(jm::QTip<Tp>::ZPAD + 4, (T)std::nan(""));
         std::vector<unsigned short> vis(8 * 12 + 8);
         std::vector<std::thread> th;
         for (int k = 0; k < 4; ++k)
@@ -221,10 +228,17 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                     {
                         C.split_e = e;
                         jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 1>(A, r, k, table, S, &C, &V);
+#ifdef JM_HOST_EMU_TRACE
+                        std::fprintf(stderr, "[%d] r=%lld e=%d after pre: %lld barriers\n", k, r, e, g_bar_count);
+#endif
                         HostQuad::sync();
                         char * ws = (char *)region.data();
                         const unsigned g0 = (unsigned)((size_t)r * RG::ROWS * sizeof(T));
-                        if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
+                        bool tip = false;
+                        if constexpr (jm::QTip<Tp>::ON)
+                            tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), vis.data(), ws, g0);
+                        if (tip) { if (k == 0) ++g_tip_solves; }
+                        else if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
                             jm::qcon_pgs_lean<T, Tp, HostQuad, 12, 64, JM_QCON_PGS_DEPTH - 1>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0);
                         HostQuad::sync();
                         jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 2>(A, r, k, table, S, &C, &V);

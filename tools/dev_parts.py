@@ -30,7 +30,7 @@ def main():
     os.makedirs(objdir, exist_ok=True)
     common = [f"--offload-arch={codegen.OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"] + list(codegen.BUILD_VARIANTS[v]) + extra
-    parts = [1, 2, 3, 4, 5, 6] + ([7, 8, 9] if codegen.qcon_split(model) else [])
+    parts = [1, 2, 3, 4, 5, 6] + ([7, 8, 9, 10] if codegen.qcon_split(model) else [])
     pf = codegen.part_flags(model)
     units = {"main": [codegen.HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(codegen.CSRC, "jm_lib.cpp")]}
     for p in parts:
