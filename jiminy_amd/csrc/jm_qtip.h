@@ -28,7 +28,7 @@
 #define JM_QTIP 1            // 0: never take the operational-space form (A / B runs)
 #endif
 #ifndef JM_QTIP_WAVES
-#define JM_QTIP_WAVES 2      // waves per SIMD of k_qtip_pgs
+#define JM_QTIP_WAVES 1      // waves per SIMD of k_qtip_pgs (measured, Atlas B = 32 768: 2.40 ms per solve at 1, 2.66 at 2 -- issue-bound either way)
 #endif
 #ifndef JM_QTIP_DEPTH
 #define JM_QTIP_DEPTH 2      // visits whose records are in flight per robot
