@@ -51,6 +51,7 @@ extern template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArg
 extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
+extern template __global__ void k_qcon_exact<double, Topo>(const QConArgs<double>);
 #endif
 }
 #endif
@@ -93,6 +94,7 @@ struct jm_batch
     void * field[JM_F_COUNT] = {};
     bool started = false;
     bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
+    bool qcon_split_start = true;   // ... and split start / reset launches (JIMINY_AMD_QCON_SPLIT_START=0: single kernel)
     bool joint_locks = false; // the batch carries user-registered JointConstraints (jm_batch_set_joint_locks)
     int split_chunks = 1;     // ... as this many independent chunks on streams of their own (JIMINY_AMD_QCON_SPLIT_CHUNKS; measured: no gain)
     hipStream_t split_stream[8] = {};
@@ -253,11 +255,42 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
         C.iter_max = C0.iter_max;
         C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
         C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
-        C.stage = nullptr; C.split_e = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
+        C.stage = nullptr; C.split_e = 0; C.split_pass = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
         constexpr int nth = 64 * jm::qcon_block_waves<double, Tp>();
         const unsigned grid = (unsigned)((A.B + nth / 4 - 1) / (nth / 4));
         if constexpr (jm::qcon_split<Tp>())
         {
+            // Engine::start / reset of such robots: the four passes of the initialisation (engine.cc:1399-1467) as launches
+            // of the split kernels -- first pass (every constraint enabled, hysteresis, free acceleration with u = 0, matrix
+            // and right-hand side) | exact solve | three times (multipliers -> u, free acceleration, right-hand side |
+            // Gauss-Seidel) | closing evaluation with the outputs.  The single kernel (k_quad_con: 2064 spilled VGPRs, 137 kB
+            // of LDS for stage rows a start does not need, the general Gauss-Seidel form at one row per memory round trip)
+            // took 52-67 ms per launch at B = 32 768 whatever the number of lanes that restart.
+            if (b->qcon_split && (A.mode == jm::MODE_START || A.mode == jm::MODE_RESET) && !(A.model_lane || A.applied || A.ground_h) &&
+                (A.B & 15) == 0 && !b->ov_flags && b->qcon_split_start)
+            {
+                C.stage = C.ws + (size_t)jm::qcon_split_region_rows<double, Tp>() * (size_t)A.B;
+                const unsigned g64 = (unsigned)((A.B + 63) / 64);
+                auto solve = [&]() {
+                    hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
+                    if constexpr (jm::QConRows<Tp>::MAXM > 64)
+                        hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 12, 64, JM_QCON_PGS_DEPTH - 1>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
+                    if constexpr (jm::QTip<Tp>::ON)
+                        hipLaunchKernelGGL((jm::k_qtip_pgs<double, Tp>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
+                };
+                C.split_pass = 0;
+                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
+                hipLaunchKernelGGL((jm::k_qcon_exact<double, Tp>), dim3(g64), dim3(256), 0, s, C);
+                for (int pass = 1; pass <= 3; ++pass)
+                {
+                    C.split_pass = pass;
+                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
+                    solve();
+                }
+                C.split_pass = 4;
+                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, s, A, C);
+                return;
+            }
             // robots whose solves live in the workspace: step launches go through pre | solve | post per evaluation (jm_qcon.h)
             if (b->qcon_split && A.mode == jm::MODE_STEP && !(A.model_lane || A.applied || A.ground_h) && (A.B & 15) == 0 && !b->ov_flags)
             {
@@ -571,6 +604,7 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     // generic one-robot-per-lane kernel (A/B measurements)
     b->variant = (Topo::QUAD && model->root_at_origin) ? VARIANT_QUAD : VARIANT_LANE;
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT")) b->qcon_split = e[0] != '0';
+    if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT_START")) b->qcon_split_start = e[0] != '0';
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT_CHUNKS"))
     {
         const int n = std::atoi(e);

@@ -98,6 +98,7 @@ template<class T> struct QConArgs
     // split stepping (k_quad_con_pre / k_qcon_pgs / k_quad_con_post): stage buffer in HBM, evaluation of this launch
     T * stage;
     int split_e;
+    int split_pass;           // Engine::start / reset in the split form: pass of the initialisation (0 first, 1..3 Gauss-Seidel passes, 4 closing)
     int split_r0, split_r1;   // robots [r0, r1) of this launch (chunks of the batch step on streams of their own, jm_lib.cpp)
 };
 
@@ -1368,15 +1369,17 @@ JM_DEV bool qcon_pgs_fixed(const QConArgs<T> & C, T friction, int k, const QConC
 // batch costs one round trip to the workspace instead of sixteen.  (Atlas, `reset` of 32 768 robots standing on sixteen
 // contact points, 94 rows: 82 -> 68 ms per launch against the serial lead-lane form; the rest is the three start passes
 // of the general Gauss-Seidel form at 94 rows.)
-template<class T, class X, class VS>
+// (SQ: the matrix is stored square, rows padded to a multiple of four entries -- the region of the split form, QStoreSq)
+template<class T, class X, class VS, bool SQ = false>
 JM_DEV bool qcon_chol(int k, int m, const VS & V)
 {
-    const int A0 = 4 * m;
+    const int A0 = 4 * m, ms = (m + 3) & ~3;
+    auto rb = [&](int i) { return SQ ? A0 + i * ms : A0 + i * (i + 1) / 2; };   // first entry of row i of the lower triangle
     bool ok = true;
     X::sync();
     // sum over c in [c0, n) step `step` of F(i, c) F(j, c), rows i, j of the packed factor
     auto rowdot = [&](int i, int j, int c0, int n, int step) {
-        const int bi = A0 + i * (i + 1) / 2, bj = A0 + j * (j + 1) / 2;
+        const int bi = rb(i), bj = rb(j);
         T s = T(0);
         int c = c0;
         for (; c + 7 * step < n; c += 8 * step)
@@ -1390,22 +1393,22 @@ JM_DEV bool qcon_chol(int k, int m, const VS & V)
     };
     for (int j = 0; j < m; ++j)
     {
-        const T sj = V.get_flat(A0 + tri_(j, j)) - rowdot(j, j, 0, j, 1);
+        const T sj = V.get_flat(rb(j) + j) - rowdot(j, j, 0, j, 1);
         ok &= sj > T(0);
         const T d = sqrt_(sj);
         X::sync();   // (every lane has read the diagonal entry before the lead lane overwrites it)
-        if (k == 0) V.put(A0 + tri_(j, j), d);
+        if (k == 0) V.put(rb(j) + j, d);
         for (int i = j + 1 + k; i < m; i += 4)
         {
-            const T t = V.get_flat(A0 + tri_(i, j)) - rowdot(i, j, 0, j, 1);
-            V.put(A0 + tri_(i, j), t / d);
+            const T t = V.get_flat(rb(i) + j) - rowdot(i, j, 0, j, 1);
+            V.put(rb(i) + j, t / d);
         }
         X::fence();   // the next column reads rows written by the other lanes of the quad
     }
     // forward and backward substitution: the lanes share the sum of a row, every lane holds the result
     for (int i = 0; i < m; ++i)
     {
-        const int bi = A0 + i * (i + 1) / 2;
+        const int bi = rb(i);
         T s = T(0);
         for (int c = k; c < i; c += 4) s += V.get_flat(bi + c) * V.get_flat(c);
         s = V.get_flat(m + i) - X::quad_sum(s);
@@ -1417,9 +1420,9 @@ JM_DEV bool qcon_chol(int k, int m, const VS & V)
     for (int i = m - 1; i >= 0; --i)
     {
         T s = T(0);
-        for (int c = i + 1 + k; c < m; c += 4) s += V.get_flat(A0 + tri_(c, i)) * V.get_flat(c);
+        for (int c = i + 1 + k; c < m; c += 4) s += V.get_flat(rb(c) + i) * V.get_flat(c);
         s = V.get_flat(i) - X::quad_sum(s);
-        const T xi = s / V.get_flat(A0 + tri_(i, i));
+        const T xi = s / V.get_flat(rb(i) + i);
         X::sync();
         if (k == 0) V.put(i, xi);
         X::fence();
@@ -1581,12 +1584,62 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         };
         if constexpr (PH == 1)
         {
+            const QStoreSq<T> W{V.hbm};
+            if (init && C.split_pass > 0)
+            {
+                // ---- Engine::start in the split form, Gauss-Seidel pass 1..3 (engine.cc:1399-1467): the multipliers of the
+                // previous pass -> lane state; the bound multipliers enter RobotState::u (plus sign whatever the direction,
+                // engine.cc:3786-3790) next to the motor efforts; free evaluation with that u; right-hand side and warm start
+                mask_io(cx.act, SR::CXL, false);
+                mask_io(cx.rev, SR::CXL + QR::NWORDS, false);
+                mask_io(cx.mine, SR::CXL + 2 * QR::NWORDS, false);
+                mask_io(cx.lock, SR::CXL + 3 * QR::NWORDS, false);
+                const int hdr = (int)S_.getl(SR::CXL + 4 * QR::NWORDS);
+                cx.m = hdr & 0xff; cx.nb = (hdr >> 8) & 0xff; cx.cb = (hdr >> 16) & 0xff; cx.overflow = (hdr >> 24) & 1;
+                any = cx.act.any();
+                const bool tipform = any && ((((int)W.get(QSplitRegion<Tp>::HDR)) >> 24) & 1) != 0;
+                if (any)
+                {
+                    const bool solved = W.get(QSplitRegion<Tp>::OK) != T(0);
+                    if (C.split_pass == 1) { if (!solved) status |= JM_LANE_NAN; }   // (the exact solve broke down)
+                    else if (solved) status &= ~JM_LANE_SOLVER_FAILURE;
+                    else status |= JM_LANE_SOLVER_FAILURE;
+                    qcon_scatter<T, Tp, QStoreSq<T>>(LT, C, B32, r32, k, ix, cx, W);
+                    X::sync();
+                    X::fence();
+                }
+                static_for<0, N>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    const int row = sel4(k, QR::limb_row(0, s), QR::limb_row(1, s), QR::limb_row(2, s), QR::limb_row(3, s));
+                    uq_l[s] = (any && row >= 0 && ix.has[s] && cx.act.test(row) && !cx.lock.test(row)) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
+                    S_.putl(SR::DDQL + s, uq_l[s]);
+                });
+                static_for<1, NT>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int row = QR::trunk_row(t);
+                    if constexpr (row >= 0) uq_b[t] = (any && cx.act.test(row) && !cx.lock.test(row)) ? C.data[(unsigned)(R::LAM + row) * B32 + r32] : T(0);
+                    S_.putb(SR::DDQB + t, uq_b[t]);
+                });
+                static_for<0, N>([&](auto sc) { ex.tau_l[decltype(sc)::value] = uq_l[decltype(sc)::value]; });
+                static_for<0, NT>([&](auto tc) { ex.tau_b[decltype(tc)::value] = uq_b[decltype(tc)::value]; });
+                ex.motors_on = true;
+                quad_eval<T, Tp, X, false, SB, 1, QKeep<T, Tp>, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq,
+                                                               status, &ex, &K, &TS);
+                if (any)
+                {
+                    // (the factorisation of the streamed form's exact solve overwrote the matrix)
+                    if (C.split_pass == 1 && !tipform) qcon_delassus<T, Tp, X, QStoreSq<T>, GEN>(P, LT, C, k, ix, K, TS, cx, W);
+                    X::sync();
+                    qcon_rhs<T, Tp, QStoreSq<T>, GEN>(P, LT, C, B32, r32, k, ix, qb, vb, ql, vl, ddqb, ddq, K, cx, W);
+                }
+                return;
+            }
+            ex.motors_on = !init;   // (first pass of Engine::start: RobotState::u is still zero)
             quad_eval<T, Tp, X, false, SB, 1, QKeep<T, Tp>, GEN>(P, LT, A, r32, k, ix, S_, qb, vb, ql, vl, cmdb, cmdl, false, ddqb, ddq,
                                                            status, &ex, &K, &TS);
-            qcon_switch<T, Tp, X, GEN>(P, LT, C, B32, r32, k, ix, qb, ql, K, false, false, cx);
+            qcon_switch<T, Tp, X, GEN>(P, LT, C, B32, r32, k, ix, qb, ql, K, init, false, cx);
             any = cx.act.any();
             if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
-            const QStoreSq<T> W{V.hbm};
             // which form the solve of this WAVE takes: the operational space of the contact-bearing tip bodies (jm_qtip.h)
             // when every robot of the wave has few active joint rows, else the delassus matrix row by row
             bool tipform = false;
@@ -1633,6 +1686,12 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
                 if (cx.overflow) status |= JM_LANE_SOLVER_FAILURE;
                 qcon_scatter<T, Tp, QStoreSq<T>>(LT, C, B32, r32, k, ix, cx, W);
                 X::sync();
+            }
+            if (init)
+            {
+                // (closing evaluation of Engine::start: u still carries the bound multipliers of the pass before the last)
+                static_for<0, N>([&](auto sc) { uq_l[decltype(sc)::value] = S_.getl(SR::DDQL + decltype(sc)::value); });
+                static_for<1, NT>([&](auto tc) { uq_b[decltype(tc)::value] = S_.getb(SR::DDQB + decltype(tc)::value); });
             }
         }
     }
@@ -2110,6 +2169,31 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
     const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
     qcon_pgs_lean<T, Tp, DppQuad, NJ, LO, D>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
                                              (T *)xs2 + (threadIdx.x >> 2) * XS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
+}
+
+// Engine::start / reset in the split form: the exact solve of the first pass (`ignoreBounds`), one quad per robot --
+// Woodbury in the operational space for the waves of that form (jm_qtip.h), an in-place Cholesky factorisation of the
+// square matrix for the others (`k_quad_con_split<1>` rebuilds the matrix in the next pass, like the single kernel)
+template<class T, class Tp>
+__global__ void __launch_bounds__(256)
+k_qcon_exact(const QConArgs<T> C)
+{
+    using RG = QSplitRegion<Tp>;
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
+    if (r >= (unsigned)C.split_r1) return;
+    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
+    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    const int k = (int)(threadIdx.x & 3);
+    T * const reg = (T *)(ws + g0);
+    const int hdr = (int)reg[RG::HDR];
+    const int m = hdr & 0xff;
+    const bool tip = ((hdr >> 24) & 1) != 0;
+    if constexpr (QTip<Tp>::ON)
+        if (DppQuad::wave_any(tip)) { qtip_exact<T, Tp, DppQuad>(k, ws, g0); return; }
+    if (m == 0) return;
+    const QStoreSq<T> W{reg};
+    const bool ok = qcon_chol<T, DppQuad, QStoreSq<T>, true>(k, m, W);
+    if (k == 0) reg[RG::OK] = ok ? T(1) : T(0);
 }
 
 // the solve in the operational-space form (jm_qtip.h): multipliers, z and the visit table of the block's 64 robots on chip

@@ -257,6 +257,101 @@ JM_DEV void qtip_build(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C
     }
 }
 
+// ---------------------------------------------------------------- exact solve (Engine::start, first pass)
+// `ignoreBounds` solve of ALL the active rows, A x = b (PGSSolver::SolveBoxedForwardDynamics with the exact pass of
+// Engine::start, engine.cc:1399-1467; the streamed form factorises A: qcon_chol).  With A = X E X^T + R this is the
+// Woodbury identity in the NE-dimensional operational space:
+//     x = R^-1 (b - X v),   (E^-1 + X^T R^-1 X) v = X^T R^-1 b,
+// solved in symmetric form: E = L L^T,  N = I + L^T G L  (G = X^T R^-1 X, block diagonal: one 6 x 6 block per tip, one
+// entry per joint slot),  v = L N^-1 L^T h.  Two 16 x 16 Cholesky factorisations instead of one of 64-96 rows.  Slots the
+// robot does not use (no row maps to them) are decoupled (unit diagonal).  Every lane of the quad computes the same small
+// system (private arrays); the rows of x are dealt over the lanes.  Returns false when a factorisation breaks down.
+template<class T, class Tp, class X>
+JM_DEV bool qtip_exact(int k, char * ws, unsigned g0)
+{
+    using RG = QSplitRegion<Tp>;
+    using TP = QTip<Tp>;
+    constexpr int NE = TP::NE, NCT = TP::NCT, REC = TP::REC;
+    auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
+    const int hdr = (int)G(RG::HDR);
+    if (!X::wave_any(((hdr >> 24) & 1) != 0)) return true;   // (a wave of the streamed form: k_qcon_chol's job)
+    const int m = hdr & 0xff;
+    if (m == 0) return true;
+    const int E0 = TP::e0(m), REC0 = TP::rec0(m);
+    T Gm[NE][NE], h[NE], L[NE][NE];
+    for (int a = 0; a < NE; ++a) { h[a] = T(0); for (int b = 0; b < NE; ++b) Gm[a][b] = T(0); }
+    // G = X^T R^-1 X and h = X^T R^-1 b over the rows
+    for (int i = 0; i < m; ++i)
+    {
+        const int rb = REC0 + REC * i;
+        const int zoff = (int)(unsigned)as_bits(G(rb + TP::RMETA));
+        const T ri = T(1) / G(rb + TP::RREG), bi = G(m + i);
+        T xr[6];
+        for (int a = 0; a < 6; ++a) xr[a] = G(rb + a);
+        const int n = zoff < 6 * NCT ? 6 : 1;
+        for (int a = 0; a < n; ++a)
+        {
+            h[zoff + a] += xr[a] * ri * bi;
+            for (int b = 0; b < n; ++b) Gm[zoff + a][zoff + b] += xr[a] * ri * xr[b];
+        }
+    }
+    // E with the unused slots decoupled, L = chol(E)
+    bool ok = true;
+    for (int a = 0; a < NE; ++a)
+        for (int b = 0; b <= a; ++b)
+        {
+            const bool used = Gm[a][a] > T(0) && Gm[b][b] > T(0);
+            T s_ = used ? G(E0 + a * NE + b) : (a == b ? T(1) : T(0));
+            for (int c = 0; c < b; ++c) s_ -= L[a][c] * L[b][c];
+            if (a == b) { ok &= s_ > T(0); L[a][a] = sqrt_(s_); }
+            else L[a][b] = s_ / L[b][b];
+        }
+    // N = I + L^T G L (symmetric), factorised in place into the lower triangle of Gm
+    {
+        T GL[NE][NE];   // G L
+        for (int a = 0; a < NE; ++a)
+            for (int b = 0; b < NE; ++b)
+            {
+                T s_ = T(0);
+                for (int c = b; c < NE; ++c) s_ += Gm[a][c] * L[c][b];
+                GL[a][b] = s_;
+            }
+        for (int a = 0; a < NE; ++a)
+            for (int b = 0; b <= a; ++b)
+            {
+                T s_ = a == b ? T(1) : T(0);
+                for (int c = a; c < NE; ++c) s_ += L[c][a] * GL[c][b];
+                Gm[a][b] = s_;
+            }
+    }
+    for (int a = 0; a < NE; ++a)
+        for (int b = 0; b <= a; ++b)
+        {
+            T s_ = Gm[a][b];
+            for (int c = 0; c < b; ++c) s_ -= Gm[a][c] * Gm[b][c];
+            if (a == b) { ok &= s_ > T(0); Gm[a][a] = sqrt_(s_); }
+            else Gm[a][b] = s_ / Gm[b][b];
+        }
+    // v = L N^-1 L^T h
+    T u[NE], v[NE];
+    for (int a = 0; a < NE; ++a) { T s_ = T(0); for (int c = a; c < NE; ++c) s_ += L[c][a] * h[c]; u[a] = s_; }
+    for (int a = 0; a < NE; ++a) { T s_ = u[a]; for (int c = 0; c < a; ++c) s_ -= Gm[a][c] * u[c]; u[a] = s_ / Gm[a][a]; }
+    for (int a = NE - 1; a >= 0; --a) { T s_ = u[a]; for (int c = a + 1; c < NE; ++c) s_ -= Gm[c][a] * u[c]; u[a] = s_ / Gm[a][a]; }
+    for (int a = 0; a < NE; ++a) { T s_ = T(0); for (int c = 0; c <= a; ++c) s_ += L[a][c] * u[c]; v[a] = s_; }
+    // x = R^-1 (b - X v)
+    for (int i = k; i < m; i += 4)
+    {
+        const int rb = REC0 + REC * i;
+        const int zoff = (int)(unsigned)as_bits(G(rb + TP::RMETA));
+        const int n = zoff < 6 * NCT ? 6 : 1;
+        T s_ = G(m + i);
+        for (int a = 0; a < n; ++a) s_ -= G(rb + a) * v[zoff + a];
+        G(i) = s_ / G(rb + TP::RREG);
+    }
+    if (k == 0) G(RG::OK) = ok ? T(1) : T(0);
+    return ok;
+}
+
 // ---------------------------------------------------------------- the solve
 // Visit table of a sweep in this form: like qcon_visit_table (same order: joint rows -- user-registered JointConstraints
 // first --, normal forces, torsion rows, friction cones), but a friction cone is ONE visit (kind 5, row = its first tangential

@@ -1738,6 +1738,7 @@ template<class Tp> constexpr int qcon_first_contact_row()   // = number of bound
 template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_contact_row<Tp>(); }   // ConRows<Tp>::LAM
 template<class T> struct QConArgs;
 template<class T> struct QStore;
+template<class Tp> struct QSplitRegion;   // (jm_qcon.h)
 template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH = 0>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
@@ -1785,7 +1786,12 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     if (A.mode == MODE_DYNAMICS) { qsrc = A.q_in; vsrc = A.v_in; }
     if (A.mode == MODE_RESET)
     {
-        if (!A.mask[r32]) return;  // uniform over the quad
+        if (!A.mask[r32])  // uniform over the quad
+        {
+            // (split form of a reset: the solve kernels run over every robot of the launch -- nothing to solve for this one)
+            if constexpr (PH == 1) { if (k == 0) V->hbm[QSplitRegion<Tp>::HDR] = T(0); }
+            return;
+        }
         qsrc = A.q_init; vsrc = A.v_init;
     }
     const T dt = A.dt;
@@ -1831,6 +1837,8 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
         });
         // NaN guard on the incoming state (engine.cc:1737-1747)
         if (bad && stepping) status |= JM_LANE_NAN;
+        // (Engine::start in the split form: the later passes carry the status of the earlier ones)
+        if constexpr (PH == 1) { if (C->split_pass > 0) status |= (int)S.getl(SR::STATUSL); }
     }
     else
     {
@@ -1978,8 +1986,10 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                     S.putl(SR::CURVL + decltype(sc)::value, vl[decltype(sc)::value]);
                 });
             }
+            // (start / reset in the split form: the four passes of Engine::start are launches of their own, C->split_pass)
             quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN, PH>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last,
-                                    A.update_sensors != 0, ddqb, ddq, status, 0);
+                                    !stepping || A.update_sensors != 0, ddqb, ddq, status,
+                                    (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : 0);
             if (PH == 1 || !last)
             {
                 S.putl(SR::STATUSL, (T)status);

@@ -221,9 +221,55 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                 {
                     jm::QConArgs<T> C = C0;
                     C.ws = region.data();
-                    C.stage = nullptr; C.split_r0 = 0; C.split_r1 = (int)A.B;
+                    C.stage = nullptr; C.split_pass = 0; C.split_r0 = 0; C.split_r1 = (int)A.B;
                     const jm::QStore<T> V{nullptr, region.data() + (size_t)r * RG::ROWS, 1u, 0};
                     const T friction = C.friction ? C.friction[r] : P[jm::Layout<Tp>::OPT + 8];
+                    char * ws = (char *)region.data();
+                    const unsigned g0 = (unsigned)((size_t)r * RG::ROWS * sizeof(T));
+                    auto solve = [&]() {
+                        bool tip = false;
+                        if constexpr (jm::QTip<Tp>::ON)
+                            tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), vis.data(), ws, g0);
+                        if (tip) { if (k == 0) ++g_tip_solves; }
+                        else if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
+                            jm::qcon_pgs_lean<T, Tp, HostQuad, 12, 64, JM_QCON_PGS_DEPTH - 1>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0);
+                    };
+                    if (A.mode == jm::MODE_START || A.mode == jm::MODE_RESET)
+                    {
+                        // Engine::start / reset in the split form (jm_lib.cpp launch_quad_con): first pass | exact solve |
+                        // 3 x (pass | Gauss-Seidel) | closing evaluation
+                        if (A.mode == jm::MODE_RESET && !A.mask[r]) continue;
+                        C.split_e = 0;
+                        jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 1>(A, r, k, table, S, &C, &V);
+                        HostQuad::sync();
+                        {
+                            T * reg = region.data() + (size_t)r * RG::ROWS;
+                            const int hdr = (int)reg[RG::HDR];
+                            const int m_ = hdr & 0xff;
+                            bool ok = true;
+                            if ((hdr >> 24) & 1) { if constexpr (jm::QTip<Tp>::ON) { ok = jm::qtip_exact<T, Tp, HostQuad>(k, ws, g0); if (k == 0) ++g_tip_solves; } }
+                            else if (m_ > 0)
+                            {
+                                const jm::QStoreSq<T> W{reg};
+                                ok = jm::qcon_chol<T, HostQuad, jm::QStoreSq<T>, true>(k, m_, W);
+                                HostQuad::sync();
+                                if (k == 0) reg[RG::OK] = ok ? T(1) : T(0);
+                            }
+                        }
+                        HostQuad::sync();
+                        for (int pass = 1; pass <= 3; ++pass)
+                        {
+                            C.split_pass = pass;
+                            jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 1>(A, r, k, table, S, &C, &V);
+                            HostQuad::sync();
+                            solve();
+                            HostQuad::sync();
+                        }
+                        C.split_pass = 4;
+                        jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 2>(A, r, k, table, S, &C, &V);
+                        HostQuad::sync();
+                        continue;
+                    }
                     for (int e = 0; e < n_evals; ++e)
                     {
                         C.split_e = e;
@@ -232,14 +278,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                         std::fprintf(stderr, "[%d] r=%lld e=%d after pre: %lld barriers\n", k, r, e, g_bar_count);
 #endif
                         HostQuad::sync();
-                        char * ws = (char *)region.data();
-                        const unsigned g0 = (unsigned)((size_t)r * RG::ROWS * sizeof(T));
-                        bool tip = false;
-                        if constexpr (jm::QTip<Tp>::ON)
-                            tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), vis.data(), ws, g0);
-                        if (tip) { if (k == 0) ++g_tip_solves; }
-                        else if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
-                            jm::qcon_pgs_lean<T, Tp, HostQuad, 12, 64, JM_QCON_PGS_DEPTH - 1>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0);
+                        solve();
                         HostQuad::sync();
                         jm::quad_lane_run<T, Tp, HostQuad, 1, 1, true, 0, false, 2>(A, r, k, table, S, &C, &V);
                         HostQuad::sync();
@@ -348,7 +387,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             const bool gen_ = gen || locks;
             bool split = false;
             if constexpr (std::is_same<T, double>::value)
-                if (!gen && g_split && jm::qcon_split<Topo>() && mode == jm::MODE_STEP)
+                if (!gen && g_split && jm::qcon_split<Topo>() && (mode == jm::MODE_STEP || mode == jm::MODE_START || mode == jm::MODE_RESET))
                 {
                     run_quad_con_split<T, Topo>(A, P, C);
                     split = true;

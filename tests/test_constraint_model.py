@@ -246,7 +246,7 @@ def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
     B = (3 if variant == "lane" else 6) if name == "atlas" else (8 if variant == "lane" else 12)   # (sized for the CPU suite)
     ref, got = _pair(model, B, seed=7)
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
-    emu.run(model, got, "start", constraint_options=TIGHT, variant=variant)
+    emu.run(model, got, "start", constraint_options=TIGHT, variant=variant, split=split)   # (split: the start passes as launches too)
     _check(got, ref, 1e-9, "start")
     n_active = int((ref["con_flags"] & 1).sum())
     assert n_active > 0 or _abi.constraint_rows(model)["n_rows"] == 0
@@ -332,7 +332,7 @@ def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
     lib = emu._lib(model)
     before = lib.emu_guard_violations()
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
-    emu.run(model, got, "start", constraint_options=TIGHT, variant="quad")
+    emu.run(model, got, "start", constraint_options=TIGHT, variant="quad", split=split)
     nb = _abi.constraint_rows(model)["n_bounds"]
     assert int((ref["con_flags"][nb:, 0] & 1).sum()) == 16 and int((ref["con_flags"][:nb, 0] & 1).sum()) >= 3
     _check(got, ref, 1e-8, "start")
@@ -342,6 +342,49 @@ def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
         emu.run(model, got, "step", constraint_options=TIGHT, variant="quad", split=split, **kw)
     _check(got, ref, 1e-6, "steps")
     assert lib.emu_guard_violations() == before
+
+
+def test_split_start_with_many_active_joint_bounds_on_the_host():
+    """`start` / `reset` of robots with large solves as launches of the split kernels (first pass | exact solve | 3 x (pass |
+    Gauss-Seidel) | closing evaluation, jm_lib.cpp): a robot with MORE than four active joint rows keeps the streamed
+    form of the solve -- in-place Cholesky factorisation of the square matrix for the exact pass, the matrix rebuilt in
+    the next pass --, one with few takes the operational-space form (Woodbury); both against the oracle's Engine::start,
+    then a masked reset of one of them."""
+    from jiminy_amd.synthetic import lowest_contact_height
+    model = load_builtin("atlas")
+    B = 2
+    q = np.repeat(model.neutral()[:, None], B, axis=1)
+    mask = model.bounded_position_mask()
+    idx = np.flatnonzero(mask)
+    q[mask] = np.clip(q[mask], (model.position_lower[mask] + 0.05)[:, None], (model.position_upper[mask] - 0.05)[:, None])
+    # robot 0: seven joints beyond a bound; robot 1: one
+    for n, lane in ((7, 0), (1, 1)):
+        for j in idx[3:3 + 2 * n:2]:
+            q[j, lane] = model.position_upper[j] + 0.01
+    q[2] -= lowest_contact_height(model, q) + 2.0e-3
+    ref, got = alloc_soa(model, B), alloc_soa(model, B)
+    for arr in (ref, got):
+        alloc_constraint_state(model, arr, B)
+        arr["q"][:] = q
+    before = emu.tip_solves(model)
+    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    emu.run(model, got, "start", constraint_options=TIGHT, variant="quad", split=True)
+    nb = _abi.constraint_rows(model)["n_bounds"]
+    assert int((ref["con_flags"][:nb, 0] & 1).sum()) >= 7 and int((ref["con_flags"][:nb, 1] & 1).sum()) <= 4
+    _check(got, ref, 1e-8, "start")
+    assert np.array_equal(got["con_flags"], ref["con_flags"])
+    # robot 1 went through the operational-space form (exact solve + three passes), robot 0 did not
+    assert emu.tip_solves(model) - before == 4
+    # masked reset of robot 0 only, to the same state: the start sequence again for that lane (bit for bit: reference pin 11),
+    # nothing touched for the other one
+    snap = {k: got[k].copy() for k in OUTS}
+    got["q_init"], got["v_init"] = q.copy(), np.zeros_like(got["v"])
+    got["mask"] = np.array([1, 0], dtype=np.uint8)
+    got["a"][:, 1] += 1.0          # (a reset must not rewrite the lane that is not restarting)
+    snap["a"][:, 1] += 1.0
+    emu.run(model, got, "reset", constraint_options=TIGHT, variant="quad", split=True)
+    for k in OUTS:
+        assert np.array_equal(got[k], snap[k]), k
 
 
 @pytest.mark.parametrize("torsion", [0.0, 0.3])
