@@ -52,6 +52,7 @@ extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH
 extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qcon_exact<double, Topo>(const QConArgs<double>);
+extern template __global__ void k_qtip_exact<double, Topo>(const QConArgs<double>);
 #endif
 }
 #endif
@@ -281,6 +282,8 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                 C.split_pass = 0;
                 hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
                 hipLaunchKernelGGL((jm::k_qcon_exact<double, Tp>), dim3(g64), dim3(256), 0, s, C);
+                if constexpr (jm::QTip<Tp>::ON)
+                    hipLaunchKernelGGL((jm::k_qtip_exact<double, Tp>), dim3((unsigned)((A.B + 255) / 256)), dim3(256), 0, s, C);
                 for (int pass = 1; pass <= 3; ++pass)
                 {
                     C.split_pass = pass;

@@ -48,5 +48,6 @@ template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>
 #elif JM_CON_PART == 10 && JM_TOPO_QCON_SPLIT
 template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
 template __global__ void k_qcon_exact<double, Topo>(const QConArgs<double>);
+template __global__ void k_qtip_exact<double, Topo>(const QConArgs<double>);
 #endif
 }

@@ -2178,22 +2178,30 @@ template<class T, class Tp>
 __global__ void __launch_bounds__(256)
 k_qcon_exact(const QConArgs<T> C)
 {
+    // (streamed form: one quad per robot; the robots of the operational-space form are k_qtip_exact's)
     using RG = QSplitRegion<Tp>;
     const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
     if (r >= (unsigned)C.split_r1) return;
-    char * const ws = (char *)(C.ws + ((size_t)C.split_r0 + (size_t)blockIdx.x * 64) * (size_t)RG::ROWS);
-    const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
+    T * const reg = C.ws + (size_t)r * (size_t)RG::ROWS;
     const int k = (int)(threadIdx.x & 3);
-    T * const reg = (T *)(ws + g0);
     const int hdr = (int)reg[RG::HDR];
     const int m = hdr & 0xff;
-    const bool tip = ((hdr >> 24) & 1) != 0;
-    if constexpr (QTip<Tp>::ON)
-        if (DppQuad::wave_any(tip)) { qtip_exact<T, Tp, DppQuad>(k, ws, g0); return; }
-    if (m == 0) return;
+    if (m == 0 || ((hdr >> 24) & 1) != 0) return;   // (uniform over the quad)
     const QStoreSq<T> W{reg};
     const bool ok = qcon_chol<T, DppQuad, QStoreSq<T>, true>(k, m, W);
     if (k == 0) reg[RG::OK] = ok ? T(1) : T(0);
+}
+// ... and of the operational-space form: ONE LANE per robot (the 20-dimensional system is the same small serial computation
+// for every lane: 64 robots per wave instead of 16)
+template<class T, class Tp>
+__global__ void __launch_bounds__(256)
+k_qtip_exact(const QConArgs<T> C)
+{
+    using RG = QSplitRegion<Tp>;
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 256u + threadIdx.x;
+    if (r >= (unsigned)C.split_r1) return;
+    if constexpr (QTip<Tp>::ON)
+        qtip_exact<T, Tp, DppQuad, 1>(0, (char *)C.ws, (size_t)r * (size_t)RG::ROWS * sizeof(T));
 }
 
 // the solve in the operational-space form (jm_qtip.h): multipliers, z and the visit table of the block's 64 robots on chip

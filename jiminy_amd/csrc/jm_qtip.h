@@ -6,7 +6,7 @@
 // the contact rows is therefore  X E X^T + R  with
 //   E  the inverse operational-space inertia of the contact-bearing tip bodies and the active joint rows: the response
 //      (spatial acceleration of every tip body, acceleration of every bounded joint) to a unit wrench on a tip body / a unit
-//      effort on a joint -- NE x NE with NE = 6 tips + joint slots, 16 for Atlas whatever the number of contact points;
+//      effort on a joint -- NE x NE with NE = 6 tips + joint slots, 20 for Atlas whatever the number of contact points;
 //   X  one 6-vector per contact row: direction d at point p -> (d, p x d) (a torsion row about n: (0, n)), a unit entry
 //      (+-1, the bound's direction) per joint row;
 //   R  the diagonal regularisation (constraint_solvers.cc:376-387).
@@ -54,7 +54,8 @@ template<class Tp> struct QTip
         for (int i = 0; i < k; ++i) n += Tp::limb_ncontact[i] > 0 ? 1 : 0;
         return n;
     }
-    static constexpr int NBX = 4;                 // joint rows (active bounds / user joint constraints) of a solve in this form
+    static constexpr int NBX = 8;                 // joint rows (active bounds / user joint constraints) of a solve in this form
+                                                  // (Atlas standing in its neutral pose already has five joints at a limit)
     static constexpr int NE = 6 * NCT + NBX;      // extended operational space
     static constexpr int ZL = (NE + 3) / 4;       // entries of z / rows of E per lane (entry e: lane e & 3, slot e >> 2)
     static constexpr bool ON = JM_QTIP != 0 && qcon_split<Tp>() && NCT >= 1 && NCT <= 2;
@@ -263,18 +264,18 @@ JM_DEV void qtip_build(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C
 // Woodbury identity in the NE-dimensional operational space:
 //     x = R^-1 (b - X v),   (E^-1 + X^T R^-1 X) v = X^T R^-1 b,
 // solved in symmetric form: E = L L^T,  N = I + L^T G L  (G = X^T R^-1 X, block diagonal: one 6 x 6 block per tip, one
-// entry per joint slot),  v = L N^-1 L^T h.  Two 16 x 16 Cholesky factorisations instead of one of 64-96 rows.  Slots the
+// entry per joint slot),  v = L N^-1 L^T h.  Two NE x NE (20 x 20) Cholesky factorisations instead of one of 64-96 rows.  Slots the
 // robot does not use (no row maps to them) are decoupled (unit diagonal).  Every lane of the quad computes the same small
 // system (private arrays); the rows of x are dealt over the lanes.  Returns false when a factorisation breaks down.
-template<class T, class Tp, class X>
-JM_DEV bool qtip_exact(int k, char * ws, unsigned g0)
+template<class T, class Tp, class X, int LANES = 4>
+JM_DEV bool qtip_exact(int k, char * ws, size_t g0)
 {
     using RG = QSplitRegion<Tp>;
     using TP = QTip<Tp>;
     constexpr int NE = TP::NE, NCT = TP::NCT, REC = TP::REC;
-    auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
+    auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (size_t)(unsigned)e * sizeof(T))); };
     const int hdr = (int)G(RG::HDR);
-    if (!X::wave_any(((hdr >> 24) & 1) != 0)) return true;   // (a wave of the streamed form: k_qcon_chol's job)
+    if (((hdr >> 24) & 1) == 0) return true;   // (a robot of the streamed form: the quad-cooperative factorisation's job)
     const int m = hdr & 0xff;
     if (m == 0) return true;
     const int E0 = TP::e0(m), REC0 = TP::rec0(m);
@@ -339,7 +340,7 @@ JM_DEV bool qtip_exact(int k, char * ws, unsigned g0)
     for (int a = NE - 1; a >= 0; --a) { T s_ = u[a]; for (int c = a + 1; c < NE; ++c) s_ -= Gm[c][a] * u[c]; u[a] = s_ / Gm[a][a]; }
     for (int a = 0; a < NE; ++a) { T s_ = T(0); for (int c = 0; c <= a; ++c) s_ += L[a][c] * u[c]; v[a] = s_; }
     // x = R^-1 (b - X v)
-    for (int i = k; i < m; i += 4)
+    for (int i = k; i < m; i += LANES)
     {
         const int rb = REC0 + REC * i;
         const int zoff = (int)(unsigned)as_bits(G(rb + TP::RMETA));
@@ -396,13 +397,16 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
     for (int i = k; i < m; i += 4) { x[i] = G(i); G(REC0 + REC * i + TP::RB) = G(m + i); G(REC0 + REC * i + TP::RYP) = T(0); }
     if (lead) { x[m] = T(0); x[m + 1] = T(0); }
     for (int i = k; i < TP::ZPAD; i += 4) z[i] = T(0);
-    // this lane's rows of E
-    T Er[ZL][NE];
+    // this lane's rows of E: the columns of the tips in registers (what every contact row needs), the columns of the joint
+    // slots stay in the region (read by the few joint rows of a sweep: 32 registers less)
+    constexpr int NTC = 6 * NCT;
+    T Er[ZL][NTC];
     static_for<0, ZL>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int e = 4 * j + k;
-        static_for<0, NE>([&](auto cc) { Er[j][decltype(cc)::value] = e < NE ? G(E0 + (e < NE ? e : 0) * NE + decltype(cc)::value) : T(0); });
+        static_for<0, NTC>([&](auto cc) { Er[j][decltype(cc)::value] = e < NE ? G(E0 + (e < NE ? e : 0) * NE + decltype(cc)::value) : T(0); });
     });
+    auto Eb = [&](int j, int b) -> T { const int e = 4 * j + k; return e < NE ? G(E0 + e * NE + NTC + b) : T(0); };
     const unsigned long long lockp = (unsigned long long)G(RG::LOCK);
     const int nv = qtip_visit_table(k, m, nb, cb, lockp, vt);
     X::fence();
@@ -437,7 +441,8 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
         static_for<0, ZL>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             T s_ = T(0);
-            static_for<0, NE>([&](auto cc) { s_ += Er[j][decltype(cc)::value] * w[decltype(cc)::value]; });
+            static_for<0, NTC>([&](auto cc) { s_ += Er[j][decltype(cc)::value] * w[decltype(cc)::value]; });
+            static_for<0, NBX>([&](auto bc) { s_ += Eb(j, decltype(bc)::value) * w[NTC + decltype(bc)::value]; });
             zo[j] = s_;
             if (4 * j + k < NE) z[4 * j + k] = s_;
         });
@@ -571,11 +576,7 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                 });
             });
             if (cur.zoff >= 6 * NCT)
-                static_for<0, NBX>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    const T gm = cur.zoff == 6 * NCT + b ? gb : T(0);
-                    static_for<0, ZL>([&](auto jc) { zo[decltype(jc)::value] += Er[decltype(jc)::value][6 * NCT + b] * gm; });
-                });
+                static_for<0, ZL>([&](auto jc) { zo[decltype(jc)::value] += Eb(decltype(jc)::value, cur.zoff - 6 * NCT) * gb; });
             static_for<0, ZL>([&](auto jc) { if (4 * decltype(jc)::value + k < NE) z[4 * decltype(jc)::value + k] = zo[decltype(jc)::value]; });
             X::sync();   // (multipliers and z in place before the next visit reads them)
             if (++tt == nv)

@@ -247,7 +247,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                             const int hdr = (int)reg[RG::HDR];
                             const int m_ = hdr & 0xff;
                             bool ok = true;
-                            if ((hdr >> 24) & 1) { if constexpr (jm::QTip<Tp>::ON) { ok = jm::qtip_exact<T, Tp, HostQuad>(k, ws, g0); if (k == 0) ++g_tip_solves; } }
+                            if ((hdr >> 24) & 1) { if constexpr (jm::QTip<Tp>::ON) { if (k == 0) { ok = jm::qtip_exact<T, Tp, HostQuad, 1>(0, ws, (size_t)g0); ++g_tip_solves; } } }
                             else if (m_ > 0)
                             {
                                 const jm::QStoreSq<T> W{reg};

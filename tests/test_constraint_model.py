@@ -346,7 +346,7 @@ def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
 
 def test_split_start_with_many_active_joint_bounds_on_the_host():
     """`start` / `reset` of robots with large solves as launches of the split kernels (first pass | exact solve | 3 x (pass |
-    Gauss-Seidel) | closing evaluation, jm_lib.cpp): a robot with MORE than four active joint rows keeps the streamed
+    Gauss-Seidel) | closing evaluation, jm_lib.cpp): a robot with MORE than eight active joint rows keeps the streamed
     form of the solve -- in-place Cholesky factorisation of the square matrix for the exact pass, the matrix rebuilt in
     the next pass --, one with few takes the operational-space form (Woodbury); both against the oracle's Engine::start,
     then a masked reset of one of them."""
@@ -357,8 +357,8 @@ def test_split_start_with_many_active_joint_bounds_on_the_host():
     mask = model.bounded_position_mask()
     idx = np.flatnonzero(mask)
     q[mask] = np.clip(q[mask], (model.position_lower[mask] + 0.05)[:, None], (model.position_upper[mask] - 0.05)[:, None])
-    # robot 0: seven joints beyond a bound; robot 1: one
-    for n, lane in ((7, 0), (1, 1)):
+    # robot 0: eleven joints beyond a bound (more than the operational-space form takes, QTip::NBX = 8); robot 1: one
+    for n, lane in ((11, 0), (1, 1)):
         for j in idx[3:3 + 2 * n:2]:
             q[j, lane] = model.position_upper[j] + 0.01
     q[2] -= lowest_contact_height(model, q) + 2.0e-3
@@ -370,7 +370,7 @@ def test_split_start_with_many_active_joint_bounds_on_the_host():
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
     emu.run(model, got, "start", constraint_options=TIGHT, variant="quad", split=True)
     nb = _abi.constraint_rows(model)["n_bounds"]
-    assert int((ref["con_flags"][:nb, 0] & 1).sum()) >= 7 and int((ref["con_flags"][:nb, 1] & 1).sum()) <= 4
+    assert int((ref["con_flags"][:nb, 0] & 1).sum()) >= 9 and int((ref["con_flags"][:nb, 1] & 1).sum()) <= 8
     _check(got, ref, 1e-8, "start")
     assert np.array_equal(got["con_flags"], ref["con_flags"])
     # robot 1 went through the operational-space form (exact solve + three passes), robot 0 did not
