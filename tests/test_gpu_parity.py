@@ -674,3 +674,33 @@ def test_simulate_runs_to_t_end_or_until_the_callback_stops_it(gpu_device):
     eng.set_options({"stepper": {"iterMax": 12}})
     eng.simulate(0.05, q0, v0)
     assert eng.stepper_state.iter == 12
+
+
+def test_bench_line_runs_the_full_extra_terms(gpu_device):
+    """The driver's command on a small batch: ONE JSON line whose launch ran the whole `computeExtraTerms` (the three
+    optional outputs bound and written), with the roofline object priced on the algorithmic bytes of SURVEY.md 8d and the
+    secondary workloads declared (ANYmal euler + constraint model = the reference's shipped options, Atlas both ways)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "4096",
+                          "--episode", "3", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("env-steps/s") and rec["unit"] == "env-steps/s" and rec["dtype"] == "f64"
+    assert rec["steps"] == 6 and rec["warmup"] == 2 and rec["n_gpus"] == 1 and rec["vs_baseline"] is None
+    cfg = rec["config"]
+    assert cfg["extra_terms"] == "full" and cfg["extra_terms_written"] is True and "computeExtraTerms" in cfg["workload"]
+    rf = rec["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches_timed"] == 6
+    assert rf["algorithmic_bytes_per_launch"] == 188 * 8 * 4096           # SURVEY.md 8d: 188 scalars per ANYmal env-step
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.0 < rf["avg_launch_ms"] < rec["ms_per_step"] * 1.5
+    sys.path.insert(0, root)
+    import bench
+    assert [(c["model_name"], c["contact_model"], c["solver"]) for c in bench.SECONDARY] == [
+        ("anymal", "constraint", "euler_explicit"), ("atlas", "spring_damper", "runge_kutta_4"), ("atlas", "constraint", "euler_explicit")]
+    assert set(bench.FULL_EXTRA_OUTPUTS) >= {"energy", "joint_forces", "centroidal"}
