@@ -61,15 +61,19 @@ def quad_structure(model: CompiledModel):
             j = parents[j]
         if chain:
             chains.append(chain[::-1])
-    if len(chains) < 4:
+    # Two or three leaf chains (a biped without arms, a tripod): the missing limbs are EMPTY -- padded with dummy joints
+    # from the first one on, attached to the root, no contact point: their lanes idle, but the robot keeps the
+    # register-resident branch-parallel kernel instead of the one-robot-per-lane fallback (kilobytes of scratch per lane)
+    if len(chains) < 2:
         return None
     chains.sort(key=lambda c: (-len(c), c[0]))
     limbs = sorted(chains[:4], key=lambda c: c[0])
+    limbs += [[] for _ in range(4 - len(limbs))]
     limb_set = {j for c in limbs for j in c}
     trunk = [j for j in range(1, nj) if j not in limb_set]          # topological (index) order
     if any(int(model.jtypes[j]) not in ONE_DOF for j in trunk[1:]):
         return None
-    if any(parents[c[0]] not in trunk for c in limbs) or any(parents[j] not in trunk for j in trunk[1:]):
+    if any(parents[c[0]] not in trunk for c in limbs if c) or any(parents[j] not in trunk for j in trunk[1:]):
         return None
     n = max(len(c) for c in limbs)
     # the padded limbs must do most of the work, otherwise the redundancy does not pay
@@ -86,7 +90,7 @@ def quad_structure(model: CompiledModel):
     pad = lambda row: list(row) + [-1] * (n - len(row))  # noqa: E731
     # contacts: only on limb tips
     cj = [model.frames[c].parent_joint for c in model.contacts]
-    limb_contacts = [[i for i, j in enumerate(cj) if j == c[-1]] for c in limbs]
+    limb_contacts = [[i for i, j in enumerate(cj) if c and j == c[-1]] for c in limbs]
     if sum(len(x) for x in limb_contacts) != len(cj):
         return None
     ncl = max([len(x) for x in limb_contacts] + [0])
@@ -96,7 +100,7 @@ def quad_structure(model: CompiledModel):
     if any(j not in tindex for j in imu):
         return None
     fj = [model.frames[x["frame"]].parent_joint for x in s.get("ForceSensor", [])]
-    limb_force = [[i for i, j in enumerate(fj) if j == c[-1]] for c in limbs]
+    limb_force = [[i for i, j in enumerate(fj) if c and j == c[-1]] for c in limbs]
     has_force = len(fj) > 0
     if any(len(x) > 1 for x in limb_force) or sum(len(x) for x in limb_force) != len(fj):
         return None
@@ -123,7 +127,7 @@ def quad_structure(model: CompiledModel):
         "trunk_enc": [-1] + [enc_of.get(j, -1) for j in trunk[1:]],
         "trunk_eff": [-1] + [eff_of.get(motor_of[j], -1) for j in trunk[1:]],
         "limb_len": [len(c) for c in limbs],
-        "limb_attach": [tindex[parents[c[0]]] for c in limbs],
+        "limb_attach": [tindex[parents[c[0]]] if c else 0 for c in limbs],
         "limb_joint": [pad(c) for c in limbs],
         "motor": [pad([motor_of[j] for j in c]) for c in limbs],
         "limb_ncontact": [len(x) for x in limb_contacts],

@@ -61,6 +61,15 @@ def crane_walker() -> CompiledModel:
                        has_freeflyer=True, name="crane_walker")
 
 
+def biped(torso: bool = False) -> CompiledModel:
+    """Free-flying biped without arms: two 3-joint legs with toe / heel contact points (two leaf chains), optionally a
+    1-joint torso on a waist joint (three uneven leaf chains). `codegen.quad_structure` completes the decomposition with
+    empty limbs, so the branch-parallel kernels serve it."""
+    name = "biped_torso" if torso else "biped"
+    return build_robot(os.path.join(DATA, name + ".urdf"), os.path.join(DATA, name + "_hardware.toml"),
+                       has_freeflyer=True, name=name)
+
+
 def hanging_pendulum() -> CompiledModel:
     """The reference's `simple_pendulum` fixture restated (tests/data/hanging_pendulum.urdf): bob welded 1 m below the
     pivot, motor without limits or armature (unit_py/utilities.py:18-59 `load_urdf_default`), IMU on the bob."""
@@ -81,4 +90,4 @@ def foot_pendulum() -> CompiledModel:
 
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
-            tree_arm(True), crane_walker()]
+            tree_arm(True), crane_walker(), biped(False), biped(True)]

@@ -190,6 +190,8 @@ def _models():
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
         "crane_walker": robots.crane_walker,
+        "biped": robots.biped,
+        "biped_torso": lambda: robots.biped(True),
     }
 
 
@@ -229,7 +231,8 @@ def _check(got, ref, tol, what=""):
         assert e < tol, (what, k, e)
 
 
-QUAD_MODELS = ("anymal", "atlas", "crane_walker")   # served by the branch-parallel kernel (jm_qcon.h)
+# served by the branch-parallel kernel (jm_qcon.h); the bipeds with two / one empty limbs (codegen.quad_structure)
+QUAD_MODELS = ("anymal", "atlas", "crane_walker", "biped", "biped_torso")
 
 
 @pytest.mark.parametrize("name,variant", [(n, "lane") for n in _models()] + [(n, "quad") for n in QUAD_MODELS] + [("atlas", "split")])
@@ -457,7 +460,7 @@ def test_spring_damper_path_is_untouched_by_the_constraint_state():
 
 # ------------------------------------------------------------------ device build (C ABI) vs oracle
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "point_mass"])
+@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "point_mass", "biped", "biped_torso"])
 def test_gpu_constraint_model_matches_oracle(name, gpu_device):
     import torch
 
@@ -717,7 +720,7 @@ def test_gpu_constrained_solution_satisfies_the_equation_of_motion(name, gpu_dev
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "cartpole"])
+@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "cartpole", "biped"])
 def test_gpu_constraint_kernel_self_test(name, gpu_device):
     """The engine's own guard against an unsound build of the constraint kernel:
     equation-of-motion residual from the device's RNEA outputs, run once per topology."""

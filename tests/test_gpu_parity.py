@@ -59,18 +59,24 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
 
 
 @pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff",
-                                   "crane_walker"])
+                                   "crane_walker", "biped", "biped_torso"])
 def test_small_robots_cover_every_joint_type(gpu_device, robot):
     """Authored test robots: aligned / unaligned revolute and prismatic joints, unbounded joints,
     fixed and floating base, friction motors, world-fixed contact frames (lane kernel) and, with
     crane_walker, the branch-parallel kernel on a trunk tree with a prismatic + an unaligned joint,
-    padded limbs on two attachment joints and a ragged batch (B % 16 != 0)."""
+    padded limbs on two attachment joints and a ragged batch (B % 16 != 0); with the bipeds, the same kernel on robots
+    with two / three leaf chains only (empty limbs)."""
     from tests import robots
     model = {"pendulum": robots.pendulum, "point_mass": robots.point_mass, "two_masses": robots.two_masses,
              "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True),
-             "crane_walker": robots.crane_walker}[robot]()
-    B, dt = (203, 2.5e-4) if robot == "crane_walker" else (192, 5e-4)
-    st = sample_states(model, B, seed=21, base_height=(0.3, 0.6), grounded_fraction=0.5)
+             "crane_walker": robots.crane_walker, "biped": robots.biped, "biped_torso": lambda: robots.biped(True)}[robot]()
+    quad = robot in ("crane_walker", "biped", "biped_torso")
+    if quad:
+        from jiminy_amd import codegen
+        assert codegen.quad_structure(model) is not None
+    B, dt = (203, 2.5e-4) if quad else (192, 5e-4)
+    st = sample_states(model, B, seed=21, base_height=(0.55, 0.75) if robot.startswith("biped") else (0.3, 0.6),
+                       grounded_fraction=0.5)
     ref = alloc_soa(model, B)
     for k in ("q", "v", "command"):
         if st[k].shape[0]:
@@ -527,11 +533,12 @@ def test_adaptive_dopri_ragged_and_tiny_batches(gpu_device, B):
     assert abs(ss.t - 0.02) < 1e-12
 
 
-def test_adaptive_dopri_crane_walker_trunk_tree_and_ragged_limbs(gpu_device):
-    """The persistent stepper on the authored robot with a prismatic / unaligned trunk tree and limbs of 3/3/2/2 joints
-    (its library is the one that needs build variant 1): landings on the spring-damper ground, against the oracle."""
+@pytest.mark.parametrize("name", ["crane_walker", "biped_torso"])
+def test_adaptive_dopri_crane_walker_trunk_tree_and_ragged_limbs(gpu_device, name):
+    """The persistent stepper on the authored robot with a prismatic / unaligned trunk tree and limbs of 3/3/2/2 joints,
+    and on the biped with limbs of 3/3/1/0 joints: landings on the spring-damper ground, against the oracle."""
     from tests import robots
-    model = robots.crane_walker()
+    model = robots.crane_walker() if name == "crane_walker" else robots.biped(True)
     B = 48
     st = sample_states(model, B, seed=19, base_height=(0.5, 0.8), grounded_fraction=0.4, command_fraction=0.2)
     eng, ref, ad = _dopri_pair(model, B, st, 5e-3, 6, 1e-7, 1e-8)

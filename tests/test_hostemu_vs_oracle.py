@@ -25,6 +25,8 @@ def _models():
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
         "crane_walker": robots.crane_walker,
+        "biped": robots.biped,
+        "biped_torso": lambda: robots.biped(True),
     }
 
 
@@ -73,6 +75,9 @@ QUAD_CASES = {
     "anymal": (dict(base_height=(0.3, 0.6), grounded_fraction=0.6), 5e-4),
     "atlas": (dict(base_height=(0.85, 1.0), grounded_fraction=0.6), 2.5e-4),
     "crane_walker": (dict(base_height=(0.45, 0.65), grounded_fraction=0.6), 2.5e-4),
+    # two / three leaf chains only: the decomposition is completed with empty limbs (codegen.quad_structure)
+    "biped": (dict(base_height=(0.55, 0.75), grounded_fraction=0.6), 2.5e-4),
+    "biped_torso": (dict(base_height=(0.55, 0.75), grounded_fraction=0.6), 2.5e-4),
 }
 
 
@@ -83,7 +88,7 @@ def test_quad_kernel_matches_oracle(name, solver):
     limbs) and Atlas (5-joint trunk tree, padded limbs attached at two different trunk joints,
     16 contact points per foot).  The formulation differs from the oracle's joint-local one, so
     agreement is at accumulated round-off (1e-11), not bitwise."""
-    model = robots.crane_walker() if name == "crane_walker" else load_builtin(name)
+    model = _models()[name]() if name in _models() else load_builtin(name)
     kw_states, dt = QUAD_CASES[name]
     B = 24 if name == "anymal" else 12
     st = sample_states(model, B, seed=4, **kw_states)
