@@ -4,6 +4,7 @@ jiminy / pinocchio (SURVEY.md section 8c lists the reference tests each of these
 The reference holds no stored numeric vectors for this path: every pin is an analytical law, a
 conservation law, a self-consistency identity or a comparison with an independent integrator.
 """
+import os
 import numpy as np
 import pytest
 from scipy.integrate import solve_ivp
@@ -413,3 +414,99 @@ def test_foot_pendulum_static_equilibrium_spring_damper_model():
     log = s.run(0.2, solver="runge_kutta_4", period=1e-3, dt_max=1e-5)
     assert log["status"] == 0
     assert np.abs(log["v"][-1]).max() < 1e-7 and np.abs(log["q"][-1] - q0).max() < 1e-7
+
+
+# ---- (12) unit_py/test_simple_pendulum.py:143-211: the motor's velocity limit (SimpleMotor::computeEffort,
+# basic_motors.cc:83-143).  Constant command 50 N.m on the 5 kg.m^2 pendulum without gravity, effort limit 1000 (URDF),
+# velocity limit 15 rad/s, velocityEffortInvSlope 0.5, DOPRI at 1e-12 for 4 s -- checked as there (the velocity never
+# exceeds the limit and reaches it, the acceleration decays exponentially once the limit acts, it starts to act at
+# v_th = 15 - (50 / 1000) * 15, the acceleration vanishes) and against the closed form of that law.
+def test_motor_velocity_limit_on_the_hanging_pendulum():
+    from jiminy_amd.model import add_motor, add_sensor, build_model_from_urdf
+    VMAX, SLOPE, TAU = 15.0, 0.5, 50.0
+    m = build_model_from_urdf(os.path.join(robots.DATA, "hanging_pendulum.urdf"), name="hanging_pendulum_vlim")
+    add_motor(m, "pivot", "pivot", enableEffortLimit=True, enableVelocityLimit=True, velocityEffortInvSlope=SLOPE,
+              velocityLimitFromUrdf=False, velocityLimit=VMAX, enableArmature=False)
+    add_sensor(m, "ImuSensor", "bob", frame_name="bob")
+    m.position_lower[:] = -1e9
+    m.position_upper[:] = 1e9
+    s = OracleSim(m, options=dict(gravity=(0, 0, 0, 0, 0, 0)))
+    s.start([0.0], [0.0], command=[TAU])
+    log = s.run(4.0, tol_abs=1e-12, tol_rel=1e-12, log_dt=5e-3)
+    assert log["status"] == 0
+    t, vel, acc = log["t"], log["v"][:, 0], log["a"][:, 0]
+    inertia, eff = 5.0, m.motors[0].effort_limit
+    assert eff == 1000.0
+    assert np.all(np.abs(vel) < VMAX)
+    assert abs(vel[-1]) - VMAX < 1e-7 and VMAX - abs(vel[-1]) < 1e-7
+    acc_thr = TAU / inertia
+    start = next(i for i, a in enumerate(acc) if a < acc_thr - 1e-9)
+    end = start + next(i for i, a in enumerate(acc[start:]) if a < 0.1)
+    slope = np.diff(np.log(acc[start:end] / acc_thr)) / np.diff(t[start:end])
+    assert end - start > 20 and np.all(np.abs(slope - slope.mean()) < 1e-5)
+    assert abs(slope.mean() + eff / (VMAX * inertia)) < 1e-6          # rate of the law: effort_limit / (v_max I)
+    v_th_max = max(VMAX - SLOPE * eff, 0.0)
+    v_th = VMAX - (TAU / eff) * (VMAX - v_th_max)
+    assert vel[start - 1] < v_th and vel[start] > v_th
+    assert abs(acc[-1]) < 1e-7
+    # closed form
+    t1 = v_th / acc_thr
+    exact = np.where(t < t1, acc_thr * t, VMAX - (VMAX - v_th) * np.exp(-(eff / (VMAX * inertia)) * (t - t1)))
+    assert np.abs(vel - exact).max() < 1e-9
+
+
+# ---- (13) unit_py/test_simple_mass.py:111-175: the energy law of a bounce.  The point mass dropped from 1 m on the
+# spring-damper ground (k = 1e6, c = 2e3, transitionEps = 1e-6): the total energy (robot + 1/2 k depth^2) never
+# increases, the robot's own energy only grows while it moves upward inside the ground, the end state is the
+# equilibrium.  (Controller period 1e-4 instead of the reference's 1e-5: the law does not depend on it.)
+def test_dropped_point_mass_energy_never_increases():
+    from scipy.signal import savgol_filter
+    m = robots.point_mass()
+    k, c, mass, dt = 1.0e6, 2.0e3, 2.0, 1.0e-4
+    s = OracleSim(m, options=dict(stiffness=k, damping=c, transition_eps=1.0e-6))
+    q, v = _ff_state(1.0)
+    s.start(q, v)
+    log = s.run(1.5, period=dt, dt_max=dt)
+    assert log["status"] == 0 and len(log["t"]) == 15001
+    z, vz = log["q"][:, 2], log["v"][:, 2]
+    depth = np.minimum(z, 0.0)
+    e_robot = log["energy"].sum(axis=1)
+    e_tot = e_robot + 0.5 * k * depth ** 2
+    assert depth.min() < -1e-3                                          # it did hit the ground
+    d_tot = savgol_filter(e_tot, 21, 2, deriv=1, delta=dt)
+    assert np.all(d_tot < 1.0e-3)
+    d_robot = np.concatenate((np.diff(e_robot) / dt, [0.0]))
+    odd = np.where((np.abs(d_robot) > 1e-9) & ((d_robot > 0.0) != ((vz > 0.0) & (depth < 0.0))))[0]
+    assert np.all(np.diff(odd) > 1)                                     # (never two consecutive samples, as there)
+    weight = mass * G
+    assert abs(log["f_external"][-1].reshape(-1, 6)[1, 2] - weight) < 1e-7
+    assert abs(-depth[-1] - weight / k) < 1e-7
+
+
+# ---- (14) unit_py/test_simple_mass.py:182-241: contact and force sensors against RobotState::f_external, under both
+# contact models, continuous and 1 kHz sensors, on a body that spins (there: a constant torque on the free-flyer; here an
+# initial spin and a tilted drop): frame_pose.act(measurement) == f_external[joint] at every log point.
+@pytest.mark.parametrize("contact_model", ["spring_damper", "constraint"])
+@pytest.mark.parametrize("period", [0.0, 1e-3])
+def test_contact_and_force_sensors_report_the_external_force(contact_model, period):
+    m = robots.point_mass()
+    con = dict(model="constraint") if contact_model == "constraint" else None
+    s = OracleSim(m, options=dict(stiffness=1.0e6, damping=2.0e3, friction=2.0, transition_velocity=5.0e-2),
+                  constraint_options=con)
+    q = np.array([0.0, 0.0, 0.02, 0.1, -0.2, 0.05, 1.0])
+    q[3:] /= np.linalg.norm(q[3:])
+    v = np.array([0.3, -0.2, 0.0, 1.0, 1.0, 1.0])
+    s.start(q, v)
+    log = s.run(0.3, period=period, log_dt=None if period else 1e-3, dt_max=1e-3)
+    assert log["status"] == 0
+    fr_c, fr_f = m.frame("body"), m.frame("sole")
+    touched = 0
+    for f_lin, f_w, f_ext in zip(log["contact"], log["force"], log["f_external"]):
+        f_true = f_ext.reshape(-1, 6)[1]
+        touched += np.abs(f_true).max() > 1.0
+        Rc, Rf = np.asarray(fr_c.R).reshape(3, 3), np.asarray(fr_f.R).reshape(3, 3)
+        lin_c = Rc @ f_lin[:3]
+        lin_f, ang_f = Rf @ f_w[:3], Rf @ f_w[3:] + np.cross(np.asarray(fr_f.p), Rf @ f_w[:3])
+        assert np.allclose(lin_c, f_true[:3], atol=1e-7)
+        assert np.allclose(np.concatenate((lin_f, ang_f)), f_true, atol=1e-7)
+    assert touched > 20
