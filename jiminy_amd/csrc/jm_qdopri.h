@@ -196,6 +196,9 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                 static_for<0, NVB>([&](auto ic) { S.putb(DR::KAB + (i - 1) * NVB + decltype(ic)::value, ddqb[decltype(ic)::value]); });
                 static_for<0, N>([&](auto sc) { if (ix.has[decltype(sc)::value]) kal[krow(i, decltype(sc)::value)] = ddq[decltype(sc)::value]; });
             }
+#ifdef JM_DOPRI_BARRIER   // (experiment of DESIGN.md section 4.7: nothing of the stage loop is carried into the estimate in registers)
+            JM_REFRESH();
+#endif
             // ---- embedded error estimate (runge_kutta_dopri_stepper.cc:18-87): solution = stage 6 = (qb|ql, vb|vl),
             // alternative (4th order) solution = x0 (+) dt sum_j e_j k_j, norm = max |difference / scale|
             double error = 0.0;
@@ -262,6 +265,16 @@ JM_DEV void quad_dopri_run(const BatchArgs<T> & A, const AdaptiveArgs<T> & D, lo
                 nan |= (eq != eq) || (ev != ev);
                 error = fmax(error, fmax(eq, ev));
                 a_nan |= (ddq[s] != ddq[s]);
+#ifdef JM_DOPRI_DEBUG   // (the terms of the first attempt's estimate, into rows the persistent kernel does not use)
+#ifndef JM_DOPRI_DEBUG_ATT
+#define JM_DOPRI_DEBUG_ATT 1
+#endif
+                if (attempts == JM_DOPRI_DEBUG_ATT && ix.has[s])
+                {
+                    D.ws[(unsigned long long)(AR::QS + ix.rq[s]) * Bq + r32] = JM_DOPRI_DEBUG == 1 ? (q0 + dq) - ql[s] : (JM_DOPRI_DEBUG == 2 ? ql[s] : q0 + dq);
+                    D.ws[(unsigned long long)(AR::CMD + ix.rm[s]) * Bq + r32] = JM_DOPRI_DEBUG == 1 ? (v0 + dv) - vl[s] : (JM_DOPRI_DEBUG == 2 ? vl[s] : v0 + dv);
+                }
+#endif
             });
             {
                 // over the four limbs (fmax drops NaN operands: the flags travel separately)

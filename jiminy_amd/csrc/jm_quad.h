@@ -2138,7 +2138,11 @@ struct DppQuad
     }
     static __device__ __forceinline__ float max_abs(float a, float b) { return fmaxf(a, fabsf(b)); }
     static __device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
+#ifdef JM_SYNC_FENCE   // (experiment of DESIGN.md section 4.7: the quad's hand-over points as compiler-visible memory fences)
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+#else
     static __device__ __forceinline__ void sync() {}  // lanes of a wave are already in lock-step
+#endif
     // stores of the quad's lanes to the workspace become visible to the other lanes' later loads
     static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     static __device__ __forceinline__ void table_ready() { __syncthreads(); }
