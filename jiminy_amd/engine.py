@@ -189,8 +189,15 @@ class RobotState:
 class JointConstraint:
     """≙ `jiminy.JointConstraint(joint_name)` (core/src/constraints/joint_constraint.cc): the joint held at a reference
     configuration (the configuration at `start`, `JointConstraint::reset`) by a bilateral kinematic constraint with the
-    Baumgarte stabilisation of the contact model.  Registered with `BatchedEngine.add_constraint`."""
+    Baumgarte stabilisation of the contact model.  Registered with `BatchedEngine.add_constraint`.
+
+    `baumgarte_freq` ≙ `AbstractConstraintBase::setBaumgarteFreq` (abstract_constraint.cc:88-98).  Deviation from the
+    reference, where a user constraint keeps gains of its own (zero until set) and `Engine::start` only overwrites those of
+    the internal constraints (engine.cc:1276-1285): the kernels know ONE pair of gains, the one of
+    `contacts.stabilizationFreq`, so `None` (default) follows that option and any other value is refused instead of being
+    silently replaced."""
     joint_name: str
+    baumgarte_freq: Optional[float] = None
 
 
 @dataclass
@@ -761,6 +768,14 @@ class BatchedEngine:
             raise NotImplementedError("only JointConstraint can be registered")
         if name in self._user_constraints:
             raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
+        freq = constraint.baumgarte_freq
+        if freq is not None:
+            if freq < 0.0:
+                raise ValueError("Natural frequency must be positive.")                             # abstract_constraint.cc:91-94
+            if abs(float(freq) - float(self._options["contacts"]["stabilizationFreq"])) > 1e-12:
+                raise NotImplementedError("user constraints share the Baumgarte gains of 'contacts.stabilizationFreq' "
+                                          f"({self._options['contacts']['stabilizationFreq']} Hz): set that option, or leave "
+                                          "baumgarte_freq to None")
         if self._options["contacts"]["model"] != "constraint" or codegen.quad_structure(self.model) is None or \
                 self.dtype != torch.float64 or os.environ.get("JM_KERNEL_VARIANT") == "lane":
             raise NotImplementedError("user constraints need the constraint contact model on a float64 batch of a "
