@@ -252,9 +252,12 @@ def _quad_lines(model: CompiledModel):
 # and moves on to the next variant when a build fails the check.  `build_variants.json` (tracked)
 # records the variant a topology is known to need, so that `__graft_entry__.build()` compiles it
 # ahead of time.
+# Variant 1 (round 4): the basic SGPR allocator instead of the greedy one -- the one switch that repairs BOTH remaining
+# failures at -O3 (tree_arm's k_batch, Atlas' persistent adaptive kernel; up to round 3 this slot held
+# -disable-machine-licm, which no library needs any more).
 BUILD_VARIANTS: Tuple[Tuple[str, ...], ...] = (
     (),
-    ("-mllvm", "-disable-machine-licm"),
+    ("-mllvm", "-sgpr-regalloc=basic"),
     ("-O1",),
 )
 _VARIANT_FILE = os.path.join(CSRC, "build_variants.json")
