@@ -252,12 +252,16 @@ def _quad_lines(model: CompiledModel):
 # and moves on to the next variant when a build fails the check.  `build_variants.json` (tracked)
 # records the variant a topology is known to need, so that `__graft_entry__.build()` compiles it
 # ahead of time.
-# Variant 1 (round 4): the basic SGPR allocator instead of the greedy one -- the one switch that repairs BOTH remaining
-# failures at -O3 (tree_arm's k_batch, Atlas' persistent adaptive kernel; up to round 3 this slot held
-# -disable-machine-licm, which no library needs any more).
+# Variant 0 (round 4): every translation unit is built with the BASIC SGPR register allocator instead of the greedy one.
+# It is the one backend switch that repairs all three mis-compiled kernels found at -O3 -- tree_arm's k_batch, the output pass of
+# tree_arm_ff's k_batch, Atlas' persistent adaptive kernels -- bit for bit against their -O1 builds, where twelve other
+# switches repair at most one; with it no library needs a pin.  Cost (MI355X, same box, two runs
+# each): ANYmal step launch 0.1507 -> 0.1495 ms, ANYmal constraint launch 0.920 -> 0.938, Atlas step launch 0.348 -> 0.362,
+# Atlas constraint launch unchanged.  Variant 1 is the compiler's default allocator, variant 2 -O1: the fall-back chain of
+# the self-tests, and what `tests/test_gpu_parity.py` forces to exercise that chain.
 BUILD_VARIANTS: Tuple[Tuple[str, ...], ...] = (
-    (),
     ("-mllvm", "-sgpr-regalloc=basic"),
+    (),
     ("-O1",),
 )
 _VARIANT_FILE = os.path.join(CSRC, "build_variants.json")

@@ -44,6 +44,15 @@
 
 namespace jm
 {
+#ifndef JM_FP_REASSOC
+#define JM_FP_REASSOC 1   // (0: A/B builds; measured in round 4, same box: ANYmal launch 0.1517 -> 0.1480 ms, Atlas 0.3606 -> 0.3477)
+#endif
+#if JM_FP_REASSOC && !defined(JM_HOST_EMU)
+// The spatial-algebra helpers below (and only they: the pragma is switched off again in front of the scalar functions, whose
+// Cody-Waite reductions and polynomials depend on their order of operations): a sum of products may be re-associated into one
+// fma chain, `a + (x y + z w + u v)` -> three fmas instead of mul + 2 fma + add
+#pragma clang fp reassociate(on)
+#endif
 #ifndef JM_HOST_EMU
 // a uniform zero the compiler cannot see through, defined after `dep` is (see JM_K)
 __device__ __forceinline__ int kzero_(double dep) { int z; asm("s_mov_b32 %0, 0" : "=s"(z) : "v"(dep)); return z; }
@@ -299,6 +308,9 @@ template<class T> JM_DEV M3<T> quat_to_matrix(T x, T y, T z, T w)
             txz - twy, tyz + twx, T(1) - (txx + tyy)};
 }
 
+#if JM_FP_REASSOC && !defined(JM_HOST_EMU)
+#pragma clang fp reassociate(off)
+#endif
 // sin and cos of a float64 angle without the libm `sincos(x, &s, &c)` out-pointer form: on the
 // device that form materialises its outputs through private (scratch) memory, and hipcc (ROCm 7.2)
 // was observed to lay those slots over live spill slots in the large unrolled kernels (wrong

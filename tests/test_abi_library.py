@@ -92,27 +92,35 @@ def test_model_desc_packing():
 
 
 def test_build_variants_bookkeeping(monkeypatch, tmp_path):
-    """codegen.BUILD_VARIANTS / build_variants.json: the variant recorded for a topology selects the
-    library file the loader opens; variant 0 is the plain flag set."""
+    """codegen.BUILD_VARIANTS / build_variants.json: the variant recorded for a topology selects the library file the
+    loader opens; variant 0 (the default of every topology since round 4: no pin is left) builds with the basic SGPR
+    allocator, variant 1 with the compiler's default flags, variant 2 at -O1."""
     import json
     model = robots.crane_walker()
     monkeypatch.delenv("JIMINY_AMD_BUILD_VARIANT", raising=False)
     monkeypatch.delenv("JIMINY_AMD_LIB_TAG", raising=False)
-    assert codegen.BUILD_VARIANTS[0] == ()
+    assert codegen.BUILD_VARIANTS[0] == ("-mllvm", "-sgpr-regalloc=basic") and codegen.BUILD_VARIANTS[1] == ()
     recorded = json.load(open(os.path.join(codegen.CSRC, "build_variants.json")))
     # (keys with a leading underscore are notes: `_dropped` keeps the history of the pins that were removed)
-    assert all(0 <= int(v["variant"]) < len(codegen.BUILD_VARIANTS) for k, v in recorded.items() if not k.startswith("_"))
-    pinned = robots.tree_arm(False)
-    assert codegen.preferred_variant(pinned) == int(recorded[pinned.topology_hash()]["variant"]) != 0
-    want = int(recorded.get(model.topology_hash(), {"variant": 0})["variant"])
-    assert codegen.preferred_variant(model) == want
-    assert codegen.lib_path(model).endswith(f"libjm_{model.topology_hash()}" + (f"_v{want}.so" if want else ".so"))
+    pins = {k: v for k, v in recorded.items() if not k.startswith("_")}
+    assert all(0 <= int(v.get("variant", 0)) < len(codegen.BUILD_VARIANTS) for v in pins.values())
+    for m in (model, robots.tree_arm(False), robots.tree_arm(True)):
+        want = int(pins.get(m.topology_hash(), {"variant": 0}).get("variant", 0))
+        assert codegen.preferred_variant(m) == want
+        assert codegen.lib_path(m).endswith(f"libjm_{m.topology_hash()}" + (f"_v{want}.so" if want else ".so"))
     assert codegen.lib_path(model, 0).endswith(f"libjm_{model.topology_hash()}.so")
     assert codegen.lib_path(model, 2).endswith(f"libjm_{model.topology_hash()}_v2.so")
     monkeypatch.setenv("JIMINY_AMD_BUILD_VARIANT", "2")
     assert codegen.preferred_variant(model) == 2
-    monkeypatch.setattr(codegen, "_VARIANT_FILE", str(tmp_path / "absent.json"))
+    # a pin in the file is honoured (per-topology variant and per-unit flags)
     monkeypatch.delenv("JIMINY_AMD_BUILD_VARIANT")
+    fake = tmp_path / "pins.json"
+    fake.write_text(json.dumps({model.topology_hash(): {"variant": 1, "part_flags": {"5": ["-O1"]}}, "_note": "x"}))
+    monkeypatch.setattr(codegen, "_VARIANT_FILE", str(fake))
+    assert codegen.preferred_variant(model) == 1 and codegen.part_flags(model) == {"5": ["-O1"]}
+    monkeypatch.setenv("JIMINY_AMD_NO_PART_FLAGS", "1")
+    assert codegen.part_flags(model) == {}
+    monkeypatch.setattr(codegen, "_VARIANT_FILE", str(tmp_path / "absent.json"))
     assert codegen.preferred_variant(model) == 0
 
 
