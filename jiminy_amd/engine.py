@@ -335,6 +335,49 @@ def _library_self_test_detail(model: CompiledModel, variant: int, dtype: torch.d
     return err, legs
 
 
+_OUTPUT_ROWS = ("a", "u", "imu", "force", "contact", "encoder", "effort", "contact_forces", "f_external", "energy", "joint_forces",
+                "centroidal")
+
+
+def _output_self_test(model: CompiledModel, variant: int, device: torch.device) -> float:
+    """The rows a launch EMITS (sensors, extra terms), which the step self-test does not look at: the float64 and the
+    float32 instantiations of the kernels are separate compilations of the same sources, so a mis-compiled output pass
+    (third case: a wrong IMU row next to a right `q`, `v`, `a`) shows as a disagreement between
+    them.  Probe batch, spring-damper contacts, after `start` and after one explicit-Euler step; returns the largest
+    disagreement over the emitted rows, relative to the row's scale + 1e-3 of its field's (sound builds: <= 2e-3, float32 round-off)."""
+    n, dt = 64, 1e-4
+    q, v, cmd = _probe_state(model, n)
+    runs = []
+    for dtype in (torch.float64, torch.float32):
+        probe = BatchedEngine(model, n, dtype=dtype, device=device, _lib_variant=variant,
+                              extra_outputs=("contact_forces", "f_external", "energy", "joint_forces", "centroidal"))
+        probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": 0.0,
+                                       "sensorsUpdatePeriod": 0.0}, "contacts": {"model": "spring_damper"}})
+        if model.nmotors:
+            probe.set_command(torch.as_tensor(cmd, dtype=dtype, device=device))
+        probe.start(torch.as_tensor(q, dtype=dtype, device=device), torch.as_tensor(v, dtype=dtype, device=device))
+        rows = [{k: probe._fields[k].double().clone() for k in _OUTPUT_ROWS if k in probe._fields}]
+        probe.step(dt)
+        rows.append({k: probe._fields[k].double().clone() for k in _OUTPUT_ROWS if k in probe._fields})
+        runs.append((rows, probe.status.reshape(-1).clone()))
+        probe.stop()
+    ok = ((runs[0][1] | runs[1][1]) & _abi.JM_LANE_NAN) == 0
+    if not bool(ok.any()):
+        return float("inf")
+    err = 0.0
+    for r64, r32 in zip(runs[0][0], runs[1][0]):
+        for k, x in r64.items():
+            if x.numel() == 0:
+                continue
+            y = r32[k]
+            # scale of a row + a share of the scale of its field: a row that is zero by cancellation (the joint wrench of a
+            # free-flyer: terms of 1e7 N on the probe batch) carries the float32 round-off of the terms, not of the row
+            scale = torch.clamp(x[:, ok].abs().amax(dim=1, keepdim=True), min=1.0) + 1e-3 * x[:, ok].abs().max()
+            e = float((((x - y)[:, ok]).abs() / scale).max())
+            err = max(err, e if e == e else float("inf"))
+    return err
+
+
 _GEN_VERIFIED: Dict[Tuple[str, int, str], float] = {}
 
 
@@ -518,6 +561,13 @@ def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.de
     for variant in [first] + [i for i in range(len(codegen.BUILD_VARIANTS)) if i != first]:
         err = _library_self_test(model, variant, dtype, device)
         tried.append(f"variant {variant}: {err:.3e}")
+        if err <= tol and dtype == torch.float64:
+            # ... and the emitted rows, float64 against float32 (5e-2: gross garbage only -- sound builds of the shipped and
+            # the test robots stay below 1.5e-3, the mis-compiled output pass of DESIGN.md section 4.7 measured 1.6)
+            err_out = _output_self_test(model, variant, device)
+            if not err_out <= 5e-2:
+                tried[-1] += f", emitted rows {err_out:.3e}"
+                continue
         if err <= tol:
             if variant != first:
                 warnings.warn(f"{model.name}: HIP library build variant {first} failed the kernel self-test "

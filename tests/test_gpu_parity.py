@@ -96,6 +96,34 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
     assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
 
 
+@pytest.mark.parametrize("name", ["anymal", "atlas", "tree_arm_ff", "cartpole"])
+def test_emitted_rows_of_float64_and_float32_kernels_agree(gpu_device, name):
+    """engine._output_self_test: the rows a launch emits (sensors, extra terms), float64 against the separately compiled
+    float32 kernels of the same library -- the check that would have caught the mis-compiled output pass of DESIGN.md section
+    4.7 (third case; measured 1.6 on that build) without an oracle.  Sound builds: float32 round-off."""
+    from jiminy_amd import codegen, engine as engine_mod
+    from tests import robots
+    model = robots.tree_arm(True) if name == "tree_arm_ff" else load_builtin(name)
+    assert engine_mod._output_self_test(model, codegen.preferred_variant(model), gpu_device) < 5e-3
+
+
+def test_a_library_with_garbage_in_its_emitted_rows_is_replaced(gpu_device, monkeypatch):
+    """`_verified_library` treats a variant whose emitted rows disagree like one that fails the step self-test: the next
+    build variant is taken, with a warning (the disagreement is injected here: no build of today shows one)."""
+    import warnings
+    from jiminy_amd import codegen, engine as engine_mod
+    model = load_builtin("cartpole")
+    real = engine_mod._output_self_test
+    monkeypatch.setattr(engine_mod, "_VERIFIED", {})
+    monkeypatch.setattr(engine_mod, "_output_self_test", lambda m, v, d: 1.6 if v == 0 else real(m, v, d))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        eng = _engine(model, 32, torch.float64, "runge_kutta_4", 1e-3)
+    chosen = engine_mod._VERIFIED[(model.topology_hash(), torch.float64)]
+    assert chosen == 1 and eng._lib.path == codegen.lib_path(model, 1)
+    assert any("failed the kernel self-test" in str(w.message) and "emitted rows" in str(w.message) for w in caught)
+
+
 @pytest.mark.parametrize("name", ["crane_walker", "tree_arm"])
 def test_library_self_test_guards_against_miscompiled_builds(gpu_device, monkeypatch, name):
     """Every HIP library is checked on first use (engine._verified_library): a build whose in-loop
