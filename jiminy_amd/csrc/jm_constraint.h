@@ -378,8 +378,10 @@ JM_DEV bool chol_solve_packed(int m, WS && ws)
 
 // PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:107-333) over the m packed rows:
 // the first `nb` rows are joint bounds, then blocks of 4 rows (x, y, z, torsion) per active contact.
+// `lockp`: bit p = packed bound row p is a user-registered JointConstraint (Model::addConstraint): unbounded, solved first in
+// every sweep, coefficient by coefficient, without relaxation or projection (constraint_solvers.cc:112-128).
 template<class T, class Tp, class WS>
-JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS && ws)
+JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS && ws, unsigned long long lockp = 0ull)
 {
     using R = ConRows<Tp>;
     constexpr int NR = R::NR;
@@ -432,9 +434,19 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             w = T(0.01);
             if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
         }
+        if (lockp)
+            for (int r = 0; r < nb; ++r)
+            {
+                if (!((lockp >> r) & 1ull)) continue;
+                const T y = ws(R::WB + r) - col_dot(r);
+                dmax = fmax_(dmax, cabs_(y - Y(r)));
+                Y(r) = y;
+                xl[r * xs] = xl[r * xs] + y / ws(R::WA + r * NR + r);
+            }
         // block 0 of every constraint: joint bounds, then the normal force of every contact
         for (int r = 0; r < m; r += (r < nb ? 1 : 4))
         {
+            if (r < nb && ((lockp >> r) & 1ull)) continue;
             const int i0 = r < nb ? r : r + 2;
             const T y = ws(R::WB + i0) - col_dot(i0);
             dmax = fmax_(dmax, cabs_(y - Y(i0)));
@@ -648,22 +660,28 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     // ---- constraint switching
     constexpr int NWORDS = ((NR + 63) / 64 > 0) ? (NR + 63) / 64 : 1;
     using RowMask = RowMaskN<NWORDS>;
-    RowMask act, rev;
+    RowMask act, rev, lck;
     act.clear();
     rev.clear();
+    lck.clear();
     static_for<0, R::NB>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int iq = Tp::idx_q[R::bjoint(k)];
         // state of the constraint: loaded once, updated in registers, stored once
         // Engine::start: JointConstraint::reset + enable, not reversed (engine.cc:1266-1308)
         const bool init = start_passes > 0;
-        int32_t f = init ? 1 : flag(k);
+        const int32_t f0 = flag(k);
+        // bit 2: a user-registered JointConstraint holds the row (Model::addConstraint, model.cc:926-936): always enabled,
+        // never reversed, no switching while it holds; its reference is the configuration at `start` (or the caller's)
+        const bool locked = (f0 & 4) != 0;
+        int32_t f = init ? (1 | (f0 & 4)) : f0;
         if (!refresh)
         {
             const T qj = q[iq], lo = P[L::QLO + iq], hi = P[L::QHI + iq];
             T ref = init ? qj : dat(k);
             bool clear = init;
-            if (hi < qj || qj < lo)
+            if (locked) f = 5;
+            else if (hi < qj || qj < lo)
             {
                 ref = clamp_(qj, lo, hi);
                 f = 1 | (hi < qj ? 2 : 0);
@@ -679,6 +697,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         }
         if (f & 1) act.set(k);
         if (f & 2) rev.set(k);
+        if (f & 4) lck.set(k);
     });
     for_contacts<Tp>([&](auto jc, int c) {
         constexpr int j = decltype(jc)::value;
@@ -877,8 +896,13 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             {
                 if (C.park)
                 for (int r = 0; r < C.park_rows; ++r) C.park[(size_t)r * B] = C.xl[r * C.xstride];
+            unsigned long long lockp = 0ull;
+            static_for<0, R::NB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (act.test(k) && lck.test(k)) lockp |= 1ull << act.rank(k);
+            });
             if constexpr (JM_CON_PGS_REG && NR <= 32) ok = pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
-            else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws);
+            else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws, lockp);
             if (C.park)
                 for (int r = 0; r < C.park_rows; ++r) C.xl[r * C.xstride] = C.park[(size_t)r * B];
                 if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
@@ -937,10 +961,11 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         // Engine::start: the next pass sees u = uInternal (bounds multipliers of this pass, added with a
         // plus sign whatever the direction, engine.cc:3786-3790) + motor efforts (engine.cc:1456-1465)
         static_for<0, NV>([&](auto ic) { uq[decltype(ic)::value] = T(0); });
+        // (the multiplier of a user constraint acts through ddq only: engine.cc:3771-3790 restores the bounds' alone)
         static_for<0, R::NB>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int iv = Tp::idx_v[R::bjoint(k)];
-            if (act.test(k)) uq[iv] = lam(k);
+            if (act.test(k) && !lck.test(k)) uq[iv] = lam(k);
         });
     }
     // ---- outputs of the last pass: total efforts, external wrenches

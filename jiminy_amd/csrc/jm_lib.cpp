@@ -653,8 +653,7 @@ int32_t jm_batch_destroy(jm_batch * b)
 int32_t jm_batch_set_joint_locks(jm_batch * b, int32_t on)
 {
     if (!b) return fail(JM_EINVAL, "jm_batch_set_joint_locks: null batch");
-    if (on && !(Topo::QUAD && b->variant == VARIANT_QUAD))
-        return fail(JM_ENOTIMPL, "user-registered joint constraints need a branch-parallel topology (floating base with four limbs)");
+    // (both kernel families read bit 2 of the constraint flags; the branch-parallel one also selects its general sweep form by this switch)
     b->joint_locks = on != 0;
     return JM_OK;
 }

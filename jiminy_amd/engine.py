@@ -763,8 +763,10 @@ class BatchedEngine:
                 os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
             return
         lane_mu = "friction" in self._fields and self._options["contacts"]["model"] != "constraint"
-        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu or
-                self._user_constraints):
+        # (user constraints: only the branch-parallel family moves to its variation kernels for them; the lane kernel has none)
+        locks = bool(self._user_constraints) and codegen.quad_structure(self.model) is not None and \
+            os.environ.get("JM_KERNEL_VARIANT") != "lane"
+        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu or locks):
             return
         self._gen_checked = True
         variant = self._lib_variant_index
@@ -806,7 +808,7 @@ class BatchedEngine:
     # ------------------------------------------------------------------ user-registered constraints
     def add_constraint(self, name: str, constraint: Any, lane_mask: Optional[torch.Tensor] = None) -> None:
         """≙ `Model::addConstraint(name, constraint)` (core/src/robot/model.cc:926-936), user registry.  `JointConstraint`s of
-        joints with position bounds, constraint contact model, float64 batches of branch-parallel topologies: the row of
+        joints with position bounds, constraint contact model, float64 batches (both kernel families since round 4): the row of
         the joint's own bound constraint becomes bilateral (bit 2 of its flag), is solved first in every Gauss-Seidel
         sweep without projection (constraint_solvers.cc:112-128) and its multiplier is not restored into
         `RobotState::u` (engine.cc:3771-3790); the bound of a locked joint is not switched while the lock holds.
@@ -826,10 +828,8 @@ class BatchedEngine:
                 raise NotImplementedError("user constraints share the Baumgarte gains of 'contacts.stabilizationFreq' "
                                           f"({self._options['contacts']['stabilizationFreq']} Hz): set that option, or leave "
                                           "baumgarte_freq to None")
-        if self._options["contacts"]["model"] != "constraint" or codegen.quad_structure(self.model) is None or \
-                self.dtype != torch.float64 or os.environ.get("JM_KERNEL_VARIANT") == "lane":
-            raise NotImplementedError("user constraints need the constraint contact model on a float64 batch of a "
-                                      "branch-parallel topology (floating base with four limbs)")
+        if self._options["contacts"]["model"] != "constraint" or self.dtype != torch.float64:
+            raise NotImplementedError("user constraints need the constraint contact model on a float64 batch")
         if "con_flags" not in self._fields:
             self._apply_options()
         # Deviation from the reference, where a user constraint is a row of its own next to the joint's bound constraint
