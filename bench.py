@@ -375,6 +375,42 @@ SECONDARY = (
 )
 
 
+def measure_adaptive(ctx, *, model_name: str = "anymal", B: int = 65536, interval: float = 0.01, intervals: int = 4):
+    """The reference's DEFAULT solver (`runge_kutta_dopri`, engine.h:307, one step size per robot) on the headline robot: robots
+    landing on the spring-damper ground, default tolerances, `intervals` controller periods of `interval` seconds, one
+    persistent launch each (jm_qdopri.h).  Unit: robot-intervals/s (a robot takes ~6 attempts of seven evaluations per
+    interval on this workload); no roofline object -- the launch is bound by the sequential chain of its stiffest robot."""
+    import torch
+
+    from jiminy_amd import load_builtin
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.synthetic import sample_states
+    model = load_builtin(model_name)
+    st = sample_states(model, B, seed=ctx.rank)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=ctx.device)
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "controllerUpdatePeriod": interval, "sensorsUpdatePeriod": interval},
+                     "contacts": {"model": "spring_damper"}})
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    eng.step(interval)          # (leaves the 1 us initial step size behind)
+    torch.cuda.synchronize(ctx.device)
+    it0 = eng.stepper_state.iter_lanes.double().mean().item()
+    attempts, t0 = 0, time.perf_counter()
+    for _ in range(intervals):
+        eng.step(interval)
+        attempts += eng.adaptive_attempts
+    torch.cuda.synchronize(ctx.device)
+    el = time.perf_counter() - t0
+    ok = float(((eng.status.reshape(-1) & 9) == 0).double().mean().item())
+    steps_acc = (eng.stepper_state.iter_lanes.double().mean().item() - it0) / intervals
+    eng.stop()
+    return {"workload": f"{model_name} runge_kutta_dopri spring_damper, {B} robots, {interval * 1e3:g} ms intervals, default tolerances",
+            "model": model_name, "solver": "runge_kutta_dopri", "contact_model": "spring_damper", "batch": B,
+            "metric": "robot-intervals/s", "value": B * intervals / el, "ms_per_interval": 1e3 * el / intervals,
+            "attempts_of_the_stiffest_robot_per_interval": attempts / intervals, "mean_accepted_steps_per_interval": steps_acc,
+            "lanes_ok": ok}
+
+
 def secondary_workloads(ctx, args):
     import torch
     res = []
@@ -385,6 +421,11 @@ def secondary_workloads(ctx, args):
         except Exception as e:  # a secondary workload must never take the headline down with it
             res.append({"workload": f"{cfg['model_name']} {cfg['contact_model']} {cfg['solver']}", "error": repr(e)[:300]})
         torch.cuda.empty_cache()
+    try:
+        res.append(measure_adaptive(ctx))
+    except Exception as e:
+        res.append({"workload": "anymal runge_kutta_dopri spring_damper", "error": repr(e)[:300]})
+    torch.cuda.empty_cache()
     return res
 
 

@@ -437,14 +437,15 @@ def _variation_self_test_leg(model: CompiledModel, variant: int, device: torch.d
     return err
 
 
-_DOPRI_FORM: Dict[Tuple[str, int], int] = {}
+_DOPRI_FORM: Dict[Tuple[str, int, bool], int] = {}
 
 
-def _adaptive_self_test(model: CompiledModel, variant: int, device: torch.device) -> float:
+def _adaptive_self_test(model: CompiledModel, variant: int, device: torch.device, gen: bool = False) -> float:
     """Persistent adaptive kernel (jm_qdopri.h) against the per-stage launches on the probe batch: three breakpoint
     intervals with tight tolerances.  Returns the largest relative disagreement over (q, v) on the lanes that follow the
     same accept / reject sequence (inf when fewer than 80 % do, or when the persistent kernel flags lanes the per-stage
-    path does not)."""
+    path does not).  `gen`: its variation form (`k_quad_dopri_gen`, a separate compilation), selected by a per-lane friction
+    field that holds the nominal coefficient."""
     n = 64
     q, v, cmd = (torch.as_tensor(x, dtype=torch.float64, device=device) for x in _probe_state(model, n))
     outs = []
@@ -454,6 +455,9 @@ def _adaptive_self_test(model: CompiledModel, variant: int, device: torch.device
         probe.set_options({"stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-8, "tolRel": 1e-7, "dtMax": 1e-3,
                                        "controllerUpdatePeriod": 1e-3, "sensorsUpdatePeriod": 1e-3},
                            "contacts": {"model": "spring_damper"}})
+        if gen:
+            probe._gen_checked = True      # (the step kernels' own variation check is not what is probed here)
+            probe.set_lane_friction(torch.full((n,), float(probe._options["contacts"]["friction"]), dtype=torch.float64))
         if model.nmotors:
             probe.set_command(cmd)
         probe.start(q, v)
@@ -1087,14 +1091,18 @@ class BatchedEngine:
         if self.dtype != torch.float64 or codegen.quad_structure(self.model) is None or \
                 self._options["contacts"]["model"] != "spring_damper" or os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
             return 0
-        key = (self.model.topology_hash(), self._lib_variant_index)
+        # (the variation form of the kernel -- per-lane body parameters / friction, height map, applied forces: jm_lib.cpp
+        # `step_adaptive` -- is a compilation of its own and is checked on its own)
+        gen = bool("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or "friction" in self._fields)
+        key = (self.model.topology_hash(), self._lib_variant_index, gen)
         if key not in _DOPRI_FORM:
             _DOPRI_FORM[key] = 0       # (the probes below are engines of the same topology)
-            err = _adaptive_self_test(self.model, self._lib_variant_index, self.device)
+            err = _adaptive_self_test(self.model, self._lib_variant_index, self.device, gen=gen)
             if not err <= 1e-6:
                 _DOPRI_FORM[key] = 1
-                warnings.warn(f"{self.model.name}: the persistent adaptive kernel of build variant {key[1]} disagrees with the "
-                              f"per-stage path on the probe batch ({err:.3e}): using the per-stage launches (DESIGN.md section 4.7)")
+                warnings.warn(f"{self.model.name}: the persistent adaptive kernel{' (variation form)' if gen else ''} of build variant "
+                              f"{key[1]} disagrees with the per-stage path on the probe batch ({err:.3e}): using the per-stage "
+                              "launches (DESIGN.md section 4.7)")
         return _DOPRI_FORM[key]
 
     def step(self, step_dt: float = -1.0) -> None:
