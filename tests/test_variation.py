@@ -48,9 +48,18 @@ def _oracle(model, arr, ml, ground, applied, copt):
     return e
 
 
-@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True)])
+def _model(name):
+    # (`biped_torso`: limbs of 3 / 3 / 1 / 0 joints -- the per-lane parameters of a decomposition with an empty limb)
+    if name == "biped_torso":
+        from tests import robots
+        return robots.biped(True)
+    return load_builtin(name)
+
+
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True),
+                                              ("biped_torso", False), ("biped_torso", True)])
 def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, constrained):
-    model = load_builtin(name)
+    model = _model(name)
     B = 16 if name == "anymal" else 4
     st, ml, ground, applied = _scene(model, B, 5 if name == "anymal" else 6, constrained)
     copt = TIGHT if constrained else None
@@ -308,12 +317,13 @@ def test_force_breakpoints_cut_the_launches():
 
 # ------------------------------------------------------------------ device build
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True)])
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False), ("atlas", True),
+                                              ("biped_torso", False), ("biped_torso", True)])
 def test_gpu_variation_matches_oracle(gpu_device, name, constrained):
     import torch
 
     from jiminy_amd.engine import BatchedEngine
-    model = load_builtin(name)
+    model = _model(name)
     B, dt = (96, 5e-4) if name == "anymal" else (24, 2.5e-4)
     st, ml, ground, applied = _scene(model, B, 9, constrained)
     copt = TIGHT if constrained else None
