@@ -249,3 +249,25 @@ def test_composite_inertia_matches_the_urdf_xml(name):
     assert got[0] == pytest.approx(want[0], rel=1e-13)
     assert np.allclose(got[1], want[1], rtol=0, atol=1e-13)
     assert np.allclose(got[2], want[2], rtol=1e-12, atol=1e-12)
+
+
+def test_branch_parallel_decomposition_of_the_shipped_and_the_authored_robots():
+    """`codegen.quad_structure`: the four longest leaf chains are the limbs, everything else the trunk tree; trees with
+    two or three leaf chains get empty limbs (round 4); fixed-base arms, single chains and robots whose contact points or
+    IMUs sit where the 4-lane kernels cannot serve them fall back to the one-robot-per-lane kernels (None)."""
+    from jiminy_amd import codegen
+    from tests import robots
+    q = codegen.quad_structure(load_builtin("anymal"))
+    assert q["n"] == 3 and q["limb_len"] == [3, 3, 3, 3] and q["limb_attach"] == [0, 0, 0, 0] and len(q["trunk"]) == 1
+    q = codegen.quad_structure(load_builtin("atlas"))
+    assert q["n"] == 7 and sorted(q["limb_len"]) == [6, 6, 7, 7] and len(q["trunk"]) == 5 and sum(q["limb_ncontact"]) == 32
+    q = codegen.quad_structure(robots.crane_walker())
+    assert sorted(q["limb_len"]) == [2, 2, 3, 3] and sorted(q["limb_attach"]) == [0, 0, 2, 2]
+    q = codegen.quad_structure(robots.biped(False))
+    assert q["limb_len"] == [3, 3, 0, 0] and q["limb_attach"] == [0, 0, 0, 0] and q["limb_ncontact"] == [2, 2, 0, 0]
+    assert all(j == -1 for row in q["limb_joint"][2:] for j in row) if "limb_joint" in q else True
+    q = codegen.quad_structure(robots.biped(True))
+    assert sorted(q["limb_len"]) == [0, 1, 3, 3] and q["limb_len"][3] == 0
+    for m in (load_builtin("cartpole"), load_builtin("double_pendulum"), robots.tree_arm(False), robots.tree_arm(True),
+              robots.point_mass()):
+        assert codegen.quad_structure(m) is None
