@@ -211,6 +211,11 @@ typedef struct jm_constraint_options {
     double regularization;      /* constraints.regularization  1e-3                   */
     double tol_abs;             /* stepper.tolAbs 1e-5: PGS tolerances (engine.cc:1372-1373) */
     double tol_rel;             /* stepper.tolRel 1e-4                                */
+    /* ABI 6: Baumgarte frequency of the user-registered constraints (jm_batch_set_joint_locks).  In the reference they keep
+     * gains of their own -- zero until `setBaumgarteFreq` is called on them -- and Engine::start only overwrites those of the
+     * internal constraints (abstract_constraint.cc:88-98, engine.cc:1276-1285).  < 0: the gains of `stabilization_freq`
+     * (what ABI 5 did); >= 0: critically damped gains of this frequency, 0 = a pure acceleration constraint. */
+    double user_stabilization_freq;
 } jm_constraint_options;
 
 typedef struct jm_model jm_model;

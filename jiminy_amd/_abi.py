@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -83,12 +83,13 @@ class ConstraintOptions(C.Structure):
         ("regularization", C.c_double),
         ("tol_abs", C.c_double),
         ("tol_rel", C.c_double),
+        ("user_stabilization_freq", C.c_double),
     ]
 
 
 def make_constraint_options(model="constraint", torsion=0.0, stabilization_freq=20.0,
                             regularization=1.0e-3, tol_abs=1.0e-5, tol_rel=1.0e-4,
-                            pgs_iter_max=100) -> ConstraintOptions:
+                            pgs_iter_max=100, user_stabilization_freq=-1.0) -> ConstraintOptions:
     """Defaults = reference engine.h:262-286, 307-325 (`contacts`, `constraints`, `stepper.tol*`),
     PGS_MAX_ITERATIONS engine.cc:62."""
     o = ConstraintOptions()
@@ -99,6 +100,7 @@ def make_constraint_options(model="constraint", torsion=0.0, stabilization_freq=
     o.regularization = float(regularization)
     o.tol_abs = float(tol_abs)
     o.tol_rel = float(tol_rel)
+    o.user_stabilization_freq = float(user_stabilization_freq)   # (< 0: user constraints share the gains of `stabilization_freq`)
     return o
 
 

@@ -56,6 +56,7 @@ template<class T> struct ConArgs
     T * ws;           // [WTOTAL][B]
     const T * friction;  // [B] per-lane contacts.friction, or null (lane-uniform option)
     T kp, kd;         // Baumgarte gains of contacts.stabilizationFreq (abstract_constraint.cc:88-98)
+    T kp_lock, kd_lock;  // ... of the user-registered constraints (jm_constraint_options::user_stabilization_freq)
     T torsion, reg, tol_abs, tol_rel;
     int iter_max;
     // set by the kernel: per-lane on-chip vector (LDS) of the packed multipliers, element p at xl[p * xstride]
@@ -848,7 +849,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 constexpr int iq = Tp::idx_q[jn], iv = Tp::idx_v[jn];
                 if (act.test(k))
                 {
-                    const T s = C.kp * (q[iq] - dat(k)) + C.kd * v[iv] + af[iv];
+                    const T s = (lck.test(k) ? C.kp_lock : C.kp) * (q[iq] - dat(k)) + (lck.test(k) ? C.kd_lock : C.kd) * v[iv] + af[iv];
                     ws(R::WB + act.rank(k)) = rev.test(k) ? s : -s;
                 }
             });

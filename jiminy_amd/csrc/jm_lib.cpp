@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 5
+#define JM_ABI_VERSION 6
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -111,7 +111,7 @@ struct jm_batch
     int32_t * ov_flags = nullptr; void * ov_data = nullptr; void * ov_ws = nullptr;
     int32_t * ad_count_host = nullptr;  // pinned host
     // constraint contact model (jm_constraint.h)
-    jm_constraint_options copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+    jm_constraint_options copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4, -1.0};
     // optional per-environment variation (GEN kernels): height map, frames of the applied wrenches
     const void * ground_h = nullptr;
     int ground_nx = 0, ground_ny = 0;
@@ -252,7 +252,7 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
     {
         jm::QConArgs<double> C;
         C.flags = C0.flags; C.data = C0.data; C.ws = C0.ws; C.friction = C0.friction;
-        C.kp = C0.kp; C.kd = C0.kd; C.torsion = C0.torsion; C.reg = C0.reg; C.tol_abs = C0.tol_abs; C.tol_rel = C0.tol_rel;
+        C.kp = C0.kp; C.kd = C0.kd; C.kp_lock = C0.kp_lock; C.kd_lock = C0.kd_lock; C.torsion = C0.torsion; C.reg = C0.reg; C.tol_abs = C0.tol_abs; C.tol_rel = C0.tol_rel;
         C.iter_max = C0.iter_max;
         C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
         C.ground_x0 = A.ground_x0; C.ground_y0 = A.ground_y0; C.ground_dx = A.ground_dx; C.ground_dy = A.ground_dy;
@@ -388,6 +388,10 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             const double omega = 2.0 * 3.14159265358979323846 * b->copt.stabilization_freq;  // abstract_constraint.cc:88-98
             C.kp = (T)(omega * omega);
             C.kd = (T)(2.0 * omega);
+            // user-registered constraints: gains of their own when the option says so (jm_constraint_options, ABI 6)
+            const double omega_u = 2.0 * 3.14159265358979323846 * b->copt.user_stabilization_freq;
+            C.kp_lock = b->copt.user_stabilization_freq < 0.0 ? C.kp : (T)(omega_u * omega_u);
+            C.kd_lock = b->copt.user_stabilization_freq < 0.0 ? C.kd : (T)(2.0 * omega_u);
             C.torsion = (T)b->copt.torsion; C.reg = (T)b->copt.regularization;
             C.tol_abs = (T)b->copt.tol_abs; C.tol_rel = (T)b->copt.tol_rel;
             C.iter_max = b->copt.pgs_iter_max;

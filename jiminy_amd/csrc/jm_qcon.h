@@ -89,6 +89,7 @@ template<class T> struct QConArgs
     T * ws;               // [QConRows::WS][B] overflow of the per-robot solver region
     const T * friction;   // [B] per-lane contacts.friction, or null
     T kp, kd, torsion, reg, tol_abs, tol_rel;
+    T kp_lock, kd_lock;   // Baumgarte gains of the user-registered constraints (jm_constraint_options::user_stabilization_freq)
     int iter_max;
     // world.groundProfile as a height map (variation kernels; fields of BatchArgs): contact rows live in the local
     // frame of the ground surface under every contact point (contact_frame, jm_kernels.h); null = flat ground
@@ -639,7 +640,10 @@ JM_DEV void qcon_rhs(CPtr<T> P, const LimbTable<T> & LT, const QConArgs<T> & C, 
     auto bound = [&](int row, T qj, T vj, T aj) {
         if (!cx.act.test(row)) return;
         const int p = cx.act.rank(row);
-        const T s = C.kp * (qj - C.data[(unsigned)row * B32 + r32]) + C.kd * vj + aj;
+        T kp = C.kp, kd = C.kd;
+        if constexpr (qcon_locks<Tp, GND>())
+            if (cx.lock.test(row)) { kp = C.kp_lock; kd = C.kd_lock; }
+        const T s = kp * (qj - C.data[(unsigned)row * B32 + r32]) + kd * vj + aj;
         V.put(m + p, cx.rev.test(row) ? s : -s);
         V.put(p, C.data[(unsigned)(R::LAM + row) * B32 + r32]);
         V.put(2 * m + p, T(0));

@@ -191,11 +191,11 @@ class JointConstraint:
     configuration (the configuration at `start`, `JointConstraint::reset`) by a bilateral kinematic constraint with the
     Baumgarte stabilisation of the contact model.  Registered with `BatchedEngine.add_constraint`.
 
-    `baumgarte_freq` ≙ `AbstractConstraintBase::setBaumgarteFreq` (abstract_constraint.cc:88-98).  Deviation from the
-    reference, where a user constraint keeps gains of its own (zero until set) and `Engine::start` only overwrites those of
-    the internal constraints (engine.cc:1276-1285): the kernels know ONE pair of gains, the one of
-    `contacts.stabilizationFreq`, so `None` (default) follows that option and any other value is refused instead of being
-    silently replaced."""
+    `baumgarte_freq` ≙ `AbstractConstraintBase::setBaumgarteFreq` (abstract_constraint.cc:88-98): a user constraint keeps gains
+    of its own -- `Engine::start` only overwrites those of the internal constraints (engine.cc:1276-1285) -- critically
+    damped for this frequency; 0.0 = the reference's state of a freshly created constraint (a pure acceleration
+    constraint).  `None` (the default HERE, kept from round 3) shares the gains of `contacts.stabilizationFreq`.  The user
+    constraints of one batch share one value (`jm_constraint_options::user_stabilization_freq`, ABI 6)."""
     joint_name: str
     baumgarte_freq: Optional[float] = None
 
@@ -805,7 +805,7 @@ class BatchedEngine:
         co = _abi.make_constraint_options(
             model=ct["model"], torsion=ct["torsion"], stabilization_freq=ct["stabilizationFreq"],
             regularization=self._options["constraints"]["regularization"],
-            tol_abs=st["tolAbs"], tol_rel=st["tolRel"])
+            tol_abs=st["tolAbs"], tol_rel=st["tolRel"], user_stabilization_freq=self._user_constraint_freq())
         self._lib.check(self._L.jm_batch_set_constraint_options(self._batch_h, C.byref(co)))
         if ct["model"] == "constraint" and "con_flags" not in self._fields:
             # per-lane constraint state + delassus workspace (caller-owned, like every batch field)
@@ -834,13 +834,12 @@ class BatchedEngine:
         if name in self._user_constraints:
             raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
         freq = constraint.baumgarte_freq
-        if freq is not None:
-            if freq < 0.0:
-                raise ValueError("Natural frequency must be positive.")                             # abstract_constraint.cc:91-94
-            if abs(float(freq) - float(self._options["contacts"]["stabilizationFreq"])) > 1e-12:
-                raise NotImplementedError("user constraints share the Baumgarte gains of 'contacts.stabilizationFreq' "
-                                          f"({self._options['contacts']['stabilizationFreq']} Hz): set that option, or leave "
-                                          "baumgarte_freq to None")
+        if freq is not None and freq < 0.0:
+            raise ValueError("Natural frequency must be positive.")                                 # abstract_constraint.cc:91-94
+        others = {c.baumgarte_freq for _, c in self._user_constraints.values()}
+        if others and others != {freq}:
+            raise NotImplementedError("the user constraints of a batch share one Baumgarte frequency "
+                                      f"({next(iter(others))}): give this one the same `baumgarte_freq`")
         if self._options["contacts"]["model"] != "constraint" or self.dtype != torch.float64:
             raise NotImplementedError("user constraints need the constraint contact model on a float64 batch")
         if "con_flags" not in self._fields:
@@ -856,6 +855,14 @@ class BatchedEngine:
         self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 1))
         self._fields["con_flags"][row] |= torch.where(mask, 4, 0).to(torch.int32)
         self._user_constraints[name] = (row, constraint)
+        self._apply_options()      # (jm_constraint_options::user_stabilization_freq)
+
+    def _user_constraint_freq(self) -> float:
+        """`jm_constraint_options::user_stabilization_freq`: the Baumgarte frequency the registered user constraints share,
+        -1 = the gains of `contacts.stabilizationFreq` (`baumgarte_freq=None`)."""
+        for _, c in getattr(self, "_user_constraints", {}).values():
+            return -1.0 if c.baumgarte_freq is None else float(c.baumgarte_freq)
+        return -1.0
 
     def remove_constraint(self, name: str) -> None:
         """≙ `Model::removeConstraint(name)` (model.cc:1010-1013)."""
@@ -865,6 +872,7 @@ class BatchedEngine:
         self._fields["con_flags"][row] &= ~4
         if not self._user_constraints:
             self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 0))
+            self._apply_options()
 
     def set_constraint_reference(self, name: str, reference: Any) -> None:
         """≙ `JointConstraint.reference_configuration = ...` (joint_constraint.cc `setReferenceConfiguration`): where the

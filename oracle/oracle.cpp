@@ -449,7 +449,7 @@ struct Engine
     // core/unit/engine_sanity_check.cc:118-121, and the CPU baseline is timed on this code)
     std::vector<double> st_kv[4], st_ka[4], st_incv, st_inca, st_qs, st_vs, st_as;
     // ---- `contacts.model = "constraint"`: per-robot constraint registry + solver state
-    jm_constraint_options copt{JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+    jm_constraint_options copt{JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4, -1.0};
     struct BoundCon  // JointConstraint (core/src/constraints/joint_constraint.cc)
     {
         int joint = 0;
@@ -1229,6 +1229,11 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     // ---- Jacobian, drift, multipliers of the enabled constraints, packed (constraint_solvers.cc:340-360)
     const double omega = 2.0 * M_PI * e.copt.stabilization_freq;  // setBaumgarteFreq (abstract_constraint.cc:88-98)
     const double kp = omega * omega, kd = 2.0 * omega;
+    // user-registered constraints keep gains of their own (abstract_constraint.cc:88-98; Engine::start only sets those of the
+    // internal ones, engine.cc:1276-1285): jm_constraint_options::user_stabilization_freq, < 0 = share the pair above
+    const double omega_u = 2.0 * M_PI * e.copt.user_stabilization_freq;
+    const double kp_u = e.copt.user_stabilization_freq < 0.0 ? kp : omega_u * omega_u;
+    const double kd_u = e.copt.user_stabilization_freq < 0.0 ? kd : 2.0 * omega_u;
     PgsRowSet rs;
     int rows = 0;
     for (const auto & b : e.bcon) if (b.enabled) { rs.cons.push_back({rows, 1, b.locked ? 0 : 1}); rows += 1; }
@@ -1242,7 +1247,7 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         const int iq = m.idx_q[b.joint], iv = m.idx_v[b.joint];
         const double sgn = b.reversed ? -1.0 : 1.0;
         J(r, iv) = sgn;
-        gamma[r] = sgn * (kp * (q[iq] - b.ref) + kd * v[iv]);
+        gamma[r] = sgn * ((b.locked ? kp_u : kp) * (q[iq] - b.ref) + (b.locked ? kd_u : kd) * v[iv]);
         lambda[r] = b.lambda;
         ++r;
     }

@@ -295,7 +295,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
 
 // constraint contact model: options + per-lane state rows (flags int32 [NF][B], data [ND][B]); the
 // delassus workspace is allocated here
-static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4};
+static jm_constraint_options g_copt = {JM_CONTACT_SPRING_DAMPER, 100, 0.0, 20.0, 1.0e-3, 1.0e-5, 1.0e-4, -1.0};
 static void * g_con_flags = nullptr;
 static void * g_con_data = nullptr;
 static void * g_friction = nullptr;
@@ -375,6 +375,11 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
             C.friction = (const T *)g_friction;
             const double omega = 2.0 * 3.14159265358979323846 * g_copt.stabilization_freq;
             C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
+            {
+                const double omega_u = 2.0 * 3.14159265358979323846 * g_copt.user_stabilization_freq;
+                C.kp_lock = g_copt.user_stabilization_freq < 0.0 ? C.kp : (T)(omega_u * omega_u);
+                C.kd_lock = g_copt.user_stabilization_freq < 0.0 ? C.kd : (T)(2.0 * omega_u);
+            }
             C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
             C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
             C.ground_h = A.ground_h; C.ground_nx = A.ground_nx; C.ground_ny = A.ground_ny;
@@ -409,6 +414,11 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         C.friction = (const T *)g_friction;
         const double omega = 2.0 * 3.14159265358979323846 * g_copt.stabilization_freq;
         C.kp = (T)(omega * omega); C.kd = (T)(2.0 * omega);
+            {
+                const double omega_u = 2.0 * 3.14159265358979323846 * g_copt.user_stabilization_freq;
+                C.kp_lock = g_copt.user_stabilization_freq < 0.0 ? C.kp : (T)(omega_u * omega_u);
+                C.kd_lock = g_copt.user_stabilization_freq < 0.0 ? C.kd : (T)(2.0 * omega_u);
+            }
         C.torsion = (T)g_copt.torsion; C.reg = (T)g_copt.regularization;
         C.tol_abs = (T)g_copt.tol_abs; C.tol_rel = (T)g_copt.tol_rel; C.iter_max = g_copt.pgs_iter_max;
         std::vector<T> xvec(jm::ConRows<Topo>::NR + 1, (T)std::nan(""));

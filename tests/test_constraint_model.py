@@ -314,6 +314,43 @@ def test_user_joint_constraints_on_the_host(name, split):
     assert np.abs(ref["con_data"][[nb + r for r in rows]][:, lanes]).max() > 1e-3
 
 
+@pytest.mark.parametrize("name,variant,freq", [("anymal", "quad", 5.0), ("anymal", "quad", 0.0), ("atlas", "split", 5.0),
+                                               ("tree_arm_ff", "lane", 5.0), ("tree_arm", "lane", 0.0)])
+def test_user_joint_constraints_with_gains_of_their_own_on_the_host(name, variant, freq):
+    """`jm_constraint_options::user_stabilization_freq` (ABI 6): user constraints keep Baumgarte gains of their own
+    (abstract_constraint.cc:88-98; `Engine::start` only sets those of the bounds and contacts, engine.cc:1276-1285) -- 5 Hz
+    and 0 Hz (the reference's state of a freshly created constraint: a pure acceleration constraint) next to the 20 Hz of
+    the contacts; kernel sources of both families on the host against the oracle, then the constraint equation itself."""
+    split = variant == "split"
+    variant = "quad" if split else variant
+    model = _models()[name]()
+    B = 8 if name == "anymal" else 4
+    ref, got = _pair(model, B, seed=33)
+    rows = [model.bound_row(j) for j in LOCKS[name]]
+    lanes = np.arange(B) % 2 == 0
+    for arr in (ref, got):
+        for r in rows:
+            arr["con_flags"][r, lanes] |= 4
+    copt = dict(TIGHT, user_stabilization_freq=freq)
+    oracle_batch(model, ref, "start", constraint_options=copt)
+    emu.run(model, got, "start", constraint_options=copt, variant=variant, split=split)
+    _check(got, ref, 1e-8, "start")
+    q0 = {j: ref["q"][int(model.idx_q[model.joint_names.index(j)])].copy() for j in LOCKS[name]}
+    for solver, n_sub in (("euler_explicit", 3), ("runge_kutta_4", 1)):
+        for _ in range(2):
+            kw = dict(solver=solver, dt=5e-4, n_substeps=n_sub, command_changed=True)
+            oracle_batch(model, ref, "step", constraint_options=copt, **kw)
+            emu.run(model, got, "step", constraint_options=copt, variant=variant, split=split, **kw)
+        _check(got, ref, 1e-7, solver)
+    omega = 2.0 * np.pi * freq
+    for j in LOCKS[name]:
+        jj = model.joint_names.index(j)
+        iq, iv = int(model.idx_q[jj]), int(model.idx_v[jj])
+        res = ref["a"][iv] + omega ** 2 * (ref["q"][iq] - q0[j]) + 2.0 * omega * ref["v"][iv]
+        # (with the 20 Hz gains of the contacts instead, the same expression is far from zero on a joint that moved)
+        assert np.abs(res[lanes]).max() < 1e-2 * max(1.0, np.abs(ref["a"][iv]).max()), (j, np.abs(res[lanes]).max())
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_atlas_standing_flat_on_both_feet_start_and_steps(split):
     """A humanoid standing flat: the 8 bottom vertices of each foot box touch, 16 contact points = 64 rows in
@@ -576,8 +613,9 @@ def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_s
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B", [("anymal", 96), ("atlas", 48), ("atlas", 40), ("tree_arm", 64), ("tree_arm_ff", 72)])
-def test_gpu_user_joint_constraints(gpu_device, name, B):
+@pytest.mark.parametrize("name,B,freq", [("anymal", 96, None), ("atlas", 48, None), ("atlas", 40, None), ("tree_arm", 64, None),
+                                         ("tree_arm_ff", 72, None), ("anymal", 64, 5.0), ("atlas", 48, 0.0), ("tree_arm_ff", 40, 5.0)])
+def test_gpu_user_joint_constraints(gpu_device, name, B, freq):
     """`BatchedEngine.add_constraint(name, JointConstraint(joint))` on the device against the oracle: every other lane
     locked (ANYmal: the general Gauss-Seidel form out of LDS; Atlas, 48 lanes: the split form with the unbounded rows first
     in its visit table; 40 lanes: the single kernel; `tree_arm` / `tree_arm_ff`: the one-robot-per-lane kernel), RK4 and Euler steps;
@@ -586,6 +624,8 @@ def test_gpu_user_joint_constraints(gpu_device, name, B):
 
     from jiminy_amd.engine import BadControlFlow, BatchedEngine, JointConstraint
     model = _models()[name]()
+    # (`freq`: Baumgarte frequency of the locks -- None = the gains of the contacts, else gains of their own, ABI 6)
+    COPT = dict(TIGHT, user_stabilization_freq=-1.0 if freq is None else freq)
     ref, _ = _pair(model, B, seed=37)
     lanes = np.arange(B) % 2 == 0
     rows = [model.bound_row(j) for j in LOCKS[name]]
@@ -597,17 +637,17 @@ def test_gpu_user_joint_constraints(gpu_device, name, B):
                                  "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]}, "contacts": {"model": "constraint"}})
     mask = torch.from_numpy(lanes).to(gpu_device)
     for j in LOCKS[name]:
-        eng.add_constraint("lock_" + j, JointConstraint(j), lane_mask=mask)
+        eng.add_constraint("lock_" + j, JointConstraint(j, baumgarte_freq=freq), lane_mask=mask)
     with pytest.raises(ValueError):
-        eng.add_constraint("lock_" + LOCKS[name][0], JointConstraint(LOCKS[name][1]))
+        eng.add_constraint("lock_" + LOCKS[name][0], JointConstraint(LOCKS[name][1], baumgarte_freq=freq))
     eng.set_command(torch.from_numpy(ref["command"]))
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     with pytest.raises(BadControlFlow):
         eng.remove_constraint("lock_" + LOCKS[name][0])
-    oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    oracle_batch(model, ref, "start", constraint_options=COPT)
     for _ in range(3):
         eng.step(2 * dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt, n_substeps=2, command_changed=True)
+        oracle_batch(model, ref, "step", constraint_options=COPT, solver="runge_kutta_4", dt=dt, n_substeps=2, command_changed=True)
     torch.cuda.synchronize()
     assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
     for k in OUTS:
