@@ -117,10 +117,10 @@ def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[s
     return [(tn, c, s) for tn, _, c, s in intervals], t_end, t_err
 
 
-def substep_sizes(dt_next: float, dt_max: float) -> List[float]:
+def substep_sizes(dt_next: float, dt_max: float, dt_first: Optional[float] = None) -> List[float]:
     """Integrator step sizes of a fixed-step solver over one breakpoint interval of length `dt_next`: the inner loop
     of `Engine::step` (engine.cc:2021-2222) for a stepper whose `tryStep` always succeeds and returns `dtLargest = INF`
-    (euler_explicit_stepper.cc:19, abstract_runge_kutta_stepper.cc:74-76), i.e. `dt = min(INF, dtMax)` before every try:
+    (euler_explicit_stepper.cc:19, abstract_runge_kutta_stepper.cc:74-76), i.e. `dt = min(INF, dtMax)` after every try:
 
       * the step is stretched to land exactly on the breakpoint when what would be left after it is below
         `clamp(0.1 dt, STEPPER_MIN_TIMESTEP, SIMULATION_MIN_TIMESTEP)` -- a residual of less than a microsecond is
@@ -128,14 +128,17 @@ def substep_sizes(dt_next: float, dt_max: float) -> List[float]:
       * a step longer than a microsecond that is not a whole number of microseconds is shortened to one (:2080-2089),
         so a `dtMax` that is not a multiple of 1 us advances in microsecond multiples and the last step takes the rest.
 
-    Deviation, documented in DESIGN.md section 1: the reference starts every simulation with ONE probe step of
-    `SIMULATION_MIN_TIMESTEP` (`stepperState_.reset(SIMULATION_MIN_TIMESTEP, ...)`, engine.cc:1176) before it settles on
-    `dtMax`; a batch whose lanes restart individually inside a running launch schedule has one step size per launch,
-    so the batched engine integrates the first interval after `start` like every other one."""
+    `dt_first`: the step size the stepper state carries INTO the interval when it is not `dtMax`.  `Engine::start` resets
+    the stepper state with `dt = SIMULATION_MIN_TIMESTEP` (`stepperState_.reset(SIMULATION_MIN_TIMESTEP, ...)`,
+    engine.cc:1176), and the loop only settles on `dtMax` AFTER its first try (:2220): every simulation opens with one
+    step of a microsecond, so the first interval of a simulation with `dt_next <= dtMax` is integrated as
+    (1e-6, dt_next - 1e-6).  The same two rules apply to that first size (1e-6 is neither stretched, unless the whole
+    interval is shorter than 1.1 us, nor snapped)."""
     sizes: List[float] = []
     t, t_next = 0.0, float(dt_next)
+    dt_state = float(dt_first) if dt_first is not None else float(dt_max)
     while t_next - t > STEPPER_MIN_TIMESTEP:
-        dt = dt_max
+        dt = dt_state
         thr = min(max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP)
         if t_next - t < dt + thr:
             dt = t_next - t
@@ -145,23 +148,26 @@ def substep_sizes(dt_next: float, dt_max: float) -> List[float]:
                 dt -= res
         sizes.append(dt)
         t += dt
+        dt_state = float(dt_max)      # `dt = min(dtLargest = INF, dtMax)` (engine.cc:2220)
     if not sizes:
         sizes.append(float(dt_next))
     return sizes
 
 
 def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dict[str, Any]],
-              extra_breakpoints: Tuple[float, ...] = ()) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
+              extra_breakpoints: Tuple[float, ...] = (), dt_first: Optional[float] = None
+              ) -> Tuple[List[Tuple[float, int, bool, bool]], float, float]:
     """Fixed-step schedule of one `Engine::step(step_size)` call: the breakpoint intervals cut in sub-steps of
     `dtMax` by the reference's rule (`substep_sizes`: residual merge and microsecond snapping, engine.cc:2063-2089).
     Returns (launches, t_end, t_error) where each launch is `(dt, n_substeps, command_changed, update_sensors)`:
-    consecutive sub-steps of the same size share a launch."""
+    consecutive sub-steps of the same size share a launch.  `dt_first` = the step size carried into the FIRST interval
+    (`SIMULATION_MIN_TIMESTEP` for the first step after `start`, engine.cc:1176)."""
     dt_max = float(options["stepper"]["dtMax"])
     intervals, t_end, t_error = _breakpoint_intervals(t, t_error, step_size, options, extra_breakpoints)
     launches: List[Tuple[float, int, bool, bool]] = []
-    for _, dt_next, command_changed, update_sensors in intervals:
+    for k, (_, dt_next, command_changed, update_sensors) in enumerate(intervals):
         groups: List[List[Any]] = []
-        for dt in substep_sizes(dt_next, dt_max):
+        for dt in substep_sizes(dt_next, dt_max, dt_first if k == 0 else None):
             # (steps that differ by the round-off of the time accumulation -- below 1e-14 s -- share a launch)
             if groups and abs(groups[-1][0] - dt) <= 1.0e-14:
                 groups[-1][1] += 1
@@ -638,6 +644,7 @@ class BatchedEngine:
         self._fields["status"] = torch.zeros((1, B), dtype=torch.int32, device=self.device)
         self._bind("status")
         self._running = False
+        self._opening_step = False
         self._t = 0.0
         self._t_prev = 0.0
         self._t_error = 0.0
@@ -1027,6 +1034,10 @@ class BatchedEngine:
         self._setup_adaptive()
         self._running = True
         self._command_dirty = False
+        # `stepperState_.reset(SIMULATION_MIN_TIMESTEP, ...)` (engine.cc:1176): the next `step` opens with a 1 us step.
+        # (`reset_lanes` re-initialises lanes INSIDE a running simulation whose launches carry one step size for the
+        # whole batch: those lanes continue with `dtMax`)
+        self._opening_step = True
 
     def stop(self) -> None:
         """≙ `Engine::stop` (reference engine.cc:2419-2460)."""
@@ -1132,8 +1143,11 @@ class BatchedEngine:
         if self._adaptive is not None:
             self._step_adaptive(step_dt)
             return
+        # the first step of a simulation opens with the reference's microsecond step (engine.cc:1176; `substep_sizes`)
         launches, t_end, t_err = plan_step(self._t, self._t_error, float(step_dt), self._options,
-                                           self._force_breakpoints(self._t))
+                                           self._force_breakpoints(self._t),
+                                           dt_first=SIMULATION_MIN_TIMESTEP if self._opening_step else None)
+        self._opening_step = False
         solver = SOLVER_IDS[self._options["stepper"]["odeSolver"]]
         stream = self._stream()
         # continuous sensor refresh (sensorsUpdatePeriod = 0) draws noise after every integrator step

@@ -619,8 +619,14 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         eng._command_dirty = False
 
     def step(self, action: torch.Tensor):
+        # (the first step of a simulation carries the reference's opening microsecond step -- `engine.substep_sizes` --:
+        # it is issued eagerly, the periodic plan is captured from the second step on)
         if not getattr(self, "_graph_whole", False):
             return super().step(action)
+        if self.engine._opening_step:
+            obs, reward, terminated, truncated, info = super().step(action)
+            info.setdefault("reset_mask", terminated | truncated)
+            return obs, reward, terminated, truncated, info
         if not self.engine.is_simulation_running:
             raise RuntimeError("No simulation running. Please call `reset` before `step`.")
         if tuple(action.shape) != (self.num_envs, self.model.nmotors):
@@ -630,7 +636,7 @@ class PDControlledWalkerVecEnv(WalkerVecEnv):
         return self.observation(), reward, terminated, truncated, {"reset_mask": done}
 
     def _step_engine(self, action: torch.Tensor) -> None:
-        if getattr(self, "_graph_enabled", False):
+        if getattr(self, "_graph_enabled", False) and not self.engine._opening_step:
             self._step_engine_graphed(action)
         else:
             self._refill_impulses(self.step_dt)

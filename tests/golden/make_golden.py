@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 
 from jiminy_amd import load_builtin  # noqa: E402
 from jiminy_amd.synthetic import sample_standing_states, sample_states  # noqa: E402
-from tests.helpers import alloc_constraint_state, alloc_soa, oracle_batch  # noqa: E402
+from tests.helpers import (ReferenceFixedStepLoop, alloc_constraint_state, alloc_soa, oracle_batch,  # noqa: E402
+                           oracle_engine_step)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 FIELDS = ("q", "v", "a", "u_motor", "imu", "force", "encoder", "effort", "energy", "contact_forces")
@@ -34,11 +35,11 @@ def main() -> None:
         for k in ("q", "v", "command"):
             arr[k][:] = st[k]
         oracle_batch(model, arr, "start")
+        loop = ReferenceFixedStepLoop(5e-4)     # `Engine::step` periods: the first one opens with the reference's 1 us step
         out = {"in_q": st["q"], "in_v": st["v"], "in_command": st["command"]}
         out.update({"start_" + k: arr[k].copy() for k in FIELDS})
         for i in range(10):
-            oracle_batch(model, arr, "step", solver="runge_kutta_4", dt=5e-4, n_substeps=1,
-                         command_changed=(i == 0))
+            oracle_engine_step(model, arr, loop, 5e-4, "runge_kutta_4", command_changed=(i == 0))
         out.update({"rk4_" + k: arr[k].copy() for k in FIELDS})
         out["status"] = arr["status"].copy()
         np.savez_compressed(os.path.join(OUT, f"{name}_oracle.npz"), **out)
@@ -52,11 +53,11 @@ def main() -> None:
         for k in ("q", "v", "command"):
             arr[k][:] = st[k]
         oracle_batch(model, arr, "start", constraint_options=CON_OPTIONS)
+        loop = ReferenceFixedStepLoop(5e-4)
         out = {"in_q": st["q"], "in_v": st["v"], "in_command": st["command"]}
         out.update({"start_" + k: arr[k].copy() for k in CON_FIELDS})
         for i in range(6):
-            oracle_batch(model, arr, "step", constraint_options=CON_OPTIONS, solver="euler_explicit", dt=5e-4,
-                         n_substeps=1, command_changed=True)
+            oracle_engine_step(model, arr, loop, 5e-4, "euler_explicit", command_changed=True, constraint_options=CON_OPTIONS)
         out.update({"euler_" + k: arr[k].copy() for k in CON_FIELDS})
         out["status"] = arr["status"].copy()
         np.savez_compressed(os.path.join(OUT, f"{name}_constraint_oracle.npz"), **out)

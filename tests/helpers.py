@@ -54,3 +54,53 @@ def rel_err(x: np.ndarray, ref: np.ndarray, lanes=None) -> float:
     num = np.abs(x - ref).max(axis=0)
     den = np.maximum(np.abs(ref).max(axis=0), 1.0)
     return float((num / den).max())
+
+
+SIMULATION_MIN_TIMESTEP, STEPPER_MIN_TIMESTEP = 1e-6, 1e-10     # reference constants.h:18-20
+
+
+class ReferenceFixedStepLoop:
+    """The reference's inner integration loop (engine.cc:2021-2222) for a fixed-step stepper, around the oracle: the
+    test-side statement of WHICH sub-steps `Engine::step` takes between two breakpoints, written from the reference and
+    independent of `jiminy_amd.engine.substep_sizes`.
+
+    `self.dt` is `stepperState_.dt`: `SIMULATION_MIN_TIMESTEP` after `Engine::start` (engine.cc:1176: every
+    simulation opens with one microsecond step), `min(dtLargest = INF, dtMax)` after every try (:2220)."""
+
+    def __init__(self, dt_max: float) -> None:
+        self.dt_max = float(dt_max)
+        self.dt = SIMULATION_MIN_TIMESTEP
+
+    def sizes(self, interval: float):
+        """Sub-step sizes up to the next breakpoint, `interval` seconds away."""
+        left = float(interval)
+        while left > STEPPER_MIN_TIMESTEP:
+            dt = self.dt
+            residual_thr = min(max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP)    # :2063-2068
+            if left < dt or left < dt + residual_thr:                                           # :2069-2073
+                dt = left
+            if dt > SIMULATION_MIN_TIMESTEP:                                                    # :2080-2089
+                r = float(np.fmod(dt, SIMULATION_MIN_TIMESTEP))
+                if STEPPER_MIN_TIMESTEP < r < SIMULATION_MIN_TIMESTEP - STEPPER_MIN_TIMESTEP and dt - r > STEPPER_MIN_TIMESTEP:
+                    dt -= r
+            yield dt
+            left -= dt
+            self.dt = self.dt_max                                                               # :2220
+
+    def advance(self, run_step, interval: float, command_changed: bool = False) -> int:
+        """`run_step(dt, command_changed)` once per sub-step of the interval; returns their number."""
+        n = 0
+        for dt in self.sizes(interval):
+            run_step(dt, command_changed and n == 0)
+            n += 1
+        return n
+
+
+def oracle_engine_step(model: CompiledModel, arr: Dict[str, np.ndarray], loop: ReferenceFixedStepLoop, interval: float,
+                       solver: str, command_changed: bool = False, options=None, constraint_options=None, **kw) -> int:
+    """One breakpoint interval of `Engine::step` on the oracle: the sub-steps of `loop` (opening microsecond step
+    included), `command_changed` (the a(t+) refresh, engine.cc:2030-2042) on the first one only."""
+    return loop.advance(lambda dt, changed: oracle_batch(model, arr, "step", options=options,
+                                                         constraint_options=constraint_options, solver=solver, dt=dt,
+                                                         n_substeps=1, command_changed=changed, **kw),
+                        interval, command_changed)

@@ -9,7 +9,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from oracle.oracle_py import OracleEngine, adaptive_state
-from tests.helpers import alloc_constraint_state, alloc_soa, oracle_io
+from tests.helpers import ReferenceFixedStepLoop, alloc_constraint_state, alloc_soa, oracle_io
 
 MIN_DT = 1e-10   # STEPPER_MIN_TIMESTEP (constants.h:18)
 
@@ -49,6 +49,7 @@ class OracleSim:
         self.e.batch_run("start", self.io)
         self.t = 0.0
         self.ad = adaptive_state(1)
+        self.loop = ReferenceFixedStepLoop(0.0)      # stepper state of a fresh simulation: dt = 1 us (engine.cc:1176)
 
     def _set_wrench(self, t: float) -> None:
         if self.wrench is None:
@@ -88,9 +89,10 @@ class OracleSim:
                 self.e.batch_run_dopri(self.arr, self.ad, t_next, tol_rel=tol_rel, tol_abs=tol_abs, dt_max=dt_max,
                                        new_step=True, command_changed=changed, update_sensors=True)
             else:
-                n = max(1, int(np.ceil((t_next - self.t) / dt_max - 1e-9)))
-                self.e.batch_run("step", self.io, solver=solver, dt=(t_next - self.t) / n, n_substeps=n,
-                                 command_changed=changed)
+                # the reference's own sub-step rule, opening microsecond step included (engine.cc:2021-2222)
+                self.loop.dt_max = float(dt_max)
+                self.loop.advance(lambda dt, first: self.e.batch_run("step", self.io, solver=solver, dt=dt, n_substeps=1,
+                                                                     command_changed=first), t_next - self.t, changed)
             self.t = t_next
             log.append(self.row())
         out = {k: np.stack([r[k] for r in log]) for k in log[0] if k != "t"}

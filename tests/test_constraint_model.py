@@ -18,7 +18,7 @@ from jiminy_amd.synthetic import sample_standing_states, sample_states
 from oracle import rbd_numpy as rbd
 from oracle.oracle_py import OracleEngine
 from tests import robots
-from tests.helpers import alloc_constraint_state, alloc_soa, oracle_batch, rel_err
+from tests.helpers import ReferenceFixedStepLoop, alloc_constraint_state, alloc_soa, oracle_batch, oracle_engine_step, rel_err
 from tests.hostemu import emu
 
 G = 9.81
@@ -520,6 +520,7 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
         eng.set_command(torch.from_numpy(ref["command"]))
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
 
     def check(tol, what):
         torch.cuda.synchronize()
@@ -538,8 +539,7 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
     check(1e-7, "start")
     for i in range(4):
         eng.step(dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="euler_explicit", dt=dt,
-                     n_substeps=1, command_changed=True)
+        oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True, constraint_options=TIGHT)
     # after steps: the north-star bar (1e-5 relative on accelerations); observed 1e-13 (Atlas) ... 1e-6
     # (ANYmal, whose PGS solves run close to the iteration cap at these tolerances)
     check(1e-5, "euler")
@@ -549,11 +549,11 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
     # (Baumgarte damping 2 * omega = 250 /s on the contact rows), 1e-8 of state difference would show as 1e-5
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     check(1e-5, "restart")
     for i in range(2):
         eng.step(dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt,
-                     n_substeps=1, command_changed=True)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=True, constraint_options=TIGHT)
     # 10 more evaluations: ANYmal's solves sit at the iteration cap with these tolerances (status bit 16 on
     # both sides), the iterate reached after 100 sweeps moves with round-off: 6e-6 on `a` (inside the
     # north-star bar), 1.3e-5 on the contact forces; every other robot stays below 1e-10
@@ -590,11 +590,12 @@ def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_s
         engines.append(eng)
     if with_oracle:
         oracle_batch(model, ref, "start", constraint_options=TIGHT)
+        loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for i in range(3):
         for eng in engines:
             eng.step(n_sub * dt)
         if with_oracle:
-            oracle_batch(model, ref, "step", constraint_options=TIGHT, solver=solver, dt=dt, n_substeps=n_sub, command_changed=True)
+            oracle_engine_step(model, ref, loop, n_sub * dt, solver, command_changed=True, constraint_options=TIGHT)
     torch.cuda.synchronize()
     split, single = engines
     assert np.array_equal(split.field("con_flags").cpu().numpy(), single.field("con_flags").cpu().numpy())
@@ -645,9 +646,10 @@ def test_gpu_user_joint_constraints(gpu_device, name, B, freq):
     with pytest.raises(BadControlFlow):
         eng.remove_constraint("lock_" + LOCKS[name][0])
     oracle_batch(model, ref, "start", constraint_options=COPT)
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for _ in range(3):
         eng.step(2 * dt)
-        oracle_batch(model, ref, "step", constraint_options=COPT, solver="runge_kutta_4", dt=dt, n_substeps=2, command_changed=True)
+        oracle_engine_step(model, ref, loop, 2 * dt, "runge_kutta_4", command_changed=True, constraint_options=COPT)
     torch.cuda.synchronize()
     assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
     for k in OUTS:
@@ -880,10 +882,10 @@ def test_gpu_per_lane_friction_and_env_ground_randomisation(gpu_device):
     eng.set_command(torch.from_numpy(ref["command"]))
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for _ in range(3):
         eng.step(dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="euler_explicit", dt=dt, n_substeps=1,
-                     command_changed=True)
+        oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True, constraint_options=TIGHT)
     torch.cuda.synchronize()
     assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
     for k in ("q", "v", "a", "con_data"):
@@ -924,9 +926,9 @@ def test_gpu_constraint_model_full_size_replicas_and_repeatability(gpu_device):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start", constraint_options={})
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for _ in range(steps):
-        oracle_batch(model, ref, "step", constraint_options={}, solver="euler_explicit", dt=dt, n_substeps=1,
-                     command_changed=True)
+        oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True, constraint_options={})
     eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
     eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt,
                                  "sensorsUpdatePeriod": dt}, "contacts": {"model": "constraint"}})
@@ -968,10 +970,10 @@ def test_gpu_constraint_model_ragged_and_tiny_batches(gpu_device, B):
     eng.set_command(torch.from_numpy(ref["command"]))
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     oracle_batch(model, ref, "start", constraint_options=TIGHT)
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for _ in range(2):
         eng.step(dt)
-        oracle_batch(model, ref, "step", constraint_options=TIGHT, solver="runge_kutta_4", dt=dt, n_substeps=1,
-                     command_changed=True)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=True, constraint_options=TIGHT)
     torch.cuda.synchronize()
     assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"])
     for k in ("q", "v", "a", "con_data", "imu"):
@@ -1001,11 +1003,11 @@ def test_gpu_constraint_model_long_horizon(gpu_device):
     eng.set_command(torch.zeros((model.nmotors, B), dtype=torch.float64))
     eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
     oracle_batch(model, ref, "start", constraint_options={})
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     worst = np.zeros(B)
     for i in range(steps // 50):
         eng.step(50 * dt)
-        oracle_batch(model, ref, "step", constraint_options={}, solver="euler_explicit", dt=dt, n_substeps=50,
-                     command_changed=False)
+        oracle_engine_step(model, ref, loop, 50 * dt, "euler_explicit", command_changed=False, constraint_options={})
         a = eng.field("a").cpu().numpy()
         err = np.abs(a - ref["a"]).max(axis=0) / np.maximum(np.abs(ref["a"]).max(axis=0), 1.0)
         worst = np.maximum(worst, err)

@@ -112,3 +112,69 @@ def test_engine_refuses_to_run_without_a_gpu():
     from jiminy_amd import load_builtin
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         E.BatchedEngine(load_builtin("cartpole"), 8)
+
+
+def test_a_simulation_opens_with_the_reference_microsecond_step():
+    """`Engine::start` resets the stepper state with dt = SIMULATION_MIN_TIMESTEP (engine.cc:1176) and the loop only
+    settles on dtMax after its first try (:2220): the first interval is (1 us, rest)."""
+    assert E.substep_sizes(1e-3, 1e-3, E.SIMULATION_MIN_TIMESTEP) == [1e-6, pytest.approx(9.99e-4, rel=1e-12)]
+    sizes = E.substep_sizes(5e-3, 1e-3, 1e-6)       # 1 us, four dtMax steps, then what is left (0.999 ms)
+    assert len(sizes) == 6 and sizes[0] == 1e-6 and sizes[1:5] == [1e-3] * 4 and sizes[5] == pytest.approx(9.99e-4, rel=1e-9)
+    assert abs(sum(sizes) - 5e-3) < 1e-18
+    assert E.substep_sizes(1e-3, 2e-2, 1e-6) == [1e-6, pytest.approx(9.99e-4, rel=1e-12)]     # dtMax above the period
+    # the launch plan: the a(t+) refresh belongs to the microsecond step, the sensor update to the end of the interval
+    o = _opts(dtMax=1e-3, controllerUpdatePeriod=5e-3, sensorsUpdatePeriod=5e-3, odeSolver="euler_explicit")
+    launches, t_end, _ = E.plan_step(0.0, 0.0, 5e-3, o, dt_first=1e-6)
+    assert [(round(dt * 1e9), n, c, s) for dt, n, c, s in launches] == [(1000, 1, True, False), (1000000, 4, False, False),
+                                                                        (999000, 1, False, True)]
+    assert t_end == pytest.approx(5e-3)
+    # only the first interval of the call carries it
+    launches, _, _ = E.plan_step(0.0, 0.0, 1e-2, o, dt_first=1e-6)
+    assert [n for _, n, _, _ in launches] == [1, 4, 1, 5]
+    # and the test-side statement of the reference's loop (tests/helpers.py) agrees with the engine's on random cases
+    from tests.helpers import ReferenceFixedStepLoop
+    rg = np.random.default_rng(3)
+    for _ in range(2000):
+        dt_max = float(rg.choice([1e-3, 5e-4, 1.2345e-3, 2e-2, 3.3e-6, 1e-6, 7.77e-4]))
+        interval = float(rg.choice([1e-3, 5e-3, 4e-2, 1.05e-6, 1e-6, 3.14159e-3, 2e-6]))
+        loop = ReferenceFixedStepLoop(dt_max)
+        assert np.allclose(list(loop.sizes(interval)), E.substep_sizes(interval, dt_max, 1e-6), rtol=0, atol=1e-15)
+        assert np.allclose(list(loop.sizes(interval)), E.substep_sizes(interval, dt_max), rtol=0, atol=1e-15)   # (settled)
+
+
+def test_first_interval_with_euler_equals_the_hand_computed_two_step_result():
+    """A point mass in free fall (a = -g exactly), explicit Euler, dt = 1 ms: the reference integrates the first
+    interval as 1 us + 999 us, i.e. z = z0 + v0 dt1 + (v0 - g dt1) dt2 and v = v0 - g (dt1 + dt2) -- 9.8e-9 m below the
+    single-step result.  The launches of `plan_step` run through the host emulation of the kernels, the oracle
+    through the test-side loop; both must give the hand-computed numbers."""
+    from tests.hostemu import emu
+    from tests.helpers import ReferenceFixedStepLoop, alloc_soa, oracle_engine_step, oracle_batch
+    from tests.robots import point_mass
+    model = point_mass()
+    g, z0, vz0, dt = 9.81, 5.0, 0.3, 1e-3
+    o = _opts(dtMax=dt, controllerUpdatePeriod=dt, sensorsUpdatePeriod=dt, odeSolver="euler_explicit")
+
+    def fresh():
+        arr = alloc_soa(model, 1)
+        arr["q"][:, 0] = [0.1, -0.2, z0, 0.0, 0.0, 0.0, 1.0]
+        arr["v"][2, 0] = vz0
+        return arr
+    got, ref = fresh(), fresh()
+    emu.run(model, got, "start")
+    oracle_batch(model, ref, "start")
+    launches, _, _ = E.plan_step(0.0, 0.0, dt, o, dt_first=E.SIMULATION_MIN_TIMESTEP)
+    assert len(launches) == 2
+    for h, n, changed, sens in launches:
+        emu.run(model, got, "step", solver="euler_explicit", dt=h, n_substeps=n, command_changed=changed, update_sensors=sens)
+    loop = ReferenceFixedStepLoop(dt)
+    assert oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True) == 2
+    dt1, dt2 = 1e-6, dt - 1e-6
+    z_hand = z0 + vz0 * dt1 + (vz0 - g * dt1) * dt2
+    v_hand = vz0 - g * dt1 - g * dt2
+    for arr in (got, ref):
+        assert arr["q"][2, 0] == pytest.approx(z_hand, abs=1e-15) and arr["v"][2, 0] == pytest.approx(v_hand, abs=1e-15)
+    assert abs(z_hand - (z0 + vz0 * dt)) > 9e-9          # the single-step result is measurably different
+    # second interval: one step of dtMax
+    launches, _, _ = E.plan_step(dt, 0.0, dt, o)
+    assert [(n) for _, n, _, _ in launches] == [1]
+    assert oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True) == 1

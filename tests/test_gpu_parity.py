@@ -6,7 +6,7 @@ import torch
 from jiminy_amd import load_builtin
 from jiminy_amd.engine import BatchedEngine
 from jiminy_amd.synthetic import sample_states
-from tests.helpers import alloc_soa, oracle_batch, rel_err
+from tests.helpers import ReferenceFixedStepLoop, alloc_soa, oracle_batch, oracle_engine_step, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,7 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     eng = _engine(model, B, torch.float64, solver, dt)
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
@@ -44,7 +45,7 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
     assert np.array_equal(eng.status.cpu().numpy(), ref["status"][0])
     nsteps = 20
     for i in range(nsteps):
-        oracle_batch(model, ref, "step", solver=solver, dt=dt, n_substeps=1, command_changed=(i == 0))
+        oracle_engine_step(model, ref, loop, dt, solver, command_changed=(i == 0))
         if i == 0:
             eng.mark_command_changed()
         eng.step(dt)
@@ -82,12 +83,13 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
         if st[k].shape[0]:
             ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     if model.nmotors:
         eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     for i in range(8):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
         eng.step(dt)
     ok = (ref["status"][0] & 1) == 0
     assert ok.sum() > B // 2
@@ -144,6 +146,7 @@ def test_library_self_test_guards_against_miscompiled_builds(gpu_device, monkeyp
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     import warnings
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
@@ -156,7 +159,7 @@ def test_library_self_test_guards_against_miscompiled_builds(gpu_device, monkeyp
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     for i in range(4):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
         eng.step(dt)
     ok = (ref["status"][0] & 1) == 0
     for k in OUTS:
@@ -175,11 +178,12 @@ def test_anymal_generic_lane_kernel_matches_oracle(gpu_device, monkeypatch):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     for i in range(10):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
         eng.step(dt)
     ok = (ref["status"][0] & 1) == 0
     for k in OUTS + ("energy", "joint_forces", "centroidal"):
@@ -192,6 +196,7 @@ def _run_1000(model, st, dt, gpu_device):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
@@ -199,8 +204,7 @@ def _run_1000(model, st, dt, gpu_device):
     contact = np.zeros(B, dtype=bool)
     err = np.zeros(B)
     for i in range(1000):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1,
-                     command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
         eng.step(dt)
         contact |= np.abs(ref["contact_forces"]).sum(axis=0) > 0
         if (i + 1) % 50 == 0:
@@ -252,6 +256,53 @@ def test_anymal_1000_steps_parity_with_contacts(gpu_device):
     e = err[valid]
     assert np.median(e) <= 1e-8, np.median(e)
     assert (e <= 1e-5).mean() >= 0.9, (e <= 1e-5).mean()
+
+
+def test_anymal_free_running_window_at_the_benchmarked_step(gpu_device):
+    """The BENCHMARKED configuration free-running (no teacher forcing): first 256 lanes of the bench batch
+    (`sample_states(seed=0)`, a quarter start in ground contact), RK4 at dt = 1e-3, default ground.  Oracle and device
+    integrate independently from the same initial state through the engine's own `step` (opening microsecond step
+    included); every lane is compared at EVERY step for as long as the oracle's lane stays in the region where the
+    comparison means something (|v| <= 1e3, |a| <= 1e9, status 0: explicit RK4 is outside its stability region on this
+    ground, lanes that touch down leave it within ~150 steps).  Bars: the median window is >= 100
+    steps; over its window a lane's worst relative error on the generalised accelerations has median <= 1e-8 and
+    >= 90 % of the lanes stay within the north-star 1e-5 (an unstable integration amplifies the round-off of two
+    summation orders at the rate it amplifies the state: the host emulation of the same kernels against the oracle
+    gives 97 % on 128 lanes)."""
+    model = load_builtin("anymal")
+    _open_bounds(model)
+    B, dt, steps = 256, 1e-3, 300
+    st = sample_states(model, 65536, seed=0)
+    ref = alloc_soa(model, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k][:, :B]
+    oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)
+    eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
+    eng.set_command(torch.from_numpy(np.ascontiguousarray(st["command"][:, :B])))
+    eng.start(torch.from_numpy(np.ascontiguousarray(st["q"][:, :B])), torch.from_numpy(np.ascontiguousarray(st["v"][:, :B])))
+    alive = np.ones(B, dtype=bool)
+    window = np.zeros(B, dtype=int)
+    worst = np.zeros(B)
+    contact = np.zeros(B, dtype=bool)
+    for i in range(steps):
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
+        eng.step(dt)
+        alive &= (ref["status"][0] == 0) & np.isfinite(ref["a"]).all(axis=0) & (np.abs(ref["v"]).max(axis=0) <= 1e3) \
+            & (np.abs(ref["a"]).max(axis=0) <= 1e9)
+        got = eng.field("a").cpu().numpy()
+        e = np.abs(got - ref["a"]).max(axis=0) / np.maximum(np.abs(ref["a"]).max(axis=0), 1.0)
+        e = np.where(np.isfinite(e), e, np.inf)
+        worst = np.where(alive, np.maximum(worst, e), worst)
+        window += alive
+        contact |= alive & (np.abs(ref["contact_forces"]).sum(axis=0) > 0)
+    print(f"free-running dt=1e-3: median window {np.median(window):.0f} steps (min {window.min()}), {int(contact.sum())} lanes touched "
+          f"the ground inside their window, {int(alive.sum())} still inside after {steps} steps; worst-lane error median "
+          f"{np.median(worst):.1e}, p90 {np.quantile(worst, 0.9):.1e}, within 1e-5: {(worst <= 1e-5).mean():.3f}")
+    assert np.median(window) >= 100, np.median(window)
+    assert contact.sum() >= B // 4, contact.sum()
+    assert np.median(worst) <= 1e-8, np.median(worst)
+    assert (worst <= 1e-5).mean() >= 0.9, (worst <= 1e-5).mean()
 
 
 def _teacher_forced_run(model, st, B, dt, steps, step_and_compare):
@@ -317,6 +368,7 @@ def _teacher_forced_test(gpu_device, name, B, dt, steps, pool, min_contact_steps
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     eng.set_command(torch.from_numpy(np.ascontiguousarray(st["command"][:, :B])))
     eng.start(torch.from_numpy(np.ascontiguousarray(st["q"][:, :B])), torch.from_numpy(np.ascontiguousarray(st["v"][:, :B])))
+    eng.step(dt)     # (the opening 1 us + 999 us interval of the simulation: every step below restarts from the oracle's state)
     worst = {"dynamics": np.zeros(B), "a": np.zeros(B), "q": np.zeros(B), "v": np.zeros(B)}
     count = {"lane_steps": 0, "contact_steps": 0}
 
@@ -452,6 +504,7 @@ def test_multi_substep_launches_match_oracle(gpu_device, name, solver):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)
     eng = BatchedEngine(model, B, dtype=torch.float64, extra_outputs=EXTRA)
     eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
                                  "sensorsUpdatePeriod": n_sub * dt}, "contacts": {"model": "spring_damper"}})
@@ -464,14 +517,15 @@ def test_multi_substep_launches_match_oracle(gpu_device, name, solver):
             cmd = st["command"] * rng.uniform(0.5, 1.0)
             ref["command"][:] = cmd
             eng.set_command(torch.from_numpy(cmd))
-        oracle_batch(model, ref, "step", solver=solver, dt=dt, n_substeps=n_sub, command_changed=changed)
+        n_done = oracle_engine_step(model, ref, loop, n_sub * dt, solver, command_changed=changed)
+        assert n_done == (n_sub + 1 if i == 0 else n_sub)       # the opening microsecond step of the simulation
         eng.step(n_sub * dt)
     torch.cuda.synchronize()
     ok = (ref["status"][0] & 1) == 0
     assert ok.sum() > 0.5 * B
     for k in OUTS + ("u", "energy", "f_external"):
         assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < 1e-8, k
-    assert abs(eng.stepper_state.t - 4 * n_sub * dt) < 1e-12
+    assert abs(eng.stepper_state.t - 4 * n_sub * dt) < 1e-12 and eng.stepper_state.iter == 4 * n_sub + 1
 
 
 def _dopri_pair(model, B, st, step_dt, n_steps, tol_rel, tol_abs, dt_max=0.02, ctrl=0.0):
@@ -628,11 +682,12 @@ def test_ragged_and_tiny_batches(gpu_device, name, B):
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     eng.set_command(torch.from_numpy(st["command"]))
     eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
     for i in range(5):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
         eng.step(dt)
     ok = (ref["status"][0] & 1) == 0
     for k in OUTS:
@@ -665,8 +720,9 @@ def test_full_size_batch_replica_invariance_and_repeatability(gpu_device, name, 
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for i in range(steps):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
     eng = _engine(model, B, torch.float64, "runge_kutta_4", dt)
     runs = []
     for rep in range(2):
@@ -698,17 +754,18 @@ def test_simulate_runs_to_t_end_or_until_the_callback_stops_it(gpu_device):
     with pytest.raises(ValueError, match="shorter than 5ms"):
         eng.simulate(1e-3, q0, v0)
     eng.simulate(0.05, q0, v0)
-    assert not eng.is_simulation_running and abs(eng.stepper_state.t - 0.05) < 1e-12 and eng.stepper_state.iter == 50
+    assert not eng.is_simulation_running and abs(eng.stepper_state.t - 0.05) < 1e-12 and eng.stepper_state.iter == 51   # (50 periods + the opening 1 us step)
     ref = alloc_soa(model, B)
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
     oracle_batch(model, ref, "start")
+    loop = ReferenceFixedStepLoop(dt)   # the reference's sub-step rule: opens with a 1 us step (engine.cc:1176)
     for i in range(50):
-        oracle_batch(model, ref, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
     assert rel_err(eng.field("q").cpu().numpy(), ref["q"], np.ones(B, bool)) < 1e-10
     calls = []
     eng.simulate(0.05, q0, v0, callback=lambda: len(calls) < 7 and not calls.append(0))
-    assert eng.stepper_state.iter == 7
+    assert eng.stepper_state.iter == 8
     eng.set_options({"stepper": {"iterMax": 12}})
     eng.simulate(0.05, q0, v0)
     assert eng.stepper_state.iter == 12

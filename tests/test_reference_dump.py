@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from jiminy_amd import load_builtin
-from tests.helpers import alloc_soa, oracle_batch, rel_err
+from tests.helpers import ReferenceFixedStepLoop, alloc_soa, oracle_batch, oracle_engine_step, rel_err
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = ["double_pendulum", "cartpole", "anymal", "atlas"]
@@ -66,8 +66,9 @@ def test_oracle_matches_the_reference_binary(name):
     assert rel_err(arr["a"], g["dynamics_a"], started) < 1e-9
     dt = float(g["dt"])
     worst = 0.0
+    loop = ReferenceFixedStepLoop(dt)     # the binary's first `step(dt)` is 1 us + the rest (engine.cc:1176)
     for i in range(g["traj_a"].shape[0]):
-        oracle_batch(model, arr, "step", solver="runge_kutta_4", dt=dt, n_substeps=1, command_changed=False)
+        oracle_engine_step(model, arr, loop, dt, "runge_kutta_4", command_changed=False)
         ok = started & (arr["status"][0] == 0) & np.isfinite(g["traj_a"][i]).all(axis=0)
         for k in ("q", "v", "a"):
             worst = max(worst, rel_err(arr[k], g["traj_" + k][i], ok))
@@ -136,8 +137,9 @@ def test_oracle_constraint_model_matches_the_reference_binary(name):
     assert rel_err(arr["a"], g["con_start_a"], started) < 1e-7
     dt = float(g["con_dt"])
     worst = 0.0
+    loop = ReferenceFixedStepLoop(dt)
     for i in range(g["con_traj_a"].shape[0]):
-        e.batch_run("step", io, solver="euler_explicit", dt=dt, n_substeps=1, command_changed=True)
+        loop.advance(lambda h, first: e.batch_run("step", io, solver="euler_explicit", dt=h, n_substeps=1, command_changed=first), dt, True)
         ok = started & ((arr["status"][0] & 1) == 0) & np.isfinite(g["con_traj_a"][i]).all(axis=0)
         for k in ("q", "v", "a"):
             worst = max(worst, rel_err(arr[k], g["con_traj_" + k][i], ok))

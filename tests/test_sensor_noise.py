@@ -287,7 +287,7 @@ def test_engine_sensor_noise_at_sensor_breakpoints(gpu_device):
 def test_engine_continuous_sensors_draw_inside_every_evaluation(gpu_device, solver, per_step):
     """`sensorsUpdatePeriod = 0`: the reference measures (and draws) inside every dynamics evaluation of an
     integrator step (engine.cc:3655-3667) and once more after it; the streams must stand where the reference's
-    stand: (INIT_ITERATIONS + 1) rounds at start + (evaluations per step + 1) per step."""
+    stand: (INIT_ITERATIONS + 1) rounds at start + (evaluations per step + 1) per integrator step."""
     import torch
     from jiminy_amd import load_builtin
     from jiminy_amd.engine import INIT_ITERATIONS, BatchedEngine
@@ -310,7 +310,8 @@ def test_engine_continuous_sensors_draw_inside_every_evaluation(gpu_device, solv
     gs = ((3 + np.arange(B, dtype=np.uint64) * 1 + 0) & 0xFFFFFFFF).astype(np.uint32)
     st_ref = oracle_py.sensor_rng_seed(gs, n_imu)
     scratch = np.zeros((n_imu * 6, B))
-    for _ in range(INIT_ITERATIONS + 1 + steps * (per_step + 1)):
+    # (`steps` calls of `step(dt)` are steps + 1 integrator steps: the simulation opens with the reference's 1 us step)
+    for _ in range(INIT_ITERATIONS + 1 + (steps + 1) * (per_step + 1)):
         oracle_py.sensor_delay(scratch, None, None, None, st_ref, n_imu, 6)
         oracle_py.sensor_noise(scratch, st_ref, n_imu, 6, np.tile([0.01, 0.01, 0.01, 0.1, 0.1, 0.1], (n_imu, 1)), None, None)
     assert np.array_equal(rng, st_ref)
