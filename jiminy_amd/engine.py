@@ -173,9 +173,13 @@ def plan_step(t: float, t_error: float, step_size: float, options: Dict[str, Dic
                 groups[-1][1] += 1
             else:
                 groups.append([dt, 1])
+        # sensors with an update period are refreshed at the END of the interval (a breakpoint of theirs); continuous
+        # sensors (sensorsUpdatePeriod = 0) after EVERY integrator step (engine.cc:2386-2410): every launch of the
+        # interval refreshes them (what a later launch overwrites still draws from the noise streams)
+        continuous_sensors = float(options["stepper"]["sensorsUpdatePeriod"]) < EPS
         for i, (dt, n) in enumerate(groups):
             launches.append((dt, n, command_changed and i == 0,
-                             update_sensors and i == len(groups) - 1))
+                             update_sensors and (continuous_sensors or i == len(groups) - 1)))
     return launches, t_end, t_error
 
 

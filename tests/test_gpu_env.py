@@ -86,8 +86,11 @@ def test_pd_env_recovers_from_a_nan_lane(gpu_device):
     assert bool(torch.isfinite(obs["features"]["mahony_filter"]).all())
     # the re-initialised lane follows the same trajectory as a lane of a fresh episode would: compare with lane 0
     # three steps after ITS start (all lanes are identical copies under a zero action)
+    # (a lane re-initialised INSIDE a running simulation continues with `dtMax` steps; a fresh simulation opens with the
+    # reference's microsecond step, which is a property of `Engine::start`, not of the lane: DESIGN.md section 1)
     env2 = make_anymal_env(B, dt_max=5e-4)
     env2.reset(seed=0)
+    env2.engine._opening_step = False
     for _ in range(3):
         obs2, *_ = env2.step(action)
     assert torch.allclose(obs["states"]["agent"]["q"][5], obs2["states"]["agent"]["q"][0], rtol=0, atol=1e-12)
