@@ -193,7 +193,7 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
 
     obs_rows = [eng.field(k) for k in ("imu", "force", "encoder", "effort") if eng._rows[k] > 0]
     gather = None
-    if gather_obs and world > 1:
+    if gather_obs and (world > 1 or getattr(ctx, "pg", False)):
         from jiminy_amd.distributed import ObservationGather
         gather = ObservationGather(dtype=torch.float32 if ctx.gather_dtype == "f32" else None, every=ctx.gather_every)
     gather_wait_s = 0.0
@@ -221,7 +221,7 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
             gather.launch(obs_rows)
 
     def barrier() -> None:
-        if world > 1:
+        if world > 1 or getattr(ctx, "pg", False):
             dist.barrier(device_ids=[ctx.local_rank])
         torch.cuda.synchronize(device)
 
@@ -249,7 +249,7 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = eng.timing_summary()
     eng.enable_timing(False)
-    if world > 1:
+    if world > 1 or getattr(ctx, "pg", False):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -550,8 +550,13 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     n_ranks = 1
-    if world > 1:
+    # one process per GPU over RCCL.  A single rank started by torch.distributed.run with --gather-obs goes through the
+    # same code -- communicator, barrier, max-over-ranks all-reduce, asynchronous all-gather -- with a world of one: the
+    # only form of the N > 1 path a one-GPU box can execute (tests/test_multi_gpu.py)
+    pg = world > 1 or ("WORLD_SIZE" in os.environ and args.gather_obs)
+    if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         n_ranks = dist.get_world_size()
         if n_ranks != args.gpus:
@@ -566,7 +571,7 @@ def main() -> None:
         B = hi - lo
     else:
         B = args.batch
-    ctx = _Ctx(rank=rank, world=world, local_rank=local_rank, device=device, n_ranks=n_ranks,
+    ctx = _Ctx(rank=rank, world=world, local_rank=local_rank, device=device, n_ranks=n_ranks, pg=pg,
                gather_dtype=args.gather_dtype, gather_every=args.gather_every)
     out, states, model = measure(ctx, model_name=args.model, B=B, dtype=dtype, solver=args.solver,
                                  contact_model=args.contact_model, dt=args.dt, steps=args.steps, warmup=args.warmup,
@@ -579,7 +584,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(model, states, args.dt, solver=args.solver,
                                                constraint_options={} if constrained else None)
         print(json.dumps(out))
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
 
 
