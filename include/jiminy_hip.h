@@ -132,6 +132,21 @@ typedef struct jm_model_desc {
     const int32_t * encoder_joint_side;     /* [nencoder] 1 = joint side */
     const double * encoder_reduction;       /* [nencoder] */
     const int32_t * effort_motor;           /* [neffort] motor index */
+    /* ABI 7 -- frames a user-registered FrameConstraint may hold (`robot.add_constraint(name, FrameConstraint(frame,
+     * maskDoFs))`, core/src/constraints/frame_constraint.cc:27-35, python/jiminy_pywrap/src/constraints.cc): part of the
+     * TOPOLOGY like the contact points (the kernels are specialised on parent joint and mask).  Bit d of the mask = dof d
+     * of (x, y, z, rot x, rot y, rot z), world aligned, is fixed.  One-robot-per-lane kernels. */
+    int32_t n_constraint_frames;
+    const int32_t * cframe_joint;  /* [n_constraint_frames] parent joint of the frame */
+    const int32_t * cframe_mask;   /* [n_constraint_frames] 6-bit mask of the fixed dofs */
+    const double * cframe_R;       /* [n_constraint_frames*9] frame placement in the joint frame */
+    const double * cframe_p;       /* [n_constraint_frames*3] */
+    /* ... and the 1-dof joints (revolute / prismatic) a user-registered JointConstraint may hold on a row of its own, next
+     * to the joint's bound constraint like in the reference (`robot.add_constraint(name, JointConstraint(joint))`,
+     * core/src/constraints/joint_constraint.cc, model.cc:884-905).  One-robot-per-lane kernels; the branch-parallel kernels
+     * keep the flag-bit-2 form on the joint's bound row (jm_batch_set_joint_locks). */
+    int32_t n_constraint_joints;
+    const int32_t * cjoint_joint;  /* [n_constraint_joints] */
 } jm_model_desc;
 
 /* ---- hot-path subset of the engine options, same names/defaults as the reference
@@ -172,7 +187,14 @@ enum {
                               always enabled, its reference configuration taken at jm_batch_start; branch-parallel
                               topologies */
     JM_F_CON_DATA = 19,    /* [n_data_rows] in/out: JointConstraint::configurationRef_ per bounded joint, then
-                              the Lagrange multipliers `lambda_` of every constraint row (PGS warm start) */
+                              the Lagrange multipliers `lambda_` of every constraint row (PGS warm start: bounds, 4 per
+                              contact point, 6 per user constraint frame), then FrameConstraint::transformRef_ of every
+                              user constraint frame (translation 3, rotation 9 row-major; taken at jm_batch_start, the
+                              caller may overwrite it: `constraint.reference_transform`).  JM_F_CON_FLAGS carries one
+                              more row per user constraint frame after the contacts (bit 0, set by the caller: the
+                              lane's robot holds that FrameConstraint), then one per user constraint joint; the latter
+                              add one multiplier row each behind the frames' and one reference-configuration row each
+                              behind the frames' reference transforms */
     JM_F_FRICTION = 20,    /* [1] in, optional: contacts.friction of every lane (domain randomisation of the ground
                               friction, gym_jiminy envs/locomotion.py:257-262); both contact models (spring-damper:
                               branch-parallel topologies), unbound = the batch-wide contacts.friction option */

@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -59,6 +59,9 @@ class ModelDesc(C.Structure):
         ("contact_sensor_contact", _pi),
         ("encoder_joint", _pi), ("encoder_joint_side", _pi), ("encoder_reduction", _pd),
         ("effort_motor", _pi),
+        ("n_constraint_frames", C.c_int32),
+        ("cframe_joint", _pi), ("cframe_mask", _pi), ("cframe_R", _pd), ("cframe_p", _pd),
+        ("n_constraint_joints", C.c_int32), ("cjoint_joint", _pi),
     ]
 
 
@@ -106,12 +109,19 @@ def make_constraint_options(model="constraint", torsion=0.0, stabilization_freq=
 
 def constraint_rows(model: CompiledModel) -> Dict[str, int]:
     """Rows of the per-lane constraint state: one constraint per bounded 1-dof joint (model joint
-    order) then one per contact point with 4 rows (x, y, z, torsion)."""
+    order), one per contact point with 4 rows (x, y, z, torsion), one per user constraint frame with 6 rows
+    (x, y, z, rot x, rot y, rot z: the dofs outside its mask are never active).  `con_data`: reference
+    configuration of every bound, the multipliers of all rows, then 12 rows of reference transform per user frame."""
     nb = int(sum(1 for t in model.jtypes if 1 <= int(t) <= 8))
     nc = model.ncontacts
-    nr = nb + 4 * nc
-    return {"n_bounds": nb, "n_contacts": nc, "n_rows": nr, "con_flags": nb + nc,
-            "con_data": nb + nr, "workspace": nr * nr + 5 * nr + 3 * model.nv}
+    nx = len(model.constraint_frames)
+    nxj = len(model.constraint_joints)      # user JointConstraints on rows of their own (one-robot-per-lane kernels)
+    nr = nb + 4 * nc + 6 * nx + nxj
+    return {"n_bounds": nb, "n_contacts": nc, "n_user_frames": nx, "n_user_joints": nxj, "n_rows": nr,
+            "con_flags": nb + nc + nx + nxj, "con_data": nb + nr + 12 * nx + nxj,
+            "user_lambda": 2 * nb + 4 * nc, "user_ref": nb + nr,
+            "user_joint_flag": nb + nc + nx, "user_joint_lambda": 2 * nb + 4 * nc + 6 * nx, "user_joint_ref": nb + nr + 12 * nx,
+            "workspace": nr * nr + 5 * nr + 3 * model.nv}
 
 
 class AdaptiveOptions(C.Structure):
@@ -205,6 +215,13 @@ def make_model_desc(model: CompiledModel) -> Tuple[ModelDesc, List[np.ndarray]]:
     d.encoder_joint_side = pi([1 if x["joint_side"] else 0 for x in enc])
     d.encoder_reduction = pd([x["reduction"] for x in enc])
     d.effort_motor = pi([x["motor_index"] for x in s.get("EffortSensor", [])])
+    xf = [model.frames[x["frame"]] for x in model.constraint_frames]
+    d.n_constraint_frames = len(xf)
+    d.cframe_joint = pi([f.parent_joint for f in xf])
+    d.cframe_mask = pi([x["mask"] for x in model.constraint_frames])
+    d.cframe_R, d.cframe_p = pd([f.R for f in xf]), pd([f.p for f in xf])
+    d.n_constraint_joints = len(model.constraint_joints)
+    d.cjoint_joint = pi([x["joint"] for x in model.constraint_joints])
     return d, keep
 
 

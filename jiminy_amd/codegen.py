@@ -49,6 +49,8 @@ def quad_structure(model: CompiledModel):
     parents = [int(x) for x in model.parents]
     if nj < 6 or int(model.jtypes[1]) != JT_FREEFLYER or parents[1] != 0:
         return None
+    if model.constraint_frames or model.constraint_joints:     # user constraints on rows of their own: one-robot-per-lane constraint kernel (jm_constraint.h)
+        return None
     children = {j: [c for c in range(1, nj) if parents[c] == j] for j in range(nj)}
     if len(children[0]) != 1:
         return None
@@ -197,6 +199,11 @@ def topology_header(model: CompiledModel) -> str:
         _arr("motor_joint", [m.joint for m in model.motors]),
         _arr("motor_flags", mflags),
         _arr("contact_joint", [model.frames[c].parent_joint for c in model.contacts]),
+        f"    static constexpr int NX = {len(model.constraint_frames)};   // user constraint frames (FrameConstraint)",
+        _arr("xframe_joint", [model.frames[x["frame"]].parent_joint for x in model.constraint_frames]),
+        _arr("xframe_mask", [x["mask"] for x in model.constraint_frames]),
+        f"    static constexpr int NXJ = {len(model.constraint_joints)};   // user constraint joints (JointConstraint rows of their own)",
+        _arr("xjoint", [x["joint"] for x in model.constraint_joints]),
         _arr("imu_joint", imu),
         _arr("force_joint", frc),
         _arr("cs_contact", css),

@@ -87,10 +87,38 @@ template<class Tp> struct ConRows
     }
     static constexpr int NB = count_bounded();  // JointConstraint rows (model joint order)
     static constexpr int NC = Tp::NC;           // FrameConstraint blocks of 4 rows
-    static constexpr int NR = NB + 4 * NC;
-    static constexpr int NF = NB + NC;
-    static constexpr int ND = NB + NR;
+    // user-registered FrameConstraints (Model::addConstraint, USER registry: last in the reference's row order,
+    // model.h:43-46): 6 rows per frame (x, y, z, rot x, rot y, rot z; world aligned), of which the dofs of the compile-time
+    // mask `Tp::xframe_mask` can be active; unbounded rows (nBlocks = 0, constraint_solvers.cc:112-128)
+    static constexpr int NX = Tp::NX;
+    static constexpr int XR0 = NB + 4 * NC;     // first user-frame row
+    // user-registered JointConstraints on rows of their own (`Tp::xjoint`: declared 1-dof joints), behind the frames: one
+    // unbounded row each, next to the joint's bound constraint like in the reference (model.cc:884-905)
+    static constexpr int NXJ = Tp::NXJ;
+    static constexpr int XJ0 = XR0 + 6 * NX;    // first user-joint row
+    static constexpr int NR = NB + 4 * NC + 6 * NX + NXJ;
+    static constexpr int NF = NB + NC + NX + NXJ;
+    static constexpr int ND = NB + NR + 12 * NX + NXJ;
     static constexpr int LAM = NB;  // first lambda row in `data`
+    static constexpr int XREF = NB + NR;        // FrameConstraint::transformRef_ of every user frame: translation 3, rotation 9
+    static constexpr int XJREF = XREF + 12 * NX;  // JointConstraint::configurationRef_ of every user joint constraint
+    static constexpr bool USER = NX > 0 || NXJ > 0;
+    static_assert(!USER || NR <= 64, "user constraints: the packed row masks of the solve are 64-bit");
+    static_assert(NB <= 64, "the packed mask of the locked bound rows is 64-bit");
+    // row of the user joint constraint on joint j, or -1
+    static constexpr int xjoint_row(int j)
+    {
+        for (int k = 0; k < NXJ; ++k)
+            if (Tp::xjoint[k] == j) return k;
+        return -1;
+    }
+    // lowest dof of the mask of user frame x (its first row that can be active)
+    static constexpr int xfirst(int x)
+    {
+        for (int d = 0; d < 6; ++d)
+            if ((Tp::xframe_mask[x] >> d) & 1) return d;
+        return 0;
+    }
     // workspace rows: delassus matrix over the PACKED active rows (stride NR), then b, y, y_prev, a diagonal
     // backup and the packed multipliers x
     static constexpr int WA = 0, WB = NR * NR, WY = WB + NR, WYP = WY + NR, WD = WYP + NR, WX = WD + NR, WPARK = WX + NR,
@@ -190,6 +218,12 @@ template<class Tp> constexpr bool joint_has_contact(int j)
 {
     for (int c = 0; c < Tp::NC; ++c)
         if (Tp::contact_joint[c] == j) return true;
+    return false;
+}
+template<class Tp> constexpr bool joint_has_xframe(int j)
+{
+    for (int x = 0; x < Tp::NX; ++x)
+        if (Tp::xframe_joint[x] == j) return true;
     return false;
 }
 template<class Tp, class F> JM_DEV void for_contacts(F && f)
@@ -381,9 +415,12 @@ JM_DEV bool chol_solve_packed(int m, WS && ws)
 // the first `nb` rows are joint bounds, then blocks of 4 rows (x, y, z, torsion) per active contact.
 // `lockp`: bit p = packed bound row p is a user-registered JointConstraint (Model::addConstraint): unbounded, solved first in
 // every sweep, coefficient by coefficient, without relaxation or projection (constraint_solvers.cc:112-128).
+// `mc`: packed index of the first row behind the contact blocks (user FrameConstraint rows, all of them unbounded: bits of
+// `lockp` too); < 0 = none, the contact blocks run up to m.
 template<class T, class Tp, class WS>
-JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS && ws, unsigned long long lockp = 0ull)
+JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS && ws, unsigned long long lockp = 0ull, int mc = -1)
 {
+    if (mc < 0) mc = m;
     using R = ConRows<Tp>;
     constexpr int NR = R::NR;
     const T eps = Eps<T>::eps;
@@ -436,8 +473,10 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
         }
         if (lockp)
-            for (int r = 0; r < nb; ++r)
+            for (int r = 0; r < m; ++r)
             {
+                if (r == nb) r = mc;   // (no unbounded row among the contact blocks)
+                if (r >= m) break;
                 if (!((lockp >> r) & 1ull)) continue;
                 const T y = ws(R::WB + r) - col_dot(r);
                 dmax = fmax_(dmax, cabs_(y - Y(r)));
@@ -445,7 +484,7 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
                 xl[r * xs] = xl[r * xs] + y / ws(R::WA + r * NR + r);
             }
         // block 0 of every constraint: joint bounds, then the normal force of every contact
-        for (int r = 0; r < m; r += (r < nb ? 1 : 4))
+        for (int r = 0; r < mc; r += (r < nb ? 1 : 4))
         {
             if (r < nb && ((lockp >> r) & 1ull)) continue;
             const int i0 = r < nb ? r : r + 2;
@@ -456,7 +495,7 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             xl[(i0) * xs] = fmax_(e, T(0));  // clamp(e, 0, inf)
         }
         // block 1: torsional friction {3, 2}
-        for (int r = nb; r < m; r += 4)
+        for (int r = nb; r < mc; r += 4)
         {
             if (torsion_zero) { xl[(r + 3) * xs] = xl[(r + 3) * xs] * T(0); continue; }
             const int i0 = r + 3;
@@ -468,7 +507,7 @@ JM_DEV bool pgs_solve_packed(const ConArgs<T> & C, T friction, int m, int nb, WS
             xl[(i0) * xs] = clamp_(e, -thr, thr);
         }
         // block 2: friction cone {0, 1, 2}
-        for (int r = nb; r < m; r += 4)
+        for (int r = nb; r < mc; r += 4)
         {
             if (friction_zero) { xl[(r) * xs] = xl[(r) * xs] * T(0); xl[(r + 1) * xs] = xl[(r + 1) * xs] * T(0); continue; }
             const T y0 = ws(R::WB + r) - col_dot(r);
@@ -725,9 +764,58 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         }
         if (f & 1) { act.set(r0); act.set(r0 + 1); act.set(r0 + 2); act.set(r0 + 3); }
     });
+    // user-registered FrameConstraints: never switched (flag bit 0 = this lane's robot holds it, set by the caller);
+    // Engine::start -> FrameConstraint::reset: transformRef_ = the frame's pose, multipliers zeroed (frame_constraint.cc:77-101)
+    RowMask xact;   // first row of every held user frame
+    xact.clear();
+    static_for<0, R::NX>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        constexpr int j = Tp::xframe_joint[x];
+        constexpr int mask = Tp::xframe_mask[x];
+        if (flag(R::NB + R::NC + x) & 1)
+        {
+            if (start_passes > 0)
+            {
+                const SE3<T> oMf = w.oMi[j] * ld_se3<T>(P, L::XFRAME + 12 * x);
+                const T t[12] = {oMf.p.x, oMf.p.y, oMf.p.z, oMf.R.m00, oMf.R.m01, oMf.R.m02, oMf.R.m10, oMf.R.m11, oMf.R.m12,
+                                 oMf.R.m20, oMf.R.m21, oMf.R.m22};
+#pragma unroll
+                for (int i = 0; i < 12; ++i) dat(R::XREF + 12 * x + i) = t[i];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) lam(R::XR0 + 6 * x + d) = T(0);
+            }
+            xact.set(R::XR0 + 6 * x + R::xfirst(x));
+            static_for<0, 6>([&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                if constexpr ((mask >> d) & 1) act.set(R::XR0 + 6 * x + d);
+            });
+        }
+    });
+    // user-registered JointConstraints on rows of their own: like the frames, held where the caller's flag says so;
+    // JointConstraint::reset at `start`: reference = the joint position, multiplier zeroed (joint_constraint.cc:56-83)
+    static_for<0, R::NXJ>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (flag(R::NB + R::NC + R::NX + k) & 1)
+        {
+            if (start_passes > 0)
+            {
+                dat(R::XJREF + k) = q[Tp::idx_q[Tp::xjoint[k]]];
+                lam(R::XJ0 + k) = T(0);
+            }
+            act.set(R::XJ0 + k);
+        }
+    });
     if (!act.any()) return;  // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
     // joints whose acceleration some active row reads (columns of the delassus matrix)
     unsigned long long fmask = 0ull;
+    static_for<0, R::NXJ>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (act.test(R::XJ0 + k)) fmask |= R::anc_mask(Tp::xjoint[k]);
+    });
+    static_for<0, R::NX>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        if (xact.test(R::XR0 + 6 * x + R::xfirst(x))) fmask |= R::anc_mask(Tp::xframe_joint[x]);
+    });
     static_for<0, R::NB>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if (act.test(k)) fmask |= R::anc_mask(R::bjoint(k));
@@ -739,7 +827,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     // ---- delassus matrix, one bias-free articulated-body solve per active row
     // (each lane walks ITS OWN active rows, lowest first: a wave runs max-over-lanes solves, not the
     // union of the rows active anywhere in the wave; column index = packed index of the row)
-    const int m_act = act.count(), nb_act = act.rank(R::NB);
+    const int m_act = act.count(), nb_act = act.rank(R::NB), mc_act = act.rank(R::XR0);
     RowMask rem = act;
 #pragma nounroll
     for (int pk = 0; pk < (refresh ? 0 : m_act); ++pk)
@@ -775,6 +863,34 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 bmask = R::anc_mask(j);
             }
         });
+        static_for<0, R::NXJ>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (r == R::XJ0 + k)
+            {
+                tiv = Tp::idx_v[Tp::xjoint[k]];
+                tsgn = T(1);
+                bmask = R::anc_mask(Tp::xjoint[k]);
+            }
+        });
+        static_for<0, R::NX>([&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            constexpr int j = Tp::xframe_joint[x];
+            constexpr int r0 = R::XR0 + 6 * x;
+            if (r >= r0 && r < r0 + 6)
+            {
+                // unit force along / unit torque about a world axis at the frame origin (rows of the world-aligned frame
+                // Jacobian, frame_constraint.cc:136-146 with rotationLocal = identity)
+                const int d = r - r0, ax = d < 3 ? d : d - 3;
+                const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
+                const M3<T> & Rj = w.oMi[j].R;
+                const V3<T> col = ax == 0 ? V3<T>{Rj.m00, Rj.m01, Rj.m02}
+                                : ax == 1 ? V3<T>{Rj.m10, Rj.m11, Rj.m12} : V3<T>{Rj.m20, Rj.m21, Rj.m22};
+                if (d < 3) fu = {col, cross(pc, col)};
+                else fu = {zero3<T>(), col};
+                jr = j;
+                bmask = R::anc_mask(j);
+            }
+        });
         // J_row . dd of every active row = column pk of the delassus matrix, written as the sweep reaches the joints
         delta_sweeps<T, Tp>(
             P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
@@ -802,6 +918,28 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                             ws(R::WA + (p0 + 3) * NR + pk) = ang.z;
                         }
                 }
+                if constexpr (R::xjoint_row(j) >= 0)
+                {
+                    constexpr int kj = R::xjoint_row(j);
+                    if (act.test(R::XJ0 + kj)) ws(R::WA + act.rank(R::XJ0 + kj) * NR + pk) = ddj[0];
+                }
+                static_for<0, R::NX>([&](auto xc) {
+                    constexpr int x = decltype(xc)::value;
+                    if constexpr (Tp::xframe_joint[x] == j)
+                    {
+                        if (xact.test(R::XR0 + 6 * x + R::xfirst(x)))
+                        {
+                            const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
+                            const V3<T> lin = w.oMi[j].R * (daj.l + cross(daj.a, pc));
+                            const V3<T> ang = w.oMi[j].R * daj.a;
+                            const T six[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};
+                            static_for<0, 6>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                if constexpr ((Tp::xframe_mask[x] >> d) & 1) ws(R::WA + act.rank(R::XR0 + 6 * x + d) * NR + pk) = six[d];
+                            });
+                        }
+                    }
+                });
             },
             bmask, fmask);
         // regularisation (constraint_solvers.cc:376-387)
@@ -826,7 +964,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         static_for<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             // (only the joints that carry contact points are read below)
-            if constexpr (joint_has_contact<Tp>(j)) sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
+            if constexpr (joint_has_contact<Tp>(j) || joint_has_xframe<Tp>(j)) sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
             else sa[j] = zero6<T>();
         });
         if (start_passes > 0)
@@ -873,6 +1011,52 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                     ws(R::WB + p0 + 3) = -(aang.z + C.kd * vang.z);
                 }
             });
+            // user FrameConstraint (frame_constraint.cc:148-182): classical frame acceleration (world aligned) + Baumgarte terms
+            // on the position error p - p_ref and the orientation error log3(R R_ref^T), gains of the user constraints
+            static_for<0, R::NX>([&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                constexpr int j = Tp::xframe_joint[x];
+                if (xact.test(R::XR0 + 6 * x + R::xfirst(x)))
+                {
+                    const SE3<T> fr = ld_se3<T>(P, L::XFRAME + 12 * x);
+                    const M3<T> & Rj = w.oMi[j].R;
+                    const V3<T> vlin = Rj * (w.vel[j].l + cross(w.vel[j].a, fr.p));
+                    const V3<T> vang = Rj * w.vel[j].a;
+                    V3<T> alin = Rj * (sa[j].l + cross(sa[j].a, fr.p));
+                    V3<T> aang = Rj * sa[j].a;
+                    alin = alin + cross(vang, vlin);
+                    const V3<T> pos = w.oMi[j].p + Rj * fr.p;
+                    const M3<T> Rf = Rj * fr.R;
+                    const V3<T> pref = {dat(R::XREF + 12 * x), dat(R::XREF + 12 * x + 1), dat(R::XREF + 12 * x + 2)};
+                    const M3<T> Rref = {dat(R::XREF + 12 * x + 3), dat(R::XREF + 12 * x + 4), dat(R::XREF + 12 * x + 5),
+                                        dat(R::XREF + 12 * x + 6), dat(R::XREF + 12 * x + 7), dat(R::XREF + 12 * x + 8),
+                                        dat(R::XREF + 12 * x + 9), dat(R::XREF + 12 * x + 10), dat(R::XREF + 12 * x + 11)};
+                    const V3<T> dr = log3(Rf * transpose(Rref));
+                    alin = alin + C.kp_lock * (pos - pref) + C.kd_lock * vlin;
+                    aang = aang + C.kp_lock * dr + C.kd_lock * vang;
+                    const T six[6] = {alin.x, alin.y, alin.z, aang.x, aang.y, aang.z};
+                    static_for<0, 6>([&](auto dc) {
+                        constexpr int d = decltype(dc)::value;
+                        if constexpr ((Tp::xframe_mask[x] >> d) & 1)
+                        {
+                            const int pr = act.rank(R::XR0 + 6 * x + d);
+                            ws(R::WB + pr) = -six[d];
+                            ws(R::WX + pr) = lam(R::XR0 + 6 * x + d);
+                        }
+                    });
+                }
+            });
+            // user JointConstraint rows (joint_constraint.cc:139-163): drift = kp (q - q_ref) + kd v, gains of the user constraints
+            static_for<0, R::NXJ>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int iq = Tp::idx_q[Tp::xjoint[k]], iv = Tp::idx_v[Tp::xjoint[k]];
+                if (act.test(R::XJ0 + k))
+                {
+                    const int pr = act.rank(R::XJ0 + k);
+                    ws(R::WB + pr) = -(C.kp_lock * (q[iq] - dat(R::XJREF + k)) + C.kd_lock * v[iv] + af[iv]);
+                    ws(R::WX + pr) = lam(R::XJ0 + k);
+                }
+            });
             // multipliers: gather the warm start into the packed vector, solve, scatter back
             static_for<0, R::NB>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -888,7 +1072,20 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 }
             });
             bool ok;
-            if (start_passes > 0 && pass == 0)
+            // packed rows of the unbounded constraints: user-registered JointConstraints (on their joint's bound row) and
+            // every row of the user FrameConstraints
+            unsigned long long lockp = 0ull;
+            static_for<0, R::NB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (act.test(k) && lck.test(k)) lockp |= 1ull << act.rank(k);
+            });
+            if constexpr (R::USER)
+                for (int pr = mc_act; pr < m_act; ++pr) lockp |= 1ull << pr;
+            // `isUnbounded` (constraint_solvers.cc:362-367, 397-412): no inequality among the enabled constraints -> the
+            // exact Cholesky solve of `ignoreBounds`, not the sweeps.  (Robots with user constraint frames only: the
+            // kernels of the other topologies keep sweeping their lock-only solves, which converge to the same multipliers.)
+            const bool unbounded_only = R::USER && __builtin_popcountll(lockp) == m_act;
+            if ((start_passes > 0 && pass == 0) || unbounded_only)
             {
                 ok = chol_solve_packed<T, Tp>(m_act, ws);
                 if (!ok) w.status |= JM_LANE_NAN;
@@ -897,13 +1094,10 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             {
                 if (C.park)
                 for (int r = 0; r < C.park_rows; ++r) C.park[(size_t)r * B] = C.xl[r * C.xstride];
-            unsigned long long lockp = 0ull;
-            static_for<0, R::NB>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                if (act.test(k) && lck.test(k)) lockp |= 1ull << act.rank(k);
-            });
-            if constexpr (JM_CON_PGS_REG && NR <= 32) ok = pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
-            else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws, lockp);
+            // (the register form of the sweeps knows no unbounded rows: solves with any go through the general form)
+            if constexpr (JM_CON_PGS_REG && NR <= 32) ok = lockp ? pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws, lockp, mc_act)
+                                                               : pgs_solve_regs<T, Tp>(C, friction, m_act, nb_act, ws);
+            else ok = pgs_solve_packed<T, Tp>(C, friction, m_act, nb_act, ws, lockp, mc_act);
             if (C.park)
                 for (int r = 0; r < C.park_rows; ++r) C.xl[r * C.xstride] = C.park[(size_t)r * B];
                 if (ok) w.status &= ~JM_LANE_SOLVER_FAILURE;
@@ -922,6 +1116,18 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                     for (int i = 0; i < 4; ++i) lam(r0 + i) = ws(R::WX + p0 + i);
                 }
             });
+            static_for<0, R::NX>([&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                if (xact.test(R::XR0 + 6 * x + R::xfirst(x)))
+                    static_for<0, 6>([&](auto dc) {
+                        constexpr int d = decltype(dc)::value;
+                        if constexpr ((Tp::xframe_mask[x] >> d) & 1) lam(R::XR0 + 6 * x + d) = ws(R::WX + act.rank(R::XR0 + 6 * x + d));
+                    });
+            });
+            static_for<0, R::NXJ>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (act.test(R::XJ0 + k)) lam(R::XJ0 + k) = ws(R::WX + act.rank(R::XJ0 + k));
+            });
         }
         // constraint forces of this pass: joint efforts + wrenches on the contact bodies
         T tl[NV];
@@ -931,6 +1137,11 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             constexpr int k = decltype(kc)::value;
             constexpr int iv = Tp::idx_v[R::bjoint(k)];
             if (act.test(k)) tl[iv] = rev.test(k) ? -lam(k) : lam(k);
+        });
+        // (user joint constraints: on top of the bound's effort; through the accelerations only, like the frames)
+        static_for<0, R::NXJ>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (act.test(R::XJ0 + k)) tl[Tp::idx_v[Tp::xjoint[k]]] += lam(R::XJ0 + k);
         });
         for_contacts<Tp>([&](auto jc, int c) {
             constexpr int j = decltype(jc)::value;
@@ -949,8 +1160,36 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 w.cf[c] = {tmul(fr.R, fl.l), tmul(fr.R, tmul(w.oMi[j].R, tW))};
             }
         });
+        // user FrameConstraints: force at the frame origin + torque, world aligned, on the frame's parent joint; they act
+        // through the accelerations only (engine.cc:3770-3857 writes the bounds and the contacts into u / fExternal)
+        Sp<T> fux[R::NX > 0 ? NJ : 1];
+        if constexpr (R::NX > 0)
+        {
+            static_for<1, NJ>([&](auto jc) { fux[decltype(jc)::value] = zero6<T>(); });
+            static_for<0, R::NX>([&](auto xc) {
+                constexpr int x = decltype(xc)::value;
+                constexpr int j = Tp::xframe_joint[x];
+                if (xact.test(R::XR0 + 6 * x + R::xfirst(x)))
+                {
+                    T l6[6];
+                    static_for<0, 6>([&](auto dc) {
+                        constexpr int d = decltype(dc)::value;
+                        if constexpr ((Tp::xframe_mask[x] >> d) & 1) l6[d] = lam(R::XR0 + 6 * x + d);
+                        else l6[d] = T(0);
+                    });
+                    const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
+                    Sp<T> fl;
+                    fl.l = tmul(w.oMi[j].R, V3<T>{l6[0], l6[1], l6[2]});
+                    fl.a = tmul(w.oMi[j].R, V3<T>{l6[3], l6[4], l6[5]}) + cross(pc, fl.l);
+                    fux[j] = fux[j] + fl;
+                }
+            });
+        }
         delta_sweeps<T, Tp>(P, w, [&](auto ic) { return tl[decltype(ic)::value]; },
-                            [&](auto jc) { return fsum[decltype(jc)::value]; },
+                            [&](auto jc) {
+                                if constexpr (R::NX > 0) return fsum[decltype(jc)::value] + fux[decltype(jc)::value];
+                                else return fsum[decltype(jc)::value];
+                            },
                             [&](auto jc, const T * ddj, const Sp<T> &) {
                                 constexpr int j = decltype(jc)::value;
                                 constexpr int iv = Tp::idx_v[j];

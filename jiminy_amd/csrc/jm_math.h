@@ -503,4 +503,35 @@ template<class T> JM_DEV void matrix_to_quat(const M3<T> & R, T & x, T & y, T & 
         y = (R.m12 + R.m21) * t;
     }
 }
+// ---- SO(3) logarithm (adaptive error norm: jm_adaptive.h; orientation error of a user FrameConstraint: jm_constraint.h)
+JM_DEV double acos_(double x) { return ::acos(x); }
+JM_DEV float acos_(float x) { return ::acosf(x); }
+JM_DEV double asin_(double x) { return ::asin(x); }
+JM_DEV float asin_(float x) { return ::asinf(x); }
+JM_DEV double fabs_(double x) { return ::fabs(x); }
+JM_DEV float fabs_(float x) { return ::fabsf(x); }
+
+// Pinocchio v2.7.0 log3
+template<class T> JM_DEV V3<T> log3(const M3<T> & R)
+{
+    const T PI_value = T(3.14159265358979323846);
+    T tr = R.m00 + R.m11 + R.m22;
+    T theta;
+    if (tr >= T(3)) { tr = T(3); theta = T(0); }
+    else if (tr <= T(-1)) { tr = T(-1); theta = PI_value; }
+    else theta = acos_((tr - T(1)) / T(2));
+    if (theta >= PI_value - T(1e-2))
+    {
+        const T cphi = -(tr - T(1)) / T(2);
+        const T beta = theta * theta / (T(1) + cphi);
+        const T t0 = (R.m00 + cphi) * beta, t1 = (R.m11 + cphi) * beta, t2 = (R.m22 + cphi) * beta;
+        return {(R.m21 > R.m12 ? T(1) : T(-1)) * (t0 > T(0) ? sqrt_(t0) : T(0)),
+                (R.m02 > R.m20 ? T(1) : T(-1)) * (t1 > T(0) ? sqrt_(t1) : T(0)),
+                (R.m10 > R.m01 ? T(1) : T(-1)) * (t2 > T(0) ? sqrt_(t2) : T(0))};
+    }
+    T s, c;
+    sincos_(theta, &s, &c);
+    const T t = ((theta > Eps<T>::taylor) ? theta / s : T(1)) / T(2);
+    return {t * (R.m21 - R.m12), t * (R.m02 - R.m20), t * (R.m10 - R.m01)};
+}
 }  // namespace jm

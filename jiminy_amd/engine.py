@@ -211,6 +211,24 @@ class JointConstraint:
 
 
 @dataclass
+class FrameConstraint:
+    """≙ `jiminy.FrameConstraint(frame_name, mask_dofs)` (core/src/constraints/frame_constraint.cc): the frame held at a
+    reference pose -- its pose at `start` (`FrameConstraint::reset`), or the one given to `set_constraint_reference` --
+    along the masked dofs (x, y, z, rot x, rot y, rot z; world aligned), with Baumgarte stabilisation on the position error
+    and on `log3(R R_ref^T)`.  The frame and mask must have been declared on the model (`model.add_frame_constraint`: the
+    kernels are specialised on them like on the contact points); `BatchedEngine.add_constraint` registers it for (some of)
+    the lanes.  `baumgarte_freq` like `JointConstraint`; the default 0.0 is the reference's freshly created constraint
+    (an acceleration-level constraint without position feedback)."""
+    frame_name: str
+    mask_dofs: Tuple[bool, ...] = (True, True, True, True, True, True)
+    baumgarte_freq: Optional[float] = 0.0
+
+    @property
+    def mask(self) -> int:
+        return int(sum(1 << d for d in range(6) if self.mask_dofs[d]))
+
+
+@dataclass
 class StepperState:
     """≙ `struct StepperState` (reference engine.h:216-250); time is shared by all lanes."""
     iter: int
@@ -592,7 +610,9 @@ def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.de
                               "jiminy_amd/csrc/build_variants.json to pre-build it.")
             _VERIFIED[key] = variant
             return load_for(model, variant=variant)
-    if len(rows_only) == len(codegen.BUILD_VARIANTS) and max(e for _, e in rows_only) <= 2.0 * min(e for _, e in rows_only):
+    # (fails closed: a non-finite disagreement -- every probe lane NaN -- or a gross one is never taken for round-off)
+    if len(rows_only) == len(codegen.BUILD_VARIANTS) and all(math.isfinite(e) for _, e in rows_only) and \
+            max(e for _, e in rows_only) <= min(1.0, 2.0 * min(e for _, e in rows_only)):
         # every compilation shows the SAME float64 / float32 disagreement: that is the conditioning of the robot in float32
         # (extreme inertia ratios), not a mis-compile of one of them -- keep the preferred variant and say so
         warnings.warn(f"{model.name}: float64 and float32 kernels disagree on emitted rows alike in every build variant "
@@ -831,23 +851,31 @@ class BatchedEngine:
 
     # ------------------------------------------------------------------ user-registered constraints
     def add_constraint(self, name: str, constraint: Any, lane_mask: Optional[torch.Tensor] = None) -> None:
-        """≙ `Model::addConstraint(name, constraint)` (core/src/robot/model.cc:926-936), user registry.  `JointConstraint`s of
-        joints with position bounds, constraint contact model, float64 batches (both kernel families since round 4): the row of
-        the joint's own bound constraint becomes bilateral (bit 2 of its flag), is solved first in every Gauss-Seidel
-        sweep without projection (constraint_solvers.cc:112-128) and its multiplier is not restored into
-        `RobotState::u` (engine.cc:3771-3790); the bound of a locked joint is not switched while the lock holds.
-        `lane_mask`: the environments that get it (default: all).  Other constraint types (`FrameConstraint`,
-        `DistanceConstraint`, `SphereConstraint`, `WheelConstraint`) are not built."""
+        """≙ `Model::addConstraint(name, constraint)` (core/src/robot/model.cc:926-936), user registry; constraint contact
+        model, float64 batches.  `lane_mask`: the environments that get it (default: all).
+
+        * `JointConstraint` of a joint with position bounds (both kernel families): the row of the joint's own bound constraint
+          becomes bilateral (bit 2 of its flag), is solved first in every Gauss-Seidel sweep without projection
+          (constraint_solvers.cc:112-128) and its multiplier is not restored into `RobotState::u` (engine.cc:3771-3790); the
+          bound of a locked joint is not switched while the lock holds.
+          A joint declared with `model.add_joint_constraint` gets a row OF ITS OWN instead (round 5, one-robot-per-lane
+          kernels): any revolute / prismatic joint, next to its bound constraint like in the reference (model.cc:884-905).
+        * `FrameConstraint` of a frame declared with `model.add_frame_constraint` (round 5; robots on the one-robot-per-lane
+          kernels): rows of their own behind the contact rows, unbounded; when nothing but unbounded constraints is enabled
+          the multipliers come from the exact solve of the reference's `isUnbounded` branch (constraint_solvers.cc:362-412).
+
+        `DistanceConstraint`, `SphereConstraint`, `WheelConstraint` are not built."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before adding constraints.")   # model.cc:866-872
-        if not isinstance(constraint, JointConstraint):
-            raise NotImplementedError("only JointConstraint can be registered")
+        if not isinstance(constraint, (JointConstraint, FrameConstraint)):
+            raise NotImplementedError("only JointConstraint and FrameConstraint can be registered")
         if name in self._user_constraints:
             raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
         freq = constraint.baumgarte_freq
         if freq is not None and freq < 0.0:
             raise ValueError("Natural frequency must be positive.")                                 # abstract_constraint.cc:91-94
-        others = {c.baumgarte_freq for _, c in self._user_constraints.values()}
+        # (the frequency is read HERE: mutating the constraint object afterwards does not move the gains of the batch)
+        others = {f for _, _, _, f in self._user_constraints.values()}
         if others and others != {freq}:
             raise NotImplementedError("the user constraints of a batch share one Baumgarte frequency "
                                       f"({next(iter(others))}): give this one the same `baumgarte_freq`")
@@ -855,49 +883,110 @@ class BatchedEngine:
             raise NotImplementedError("user constraints need the constraint contact model on a float64 batch")
         if "con_flags" not in self._fields:
             self._apply_options()
-        # Deviation from the reference, where a user constraint is a row of its own next to the joint's bound constraint
+        mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if lane_mask is None else \
+            lane_mask.to(self.device).bool()
+        if isinstance(constraint, FrameConstraint):
+            declared = [(x["frame"], int(x["mask"])) for x in self.model.constraint_frames]
+            if (constraint.frame_name, constraint.mask) not in declared:
+                raise LookupError(f"no constraint frame ('{constraint.frame_name}', mask {constraint.mask:06b}) declared on the model: "
+                                  "call jiminy_amd.model.add_frame_constraint(model, name, frame_name, mask_dofs) before "
+                                  "creating the engine (the kernels are specialised on the constraint frames)")
+            x = declared.index((constraint.frame_name, constraint.mask))
+            if any(k == "frame" and r == x for k, r, _, _ in self._user_constraints.values()):
+                raise ValueError(f"frame '{constraint.frame_name}' already carries this user constraint")
+            rows = _abi.constraint_rows(self.model)
+            self._fields["con_flags"][rows["n_bounds"] + rows["n_contacts"] + x] = torch.where(mask, 1, 0).to(torch.int32)
+            self._user_constraints[name] = ("frame", x, constraint, freq)
+            self._apply_options()
+            return
+        declared_j = [int(x["joint"]) for x in self.model.constraint_joints]
+        if self.model.joint_index(constraint.joint_name) in declared_j:
+            # a row of its own (declared with `model.add_joint_constraint`; one-robot-per-lane kernels): coexists with the
+            # joint's bound constraint like in the reference (model.cc:884-905), any revolute / prismatic joint
+            k = declared_j.index(self.model.joint_index(constraint.joint_name))
+            if any(kd == "jrow" and r == k for kd, r, _, _ in self._user_constraints.values()):
+                raise ValueError(f"joint '{constraint.joint_name}' already carries a user constraint")
+            rows = _abi.constraint_rows(self.model)
+            self._fields["con_flags"][rows["user_joint_flag"] + k] = torch.where(mask, 1, 0).to(torch.int32)
+            self._user_constraints[name] = ("jrow", k, constraint, freq)
+            self._apply_options()
+            return
+        # Deviation from the reference, where a user JointConstraint is a row of its own next to the joint's bound constraint
         # (model.cc:884-905): here it REUSES the bound row of the joint (flag bit 2), so only bounded 1-dof joints can be
         # locked and the bound does not switch while the lock holds -- the lock is the tighter constraint anyway.
         row = self.model.bound_row(constraint.joint_name)
-        if any(r == row for r, _ in self._user_constraints.values()):
+        if any(k == "joint" and r == row for k, r, _, _ in self._user_constraints.values()):
             raise ValueError(f"joint '{constraint.joint_name}' already carries a user constraint")
-        mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if lane_mask is None else \
-            lane_mask.to(self.device).bool()
         self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 1))
         self._fields["con_flags"][row] |= torch.where(mask, 4, 0).to(torch.int32)
-        self._user_constraints[name] = (row, constraint)
+        self._user_constraints[name] = ("joint", row, constraint, freq)
         self._apply_options()      # (jm_constraint_options::user_stabilization_freq)
 
     def _user_constraint_freq(self) -> float:
-        """`jm_constraint_options::user_stabilization_freq`: the Baumgarte frequency the registered user constraints share,
-        -1 = the gains of `contacts.stabilizationFreq` (`baumgarte_freq=None`)."""
-        for _, c in getattr(self, "_user_constraints", {}).values():
-            return -1.0 if c.baumgarte_freq is None else float(c.baumgarte_freq)
+        """`jm_constraint_options::user_stabilization_freq`: the Baumgarte frequency the registered user constraints share
+        (as given when they were registered), -1 = the gains of `contacts.stabilizationFreq` (`baumgarte_freq=None`)."""
+        for _, _, _, freq in getattr(self, "_user_constraints", {}).values():
+            return -1.0 if freq is None else float(freq)
         return -1.0
 
     def remove_constraint(self, name: str) -> None:
         """≙ `Model::removeConstraint(name)` (model.cc:1010-1013)."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before removing constraints.")
-        row, _ = self._user_constraints.pop(name)
-        self._fields["con_flags"][row] &= ~4
-        if not self._user_constraints:
+        kind, row, _, _ = self._user_constraints.pop(name)
+        if kind == "frame":
+            rows = _abi.constraint_rows(self.model)
+            self._fields["con_flags"][rows["n_bounds"] + rows["n_contacts"] + row] = 0
+        elif kind == "jrow":
+            self._fields["con_flags"][_abi.constraint_rows(self.model)["user_joint_flag"] + row] = 0
+        else:
+            self._fields["con_flags"][row] &= ~4
+        if not any(k == "joint" for k, _, _, _ in self._user_constraints.values()):
             self._lib.check(self._L.jm_batch_set_joint_locks(self._batch_h, 0))
-            self._apply_options()
+        self._apply_options()
 
     def set_constraint_reference(self, name: str, reference: Any) -> None:
         """≙ `JointConstraint.reference_configuration = ...` (joint_constraint.cc `setReferenceConfiguration`): where the
-        constraint holds its joint, one value per lane or one for all.  `start` / `reset_lanes` take the reference from the
-        state again (`JointConstraint::reset`): call it after them."""
-        row, _ = self._user_constraints[name]
+        constraint holds its joint, one value per lane or one for all; ≙ `FrameConstraint.reference_transform = ...`
+        (frame_constraint.cc:52-60): `reference` = (translation `(3,)` or `(3, B)`, rotation `(3, 3)` or `(3, 3, B)`).
+        `start` / `reset_lanes` take the reference from the state again (`reset` of the constraint): call it after them."""
+        kind, row, _, _ = self._user_constraints[name]
+        if kind == "frame":
+            p, R = reference
+            p = torch.as_tensor(p, dtype=self.dtype, device=self.device)
+            R = torch.as_tensor(R, dtype=self.dtype, device=self.device)
+            if p.dim() == 1:
+                p = p[:, None].expand(3, self.batch_size)
+            if R.dim() == 2:
+                R = R[:, :, None].expand(3, 3, self.batch_size)
+            if tuple(p.shape) != (3, self.batch_size) or tuple(R.shape) != (3, 3, self.batch_size):
+                raise ValueError("reference transform: translation (3,) or (3, B) and rotation (3, 3) or (3, 3, B)")
+            r0 = _abi.constraint_rows(self.model)["user_ref"] + 12 * row
+            self._fields["con_data"][r0:r0 + 3] = p
+            self._fields["con_data"][r0 + 3:r0 + 12] = R.reshape(9, self.batch_size)
+            return
         ref = torch.as_tensor(reference, dtype=self.dtype, device=self.device).reshape(-1)
         if ref.numel() not in (1, self.batch_size):
             raise ValueError("one reference per lane (or one for all)")
+        if kind == "jrow":
+            row = _abi.constraint_rows(self.model)["user_joint_ref"] + row
         self._fields["con_data"][row] = ref.expand(self.batch_size)
+
+    def constraint_reference(self, name: str) -> Any:
+        """The reference the constraint holds at the moment: `(B,)` joint positions, or (translation `(3, B)`, rotation
+        `(3, 3, B)`) of a `FrameConstraint` (views of the `con_data` field)."""
+        kind, row, _, _ = self._user_constraints[name]
+        if kind == "frame":
+            r0 = _abi.constraint_rows(self.model)["user_ref"] + 12 * row
+            d = self._fields["con_data"]
+            return d[r0:r0 + 3], d[r0 + 3:r0 + 12].view(3, 3, self.batch_size)
+        if kind == "jrow":
+            row = _abi.constraint_rows(self.model)["user_joint_ref"] + row
+        return self._fields["con_data"][row]
 
     @property
     def user_constraints(self) -> Dict[str, Any]:
-        return {k: c for k, (_, c) in self._user_constraints.items()}
+        return {k: c for k, (_, _, c, _) in self._user_constraints.items()}
 
     def set_lane_friction(self, friction: Optional[Any]) -> None:
         """Ground friction coefficient of every lane (`contacts.friction` randomised per environment as

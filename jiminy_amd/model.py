@@ -310,6 +310,11 @@ class CompiledModel:
     motors: List[Motor]
     contacts: List[str]               # contact frame names, in engine order
     sensors: Dict[str, List[Dict[str, Any]]]
+    # frames a user `FrameConstraint(frame, mask)` may hold (`add_frame_constraint`): {"name", "frame", "mask"} with bit d
+    # of the mask = dof d of (x, y, z, rot x, rot y, rot z) fixed.  Part of the topology, like the contact points.
+    constraint_frames: List[Dict[str, Any]] = field(default_factory=list)
+    # 1-dof joints a user `JointConstraint(joint)` may hold on a row of its own (`add_joint_constraint`): {"name", "joint"}
+    constraint_joints: List[Dict[str, Any]] = field(default_factory=list)
 
     # ---- sizes
     @property
@@ -401,6 +406,11 @@ class CompiledModel:
         sa = self.signed_axes()
         if any(int(self.jtypes[j]) in (JT_RU, JT_PU) and sa[j] != 0 for j in range(self.njoints)):
             parts += ["AX", ",".join(str(int(x)) for x in sa)]
+        # user constraint frames (parent joint : mask), appended only when there are any: other topologies keep their hash
+        if self.constraint_frames:
+            parts += ["X", ",".join(f"{self.frames[x['frame']].parent_joint}:{int(x['mask'])}" for x in self.constraint_frames)]
+        if self.constraint_joints:
+            parts += ["XJ", ",".join(str(int(x["joint"])) for x in self.constraint_joints)]
         return "|".join(parts)
 
     def signed_axes(self) -> np.ndarray:
@@ -618,6 +628,39 @@ def add_contact_points(model: CompiledModel, frame_names: Sequence[str]) -> None
         if fn in model.contacts:
             raise ValueError(f"contact point '{fn}' already registered")
         model.contacts.append(fn)
+
+
+def add_frame_constraint(model: CompiledModel, name: str, frame_name: str,
+                         mask_dofs: Sequence[bool] = (True, True, True, True, True, True)) -> None:
+    """≙ `robot.add_constraint(name, jiminy.FrameConstraint(frame_name, mask_dofs))` at MODEL level (reference
+    core/src/constraints/frame_constraint.cc:27-35, Model::addConstraint model.cc:926-936): declares that robots of this
+    model may hold the frame at a reference pose along the masked dofs (x, y, z, rot x, rot y, rot z; world aligned).  The
+    kernels are specialised on it like on the contact points, so it is declared before the engine is created; which
+    lanes actually hold it (and with which gains / reference) is run-time state: `BatchedEngine.add_constraint(name,
+    FrameConstraint(frame_name, mask_dofs))`."""
+    model.frame(frame_name)
+    if len(mask_dofs) != 6 or not any(mask_dofs):
+        raise ValueError("mask_dofs must hold six booleans, at least one of them set")
+    if any(x["name"] == name for x in model.constraint_frames):
+        raise ValueError(f"constraint '{name}' already declared")     # model.cc: "A constraint with name ... already exists"
+    model.constraint_frames.append({"name": name, "frame": frame_name,
+                                    "mask": int(sum(1 << d for d in range(6) if mask_dofs[d]))})
+
+
+def add_joint_constraint(model: CompiledModel, name: str, joint_name: str) -> None:
+    """≙ `robot.add_constraint(name, jiminy.JointConstraint(joint_name))` at MODEL level (joint_constraint.cc, Model::addConstraint
+    model.cc:926-936): robots of this model may hold the 1-dof joint at a reference position through a constraint row OF ITS
+    OWN, which coexists with the joint's bound constraint like in the reference and also exists for joints without position
+    bounds.  Declared before the engine is created (the kernels are specialised on it; one-robot-per-lane kernel family);
+    registered per lane with `BatchedEngine.add_constraint(name, JointConstraint(joint_name))`."""
+    j = model.joint_index(joint_name)
+    if not 1 <= int(model.jtypes[j]) <= 8:
+        raise NotImplementedError("JointConstraint rows of their own: revolute / prismatic 1-dof joints")
+    if any(x["name"] == name for x in model.constraint_frames + model.constraint_joints):
+        raise ValueError(f"constraint '{name}' already declared")
+    if any(x["joint"] == j for x in model.constraint_joints):
+        raise ValueError(f"joint '{joint_name}' already carries a declared user constraint")
+    model.constraint_joints.append({"name": name, "joint": int(j)})
 
 
 def add_motor(model: CompiledModel, name: str, joint_name: str, **options: Any) -> Motor:

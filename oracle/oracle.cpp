@@ -404,6 +404,13 @@ struct Model
     std::vector<double> rotor, qlo, qhi;
     std::vector<MotorP> motors;
     std::vector<FrameP> contacts, imus, forces;
+    // frames a user `FrameConstraint(frame, maskDoFs)` may hold (Model::addConstraint; jm_model_desc::cframe_*), bit d of the
+    // mask = dof d of (x, y, z, rot x, rot y, rot z) is fixed (frame_constraint.cc:11-35)
+    std::vector<FrameP> cframes;
+    std::vector<int> cframe_mask;
+    // 1-dof joints a user `JointConstraint(joint)` may hold on a row OF ITS OWN (jm_model_desc::cjoint_joint), next to the
+    // joint's bound constraint like in the reference (model.cc:884-905)
+    std::vector<int> cjoints;
     std::vector<int> contact_sensors, effort_sensors;
     std::vector<EncoderP> encoders;
     // force sensor -> (contact index, relative placement)  basic_sensors.cc:326-350
@@ -470,8 +477,22 @@ struct Engine
         M3 Rloc = M3::identity();
         double depth = 0.0;
     };
+    struct UserFrameCon  // user-registered FrameConstraint (core/src/constraints/frame_constraint.cc), USER registry
+    {
+        bool enabled = false;          // registered for this robot (batch flag bit 0)
+        SE3 ref;                       // transformRef_: the frame's pose at `start` (FrameConstraint::reset) or the caller's
+        double lambda[6] = {0, 0, 0, 0, 0, 0};   // per dof of the mask order (x, y, z, rx, ry, rz); unused dofs stay 0
+    };
     std::vector<BoundCon> bcon;
     std::vector<FrameCon> fcon;
+    struct UserJointCon  // user-registered JointConstraint (joint_constraint.cc), USER registry, own row
+    {
+        int joint = 0;
+        bool enabled = false;
+        double ref = 0.0, lambda = 0.0;
+    };
+    std::vector<UserFrameCon> xcon;
+    std::vector<UserJointCon> jcon;
     std::vector<double> uInternal;
     int pgsIterLast = 0;
     // optional per-lane storage of the constraint state for the batch drivers ([rows][B])
@@ -923,6 +944,12 @@ void init_constraints(Engine & e)
             }
         e.fcon.resize(m.contacts.size());
     }
+    if (e.xcon.size() != m.cframes.size()) e.xcon.resize(m.cframes.size());
+    if (e.jcon.size() != m.cjoints.size())
+    {
+        e.jcon.resize(m.cjoints.size());
+        for (size_t i = 0; i < e.jcon.size(); ++i) e.jcon[i].joint = m.cjoints[i];
+    }
     e.uInternal.assign(m.nv, 0.0);
 }
 
@@ -941,6 +968,20 @@ void reset_constraints(Engine & e)
     {
         f.enabled = true;
         for (double & l : f.lambda) l = 0.0;
+    }
+    // user constraints keep their enabled state (Model::addConstraints enables USER constraints, model.cc:926-936);
+    // FrameConstraint::reset: transformRef_ = oMf at the start configuration, multipliers zeroed (frame_constraint.cc:77-101)
+    for (size_t i = 0; i < e.xcon.size(); ++i)
+    {
+        if (!e.xcon[i].enabled) continue;    // (not registered for this robot: no such constraint object)
+        e.xcon[i].ref = e.oMi[e.mdl.cframes[i].joint] * e.mdl.cframes[i].M;
+        for (double & l : e.xcon[i].lambda) l = 0.0;
+    }
+    for (auto & jc : e.jcon)
+    {
+        if (!jc.enabled) continue;
+        jc.ref = e.q[e.mdl.idx_q[jc.joint]];   // JointConstraint::reset: configurationRef_ = q (joint_constraint.cc:56-83)
+        jc.lambda = 0.0;
     }
 }
 
@@ -1013,6 +1054,8 @@ bool has_constraints(const Engine & e)
 {
     for (const auto & b : e.bcon) if (b.enabled) return true;
     for (const auto & f : e.fcon) if (f.enabled) return true;
+    for (const auto & x : e.xcon) if (x.enabled) return true;
+    for (const auto & jc : e.jcon) if (jc.enabled) return true;
     return false;
 }
 
@@ -1126,6 +1169,7 @@ bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const st
     return false;
 }
 
+V3 log3(const M3 & R);
 // Engine::computeAcceleration (engine.cc:3710-3866). `u` is RobotState::u (in: efforts without the
 // constraint forces; out: + joint-bound multipliers), e.fExternal likewise for the contact forces.
 void compute_acceleration(Engine & e, const double * q, const double * v, std::vector<double> & u, bool ignoreBounds)
@@ -1238,6 +1282,15 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     int rows = 0;
     for (const auto & b : e.bcon) if (b.enabled) { rs.cons.push_back({rows, 1, b.locked ? 0 : 1}); rows += 1; }
     for (const auto & f : e.fcon) if (f.enabled) { rs.cons.push_back({rows, 4, 3}); rows += 4; }
+    // USER registry last (constraintNodeTypesAll, model.h:43-46): unbounded constraints, nBlocks = 0
+    for (size_t i = 0; i < e.xcon.size(); ++i)
+        if (e.xcon[i].enabled)
+        {
+            const int dim = __builtin_popcount((unsigned)m.cframe_mask[i] & 63u);
+            rs.cons.push_back({rows, dim, 0});
+            rows += dim;
+        }
+    for (const auto & jc : e.jcon) if (jc.enabled) { rs.cons.push_back({rows, 1, 0}); rows += 1; }
     Dense J(rows, nv);
     std::vector<double> gamma(rows, 0.0), lambda(rows, 0.0);
     int r = 0;
@@ -1283,6 +1336,49 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         for (int k = 0; k < 4; ++k) lambda[r + k] = e.fcon[i].lambda[k];
         r += 4;
     }
+    // user FrameConstraint (frame_constraint.cc:103-183): world-aligned frame Jacobian rows of the fixed dofs; drift =
+    // classical frame acceleration (ddq = 0, no gravity) + kp (p - p_ref) | kp log3(R R_ref^T) + kd v, own gains
+    for (size_t i = 0; i < e.xcon.size(); ++i)
+    {
+        if (!e.xcon[i].enabled) continue;
+        const FrameP & fr = m.cframes[i];
+        const SE3 oMf = e.oMi[fr.joint] * fr.M;
+        const Motion vl = actInv(fr.M, e.dv[fr.joint]);
+        const Motion al = actInv(fr.M, adrift[fr.joint]);
+        const V3 vlin = oMf.R * vl.lin, vang = oMf.R * vl.ang;
+        V3 dlin = oMf.R * al.lin, dang = oMf.R * al.ang;
+        dlin = dlin + cross(vang, vlin);
+        const V3 dp = oMf.p - e.xcon[i].ref.p;
+        const V3 dr = log3(oMf.R * transpose(e.xcon[i].ref.R));
+        dlin = dlin + kp_u * dp + kd_u * vlin;
+        dang = dang + kp_u * dr + kd_u * vang;
+        const double drift6[6] = {dlin.x, dlin.y, dlin.z, dang.x, dang.y, dang.z};
+        for (int d = 0; d < 6; ++d)
+        {
+            if (!((m.cframe_mask[i] >> d) & 1)) continue;
+            for (int a = 0; a < nv; ++a)
+            {
+                if (!supports(fr.joint, a)) continue;
+                const V3 lin = Jw[a].lin - cross(oMf.p, Jw[a].ang);   // transformLocal.actInv(data.J col), rotationLocal = I
+                const double row6[6] = {lin.x, lin.y, lin.z, Jw[a].ang.x, Jw[a].ang.y, Jw[a].ang.z};
+                J(r, a) = row6[d];
+            }
+            gamma[r] = drift6[d];
+            lambda[r] = e.xcon[i].lambda[d];
+            ++r;
+        }
+    }
+    // user JointConstraint on its own row (joint_constraint.cc:139-163): J = selector of the joint's dof, drift =
+    // kp (q - q_ref) + kd v with the user gains; never reversed
+    for (const auto & jc : e.jcon)
+    {
+        if (!jc.enabled) continue;
+        const int iq = m.idx_q[jc.joint], iv = m.idx_v[jc.joint];
+        J(r, iv) = 1.0;
+        gamma[r] = kp_u * (q[iq] - jc.ref) + kd_u * v[iv];
+        lambda[r] = jc.lambda;
+        ++r;
+    }
     // ---- JMinvJt (computeJMinvJt :491-533) + regularisation (constraint_solvers.cc:376-387)
     Dense L = M;
     if (!llt_inplace(L)) e.status |= JM_LANE_NAN;
@@ -1318,7 +1414,10 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     }
     // ---- multipliers
     bool ok = true;
-    if (ignoreBounds)
+    // `isUnbounded`: every enabled constraint is an unbounded one (constraint_solvers.cc:362-367) -> exact solve like `ignoreBounds`
+    bool isUnbounded = true;
+    for (const auto & c : rs.cons) isUnbounded &= c.nblocks == 0;
+    if (ignoreBounds || isUnbounded)
     {
         Dense LA = A;
         if (!llt_inplace(LA)) e.status |= JM_LANE_NAN;
@@ -1367,6 +1466,14 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         e.fExternal[fr.joint] = e.fExternal[fr.joint] + fl;
         r += 4;
     }
+    // user constraints: the multipliers act through ddq only (engine.cc:3770-3857 restores bounds and contacts alone)
+    for (size_t i = 0; i < e.xcon.size(); ++i)
+    {
+        if (!e.xcon[i].enabled) continue;
+        for (int d = 0; d < 6; ++d)
+            if ((m.cframe_mask[i] >> d) & 1) e.xcon[i].lambda[d] = lambda[r++];
+    }
+    for (auto & jc : e.jcon) if (jc.enabled) jc.lambda = lambda[r++];
 }
 
 // Engine::computeRobotsDynamics with `contacts.model = "constraint"` (engine.cc:3585-3708):
@@ -2009,6 +2116,9 @@ Engine * make_engine(const jm_model_desc * d, const jm_options * o)
     m.contacts = frames(d->ncontacts, d->contact_joint, d->contact_R, d->contact_p);
     m.imus = frames(d->nimu, d->imu_joint, d->imu_R, d->imu_p);
     m.forces = frames(d->nforce, d->force_joint, d->force_R, d->force_p);
+    m.cframes = frames(d->n_constraint_frames, d->cframe_joint, d->cframe_R, d->cframe_p);
+    m.cframe_mask.assign(d->cframe_mask, d->cframe_mask + d->n_constraint_frames);
+    m.cjoints.assign(d->cjoint_joint, d->cjoint_joint + d->n_constraint_joints);
     m.contact_sensors.assign(d->contact_sensor_contact, d->contact_sensor_contact + d->ncontact_sensors);
     m.effort_sensors.assign(d->effort_motor, d->effort_motor + d->neffort);
     for (int i = 0; i < d->nencoder; ++i)
@@ -2189,6 +2299,25 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
             e.fcon[c].enabled = e.con_flags[(nb + c) * B + l] & 1;
             for (int k = 0; k < 4; ++k) e.fcon[c].lambda[k] = e.con_data[(2 * nb + 4 * c + k) * B + l];
         }
+        // user frame constraints: flag rows after the contacts; 6 multiplier rows each after the contact multipliers; then
+        // the reference transforms (translation 3, rotation 9 row-major)
+        // (... then the user joint constraints: one flag row, one multiplier row, one reference row each)
+        const int64_t nx = (int64_t)e.xcon.size(), nxj = (int64_t)e.jcon.size(), lam0 = 2 * nb + 4 * nc, ref0 = lam0 + 6 * nx + nxj;
+        for (int64_t k = 0; k < nxj; ++k)
+        {
+            e.jcon[k].enabled = e.con_flags[(nb + nc + nx + k) * B + l] & 1;
+            e.jcon[k].lambda = e.con_data[(lam0 + 6 * nx + k) * B + l];
+            e.jcon[k].ref = e.con_data[(ref0 + 12 * nx + k) * B + l];
+        }
+        for (int64_t x = 0; x < nx; ++x)
+        {
+            e.xcon[x].enabled = e.con_flags[(nb + nc + x) * B + l] & 1;
+            for (int k = 0; k < 6; ++k) e.xcon[x].lambda[k] = e.con_data[(lam0 + 6 * x + k) * B + l];
+            double t[12];
+            for (int k = 0; k < 12; ++k) t[k] = e.con_data[(ref0 + 12 * x + k) * B + l];
+            e.xcon[x].ref.p = v3_from(t);
+            e.xcon[x].ref.R = m3_from(t + 3);
+        }
     }
     for (int i = 0; i < e.mdl.nq; ++i) e.q[i] = io.q[i * B + l];
     for (int i = 0; i < e.mdl.nv; ++i) e.v[i] = io.v[i * B + l];
@@ -2223,6 +2352,23 @@ static void store_lane(Engine & e, const orc_batch_io & io, int64_t l)
         {
             e.con_flags[(nb + c) * B + l] = e.fcon[c].enabled ? 1 : 0;
             for (int k = 0; k < 4; ++k) e.con_data[(2 * nb + 4 * c + k) * B + l] = e.fcon[c].lambda[k];
+        }
+        const int64_t nx = (int64_t)e.xcon.size(), nxj = (int64_t)e.jcon.size(), lam0 = 2 * nb + 4 * nc, ref0 = lam0 + 6 * nx + nxj;
+        for (int64_t k = 0; k < nxj; ++k)
+        {
+            e.con_flags[(nb + nc + nx + k) * B + l] = e.jcon[k].enabled ? 1 : 0;
+            e.con_data[(lam0 + 6 * nx + k) * B + l] = e.jcon[k].lambda;
+            e.con_data[(ref0 + 12 * nx + k) * B + l] = e.jcon[k].ref;
+        }
+        for (int64_t x = 0; x < nx; ++x)
+        {
+            e.con_flags[(nb + nc + x) * B + l] = e.xcon[x].enabled ? 1 : 0;
+            for (int k = 0; k < 6; ++k) e.con_data[(lam0 + 6 * x + k) * B + l] = e.xcon[x].lambda[k];
+            const V3 & p = e.xcon[x].ref.p;
+            const double t[12] = {p.x, p.y, p.z, e.xcon[x].ref.R.m[0][0], e.xcon[x].ref.R.m[0][1], e.xcon[x].ref.R.m[0][2],
+                                  e.xcon[x].ref.R.m[1][0], e.xcon[x].ref.R.m[1][1], e.xcon[x].ref.R.m[1][2],
+                                  e.xcon[x].ref.R.m[2][0], e.xcon[x].ref.R.m[2][1], e.xcon[x].ref.R.m[2][2]};
+            for (int k = 0; k < 12; ++k) e.con_data[(ref0 + 12 * x + k) * B + l] = t[k];
         }
     }
     for (int i = 0; i < e.mdl.nq; ++i) io.q[i * B + l] = e.q[i];

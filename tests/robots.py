@@ -91,3 +91,50 @@ def foot_pendulum() -> CompiledModel:
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
             tree_arm(True), crane_walker(), biped(False), biped(True)]
+
+
+# ---- robots of the reference's user-FrameConstraint tests, restated (the constraint frames are part of the topology)
+def two_masses_fixed_second() -> CompiledModel:
+    """unit_py/test_double_spring_mass.py:225-252: `FrameConstraint("SecondMass")`, all six dofs, on the second mass."""
+    from jiminy_amd.model import add_frame_constraint
+    m = two_masses()
+    m.name = "two_masses_fix"
+    add_frame_constraint(m, "fixMass", "mass_b")
+    return m
+
+
+def sphere_fixed_frame() -> CompiledModel:
+    """unit_py/test_simple_mass.py:335-377: free-flying body, `FrameConstraint("MassBody", [True] * 6)`."""
+    from jiminy_amd.model import add_frame_constraint
+    m = build_model_from_urdf(os.path.join(DATA, "point_mass.urdf"), has_freeflyer=True, name="sphere_fix")
+    add_frame_constraint(m, "MassBody", "body")
+    return m
+
+
+def pendulum_ff_fixed_world(armature: float = 0.1) -> CompiledModel:
+    """unit_py/test_simple_pendulum.py:752-813: pendulum on a free-flyer whose root body is held by
+    `FrameConstraint("world")`, rotor inertia on the pendulum joint."""
+    from jiminy_amd.model import add_frame_constraint
+    m = build_model_from_urdf(os.path.join(DATA, "pendulum_base.urdf"), has_freeflyer=True, name="pendulum_ff_fix")
+    add_motor(m, "pivot", "pivot", enableVelocityLimit=False, enableEffortLimit=False, enableArmature=armature > 0,
+              armature=armature)
+    add_frame_constraint(m, "world", "world_link")
+    return m
+
+
+def tree_arm_own_locks(has_freeflyer: bool) -> CompiledModel:
+    """`tree_arm` whose `b_yaw` (revolute) and `d_skew_slide` (prismatic, unaligned) joints are declared for user
+    JointConstraints on rows of their own (`add_joint_constraint`), plus a FrameConstraint on the position of the tool:
+    user rows next to bounds and contact points in one solve."""
+    from jiminy_amd.model import add_frame_constraint, add_joint_constraint
+    m = tree_arm(has_freeflyer)
+    m.name = "tree_arm_ff_locks" if has_freeflyer else "tree_arm_locks"
+    add_joint_constraint(m, "hold_yaw", "b_yaw")
+    add_joint_constraint(m, "hold_slide", "d_skew_slide")
+    add_frame_constraint(m, "pin_tool", "tool", (True, True, True, False, False, False))
+    return m
+
+
+def frame_constraint_models() -> List[CompiledModel]:
+    return [two_masses_fixed_second(), sphere_fixed_frame(), pendulum_ff_fixed_world(), tree_arm_own_locks(False),
+            tree_arm_own_locks(True)]

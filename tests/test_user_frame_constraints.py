@@ -1,0 +1,379 @@
+"""User-registered `FrameConstraint`s (reference core/src/constraints/frame_constraint.cc).
+
+Pins: the reference's own analytic tests of the constraint, restated on the robots of tests/robots.py --
+  * unit_py/test_double_spring_mass.py:225-252  second mass of a spring chain held in the world: the first one moves as if alone;
+  * unit_py/test_simple_mass.py:335-377         free body held at a moving reference pose with Baumgarte gains: the pose error
+                                                decays like the critically damped oscillator of that frequency;
+  * unit_py/test_simple_pendulum.py:752-813     pendulum on a free-flyer whose root is held + rotor inertia: the pendulum is the
+                                                fixed-base one, the root does not move.
+First the CPU oracle against the analytic solutions, then the host emulation of the kernels against the oracle, then
+(`-m gpu`) the HIP path through `BatchedEngine.add_constraint` against the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+from jiminy_amd import _abi
+from tests import robots
+from tests.helpers import ReferenceFixedStepLoop, alloc_constraint_state, alloc_soa, oracle_io, rel_err
+
+EXACT = dict(regularization=0.0, tol_abs=1e-12, tol_rel=1e-11)     # the reference tests switch the regularisation off
+
+
+def _unit_circle_joints(model, q, rg):
+    """(cos, sin) coordinates of the unbounded revolute joints of a randomly filled configuration array."""
+    for j in range(1, model.njoints):
+        if 9 <= int(model.jtypes[j]) <= 12:
+            iq = int(model.idx_q[j])
+            th = rg.uniform(-1.0, 1.0, q.shape[1])
+            q[iq], q[iq + 1] = np.cos(th), np.sin(th)
+
+
+def _oracle(model, B, user_freq, **options):
+    from oracle.oracle_py import OracleEngine
+    arr = alloc_soa(model, B)
+    alloc_constraint_state(model, arr, B)
+    rows = _abi.constraint_rows(model)
+    arr["con_flags"][rows["n_bounds"] + rows["n_contacts"]:] = 1      # every lane holds every declared user frame
+    e = OracleEngine(model, **options)
+    e.set_constraint_options(user_stabilization_freq=user_freq, **EXACT)
+    e.bind_constraints(arr["con_flags"], arr["con_data"])
+    return e, arr, oracle_io(arr), rows
+
+
+def test_second_mass_held_in_the_world_leaves_the_first_one_alone():
+    """Relative coordinates (q_b measured from mass a): the constraint is q_a + q_b = const, i.e. a_b = -a_a, and mass a
+    feels u_a - u_b alone: a_a = (u_a - u_b) / m_a.  Zero-order-hold spring-damper efforts sampled every millisecond, RK4
+    (exact for the piecewise-constant accelerations): the oracle must follow the exact discretisation."""
+    model = robots.two_masses_fixed_second()
+    e, arr, io, rows = _oracle(model, 1, 0.0, gravity=(0, 0, 0, 0, 0, 0))
+    k1, k2, c1, c2, ma = 80.0, 50.0, 1.5, 0.8, 3.0
+    x = np.array([0.1, -0.05, 0.3, -0.3])      # (q_a, q_b, v_a, v_b): consistent with the constraint (v_b = -v_a)
+    arr["q"][:, 0], arr["v"][:, 0] = x[:2], x[2:]
+    dt = 1e-3
+    loop = ReferenceFixedStepLoop(dt)
+    u = -np.array([k1, k2]) * x[:2] - np.array([c1, c2]) * x[2:]
+    arr["command"][:, 0] = u
+    e.batch_run("start", io)
+    q_a, v_a, sum0 = x[0], x[2], x[0] + x[1]
+    for _ in range(1500):
+        u = -np.array([k1, k2]) * arr["q"][:, 0] - np.array([c1, c2]) * arr["v"][:, 0]
+        # the hand-written solution sees the same sampled efforts
+        a_a = (u[0] - u[1]) / ma
+        q_a, v_a = q_a + v_a * dt + 0.5 * a_a * dt * dt, v_a + a_a * dt
+        arr["command"][:, 0] = u
+        loop.advance(lambda h, first: e.batch_run("step", io, solver="runge_kutta_4", dt=h, n_substeps=1, command_changed=first), dt, True)
+    assert arr["status"][0, 0] == 0
+    assert abs(arr["q"][0, 0] - q_a) < 1e-9 and abs(arr["v"][0, 0] - v_a) < 1e-9
+    assert abs(arr["q"][0, 0] + arr["q"][1, 0] - sum0) < 1e-9 and abs(arr["v"][0, 0] + arr["v"][1, 0]) < 1e-9
+    assert abs(arr["q"][0, 0] - x[0]) > 1e-2      # (it did move)
+    # the multiplier of the x row carries what holds the mass: lambda = -u_b (second row of the equations of motion)
+    lam_x = arr["con_data"][rows["user_lambda"], 0]
+    assert lam_x == pytest.approx(-u[1], rel=1e-6, abs=1e-6)
+
+
+def test_free_body_follows_a_reference_pose_like_a_critically_damped_oscillator():
+    """Six rows on a free-flyer with regularisation 0 determine its acceleration completely: a = -kp e - kd v with
+    kp = omega^2, kd = 2 omega, omega = 2 pi f (abstract_constraint.cc:88-98), whatever gravity does.  The position
+    error is e(t) = (e0 + (v0 + omega e0) t) exp(-omega t); the orientation error log3(R R_ref^T) shrinks monotonically
+    (the reference's own assertion)."""
+    from oracle.oracle_py import adaptive_state
+    model = robots.sphere_fixed_frame()
+    f = 1.0
+    e, arr, io, rows = _oracle(model, 1, f)
+    arr["q"][:, 0] = [0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+    e.batch_run("start", io)
+    ref0 = arr["con_data"][rows["user_ref"]:rows["user_ref"] + 12, 0].copy()
+    assert np.allclose(ref0[:3], [0, 0, 1.0]) and np.allclose(ref0[3:].reshape(3, 3), np.eye(3))   # FrameConstraint::reset
+    # move the reference: 0.3 m away and rotated by 0.8 rad about a skew axis (`constraint.reference_transform = ...`)
+    axis = np.array([1.0, 2.0, -1.0]) / math.sqrt(6.0)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R_ref = np.eye(3) + math.sin(0.8) * K + (1 - math.cos(0.8)) * K @ K
+    p_ref = np.array([0.2, -0.1, 1.2])
+    arr["con_data"][rows["user_ref"]:rows["user_ref"] + 3, 0] = p_ref
+    arr["con_data"][rows["user_ref"] + 3:rows["user_ref"] + 12, 0] = R_ref.reshape(-1)
+    omega = 2 * math.pi * f
+    e0 = np.array([0.0, 0.0, 1.0]) - p_ref
+    ad = adaptive_state(1)
+    prev_rot = np.inf
+    for k in range(1, 41):
+        t = 0.05 * k
+        e.batch_run_dopri(arr, ad, t, tol_rel=1e-9, tol_abs=1e-9, dt_max=0.02, new_step=True, command_changed=(k == 1))
+        want = (e0 + omega * e0 * t) * math.exp(-omega * t)
+        # (1.2e-6 observed, 1.7e-11 without the rotation: the stages of the reference's Runge-Kutta steppers add
+        # tangent vectors of SE(3) at the step's base point, which couples the turning body into the translation)
+        assert np.abs(arr["q"][:3, 0] - p_ref - want).max() < 5e-6, t
+        x, y, z, w_ = arr["q"][3:7, 0]
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)],
+                       [2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)],
+                       [2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)]])
+        ang = math.acos(min(1.0, max(-1.0, (np.trace(Rm @ R_ref.T) - 1) / 2)))
+        assert ang <= prev_rot + 1e-12
+        prev_rot = ang
+    assert prev_rot < 1e-3 and arr["status"][0, 0] == 0
+
+
+def test_pendulum_on_a_held_free_flyer_is_the_fixed_base_pendulum():
+    """Zero gravity, spring on the joint (zero-order hold, 1 ms), rotor inertia J: q'' = -k q / (I + J) and the root does
+    not move (tolerance of the reference: 1e-7 on a 2 s run with its adaptive stepper)."""
+    model = robots.pendulum_ff_fixed_world(armature=0.1)
+    e, arr, io, rows = _oracle(model, 1, 0.0, gravity=(0, 0, 0, 0, 0, 0))
+    k_spring, I_eq, dt = 500.0, 0.1 + 5.0 * 1.0 ** 2 + 0.1, 1e-3      # bob inertia + m l^2 + rotor inertia
+    q0 = np.array([0.3, -0.2, 0.7, 0.0, 0.0, 0.0, 1.0, 0.1])
+    arr["q"][:, 0] = q0
+    arr["command"][0, 0] = -k_spring * q0[-1]
+    e.batch_run("start", io)
+    A = np.array([[0.0, 1.0], [0.0, 0.0]])
+    Bm = np.array([[0.0], [1.0 / I_eq]])
+    aug = expm(np.block([[A, Bm], [np.zeros((1, 3))]]) * dt)
+    Ad, Bd = aug[:2, :2], aug[:2, 2:]
+    x = np.array([q0[-1], 0.0])
+    loop = ReferenceFixedStepLoop(dt)
+    for _ in range(1000):
+        arr["command"][0, 0] = -k_spring * arr["q"][-1, 0]
+        loop.advance(lambda h, first: e.batch_run("step", io, solver="runge_kutta_4", dt=h, n_substeps=1, command_changed=first), dt, True)
+        x = Ad @ x + Bd[:, 0] * (-k_spring * x[0])       # the fixed-base pendulum under its own sampled spring
+    assert abs(arr["q"][-1, 0] - x[0]) < 1e-8 and abs(arr["v"][-1, 0] - x[1]) < 1e-7
+    assert np.abs(arr["q"][:7, 0] - q0[:7]).max() < 1e-9 and np.abs(arr["v"][:6, 0]).max() < 1e-8
+    assert abs(x[0] - q0[-1]) > 0.05
+
+
+@pytest.mark.parametrize("name", ["two_masses_fix", "sphere_fix", "pendulum_ff_fix", "tree_arm_locks", "tree_arm_ff_locks"])
+@pytest.mark.parametrize("freq", [0.0, 3.0])
+def test_kernels_match_the_oracle_on_the_host(name, freq):
+    """The one-robot-per-lane constraint kernel (jm_constraint.h) through the host emulation, user frames on half of the
+    lanes, RK4 and Euler steps, a moved reference, gains of their own: states, flags, multipliers and reference rows.
+    `tree_arm_locks` / `tree_arm_ff_locks`: user JointConstraints on rows of their own (a revolute and an unaligned
+    prismatic joint, one of them beyond its position bound so that bound row and lock row of the same joint are active
+    together) + a position-only FrameConstraint + contact points, solved by the sweeps with the unbounded rows first."""
+    from tests.hostemu import emu
+    model = {m.name: m for m in robots.frame_constraint_models()}[name]
+    B = 8
+    rg = np.random.default_rng(5)
+    rows = _abi.constraint_rows(model)
+    opts = dict(EXACT, user_stabilization_freq=freq)
+    if name.startswith("tree_arm"):
+        # (bound row and lock row of one joint are the same Jacobian row twice: without regularisation the start pass would
+        # factorise a singular matrix and the split of the multiplier between the two rows would be round-off)
+        opts["regularization"] = 1e-3
+    grav = (0, 0, 0, 0, 0, 0) if name not in ("sphere_fix", "tree_arm_locks", "tree_arm_ff_locks") else (0, 0, -9.81, 0, 0, 0)
+
+    def fresh():
+        arr = alloc_soa(model, B)
+        alloc_constraint_state(model, arr, B)
+        arr["con_flags"][rows["n_bounds"] + rows["n_contacts"]:, ::2] = 1
+        return arr
+    ref, got = fresh(), fresh()
+    q = np.tile(model.neutral()[:, None], (1, B))
+    if model.has_freeflyer:
+        q[:3] += rg.normal(0, 0.3, (3, B)); q[2] += 2.0
+        quat = rg.normal(size=(4, B)); q[3:7] = quat / np.linalg.norm(quat, axis=0)
+        q[7:] = rg.uniform(-0.5, 0.5, (model.nq - 7, B))
+    else:
+        q[:] = rg.uniform(-0.3, 0.3, (model.nq, B))
+    _unit_circle_joints(model, q, rg)
+    v = rg.normal(0, 0.3, (model.nv, B))
+    cmd = rg.uniform(-3, 3, (model.nmotors, 1)) * np.ones((1, B))
+    if name.startswith("tree_arm"):
+        # lanes 0..3: `b_yaw` starts beyond its upper bound (bound row AND lock row of the joint active together); the tree
+        # stands on the ground (contact rows: inequalities in the same solve)
+        iq = int(model.idx_q[model.joint_index("b_yaw")])
+        q[iq, :4] = model.position_upper[iq] + 0.05
+        if model.has_freeflyer:
+            q[:3] = [[0.0], [0.0], [-0.37]]          # upright, the fan a centimetre or two below the ground
+            q[3:7] = [[0.0], [0.0], [0.0], [1.0]]
+
+    for a in (ref, got):
+        a["q"][:], a["v"][:] = q, v
+        if model.nmotors:
+            a["command"][:] = cmd
+    from oracle.oracle_py import OracleEngine
+    e = OracleEngine(model, gravity=grav)
+    e.set_constraint_options(**opts)
+    e.bind_constraints(ref["con_flags"], ref["con_data"])
+    io = oracle_io(ref)
+    e.batch_run("start", io)
+    emu.run(model, got, "start", options=_abi.make_options(gravity=grav), constraint_options=opts)
+
+    def check(what, tol):
+        assert np.array_equal(got["con_flags"], ref["con_flags"]), what
+        for k in ("q", "v", "a", "con_data", "u", "f_external", "energy"):
+            assert rel_err(got[k], ref[k]) < tol, (what, k, rel_err(got[k], ref[k]))
+    check("start", 1e-9 if not name.startswith("tree_arm") else 1e-7)
+    assert np.abs(ref["con_data"][rows["user_lambda"]:rows["user_ref"], ::2]).max() > 1e-3     # the constraint works
+    assert np.abs(ref["con_data"][rows["user_lambda"]:, 1::2]).max() == 0.0                     # ... only where held
+    if name.startswith("tree_arm"):
+        kb = model.bound_row("b_yaw")
+        assert (ref["con_flags"][kb, :4] & 1).all() and (ref["con_flags"][rows["user_joint_flag"], :4:2] & 1).all()
+        if model.has_freeflyer:
+            assert (ref["con_flags"][rows["n_bounds"]:rows["n_bounds"] + rows["n_contacts"]] & 1).any()
+    # move the reference of the held lanes a little, then step
+    for a in (ref, got):
+        a["con_data"][rows["user_ref"]:rows["user_ref"] + 3, ::2] += 0.01
+    for solver, n in (("runge_kutta_4", 3), ("euler_explicit", 3)):
+        for _ in range(n):
+            kw = dict(solver=solver, dt=5e-4, n_substeps=2, command_changed=True)
+            e.batch_run("step", io, **kw)
+            emu.run(model, got, "step", options=_abi.make_options(gravity=grav), constraint_options=opts, **kw)
+        check(solver, 1e-8 if not name.startswith("tree_arm") else 1e-6)
+    assert ((ref["status"] & ~16) == 0).all() and ((got["status"] & ~16) == 0).all()
+
+
+# ------------------------------------------------------------------ the HIP path, through the engine's user-constraint API
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["two_masses_fix", "sphere_fix", "pendulum_ff_fix", "tree_arm_locks", "tree_arm_ff_locks"])
+@pytest.mark.parametrize("freq", [0.0, 3.0])
+def test_gpu_frame_constraint_matches_the_oracle(gpu_device, name, freq):
+    """`BatchedEngine.add_constraint(name, FrameConstraint(frame, mask))` on every other lane: start, a moved reference
+    (`set_constraint_reference`), Runge-Kutta and Euler periods through `step` (opening microsecond step included), against
+    the oracle driven by the reference's own sub-step loop; the lanes without the constraint are the unconstrained robot."""
+    import torch
+
+    from jiminy_amd.engine import BadControlFlow, BatchedEngine, FrameConstraint, JointConstraint
+    from oracle.oracle_py import OracleEngine
+    model = {m.name: m for m in robots.frame_constraint_models()}[name]
+    B, dt = 64, 5e-4
+    rg = np.random.default_rng(9)
+    rows = _abi.constraint_rows(model)
+    tree = name.startswith("tree_arm")
+    grav = [0.0, 0.0, -9.81, 0.0, 0.0, 0.0] if (name == "sphere_fix" or tree) else [0.0] * 6
+    copt = dict(EXACT, regularization=1e-3) if tree else EXACT      # (duplicate rows: see the host test)
+    q = np.tile(model.neutral()[:, None], (1, B))
+    if model.has_freeflyer:
+        q[:3] += rg.normal(0, 0.3, (3, B)); q[2] += 2.0
+        quat = rg.normal(size=(4, B)); q[3:7] = quat / np.linalg.norm(quat, axis=0)
+        q[7:] = rg.uniform(-0.5, 0.5, (model.nq - 7, B))
+    else:
+        q[:] = rg.uniform(-0.3, 0.3, (model.nq, B))
+    _unit_circle_joints(model, q, rg)
+    v = rg.normal(0, 0.3, (model.nv, B))
+    cmd = rg.uniform(-3, 3, (model.nmotors, B))
+    if tree:
+        iq = int(model.idx_q[model.joint_index("b_yaw")])
+        q[iq, :8] = model.position_upper[iq] + 0.05      # bound row and lock row of one joint together
+        if model.has_freeflyer:
+            q[:3] = [[0.0], [0.0], [-0.37]]
+            q[3:7] = [[0.0], [0.0], [0.0], [1.0]]
+    held = np.arange(B) % 2 == 0
+    # ---- oracle
+    ref = alloc_soa(model, B)
+    alloc_constraint_state(model, ref, B)
+    ref["con_flags"][rows["n_bounds"] + rows["n_contacts"]:, held] = 1
+    ref["q"][:], ref["v"][:] = q, v
+    if model.nmotors:
+        ref["command"][:] = cmd
+    e = OracleEngine(model, gravity=tuple(grav))
+    e.set_constraint_options(user_stabilization_freq=freq, **copt)
+    e.bind_constraints(ref["con_flags"], ref["con_data"])
+    io = oracle_io(ref)
+    # ---- engine
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("f_external", "energy"))
+    eng.set_options({"world": {"gravity": grav}, "constraints": {"regularization": copt["regularization"]},
+                     "stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": 2 * dt, "sensorsUpdatePeriod": 2 * dt,
+                                 "tolAbs": EXACT["tol_abs"], "tolRel": EXACT["tol_rel"]}, "contacts": {"model": "constraint"}})
+    x = model.constraint_frames[0]
+    with pytest.raises(LookupError):
+        eng.add_constraint("nope", FrameConstraint(x["frame"], (False, False, False, False, True, False), baumgarte_freq=freq))
+    eng.add_constraint("hold", FrameConstraint(x["frame"], tuple(bool((x["mask"] >> d) & 1) for d in range(6)), baumgarte_freq=freq),
+                       lane_mask=torch.from_numpy(held))
+    for xj in model.constraint_joints:      # JointConstraints on rows of their own (declared joints)
+        eng.add_constraint(xj["name"], JointConstraint(model.joint_names[xj["joint"]], baumgarte_freq=freq),
+                           lane_mask=torch.from_numpy(held))
+    if model.nmotors:
+        eng.set_command(torch.from_numpy(cmd))
+    eng.start(torch.from_numpy(q), torch.from_numpy(v))
+    with pytest.raises(BadControlFlow):
+        eng.remove_constraint("hold")
+    e.batch_run("start", io)
+
+    def check(what, tol):
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"]), what
+        for k in ("q", "v", "a", "con_data", "u", "f_external", "energy"):
+            err = rel_err(eng.field(k).cpu().numpy(), ref[k])
+            assert err < tol, (what, k, err)
+    check("start", 1e-7 if tree else 1e-9)
+    p_ref, R_ref = eng.constraint_reference("hold")
+    assert np.allclose(p_ref.cpu().numpy()[:, held], ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3][:, held])
+    eng.set_constraint_reference("hold", (p_ref + 0.01, R_ref))
+    ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3, held] += 0.01
+    loop = ReferenceFixedStepLoop(dt)
+    for solver in ("runge_kutta_4", "euler_explicit"):
+        if solver == "euler_explicit":
+            eng.stop()
+            eng.set_options({"stepper": {"odeSolver": solver}})
+            # a new simulation from the oracle's state; the constraint takes the frame's pose there as its reference again
+            eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+            e.batch_run("start", io)
+            loop = ReferenceFixedStepLoop(dt)
+            check("restart", 1e-7 if tree else 1e-9)
+        for _ in range(3):
+            eng.step(2 * dt)
+            loop.advance(lambda h, first: e.batch_run("step", io, solver=solver, dt=h, n_substeps=1, command_changed=first), 2 * dt, True)
+        check(solver, 1e-6 if tree else 1e-8)
+    assert ((ref["status"] & ~16) == 0).all() and int((eng.status & ~16).abs().sum()) == 0
+    assert np.abs(ref["con_data"][rows["user_lambda"]:rows["user_ref"]][:, held]).max() > 1e-3
+    eng.stop()
+    for cname in list(eng.user_constraints):
+        eng.remove_constraint(cname)
+    assert not eng.user_constraints and int(eng.field("con_flags")[rows["n_bounds"] + rows["n_contacts"]:].sum()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_free_body_tracks_a_moving_reference_pose(gpu_device):
+    """The reference's acceptance test of the constraint (unit_py/test_simple_mass.py:335-377) on the device: all six dofs of
+    a free body held with a 1 Hz Baumgarte frequency, the reference pose replaced every 2 s by a random one per lane: every
+    component of the pose error shrinks from step to step, and the position error follows the critically damped law."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, FrameConstraint
+    model = robots.sphere_fixed_frame()
+    B, f, step_dt = 96, 1.0, 0.01
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"constraints": {"regularization": 0.0}, "contacts": {"model": "constraint"},
+                     "stepper": {"odeSolver": "runge_kutta_4", "dtMax": 1e-3, "controllerUpdatePeriod": step_dt, "sensorsUpdatePeriod": step_dt}})
+    eng.add_constraint("MassBody", FrameConstraint("body", baumgarte_freq=f))
+    q0 = np.tile(np.array([0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])[:, None], (1, B))
+    eng.start(torch.from_numpy(q0), torch.zeros((6, B), dtype=torch.float64))
+    g = torch.Generator(device="cpu").manual_seed(4)
+    omega = 2 * math.pi * f
+    for episode in range(2):
+        axis = torch.nn.functional.normalize(torch.randn(3, B, generator=g, dtype=torch.float64), dim=0)
+        ang = torch.rand(B, generator=g, dtype=torch.float64) * 2.0
+        K = torch.zeros(3, 3, B, dtype=torch.float64)
+        K[0, 1], K[0, 2], K[1, 0], K[1, 2], K[2, 0], K[2, 1] = -axis[2], axis[1], axis[2], -axis[0], -axis[1], axis[0]
+        KK = torch.einsum("ijb,jkb->ikb", K, K)
+        R_ref = torch.eye(3, dtype=torch.float64)[:, :, None] + torch.sin(ang) * K + (1 - torch.cos(ang)) * KK
+        p_now = eng.field("q")[:3].cpu()
+        v_now = None
+        p_ref = p_now + torch.randn(3, B, generator=g, dtype=torch.float64) * 0.3
+        eng.set_constraint_reference("MassBody", (p_ref, R_ref))
+        e0 = (p_now - p_ref)
+        # world-frame velocity of the frame origin at the switch (R v_lin)
+        qq = eng.field("q").cpu()
+        x, y, z, w_ = qq[3], qq[4], qq[5], qq[6]
+        Rm = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)]),
+                          torch.stack([2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)]),
+                          torch.stack([2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)])])
+        v0 = torch.einsum("ijb,jb->ib", Rm, eng.field("v")[:3].cpu())
+        prev = None
+        for k in range(1, 201):
+            eng.step(step_dt)
+            t = k * step_dt
+            err = eng.field("q")[:3].cpu() - p_ref
+            want = (e0 + (v0 + omega * e0) * t) * math.exp(-omega * t)
+            assert float((err - want).abs().max()) < 2e-4, (episode, k)      # (fixed-step RK4 on SE(3) with a turning body)
+            qq = eng.field("q").cpu()
+            x, y, z, w_ = qq[3], qq[4], qq[5], qq[6]
+            Rm = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)]),
+                              torch.stack([2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)]),
+                              torch.stack([2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)])])
+            tr = torch.einsum("ijb,ijb->b", Rm, R_ref)
+            rot = torch.acos(torch.clamp((tr - 1) / 2, -1.0, 1.0))
+            if prev is not None and episode == 0:
+                assert bool((rot <= prev + 1e-9).all()), (episode, k)       # (from rest: the orientation error never grows)
+            prev = rot
+        assert float(prev.max()) < 1e-3 and float((eng.field("q")[:3].cpu() - p_ref).abs().max()) < 1e-3
+    assert int(eng.status.abs().sum()) == 0
