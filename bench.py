@@ -308,12 +308,21 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                 # evenly over the 1024 SIMDs
                 ipw, waves = pmc.get("valu_insts_per_wave"), pmc.get("waves_per_launch")
                 if ipw and waves:
-                    cyc = 4 if dname == "f64" else 2
-                    floor_s = ipw * cyc * -(-int(waves) // SIMDS) / CLOCK_HZ
+                    # cycles a SIMD needs per wave64 instruction, measured on the MI355X with two waves per SIMD
+                    # (tools/microbench/op_issue, profiles/r05_op_issue.txt): 4.44 for the fp64 / 64-bit / DPP classes
+                    # that make up the loop, 2.5 for plain 32-bit ops; clock: what the chip sustained under the profiled
+                    # kernel (GRBM_GUI_ACTIVE / duration), nominal 2.4 GHz when the profile has none
+                    cyc = 4.44 if dname == "f64" else 2.5
+                    clock_hz = 1e9 * pmc["sustained_clock_ghz"] if pmc.get("sustained_clock_ghz") else CLOCK_HZ
+                    floor_s = ipw * cyc * -(-int(waves) // SIMDS) / clock_hz
                     valu = {"bound": "valu-issue", "insts_per_wave_per_launch": ipw, "waves": waves,
-                            "cycles_per_inst": cyc, "floor_ms": 1e3 * floor_s,
+                            "cycles_per_inst": cyc, "clock_ghz": clock_hz / 1e9, "floor_ms": 1e3 * floor_s,
                             "frac": floor_s / avg_launch_s if avg_launch_s else None,
-                            "from": pmc.get("from")}
+                            # measured, not modelled: share of the time the VALU pipes of the profiled launch were issuing
+                            "valu_pipe_busy_frac_profiled": pmc.get("valu_pipe_busy_frac"),
+                            "from": pmc.get("from"),
+                            "note": "counters come from the committed profile named in `from` (same workload, another run), "
+                                    "only avg_launch_ms is measured in this run"}
         except Exception:
             traffic = None
     what_ran = ("4 dynamics evaluations (FK + contacts + motors + ABA)" if solver == "runge_kutta_4" else
@@ -345,6 +354,8 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                       if constrained else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": (f"PMC counters of the committed profile {os.path.relpath(pmc_path, ROOT)} (same workload, "
+                                        "separate rocprofv3 --pmc passes; not re-measured by this run)") if traffic is not None else None,
                      "kernel": kernel_name, "launches_timed": n_launch,
                      "avg_launch_ms": 1e3 * avg_launch_s,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,

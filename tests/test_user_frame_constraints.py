@@ -297,7 +297,8 @@ def test_gpu_frame_constraint_matches_the_oracle(gpu_device, name, freq):
     check("start", 1e-7 if tree else 1e-9)
     p_ref, R_ref = eng.constraint_reference("hold")
     assert np.allclose(p_ref.cpu().numpy()[:, held], ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3][:, held])
-    eng.set_constraint_reference("hold", (p_ref + 0.01, R_ref))
+    held_dev = torch.from_numpy(held).to(gpu_device)
+    eng.set_constraint_reference("hold", (torch.where(held_dev[None, :], p_ref + 0.01, p_ref), R_ref.clone()))
     ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3, held] += 0.01
     loop = ReferenceFixedStepLoop(dt)
     for solver in ("runge_kutta_4", "euler_explicit"):

@@ -18,6 +18,7 @@ static const char * NAMES[OPS] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_fma_
 
 template<int OP> __device__ __forceinline__ void step(double (&x)[8], float (&f)[8], unsigned (&u)[8], double a, double b, const double * lds)
 {
+    const unsigned long long mask = 0x5555555555555555ull;   // lane mask of the selects (an SGPR pair, read-only)
 #pragma unroll
     for (int c = 0; c < 8; ++c)
     {
@@ -27,7 +28,7 @@ template<int OP> __device__ __forceinline__ void step(double (&x)[8], float (&f)
         else if constexpr (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"((float)a), "v"((float)b));
         else if constexpr (OP == MOV32) asm volatile("v_mov_b32 %0, %1" : "=v"(u[c]) : "v"(u[(c + 1) & 7]));
         else if constexpr (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(u[c]) : "v"(u[(c + 1) & 7]));
-        else if constexpr (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[c]) : "v"(u[(c + 1) & 7]) : "vcc");
+        else if constexpr (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(u[c]) : "v"(u[(c + 1) & 7]), "s"(mask));
         else if constexpr (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[c]) : "v"(u[(c + 1) & 7]));
         else if constexpr (OP == LSHL_B64) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(x[c]));
         else if constexpr (OP == RCP64) asm volatile("v_rcp_f64 %0, %0" : "+v"(x[c]));

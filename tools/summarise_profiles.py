@@ -65,6 +65,7 @@ def summarise_kernel(src, stats_db, like):
                 vals.setdefault(cname, []).append(value)
         for k, v in vals.items():
             summary["counters_per_launch_median"][k] = statistics.median(v)
+            summary.setdefault("pass_median_ns", {})[k] = med     # (a launch under counters is 3-6 % longer than without)
     c = summary["counters_per_launch_median"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         lo = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
@@ -79,6 +80,15 @@ def summarise_kernel(src, stats_db, like):
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
             if k in c:
                 summary[k + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    # clock the chip sustained under this kernel: GRBM_GUI_ACTIVE counts busy gfx-clock cycles of every XCD (8 on the
+    # MI355X; calibrated in round 5 against the s_memtime / s_memrealtime clock of tools/microbench/op_issue) over the
+    # dispatch -- taken against the median duration of the pass that collected it
+    if c.get("GRBM_GUI_ACTIVE") and summary.get("pass_median_ns", {}).get("GRBM_GUI_ACTIVE"):
+        summary["sustained_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / summary["pass_median_ns"]["GRBM_GUI_ACTIVE"]
+    # measured occupancy of the VALU issue pipes: SQ_ACTIVE_INST_VALU is in quad-cycles summed over the SIMDs
+    if c.get("SQ_ACTIVE_INST_VALU") and summary.get("pass_median_ns", {}).get("SQ_ACTIVE_INST_VALU"):
+        clk = summary.get("sustained_clock_ghz", 2.4)
+        summary["valu_pipe_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / (clk * summary["pass_median_ns"]["SQ_ACTIVE_INST_VALU"])
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         summary["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
     return summary
@@ -130,6 +140,8 @@ def main():
                                           "hbm_bytes_per_launch_uncorrected", "dominant_kernel", "source")}
     latest["valu_insts_per_wave"] = summary.get("SQ_INSTS_VALU_per_wave")
     latest["waves_per_launch"] = c.get("SQ_WAVES")
+    latest["sustained_clock_ghz"] = summary.get("sustained_clock_ghz")
+    latest["valu_pipe_busy_frac"] = summary.get("valu_pipe_busy_frac")
     latest["from"] = f"profiles/{name}_pmc.json"
     # fourth argument: name of the "latest" file bench.py reads (pmc_latest.json / pmc_con_latest.json)
     latest_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_latest.json"
