@@ -98,6 +98,9 @@ enum {
 
 /* ---- model description: plain arrays, all host memory, copied by jm_model_create.
  * Joint 0 is the universe. Matrices are row-major 3x3. */
+/* kinds of user constraint frames (jm_model_desc::cframe_kind) */
+enum { JM_XKIND_FRAME = 0, JM_XKIND_SPHERE = 1, JM_XKIND_WHEEL = 2, JM_XKIND_DISTANCE = 3 };
+
 typedef struct jm_model_desc {
     int32_t njoints, nq, nv;
     int32_t nmotors, ncontacts;
@@ -141,6 +144,14 @@ typedef struct jm_model_desc {
     const int32_t * cframe_mask;   /* [n_constraint_frames] 6-bit mask of the fixed dofs */
     const double * cframe_R;       /* [n_constraint_frames*9] frame placement in the joint frame */
     const double * cframe_p;       /* [n_constraint_frames*3] */
+    /* kind of every constraint frame (JM_XKIND_*), second parent joint (DistanceConstraint, else 0) and 8 parameters:
+     * SphereConstraint (sphere_constraint.cc) radius, normal[3]; WheelConstraint (wheel_constraint.cc) radius, normal[3],
+     * axis[3] (wheel axis in the frame); DistanceConstraint (distance_constraint.cc) -, position[3] of the second frame
+     * in ITS parent joint.  Masks: frame = the user's, sphere / wheel = 0b000111 (three rows at the contact point),
+     * distance = 0b000001 (one row). */
+    const int32_t * cframe_kind;   /* [n_constraint_frames] */
+    const int32_t * cframe_joint2; /* [n_constraint_frames] */
+    const double * cframe_params;  /* [n_constraint_frames*8] */
     /* ... and the 1-dof joints (revolute / prismatic) a user-registered JointConstraint may hold on a row of its own, next
      * to the joint's bound constraint like in the reference (`robot.add_constraint(name, JointConstraint(joint))`,
      * core/src/constraints/joint_constraint.cc, model.cc:884-905).  One-robot-per-lane kernels; the branch-parallel kernels

@@ -61,6 +61,7 @@ class ModelDesc(C.Structure):
         ("effort_motor", _pi),
         ("n_constraint_frames", C.c_int32),
         ("cframe_joint", _pi), ("cframe_mask", _pi), ("cframe_R", _pd), ("cframe_p", _pd),
+        ("cframe_kind", _pi), ("cframe_joint2", _pi), ("cframe_params", _pd),
         ("n_constraint_joints", C.c_int32), ("cjoint_joint", _pi),
     ]
 
@@ -160,6 +161,19 @@ def _f64(x: Any) -> np.ndarray:
     return a if a.size else np.zeros(1, dtype=np.float64)
 
 
+XKINDS = {"frame": 0, "sphere": 1, "wheel": 2, "distance": 3}
+
+
+def constraint_frame_params(model: CompiledModel, x: Dict[str, Any]) -> List[float]:
+    """The 8 parameters of a user constraint frame (jm_model_desc::cframe_params)."""
+    kind = x.get("kind", "frame")
+    if kind == "distance":
+        return [0.0, *[float(v) for v in model.frames[x["frame2"]].p], 0.0, 0.0, 0.0, 0.0]
+    n = [float(v) for v in x.get("normal", (0.0, 0.0, 1.0))]
+    a = [float(v) for v in x.get("axis", (0.0, 0.0, 0.0))]
+    return [float(x.get("radius", 0.0)), *n, *a, 0.0]
+
+
 def make_model_desc(model: CompiledModel) -> Tuple[ModelDesc, List[np.ndarray]]:
     """Flatten a CompiledModel into the C description. Returns (desc, keepalive arrays)."""
     keep: List[np.ndarray] = []
@@ -220,6 +234,9 @@ def make_model_desc(model: CompiledModel) -> Tuple[ModelDesc, List[np.ndarray]]:
     d.cframe_joint = pi([f.parent_joint for f in xf])
     d.cframe_mask = pi([x["mask"] for x in model.constraint_frames])
     d.cframe_R, d.cframe_p = pd([f.R for f in xf]), pd([f.p for f in xf])
+    d.cframe_kind = pi([XKINDS[x.get("kind", "frame")] for x in model.constraint_frames])
+    d.cframe_joint2 = pi([model.frames[x["frame2"]].parent_joint if x.get("frame2") else 0 for x in model.constraint_frames])
+    d.cframe_params = pd([constraint_frame_params(model, x) for x in model.constraint_frames])
     d.n_constraint_joints = len(model.constraint_joints)
     d.cjoint_joint = pi([x["joint"] for x in model.constraint_joints])
     return d, keep

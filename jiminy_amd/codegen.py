@@ -202,6 +202,8 @@ def topology_header(model: CompiledModel) -> str:
         f"    static constexpr int NX = {len(model.constraint_frames)};   // user constraint frames (FrameConstraint)",
         _arr("xframe_joint", [model.frames[x["frame"]].parent_joint for x in model.constraint_frames]),
         _arr("xframe_mask", [x["mask"] for x in model.constraint_frames]),
+        _arr("xframe_kind", [{"frame": 0, "sphere": 1, "wheel": 2, "distance": 3}[x.get("kind", "frame")] for x in model.constraint_frames]),
+        _arr("xframe_joint2", [model.frames[x["frame2"]].parent_joint if x.get("frame2") else 0 for x in model.constraint_frames]),
         f"    static constexpr int NXJ = {len(model.constraint_joints)};   // user constraint joints (JointConstraint rows of their own)",
         _arr("xjoint", [x["joint"] for x in model.constraint_joints]),
         _arr("imu_joint", imu),

@@ -226,6 +226,12 @@ template<class Tp> constexpr bool joint_has_xframe(int j)
         if (Tp::xframe_joint[x] == j) return true;
     return false;
 }
+template<class Tp> constexpr bool joint_has_xframe2(int j)   // second frame of a DistanceConstraint
+{
+    for (int x = 0; x < Tp::NX; ++x)
+        if (Tp::xframe_kind[x] == JM_XKIND_DISTANCE && Tp::xframe_joint2[x] == j) return true;
+    return false;
+}
 template<class Tp, class F> JM_DEV void for_contacts(F && f)
 {
     if constexpr (Tp::NC > 0)
@@ -665,6 +671,33 @@ JM_DEV bool pgs_solve_regs(const ConArgs<T> & C, T friction, int m, int nb, WS &
     return converged;
 }
 
+// ---- kinds of user constraint frames (JM_XKIND_*): what differs from the plain FrameConstraint rows
+// SphereConstraint / WheelConstraint: radius * (direction from the contact point to the frame origin), world aligned:
+// skewRadius_ = [rd]x (sphere_constraint.cc:96-101: the ground normal; wheel_constraint.cc:96-101: y, which tilts with the wheel)
+template<class T, class Tp, int X, class W> JM_DEV V3<T> xframe_rd(CPtr<T> P, const W & w)
+{
+    using L = Layout<Tp>;
+    constexpr int kind = Tp::xframe_kind[X];
+    if constexpr (kind == JM_XKIND_SPHERE) return P[L::XPAR + 8 * X] * ld_v3<T>(P, L::XPAR + 8 * X + 1);
+    else if constexpr (kind == JM_XKIND_WHEEL)
+    {
+        constexpr int j = Tp::xframe_joint[X];
+        const V3<T> nrm = ld_v3<T>(P, L::XPAR + 8 * X + 1);
+        const V3<T> axis = w.oMi[j].R * (ld_m3<T>(P, L::XFRAME + 12 * X) * ld_v3<T>(P, L::XPAR + 8 * X + 4));
+        const V3<T> x = cross(cross(axis, nrm), axis);
+        return (P[L::XPAR + 8 * X] * rsqrt_(dot(x, x))) * x;
+    }
+    else return zero3<T>();
+}
+// DistanceConstraint: world positions of the two frame origins
+template<class T, class Tp, int X, class W> JM_DEV void xframe_points(CPtr<T> P, const W & w, V3<T> & p1, V3<T> & p2)
+{
+    using L = Layout<Tp>;
+    constexpr int j1 = Tp::xframe_joint[X], j2 = Tp::xframe_joint2[X];
+    p1 = w.oMi[j1].p + w.oMi[j1].R * ld_v3<T>(P, L::XFRAME + 12 * X + 9);
+    p2 = w.oMi[j2].p + w.oMi[j2].R * ld_v3<T>(P, L::XPAR + 8 * X + 1);
+}
+
 template<class T, class Tp, class CA>
 JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
                              long long lane, long long B, int start_passes)
@@ -776,7 +809,14 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         {
             if (start_passes > 0)
             {
-                const SE3<T> oMf = w.oMi[j] * ld_se3<T>(P, L::XFRAME + 12 * x);
+                SE3<T> oMf = w.oMi[j] * ld_se3<T>(P, L::XFRAME + 12 * x);
+                if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                {
+                    // DistanceConstraint::reset: distanceRef_ = |p_1 - p_2| in the first slot (distance_constraint.cc:73-77)
+                    V3<T> p1, p2;
+                    xframe_points<T, Tp, x>(P, w, p1, p2);
+                    oMf = {ident3<T>(), {sqrt_(dot(p1 - p2, p1 - p2)), T(0), T(0)}};
+                }
                 const T t[12] = {oMf.p.x, oMf.p.y, oMf.p.z, oMf.R.m00, oMf.R.m01, oMf.R.m02, oMf.R.m10, oMf.R.m11, oMf.R.m12,
                                  oMf.R.m20, oMf.R.m21, oMf.R.m22};
 #pragma unroll
@@ -814,7 +854,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     });
     static_for<0, R::NX>([&](auto xc) {
         constexpr int x = decltype(xc)::value;
-        if (xact.test(R::XR0 + 6 * x + R::xfirst(x))) fmask |= R::anc_mask(Tp::xframe_joint[x]);
+        if (xact.test(R::XR0 + 6 * x + R::xfirst(x))) fmask |= R::anc_mask(Tp::xframe_joint[x]) | R::anc_mask(Tp::xframe_joint2[x]);
     });
     static_for<0, R::NB>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -833,9 +873,9 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     for (int pk = 0; pk < (refresh ? 0 : m_act); ++pk)
     {
         const int r = rem.pop_lowest();
-        int jr = 0, tiv = -1;
+        int jr = 0, jr2 = -1, tiv = -1;
         T tsgn = T(0);
-        Sp<T> fu = zero6<T>();
+        Sp<T> fu = zero6<T>(), fu2 = zero6<T>();
         unsigned long long bmask = 0ull;
         static_for<0, R::NB>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -883,18 +923,49 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 const int d = r - r0, ax = d < 3 ? d : d - 3;
                 const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
                 const M3<T> & Rj = w.oMi[j].R;
-                const V3<T> col = ax == 0 ? V3<T>{Rj.m00, Rj.m01, Rj.m02}
-                                : ax == 1 ? V3<T>{Rj.m10, Rj.m11, Rj.m12} : V3<T>{Rj.m20, Rj.m21, Rj.m22};
-                if (d < 3) fu = {col, cross(pc, col)};
-                else fu = {zero3<T>(), col};
-                jr = j;
-                bmask = R::anc_mask(j);
+                if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                {
+                    // + dir on the first frame origin, - dir on the second one (J = dir^T (J_1 - J_2), distance_constraint.cc:113-121)
+                    constexpr int j2 = Tp::xframe_joint2[x];
+                    V3<T> p1, p2;
+                    xframe_points<T, Tp, x>(P, w, p1, p2);
+                    const V3<T> dir = rsqrt_(dot(p1 - p2, p1 - p2)) * (p1 - p2);
+                    const V3<T> c1 = tmul(Rj, dir), c2 = tmul(w.oMi[j2].R, dir);
+                    fu = {c1, cross(pc, c1)};
+                    fu2 = {-c2, -cross(ld_v3<T>(P, L::XPAR + 8 * x + 1), c2)};
+                    jr = j; jr2 = j2;
+                    bmask = R::anc_mask(j) | R::anc_mask(j2);
+                }
+                else
+                {
+                    const V3<T> col = ax == 0 ? V3<T>{Rj.m00, Rj.m01, Rj.m02}
+                                    : ax == 1 ? V3<T>{Rj.m10, Rj.m11, Rj.m12} : V3<T>{Rj.m20, Rj.m21, Rj.m22};
+                    if (d < 3) fu = {col, cross(pc, col)};
+                    else fu = {zero3<T>(), col};
+                    if constexpr (Tp::xframe_kind[x] != JM_XKIND_FRAME)
+                    {
+                        // row taken at the contact point: J = J_lin + [rd]x J_ang  <=>  torque e_d x rd next to the force e_d
+                        const V3<T> ed = ax == 0 ? V3<T>{T(1), T(0), T(0)} : ax == 1 ? V3<T>{T(0), T(1), T(0)} : V3<T>{T(0), T(0), T(1)};
+                        fu.a = fu.a + tmul(Rj, cross(ed, xframe_rd<T, Tp, x>(P, w)));
+                    }
+                    jr = j;
+                    bmask = R::anc_mask(j);
+                }
             }
+        });
+        // (the entry of a DistanceConstraint row is accumulated by the visits of its two joints: cleared first)
+        static_for<0, R::NX>([&](auto xc) {
+            constexpr int x = decltype(xc)::value;
+            if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                if (xact.test(R::XR0 + 6 * x)) ws(R::WA + act.rank(R::XR0 + 6 * x) * NR + pk) = T(0);
         });
         // J_row . dd of every active row = column pk of the delassus matrix, written as the sweep reaches the joints
         delta_sweeps<T, Tp>(
             P, w, [&](auto ic) { return decltype(ic)::value == tiv ? tsgn : T(0); },
-            [&](auto jc) { return decltype(jc)::value == jr ? fu : zero6<T>(); },
+            [&](auto jc) {
+                if constexpr (R::NX > 0) return (decltype(jc)::value == jr ? fu : zero6<T>()) + (decltype(jc)::value == jr2 ? fu2 : zero6<T>());
+                else return decltype(jc)::value == jr ? fu : zero6<T>();
+            },
             [&](auto jc, const T * ddj, const Sp<T> & daj) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int k = bound_row_of<Tp>(j);
@@ -925,13 +996,30 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                 }
                 static_for<0, R::NX>([&](auto xc) {
                     constexpr int x = decltype(xc)::value;
-                    if constexpr (Tp::xframe_joint[x] == j)
+                    if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                    {
+                        if constexpr (Tp::xframe_joint[x] == j || Tp::xframe_joint2[x] == j)
+                            if (xact.test(R::XR0 + 6 * x))
+                            {
+                                V3<T> p1, p2;
+                                xframe_points<T, Tp, x>(P, w, p1, p2);
+                                const V3<T> dir = rsqrt_(dot(p1 - p2, p1 - p2)) * (p1 - p2);
+                                T s = T(0);
+                                if constexpr (Tp::xframe_joint[x] == j)
+                                    s += dot(dir, w.oMi[j].R * (daj.l + cross(daj.a, ld_v3<T>(P, L::XFRAME + 12 * x + 9))));
+                                if constexpr (Tp::xframe_joint2[x] == j)
+                                    s -= dot(dir, w.oMi[j].R * (daj.l + cross(daj.a, ld_v3<T>(P, L::XPAR + 8 * x + 1))));
+                                ws(R::WA + act.rank(R::XR0 + 6 * x) * NR + pk) += s;
+                            }
+                    }
+                    else if constexpr (Tp::xframe_joint[x] == j)
                     {
                         if (xact.test(R::XR0 + 6 * x + R::xfirst(x)))
                         {
                             const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
-                            const V3<T> lin = w.oMi[j].R * (daj.l + cross(daj.a, pc));
+                            V3<T> lin = w.oMi[j].R * (daj.l + cross(daj.a, pc));
                             const V3<T> ang = w.oMi[j].R * daj.a;
+                            if constexpr (Tp::xframe_kind[x] != JM_XKIND_FRAME) lin = lin + cross(xframe_rd<T, Tp, x>(P, w), ang);
                             const T six[6] = {lin.x, lin.y, lin.z, ang.x, ang.y, ang.z};
                             static_for<0, 6>([&](auto dc) {
                                 constexpr int d = decltype(dc)::value;
@@ -960,11 +1048,12 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
         // free acceleration of this pass (joint accelerations + spatial accelerations, gravity field removed)
         T af[NV];
         Sp<T> sa[NJ];
+        sa[0] = zero6<T>();   // (a DistanceConstraint may anchor one of its frames in the world)
         static_for<0, NV>([&](auto ic) { af[decltype(ic)::value] = ddq_free[decltype(ic)::value]; });
         static_for<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             // (only the joints that carry contact points are read below)
-            if constexpr (joint_has_contact<Tp>(j) || joint_has_xframe<Tp>(j)) sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
+            if constexpr (joint_has_contact<Tp>(j) || joint_has_xframe<Tp>(j) || joint_has_xframe2<Tp>(j)) sa[j] = w.agf[j] + actinv_motion(w.oMi[j], Sp<T>{g, gw});
             else sa[j] = zero6<T>();
         });
         if (start_passes > 0)
@@ -1026,14 +1115,62 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                     V3<T> aang = Rj * sa[j].a;
                     alin = alin + cross(vang, vlin);
                     const V3<T> pos = w.oMi[j].p + Rj * fr.p;
-                    const M3<T> Rf = Rj * fr.R;
                     const V3<T> pref = {dat(R::XREF + 12 * x), dat(R::XREF + 12 * x + 1), dat(R::XREF + 12 * x + 2)};
+                    if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                    {
+                        // distance_constraint.cc:96-150: relative classical acceleration along the direction + the
+                        // centripetal term of the turning direction + Baumgarte on (distance - reference) and its rate
+                        constexpr int j2 = Tp::xframe_joint2[x];
+                        const V3<T> pl2 = ld_v3<T>(P, L::XPAR + 8 * x + 1);
+                        const M3<T> & R2 = w.oMi[j2].R;
+                        const V3<T> p2 = w.oMi[j2].p + R2 * pl2;
+                        Sp<T> v2 = zero6<T>(), a2 = zero6<T>();
+                        if constexpr (j2 > 0) { v2 = w.vel[j2]; a2 = sa[j2]; }
+                        const V3<T> v2lin = R2 * (v2.l + cross(v2.a, pl2)), v2ang = R2 * v2.a;
+                        const V3<T> a2lin = R2 * (a2.l + cross(a2.a, pl2)) + cross(v2ang, v2lin);
+                        const V3<T> delta = pos - p2, dvel = vlin - v2lin;
+                        const T inv = rsqrt_(dot(delta, delta)), dn = dot(delta, delta) * inv;
+                        const V3<T> dir = inv * delta;
+                        const T dvp = dot(dvel, dir);
+                        const T drift = dot(dir, alin - a2lin) + (dot(dvel, dvel) - dvp * dvp) * inv + C.kp_lock * (dn - pref.x) + C.kd_lock * dvp;
+                        const int pr = act.rank(R::XR0 + 6 * x);
+                        ws(R::WB + pr) = -drift;
+                        ws(R::WX + pr) = lam(R::XR0 + 6 * x);
+                        return;
+                    }
+                    else if constexpr (Tp::xframe_kind[x] != JM_XKIND_FRAME)
+                    {
+                        // sphere_constraint.cc:103-139 / wheel_constraint.cc:96-152: drift at the contact point + Baumgarte on
+                        // the height error along the ground normal and on the contact-point velocity
+                        const T radius = P[L::XPAR + 8 * x];
+                        const V3<T> nrm = ld_v3<T>(P, L::XPAR + 8 * x + 1);
+                        const V3<T> rd = xframe_rd<T, Tp, x>(P, w);
+                        T dpos = dot(pos - pref, nrm);
+                        V3<T> extra = zero3<T>();
+                        if constexpr (Tp::xframe_kind[x] == JM_XKIND_WHEEL)
+                        {
+                            const V3<T> axis = Rj * (fr.R * ld_v3<T>(P, L::XPAR + 8 * x + 4));
+                            const V3<T> xx = cross(cross(axis, nrm), axis);
+                            const T xinv = rsqrt_(dot(xx, xx));
+                            const V3<T> y = xinv * xx;
+                            dpos = dot((pos - pref) + radius * (nrm - y), nrm);
+                            const V3<T> daxis = cross(vang, axis);
+                            const V3<T> z = xinv * (cross(cross(daxis, nrm), axis) + cross(cross(axis, nrm), daxis));
+                            const V3<T> dy = z - dot(y, z) * y;
+                            extra = cross(radius * dy, vang);
+                        }
+                        alin = alin + cross(rd, aang) + extra + (C.kp_lock * dpos) * nrm + C.kd_lock * (vlin + cross(rd, vang));
+                    }
+                    else
+                    {
+                    const M3<T> Rf = Rj * fr.R;
                     const M3<T> Rref = {dat(R::XREF + 12 * x + 3), dat(R::XREF + 12 * x + 4), dat(R::XREF + 12 * x + 5),
                                         dat(R::XREF + 12 * x + 6), dat(R::XREF + 12 * x + 7), dat(R::XREF + 12 * x + 8),
                                         dat(R::XREF + 12 * x + 9), dat(R::XREF + 12 * x + 10), dat(R::XREF + 12 * x + 11)};
                     const V3<T> dr = log3(Rf * transpose(Rref));
                     alin = alin + C.kp_lock * (pos - pref) + C.kd_lock * vlin;
                     aang = aang + C.kp_lock * dr + C.kd_lock * vang;
+                    }
                     const T six[6] = {alin.x, alin.y, alin.z, aang.x, aang.y, aang.z};
                     static_for<0, 6>([&](auto dc) {
                         constexpr int d = decltype(dc)::value;
@@ -1179,9 +1316,30 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                     });
                     const V3<T> pc = ld_v3<T>(P, L::XFRAME + 12 * x + 9);
                     Sp<T> fl;
-                    fl.l = tmul(w.oMi[j].R, V3<T>{l6[0], l6[1], l6[2]});
-                    fl.a = tmul(w.oMi[j].R, V3<T>{l6[3], l6[4], l6[5]}) + cross(pc, fl.l);
+                    if constexpr (Tp::xframe_kind[x] == JM_XKIND_DISTANCE)
+                    {
+                        constexpr int j2 = Tp::xframe_joint2[x];
+                        V3<T> p1, p2;
+                        xframe_points<T, Tp, x>(P, w, p1, p2);
+                        const V3<T> fW = (l6[0] * rsqrt_(dot(p1 - p2, p1 - p2))) * (p1 - p2);
+                        fl.l = tmul(w.oMi[j].R, fW);
+                        fl.a = cross(pc, fl.l);
+                        if constexpr (j2 > 0)
+                        {
+                            const V3<T> f2 = tmul(w.oMi[j2].R, fW);
+                            fux[j2] = fux[j2] - Sp<T>{f2, cross(ld_v3<T>(P, L::XPAR + 8 * x + 1), f2)};
+                        }
+                        if constexpr (j > 0) fux[j] = fux[j] + fl;
+                    }
+                    else
+                    {
+                    const V3<T> fW = {l6[0], l6[1], l6[2]};
+                    V3<T> tW = {l6[3], l6[4], l6[5]};
+                    if constexpr (Tp::xframe_kind[x] != JM_XKIND_FRAME) tW = cross(fW, xframe_rd<T, Tp, x>(P, w));   // sum_d lambda_d (e_d x rd)
+                    fl.l = tmul(w.oMi[j].R, fW);
+                    fl.a = tmul(w.oMi[j].R, tW) + cross(pc, fl.l);
                     fux[j] = fux[j] + fl;
+                    }
                 }
             });
         }

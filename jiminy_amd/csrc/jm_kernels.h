@@ -74,7 +74,8 @@ template<class Tp> struct Layout
     static constexpr int FREL = IMU + Tp::NIMU * 12;                   // NFORCE * NC * 12
     static constexpr int ENC = FREL + Tp::NFORCE * Tp::NC * 12;        // NENC
     static constexpr int XFRAME = ENC + Tp::NENC;                      // NX * 12: user constraint frames (R9 p3)
-    static constexpr int OPT = XFRAME + Tp::NX * 12;  // gravity6 k c mu eps vt
+    static constexpr int XPAR = XFRAME + Tp::NX * 12;                  // NX * 8: radius, normal 3, axis 3 | -, second frame position 3
+    static constexpr int OPT = XPAR + Tp::NX * 8;  // gravity6 k c mu eps vt
     static constexpr int TOTAL = OPT + 11;
 };
 

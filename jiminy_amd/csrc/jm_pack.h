@@ -40,7 +40,8 @@ template<class Tp> inline bool check_topology(const jm_model_desc & d, std::stri
         if (d.effort_motor[s] != Tp::eff_motor[s]) return fail("effort sensors");
     if (d.n_constraint_frames != Tp::NX) return fail("user constraint frame count");
     for (int x = 0; x < Tp::NX; ++x)
-        if (d.cframe_joint[x] != Tp::xframe_joint[x] || d.cframe_mask[x] != Tp::xframe_mask[x]) return fail("user constraint frames");
+        if (d.cframe_joint[x] != Tp::xframe_joint[x] || d.cframe_mask[x] != Tp::xframe_mask[x] || d.cframe_kind[x] != Tp::xframe_kind[x] ||
+            d.cframe_joint2[x] != Tp::xframe_joint2[x]) return fail("user constraint frames");
     if (d.n_constraint_joints != Tp::NXJ) return fail("user constraint joint count");
     for (int k = 0; k < Tp::NXJ; ++k)
         if (d.cjoint_joint[k] != Tp::xjoint[k]) return fail("user constraint joints");
@@ -90,7 +91,11 @@ template<class Tp> inline std::vector<double> pack_model(const jm_model_desc & d
             put_frame(L::FREL + 12 * (s * Tp::NC + c), R, p);
         }
     for (int s = 0; s < Tp::NENC; ++s) P[L::ENC + s] = d.encoder_reduction[s];
-    for (int x = 0; x < Tp::NX; ++x) put_frame(L::XFRAME + 12 * x, d.cframe_R + 9 * x, d.cframe_p + 3 * x);
+    for (int x = 0; x < Tp::NX; ++x)
+    {
+        put_frame(L::XFRAME + 12 * x, d.cframe_R + 9 * x, d.cframe_p + 3 * x);
+        for (int k = 0; k < 8; ++k) P[L::XPAR + 8 * x + k] = d.cframe_params[8 * x + k];
+    }
     return P;
 }
 // total size of the parameter block, including the limb table of the limb-parallel kernel

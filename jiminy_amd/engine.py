@@ -229,6 +229,40 @@ class FrameConstraint:
 
 
 @dataclass
+class SphereConstraint:
+    """≙ `jiminy.SphereConstraint(frame_name, sphere_radius, ground_normal)` (core/src/constraints/sphere_constraint.cc):
+    declared with `model.add_sphere_constraint`; reference = the frame's pose at `start` (its height along the normal is
+    what the Baumgarte term holds)."""
+    frame_name: str
+    radius: float
+    ground_normal: Tuple[float, float, float] = (0.0, 0.0, 1.0)
+    baumgarte_freq: Optional[float] = 0.0
+    kind = "sphere"
+
+
+@dataclass
+class WheelConstraint:
+    """≙ `jiminy.WheelConstraint(frame_name, wheel_radius, ground_normal, wheel_axis)` (core/src/constraints/wheel_constraint.cc);
+    declared with `model.add_wheel_constraint`."""
+    frame_name: str
+    radius: float
+    ground_normal: Tuple[float, float, float] = (0.0, 0.0, 1.0)
+    wheel_axis: Tuple[float, float, float] = (0.0, 0.0, 1.0)
+    baumgarte_freq: Optional[float] = 0.0
+    kind = "wheel"
+
+
+@dataclass
+class DistanceConstraint:
+    """≙ `jiminy.DistanceConstraint(first_frame_name, second_frame_name)` (core/src/constraints/distance_constraint.cc);
+    declared with `model.add_distance_constraint`; reference = the distance at `start` (`reference_distance`)."""
+    first_frame_name: str
+    second_frame_name: str
+    baumgarte_freq: Optional[float] = 0.0
+    kind = "distance"
+
+
+@dataclass
 class StepperState:
     """≙ `struct StepperState` (reference engine.h:216-250); time is shared by all lanes."""
     iter: int
@@ -864,11 +898,14 @@ class BatchedEngine:
           kernels): rows of their own behind the contact rows, unbounded; when nothing but unbounded constraints is enabled
           the multipliers come from the exact solve of the reference's `isUnbounded` branch (constraint_solvers.cc:362-412).
 
-        `DistanceConstraint`, `SphereConstraint`, `WheelConstraint` are not built."""
+        * `SphereConstraint`, `WheelConstraint`, `DistanceConstraint` (round 5): declared with `model.add_sphere_constraint` /
+          `add_wheel_constraint` / `add_distance_constraint`; three rows at the contact point of the rolling body, one row along
+          the line between two frames (either of which may be fixed to the world)."""
         if self._running:
             raise BadControlFlow("Please stop the simulation before adding constraints.")   # model.cc:866-872
-        if not isinstance(constraint, (JointConstraint, FrameConstraint)):
-            raise NotImplementedError("only JointConstraint and FrameConstraint can be registered")
+        if not isinstance(constraint, (JointConstraint, FrameConstraint, SphereConstraint, WheelConstraint, DistanceConstraint)):
+            raise NotImplementedError("JointConstraint, FrameConstraint, SphereConstraint, WheelConstraint and DistanceConstraint "
+                                      "can be registered")
         if name in self._user_constraints:
             raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
         freq = constraint.baumgarte_freq
@@ -885,15 +922,29 @@ class BatchedEngine:
             self._apply_options()
         mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if lane_mask is None else \
             lane_mask.to(self.device).bool()
-        if isinstance(constraint, FrameConstraint):
-            declared = [(x["frame"], int(x["mask"])) for x in self.model.constraint_frames]
-            if (constraint.frame_name, constraint.mask) not in declared:
-                raise LookupError(f"no constraint frame ('{constraint.frame_name}', mask {constraint.mask:06b}) declared on the model: "
-                                  "call jiminy_amd.model.add_frame_constraint(model, name, frame_name, mask_dofs) before "
-                                  "creating the engine (the kernels are specialised on the constraint frames)")
-            x = declared.index((constraint.frame_name, constraint.mask))
+        if not isinstance(constraint, JointConstraint):
+            def close(a, b):
+                return a is not None and np.allclose(np.asarray(a, dtype=float) / np.linalg.norm(a), np.asarray(b, dtype=float))
+            declared = []
+            for xd in self.model.constraint_frames:
+                kd = xd.get("kind", "frame")
+                declared.append(
+                    (kd == "frame" and isinstance(constraint, FrameConstraint) and xd["frame"] == constraint.frame_name
+                     and int(xd["mask"]) == constraint.mask)
+                    or (kd == "sphere" and isinstance(constraint, SphereConstraint) and xd["frame"] == constraint.frame_name
+                        and abs(xd["radius"] - constraint.radius) < 1e-12 and close(constraint.ground_normal, xd["normal"]))
+                    or (kd == "wheel" and isinstance(constraint, WheelConstraint) and xd["frame"] == constraint.frame_name
+                        and abs(xd["radius"] - constraint.radius) < 1e-12 and close(constraint.ground_normal, xd["normal"])
+                        and close(constraint.wheel_axis, xd["axis"]))
+                    or (kd == "distance" and isinstance(constraint, DistanceConstraint) and xd["frame"] == constraint.first_frame_name
+                        and xd["frame2"] == constraint.second_frame_name))
+            if True not in declared:
+                raise LookupError(f"{constraint!r} is not declared on the model: call jiminy_amd.model.add_frame_constraint / "
+                                  "add_sphere_constraint / add_wheel_constraint / add_distance_constraint with the same arguments "
+                                  "before creating the engine (the kernels are specialised on the constraint frames)")
+            x = declared.index(True)
             if any(k == "frame" and r == x for k, r, _, _ in self._user_constraints.values()):
-                raise ValueError(f"frame '{constraint.frame_name}' already carries this user constraint")
+                raise ValueError(f"{constraint!r} is already registered")
             rows = _abi.constraint_rows(self.model)
             self._fields["con_flags"][rows["n_bounds"] + rows["n_contacts"] + x] = torch.where(mask, 1, 0).to(torch.int32)
             self._user_constraints[name] = ("frame", x, constraint, freq)
@@ -951,6 +1002,13 @@ class BatchedEngine:
         (frame_constraint.cc:52-60): `reference` = (translation `(3,)` or `(3, B)`, rotation `(3, 3)` or `(3, 3, B)`).
         `start` / `reset_lanes` take the reference from the state again (`reset` of the constraint): call it after them."""
         kind, row, _, _ = self._user_constraints[name]
+        if kind == "frame" and isinstance(self._user_constraints[name][2], DistanceConstraint):
+            # ≙ `DistanceConstraint.reference_distance = ...` (distance_constraint.cc:44-52): one length per lane or one for all
+            d = torch.as_tensor(reference, dtype=self.dtype, device=self.device).reshape(-1)
+            if d.numel() not in (1, self.batch_size) or bool((d < 0).any()):
+                raise ValueError("one non-negative reference distance per lane (or one for all)")
+            self._fields["con_data"][_abi.constraint_rows(self.model)["user_ref"] + 12 * row] = d.expand(self.batch_size)
+            return
         if kind == "frame":
             p, R = reference
             p = torch.as_tensor(p, dtype=self.dtype, device=self.device)
@@ -979,6 +1037,8 @@ class BatchedEngine:
         if kind == "frame":
             r0 = _abi.constraint_rows(self.model)["user_ref"] + 12 * row
             d = self._fields["con_data"]
+            if isinstance(self._user_constraints[name][2], DistanceConstraint):
+                return d[r0]
             return d[r0:r0 + 3], d[r0 + 3:r0 + 12].view(3, 3, self.batch_size)
         if kind == "jrow":
             row = _abi.constraint_rows(self.model)["user_joint_ref"] + row

@@ -408,7 +408,10 @@ class CompiledModel:
             parts += ["AX", ",".join(str(int(x)) for x in sa)]
         # user constraint frames (parent joint : mask), appended only when there are any: other topologies keep their hash
         if self.constraint_frames:
-            parts += ["X", ",".join(f"{self.frames[x['frame']].parent_joint}:{int(x['mask'])}" for x in self.constraint_frames)]
+            parts += ["X", ",".join(f"{self.frames[x['frame']].parent_joint}:{int(x['mask'])}"
+                                    + (f":{x['kind']}" if x.get("kind", "frame") != "frame" else "")
+                                    + (f":{self.frames[x['frame2']].parent_joint}" if x.get("frame2") else "")
+                                    for x in self.constraint_frames)]
         if self.constraint_joints:
             parts += ["XJ", ",".join(str(int(x["joint"])) for x in self.constraint_joints)]
         return "|".join(parts)
@@ -645,6 +648,46 @@ def add_frame_constraint(model: CompiledModel, name: str, frame_name: str,
         raise ValueError(f"constraint '{name}' already declared")     # model.cc: "A constraint with name ... already exists"
     model.constraint_frames.append({"name": name, "frame": frame_name,
                                     "mask": int(sum(1 << d for d in range(6) if mask_dofs[d]))})
+
+
+def add_sphere_constraint(model: CompiledModel, name: str, frame_name: str, radius: float,
+                          ground_normal: Sequence[float] = (0.0, 0.0, 1.0)) -> None:
+    """≙ `jiminy.SphereConstraint(frame_name, radius, ground_normal)` (core/src/constraints/sphere_constraint.cc): a sphere
+    of that radius centred on the frame rolls on the plane through its lowest point without slipping or lifting off -- the
+    three velocity components of the contact point (frame origin - radius * normal) are held at zero."""
+    model.frame(frame_name)
+    if any(x["name"] == name for x in model.constraint_frames + model.constraint_joints):
+        raise ValueError(f"constraint '{name}' already declared")
+    n = np.asarray(ground_normal, dtype=np.float64)
+    model.constraint_frames.append({"name": name, "frame": frame_name, "mask": 7, "kind": "sphere", "radius": float(radius),
+                                    "normal": [float(v) for v in n / np.linalg.norm(n)]})
+
+
+def add_wheel_constraint(model: CompiledModel, name: str, frame_name: str, radius: float,
+                         ground_normal: Sequence[float] = (0.0, 0.0, 1.0), wheel_axis: Sequence[float] = (0.0, 0.0, 1.0)) -> None:
+    """≙ `jiminy.WheelConstraint(frame_name, radius, ground_normal, wheel_axis)` (core/src/constraints/wheel_constraint.cc): a
+    thin wheel whose axis is `wheel_axis` in the frame rolls on the plane without slipping; the contact point follows the
+    wheel's tilt (frame origin - radius * y with y the direction from the contact point to the centre)."""
+    model.frame(frame_name)
+    if any(x["name"] == name for x in model.constraint_frames + model.constraint_joints):
+        raise ValueError(f"constraint '{name}' already declared")
+    n = np.asarray(ground_normal, dtype=np.float64)
+    a = np.asarray(wheel_axis, dtype=np.float64)
+    model.constraint_frames.append({"name": name, "frame": frame_name, "mask": 7, "kind": "wheel", "radius": float(radius),
+                                    "normal": [float(v) for v in n / np.linalg.norm(n)],
+                                    "axis": [float(v) for v in a / np.linalg.norm(a)]})
+
+
+def add_distance_constraint(model: CompiledModel, name: str, first_frame_name: str, second_frame_name: str) -> None:
+    """≙ `jiminy.DistanceConstraint(first_frame_name, second_frame_name)` (core/src/constraints/distance_constraint.cc): the
+    distance between the origins of the two frames is held at its value at `start` (Cassie's and Digit's push-rods,
+    gym_jiminy/envs/cassie.py:135-158).  Either frame may be fixed to the world (parent joint 0)."""
+    model.frame(first_frame_name)
+    model.frame(second_frame_name)
+    if any(x["name"] == name for x in model.constraint_frames + model.constraint_joints):
+        raise ValueError(f"constraint '{name}' already declared")
+    model.constraint_frames.append({"name": name, "frame": first_frame_name, "frame2": second_frame_name, "mask": 1,
+                                    "kind": "distance"})
 
 
 def add_joint_constraint(model: CompiledModel, name: str, joint_name: str) -> None:

@@ -408,6 +408,9 @@ struct Model
     // mask = dof d of (x, y, z, rot x, rot y, rot z) is fixed (frame_constraint.cc:11-35)
     std::vector<FrameP> cframes;
     std::vector<int> cframe_mask;
+    // kind (JM_XKIND_*), second parent joint and 8 parameters of every constraint frame (jm_model_desc::cframe_kind ...)
+    std::vector<int> cframe_kind, cframe_joint2;
+    std::vector<double> cframe_params;
     // 1-dof joints a user `JointConstraint(joint)` may hold on a row OF ITS OWN (jm_model_desc::cjoint_joint), next to the
     // joint's bound constraint like in the reference (model.cc:884-905)
     std::vector<int> cjoints;
@@ -975,6 +978,15 @@ void reset_constraints(Engine & e)
     {
         if (!e.xcon[i].enabled) continue;    // (not registered for this robot: no such constraint object)
         e.xcon[i].ref = e.oMi[e.mdl.cframes[i].joint] * e.mdl.cframes[i].M;
+        if (e.mdl.cframe_kind[i] == JM_XKIND_DISTANCE)
+        {
+            // DistanceConstraint::reset: distanceRef_ = |p_1 - p_2| (distance_constraint.cc:73-77), kept in the first slot
+            const double * pr = &e.mdl.cframe_params[8 * i];
+            const SE3 & M2 = e.oMi[e.mdl.cframe_joint2[i]];
+            const V3 p2 = M2.p + M2.R * V3{pr[1], pr[2], pr[3]};
+            e.xcon[i].ref.p = {norm(e.xcon[i].ref.p - p2), 0.0, 0.0};
+            e.xcon[i].ref.R = M3::identity();
+        }
         for (double & l : e.xcon[i].lambda) l = 0.0;
     }
     for (auto & jc : e.jcon)
@@ -1348,6 +1360,85 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
         const V3 vlin = oMf.R * vl.lin, vang = oMf.R * vl.ang;
         V3 dlin = oMf.R * al.lin, dang = oMf.R * al.ang;
         dlin = dlin + cross(vang, vlin);
+        const int kind = m.cframe_kind[i];
+        const double * par = &m.cframe_params[8 * i];
+        if (kind == JM_XKIND_DISTANCE)
+        {
+            // DistanceConstraint::computeJacobianAndDrift (distance_constraint.cc:80-150): one row along the direction
+            // between the two frame origins
+            const int j2 = m.cframe_joint2[i];
+            const V3 pl2 = {par[1], par[2], par[3]};
+            const V3 p2 = e.oMi[j2].p + e.oMi[j2].R * pl2;
+            const V3 delta = oMf.p - p2;
+            const double dn = norm(delta);
+            const V3 dir = (1.0 / dn) * delta;
+            // world-aligned velocity / classical drift acceleration of the second frame origin
+            const Motion v2j = e.dv[j2], a2j = j2 > 0 ? adrift[j2] : Motion();
+            const V3 v2lin = e.oMi[j2].R * (v2j.lin + cross(v2j.ang, pl2)), v2ang = e.oMi[j2].R * v2j.ang;
+            V3 a2lin = e.oMi[j2].R * (a2j.lin + cross(a2j.ang, pl2));
+            a2lin = a2lin + cross(v2ang, v2lin);
+            const V3 dvel = vlin - v2lin;
+            for (int a = 0; a < nv; ++a)
+            {
+                double jv = 0.0;
+                if (supports(fr.joint, a)) jv += dot(dir, Jw[a].lin - cross(oMf.p, Jw[a].ang));
+                if (j2 > 0 && supports(j2, a)) jv -= dot(dir, Jw[a].lin - cross(p2, Jw[a].ang));
+                J(r, a) = jv;
+            }
+            const double dvp = dot(dvel, dir);
+            gamma[r] = dot(dir, dlin - a2lin) + (dot(dvel, dvel) - dvp * dvp) / dn + kp_u * (dn - e.xcon[i].ref.p.x) + kd_u * dvp;
+            lambda[r] = e.xcon[i].lambda[0];
+            ++r;
+            continue;
+        }
+        V3 rd = {0.0, 0.0, 0.0};      // radius * (direction from the contact point to the frame origin): skewRadius_ = [rd]x
+        if (kind == JM_XKIND_SPHERE || kind == JM_XKIND_WHEEL)
+        {
+            // SphereConstraint (sphere_constraint.cc:77-140) / WheelConstraint (wheel_constraint.cc:85-153): the three linear
+            // rows taken at the contact point, J = J_lin + [rd]x J_ang
+            const double radius = par[0];
+            const V3 nrm = {par[1], par[2], par[3]};
+            const V3 rel = oMf.p - e.xcon[i].ref.p;
+            double deltaPosition;
+            V3 extra = {0.0, 0.0, 0.0};
+            if (kind == JM_XKIND_SPHERE)
+            {
+                rd = radius * nrm;
+                deltaPosition = dot(rel, nrm);
+            }
+            else
+            {
+                const V3 axis = oMf.R * V3{par[4], par[5], par[6]};
+                const V3 x = cross(cross(axis, nrm), axis);
+                const double xn = norm(x);
+                const V3 y = (1.0 / xn) * x;
+                rd = radius * y;
+                deltaPosition = dot(rel + radius * (nrm - y), nrm);
+                const V3 daxis = cross(vang, axis);
+                const V3 dx = cross(cross(daxis, nrm), axis) + cross(cross(axis, nrm), daxis);
+                const V3 z = (1.0 / xn) * dx;
+                const V3 dy = z - dot(y, z) * y;
+                extra = cross(radius * dy, vang);      // dskewRadius_ * omega
+            }
+            const V3 velocity = vlin + cross(rd, vang);
+            // (dlin / dang still hold the classical drift acceleration here: the Baumgarte terms of this kind differ)
+            const V3 drift = dlin + cross(rd, dang) + extra + (kp_u * deltaPosition) * nrm + kd_u * velocity;
+            const double drift3[3] = {drift.x, drift.y, drift.z};
+            for (int d = 0; d < 3; ++d)
+            {
+                for (int a = 0; a < nv; ++a)
+                {
+                    if (!supports(fr.joint, a)) continue;
+                    const V3 lin = Jw[a].lin - cross(oMf.p, Jw[a].ang) + cross(rd, Jw[a].ang);
+                    const double row3[3] = {lin.x, lin.y, lin.z};
+                    J(r, a) = row3[d];
+                }
+                gamma[r] = drift3[d];
+                lambda[r] = e.xcon[i].lambda[d];
+                ++r;
+            }
+            continue;
+        }
         const V3 dp = oMf.p - e.xcon[i].ref.p;
         const V3 dr = log3(oMf.R * transpose(e.xcon[i].ref.R));
         dlin = dlin + kp_u * dp + kd_u * vlin;
@@ -2118,6 +2209,9 @@ Engine * make_engine(const jm_model_desc * d, const jm_options * o)
     m.forces = frames(d->nforce, d->force_joint, d->force_R, d->force_p);
     m.cframes = frames(d->n_constraint_frames, d->cframe_joint, d->cframe_R, d->cframe_p);
     m.cframe_mask.assign(d->cframe_mask, d->cframe_mask + d->n_constraint_frames);
+    m.cframe_kind.assign(d->cframe_kind, d->cframe_kind + d->n_constraint_frames);
+    m.cframe_joint2.assign(d->cframe_joint2, d->cframe_joint2 + d->n_constraint_frames);
+    m.cframe_params.assign(d->cframe_params, d->cframe_params + 8 * d->n_constraint_frames);
     m.cjoints.assign(d->cjoint_joint, d->cjoint_joint + d->n_constraint_joints);
     m.contact_sensors.assign(d->contact_sensor_contact, d->contact_sensor_contact + d->ncontact_sensors);
     m.effort_sensors.assign(d->effort_motor, d->effort_motor + d->neffort);

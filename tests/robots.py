@@ -135,6 +135,42 @@ def tree_arm_own_locks(has_freeflyer: bool) -> CompiledModel:
     return m
 
 
+def rolling_ball() -> CompiledModel:
+    """Free body (2 kg, inertia 0.5 kg.m^2) that a `SphereConstraint` of radius 0.5 m makes roll on the plane z = z_start - r."""
+    from jiminy_amd.model import add_sphere_constraint
+    m = build_model_from_urdf(os.path.join(DATA, "point_mass.urdf"), has_freeflyer=True, name="rolling_ball")
+    add_sphere_constraint(m, "roll", "body", 0.5)
+    return m
+
+
+def rolling_wheel() -> CompiledModel:
+    """The same body as a thin wheel about its y axis (`WheelConstraint`, radius 0.5 m)."""
+    from jiminy_amd.model import add_wheel_constraint
+    m = build_model_from_urdf(os.path.join(DATA, "point_mass.urdf"), has_freeflyer=True, name="rolling_wheel")
+    add_wheel_constraint(m, "roll", "body", 0.5, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
+    return m
+
+
+def tethered_mass() -> CompiledModel:
+    """Free body held at a fixed distance from a world-fixed anchor (`DistanceConstraint` with one frame on the universe)."""
+    import numpy as np
+
+    from jiminy_amd.model import Frame, add_distance_constraint
+    m = build_model_from_urdf(os.path.join(DATA, "point_mass.urdf"), has_freeflyer=True, name="tethered_mass")
+    m.frames["anchor"] = Frame("anchor", 0, np.eye(3), np.array([0.0, 0.0, 1.0]), "op")
+    add_distance_constraint(m, "tether", "body", "anchor")
+    return m
+
+
+def two_masses_rod() -> CompiledModel:
+    """The two sliding masses joined by a rigid rod (`DistanceConstraint` between two moving frames)."""
+    from jiminy_amd.model import add_distance_constraint
+    m = two_masses()
+    m.name = "two_masses_rod"
+    add_distance_constraint(m, "rod", "mass_b", "mass_a")
+    return m
+
+
 def frame_constraint_models() -> List[CompiledModel]:
     return [two_masses_fixed_second(), sphere_fixed_frame(), pendulum_ff_fixed_world(), tree_arm_own_locks(False),
-            tree_arm_own_locks(True)]
+            tree_arm_own_locks(True), rolling_ball(), rolling_wheel(), tethered_mass(), two_masses_rod()]
