@@ -105,3 +105,57 @@ def random_tile_ground(size: Tuple[float, float], height_max: float, interp_delt
         return torch.where(ex & ey, h_xy, torch.where(ey, h_y, h_x))
 
     return heightmap
+
+
+def periodic_stairs(step_width: float, step_height: float, step_number: int, orientation: float
+                    ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `periodicStairs(stepWidth, stepHeight, stepNumber, orientation)` (core/src/utilities/geometry.cc:797-868):
+    alternating ascending / descending staircases of `step_number` steps along the direction `orientation`, the vertical
+    edge of every step replaced by a ramp over the last 1 % of the step (`interpDelta = 0.01`).  `heightmap(x, y) -> height`
+    on float64 tensors of any shape and device."""
+    interp_delta = 0.01
+    ax, ay = math.cos(float(orientation)), math.sin(float(orientation))
+    w, hgt, n = float(step_width), float(step_height), int(step_number)
+    eps32 = float(torch.finfo(torch.float32).eps)
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        y = torch.as_tensor(y, dtype=torch.float64, device=x.device)
+        pos = ax * x + ay * y
+        mod = torch.fmod(pos.abs(), w * n * 2)
+        idx = torch.floor(mod / w).to(torch.int64)                       # static_cast<uint32_t>(modPos / stepWidth)
+        down = idx >= n
+        idx = torch.where(down, 2 * n - idx, idx)
+        sign = torch.where(down, -1.0, 1.0).to(torch.float64)
+        height = idx.to(torch.float64) * hgt
+        rel = torch.fmod(mod + eps32, w) / w
+        slope = sign * hgt / interp_delta
+        return torch.where((1.0 - rel) < interp_delta, height + slope * (rel - (1.0 - interp_delta)), height)
+    return heightmap
+
+
+def sum_heightmaps(heightmaps: Sequence[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]]
+                   ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `sumHeightmaps` (geometry.cc:694-736): the heights add up (the normals of the reference are re-derived from the
+    sampled height map by `BatchedEngine.set_ground_profile`, like for every ground here)."""
+    if not heightmaps:
+        raise ValueError("At least one heightmap must be specified.")
+    if len(heightmaps) == 1:
+        return heightmaps[0]
+    return lambda x, y: sum(h(x, y) for h in heightmaps[1:]) + heightmaps[0](x, y)
+
+
+def merge_heightmaps(heightmaps: Sequence[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]]
+                     ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `mergeHeightmaps` (geometry.cc:738-795): the highest of the grounds at every point."""
+    if not heightmaps:
+        raise ValueError("At least one heightmap must be specified.")
+    if len(heightmaps) == 1:
+        return heightmaps[0]
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        out = heightmaps[0](x, y)
+        for h in heightmaps[1:]:
+            out = torch.maximum(out, h(x, y))
+        return out
+    return heightmap

@@ -92,3 +92,25 @@ class PeriodicGaussianProcess:
         a = self.grads[il] * self.dt - dy
         b = -self.grads[ir] * self.dt + dy
         return ((1.0 - ratio) * (1.0 - 3.0 * ratio) * a + ratio * (2.0 - 3.0 * ratio) * b + dy) / self.dt
+
+
+class PeriodicFourierProcess(PeriodicGaussianProcess):
+    """random.h:389-409 / random.cc:462-485, scalar, one realisation; evaluation inherited (PeriodicTabularProcess)."""
+
+    def __init__(self, wavelength, period):
+        self.wavelength, self.period = wavelength, period
+        self.num_times = int(math.ceil(period / (0.1 * wavelength)))
+        self.dt = period / float(self.num_times)
+        self.num_harmonics = int(math.ceil(period / wavelength))
+        n, H = self.num_times, self.num_harmonics
+        self.cos_mat = np.array([[math.cos(2 * math.pi / n * i * (j + 1)) for j in range(H)] for i in range(n)])
+        self.sin_mat = np.array([[math.sin(2 * math.pi / n * i * (j + 1)) for j in range(H)] for i in range(n)])
+        self.values = np.zeros(n)
+        self.grads = np.zeros(n)
+
+    def reset(self, normal_vec1, normal_vec2):
+        H = self.num_harmonics
+        scale = math.sqrt(2.0) / math.sqrt(2 * H + 1)
+        self.values = scale * self.sin_mat @ normal_vec1 + scale * self.cos_mat @ normal_vec2
+        diff = 2 * math.pi / self.period * np.linspace(1.0, float(H), H)
+        self.grads = scale * self.cos_mat @ (normal_vec1 * diff) - scale * self.sin_mat @ (normal_vec2 * diff)

@@ -97,3 +97,33 @@ def tiles(size, height_max, interp_delta, sparsity, orientation, seed):
             return h0 + (hp - h0) * ((1.0 + (rel[1] - 1.0) / thr[1]) / 2.0)
         return height_max * uniform_sparse(struct.pack("<2i", *idx), sparsity, seed)
     return heightmap
+
+
+def periodic_stairs(step_width, step_height, step_number, orientation):
+    """geometry.cc:797-868, statement by statement (height only), one point at a time."""
+    interp_delta = 0.01
+    axis = (math.cos(orientation), math.sin(orientation))
+
+    def heightmap(x, y):
+        pos_rel = axis[0] * x + axis[1] * y
+        mod_pos = math.fmod(abs(pos_rel), step_width * step_number * 2)
+        stair_index = int(mod_pos / step_width)
+        sign = 1
+        if stair_index >= step_number:
+            stair_index = 2 * step_number - stair_index
+            sign = -1
+        height = stair_index * step_height
+        pos_rel_on_step = math.fmod(mod_pos + 1.1920929e-07, step_width) / step_width
+        if 1.0 - pos_rel_on_step < interp_delta:
+            slope = sign * step_height / interp_delta
+            height += slope * (pos_rel_on_step - (1.0 - interp_delta))
+        return height
+    return heightmap
+
+
+def sum_heightmaps(heightmaps):
+    return lambda x, y: sum(h(x, y) for h in heightmaps)
+
+
+def merge_heightmaps(heightmaps):
+    return lambda x, y: max(h(x, y) for h in heightmaps)

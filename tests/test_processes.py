@@ -69,3 +69,39 @@ def test_toeplitz_factor_reproduces_the_covariance():
     assert np.allclose(L @ L.T, K + 1e-9 * np.eye(n), atol=1e-7)
     with pytest.raises(ValueError):
         PeriodicGaussianProcess(0.2, -1.0, 2)
+
+
+@pytest.mark.parametrize("wavelength,period", [(0.2, 1.0), (0.35, 2.0)])
+def test_fourier_process_matches_the_scalar_restatement_and_its_series(wavelength, period):
+    """`PeriodicFourierProcess` (random.cc:462-485): batched against scalar, and at the knots the tabulated values /
+    derivatives ARE the truncated Fourier series and its time derivative."""
+    import math
+
+    from jiminy_amd.processes import PeriodicFourierProcess
+    B = 4
+    ref = process_numpy.PeriodicFourierProcess(wavelength, period)
+    proc = PeriodicFourierProcess(wavelength, period, B)
+    H, n = ref.num_harmonics, ref.num_times
+    assert proc.num_harmonics == H == math.ceil(period / wavelength) and proc.num_times == n
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((2 * H, B)).astype(np.float32)
+    proc.reset(normal=torch.from_numpy(z))
+    scale = math.sqrt(2.0 / (2 * H + 1))
+    for lane in range(B):
+        z1, z2 = z[:H, lane].astype(np.float64), z[H:, lane].astype(np.float64)
+        ref.reset(z1, z2)
+        assert np.allclose(proc.values[:, lane].numpy(), ref.values, rtol=0, atol=1e-12)
+        assert np.allclose(proc.grads[:, lane].numpy(), ref.grads, rtol=0, atol=1e-10)
+        tk = np.arange(n) * ref.dt
+        k = np.arange(1, H + 1)[None, :]
+        series = scale * (np.sin(2 * np.pi * k * tk[:, None] / period) @ z1 + np.cos(2 * np.pi * k * tk[:, None] / period) @ z2)
+        dseries = scale * ((np.cos(2 * np.pi * k * tk[:, None] / period) * (2 * np.pi * k / period)) @ z1
+                           - (np.sin(2 * np.pi * k * tk[:, None] / period) * (2 * np.pi * k / period)) @ z2)
+        assert np.allclose(ref.values, series, atol=1e-12) and np.allclose(ref.grads, dseries, atol=1e-10)
+        for t in (-0.3, 0.0, 0.123, period, 1.7 * period):
+            assert abs(float(proc(float(t))[lane]) - ref(float(t))) < 1e-10
+            assert abs(float(proc.grad(float(t))[lane]) - ref.grad(float(t))) < 1e-8
+    # unit variance by construction: 2 H amplitudes of variance scale^2 / 2 each ... = 2 H / (2 H + 1)
+    big = PeriodicFourierProcess(wavelength, period, 8192)
+    big.reset(torch.Generator().manual_seed(1))
+    assert abs(float(big.values.var()) - 2 * H / (2 * H + 1)) < 0.05

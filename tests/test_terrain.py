@@ -70,3 +70,42 @@ def test_tiles_on_the_device_and_as_engine_ground(gpu_device):
     eng = BatchedEngine(load_builtin("anymal"), 8, dtype=torch.float64, device=gpu_device)
     eng.set_ground_profile(f, (-2.0, 2.0), (-2.0, 2.0), 0.05)
     assert eng._ground is not None and eng._ground.device.type == "cuda" and float(eng._ground.max()) <= 0.05 + 1e-12
+
+
+def test_periodic_stairs_sum_and_merge_match_the_scalar_restatement():
+    """`periodicStairs`, `sumHeightmaps`, `mergeHeightmaps` (geometry.cc:694-868): the tensor programs against the scalar
+    restatement on random points, and the staircase law itself -- N steps up, N steps down, period 2 N W, even in x, every
+    riser a ramp over the last 1 % of its step."""
+    import math
+
+    from jiminy_amd import terrain
+    from oracle import terrain_numpy as orc
+    rg = np.random.default_rng(4)
+    x, y = rg.uniform(-9, 9, 4000), rg.uniform(-9, 9, 4000)
+    for w, h, n, ori in ((0.4, 0.15, 3, 0.0), (0.25, 0.1, 5, 0.7), (1.0, 0.3, 1, -2.0)):
+        t = terrain.periodic_stairs(w, h, n, ori)
+        s = orc.periodic_stairs(w, h, n, ori)
+        got = t(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        want = np.array([s(a, b) for a, b in zip(x, y)])
+        assert np.abs(got - want).max() < 1e-12
+    w, h, n = 0.4, 0.15, 3
+    t = terrain.periodic_stairs(w, h, n, 0.0)
+    mid = torch.tensor([(i + 0.5) * w for i in range(2 * n)], dtype=torch.float64)       # middle of every tread of one period
+    assert np.allclose(t(mid, torch.zeros_like(mid)).numpy(), [0.0, h, 2 * h, 3 * h, 2 * h, h])
+    assert np.allclose(t(mid + 2 * n * w, torch.zeros_like(mid)).numpy(), t(mid, torch.zeros_like(mid)).numpy())     # periodic
+    assert np.allclose(t(-mid, torch.zeros_like(mid)).numpy(), t(mid, torch.zeros_like(mid)).numpy())                 # even
+    edge = torch.tensor([w * (1 - 0.005)], dtype=torch.float64)                          # half way up the first riser
+    assert float(t(edge, torch.zeros(1, dtype=torch.float64))) == pytest.approx(0.5 * h, rel=1e-3)   # (the float-epsilon shift of the reference moves it by 4e-6)
+    # sum / merge of a staircase and a tile ground
+    tiles_t = terrain.random_tile_ground((1.0, 1.5), 0.3, (0.05, 0.05), 1, 0.3, 7)
+    tiles_s = orc.tiles((1.0, 1.5), 0.3, (0.05, 0.05), 1, 0.3, 7)
+    s = orc.periodic_stairs(w, h, n, 0.0)
+    xs, ys = torch.from_numpy(x[:500]), torch.from_numpy(y[:500])
+    got_sum = terrain.sum_heightmaps([t, tiles_t])(xs, ys).numpy()
+    got_max = terrain.merge_heightmaps([t, tiles_t])(xs, ys).numpy()
+    want_sum = np.array([orc.sum_heightmaps([s, tiles_s])(a, b) for a, b in zip(x[:500], y[:500])])
+    want_max = np.array([orc.merge_heightmaps([s, tiles_s])(a, b) for a, b in zip(x[:500], y[:500])])
+    assert np.abs(got_sum - want_sum).max() < 1e-12 and np.abs(got_max - want_max).max() < 1e-12
+    assert terrain.sum_heightmaps([t]) is t and terrain.merge_heightmaps([t]) is t
+    with pytest.raises(ValueError):
+        terrain.sum_heightmaps([])
