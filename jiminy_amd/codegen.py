@@ -293,7 +293,14 @@ def qcon_split(model: CompiledModel) -> bool:
     if quad_structure(model) is None:
         return False
     nb = sum(1 for t in model.jtypes[1:] if 1 <= int(t) <= 8)
-    return min(nb + 4 * model.ncontacts, 96) > 32
+    return min(nb + 4 * model.ncontacts, 96) > qcon_split_min()
+
+
+def qcon_split_min() -> int:
+    """Solves of more rows than this step through pre | solve | post launches (`JM_QCON_SPLIT_MIN` of jm_qcon.h, 32).
+    JIMINY_AMD_QCON_SPLIT_MIN builds an experimental library with another threshold (use with JIMINY_AMD_LIB_TAG: round 5
+    measured ANYmal -- 28 rows -- in the split form)."""
+    return int(os.environ.get("JIMINY_AMD_QCON_SPLIT_MIN", "32"))
 
 
 def part_flags(model: CompiledModel) -> Dict[str, List[str]]:
@@ -318,7 +325,9 @@ def lib_path(model: CompiledModel, variant: Optional[int] = None) -> str:
 
 
 def header_path(model: CompiledModel) -> str:
-    return os.path.join(BUILD, f"topo_{model.topology_hash()}.h")
+    # (experimental builds that change what the header says keep a header of their own)
+    tag = os.environ.get("JIMINY_AMD_LIB_TAG", "") if qcon_split_min() != 32 else ""
+    return os.path.join(BUILD, f"topo_{model.topology_hash()}{('_' + tag) if tag else ''}.h")
 
 
 def write_header(model: CompiledModel) -> str:
@@ -395,6 +404,8 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"]
     common += list(BUILD_VARIANTS[v])
     common += extra_flags or []
+    if qcon_split_min() != 32:
+        common.append(f"-DJM_QCON_SPLIT_MIN={qcon_split_min()}")
     parts = [1, 2, 3, 4, 5, 6] if quad_structure(model) is not None else [1]
     if qcon_split(model):
         parts += [7, 8, 9, 10]

@@ -532,3 +532,60 @@ def test_gpu_sphere_wheel_distance_constraints_match_the_oracle(gpu_device, name
     check("runge_kutta_4", 1e-8)
     assert (ref["status"] == 0).all() and int(eng.status.abs().sum()) == 0
     assert np.abs(ref["con_data"][rows["user_lambda"]:rows["user_ref"]][:, held]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_frame_constraint_under_the_adaptive_stepper(gpu_device):
+    """The reference's default solver (`runge_kutta_dopri`, per-lane step sizes, per-stage launches over compacted lanes:
+    the constraint state travels with the lanes) with a user FrameConstraint pulling a free body to a moved reference pose:
+    against the oracle's restatement of the adaptive loop; lanes that follow the same accept / reject sequence agree to the
+    integration tolerance."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, FrameConstraint, plan_breakpoints
+    from oracle.oracle_py import OracleEngine, adaptive_state
+    model = robots.sphere_fixed_frame()
+    B, f, step_dt = 32, 2.0, 0.01
+    rows = _abi.constraint_rows(model)
+    rg = np.random.default_rng(21)
+    q = np.tile(np.array([0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0])[:, None], (1, B))
+    q[:3] += rg.normal(0, 0.2, (3, B))
+    v = rg.normal(0, 0.2, (6, B))
+    ref = alloc_soa(model, B)
+    alloc_constraint_state(model, ref, B)
+    ref["con_flags"][rows["n_bounds"] + rows["n_contacts"]:] = 1
+    ref["q"][:], ref["v"][:] = q, v
+    opts = dict(EXACT, tol_abs=1e-8, tol_rel=1e-7)
+    e = OracleEngine(model)
+    e.set_constraint_options(user_stabilization_freq=f, **opts)
+    e.bind_constraints(ref["con_flags"], ref["con_data"])
+    io = oracle_io(ref)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"constraints": {"regularization": 0.0}, "contacts": {"model": "constraint"},
+                     "stepper": {"odeSolver": "runge_kutta_dopri", "tolAbs": 1e-8, "tolRel": 1e-7, "controllerUpdatePeriod": step_dt,
+                                 "sensorsUpdatePeriod": step_dt}})
+    eng.add_constraint("MassBody", FrameConstraint("body", baumgarte_freq=f))
+    eng.start(torch.from_numpy(q), torch.from_numpy(v))
+    e.batch_run("start", io)
+    shift = rg.normal(0, 0.2, (3, B))
+    p_ref, R_ref = eng.constraint_reference("MassBody")
+    eng.set_constraint_reference("MassBody", (p_ref + torch.from_numpy(shift).to(gpu_device), R_ref.clone()))
+    ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3] += shift
+    ad = adaptive_state(B)
+    t, t_err = 0.0, 0.0
+    for _ in range(20):
+        intervals, t_end, t_err = plan_breakpoints(t, t_err, step_dt, eng.get_options())
+        for i, (t_next, cmd, sens) in enumerate(intervals):
+            e.batch_run_dopri(ref, ad, t_next, tol_rel=1e-7, tol_abs=1e-8, new_step=(i == 0), command_changed=True, update_sensors=sens)
+        t = t_end
+        eng.step(step_dt)
+    ss = eng.stepper_state
+    same = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+    assert same.mean() > 0.8, (ss.iter_lanes.cpu().numpy(), ad["iter"])
+    for k in ("q", "v"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-6, k
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-4, k
+    assert int(eng.status.abs().sum()) == 0 and abs(ss.t - 0.2) < 1e-12
+    # the body has moved most of the way to the new reference (2 Hz, critically damped, 0.2 s)
+    err = np.abs(eng.field("q")[:3].cpu().numpy() - ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3])
+    assert err.max() < 0.6 * np.abs(shift).max() + 0.05
