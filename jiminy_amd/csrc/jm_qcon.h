@@ -211,7 +211,12 @@ template<class Tp> struct QSplitRegion
 };
 
 // which topologies step in the split form (jm_qcon.h, bottom): solves of more than 32 rows
-template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > 32; }
+// (JM_QCON_SPLIT_MIN: experimental builds -- codegen.qcon_split_min -- move the threshold, e.g. to put ANYmal's 28-row solves
+// through the split form: measured in round 5)
+#ifndef JM_QCON_SPLIT_MIN
+#define JM_QCON_SPLIT_MIN 32
+#endif
+template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > JM_QCON_SPLIT_MIN; }
 // which kernels know user-registered JointConstraints (bit 2 of a joint row's flag): the variation kernels, and every
 // constraint kernel of the topologies that step in the split form (their solves run out of the workspace anyway); the plain
 // kernels of robots with register-resident solves (ANYmal) stay free of it -- the host launches the variation kernel for a

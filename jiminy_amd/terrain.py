@@ -159,3 +159,113 @@ def merge_heightmaps(heightmaps: Sequence[Callable[[torch.Tensor, torch.Tensor],
             out = torch.maximum(out, h(x, y))
         return out
     return heightmap
+
+
+# ---- Perlin grounds (`randomPerlinGround`, `unidirectionalRandomPerlinGround`: core/src/utilities/geometry.cc:858-926 on
+# `RandomPerlinProcess<N>`, core/include/jiminy/core/utilities/random.hxx:200-420, 564-690)
+PERLIN_NOISE_PERSISTENCE, PERLIN_NOISE_LACUNARITY = 1.50, 0.85     # random.hxx:11-12
+
+
+class _Pcg32:
+    """Host copy of the reference's `PCG32` (random.cc:10-37): the two or three draws per octave that place a ground."""
+
+    def __init__(self, seed: int) -> None:
+        self.state = (int(seed) | 3) & 0xFFFFFFFFFFFFFFFF
+
+    def __call__(self) -> int:
+        self.state = (self.state * 6364136223846793005) & 0xFFFFFFFFFFFFFFFF
+        s = self.state
+        rshift = (s >> 61) & 7
+        s ^= s >> 22
+        return (s >> (22 + rshift)) & 0xFFFFFFFF
+
+    def uniform(self) -> float:      # std::generate_canonical<float, 24>: one word
+        r = torch.tensor(self(), dtype=torch.int64).to(torch.float32) * (1.0 / 4294967296.0)
+        return min(float(r), float(torch.nextafter(torch.tensor(1.0), torch.tensor(0.0))))
+
+
+def _fade(d: torch.Tensor) -> torch.Tensor:
+    return d * d * d * (d * (d * 6.0 - 15.0) + 10.0)
+
+
+def _perlin_process(wavelength: float, num_octaves: int, n: int, seed: int):
+    """`RandomPerlinProcess<n>(wavelength, numOctaves)` reset with `PCG32(seed)`: returns f(list of n coordinate tensors)."""
+    if num_octaves < 1:
+        raise ValueError("'numOctaves' must at least 1.")
+    if wavelength <= 0.0:
+        raise ValueError("'wavelength' must be strictly larger than 0.0.")
+    g = _Pcg32(seed)
+    octaves, scale, wl = [], 1.0, float(wavelength)
+    for _ in range(int(num_octaves)):
+        shift = [g.uniform() for _ in range(n)]
+        octaves.append((wl, scale, shift, g()))
+        wl /= PERLIN_NOISE_LACUNARITY
+        scale *= PERLIN_NOISE_PERSISTENCE
+    amplitude = math.sqrt(sum(s * s for _, s, _, _ in octaves))
+    fmax = 4294967295.0
+
+    def grad_knot(knot: Sequence[torch.Tensor], oseed: int) -> Sequence[torch.Tensor]:
+        # xxHash of the int32 knot coordinates (4 bytes each): 1-D = one word, 2-D = two words
+        h = xxh32_words([k.to(torch.int64) & 0xFFFFFFFF for k in knot], oseed)
+        if n == 1:
+            return [2.0 * (h.to(torch.float32) / torch.tensor(fmax, dtype=torch.float32)).to(torch.float64) - 1.0]
+        # rejection sampling on the disk (random.hxx:438-452): every point keeps hashing until it is inside
+        one, two, f = torch.tensor(1.0, dtype=torch.float32), torch.tensor(2.0, dtype=torch.float32), torch.tensor(fmax, dtype=torch.float32)
+        gx = torch.zeros(h.shape, dtype=torch.float32, device=h.device)
+        gy = torch.zeros_like(gx)
+        todo = torch.ones(h.shape, dtype=torch.bool, device=h.device)
+        for _ in range(64):
+            x = two * h.to(torch.float32) / f - one
+            h = xxh32_words([h], oseed)
+            y = two * h.to(torch.float32) / f - one
+            ok = todo & (x * x + y * y <= one)
+            gx, gy = torch.where(ok, x, gx), torch.where(ok, y, gy)
+            todo = todo & ~ok
+            if not bool(todo.any()):
+                break
+        return [gx.to(torch.float64), gy.to(torch.float64)]
+
+    def octave(coords: Sequence[torch.Tensor], wl_: float, shift: Sequence[float], oseed: int) -> torch.Tensor:
+        cell = [coords[i] / wl_ + shift[i] for i in range(n)]
+        left = [torch.floor(c) for c in cell]
+        dl = [cell[i] - left[i] for i in range(n)]
+        dr = [d - 1.0 for d in dl]
+        li = [l_.to(torch.int64) for l_ in left]
+        offsets = []
+        for k in range(1 << n):
+            knot = [li[i] + 1 if k & (1 << i) else li[i] for i in range(n)]
+            delta = [dr[i] if k & (1 << i) else dl[i] for i in range(n)]
+            gk = grad_knot(knot, oseed)
+            offsets.append(sum(gk[i] * delta[i] for i in range(n)))
+        ratio = [_fade(d) for d in dl]
+        for i in range(n - 1, -1, -1):
+            for k in range(1 << i):
+                offsets[k] = offsets[k] + ratio[i] * (offsets[k | (1 << i)] - offsets[k])
+        return offsets[0]
+
+    def process(coords: Sequence[torch.Tensor]) -> torch.Tensor:
+        return sum(s * octave(coords, wl_, sh, sd) for wl_, s, sh, sd in octaves) / amplitude
+    return process
+
+
+def random_perlin_ground(wavelength: float, num_octaves: int, seed: int) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `randomPerlinGround(wavelength, numOctaves, seed)` (geometry.cc:921-926): 2-D gradient noise in [-1, 1], octaves of
+    wavelength / 0.85^i weighted 1.5^i; `heightmap(x, y) -> height` on float64 tensors."""
+    fun = _perlin_process(wavelength, num_octaves, 2, seed)
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        return fun([x, torch.as_tensor(y, dtype=torch.float64, device=x.device)])
+    return heightmap
+
+
+def unidirectional_random_perlin_ground(wavelength: float, num_octaves: int, orientation: float, seed: int
+                                        ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `unidirectionalRandomPerlinGround(wavelength, numOctaves, orientation, seed)` (geometry.cc:913-919)."""
+    fun = _perlin_process(wavelength, num_octaves, 1, seed)
+    ax, ay = math.cos(float(orientation)), math.sin(float(orientation))
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        return fun([ax * x + ay * torch.as_tensor(y, dtype=torch.float64, device=x.device)])
+    return heightmap

@@ -127,3 +127,101 @@ def sum_heightmaps(heightmaps):
 
 def merge_heightmaps(heightmaps):
     return lambda x, y: max(h(x, y) for h in heightmaps)
+
+
+# ---- Perlin grounds: `RandomPerlinProcess<N>` (core/include/jiminy/core/utilities/random.hxx:200-420, 564-690) behind
+# `randomPerlinGround` / `unidirectionalRandomPerlinGround` (core/src/utilities/geometry.cc:858-926), scalar, N = 1 or 2
+PERLIN_NOISE_PERSISTENCE, PERLIN_NOISE_LACUNARITY = 1.50, 0.85     # random.hxx:11-12
+
+
+class Pcg32:
+    """`PCG32` of the reference (random.cc:10-37): 64-bit MCG, XSH-RS output; `uniform()` = generate_canonical<float, 24>."""
+
+    def __init__(self, seed):
+        self.state = (int(seed) | 3) & M64
+
+    def __call__(self):
+        self.state = (self.state * 6364136223846793005) & M64
+        s = self.state
+        rshift = (s >> 61) & 7
+        s ^= s >> 22
+        return (s >> (22 + rshift)) & M32
+
+    def uniform(self):
+        import numpy as np
+        r = np.float32(self()) * np.float32(1.0 / 4294967296.0)
+        return float(r) if r < np.float32(1.0) else float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+
+
+M64, M32 = (1 << 64) - 1, (1 << 32) - 1
+
+
+def _fade(d):
+    return d * d * d * (d * (d * 6.0 - 15.0) + 10.0)
+
+
+class RandomPerlinOctave:
+    def __init__(self, wavelength, n, g):
+        import numpy as np
+        self.wavelength, self.n = wavelength, n
+        self.shift = [g.uniform() for _ in range(n)]       # AbstractPerlinNoiseOctave::reset: uniform(N, 1, g)
+        self.seed = g()                                    # RandomPerlinNoiseOctave::reset: seed_ = g()
+        self._np = np
+
+    def grad_knot(self, knot):
+        np = self._np
+        fmax = np.float32(4294967295.0)
+        h = xx_hash(struct.pack("<%di" % self.n, *knot), self.seed)
+        if self.n == 1:
+            return [2.0 * float(np.float32(h) / fmax) - 1.0]
+        while True:                                        # rejection sampling on the disk (random.hxx:438-452)
+            x = np.float32(2) * np.float32(h) / fmax - np.float32(1)
+            h = xx_hash(struct.pack("<I", h), self.seed)
+            y = np.float32(2) * np.float32(h) / fmax - np.float32(1)
+            if x * x + y * y <= np.float32(1):
+                return [float(x), float(y)]
+
+    def __call__(self, x):
+        n = self.n
+        cell = [x[i] / self.wavelength + self.shift[i] for i in range(n)]
+        left = [int(math.floor(c)) for c in cell]
+        dl = [cell[i] - left[i] for i in range(n)]
+        dr = [d - 1.0 for d in dl]
+        offsets = []
+        for k in range(1 << n):
+            knot = [left[i] + 1 if k & (1 << i) else left[i] for i in range(n)]
+            delta = [dr[i] if k & (1 << i) else dl[i] for i in range(n)]
+            g = self.grad_knot(knot)
+            offsets.append(sum(g[i] * delta[i] for i in range(n)))
+        ratio = [_fade(d) for d in dl]
+        for i in range(n - 1, -1, -1):
+            for k in range(1 << i):
+                offsets[k] = offsets[k] + ratio[i] * (offsets[k | (1 << i)] - offsets[k])
+        return offsets[0]
+
+
+class RandomPerlinProcess:
+    def __init__(self, wavelength, num_octaves, n, seed):
+        g = Pcg32(seed)
+        self.octaves, scale = [], 1.0
+        for _ in range(num_octaves):
+            self.octaves.append([wavelength, scale, None])
+            wavelength /= PERLIN_NOISE_LACUNARITY
+            scale *= PERLIN_NOISE_PERSISTENCE
+        self.amplitude = math.sqrt(sum(s * s for _, s, _ in self.octaves))
+        for o in self.octaves:                              # AbstractPerlinProcess::reset: the octaves in order, one generator
+            o[2] = RandomPerlinOctave(o[0], n, g)
+
+    def __call__(self, x):
+        return sum(s * o(x) for _, s, o in self.octaves) / self.amplitude
+
+
+def random_perlin_ground(wavelength, num_octaves, seed):
+    fun = RandomPerlinProcess(wavelength, num_octaves, 2, seed)
+    return lambda x, y: fun([x, y])
+
+
+def unidirectional_random_perlin_ground(wavelength, num_octaves, orientation, seed):
+    fun = RandomPerlinProcess(wavelength, num_octaves, 1, seed)
+    ax = (math.cos(orientation), math.sin(orientation))
+    return lambda x, y: fun([ax[0] * x + ax[1] * y])

@@ -109,3 +109,41 @@ def test_periodic_stairs_sum_and_merge_match_the_scalar_restatement():
     assert terrain.sum_heightmaps([t]) is t and terrain.merge_heightmaps([t]) is t
     with pytest.raises(ValueError):
         terrain.sum_heightmaps([])
+
+
+def test_perlin_grounds_match_the_scalar_restatement():
+    """`randomPerlinGround` / `unidirectionalRandomPerlinGround` (geometry.cc:858-926 on `RandomPerlinProcess`, random.hxx:200-690):
+    the tensor programs against the scalar restatement point by point, and what the process promises: values in [-1, 1],
+    continuity across cell borders, zero at the knots of a single octave, another ground for another seed."""
+    import math
+
+    from jiminy_amd import terrain
+    from oracle import terrain_numpy as orc
+    rg = np.random.default_rng(6)
+    x, y = rg.uniform(-6, 6, 600), rg.uniform(-6, 6, 600)
+    for wl, n_oct, seed in ((1.3, 1, 5), (0.8, 3, 12345), (2.0, 4, 0)):
+        t2, s2 = terrain.random_perlin_ground(wl, n_oct, seed), orc.random_perlin_ground(wl, n_oct, seed)
+        got = t2(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        want = np.array([s2(a, b) for a, b in zip(x, y)])
+        assert np.abs(got - want).max() < 1e-12
+        assert np.abs(got).max() <= 1.0 and np.abs(got).max() > 0.05
+        t1 = terrain.unidirectional_random_perlin_ground(wl, n_oct, 0.6, seed)
+        s1 = orc.unidirectional_random_perlin_ground(wl, n_oct, 0.6, seed)
+        got1 = t1(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        assert np.abs(got1 - np.array([s1(a, b) for a, b in zip(x, y)])).max() < 1e-12
+        # constant across the direction it does not depend on
+        f64 = lambda v: torch.tensor(v, dtype=torch.float64)  # noqa: E731
+        assert abs(float(t1(f64(1.0), f64(2.0))) - float(t1(f64(1.0 - 0.3 * math.sin(0.6)), f64(2.0 + 0.3 * math.cos(0.6))))) < 1e-12
+    # gradient noise vanishes at its knots: one octave, query points exactly on the (shifted) lattice
+    proc = orc.RandomPerlinProcess(1.3, 1, 2, 5)
+    sh = proc.octaves[0][2].shift
+    kx, ky = (3 - sh[0]) * 1.3, (-2 - sh[1]) * 1.3
+    t = terrain.random_perlin_ground(1.3, 1, 5)
+    assert abs(float(t(f64(kx), f64(ky)))) < 1e-12
+    # continuity across a cell border
+    eps = 1e-9
+    assert abs(float(t(f64(kx - eps), f64(0.37))) - float(t(f64(kx + eps), f64(0.37)))) < 1e-7
+    other = terrain.random_perlin_ground(1.3, 1, 9)      # (not 6: PCG32 seeds its state with `seed | 3`, 5 and 6 are one ground)
+    assert abs(float(t(f64(0.4), f64(0.9))) - float(other(f64(0.4), f64(0.9)))) > 1e-6
+    with pytest.raises(ValueError):
+        terrain.random_perlin_ground(1.0, 0, 1)

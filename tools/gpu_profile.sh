@@ -16,7 +16,7 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" \
-         "TCC_HIT_sum TCC_MISS_sum"; do
+         "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$N" -o run -- $BENCH > "$OUT/pmc_$N.log" 2>&1
   echo "pmc $N rc=$?"
