@@ -171,6 +171,19 @@ def two_masses_rod() -> CompiledModel:
     return m
 
 
+def anymal_held() -> CompiledModel:
+    """BASELINE's ANYmal with user constraints declared: its base may be held in the world (`FrameConstraint("base")`) and a
+    foot tied to the base by a rod (`DistanceConstraint`).  A robot that declares user constraint frames runs on the
+    one-robot-per-lane kernels."""
+    from jiminy_amd import load_builtin
+    from jiminy_amd.model import add_distance_constraint, add_frame_constraint
+    m = load_builtin("anymal")
+    m.name = "anymal_held"
+    add_frame_constraint(m, "hold_base", "base")
+    add_distance_constraint(m, "rod", m.contacts[0], "base")
+    return m
+
+
 def frame_constraint_models() -> List[CompiledModel]:
     return [two_masses_fixed_second(), sphere_fixed_frame(), pendulum_ff_fixed_world(), tree_arm_own_locks(False),
-            tree_arm_own_locks(True), rolling_ball(), rolling_wheel(), tethered_mass(), two_masses_rod()]
+            tree_arm_own_locks(True), rolling_ball(), rolling_wheel(), tethered_mass(), two_masses_rod(), anymal_held()]

@@ -589,3 +589,61 @@ def test_gpu_frame_constraint_under_the_adaptive_stepper(gpu_device):
     # the body has moved most of the way to the new reference (2 Hz, critically damped, 0.2 s)
     err = np.abs(eng.field("q")[:3].cpu().numpy() - ref["con_data"][rows["user_ref"]:rows["user_ref"] + 3])
     assert err.max() < 0.6 * np.abs(shift).max() + 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_anymal_with_a_held_base_and_a_rod(gpu_device):
+    """User constraints on a BASELINE robot: ANYmal standing on the constraint contact model with its base held in the world
+    (`FrameConstraint`, six rows) on half of the lanes and the first foot tied to the base by a rod (`DistanceConstraint`) on
+    the other half -- joint bounds, four contact blocks and the user rows in one solve, Euler at the reference's shipped
+    step, against the oracle.  A model that declares user constraint frames steps through the one-robot-per-lane kernels."""
+    import torch
+
+    from jiminy_amd import codegen
+    from jiminy_amd.engine import BatchedEngine
+    from jiminy_amd.synthetic import sample_standing_states
+    from oracle.oracle_py import OracleEngine
+    model = robots.anymal_held()
+    assert codegen.quad_structure(model) is None
+    B, dt, freq = 48, 1e-3, 10.0
+    rows = _abi.constraint_rows(model)
+    st = sample_standing_states(model, B, seed=3)
+    held = np.arange(B) % 2 == 0
+    copt = dict(tol_abs=1e-11, tol_rel=1e-10, regularization=1e-3)
+    ref = alloc_soa(model, B)
+    alloc_constraint_state(model, ref, B)
+    f0 = rows["n_bounds"] + rows["n_contacts"]
+    ref["con_flags"][f0, held] = 1
+    ref["con_flags"][f0 + 1, ~held] = 1
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = OracleEngine(model)
+    e.set_constraint_options(user_stabilization_freq=freq, **copt)
+    e.bind_constraints(ref["con_flags"], ref["con_data"])
+    io = oracle_io(ref)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces", "f_external", "energy"))
+    eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt,
+                                 "tolAbs": copt["tol_abs"], "tolRel": copt["tol_rel"]}, "contacts": {"model": "constraint"}})
+    xs = model.constraint_frames
+    eng.add_constraint("hold_base", _user_constraint_of(model, xs[0], freq), lane_mask=torch.from_numpy(held))
+    eng.add_constraint("rod", _user_constraint_of(model, xs[1], freq), lane_mask=torch.from_numpy(~held))
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+
+    def check(what, tol):
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.field("con_flags").cpu().numpy(), ref["con_flags"]), what
+        for k in ("q", "v", "a", "con_data", "u", "f_external", "contact_forces", "imu", "force"):
+            err = rel_err(eng.field(k).cpu().numpy(), ref[k])
+            assert err < tol, (what, k, err)
+    check("start", 1e-6)
+    loop = ReferenceFixedStepLoop(dt)
+    for _ in range(5):
+        eng.step(dt)
+        loop.advance(lambda h, first: e.batch_run("step", io, solver="euler_explicit", dt=h, n_substeps=1, command_changed=first), dt, True)
+    check("euler", 1e-5)
+    # the held bases stay where they were (they start with a small twist that the 10 Hz Baumgarte term takes out)
+    assert np.abs(ref["q"][:3, held] - st["q"][:3, held]).max() < 2e-3
+    lam = ref["con_data"][rows["user_lambda"]:rows["user_ref"]]
+    assert np.abs(lam[:6, held]).max() > 1.0 and np.abs(lam[6, ~held]).max() > 1e-3
