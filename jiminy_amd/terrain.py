@@ -11,7 +11,7 @@ fill the height map of `BatchedEngine.set_ground_profile` from a seed without le
 from __future__ import annotations
 
 import math
-from typing import Callable, Sequence, Tuple
+from typing import Optional, Callable, Sequence, Tuple
 
 import torch
 
@@ -188,23 +188,50 @@ def _fade(d: torch.Tensor) -> torch.Tensor:
     return d * d * d * (d * (d * 6.0 - 15.0) + 10.0)
 
 
-def _perlin_process(wavelength: float, num_octaves: int, n: int, seed: int):
-    """`RandomPerlinProcess<n>(wavelength, numOctaves)` reset with `PCG32(seed)`: returns f(list of n coordinate tensors)."""
+def _perlin_process(wavelength: float, num_octaves: int, n: int, seed: int, period: Optional[float] = None):
+    """`RandomPerlinProcess<n>(wavelength, numOctaves)` -- or, with `period`, `PeriodicPerlinProcess<n>(wavelength, period,
+    numOctaves)` (random.hxx:491-556, 640-690: gradients from a table drawn once per octave, knots wrapped into the period) --
+    reset with `PCG32(seed)`: returns f(list of n coordinate tensors)."""
     if num_octaves < 1:
         raise ValueError("'numOctaves' must at least 1.")
     if wavelength <= 0.0:
         raise ValueError("'wavelength' must be strictly larger than 0.0.")
+    if period is not None and period < max(wavelength, wavelength / PERLIN_NOISE_LACUNARITY ** (num_octaves - 1)):
+        raise ValueError("'period' must be larger than the wavelength of all the octaves")
     g = _Pcg32(seed)
     octaves, scale, wl = [], 1.0, float(wavelength)
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
     for _ in range(int(num_octaves)):
-        shift = [g.uniform() for _ in range(n)]
-        octaves.append((wl, scale, shift, g()))
+        if period is None:
+            shift = [g.uniform() for _ in range(n)]
+            octaves.append((wl, scale, shift, g()))
+        else:
+            wl_p = float(period) / max(round(float(period) / wl), 1.0)
+            size = int(float(period) / wl_p)
+            shift = [g.uniform() for _ in range(n)]
+            table = []
+            for _ in range(size ** n):
+                if n == 1:
+                    table.append([float(f32(g.uniform()) * f32(2.0) + f32(-1.0))])     # uniform_real_distribution<float>(-1, 1)
+                else:
+                    theta = 2.0 * math.pi * g.uniform()
+                    radius = float(torch.sqrt(f32(g.uniform())))
+                    table.append([radius * math.cos(theta), radius * math.sin(theta)])
+            octaves.append((wl_p, scale, shift, (size, torch.tensor(table, dtype=torch.float64))))
         wl /= PERLIN_NOISE_LACUNARITY
         scale *= PERLIN_NOISE_PERSISTENCE
     amplitude = math.sqrt(sum(s * s for _, s, _, _ in octaves))
     fmax = 4294967295.0
 
-    def grad_knot(knot: Sequence[torch.Tensor], oseed: int) -> Sequence[torch.Tensor]:
+    def grad_knot(knot: Sequence[torch.Tensor], oseed) -> Sequence[torch.Tensor]:
+        if period is not None:
+            size, table = oseed
+            index, mul = torch.zeros_like(knot[0]), 1
+            for k in knot:
+                index = index + torch.remainder(k, size) * mul
+                mul *= size
+            gk = table.to(index.device)[index]
+            return [gk[..., i] for i in range(n)]
         # xxHash of the int32 knot coordinates (4 bytes each): 1-D = one word, 2-D = two words
         h = xxh32_words([k.to(torch.int64) & 0xFFFFFFFF for k in knot], oseed)
         if n == 1:
@@ -225,7 +252,7 @@ def _perlin_process(wavelength: float, num_octaves: int, n: int, seed: int):
                 break
         return [gx.to(torch.float64), gy.to(torch.float64)]
 
-    def octave(coords: Sequence[torch.Tensor], wl_: float, shift: Sequence[float], oseed: int) -> torch.Tensor:
+    def octave(coords: Sequence[torch.Tensor], wl_: float, shift: Sequence[float], oseed) -> torch.Tensor:
         cell = [coords[i] / wl_ + shift[i] for i in range(n)]
         left = [torch.floor(c) for c in cell]
         dl = [cell[i] - left[i] for i in range(n)]
@@ -263,6 +290,29 @@ def unidirectional_random_perlin_ground(wavelength: float, num_octaves: int, ori
                                         ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
     """≙ `unidirectionalRandomPerlinGround(wavelength, numOctaves, orientation, seed)` (geometry.cc:913-919)."""
     fun = _perlin_process(wavelength, num_octaves, 1, seed)
+    ax, ay = math.cos(float(orientation)), math.sin(float(orientation))
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        return fun([ax * x + ay * torch.as_tensor(y, dtype=torch.float64, device=x.device)])
+    return heightmap
+
+
+def periodic_perlin_ground(wavelength: float, period: float, num_octaves: int, seed: int
+                           ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `periodicPerlinGround(wavelength, period, numOctaves, seed)` (geometry.cc:928-934): the same noise, periodic in x and y."""
+    fun = _perlin_process(wavelength, num_octaves, 2, seed, period=period)
+
+    def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        x = torch.as_tensor(x, dtype=torch.float64)
+        return fun([x, torch.as_tensor(y, dtype=torch.float64, device=x.device)])
+    return heightmap
+
+
+def unidirectional_periodic_perlin_ground(wavelength: float, period: float, num_octaves: int, orientation: float, seed: int
+                                          ) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """≙ `unidirectionalPeriodicPerlinGround(wavelength, period, numOctaves, orientation, seed)` (geometry.cc:936-945)."""
+    fun = _perlin_process(wavelength, num_octaves, 1, seed, period=period)
     ax, ay = math.cos(float(orientation)), math.sin(float(orientation))
 
     def heightmap(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

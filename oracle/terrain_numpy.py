@@ -225,3 +225,60 @@ def unidirectional_random_perlin_ground(wavelength, num_octaves, orientation, se
     fun = RandomPerlinProcess(wavelength, num_octaves, 1, seed)
     ax = (math.cos(orientation), math.sin(orientation))
     return lambda x, y: fun([ax[0] * x + ax[1] * y])
+
+
+class PeriodicPerlinOctave(RandomPerlinOctave):
+    """`PeriodicPerlinNoiseOctave<N>` (random.h:483-506, random.hxx:491-556): gradients from a table of size^N entries drawn
+    once, knots wrapped into the period."""
+
+    def __init__(self, wavelength, period, n, g):
+        import numpy as np
+        if period < wavelength:
+            raise ValueError("'period' must be larger than 'wavelength'.")
+        self.wavelength = period / max(round(period / wavelength), 1.0)
+        self.n, self.period, self._np = n, period, np
+        self.size = int(period / self.wavelength)
+        self.shift = [g.uniform() for _ in range(n)]
+        self.grads = []
+        for _ in range(self.size ** n):
+            if n == 1:
+                # std::uniform_real_distribution<float>(-1, 1): generate_canonical * (b - a) + a, in float
+                self.grads.append([float(np.float32(g.uniform()) * np.float32(2.0) + np.float32(-1.0))])
+            else:
+                theta = 2 * math.pi * g.uniform()
+                radius = float(np.sqrt(np.float32(g.uniform())))
+                self.grads.append([radius * math.cos(theta), radius * math.sin(theta)])
+
+    def grad_knot(self, knot):
+        index, shift = 0, 1
+        for i in range(self.n):
+            index += (knot[i] % self.size) * shift
+            shift *= self.size
+        return self.grads[index]
+
+
+class PeriodicPerlinProcess(RandomPerlinProcess):
+    def __init__(self, wavelength, period, num_octaves, n, seed):
+        final = wavelength / PERLIN_NOISE_LACUNARITY ** (num_octaves - 1)
+        if period < max(wavelength, final):
+            raise ValueError("'period' must be larger than the wavelength of all the octaves")
+        g = Pcg32(seed)
+        self.octaves, scale = [], 1.0
+        for _ in range(num_octaves):
+            self.octaves.append([wavelength, scale, None])
+            wavelength /= PERLIN_NOISE_LACUNARITY
+            scale *= PERLIN_NOISE_PERSISTENCE
+        self.amplitude = math.sqrt(sum(s * s for _, s, _ in self.octaves))
+        for o in self.octaves:
+            o[2] = PeriodicPerlinOctave(o[0], period, n, g)
+
+
+def periodic_perlin_ground(wavelength, period, num_octaves, seed):
+    fun = PeriodicPerlinProcess(wavelength, period, num_octaves, 2, seed)
+    return lambda x, y: fun([x, y])
+
+
+def unidirectional_periodic_perlin_ground(wavelength, period, num_octaves, orientation, seed):
+    fun = PeriodicPerlinProcess(wavelength, period, num_octaves, 1, seed)
+    ax = (math.cos(orientation), math.sin(orientation))
+    return lambda x, y: fun([ax[0] * x + ax[1] * y])

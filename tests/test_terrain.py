@@ -147,3 +147,25 @@ def test_perlin_grounds_match_the_scalar_restatement():
     assert abs(float(t(f64(0.4), f64(0.9))) - float(other(f64(0.4), f64(0.9)))) > 1e-6
     with pytest.raises(ValueError):
         terrain.random_perlin_ground(1.0, 0, 1)
+
+
+def test_periodic_perlin_grounds_match_the_scalar_restatement_and_are_periodic():
+    """`periodicPerlinGround` / `unidirectionalPeriodicPerlinGround` (geometry.cc:928-945 on `PeriodicPerlinProcess`,
+    random.hxx:491-556): tensor programs against the scalar restatement, and f(x + period) = f(x)."""
+    from jiminy_amd import terrain
+    from oracle import terrain_numpy as orc
+    rg = np.random.default_rng(16)
+    x, y = rg.uniform(-7, 7, 400), rg.uniform(-7, 7, 400)
+    for wl, period, n_oct, seed in ((1.0, 4.0, 1, 3), (1.5, 6.0, 3, 77)):
+        t2, s2 = terrain.periodic_perlin_ground(wl, period, n_oct, seed), orc.periodic_perlin_ground(wl, period, n_oct, seed)
+        got = t2(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        assert np.abs(got - np.array([s2(a, b) for a, b in zip(x, y)])).max() < 1e-12
+        assert np.abs(got - t2(torch.from_numpy(x + period), torch.from_numpy(y - 2 * period)).numpy()).max() < 1e-9
+        assert np.abs(got).max() <= 1.0 and np.abs(got).max() > 0.05
+        t1 = terrain.unidirectional_periodic_perlin_ground(wl, period, n_oct, 0.0, seed)
+        s1 = orc.unidirectional_periodic_perlin_ground(wl, period, n_oct, 0.0, seed)
+        got1 = t1(torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        assert np.abs(got1 - np.array([s1(a, b) for a, b in zip(x, y)])).max() < 1e-12
+        assert np.abs(got1 - t1(torch.from_numpy(x + 3 * period), torch.from_numpy(y)).numpy()).max() < 1e-9
+    with pytest.raises(ValueError):
+        terrain.periodic_perlin_ground(2.0, 1.0, 1, 0)
