@@ -609,6 +609,63 @@ def _constraint_self_test(model: CompiledModel, variant: int, device: torch.devi
     return float(res.max()) if np.isfinite(res).all() else float("inf")
 
 
+def _constraint_rows_self_test(model: CompiledModel, variant: int, device: torch.device) -> float:
+    """The rows the CONSTRAINT-model kernels emit, against the spring-damper kernels of the same library (whose own emitted
+    rows `_output_self_test` checks): with no constraint active -- robots in the air, joints inside their bounds -- the
+    constrained evaluation is the plain articulated-body solve (`Engine::computeAcceleration`, engine.cc:3861-3865), so every
+    output row of `start` and of one Euler step must agree to round-off.  Covers the output pass of the constraint family
+    (sensors, extra terms), which the equation-of-motion residual of `_constraint_self_test` does not look at: the class of
+    fault of DESIGN.md section 4.7, third case (a wrong IMU row next to right accelerations)."""
+    n, dt = 64, 1e-4
+    q, v, cmd = _probe_state(model, n)
+    if model.has_freeflyer:
+        q[2] += 5.0
+    elif model.ncontacts:
+        return 0.0          # (fixed-base robots cannot be lifted off the ground: nothing to compare without contacts)
+    # every bounded joint well inside its range (a joint AT a limit keeps its bound constraint through the hysteresis)
+    for j in range(1, model.njoints):
+        if 1 <= int(model.jtypes[j]) <= 8:
+            iq = int(model.idx_q[j])
+            lo, hi = float(model.position_lower[iq]), float(model.position_upper[iq])
+            if math.isfinite(lo) and math.isfinite(hi):
+                q[iq] = lo + (0.3 + 0.4 * (np.arange(n) % 7) / 6.0) * (hi - lo)
+    extras = ("contact_forces", "f_external", "energy", "joint_forces", "centroidal")
+    probes = {}
+    for contact_model in ("constraint", "spring_damper"):
+        probe = BatchedEngine(model, n, dtype=torch.float64, device=device, _lib_variant=variant, extra_outputs=extras)
+        probe.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt},
+                           "contacts": {"model": contact_model}}, _skip_constraint_check=True)
+        if model.nmotors:
+            probe.set_command(torch.as_tensor(cmd, dtype=torch.float64))
+        probe.start(torch.as_tensor(q), torch.as_tensor(v))
+        probe.step(dt)
+        probes[contact_model] = probe
+    # `Engine::start` enables every constraint and solves with them (engine.cc:1266-1308): the first evaluations differ by
+    # design.  After one step the switching has released them all; from THAT state (q, v, a copied over) one more step of
+    # either model is the same computation
+    for k in ("q", "v", "a"):
+        probes["spring_damper"]._fields[k].copy_(probes["constraint"]._fields[k])
+    runs = []
+    for contact_model in ("spring_damper", "constraint"):
+        probe = probes[contact_model]
+        probe.step(dt)
+        runs.append(({k: probe._fields[k].clone() for k in _OUTPUT_ROWS if k in probe._fields}, probe.status.reshape(-1).clone()))
+    active = probes["constraint"]._fields["con_flags"].bitwise_and(1).sum(0) > 0
+    for probe in probes.values():
+        probe.stop()
+    ok = (((runs[0][1] | runs[1][1]) & (_abi.JM_LANE_NAN | _abi.JM_LANE_OUT_OF_BOUNDS)) == 0) & ~active
+    if not bool(ok.any()):
+        return float("inf")
+    err = 0.0
+    for k in runs[0][0]:
+        x, y = runs[0][0][k][:, ok], runs[1][0][k][:, ok]
+        if x.numel() == 0:
+            continue
+        e = float((x - y).abs().max() / torch.clamp(x.abs().max(), min=1.0))
+        err = max(err, e if e == e else float("inf"))
+    return err
+
+
 def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
     """The HIP library of `model`, checked once per process, topology and dtype by
     `_library_self_test`.  A build that fails the check is a toolchain mis-compile (DESIGN.md
@@ -832,6 +889,13 @@ class BatchedEngine:
                 f"({self.model.name}, build variant {key[1]}): equation-of-motion residual {err:.3e}. "
                 "The compiled library is unsound (toolchain mis-compile, DESIGN.md section 4.7); rebuild it "
                 "with another variant (JIMINY_AMD_BUILD_VARIANT).")
+        err_rows = _constraint_rows_self_test(self.model, key[1], self.device)
+        if not err_rows <= 1e-8:
+            raise RuntimeError(
+                f"constraint-model kernel self-test failed for topology {self.model.topology_hash()} ({self.model.name}, build "
+                f"variant {key[1]}): with no constraint active its emitted rows differ from the spring-damper kernels' by "
+                f"{err_rows:.3e} (toolchain mis-compile of its output pass, DESIGN.md section 4.7); rebuild the library with "
+                "another variant (JIMINY_AMD_BUILD_VARIANT).")
         _CON_VERIFIED[key] = err
 
     def _check_variation_kernels(self) -> None:

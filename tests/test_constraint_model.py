@@ -781,6 +781,10 @@ def test_gpu_constraint_kernel_self_test(name, gpu_device):
     model = _models()[name]()
     err = _constraint_self_test(model, codegen.preferred_variant(model), gpu_device)
     assert err < 1e-8, err
+    # ... and the rows its output pass emits: with no constraint active they are the spring-damper kernels' rows (round 5)
+    from jiminy_amd.engine import _constraint_rows_self_test
+    err_rows = _constraint_rows_self_test(model, codegen.preferred_variant(model), gpu_device)
+    assert err_rows < 1e-8, err_rows
 
 
 @pytest.mark.gpu
