@@ -712,15 +712,6 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     // ---- unconstrained part: FK, motors, ABA without contact forces
     eval_dynamics<T, Tp>(P, q, v, cmd, w);
     w.status &= ~JM_LANE_SOLVER_FAILURE;
-    static_for<1, Tp::NJ>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int t = Tp::jtype[j];
-        constexpr int iq = Tp::idx_q[j];
-        if constexpr (t == JM_JT_FREEFLYER) { w.jcs[j][0] = T(0); w.jcs[j][1] = T(0); }
-        else if constexpr (jt_is_unb(t)) { w.jcs[j][0] = q[iq]; w.jcs[j][1] = q[iq + 1]; }
-        else if constexpr (jt_is_rev(t)) sincos_(q[iq], &w.jcs[j][1], &w.jcs[j][0]);
-        else { w.jcs[j][0] = q[iq]; w.jcs[j][1] = T(0); }
-    });
     if constexpr (NR == 0) return;
     auto flag = [&](int r) -> int32_t & { return C.flags[(size_t)r * B + lane]; };
     auto dat = [&](int r) -> T & { return C.data[(size_t)r * B + lane]; };

@@ -156,6 +156,9 @@ template<class T, class Tp> struct Work
     T ueff[Tp::NV];              // total effort vector (RobotState::u)
     T umotor[c_max(Tp::NM, 1)];
     T ddq[Tp::NV];
+    // joint coordinate of every 1-dof joint as (cos, sin) or (displacement, -): the sweeps rebuild liMi from
+    // these 2 scalars + the constant placement (scalar loads) instead of keeping 12 scalars per joint alive
+    T jcs[Tp::NJ][2];
     int status;
     static constexpr bool CONSTRAINED = false;
 };
@@ -164,9 +167,6 @@ template<class T, class Tp> struct WorkC : Work<T, Tp>
 {
     T rootA[6][6];   // LDL^T factor of (Ia_root + rotor) left by chol6_solve (unit lower + diagonal)
     T rootdinv[6];
-    // joint coordinate of every 1-dof joint as (cos, sin) or (displacement, -): the bias-free solves
-    // rebuild liMi from these 2 scalars + the constant placement instead of re-reading 12 scalars per joint
-    T jcs[Tp::NJ][2];
     static constexpr bool CONSTRAINED = true;
 };
 // evaluation policy of lane_run: plain (spring-damper contacts) or constraint contact model
@@ -188,8 +188,10 @@ template<class T, class Tp, int J> JM_DEV V3<T> joint_axis(CPtr<T> P)
 }
 
 // joint transform M_j(q) and joint velocity S qd
+// `cs`: the joint coordinate as the sweeps cache it -- (cos, sin) of a revolute joint, (displacement, 0) of a
+// prismatic one
 template<class T, class Tp, int J>
-JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> & vj)
+JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> & vj, T (&cs)[2])
 {
     constexpr int t = Tp::jtype[J];
     constexpr int iq = Tp::idx_q[J], iv = Tp::idx_v[J];
@@ -198,6 +200,7 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
         Mj.R = quat_to_matrix(q[iq + 3], q[iq + 4], q[iq + 5], q[iq + 6]);
         Mj.p = {q[iq], q[iq + 1], q[iq + 2]};
         vj = {{v[iv], v[iv + 1], v[iv + 2]}, {v[iv + 3], v[iv + 4], v[iv + 5]}};
+        cs[0] = T(0); cs[1] = T(0);
     }
     else if constexpr (jt_is_rev(t))
     {
@@ -210,6 +213,7 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
         else Mj.R = rot_rodrigues(n, c, s);
         Mj.p = zero3<T>();
         vj = {zero3<T>(), v[iv] * n};
+        cs[0] = c; cs[1] = s;
     }
     else
     {
@@ -217,6 +221,47 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
         Mj.R = ident3<T>();
         Mj.p = q[iq] * n;
         vj = {v[iv] * n, zero3<T>()};
+        cs[0] = q[iq]; cs[1] = T(0);
+    }
+}
+template<class T, class Tp, int J>
+JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> & vj)
+{
+    T cs[2];
+    joint_calc<T, Tp, J>(P, q, v, Mj, vj, cs);
+}
+// liMi of a joint for the sweeps: rebuilt from the cached joint coordinate and the constant placement (a
+// free-flyer's is kept)
+#ifndef JM_LANE_REBUILD
+#define JM_LANE_REBUILD 1
+#endif
+template<class T, class Tp, int J, class W> JM_DEV SE3<T> limi_of(CPtr<T> P, const W & w)
+{
+    constexpr int t = Tp::jtype[J];
+    if constexpr (t == JM_JT_FREEFLYER || !JM_LANE_REBUILD) return w.liMi[J];
+    else
+    {
+        using L = Layout<Tp>;
+        const SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
+        SE3<T> Mj;
+        // (opaque copies: common-subexpression elimination would otherwise merge the rebuilt placement with the
+        // one the forward kinematics formed and keep all twelve scalars alive in between)
+        T c = w.jcs[J][0], sn = w.jcs[J][1];
+        JM_OPAQUE(c);
+        if constexpr (jt_is_rev(t))
+        {
+            JM_OPAQUE(sn);
+            constexpr int ax = jt_axis(t);
+            if constexpr (ax >= 0) Mj.R = rot_axis<T>(ax, c, sn);
+            else Mj.R = rot_rodrigues(joint_axis<T, Tp, J>(P), c, sn);
+            Mj.p = zero3<T>();
+        }
+        else
+        {
+            Mj.R = ident3<T>();
+            Mj.p = c * joint_axis<T, Tp, J>(P);
+        }
+        return plc * Mj;
     }
 }
 template<class T, class Tp, int J> JM_DEV Sp<T> joint_S_times(CPtr<T> P, const T * x)
@@ -403,8 +448,11 @@ template<class T> JM_DEV void chol6_resolve(const T (&A)[6][6], const T (&dinv)[
 // ---------------------------------------------------------------- a = f(q, v) with held command
 // W = Work<T, Tp>: spring-damper contact model.  W = WorkC<T, Tp>: the unconstrained part of the
 // constraint contact model (no contact forces, no out-of-bounds flag, root factor kept).
+// Kinematic half: placements, velocities, bias accelerations, contact forces, motor efforts.  It is all the
+// output pass needs of an evaluation, so lane_run calls it on its own after the last evaluation of a launch
+// instead of keeping oMi / vel / fext / cf alive across the ABA sweeps of every evaluation.
 template<class T, class Tp, class W>
-JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w)
+JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w)
 {
     using L = Layout<Tp>;
     constexpr int NJ = Tp::NJ;
@@ -418,7 +466,7 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
         constexpr int p = Tp::parent[j];
         SE3<T> Mj;
         Sp<T> vj;
-        joint_calc<T, Tp, j>(P, q, v, Mj, vj);
+        joint_calc<T, Tp, j>(P, q, v, Mj, vj, w.jcs[j]);
         const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
         w.liMi[j] = plc * Mj;
         if constexpr (p > 0)
@@ -431,7 +479,6 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
             w.oMi[j] = w.liMi[j];
             w.vel[j] = vj;
         }
-        w.agf[j] = cross_mm(w.vel[j], vj);  // c_j = 0 for every supported joint
         w.fext[j] = zero6<T>();
         if constexpr (jt_bounded(Tp::jtype[j]) && !W::CONSTRAINED)
         {
@@ -497,26 +544,58 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
         w.ueff[iv] += ut;
     });
     static_for<0, Tp::NV>([&](auto ic) { w.u[decltype(ic)::value] = w.ueff[decltype(ic)::value]; });
-    // ---- ABA pass 1 (force part): f = v x* (I v) - fext
-    static_for<1, NJ>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
-        const Sp<T> h = rbi_mul(Y, w.vel[j]);
-        w.f[j] = cross_mf(w.vel[j], h) - w.fext[j];
-    });
-    // ---- ABA pass 2 (AbaBackwardStep), leaves -> root
+}
+
+// Articulated-body sweeps on what eval_kinematics left in `w`
+// The sweeps keep ONE spatial vector per joint between the passes -- its velocity: the bias acceleration
+// c_j = v_j x (S qd) and the bias force v x* (I v) - fext are formed where the backward / forward sweeps consume
+// them (a dozen multiply-adds each) instead of sitting in registers from the forward kinematics on.
+template<class T, class Tp, int J, class W> JM_DEV Sp<T> joint_bias_acc(CPtr<T> P, const T * v, const W & w)
+{
+    Sp<T> vj = w.vel[J];
+    JM_OPAQUE(vj.l.x); JM_OPAQUE(vj.l.y); JM_OPAQUE(vj.l.z); JM_OPAQUE(vj.a.x); JM_OPAQUE(vj.a.y); JM_OPAQUE(vj.a.z);
+    return cross_mm(vj, joint_S_times<T, Tp, J>(P, v));  // c_j = 0 for every supported joint
+}
+// What the backward sweep leaves for the forward sweep -- U_j (6), 1/D_j, the reduced effort u_j of every 1-dof
+// joint -- is written once and read once, with both sweeps' whole working set in between: the plain lane kernel
+// parks it in LDS (`stash`: element r of the lane at stash[r * SS]) instead of leaving it to the register
+// allocator's scratch spills.  Joints are served from the leaves (produced first, consumed last) while rows last.
+template<class Tp> constexpr int stash_rows_wanted() { return 8 * (Tp::NJ - 1); }
+template<class T, class Tp> constexpr int stash_rows()
+{
+    // one wave per SIMD (512 registers): 4 blocks of 64 lanes share the 160 kB of a CU
+    constexpr int budget = (int)(160 * 1024 / 4 / (64 * sizeof(T))) - 3 * Tp::NV;
+    constexpr int want = stash_rows_wanted<Tp>();
+    if (Tp::NJ - 1 < 4) return 0;   // short chains fit their sweeps in registers
+    return budget <= 0 ? 0 : (want < budget ? want : (budget / 8) * 8);
+}
+template<class T, class Tp, int SS, class W>
+JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w, T * stash)
+{
+    using L = Layout<Tp>;
+    constexpr int NJ = Tp::NJ;
+    constexpr int NSTASH = SS > 0 ? stash_rows<T, Tp>() / 8 : 0;   // joints NJ-1, NJ-2, ... NJ-NSTASH are parked
+    (void)stash;
+    // ---- ABA pass 2 (AbaBackwardStep), leaves -> root; pass 1's force part f = v x* (I v) - fext at the visit
     AI<T> Yacc[NJ];
+    Sp<T> facc[NJ];   // bias forces handed up by the children
 #ifdef JM_HOST_EMU
     std::memset(Yacc, 0xFF, sizeof(Yacc));
+    std::memset(facc, 0xFF, sizeof(facc));
 #endif
     static_rfor<1, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int p = Tp::parent[j];
         constexpr int t = Tp::jtype[j];
         constexpr int iv = Tp::idx_v[j];
+        const RBI<T> Yj = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
         AI<T> Ia;
         if constexpr (Tp::nchildren[j] > 0) Ia = Yacc[j];
-        else Ia = ai_from_rbi(ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12));
+        else Ia = ai_from_rbi(Yj);
+        Sp<T> fj = cross_mf(w.vel[j], rbi_mul(Yj, w.vel[j])) - w.fext[j];
+        if constexpr (Tp::nchildren[j] > 0) fj = fj + facc[j];
+        w.f[j] = fj;
+        w.agf[j] = joint_bias_acc<T, Tp, j>(P, v, w);
         if constexpr (t == JM_JT_FREEFLYER)
         {
             static_assert(t != JM_JT_FREEFLYER || p == 0, "free-flyer joints are only supported at the root");
@@ -562,20 +641,35 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
             else U = {Ia.A * n, tmul(Ia.B, n)};
             const T D = joint_St_dot<T, Tp, j>(P, U) + P[L::ROTOR + iv];
             const T dinv = T(1) / D;
-            w.U[j] = U;
-            w.dinv[j] = dinv;
+            if constexpr (NJ - j <= NSTASH)
+            {
+                T * o = stash + (long long)(8 * (NJ - 1 - j)) * SS;
+                o[0] = U.l.x; o[SS] = U.l.y; o[2 * SS] = U.l.z; o[3 * SS] = U.a.x; o[4 * SS] = U.a.y; o[5 * SS] = U.a.z;
+                o[6 * SS] = dinv; o[7 * SS] = uj;
+            }
+            else
+            {
+                w.U[j] = U;
+                w.dinv[j] = dinv;
+            }
             if constexpr (p > 0)
             {
                 ai_rank1_sub(Ia, U, dinv);
                 const Sp<T> Ya = ai_mul(Ia, w.agf[j]);
                 const T ud = uj * dinv;
                 const Sp<T> pa = {w.f[j].l + Ya.l + ud * U.l, w.f[j].a + Ya.a + ud * U.a};
-                const AI<T> Tr = ai_transform(w.liMi[j], Ia);
+                const SE3<T> M = limi_of<T, Tp, j>(P, w);
+                const AI<T> Tr = ai_transform(M, Ia);
                 if constexpr (Tp::first_child[p] == j)
+                {
                     Yacc[p] = ai_from_rbi(ld_rbi<T>(P, L::JOINT + p * L::JSTRIDE + 12)) + Tr;
+                    facc[p] = act_force(M, pa);
+                }
                 else
+                {
                     Yacc[p] = Yacc[p] + Tr;
-                w.f[p] = w.f[p] + act_force(w.liMi[j], pa);
+                    facc[p] = facc[p] + act_force(M, pa);
+                }
             }
         }
     });
@@ -594,9 +688,18 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
                 const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
                 ap = {-g, -gw};
             }
-            const Sp<T> ag = w.agf[j] + actinv_motion(w.liMi[j], ap);
-            const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
-            const T dd = w.dinv[j] * (w.u[iv] - Ua);
+            const Sp<T> ag = joint_bias_acc<T, Tp, j>(P, v, w) + actinv_motion(limi_of<T, Tp, j>(P, w), ap);
+            Sp<T> U;
+            T dinv, uj;
+            if constexpr (NJ - j <= NSTASH)
+            {
+                const T * o = stash + (long long)(8 * (NJ - 1 - j)) * SS;
+                U = {{o[0], o[SS], o[2 * SS]}, {o[3 * SS], o[4 * SS], o[5 * SS]}};
+                dinv = o[6 * SS]; uj = o[7 * SS];
+            }
+            else { U = w.U[j]; dinv = w.dinv[j]; uj = w.u[iv]; }
+            const T Ua = dot(U.l, ag.l) + dot(U.a, ag.a);
+            const T dd = dinv * (uj - Ua);
             w.ddq[iv] = dd;
             const V3<T> n = joint_axis<T, Tp, j>(P);
             if constexpr (jt_is_rev(t)) w.agf[j] = {ag.l, ag.a + dd * n};
@@ -607,6 +710,13 @@ JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W 
         constexpr int i = decltype(ic)::value;
         if (w.ddq[i] != w.ddq[i]) w.status |= JM_LANE_NAN;
     });
+}
+
+template<class T, class Tp, int SS = 0, class W>
+JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w, T * stash = nullptr)
+{
+    eval_kinematics<T, Tp>(P, q, v, cmd, w);
+    eval_aba<T, Tp, SS>(P, v, w, stash);
 }
 
 // ---------------------------------------------------------------- q (+) dv on the manifold
@@ -850,6 +960,8 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 // Rows: [0,NV) accumulated velocity increment, [NV,2NV) accumulated acceleration increment,
 //       [2NV,3NV) velocity of the previous stage.
 template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
+// rows of the per-lane buffer the plain lane kernel hands to lane_run: the stage rows, then the sweeps' stash
+template<class T, class Tp> constexpr int lane_rows() { return stage_rows<Tp>() + stash_rows<T, Tp>(); }
 
 // constraint contact model (jm_constraint.h): the free evaluation above + constraint switching +
 // the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence, < 0 only re-applies the
@@ -858,15 +970,15 @@ template<class T, class Tp, class CA>
 JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
                              long long lane, long long B, int start_passes);
 
-template<class T, class Tp, class CON, class W>
+template<class T, class Tp, class CON, int SS, class W>
 JM_DEV void eval_any(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w,
-                     const typename CON::template ArgsT<T> & C, long long lane, long long B, int start_passes)
+                     const typename CON::template ArgsT<T> & C, long long lane, long long B, int start_passes, T * stash)
 {
     if constexpr (CON::ON) eval_constrained<T, Tp>(P, q, v, cmd, w, C, lane, B, start_passes);
     else
     {
         (void)C; (void)lane; (void)B; (void)start_passes;
-        eval_dynamics<T, Tp>(P, q, v, cmd, w);
+        eval_dynamics<T, Tp, SS>(P, q, v, cmd, w, stash);
     }
 }
 
@@ -881,6 +993,9 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
     const long long B = A.B;
     CPtr<T> P = (CPtr<T>)A.P;
     typename CON::template WorkT<T, Tp> w;
+    // the sweeps' stash follows the stage rows when the caller's buffer has a compile-time stride (the plain kernel)
+    constexpr int SS = CON::ON ? 0 : SBS;
+    T * const stash = sb + (long long)stage_rows<Tp>() * SS;
     T qs[NQ], vs[NV], as[NV], cmd[c_max(NM, 1)];
 #ifdef JM_HOST_EMU
     // poison everything a GPU lane would find uninitialised: a read-before-write shows up as NaN
@@ -896,15 +1011,17 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
         static_for<0, NQ>([&](auto ic) { A.q[decltype(ic)::value * B + lane] = A.q_init[decltype(ic)::value * B + lane]; });
         static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = A.v_init[decltype(ic)::value * B + lane]; });
     }
-    if (A.mode != MODE_STEP)
+    // The plain kernel runs the other modes through the loop below as ONE evaluation of the "refresh a(t+)" kind
+    // (k = -1): a single copy of the evaluation and of the output pass in the kernel instead of two.
+    if (CON::ON && A.mode != MODE_STEP)
     {
         // one evaluation at the given state
         const T * qsrc = (A.mode == MODE_DYNAMICS) ? A.q_in : A.q;
         const T * vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
         static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
         static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
-        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B,
-                             (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0));
+        eval_any<T, Tp, CON, SS>(P, qs, vs, cmd, w, C, lane, B,
+                                 (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0), stash);
         if (A.mode == MODE_DYNAMICS)
         {
             static_for<0, NV>([&](auto ic) { A.a_out[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
@@ -928,11 +1045,16 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
 
     // ---- MODE_STEP: n_sub fixed steps of dt with the command held
     const T dt = A.dt;
+    const bool stepping = A.mode == MODE_STEP;
     const bool rk4 = A.solver == JM_SOLVER_RUNGE_KUTTA_4;
     const int evals_per_step = rk4 ? 4 : 1;
-    const int pre = A.command_changed ? 1 : 0;
-    const int n_evals = pre + A.n_sub * evals_per_step;
+    const int pre = stepping ? (A.command_changed ? 1 : 0) : 1;
+    const int n_evals = stepping ? pre + A.n_sub * evals_per_step : 1;
+    const T * const qsrc = (A.mode == MODE_DYNAMICS) ? A.q_in : A.q;
+    const T * const vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
+    T * const adst = (A.mode == MODE_DYNAMICS) ? A.a_out : A.a;
     // NaN guard on the incoming state (engine.cc:1737-1747)
+    if (stepping)
     {
         bool bad = false;
         static_for<0, NQ>([&](auto ic) { const T x = A.q[decltype(ic)::value * B + lane]; bad |= (x != x); });
@@ -947,8 +1069,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
         const int k = (e < pre) ? -1 : (rk4 ? ((e - pre) & 3) : 3);
         if (k == -1)
         {
-            static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
-            static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = A.v[decltype(ic)::value * B + lane]; });
+            static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
+            static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
         }
         else
         {
@@ -988,23 +1110,49 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
                 static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = vs[decltype(ic)::value]; });
             }
         }
-        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B, 0);
+        eval_any<T, Tp, CON, SS>(P, qs, vs, cmd, w, C, lane, B, 0, stash);
         static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = w.ddq[decltype(ic)::value]; });
         if (k == -1 || k == 3)
-            static_for<0, NV>([&](auto ic) { A.a[decltype(ic)::value * B + lane] = as[decltype(ic)::value]; });
-        if (e == n_evals - 1)
+            static_for<0, NV>([&](auto ic) { adst[decltype(ic)::value * B + lane] = as[decltype(ic)::value]; });
+        if constexpr (CON::ON)
         {
-            extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.update_sensors != 0);
-            if (A.status) A.status[lane] = w.status;
+            if (e == n_evals - 1) extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.update_sensors != 0);
         }
     }
+    if constexpr (!CON::ON)
+    {
+        if (n_evals <= 0 || A.mode == MODE_DYNAMICS) return;
+        // the output pass takes its kinematics from an evaluation of its own at the closing state: nothing but
+        // the sweeps' own operands stays live inside the evaluations of the loop
+        // (state read back from the rows the closing evaluation wrote: qs / vs / as need not survive the loop)
+        static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = A.v[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = A.a[decltype(ic)::value * B + lane]; });
+        const int status = w.status;
+        eval_kinematics<T, Tp>(P, qs, vs, cmd, w);
+        w.status |= status;
+        // Engine::start: refuse huge initial contact forces (engine.cc:1310-1346)
+        if (A.mode == MODE_START || A.mode == MODE_RESET)
+        {
+            T fmax2 = T(0);
+            static_for<0, Tp::NC>([&](auto cc) {
+                const Sp<T> & f = w.cf[decltype(cc)::value];
+                fmax2 = fmax_(fmax2, dot(f.l, f.l));
+            });
+            if (fmax2 > T(1e10)) w.status |= JM_LANE_FORCE_OVERFLOW;
+        }
+        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.mode != MODE_REFRESH || A.update_sensors != 0);
+        if (A.status) A.status[lane] = (A.mode == MODE_REFRESH) ? (A.status[lane] | w.status) : w.status;
+        return;
+    }
+    if (A.status) A.status[lane] = w.status;
 }
 
 #ifndef JM_HOST_EMU
 template<class T, class Tp>
 __global__ void __launch_bounds__(64) k_batch(const BatchArgs<T> A)
 {
-    __shared__ T lds[stage_rows<Tp>() * 64];
+    __shared__ T lds[lane_rows<T, Tp>() * 64];
     const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
     if (lane >= A.B) return;
     lane_run<T, Tp, 64>(A, lane, lds + threadIdx.x);

@@ -405,7 +405,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         else run_quad<T, Topo>(A, P);
         return 0;
     }
-    std::vector<T> sb(jm::stage_rows<Topo>() + 1, (T)std::nan(""));
+    std::vector<T> sb(jm::lane_rows<T, Topo>() + 1, (T)std::nan(""));
     if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
     {
         std::vector<T> wsp((size_t)(jm::ConRows<Topo>::WTOTAL + 1) * io->B, (T)std::nan(""));

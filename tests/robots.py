@@ -187,3 +187,10 @@ def anymal_held() -> CompiledModel:
 def frame_constraint_models() -> List[CompiledModel]:
     return [two_masses_fixed_second(), sphere_fixed_frame(), pendulum_ff_fixed_world(), tree_arm_own_locks(False),
             tree_arm_own_locks(True), rolling_ball(), rolling_wheel(), tethered_mass(), two_masses_rod(), anymal_held()]
+
+
+def arm7() -> CompiledModel:
+    """Seven-joint fixed-base arm: a serial chain, i.e. the kind of robot the branch-parallel kernels
+    cannot take (no leaf chains on a free-flyer) and the one-robot-per-lane kernels get."""
+    return build_robot(os.path.join(DATA, "arm7.urdf"), os.path.join(DATA, "arm7_hardware.toml"),
+                       has_freeflyer=False, name="arm7")

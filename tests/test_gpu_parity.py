@@ -59,7 +59,7 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
     assert np.array_equal(eng.status.cpu().numpy()[ok], ref["status"][0][ok])
 
 
-@pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff",
+@pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff", "arm7",
                                    "crane_walker", "biped", "biped_torso"])
 def test_small_robots_cover_every_joint_type(gpu_device, robot):
     """Authored test robots: aligned / unaligned revolute and prismatic joints, unbounded joints,
@@ -69,7 +69,7 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
     with two / three leaf chains only (empty limbs)."""
     from tests import robots
     model = {"pendulum": robots.pendulum, "point_mass": robots.point_mass, "two_masses": robots.two_masses,
-             "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True),
+             "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True), "arm7": robots.arm7,
              "crane_walker": robots.crane_walker, "biped": robots.biped, "biped_torso": lambda: robots.biped(True)}[robot]()
     quad = robot in ("crane_walker", "biped", "biped_torso")
     if quad:

@@ -24,6 +24,7 @@ def _models():
         "two_masses": robots.two_masses,
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
+        "arm7": robots.arm7,
         "crane_walker": robots.crane_walker,
         "biped": robots.biped,
         "biped_torso": lambda: robots.biped(True),
