@@ -767,24 +767,6 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
     constexpr int NJ = Tp::NJ;
     const long long B = A.B;
     const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
-    // true spatial accelerations (ForwardKinematicsAccelerationStep, engine.cc:858-868)
-    Sp<T> da[NJ], dagf[NJ];
-    static_for<1, NJ>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int p = Tp::parent[j];
-        const Sp<T> vj = joint_S_times<T, Tp, j>(P, v);
-        const Sp<T> aj = cross_mm(w.vel[j], vj) + joint_S_times<T, Tp, j>(P, acc);
-        if constexpr (p > 0)
-        {
-            da[j] = aj + actinv_motion(w.liMi[j], da[p]);
-            dagf[j] = aj + actinv_motion(w.liMi[j], dagf[p]);
-        }
-        else
-        {
-            da[j] = aj;  // data.a[0] = 0
-            dagf[j] = aj + actinv_motion(w.liMi[j], Sp<T>{-g, -gw});
-        }
-    });
     if (A.energy)
     {
         T kin = T(0), pot = T(0), rot = T(0);
@@ -802,44 +784,75 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
         A.energy[lane] = T(0.5) * kin + T(0.5) * rot;
         A.energy[B + lane] = pot;
     }
+    // true spatial accelerations (ForwardKinematicsAccelerationStep, engine.cc:858-868)
+    Sp<T> da[NJ], dagf[NJ];
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int p = Tp::parent[j];
+        const Sp<T> vj = joint_S_times<T, Tp, j>(P, v);
+        const Sp<T> aj = cross_mm(w.vel[j], vj) + joint_S_times<T, Tp, j>(P, acc);
+        const SE3<T> M = limi_of<T, Tp, j>(P, w);
+        if constexpr (p > 0)
+        {
+            da[j] = aj + actinv_motion(M, da[p]);
+            dagf[j] = aj + actinv_motion(M, dagf[p]);
+        }
+        else
+        {
+            da[j] = aj;  // data.a[0] = 0
+            dagf[j] = aj + actinv_motion(M, Sp<T>{-g, -gw});
+        }
+    });
     if (A.joint_forces || A.centroidal)
     {
         // RNEA-like sweeps (engine.cc:870-887)
-        Sp<T> h[NJ], fB[NJ], fj[NJ];
-        static_for<1, NJ>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
-            h[j] = rbi_mul(Y, w.vel[j]);
-            const Sp<T> vxh = cross_mf(w.vel[j], h[j]);
-            fB[j] = rbi_mul(Y, da[j]) + vxh;
-            fj[j] = vxh + rbi_mul(Y, dagf[j]) - w.fext[j];
-        });
+        // (momenta and wrenches are formed at the visit of the backward sweep and handed up: the frontier of the sweep
+        // is all that is alive, not three spatial vectors per joint)
+        Sp<T> hup[NJ], fBup[NJ], fjup[NJ];
         Sp<T> h0 = zero6<T>(), fB0 = zero6<T>();
+        if (A.joint_forces) static_for<0, 6>([&](auto kc) { A.joint_forces[decltype(kc)::value * B + lane] = T(0); });
         static_rfor<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int p = Tp::parent[j];
+            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+            Sp<T> hj = rbi_mul(Y, w.vel[j]);
+            const Sp<T> vxh = cross_mf(w.vel[j], hj);
+            Sp<T> fBj = rbi_mul(Y, da[j]) + vxh;
+            Sp<T> fjj = vxh + rbi_mul(Y, dagf[j]) - w.fext[j];
+            if constexpr (Tp::nchildren[j] > 0)
+            {
+                hj = hj + hup[j];
+                fBj = fBj + fBup[j];
+                fjj = fjj + fjup[j];
+            }
+            if (A.joint_forces)
+            {
+                T * o = A.joint_forces + (long long)(6 * j) * B + lane;
+                o[0] = fjj.l.x; o[B] = fjj.l.y; o[2 * B] = fjj.l.z;
+                o[3 * B] = fjj.a.x; o[4 * B] = fjj.a.y; o[5 * B] = fjj.a.z;
+            }
+            const SE3<T> M = limi_of<T, Tp, j>(P, w);
             if constexpr (p > 0)
             {
-                fB[p] = fB[p] + act_force(w.liMi[j], fB[j]);
-                h[p] = h[p] + act_force(w.liMi[j], h[j]);
-                fj[p] = fj[p] + act_force(w.liMi[j], fj[j]);
+                if constexpr (Tp::first_child[p] == j)
+                {
+                    fBup[p] = act_force(M, fBj);
+                    hup[p] = act_force(M, hj);
+                    fjup[p] = act_force(M, fjj);
+                }
+                else
+                {
+                    fBup[p] = fBup[p] + act_force(M, fBj);
+                    hup[p] = hup[p] + act_force(M, hj);
+                    fjup[p] = fjup[p] + act_force(M, fjj);
+                }
             }
             else
             {
-                fB0 = fB0 + act_force(w.liMi[j], fB[j]);
-                h0 = h0 + act_force(w.liMi[j], h[j]);
+                fB0 = fB0 + act_force(M, fBj);
+                h0 = h0 + act_force(M, hj);
             }
         });
-        if (A.joint_forces)
-        {
-            static_for<0, 6>([&](auto kc) { A.joint_forces[decltype(kc)::value * B + lane] = T(0); });
-            static_for<1, NJ>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                T * o = A.joint_forces + (long long)(6 * j) * B + lane;
-                o[0] = fj[j].l.x; o[B] = fj[j].l.y; o[2 * B] = fj[j].l.z;
-                o[3 * B] = fj[j].a.x; o[4 * B] = fj[j].a.y; o[5 * B] = fj[j].a.z;
-            });
-        }
         if (A.centroidal)
         {
             // subtree inertia of joint 1 (engine.cc:817-832) -> com (engine.cc:889-904)
@@ -856,12 +869,14 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
                 constexpr int p = Tp::parent[j];
                 if constexpr (p > 0)
                 {
-                    mc[p] = mc[p] + w.liMi[j].R * mc[j] + ms[j] * w.liMi[j].p;
+                    const SE3<T> M = limi_of<T, Tp, j>(P, w);
+                    mc[p] = mc[p] + M.R * mc[j] + ms[j] * M.p;
                     ms[p] = ms[p] + ms[j];
                 }
             });
             const V3<T> c1 = (T(1) / ms[1]) * mc[1];
-            const V3<T> com0 = w.liMi[1].R * c1 + w.liMi[1].p;
+            const SE3<T> M1 = limi_of<T, Tp, 1>(P, w);
+            const V3<T> com0 = M1.R * c1 + M1.p;
             Sp<T> hg = h0, dhg = fB0;
             hg.a = hg.a + cross(hg.l, com0);
             dhg.a = dhg.a + cross(dhg.l, com0);
