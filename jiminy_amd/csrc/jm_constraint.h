@@ -330,8 +330,9 @@ JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb,
             ur[iv] = uj;
             if constexpr (p > 0)
             {
-                const T ud = uj * w.dinv[j];
-                const Sp<T> pa = {pf.l + ud * w.U[j].l, pf.a + ud * w.U[j].a};
+                const T ud = uj * sweep_dinv<T, Tp, j>(w);
+                const Sp<T> Uj = sweep_U<T, Tp, j>(w);
+                const Sp<T> pa = {pf.l + ud * Uj.l, pf.a + ud * Uj.a};
                 acc[d - 1] = acc[d - 1] + act_force(limi_rebuilt<T, Tp, j>(P, w), pa);
             }
         }
@@ -355,8 +356,9 @@ JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb,
             Sp<T> ag;
             if constexpr (p > 0) ag = actinv_motion(limi_rebuilt<T, Tp, j>(P, w), lvl[d - 1]);
             else ag = zero6<T>();
-            const T Ua = dot(w.U[j].l, ag.l) + dot(w.U[j].a, ag.a);
-            const T ddj = w.dinv[j] * (ur[iv] - Ua);
+            const Sp<T> Uj = sweep_U<T, Tp, j>(w);
+            const T Ua = dot(Uj.l, ag.l) + dot(Uj.a, ag.a);
+            const T ddj = sweep_dinv<T, Tp, j>(w) * (ur[iv] - Ua);
             const V3<T> n = joint_axis<T, Tp, j>(P);
             if constexpr (jt_is_rev(t)) lvl[d] = {ag.l, ag.a + ddj * n};
             else lvl[d] = {ag.l + ddj * n, ag.a};
@@ -709,10 +711,15 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     // evaluation, which an adaptive step took at this very state) are applied to the free acceleration, so
     // that the outputs are the ones the reference reads after its last evaluation (engine.cc:2143-2151)
     const bool refresh = start_passes < 0;
-    // ---- unconstrained part: FK, motors, ABA without contact forces
-    eval_dynamics<T, Tp>(P, q, v, cmd, w);
+    // ---- unconstrained part: FK, motors (the ABA without contact forces follows the switching: lanes without an
+    // active constraint -- the common case -- run it in a branch of their own that nothing of the solve lives across)
+    eval_kinematics<T, Tp>(P, q, v, cmd, w);
     w.status &= ~JM_LANE_SOLVER_FAILURE;
-    if constexpr (NR == 0) return;
+    if constexpr (NR == 0)
+    {
+        eval_aba<T, Tp>(P, v, w);
+        return;
+    }
     auto flag = [&](int r) -> int32_t & { return C.flags[(size_t)r * B + lane]; };
     auto dat = [&](int r) -> T & { return C.data[(size_t)r * B + lane]; };
     auto lam = [&](int r) -> T & { return C.data[(size_t)(R::LAM + r) * B + lane]; };
@@ -836,7 +843,16 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
             act.set(R::XJ0 + k);
         }
     });
-    if (!act.any()) return;  // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
+    if (!act.any())
+    {
+        // Engine::computeAcceleration: plain ABA (engine.cc:3861-3865)
+#ifndef JM_HOST_EMU
+        asm volatile("; free lane: sweeps of its own");   // (keeps this copy from being merged with the one below)
+#endif
+        eval_aba<T, Tp>(P, v, w);
+        return;
+    }
+    eval_aba<T, Tp>(P, v, w);
     // joints whose acceleration some active row reads (columns of the delassus matrix)
     unsigned long long fmask = 0ull;
     static_for<0, R::NXJ>([&](auto kc) {
@@ -1366,13 +1382,46 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
     });
 }
 
+// What an evaluation's last pass adds to the efforts / external wrenches / contact forces of the kinematic half, from
+// the flags and multipliers it stored (engine.cc:3770-3857: bounds into u, contacts into fExternal; user constraints act
+// through the accelerations only)
+template<class T, class Tp, class CA>
+JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WorkC<T, Tp> & w, const CA & C, long long lane, long long B)
+{
+    using L = Layout<Tp>;
+    using R = ConRows<Tp>;
+    if constexpr (R::NR == 0) return;
+    static_for<0, R::NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int iv = Tp::idx_v[R::bjoint(k)];
+        const int32_t f = C.flags[(size_t)k * B + lane];
+        if ((f & 1) && !(f & 4)) w.ueff[iv] += C.data[(size_t)(R::LAM + k) * B + lane];
+    });
+    for_contacts<Tp>([&](auto jc, int c) {
+        constexpr int j = decltype(jc)::value;
+        const int r0 = R::NB + 4 * c;
+        if (C.flags[(size_t)(R::NB + c) * B + lane] & 1)
+        {
+            auto lam = [&](int r) { return C.data[(size_t)(R::LAM + r) * B + lane]; };
+            const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);
+            const V3<T> fW = {lam(r0), lam(r0 + 1), lam(r0 + 2)};
+            const V3<T> tW = {T(0), T(0), lam(r0 + 3)};
+            Sp<T> fl;
+            fl.l = tmul(w.oMi[j].R, fW);
+            fl.a = tmul(w.oMi[j].R, tW) + cross(fr.p, fl.l);
+            w.fext[j] = w.fext[j] + fl;
+            w.cf[c] = {tmul(fr.R, fl.l), tmul(fr.R, tmul(w.oMi[j].R, tW))};
+        }
+    });
+}
+
 #ifndef JM_HOST_EMU
 // One wave per SIMD (512 registers): capping the registers for 2-3 resident waves was measured 1.5x
 // slower (more spill traffic), see DESIGN.md section 4.8.
 template<class T, class Tp>
 __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const ConArgs<T> C)
 {
-    __shared__ T lds[stage_rows<Tp>() * 64];
+    T * const lds = lane_lds<T, Tp>();
     const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
     if (lane >= A.B) return;
     ConArgs<T> Cl = C;

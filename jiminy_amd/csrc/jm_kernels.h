@@ -140,6 +140,12 @@ template<class T> struct BatchArgs
 // the lane status into the existing one: the closing launch of an adaptive-step interval
 enum { MODE_STEP = 0, MODE_START = 1, MODE_DYNAMICS = 2, MODE_RESET = 3, MODE_REFRESH = 4 };
 
+// stride between the rows of a lane's on-chip buffer (stage rows + stash): the 64 lanes of the block interleave
+#ifdef JM_HOST_EMU
+constexpr int LANE_STRIDE = 1;
+#else
+constexpr int LANE_STRIDE = 64;
+#endif
 // ---------------------------------------------------------------- per-lane working set
 template<class T, class Tp> struct Work
 {
@@ -159,6 +165,8 @@ template<class T, class Tp> struct Work
     // joint coordinate of every 1-dof joint as (cos, sin) or (displacement, -): the sweeps rebuild liMi from
     // these 2 scalars + the constant placement (scalar loads) instead of keeping 12 scalars per joint alive
     T jcs[Tp::NJ][2];
+    // the lane's column of the sweeps' stash (LDS on the device, see eval_aba): element r at stash[r * LANE_STRIDE]
+    T * stash;
     int status;
     static constexpr bool CONSTRAINED = false;
 };
@@ -557,9 +565,10 @@ template<class T, class Tp, int J, class W> JM_DEV Sp<T> joint_bias_acc(CPtr<T> 
     return cross_mm(vj, joint_S_times<T, Tp, J>(P, v));  // c_j = 0 for every supported joint
 }
 // What the backward sweep leaves for the forward sweep -- U_j (6), 1/D_j, the reduced effort u_j of every 1-dof
-// joint -- is written once and read once, with both sweeps' whole working set in between: the plain lane kernel
-// parks it in LDS (`stash`: element r of the lane at stash[r * SS]) instead of leaving it to the register
-// allocator's scratch spills.  Joints are served from the leaves (produced first, consumed last) while rows last.
+// joint -- is written once and read once, with both sweeps' whole working set in between (and, under the constraint
+// model, every bias-free solve of the delassus columns reads U_j and 1/D_j again): the lane kernels park it in LDS
+// (`Work::stash`) instead of leaving it to the register allocator's scratch spills.  Joints are served from the
+// leaves (produced first, consumed last) while rows last.
 template<class Tp> constexpr int stash_rows_wanted() { return 8 * (Tp::NJ - 1); }
 template<class T, class Tp> constexpr int stash_rows()
 {
@@ -569,13 +578,52 @@ template<class T, class Tp> constexpr int stash_rows()
     if (Tp::NJ - 1 < 4) return 0;   // short chains fit their sweeps in registers
     return budget <= 0 ? 0 : (want < budget ? want : (budget / 8) * 8);
 }
-template<class T, class Tp, int SS, class W>
-JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w, T * stash)
+template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
+// rows of the per-lane buffer of the lane kernels: the Runge-Kutta stage rows, then the sweeps' stash
+template<class T, class Tp> constexpr int lane_rows() { return stage_rows<Tp>() + stash_rows<T, Tp>(); }
+#ifndef JM_HOST_EMU
+// the block's buffer (one object per topology and scalar type, named here so that every access is an LDS instruction
+// with a constant base: a pointer kept in the working set decays to a generic one)
+template<class T, class Tp> JM_DEV T * lane_lds()
+{
+    __shared__ T buf[lane_rows<T, Tp>() * 64];
+    return buf;
+}
+#endif
+template<class T, class Tp, class W> JM_DEV T * stash_of(const W & w)
+{
+#ifdef JM_HOST_EMU
+    return w.stash;
+#else
+    (void)w;
+    return lane_lds<T, Tp>() + stage_rows<Tp>() * 64 + threadIdx.x;
+#endif
+}
+// joints NJ-1, NJ-2, ... are parked while rows last
+template<class T, class Tp, int J> constexpr bool stashed() { return Tp::NJ - J <= stash_rows<T, Tp>() / 8; }
+// what the sweeps left for joint J: U_J, 1/D_J (read by the forward sweep and by the bias-free solves)
+template<class T, class Tp, int J, class W> JM_DEV Sp<T> sweep_U(const W & w)
+{
+    if constexpr (stashed<T, Tp, J>())
+    {
+        constexpr int SS = LANE_STRIDE;
+        const T * o = stash_of<T, Tp>(w) + (8 * (Tp::NJ - 1 - J)) * SS;
+        return {{o[0], o[SS], o[2 * SS]}, {o[3 * SS], o[4 * SS], o[5 * SS]}};
+    }
+    else return w.U[J];
+}
+template<class T, class Tp, int J, class W> JM_DEV T sweep_dinv(const W & w)
+{
+    if constexpr (stashed<T, Tp, J>()) return stash_of<T, Tp>(w)[(8 * (Tp::NJ - 1 - J) + 6) * LANE_STRIDE];
+    else return w.dinv[J];
+}
+template<class T, class Tp, class W>
+JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
 {
     using L = Layout<Tp>;
     constexpr int NJ = Tp::NJ;
-    constexpr int NSTASH = SS > 0 ? stash_rows<T, Tp>() / 8 : 0;   // joints NJ-1, NJ-2, ... NJ-NSTASH are parked
-    (void)stash;
+    constexpr int SS = LANE_STRIDE;
+    T * const stash = stash_of<T, Tp>(w);
     // ---- ABA pass 2 (AbaBackwardStep), leaves -> root; pass 1's force part f = v x* (I v) - fext at the visit
     AI<T> Yacc[NJ];
     Sp<T> facc[NJ];   // bias forces handed up by the children
@@ -641,9 +689,9 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w, T * stash)
             else U = {Ia.A * n, tmul(Ia.B, n)};
             const T D = joint_St_dot<T, Tp, j>(P, U) + P[L::ROTOR + iv];
             const T dinv = T(1) / D;
-            if constexpr (NJ - j <= NSTASH)
+            if constexpr (stashed<T, Tp, j>())
             {
-                T * o = stash + (long long)(8 * (NJ - 1 - j)) * SS;
+                T * o = stash + (8 * (NJ - 1 - j)) * SS;
                 o[0] = U.l.x; o[SS] = U.l.y; o[2 * SS] = U.l.z; o[3 * SS] = U.a.x; o[4 * SS] = U.a.y; o[5 * SS] = U.a.z;
                 o[6 * SS] = dinv; o[7 * SS] = uj;
             }
@@ -691,9 +739,9 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w, T * stash)
             const Sp<T> ag = joint_bias_acc<T, Tp, j>(P, v, w) + actinv_motion(limi_of<T, Tp, j>(P, w), ap);
             Sp<T> U;
             T dinv, uj;
-            if constexpr (NJ - j <= NSTASH)
+            if constexpr (stashed<T, Tp, j>())
             {
-                const T * o = stash + (long long)(8 * (NJ - 1 - j)) * SS;
+                const T * o = stash + (8 * (NJ - 1 - j)) * SS;
                 U = {{o[0], o[SS], o[2 * SS]}, {o[3 * SS], o[4 * SS], o[5 * SS]}};
                 dinv = o[6 * SS]; uj = o[7 * SS];
             }
@@ -712,11 +760,11 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w, T * stash)
     });
 }
 
-template<class T, class Tp, int SS = 0, class W>
-JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w, T * stash = nullptr)
+template<class T, class Tp, class W>
+JM_DEV void eval_dynamics(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w)
 {
     eval_kinematics<T, Tp>(P, q, v, cmd, w);
-    eval_aba<T, Tp, SS>(P, v, w, stash);
+    eval_aba<T, Tp>(P, v, w);
 }
 
 // ---------------------------------------------------------------- q (+) dv on the manifold
@@ -974,9 +1022,6 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 // the run-time `sb_stride` (stage rows kept in an HBM workspace, constraint-model kernel).
 // Rows: [0,NV) accumulated velocity increment, [NV,2NV) accumulated acceleration increment,
 //       [2NV,3NV) velocity of the previous stage.
-template<class Tp> constexpr int stage_rows() { return 3 * Tp::NV; }
-// rows of the per-lane buffer the plain lane kernel hands to lane_run: the stage rows, then the sweeps' stash
-template<class T, class Tp> constexpr int lane_rows() { return stage_rows<Tp>() + stash_rows<T, Tp>(); }
 
 // constraint contact model (jm_constraint.h): the free evaluation above + constraint switching +
 // the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence, < 0 only re-applies the
@@ -985,15 +1030,19 @@ template<class T, class Tp, class CA>
 JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
                              long long lane, long long B, int start_passes);
 
-template<class T, class Tp, class CON, int SS, class W>
+// efforts and wrenches of the stored multipliers on top of eval_kinematics' (the output pass of the constraint model)
+template<class T, class Tp, class CA>
+JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WorkC<T, Tp> & w, const CA & C, long long lane, long long B);
+
+template<class T, class Tp, class CON, class W>
 JM_DEV void eval_any(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w,
-                     const typename CON::template ArgsT<T> & C, long long lane, long long B, int start_passes, T * stash)
+                     const typename CON::template ArgsT<T> & C, long long lane, long long B, int start_passes)
 {
     if constexpr (CON::ON) eval_constrained<T, Tp>(P, q, v, cmd, w, C, lane, B, start_passes);
     else
     {
         (void)C; (void)lane; (void)B; (void)start_passes;
-        eval_dynamics<T, Tp, SS>(P, q, v, cmd, w, stash);
+        eval_dynamics<T, Tp>(P, q, v, cmd, w);
     }
 }
 
@@ -1008,9 +1057,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
     const long long B = A.B;
     CPtr<T> P = (CPtr<T>)A.P;
     typename CON::template WorkT<T, Tp> w;
-    // the sweeps' stash follows the stage rows when the caller's buffer has a compile-time stride (the plain kernel)
-    constexpr int SS = CON::ON ? 0 : SBS;
-    T * const stash = sb + (long long)stage_rows<Tp>() * SS;
+    // the sweeps' stash follows the stage rows
+    static_assert(SBS == LANE_STRIDE, "the lane buffer interleaves the lanes of a block");
     T qs[NQ], vs[NV], as[NV], cmd[c_max(NM, 1)];
 #ifdef JM_HOST_EMU
     // poison everything a GPU lane would find uninitialised: a read-before-write shows up as NaN
@@ -1018,6 +1066,7 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
     std::memset(qs, 0xFF, sizeof(qs)); std::memset(vs, 0xFF, sizeof(vs)); std::memset(as, 0xFF, sizeof(as));
 #endif
     w.status = 0;
+    w.stash = sb + (long long)stage_rows<Tp>() * SBS;
     static_for<0, NM>([&](auto mc) { cmd[decltype(mc)::value] = A.command[decltype(mc)::value * B + lane]; });
 
     if (A.mode == MODE_RESET)
@@ -1035,8 +1084,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
         const T * vsrc = (A.mode == MODE_DYNAMICS) ? A.v_in : A.v;
         static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = qsrc[decltype(ic)::value * B + lane]; });
         static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = vsrc[decltype(ic)::value * B + lane]; });
-        eval_any<T, Tp, CON, SS>(P, qs, vs, cmd, w, C, lane, B,
-                                 (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0), stash);
+        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B,
+                             (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0));
         if (A.mode == MODE_DYNAMICS)
         {
             static_for<0, NV>([&](auto ic) { A.a_out[decltype(ic)::value * B + lane] = w.ddq[decltype(ic)::value]; });
@@ -1125,16 +1174,26 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
                 static_for<0, NV>([&](auto ic) { A.v[decltype(ic)::value * B + lane] = vs[decltype(ic)::value]; });
             }
         }
-        eval_any<T, Tp, CON, SS>(P, qs, vs, cmd, w, C, lane, B, 0, stash);
+        eval_any<T, Tp, CON>(P, qs, vs, cmd, w, C, lane, B, 0);
         static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = w.ddq[decltype(ic)::value]; });
         if (k == -1 || k == 3)
             static_for<0, NV>([&](auto ic) { adst[decltype(ic)::value * B + lane] = as[decltype(ic)::value]; });
-        if constexpr (CON::ON)
-        {
-            if (e == n_evals - 1) extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.update_sensors != 0);
-        }
     }
-    if constexpr (!CON::ON)
+    if constexpr (CON::ON)
+    {
+        // constraint model: kinematics of its own at the closing state + the forces of the multipliers the closing
+        // evaluation stored
+        if (n_evals <= 0) return;
+        static_for<0, NQ>([&](auto ic) { qs[decltype(ic)::value] = A.q[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { vs[decltype(ic)::value] = A.v[decltype(ic)::value * B + lane]; });
+        static_for<0, NV>([&](auto ic) { as[decltype(ic)::value] = A.a[decltype(ic)::value * B + lane]; });
+        const int status = w.status;
+        eval_kinematics<T, Tp>(P, qs, vs, cmd, w);
+        w.status |= status;
+        constraint_forces_from_multipliers<T, Tp>(P, w, C, lane, B);
+        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.update_sensors != 0);
+    }
+    else
     {
         if (n_evals <= 0 || A.mode == MODE_DYNAMICS) return;
         // the output pass takes its kinematics from an evaluation of its own at the closing state: nothing but
@@ -1156,7 +1215,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
             });
             if (fmax2 > T(1e10)) w.status |= JM_LANE_FORCE_OVERFLOW;
         }
-        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w, A.mode != MODE_REFRESH || A.update_sensors != 0);
+        extra_terms_and_outputs<T, Tp>(P, A, lane, qs, vs, as, w,
+                                       A.update_sensors != 0 || (!stepping && A.mode != MODE_REFRESH));
         if (A.status) A.status[lane] = (A.mode == MODE_REFRESH) ? (A.status[lane] | w.status) : w.status;
         return;
     }
@@ -1167,10 +1227,9 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
 template<class T, class Tp>
 __global__ void __launch_bounds__(64) k_batch(const BatchArgs<T> A)
 {
-    __shared__ T lds[lane_rows<T, Tp>() * 64];
     const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
     if (lane >= A.B) return;
-    lane_run<T, Tp, 64>(A, lane, lds + threadIdx.x);
+    lane_run<T, Tp, 64>(A, lane, lane_lds<T, Tp>() + threadIdx.x);
 }
 #endif
 }  // namespace jm

@@ -90,7 +90,7 @@ def foot_pendulum() -> CompiledModel:
 
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
-            tree_arm(True), crane_walker(), biped(False), biped(True)]
+            tree_arm(True), crane_walker(), biped(False), biped(True), arm7()]
 
 
 # ---- robots of the reference's user-FrameConstraint tests, restated (the constraint frames are part of the topology)

@@ -22,7 +22,13 @@ def main():
     name, tag, want = argv[0], argv[1], argv[2:]
     os.environ["JIMINY_AMD_LIB_TAG"] = tag
     from jiminy_amd import codegen, load_builtin
-    model = load_builtin(name)
+    try:
+        model = load_builtin(name)
+    except LookupError:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import robots
+        fn = getattr(robots, name)
+        model = fn(False) if name == "tree_arm" else fn()
     hdr = codegen.write_header(model)
     v = codegen.preferred_variant(model)
     lib = codegen.lib_path(model, v)
@@ -30,7 +36,7 @@ def main():
     os.makedirs(objdir, exist_ok=True)
     common = [f"--offload-arch={codegen.OFFLOAD_ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
               f"-DJM_TOPO_HEADER=\"{hdr}\"", "-Wno-unused-value", "-ffp-contract=fast"] + list(codegen.BUILD_VARIANTS[v]) + extra
-    parts = [1, 2, 3, 4, 5, 6] + ([7, 8, 9, 10] if codegen.qcon_split(model) else [])
+    parts = ([1, 2, 3, 4, 5, 6] if codegen.quad_structure(model) is not None else [1]) + ([7, 8, 9, 10] if codegen.qcon_split(model) else [])
     pf = codegen.part_flags(model)
     units = {"main": [codegen.HIPCC] + common + ["-DJM_SPLIT_CONSTRAINT", "-c", os.path.join(codegen.CSRC, "jm_lib.cpp")]}
     for p in parts:

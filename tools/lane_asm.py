@@ -30,6 +30,6 @@ with open(src, "w") as f:
 out = f"/tmp/lane/{name}{'_con' if con else ''}.s"
 v = codegen.preferred_variant(model)
 cmd = [codegen.HIPCC, f"--offload-arch={codegen.OFFLOAD_ARCH}", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S",
-       "-I", codegen.CSRC, "-I", os.path.join(ROOT, "include"), "-Wno-unused-value", "-ffp-contract=fast"] + list(codegen.BUILD_VARIANTS[v]) + extra + [src, "-o", out]
+       "-I", os.environ.get("LANE_CSRC", codegen.CSRC), "-I", os.path.join(ROOT, "include"), "-Wno-unused-value", "-ffp-contract=fast"] + list(codegen.BUILD_VARIANTS[v]) + extra + [src, "-o", out]
 subprocess.check_call(cmd)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "loop_stats.py"), out, "k_"])
