@@ -303,17 +303,28 @@ def qcon_split_min() -> int:
     return int(os.environ.get("JIMINY_AMD_QCON_SPLIT_MIN", "32"))
 
 
+# Flags every topology compiles a unit with.  Unit 1 (the one-robot-per-lane constraint kernel): without the IR
+# load-store vectorizer.  Its scalar-register pressure is far beyond the file; under the basic SGPR allocator (the default
+# of every build) a spilled 16-dword tuple of model constants is re-loaded WHOLE (s_load_dwordx16 +
+# wait) in front of every single use: narrow loads halve the instructions of the kernel (round 5: 0.29 -> 0.25 ms on the
+# 7-joint arm, 0.22 -> 0.18 on `tree_arm`).
+DEFAULT_PART_FLAGS: Dict[str, List[str]] = {"1": ["-mllvm", "-amdgpu-load-store-vectorizer=0"]}
+
+
 def part_flags(model: CompiledModel) -> Dict[str, List[str]]:
     """Extra flags of single translation units of a topology (build_variants.json `part_flags`: {"5": ["-O1"]} compiles
-    the persistent adaptive kernel of that topology at -O1), appended after the common flags.
-    JIMINY_AMD_NO_PART_FLAGS=1 ignores them (re-testing whether a pinned unit still needs its flags)."""
+    the persistent adaptive kernel of that topology at -O1), appended after the common flags and DEFAULT_PART_FLAGS.
+    JIMINY_AMD_NO_PART_FLAGS=1 ignores the per-topology ones (re-testing whether a pinned unit still needs its flags)."""
+    flags = {k: list(v) for k, v in DEFAULT_PART_FLAGS.items()}
     if os.environ.get("JIMINY_AMD_NO_PART_FLAGS") == "1":
-        return {}
+        return flags
     try:
         with open(_VARIANT_FILE) as f:
-            return {str(k): list(v) for k, v in json.load(f).get(model.topology_hash(), {}).get("part_flags", {}).items()}
+            for k, v in json.load(f).get(model.topology_hash(), {}).get("part_flags", {}).items():
+                flags[str(k)] = flags.get(str(k), []) + list(v)
     except (OSError, ValueError):
-        return {}
+        pass
+    return flags
 
 
 def lib_path(model: CompiledModel, variant: Optional[int] = None) -> str:

@@ -117,9 +117,10 @@ def test_build_variants_bookkeeping(monkeypatch, tmp_path):
     fake = tmp_path / "pins.json"
     fake.write_text(json.dumps({model.topology_hash(): {"variant": 1, "part_flags": {"5": ["-O1"]}}, "_note": "x"}))
     monkeypatch.setattr(codegen, "_VARIANT_FILE", str(fake))
-    assert codegen.preferred_variant(model) == 1 and codegen.part_flags(model) == {"5": ["-O1"]}
+    assert codegen.preferred_variant(model) == 1
+    assert codegen.part_flags(model) == {**codegen.DEFAULT_PART_FLAGS, "5": ["-O1"]}
     monkeypatch.setenv("JIMINY_AMD_NO_PART_FLAGS", "1")
-    assert codegen.part_flags(model) == {}
+    assert codegen.part_flags(model) == codegen.DEFAULT_PART_FLAGS
     monkeypatch.setattr(codegen, "_VARIANT_FILE", str(tmp_path / "absent.json"))
     assert codegen.preferred_variant(model) == 0
 
