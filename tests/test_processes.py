@@ -105,3 +105,48 @@ def test_fourier_process_matches_the_scalar_restatement_and_its_series(wavelengt
     big = PeriodicFourierProcess(wavelength, period, 8192)
     big.reset(torch.Generator().manual_seed(1))
     assert abs(float(big.values.var()) - 2 * H / (2 * H + 1)) < 0.05
+
+
+def test_perlin_time_processes_match_the_scalar_restatement_lane_by_lane():
+    """`RandomPerlinProcess<1>` / `PeriodicPerlinProcess<1>` (random.h:564-590) as per-lane time processes: every lane equals
+    the scalar restatement reset from `PCG32(seed of the lane)` BIT FOR BIT (hash / table gradients, float32 draws, octave
+    wavelengths rounded into the period), a masked reset leaves the other lanes alone, the periodic one repeats with its
+    period, `grad` is the derivative of the value."""
+    from jiminy_amd.processes import PeriodicPerlinProcess, RandomPerlinProcess
+    from oracle import terrain_numpy
+    B = 6
+    times = (0.0, 0.13, 1.7, -2.4, 31.9)
+    rnd = RandomPerlinProcess(0.4, 5, B)
+    rnd.reset(100)
+    seeds = [5, 9, 11, 12, 400, 2 ** 40 + 3]
+    per = PeriodicPerlinProcess(0.4, 3.0, 4, B)
+    per.reset(torch.tensor(seeds))
+    for t in times:
+        got_r, got_p = rnd(t).numpy(), per(t).numpy()
+        for lane in range(B):
+            assert got_r[lane] == terrain_numpy.RandomPerlinProcess(0.4, 5, 1, 100 + lane)([t])
+            assert got_p[lane] == terrain_numpy.PeriodicPerlinProcess(0.4, 3.0, 4, 1, seeds[lane])([t])
+    # one time per lane
+    tt = torch.linspace(-1.0, 2.0, B, dtype=torch.float64)
+    got = per(tt).numpy()
+    for lane in range(B):
+        assert got[lane] == terrain_numpy.PeriodicPerlinProcess(0.4, 3.0, 4, 1, seeds[lane])([float(tt[lane])])
+    assert float((per(0.37) - per(3.37)).abs().max()) < 1e-12 and float((per(0.37) - per(-2.63)).abs().max()) < 1e-12
+    assert float((rnd(0.37) - rnd(3.37)).abs().min()) > 1e-6            # ... and the random one does not repeat
+    # masked reset
+    before = rnd(0.5).clone()
+    mask = torch.tensor([1, 0, 0, 1, 0, 0], dtype=torch.uint8)
+    rnd.reset(7000, lane_mask=mask)
+    after = rnd(0.5)
+    assert torch.equal(after[mask == 0], before[mask == 0]) and bool((after[mask == 1] != before[mask == 1]).all())
+    assert float(after[3]) == terrain_numpy.RandomPerlinProcess(0.4, 5, 1, 7003)([0.5])
+    # derivative, range
+    h = 1e-6
+    for p in (rnd, per):
+        assert float((p.grad(0.77) - (p(0.77 + h) - p(0.77 - h)) / (2 * h)).abs().max()) < 1e-8
+    dense = torch.stack([per(float(t)) for t in np.linspace(0.0, 3.0, 400)])
+    assert 0.05 < float(dense.abs().max()) < 1.5
+    with pytest.raises(ValueError):
+        PeriodicPerlinProcess(0.4, 0.3, 2, B)
+    with pytest.raises(ValueError):
+        RandomPerlinProcess(0.4, 0, B)
