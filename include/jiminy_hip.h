@@ -65,7 +65,12 @@ enum {
     JM_JT_RX = 1, JM_JT_RY = 2, JM_JT_RZ = 3, JM_JT_RU = 4,
     JM_JT_PX = 5, JM_JT_PY = 6, JM_JT_PZ = 7, JM_JT_PU = 8,
     JM_JT_RUBX = 9, JM_JT_RUBY = 10, JM_JT_RUBZ = 11, JM_JT_RUBU = 12,
-    JM_JT_FREEFLYER = 13
+    JM_JT_FREEFLYER = 13,
+    /* spherical joint (nq = 4: unit quaternion x y z w, nv = 3: angular velocity in the joint frame): the reference inserts
+     * them as FLEXIBILITY joints (Model::addFlexibilityJointsToExtendedModel, core/src/robot/model.cc:1087-1165) and
+     * applies a spring-damper on their rotation (Engine::computeInternalDynamics, core/src/engine/engine.cc:3365-3391).
+     * One-robot-per-lane kernels. */
+    JM_JT_SPHERICAL = 14
 };
 
 /* ---- scalar type of a batch */
@@ -158,6 +163,11 @@ typedef struct jm_model_desc {
      * keep the flag-bit-2 form on the joint's bound row (jm_batch_set_joint_locks). */
     int32_t n_constraint_joints;
     const int32_t * cjoint_joint;  /* [n_constraint_joints] */
+    /* ABI 8.  Flexibility of the spherical joints (`model_options["dynamics"]["flexibilityConfig"]`: stiffness, damping per
+     * axis; the `inertia` entry is the joint's rotor inertia): u_internal -= Jlog3(q) (stiffness * log3(q)) + damping * w,
+     * engine.cc:3377-3390.  [3 * njoints], rows of the other joints ignored; NULL when the model has no spherical joint. */
+    const double * flex_stiffness;
+    const double * flex_damping;
 } jm_model_desc;
 
 /* ---- hot-path subset of the engine options, same names/defaults as the reference

@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -63,6 +63,7 @@ class ModelDesc(C.Structure):
         ("cframe_joint", _pi), ("cframe_mask", _pi), ("cframe_R", _pd), ("cframe_p", _pd),
         ("cframe_kind", _pi), ("cframe_joint2", _pi), ("cframe_params", _pd),
         ("n_constraint_joints", C.c_int32), ("cjoint_joint", _pi),
+        ("flex_stiffness", _pd), ("flex_damping", _pd),
     ]
 
 
@@ -239,6 +240,8 @@ def make_model_desc(model: CompiledModel) -> Tuple[ModelDesc, List[np.ndarray]]:
     d.cframe_params = pd([constraint_frame_params(model, x) for x in model.constraint_frames])
     d.n_constraint_joints = len(model.constraint_joints)
     d.cjoint_joint = pi([x["joint"] for x in model.constraint_joints])
+    if getattr(model, "flex_stiffness", None) is not None:
+        d.flex_stiffness, d.flex_damping = pd(model.flex_stiffness), pd(model.flex_damping)
     return d, keep
 
 

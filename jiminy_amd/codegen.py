@@ -51,6 +51,8 @@ def quad_structure(model: CompiledModel):
         return None
     if model.constraint_frames or model.constraint_joints:     # user constraints on rows of their own: one-robot-per-lane constraint kernel (jm_constraint.h)
         return None
+    if any(int(t) == 14 for t in model.jtypes):                # spherical (flexibility) joints: one-robot-per-lane kernels
+        return None
     children = {j: [c for c in range(1, nj) if parents[c] == j] for j in range(nj)}
     if len(children[0]) != 1:
         return None

@@ -116,6 +116,14 @@ template<class T, class Tp> JM_DEV void difference_q(const T * q0, const T * q1,
             out[iv] = d.l.x; out[iv + 1] = d.l.y; out[iv + 2] = d.l.z;
             out[iv + 3] = d.a.x; out[iv + 4] = d.a.y; out[iv + 5] = d.a.z;
         }
+        else if constexpr (jt_is_sph(t))
+        {
+            // SpecialOrthogonalOperationTpl<3>::difference_impl: log3(R0^T R1)
+            const M3<T> R0 = quat_to_matrix(q0[iq], q0[iq + 1], q0[iq + 2], q0[iq + 3]);
+            const M3<T> R1 = quat_to_matrix(q1[iq], q1[iq + 1], q1[iq + 2], q1[iq + 3]);
+            const V3<T> d = log3(transpose(R0) * R1);
+            out[iv] = d.x; out[iv + 1] = d.y; out[iv + 2] = d.z;
+        }
         else if constexpr (jt_is_unb(t))
         {
             const T c = q0[iq] * q1[iq] + q0[iq + 1] * q1[iq + 1], sn = q0[iq] * q1[iq + 1] - q0[iq + 1] * q1[iq];

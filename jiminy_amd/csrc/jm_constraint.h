@@ -253,6 +253,7 @@ template<class T, class Tp, int J> JM_DEV SE3<T> limi_rebuilt(CPtr<T> P, const W
 #if JM_CON_REBUILD
     using L = Layout<Tp>;
     constexpr int t = Tp::jtype[J];
+    if constexpr (jt_is_sph(t)) return w.liMi[J];
     const SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
     SE3<T> Mj;
     if constexpr (jt_is_rev(t))
@@ -322,6 +323,20 @@ JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb,
             ur[iv] -= pf.l.x; ur[iv + 1] -= pf.l.y; ur[iv + 2] -= pf.l.z;
             ur[iv + 3] -= pf.a.x; ur[iv + 4] -= pf.a.y; ur[iv + 5] -= pf.a.z;
         }
+        else if constexpr (jt_is_sph(t))
+        {
+            // spherical joint: u -= S^T f (the angular part), pa = pf + U Dinv u with U = [B; D] of the last evaluation
+            constexpr int k = spherical_rank<Tp>(j);
+            const Sp<T> pf = acc[d] - fb(jc);
+            acc[d] = zero6<T>();
+            ur[iv] -= pf.a.x; ur[iv + 1] -= pf.a.y; ur[iv + 2] -= pf.a.z;
+            if constexpr (p > 0)
+            {
+                const V3<T> t3 = w.sphDinv[k] * V3<T>{ur[iv], ur[iv + 1], ur[iv + 2]};
+                const Sp<T> pa = {pf.l + w.sphB[k] * t3, pf.a + w.sphD[k] * t3};
+                acc[d - 1] = acc[d - 1] + act_force(limi_rebuilt<T, Tp, j>(P, w), pa);
+            }
+        }
         else if (!JM_CON_MASKS || ((bmask >> j) & 1ull))
         {
             const Sp<T> pf = acc[d] - fb(jc);
@@ -349,6 +364,18 @@ JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb,
             T b[6] = {ur[iv], ur[iv + 1], ur[iv + 2], ur[iv + 3], ur[iv + 4], ur[iv + 5]};
             chol6_resolve(w.rootA, w.rootdinv, b);
             lvl[d] = {{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
+            visit(jc, b, lvl[d]);
+        }
+        else if constexpr (jt_is_sph(t))
+        {
+            constexpr int k = spherical_rank<Tp>(j);
+            Sp<T> ag;
+            if constexpr (p > 0) ag = actinv_motion(limi_rebuilt<T, Tp, j>(P, w), lvl[d - 1]);
+            else ag = zero6<T>();
+            const V3<T> Ua = tmul(w.sphB[k], ag.l) + w.sphD[k] * ag.a;
+            const V3<T> dd = w.sphDinv[k] * (V3<T>{ur[iv], ur[iv + 1], ur[iv + 2]} - Ua);
+            const T b[3] = {dd.x, dd.y, dd.z};
+            lvl[d] = {ag.l, ag.a + dd};
             visit(jc, b, lvl[d]);
         }
         else if (!JM_CON_MASKS || ((fmask >> j) & 1ull))
@@ -1069,7 +1096,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                                 [&](auto jc, const T * ddj, const Sp<T> & daj) {
                                     constexpr int j = decltype(jc)::value;
                                     constexpr int iv = Tp::idx_v[j];
-                                    constexpr int nvj = Tp::jtype[j] == JM_JT_FREEFLYER ? 6 : 1;
+                                    constexpr int nvj = jt_nv(Tp::jtype[j]);
                                     static_for<0, nvj>([&](auto kc) { af[iv + decltype(kc)::value] += ddj[decltype(kc)::value]; });
                                     sa[j] = sa[j] + daj;
                                 });
@@ -1358,7 +1385,7 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                             [&](auto jc, const T * ddj, const Sp<T> &) {
                                 constexpr int j = decltype(jc)::value;
                                 constexpr int iv = Tp::idx_v[j];
-                                constexpr int nvj = Tp::jtype[j] == JM_JT_FREEFLYER ? 6 : 1;
+                                constexpr int nvj = jt_nv(Tp::jtype[j]);
                                 static_for<0, nvj>([&](auto kc) {
                                     w.ddq[iv + decltype(kc)::value] = af[iv + decltype(kc)::value] + ddj[decltype(kc)::value];
                                 });

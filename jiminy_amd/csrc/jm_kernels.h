@@ -51,6 +51,21 @@ constexpr bool jt_is_rev(int t) { return (t >= JM_JT_RX && t <= JM_JT_RU) || (t 
 constexpr bool jt_is_pri(int t) { return t >= JM_JT_PX && t <= JM_JT_PU; }
 constexpr bool jt_is_unb(int t) { return t >= JM_JT_RUBX && t <= JM_JT_RUBU; }
 constexpr bool jt_bounded(int t) { return t >= JM_JT_RX && t <= JM_JT_PU; }
+constexpr bool jt_is_sph(int t) { return t == JM_JT_SPHERICAL; }
+constexpr int jt_nv(int t) { return t == JM_JT_FREEFLYER ? 6 : (t == JM_JT_SPHERICAL ? 3 : (t == JM_JT_NONE ? 0 : 1)); }
+// spherical (flexibility) joints of a topology: how many, and the rank of joint j among them
+template<class Tp> constexpr int n_spherical()
+{
+    int n = 0;
+    for (int j = 0; j < Tp::NJ; ++j) n += Tp::jtype[j] == JM_JT_SPHERICAL ? 1 : 0;
+    return n;
+}
+template<class Tp> constexpr int spherical_rank(int j)
+{
+    int n = 0;
+    for (int i = 0; i < j; ++i) n += Tp::jtype[i] == JM_JT_SPHERICAL ? 1 : 0;
+    return n;
+}
 constexpr int jt_axis(int t)  // 0,1,2 aligned; -1 unaligned
 {
     return (t == JM_JT_RX || t == JM_JT_PX || t == JM_JT_RUBX) ? 0
@@ -75,7 +90,8 @@ template<class Tp> struct Layout
     static constexpr int ENC = FREL + Tp::NFORCE * Tp::NC * 12;        // NENC
     static constexpr int XFRAME = ENC + Tp::NENC;                      // NX * 12: user constraint frames (R9 p3)
     static constexpr int XPAR = XFRAME + Tp::NX * 12;                  // NX * 8: radius, normal 3, axis 3 | -, second frame position 3
-    static constexpr int OPT = XPAR + Tp::NX * 8;  // gravity6 k c mu eps vt
+    static constexpr int FLEX = XPAR + Tp::NX * 8;                     // 6 per spherical joint: stiffness 3, damping 3
+    static constexpr int OPT = FLEX + 6 * n_spherical<Tp>();  // gravity6 k c mu eps vt
     static constexpr int TOTAL = OPT + 11;
 };
 
@@ -165,6 +181,11 @@ template<class T, class Tp> struct Work
     // joint coordinate of every 1-dof joint as (cos, sin) or (displacement, -): the sweeps rebuild liMi from
     // these 2 scalars + the constant placement (scalar loads) instead of keeping 12 scalars per joint alive
     T jcs[Tp::NJ][2];
+    // spherical joints: what the backward sweep leaves for the forward one (U = [B; D] of the articulated inertia at the
+    // visit, the inverse of D + rotor inertia, the reduced effort)
+    M3<T> sphB[c_max(n_spherical<Tp>(), 1)];
+    S3<T> sphD[c_max(n_spherical<Tp>(), 1)], sphDinv[c_max(n_spherical<Tp>(), 1)];
+    V3<T> sphu[c_max(n_spherical<Tp>(), 1)];
     // the lane's column of the sweeps' stash (LDS on the device, see eval_aba): element r at stash[r * LANE_STRIDE]
     T * stash;
     int status;
@@ -210,6 +231,13 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
         vj = {{v[iv], v[iv + 1], v[iv + 2]}, {v[iv + 3], v[iv + 4], v[iv + 5]}};
         cs[0] = T(0); cs[1] = T(0);
     }
+    else if constexpr (jt_is_sph(t))
+    {
+        Mj.R = quat_to_matrix(q[iq], q[iq + 1], q[iq + 2], q[iq + 3]);
+        Mj.p = zero3<T>();
+        vj = {zero3<T>(), {v[iv], v[iv + 1], v[iv + 2]}};
+        cs[0] = T(0); cs[1] = T(0);
+    }
     else if constexpr (jt_is_rev(t))
     {
         T c, s;
@@ -246,7 +274,7 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
 template<class T, class Tp, int J, class W> JM_DEV SE3<T> limi_of(CPtr<T> P, const W & w)
 {
     constexpr int t = Tp::jtype[J];
-    if constexpr (t == JM_JT_FREEFLYER || !JM_LANE_REBUILD) return w.liMi[J];
+    if constexpr (t == JM_JT_FREEFLYER || jt_is_sph(t) || !JM_LANE_REBUILD) return w.liMi[J];
     else
     {
         using L = Layout<Tp>;
@@ -278,6 +306,8 @@ template<class T, class Tp, int J> JM_DEV Sp<T> joint_S_times(CPtr<T> P, const T
     constexpr int iv = Tp::idx_v[J];
     if constexpr (t == JM_JT_FREEFLYER)
         return {{x[iv], x[iv + 1], x[iv + 2]}, {x[iv + 3], x[iv + 4], x[iv + 5]}};
+    else if constexpr (jt_is_sph(t))
+        return {zero3<T>(), {x[iv], x[iv + 1], x[iv + 2]}};
     else if constexpr (jt_is_rev(t))
         return {zero3<T>(), x[iv] * joint_axis<T, Tp, J>(P)};
     else
@@ -551,6 +581,26 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
         w.umotor[m] = um;
         w.ueff[iv] += ut;
     });
+    // ---- flexibility of the spherical joints (Engine::computeInternalDynamics, engine.cc:3365-3391):
+    // u_internal -= Jlog3(q) (stiffness * log3(q)) + damping * w
+    static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (jt_is_sph(Tp::jtype[j]))
+        {
+            constexpr int iq = Tp::idx_q[j], iv = Tp::idx_v[j];
+            constexpr int o = L::FLEX + 6 * spherical_rank<Tp>(j);
+            T angle;
+            const V3<T> aa = quat_log3(q[iq], q[iq + 1], q[iq + 2], q[iq + 3], angle);
+            V3<T> t3 = jlog3_mul(angle, aa, V3<T>{P[o] * aa.x, P[o + 1] * aa.y, P[o + 2] * aa.z});
+            // "Flexible joint angle must be smaller than 0.95 * pi": the reference throws (engine.cc:3379-3383) -- a rejected
+            // trial of the adaptive stepper, the end of a fixed-step simulation.  The efforts become NaN and so does the
+            // acceleration, which takes those very paths (JM_LANE_NAN / a rejected attempt).
+            if (angle > T(0.95 * 3.14159265358979323846)) t3.x = T(__builtin_nan(""));
+            w.ueff[iv] -= t3.x + P[o + 3] * v[iv];
+            w.ueff[iv + 1] -= t3.y + P[o + 4] * v[iv + 1];
+            w.ueff[iv + 2] -= t3.z + P[o + 5] * v[iv + 2];
+        }
+    });
     static_for<0, Tp::NV>([&](auto ic) { w.u[decltype(ic)::value] = w.ueff[decltype(ic)::value]; });
 }
 
@@ -679,6 +729,41 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
             for (int k = 0; k < 6; ++k) w.ddq[iv + k] = b[k];
             w.agf[j] = w.agf[j] + Sp<T>{{b[0], b[1], b[2]}, {b[3], b[4], b[5]}};
         }
+        else if constexpr (jt_is_sph(t))
+        {
+            // JointModelSpherical::calc_aba: S = [0; 1]: U = [B; D], Dinv = (D + rotor)^-1, Ia -= U Dinv U^T
+            constexpr int k = spherical_rank<Tp>(j);
+            const V3<T> u3 = V3<T>{w.u[iv], w.u[iv + 1], w.u[iv + 2]} - w.f[j].a;
+            S3<T> Dm = Ia.D;
+            Dm.xx += P[L::ROTOR + iv]; Dm.yy += P[L::ROTOR + iv + 1]; Dm.zz += P[L::ROTOR + iv + 2];
+            const S3<T> Di = sym_inverse(Dm);
+            w.sphB[k] = Ia.B; w.sphD[k] = Ia.D; w.sphDinv[k] = Di; w.sphu[k] = u3;
+            if constexpr (p > 0)
+            {
+                const M3<T> Dif = full(Di), Df = full(Ia.D);
+                const M3<T> BDi = Ia.B * Dif, DDi = Df * Dif;
+                const M3<T> BDB = mul_bt(BDi, Ia.B), DDD = DDi * Df;
+                AI<T> Y;
+                Y.A = {Ia.A.xx - BDB.m00, Ia.A.xy - BDB.m01, Ia.A.xz - BDB.m02, Ia.A.yy - BDB.m11, Ia.A.yz - BDB.m12, Ia.A.zz - BDB.m22};
+                Y.B = Ia.B - BDi * Df;
+                Y.D = {Ia.D.xx - DDD.m00, Ia.D.xy - DDD.m01, Ia.D.xz - DDD.m02, Ia.D.yy - DDD.m11, Ia.D.yz - DDD.m12, Ia.D.zz - DDD.m22};
+                const Sp<T> Ya = ai_mul(Y, w.agf[j]);
+                const V3<T> t3 = Di * u3;
+                const Sp<T> pa = {w.f[j].l + Ya.l + Ia.B * t3, w.f[j].a + Ya.a + Ia.D * t3};
+                const SE3<T> M = limi_of<T, Tp, j>(P, w);
+                const AI<T> Tr = ai_transform(M, Y);
+                if constexpr (Tp::first_child[p] == j)
+                {
+                    Yacc[p] = ai_from_rbi(ld_rbi<T>(P, L::JOINT + p * L::JSTRIDE + 12)) + Tr;
+                    facc[p] = act_force(M, pa);
+                }
+                else
+                {
+                    Yacc[p] = Yacc[p] + Tr;
+                    facc[p] = facc[p] + act_force(M, pa);
+                }
+            }
+        }
         else
         {
             const V3<T> n = joint_axis<T, Tp, j>(P);
@@ -727,7 +812,23 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
         constexpr int p = Tp::parent[j];
         constexpr int t = Tp::jtype[j];
         constexpr int iv = Tp::idx_v[j];
-        if constexpr (t != JM_JT_FREEFLYER)
+        if constexpr (jt_is_sph(t))
+        {
+            constexpr int k = spherical_rank<Tp>(j);
+            Sp<T> ap;
+            if constexpr (p > 0) ap = w.agf[p];
+            else
+            {
+                const V3<T> g = ld_v3<T>(P, L::OPT), gw = ld_v3<T>(P, L::OPT + 3);
+                ap = {-g, -gw};
+            }
+            const Sp<T> ag = joint_bias_acc<T, Tp, j>(P, v, w) + actinv_motion(limi_of<T, Tp, j>(P, w), ap);
+            const V3<T> Ua = tmul(w.sphB[k], ag.l) + w.sphD[k] * ag.a;
+            const V3<T> dd = w.sphDinv[k] * (w.sphu[k] - Ua);
+            w.ddq[iv] = dd.x; w.ddq[iv + 1] = dd.y; w.ddq[iv + 2] = dd.z;
+            w.agf[j] = {ag.l, ag.a + dd};
+        }
+        else if constexpr (t != JM_JT_FREEFLYER)
         {
             Sp<T> ap;
             if constexpr (p > 0) ap = w.agf[p];
@@ -789,6 +890,16 @@ template<class T, class Tp> JM_DEV void integrate_q(CPtr<T> P, const T * q, cons
             const T al = sg * (T(3) - n2) * T(0.5);
             qo[iq] = M1.p.x; qo[iq + 1] = M1.p.y; qo[iq + 2] = M1.p.z;
             qo[iq + 3] = x * al; qo[iq + 4] = y * al; qo[iq + 5] = z * al; qo[iq + 6] = ww * al;
+        }
+        else if constexpr (jt_is_sph(t))
+        {
+            // SpecialOrthogonalOperationTpl<3>::integrate_impl: quat * exp3(omega), firstOrderNormalize
+            T e4[4], r[4];
+            quat_exp3(V3<T>{d[iv], d[iv + 1], d[iv + 2]}, e4);
+            quat_mul(q + iq, e4, r);
+            const T n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+            const T al = (T(3) - n2) * T(0.5);
+            qo[iq] = r[0] * al; qo[iq + 1] = r[1] * al; qo[iq + 2] = r[2] * al; qo[iq + 3] = r[3] * al;
         }
         else if constexpr (jt_is_unb(t))
         {

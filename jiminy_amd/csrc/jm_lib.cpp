@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 7
+#define JM_ABI_VERSION 8
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)

@@ -534,4 +534,75 @@ template<class T> JM_DEV V3<T> log3(const M3<T> & R)
     const T t = ((theta > Eps<T>::taylor) ? theta / s : T(1)) / T(2);
     return {t * (R.m21 - R.m12), t * (R.m02 - R.m20), t * (R.m10 - R.m01)};
 }
+
+// ---- spherical joints (the reference's flexibility joints): quaternions are stored x y z w like Eigen's
+// quaternion::exp3 (Pinocchio v2.7.0 math/quaternion.hpp): unit quaternion of a rotation vector
+template<class T> JM_DEV void quat_exp3(V3<T> v, T (&out)[4])
+{
+    const T t2 = dot(v, v);
+    const T ts_prec = sizeof(T) == 8 ? T(1.220703125e-4) : T(1.86264515e-2);   // eps^(1/4): TaylorSeriesExpansion::precision<3>()
+    T k, w;
+    if (t2 > ts_prec)
+    {
+        const T theta = sqrt_(t2);
+        T sh, ch;
+        sincos_(T(0.5) * theta, &sh, &ch);
+        k = sh / theta;
+        w = ch;
+    }
+    else
+    {
+        k = T(0.5) - t2 * T(1.0 / 48.0);
+        w = T(1) - t2 * T(0.125);
+    }
+    out[0] = k * v.x; out[1] = k * v.y; out[2] = k * v.z; out[3] = w;
+}
+// Hamilton product a * b
+template<class T> JM_DEV void quat_mul(const T * a, const T (&b)[4], T (&r)[4])
+{
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// quaternion::log3: rotation vector of a unit quaternion, `theta` >= 0 its angle
+template<class T> JM_DEV V3<T> quat_log3(T x, T y, T z, T w, T & theta)
+{
+    const T n2 = x * x + y * y + z * z;
+    const T n = sqrt_(n2);
+    const T ts_prec = sizeof(T) == 8 ? T(1.220703125e-4) : T(1.86264515e-2);
+    const T sgn = w >= T(0) ? T(1) : T(-1);
+    theta = T(2) * atan2_(n, sgn * w);
+    const T k = n2 > ts_prec ? sgn * theta / n : sgn * (T(2) / fabs_(w)) * (T(1) - n2 / (T(3) * w * w));
+    return {k * x, k * y, k * z};
+}
+// Jlog3 (Pinocchio v2.7.0 spatial/explog.hpp) applied to a vector: Jlog3(theta, lg) * v
+template<class T> JM_DEV V3<T> jlog3_mul(T theta, V3<T> lg, V3<T> v)
+{
+    const T ts_prec = sizeof(T) == 8 ? T(1.220703125e-4) : T(1.86264515e-2);
+    T alpha, diag;
+    if (theta < ts_prec)
+    {
+        alpha = T(1.0 / 12.0) + theta * theta * T(1.0 / 720.0);
+        diag = T(0.5) * (T(2) - theta * theta * T(1.0 / 6.0));
+    }
+    else
+    {
+        T st, ct;
+        sincos_(theta, &st, &ct);
+        const T st_1mct = st / (T(1) - ct);
+        alpha = T(1) / (theta * theta) - st_1mct / (T(2) * theta);
+        diag = T(0.5) * (theta * st_1mct);
+    }
+    // (alpha lg lg^T + diag 1 + [lg/2]x) v
+    return (alpha * dot(lg, v)) * lg + diag * v + T(0.5) * cross(lg, v);
+}
+// inverse of a symmetric positive definite 3x3 (cofactors)
+template<class T> JM_DEV S3<T> sym_inverse(const S3<T> & A)
+{
+    const T c00 = A.yy * A.zz - A.yz * A.yz, c01 = A.xz * A.yz - A.xy * A.zz, c02 = A.xy * A.yz - A.xz * A.yy;
+    const T idet = T(1) / (A.xx * c00 + A.xy * c01 + A.xz * c02);
+    return {c00 * idet, c01 * idet, c02 * idet, (A.xx * A.zz - A.xz * A.xz) * idet, (A.xy * A.xz - A.xx * A.yz) * idet,
+            (A.xx * A.yy - A.xy * A.xy) * idet};
+}
 }  // namespace jm

@@ -96,6 +96,17 @@ template<class Tp> inline std::vector<double> pack_model(const jm_model_desc & d
         put_frame(L::XFRAME + 12 * x, d.cframe_R + 9 * x, d.cframe_p + 3 * x);
         for (int k = 0; k < 8; ++k) P[L::XPAR + 8 * x + k] = d.cframe_params[8 * x + k];
     }
+    // flexibility of the spherical joints: stiffness 3, damping 3 (zero without a configuration)
+    for (int j = 0, k = 0; j < Tp::NJ; ++j)
+        if (Tp::jtype[j] == JM_JT_SPHERICAL)
+        {
+            for (int i = 0; i < 3; ++i)
+            {
+                P[L::FLEX + 6 * k + i] = d.flex_stiffness ? d.flex_stiffness[3 * j + i] : 0.0;
+                P[L::FLEX + 6 * k + 3 + i] = d.flex_damping ? d.flex_damping[3 * j + i] : 0.0;
+            }
+            ++k;
+        }
     return P;
 }
 // total size of the parameter block, including the limb table of the limb-parallel kernel

@@ -53,17 +53,20 @@ JT_PU = 8
 JT_RUBX, JT_RUBY, JT_RUBZ = 9, 10, 11
 JT_RUBU = 12
 JT_FREEFLYER = 13
+JT_SPHERICAL = 14     # flexibility joints (unit quaternion x y z w, angular velocity in the joint frame)
 
 JT_NQ = {JT_NONE: 0, JT_RX: 1, JT_RY: 1, JT_RZ: 1, JT_RU: 1,
          JT_PX: 1, JT_PY: 1, JT_PZ: 1, JT_PU: 1,
-         JT_RUBX: 2, JT_RUBY: 2, JT_RUBZ: 2, JT_RUBU: 2, JT_FREEFLYER: 7}
+         JT_RUBX: 2, JT_RUBY: 2, JT_RUBZ: 2, JT_RUBU: 2, JT_FREEFLYER: 7, JT_SPHERICAL: 4}
 JT_NV = {JT_NONE: 0, JT_RX: 1, JT_RY: 1, JT_RZ: 1, JT_RU: 1,
          JT_PX: 1, JT_PY: 1, JT_PZ: 1, JT_PU: 1,
-         JT_RUBX: 1, JT_RUBY: 1, JT_RUBZ: 1, JT_RUBU: 1, JT_FREEFLYER: 6}
+         JT_RUBX: 1, JT_RUBY: 1, JT_RUBZ: 1, JT_RUBU: 1, JT_FREEFLYER: 6, JT_SPHERICAL: 3}
 JT_NAME = {JT_NONE: "universe", JT_RX: "RX", JT_RY: "RY", JT_RZ: "RZ",
            JT_RU: "RU", JT_PX: "PX", JT_PY: "PY", JT_PZ: "PZ", JT_PU: "PU",
            JT_RUBX: "RUBX", JT_RUBY: "RUBY", JT_RUBZ: "RUBZ",
-           JT_RUBU: "RUBU", JT_FREEFLYER: "FF"}
+           JT_RUBU: "RUBU", JT_FREEFLYER: "FF", JT_SPHERICAL: "S"}
+FLEXIBLE_JOINT_SUFFIX = "Flexibility"   # core/include/jiminy/core/robot/model.h (name of a flexibility joint inserted
+                                        # in front of the mechanical joint `<name>`: `<name>Flexibility`)
 
 # Sensor type names follow the reference (core/src/hardware/basic_sensors.cc)
 SENSOR_TYPES = ("ImuSensor", "ContactSensor", "ForceSensor",
@@ -315,6 +318,9 @@ class CompiledModel:
     constraint_frames: List[Dict[str, Any]] = field(default_factory=list)
     # 1-dof joints a user `JointConstraint(joint)` may hold on a row of its own (`add_joint_constraint`): {"name", "joint"}
     constraint_joints: List[Dict[str, Any]] = field(default_factory=list)
+    # flexibility of the spherical joints (`flexibilityConfig`: stiffness / damping per axis), (njoints, 3); None: no such joint
+    flex_stiffness: Optional[np.ndarray] = None
+    flex_damping: Optional[np.ndarray] = None
 
     # ---- sizes
     @property
@@ -359,7 +365,14 @@ class CompiledModel:
                 q[iq] = 1.0
             elif t == JT_FREEFLYER:
                 q[iq + 6] = 1.0
+            elif t == JT_SPHERICAL:
+                q[iq + 3] = 1.0
         return q
+
+    @property
+    def flexibility_joint_indices(self) -> List[int]:
+        """≙ `robot.flexibility_joint_indices`."""
+        return [j for j in range(1, self.njoints) if int(self.jtypes[j]) == JT_SPHERICAL]
 
     def bounded_position_mask(self) -> np.ndarray:
         """nq mask of coordinates subject to position bounds (1-dof R/P joints only,
@@ -492,10 +505,23 @@ class CompiledModel:
 def build_model_from_urdf(urdf_path: str,
                           has_freeflyer: bool = False,
                           name: Optional[str] = None,
-                          gravity: Sequence[float] = (0.0, 0.0, -9.81, 0.0, 0.0, 0.0)
+                          gravity: Sequence[float] = (0.0, 0.0, -9.81, 0.0, 0.0, 0.0),
+                          flexibility: Optional[Sequence[Dict[str, Any]]] = None
                           ) -> CompiledModel:
-    """URDF -> CompiledModel without hardware (≙ `jiminy.Robot.initialize(urdf, has_freeflyer)`)."""
+    """URDF -> CompiledModel without hardware (≙ `jiminy.Robot.initialize(urdf, has_freeflyer)`).
+
+    `flexibility`: the reference's `model_options["dynamics"]["flexibilityConfig"]` with `enableFlexibility` -- a list of
+    `{"frameName", "stiffness" (3), "damping" (3), "inertia" (3)}`.  A spherical joint is inserted at every named frame
+    (Model::addFlexibilityJointsToExtendedModel, core/src/robot/model.cc:1087-1165): in FRONT of a mechanical joint of that name
+    (`<name>Flexibility`, at the joint's placement, the mechanical joint then sits at its origin; weightless body --
+    addFlexibilityJointBeforeMechanicalJoint, utilities/pinocchio.cc:460-503) or IN PLACE of a fixed joint of that name (the
+    links behind it hang on the new joint -- addFlexibilityJointAtFixedFrame :578-700); `inertia` is the joint's rotor
+    inertia.  Joints stay numbered depth-first (the reference re-sorts its joints after the insertion)."""
     robot_name, links, joints = _parse_urdf(urdf_path)
+    flex = {str(f["frameName"]): f for f in (flexibility or [])}
+    for fname in flex:
+        if fname not in joints:
+            raise LookupError(f"Frame '{fname}' does not exists. Impossible to insert flexibility joint on it.")
     children = {j.child for j in joints.values()}
     roots = [l for l in links if l not in children]
     if len(roots) != 1:
@@ -517,6 +543,23 @@ def build_model_from_urdf(urdf_path: str,
     eff: List[float] = []
     vel: List[float] = []
     frames: Dict[str, Frame] = {}
+    flex_of_joint: Dict[int, Dict[str, Any]] = {}
+
+    def add_spherical(jname: str, parent: int, M: SE3, cfg: Dict[str, Any]) -> int:
+        joint_names.append(jname)
+        parents.append(parent)
+        jtypes.append(JT_SPHERICAL)
+        axes.append(np.zeros(3))
+        placements.append(M)
+        inertias.append(Inertia())
+        lower.extend([-1.01] * 4)
+        upper.extend([1.01] * 4)
+        eff.extend([math.inf] * 3)
+        vel.extend([math.inf] * 3)
+        new = len(joint_names) - 1
+        flex_of_joint[new] = cfg
+        add_frame(jname, new, SE3(), "joint")
+        return new
 
     def add_frame(fname: str, jidx: int, M: SE3, kind: str) -> None:
         if fname in frames:
@@ -552,13 +595,22 @@ def build_model_from_urdf(urdf_path: str,
             inertias[jidx] = inertias[jidx].add(link.inertia.transformed(M_link))
         for uj in child_joints[link_name]:
             M_joint = M_link * uj.origin
-            if uj.jtype == "fixed":
+            if uj.jtype == "fixed" and uj.name in flex:
+                # flexibility in place of the fixed joint: what hangs behind it hangs on the spherical joint
+                new = add_spherical(uj.name, jidx, M_joint, flex[uj.name])
+                visit(uj.child, new, SE3())
+            elif uj.jtype == "fixed":
                 add_frame(uj.name, jidx, M_joint, "fixed_joint")
                 visit(uj.child, jidx, M_joint)
             else:
                 t, ax = _classify_joint(uj)
+                jparent = jidx
+                if uj.name in flex:
+                    # flexibility in front of the mechanical joint: at the joint's placement, the joint at its origin
+                    jparent = add_spherical(uj.name + FLEXIBLE_JOINT_SUFFIX, jidx, M_joint, flex[uj.name])
+                    M_joint = SE3()
                 joint_names.append(uj.name)
-                parents.append(jidx)
+                parents.append(jparent)
                 jtypes.append(t)
                 axes.append(ax)
                 placements.append(M_joint)
@@ -585,6 +637,14 @@ def build_model_from_urdf(urdf_path: str,
         idx_q[j], idx_v[j] = iq, iv
         iq += JT_NQ[jtypes[j]]
         iv += JT_NV[jtypes[j]]
+    rotor = np.zeros(iv)
+    fk = fd = None
+    if flex_of_joint:
+        fk, fd = np.zeros((n, 3)), np.zeros((n, 3))
+        for j, cfg in flex_of_joint.items():
+            fk[j] = np.asarray(cfg["stiffness"], dtype=np.float64)
+            fd[j] = np.asarray(cfg["damping"], dtype=np.float64)
+            rotor[idx_v[j]:idx_v[j] + 3] = np.asarray(cfg["inertia"], dtype=np.float64)   # model.cc:1133-1143
     model = CompiledModel(
         name=name or robot_name,
         has_freeflyer=has_freeflyer,
@@ -598,14 +658,21 @@ def build_model_from_urdf(urdf_path: str,
         mass=np.array([I.mass for I in inertias]),
         com=np.array([I.com for I in inertias]),
         inertia=np.array([I.I for I in inertias]),
-        rotor_inertia=np.zeros(iv),
+        rotor_inertia=rotor,
         position_lower=np.array(lower, dtype=np.float64),
         position_upper=np.array(upper, dtype=np.float64),
         effort_limit=np.array(eff, dtype=np.float64),
         velocity_limit=np.array(vel, dtype=np.float64),
         gravity=np.array(gravity, dtype=np.float64),
         frames=frames, motors=[], contacts=[],
-        sensors={k: [] for k in SENSOR_TYPES})
+        sensors={k: [] for k in SENSOR_TYPES}, flex_stiffness=fk, flex_damping=fd)
+    if flex_of_joint:
+        # model.cc:1146-1163: the diagonal inertia seen by a flexibility joint must not vanish
+        for j in flex_of_joint:
+            diag = rotor[idx_v[j]:idx_v[j] + 3] + np.diag(model.inertia[j])
+            if np.any(diag < 1e-5):
+                raise ValueError(f"The subtree diagonal inertia for flexibility joint {j} must be larger than 1e-5 for "
+                                 f"numerical stability: {diag}")
     model._urdf_links = links  # type: ignore[attr-defined]  (collision boxes for hardware loading)
     return model
 
@@ -856,13 +923,14 @@ def load_hardware_description_file(model: CompiledModel, hardware_path: str,
 
 
 def build_robot(urdf_path: str, hardware_path: Optional[str] = None,
-                has_freeflyer: bool = False, name: Optional[str] = None) -> CompiledModel:
+                has_freeflyer: bool = False, name: Optional[str] = None,
+                flexibility: Optional[Sequence[Dict[str, Any]]] = None) -> CompiledModel:
     """≙ `BaseJiminyRobot.initialize(urdf_path, hardware_path, has_freeflyer=...)`.
 
     As in the reference, a `<urdf>_hardware.toml` next to the URDF is picked up
     automatically when `hardware_path` is None.
     """
-    model = build_model_from_urdf(urdf_path, has_freeflyer, name)
+    model = build_model_from_urdf(urdf_path, has_freeflyer, name, flexibility=flexibility)
     if hardware_path is None:
         cand = os.path.splitext(urdf_path)[0] + "_hardware.toml"
         if os.path.exists(cand):

@@ -10,7 +10,7 @@ from typing import Dict
 
 import numpy as np
 
-from .model import (CompiledModel, JT_FREEFLYER, JT_RUBU, JT_RUBX, JT_RUBY, JT_RUBZ, JT_NV)
+from .model import (CompiledModel, JT_FREEFLYER, JT_RUBU, JT_RUBX, JT_RUBY, JT_RUBZ, JT_NV, JT_SPHERICAL)
 
 
 def _quat_from_axis_angle(axis: np.ndarray, angle: np.ndarray) -> np.ndarray:
@@ -56,6 +56,10 @@ def sample_states(model: CompiledModel, batch_size: int, seed: int = 0,
             axis = rng.normal(size=(3, B))
             q[iq + 3:iq + 7] = _quat_from_axis_angle(axis, rng.uniform(0.0, base_angle_max, B))
             v[iv:iv + 6] = rng.normal(0.0, base_twist_std, (6, B))
+        elif t == JT_SPHERICAL:
+            # flexibility joints: a small deflection and a slow rate
+            q[iq:iq + 4] = _quat_from_axis_angle(rng.normal(size=(3, B)), rng.uniform(0.0, 0.15, B))
+            v[iv:iv + 3] = rng.normal(0.0, 0.3, (3, B))
         elif t in (JT_RUBX, JT_RUBY, JT_RUBZ, JT_RUBU):
             th = rng.uniform(-small, small, B) if not floating else rng.uniform(-joint_range, joint_range, B)
             q[iq], q[iq + 1] = np.cos(th), np.sin(th)
@@ -120,6 +124,12 @@ def joint_world_placements(model: CompiledModel, q: np.ndarray):
                 np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
                 np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
             pj = q[iq:iq + 3].T
+        elif t == JT_SPHERICAL:
+            x, y, z, w = q[iq], q[iq + 1], q[iq + 2], q[iq + 3]
+            Rj = np.stack([
+                np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
         elif t in (JT_RX, JT_RY, JT_RZ, JT_RU, JT_RUBX, JT_RUBY, JT_RUBZ, JT_RUBU):
             c, s = (q[iq], q[iq + 1]) if t >= JT_RUBX else (np.cos(q[iq]), np.sin(q[iq]))
             Rj = _batched_rot(n, c, s)
@@ -169,6 +179,9 @@ def sample_standing_states(model: CompiledModel, batch_size: int, seed: int = 0,
             axis = rng.normal(size=(3, B))
             q[iq + 3:iq + 7] = _quat_from_axis_angle(axis, rng.uniform(0.0, base_angle_max, B))
             v[iv:iv + 6] = rng.normal(0.0, twist_std, (6, B))
+        elif t == JT_SPHERICAL:
+            q[iq:iq + 4] = _quat_from_axis_angle(rng.normal(size=(3, B)), rng.uniform(0.0, 0.15, B))
+            v[iv:iv + 3] = rng.normal(0.0, 0.3, (3, B))
         elif t in (JT_RUBX, JT_RUBY, JT_RUBZ, JT_RUBU):
             th = rng.uniform(-joint_noise, joint_noise, B)
             q[iq], q[iq + 1] = np.cos(th), np.sin(th)

@@ -402,6 +402,8 @@ struct Model
     std::vector<SE3> placement;
     std::vector<Inertia> inertia;
     std::vector<double> rotor, qlo, qhi;
+    // flexibility of the spherical joints (jm_model_desc::flex_stiffness / flex_damping, [3 * njoints]; empty: none)
+    std::vector<double> flex_k, flex_d;
     std::vector<MotorP> motors;
     std::vector<FrameP> contacts, imus, forces;
     // frames a user `FrameConstraint(frame, maskDoFs)` may hold (Model::addConstraint; jm_model_desc::cframe_*), bit d of the
@@ -420,7 +422,7 @@ struct Model
     std::vector<std::vector<std::pair<int, SE3>>> force_pairs;
 };
 
-inline int jt_nv(int t) { return t == JM_JT_FREEFLYER ? 6 : (t == JM_JT_NONE ? 0 : 1); }
+inline int jt_nv(int t) { return t == JM_JT_FREEFLYER ? 6 : (t == JM_JT_SPHERICAL ? 3 : (t == JM_JT_NONE ? 0 : 1)); }
 inline bool is_revolute(int t) { return (t >= JM_JT_RX && t <= JM_JT_RU) || (t >= JM_JT_RUBX && t <= JM_JT_RUBU); }
 inline bool is_prismatic(int t) { return t >= JM_JT_PX && t <= JM_JT_PU; }
 inline bool is_unbounded(int t) { return t >= JM_JT_RUBX && t <= JM_JT_RUBU; }
@@ -588,6 +590,12 @@ void joint_calc(const Model & m, int j, const double * q, const double * v, SE3 
         vj = motion6(vjv);
         return;
     }
+    if (t == JM_JT_SPHERICAL)   // JointModelSphericalTpl::calc: rotation of the unit quaternion, angular joint velocity
+    {
+        Mj.R = quat_to_matrix(qj[0], qj[1], qj[2], qj[3]);
+        vj.ang = {vjv[0], vjv[1], vjv[2]};
+        return;
+    }
     const V3 ax = joint_axis(m, j);
     if (is_revolute(t))
     {
@@ -608,8 +616,9 @@ Motion S_times(const Model & m, int j, const double * x)
 {
     const int t = m.jtype[j];
     if (t == JM_JT_FREEFLYER) return motion6(x);
-    const V3 ax = joint_axis(m, j);
     Motion r;
+    if (t == JM_JT_SPHERICAL) { r.ang = {x[0], x[1], x[2]}; return r; }
+    const V3 ax = joint_axis(m, j);
     if (is_revolute(t)) r.ang = x[0] * ax; else r.lin = x[0] * ax;
     return r;
 }
@@ -804,6 +813,33 @@ void aba(Engine & e, const double * q, const double * v, const double * tau, con
                     {
                         double s = 0;
                         for (int k = 0; k < 6; ++k) s += jd.UDinv[a][k] * jd.U[b][k];
+                        Ia.m[a][b] -= s;
+                    }
+        }
+        else if (t == JM_JT_SPHERICAL)
+        {
+            // JointModelSphericalTpl::calc_aba: S = [0; I3]: U = Ia[:, 3:6], D = U[3:6, :] + armature, Ia -= U D^-1 U^T
+            for (int k = 0; k < 3; ++k) e.du[iv + k] -= fv[3 + k];
+            double D[6][6] = {};
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 3; ++b) jd.U[a][b] = Ia.m[a][3 + b];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) D[a][b] = jd.U[3 + a][b];
+            for (int a = 0; a < 3; ++a) D[a][a] += m.rotor[iv + a];
+            spd_inverse(3, D, jd.Dinv);
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 3; ++b)
+                {
+                    double s = 0;
+                    for (int k = 0; k < 3; ++k) s += jd.U[a][k] * jd.Dinv[k][b];
+                    jd.UDinv[a][b] = s;
+                }
+            if (p > 0)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b)
+                    {
+                        double s = 0;
+                        for (int k = 0; k < 3; ++k) s += jd.UDinv[a][k] * jd.U[b][k];
                         Ia.m[a][b] -= s;
                     }
         }
@@ -1567,6 +1603,96 @@ void compute_acceleration(Engine & e, const double * q, const double * v, std::v
     for (auto & jc : e.jcon) if (jc.enabled) jc.lambda = lambda[r++];
 }
 
+// quaternion::exp3 (pinocchio v2.7.0 math/quaternion.hpp): unit quaternion (x y z w) of the rotation vector
+inline void quat_exp3(const double * v, double * out)
+{
+    const double t2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double ts_prec = std::sqrt(std::sqrt(EPS));   // TaylorSeriesExpansion<double>::precision<3>()
+    double k, w;
+    if (t2 > ts_prec)
+    {
+        const double theta = std::sqrt(t2);
+        k = std::sin(0.5 * theta) / theta;
+        w = std::cos(0.5 * theta);
+    }
+    else
+    {
+        k = 0.5 - t2 / 48.0;
+        w = 1.0 - t2 / 8.0;
+    }
+    out[0] = k * v[0]; out[1] = k * v[1]; out[2] = k * v[2]; out[3] = w;
+}
+// Hamilton product a * b of quaternions stored x y z w (Eigen)
+inline void quat_mul(const double * a, const double * b, double * r)
+{
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// quaternion::log3 (pinocchio v2.7.0 math/quaternion.hpp): rotation vector of a unit quaternion, theta >= 0 its angle
+inline V3 quat_log3(const double * q, double & theta)
+{
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const double n = std::sqrt(n2);
+    const double ts_prec = std::sqrt(std::sqrt(EPS));
+    const double sgn = q[3] >= 0.0 ? 1.0 : -1.0;       // the shortest of the two rotations the quaternion stands for
+    theta = 2.0 * std::atan2(n, sgn * q[3]);
+    const double k = n2 > ts_prec ? sgn * theta / n : sgn * (2.0 / std::fabs(q[3])) * (1.0 - n2 / (3.0 * q[3] * q[3]));
+    return {k * q[0], k * q[1], k * q[2]};
+}
+// Jlog3 (pinocchio v2.7.0 spatial/explog.hpp): derivative of log3 w.r.t. a rotation composed on the right
+inline M3 jlog3(double theta, V3 lg)
+{
+    const double ts_prec = std::sqrt(std::sqrt(EPS));
+    double alpha, diag;
+    if (theta < ts_prec)
+    {
+        alpha = 1.0 / 12.0 + theta * theta / 720.0;
+        diag = 0.5 * (2.0 - theta * theta / 6.0);
+    }
+    else
+    {
+        const double st = std::sin(theta), ct = std::cos(theta), st_1mct = st / (1.0 - ct);
+        alpha = 1.0 / (theta * theta) - st_1mct / (2.0 * theta);
+        diag = 0.5 * (theta * st_1mct);
+    }
+    const double l[3] = {lg.x, lg.y, lg.z};
+    M3 J;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) J.m[a][b] = alpha * l[a] * l[b];
+    for (int a = 0; a < 3; ++a) J.m[a][a] += diag;
+    // addSkew(0.5 * log, J)
+    J.m[0][1] -= 0.5 * l[2]; J.m[0][2] += 0.5 * l[1];
+    J.m[1][0] += 0.5 * l[2]; J.m[1][2] -= 0.5 * l[0];
+    J.m[2][0] -= 0.5 * l[1]; J.m[2][1] += 0.5 * l[0];
+    return J;
+}
+// Flexibility efforts of the spherical joints (Engine::computeInternalDynamics, engine.cc:3365-3391):
+// u -= Jlog3 (stiffness * log3(q)) + damping * w
+void add_flexibility_efforts(Engine & e, const double * q, const double * v, std::vector<double> & u)
+{
+    const Model & m = e.mdl;
+    if (m.flex_k.empty()) return;
+    for (int j = 1; j < m.njoints; ++j)
+    {
+        if (m.jtype[j] != JM_JT_SPHERICAL) continue;
+        const int iq = m.idx_q[j], iv = m.idx_v[j];
+        double angle;
+        const V3 aa = quat_log3(q + iq, angle);
+        const M3 J = jlog3(angle, aa);
+        const V3 ka = {m.flex_k[3 * j] * aa.x, m.flex_k[3 * j + 1] * aa.y, m.flex_k[3 * j + 2] * aa.z};
+        V3 t3 = J * ka;
+        // "Flexible joint angle must be smaller than 0.95 * pi" (engine.cc:3379-3383): the reference throws, i.e. the
+        // evaluation fails -- a trial of the adaptive stepper is rejected (abstract_stepper.cc:33-54), a fixed step ends the
+        // simulation.  Here the efforts become NaN: the acceleration is NaN and takes those very paths.
+        if (angle > 0.95 * 3.14159265358979323846) t3.x = std::nan("");
+        u[iv] -= t3.x + m.flex_d[3 * j] * v[iv];
+        u[iv + 1] -= t3.y + m.flex_d[3 * j + 1] * v[iv + 1];
+        u[iv + 2] -= t3.z + m.flex_d[3 * j + 2] * v[iv + 2];
+    }
+}
+
 // Engine::computeRobotsDynamics with `contacts.model = "constraint"` (engine.cc:3585-3708):
 // computeAllTerms (hysteresis) -> motors -> u -> computeAcceleration
 void dynamics_constraint(Engine & e, const double * q, const double * v, double * a_out)
@@ -1578,6 +1704,7 @@ void dynamics_constraint(Engine & e, const double * q, const double * v, double 
     if (e.applied_k > 0) add_applied_wrenches(e);
     std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
     toggle_bounds(e, q);
+    add_flexibility_efforts(e, q, v, e.uInternal);
     toggle_contacts(e);
     motor_efforts(e, v);
     for (int i = 0; i < m.nv; ++i) e.u[i] = e.uInternal[i];
@@ -1619,6 +1746,7 @@ void dynamics(Engine & e, const double * q, const double * v, double * a_out)
     if (e.applied_k > 0) add_applied_wrenches(e);
     motor_efforts(e, v);
     for (int i = 0; i < m.nv; ++i) e.u[i] = 0.0;  // uInternal + uCustom
+    add_flexibility_efforts(e, q, v, e.u);
     for (size_t i = 0; i < m.motors.size(); ++i) e.u[m.motors[i].idx_v] += e.uTransmission[i];
     aba(e, q, v, e.u.data(), e.fExternal);
     for (int i = 0; i < m.nv; ++i)
@@ -1651,6 +1779,18 @@ void integrate(const Model & m, const double * q, const double * dvv, double * q
             const double alpha = (3.0 - N2) / 2.0;  // firstOrderNormalize
             o[0] = M1.p.x; o[1] = M1.p.y; o[2] = M1.p.z;
             for (int k = 0; k < 4; ++k) o[3 + k] = quat[k] * alpha;
+        }
+        else if (t == JM_JT_SPHERICAL)
+        {
+            // SpecialOrthogonalOperationTpl<3>::integrate_impl (pinocchio v2.7.0 liegroup/special-orthogonal.hpp):
+            // quat_out = quat * exp3(omega) as quaternions, then firstOrderNormalize
+            double w4[4];
+            quat_exp3(d, w4);
+            double r[4];
+            quat_mul(qj, w4, r);
+            const double N2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+            const double alpha = (3.0 - N2) / 2.0;
+            for (int k = 0; k < 4; ++k) o[k] = r[k] * alpha;
         }
         else if (is_unbounded(t))
         {
@@ -1803,7 +1943,9 @@ void start_constraint(Engine & e)
     {
         for (auto & f : e.fExternal) f = Force();
         if (e.applied_k > 0) add_applied_wrenches(e);
+        // (uInternalConst of engine.cc:1386-1396: what computeAllTerms left, i.e. the flexibility efforts)
         std::fill(e.uInternal.begin(), e.uInternal.end(), 0.0);
+        add_flexibility_efforts(e, e.q.data(), e.v.data(), e.uInternal);
         compute_acceleration(e, e.q.data(), e.v.data(), e.u, it == 0);
         for (int i = 0; i < m.nv; ++i)
         {
@@ -1997,6 +2139,13 @@ void difference(const Model & m, const double * q0, const double * q1, double * 
             rel.p = tmul(M0.R, M1.p - M0.p);
             to6(log6(rel), o);
         }
+        else if (t == JM_JT_SPHERICAL)
+        {
+            // SpecialOrthogonalOperationTpl<3>::difference_impl: log3(R0^T R1)
+            const M3 R0 = quat_to_matrix(a[0], a[1], a[2], a[3]), R1 = quat_to_matrix(bq[0], bq[1], bq[2], bq[3]);
+            const V3 d3 = log3(transpose(R0) * R1);
+            o[0] = d3.x; o[1] = d3.y; o[2] = d3.z;
+        }
         else if (is_unbounded(t))
         {
             // SO(2): R = R0^T R1 from (cos, sin) pairs, log = signed angle (liegroup/special-orthogonal.hpp)
@@ -2171,6 +2320,11 @@ Engine * make_engine(const jm_model_desc * d, const jm_options * o)
     m.njoints = d->njoints; m.nq = d->nq; m.nv = d->nv;
     m.parent.assign(d->parents, d->parents + d->njoints);
     m.jtype.assign(d->jtypes, d->jtypes + d->njoints);
+    if (d->flex_stiffness && d->flex_damping)
+    {
+        m.flex_k.assign(d->flex_stiffness, d->flex_stiffness + 3 * d->njoints);
+        m.flex_d.assign(d->flex_damping, d->flex_damping + 3 * d->njoints);
+    }
     m.idx_q.assign(d->idx_q, d->idx_q + d->njoints);
     m.idx_v.assign(d->idx_v, d->idx_v + d->njoints);
     m.axis.resize(d->njoints); m.placement.resize(d->njoints); m.inertia.resize(d->njoints);

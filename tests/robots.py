@@ -90,7 +90,8 @@ def foot_pendulum() -> CompiledModel:
 
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
-            tree_arm(True), crane_walker(), biped(False), biped(True), arm7()]
+            tree_arm(True), crane_walker(), biped(False), biped(True), arm7(),
+            pendulum_flexible(), tree_arm_flexible(False), tree_arm_flexible(True)]
 
 
 # ---- robots of the reference's user-FrameConstraint tests, restated (the constraint frames are part of the topology)
@@ -194,3 +195,30 @@ def arm7() -> CompiledModel:
     cannot take (no leaf chains on a free-flyer) and the one-robot-per-lane kernels get."""
     return build_robot(os.path.join(DATA, "arm7.urdf"), os.path.join(DATA, "arm7_hardware.toml"),
                        has_freeflyer=False, name="arm7")
+
+
+def pendulum_flexible(k: float = 20.0, nu: float = 0.1, armature: float = 0.1, flex_inertia: float = 1e-5) -> CompiledModel:
+    """unit_py/test_simple_pendulum.py:662-691: the pendulum with a flexibility (a spherical joint with a spring-damper on its
+    rotation) in front of its joint and a rotor inertia on its motor -- a series-elastic actuator."""
+    import numpy as np
+    m = build_model_from_urdf(os.path.join(DATA, "pendulum.urdf"), name="pendulum_flexible",
+                              flexibility=[{"frameName": "pivot", "stiffness": k * np.ones(3), "damping": nu * np.ones(3),
+                                            "inertia": flex_inertia * np.ones(3)}])
+    add_motor(m, "pivot", "pivot", enableVelocityLimit=False, enableEffortLimit=False,
+              enableArmature=armature > 0, armature=armature)
+    add_sensor(m, "EncoderSensor", "pivot", joint_name="pivot")
+    add_sensor(m, "ImuSensor", "tip", frame_name="tip")
+    return m
+
+
+def tree_arm_flexible(has_freeflyer: bool = False) -> CompiledModel:
+    """`tree_arm` with two flexibilities: in place of the fixed joint that carries the plate (the plate then hangs on a
+    spherical joint of its own) and in front of the unaligned revolute joint `c_skew`."""
+    import numpy as np
+    flex = [{"frameName": "z_fixed_plate", "stiffness": np.array([60.0, 80.0, 50.0]), "damping": np.array([0.4, 0.5, 0.3]),
+             "inertia": np.array([2e-3, 1e-3, 3e-3])},
+            {"frameName": "c_skew", "stiffness": np.array([150.0, 120.0, 90.0]), "damping": np.array([0.8, 0.6, 0.7]),
+             "inertia": np.array([1e-3, 2e-3, 1e-3])}]
+    return build_robot(os.path.join(DATA, "tree_arm.urdf"), os.path.join(DATA, "tree_arm_hardware.toml"),
+                       has_freeflyer=has_freeflyer, name="tree_arm_flex_ff" if has_freeflyer else "tree_arm_flex",
+                       flexibility=flex)

@@ -189,6 +189,8 @@ def _models():
         "point_mass": robots.point_mass,
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
+        "tree_arm_flex": lambda: robots.tree_arm_flexible(False),
+        "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True),
         "crane_walker": robots.crane_walker,
         "biped": robots.biped,
         "biped_torso": lambda: robots.biped(True),

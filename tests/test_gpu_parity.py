@@ -60,7 +60,7 @@ def test_start_and_steps_match_oracle_fp64(gpu_device, name, B, solver):
 
 
 @pytest.mark.parametrize("robot", ["pendulum", "point_mass", "two_masses", "tree_arm", "tree_arm_ff", "arm7",
-                                   "crane_walker", "biped", "biped_torso"])
+                                   "tree_arm_flex", "tree_arm_flex_ff", "crane_walker", "biped", "biped_torso"])
 def test_small_robots_cover_every_joint_type(gpu_device, robot):
     """Authored test robots: aligned / unaligned revolute and prismatic joints, unbounded joints,
     fixed and floating base, friction motors, world-fixed contact frames (lane kernel) and, with
@@ -70,6 +70,8 @@ def test_small_robots_cover_every_joint_type(gpu_device, robot):
     from tests import robots
     model = {"pendulum": robots.pendulum, "point_mass": robots.point_mass, "two_masses": robots.two_masses,
              "tree_arm": lambda: robots.tree_arm(False), "tree_arm_ff": lambda: robots.tree_arm(True), "arm7": robots.arm7,
+             # (spherical flexibility joints: in place of a fixed joint and in front of a mechanical one)
+             "tree_arm_flex": lambda: robots.tree_arm_flexible(False), "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True),
              "crane_walker": robots.crane_walker, "biped": robots.biped, "biped_torso": lambda: robots.biped(True)}[robot]()
     quad = robot in ("crane_walker", "biped", "biped_torso")
     if quad:
@@ -560,7 +562,7 @@ def _dopri_pair(model, B, st, step_dt, n_steps, tol_rel, tol_abs, dt_max=0.02, c
     return eng, ref, ad
 
 
-@pytest.mark.parametrize("robot", ["pendulum", "double_pendulum", "cartpole"])
+@pytest.mark.parametrize("robot", ["pendulum", "double_pendulum", "cartpole", "pendulum_flexible", "tree_arm_flex"])
 def test_adaptive_dopri_matches_oracle_small_robots(gpu_device, robot):
     """`odeSolver = "runge_kutta_dopri"` (reference default) on the one-robot-per-lane kernel: every
     lane carries its own step size.  The accept / reject decisions are discontinuous in the error
@@ -568,7 +570,8 @@ def test_adaptive_dopri_matches_oracle_small_robots(gpu_device, robot):
     (round-off agreement), the rest stay within the integration tolerance."""
     from tests import robots
     model = {"pendulum": robots.pendulum, "double_pendulum": robots.double_pendulum,
-             "cartpole": lambda: load_builtin("cartpole")}[robot]()
+             "cartpole": lambda: load_builtin("cartpole"), "pendulum_flexible": robots.pendulum_flexible,
+             "tree_arm_flex": lambda: robots.tree_arm_flexible(False)}[robot]()
     B = 192
     st = sample_states(model, B, seed=31)
     eng, ref, ad = _dopri_pair(model, B, st, 0.01, 30, 1e-6, 1e-7)
@@ -578,7 +581,12 @@ def test_adaptive_dopri_matches_oracle_small_robots(gpu_device, robot):
     same = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
     assert same.mean() > 0.9
     assert np.allclose(ss.dt_largest.cpu().numpy()[same], ad["dt_largest"][same], rtol=1e-6)
-    assert int(eng.status.abs().sum()) == 0
+    if "flex" in robot:
+        # (`tree_arm`'s seeded states leave a joint outside its bounds -- flagged alike on both sides --, the flexible
+        # pendulum's stiffest lanes may give up alike)
+        assert np.array_equal(eng.status.cpu().numpy().reshape(-1)[same], ref["status"].reshape(-1)[same])
+    else:
+        assert int(eng.status.abs().sum()) == 0
 
 
 def test_adaptive_dopri_anymal_free_flight_and_energy(gpu_device):
@@ -799,3 +807,48 @@ def test_bench_line_runs_the_full_extra_terms(gpu_device):
     assert [(c["model_name"], c["contact_model"], c["solver"]) for c in bench.SECONDARY] == [
         ("anymal", "constraint", "euler_explicit"), ("atlas", "spring_damper", "runge_kutta_4"), ("atlas", "constraint", "euler_explicit")]
     assert set(bench.FULL_EXTRA_OUTPUTS) >= {"energy", "joint_forces", "centroidal"}
+
+
+@pytest.mark.gpu
+def test_flexibility_with_armature_is_a_series_elastic_actuator_on_the_device(gpu_device):
+    """unit_py/test_simple_pendulum.py:662-750 through the engine: the flexible pendulum with a rotor inertia and a PD law on
+    its motor against the linear SEA system (exact discretisation of plant + held command), on every lane of a small batch
+    with lane-dependent gains; 1 s of 1e-4 s steps."""
+    from scipy.linalg import expm
+    from tests import robots
+    k, nu, J, I = 20.0, 0.1, 0.1, 5.0
+    model = robots.pendulum_flexible(k, nu, J)
+    B, dt, n = 8, 1e-4, 10000
+    kc = torch.linspace(60.0, 130.0, B, dtype=torch.float64, device=gpu_device)
+    nc = torch.linspace(0.5, 1.5, B, dtype=torch.float64, device=gpu_device)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"world": {"gravity": [0.0] * 6},
+                     "stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt},
+                     "contacts": {"model": "spring_damper"}})
+    q0 = torch.zeros((5, B), dtype=torch.float64)
+    q0[3] = 1.0
+    v0 = torch.zeros((4, B), dtype=torch.float64)
+    v0[1] = 0.1
+    eng.set_command(torch.zeros((1, B), dtype=torch.float64))
+    eng.start(q0, v0)
+    Ap = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [-k * (1 / I + 1 / J), 0, -nu * (1 / I + 1 / J), 0], [k / J, 0, nu / J, 0]])
+    Bp = np.array([0, 0, -1 / J, 1 / J])
+    aug = np.zeros((5, 5))
+    aug[:4, :4], aug[:4, 4] = Ap, Bp
+    Ed = expm(aug * dt)
+    x = np.tile(np.array([0.0, 0.0, 0.1, 0.0])[:, None], (1, B))
+    kc_h, nc_h = kc.cpu().numpy(), nc.cpu().numpy()
+    q, v = eng.field("q"), eng.field("v")
+    err = 0.0
+    for i in range(n):
+        u = -kc * q[4] - nc * v[3]
+        eng.set_command(u[None, :])
+        eng.step(dt)
+        x = Ed[:4, :4] @ x + np.outer(Ed[:4, 4], -kc_h * x[1] - nc_h * x[3])
+        if i % 500 == 499 or i == n - 1:
+            qh, vh = q.cpu().numpy(), v.cpu().numpy()
+            err = max(err, np.abs(2 * np.arctan2(qh[1], qh[3]) - x[0]).max(), np.abs(qh[4] - x[1]).max(),
+                      np.abs(vh[1] - x[2]).max(), np.abs(vh[3] - x[3]).max())
+            assert np.abs(qh[[0, 2]]).max() == 0.0 and np.abs(vh[[0, 2]]).max() == 0.0
+    assert err < 1e-4, err
+    assert int(eng.status.abs().sum()) == 0

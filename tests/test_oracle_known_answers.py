@@ -510,3 +510,66 @@ def test_contact_and_force_sensors_report_the_external_force(contact_model, peri
         assert np.allclose(lin_c, f_true[:3], atol=1e-7)
         assert np.allclose(np.concatenate((lin_f, ang_f)), f_true, atol=1e-7)
     assert touched > 20
+
+
+# ---- reference unit_py/test_simple_pendulum.py:662-750: flexibility + rotor inertia = a series-elastic actuator
+def test_flexibility_with_armature_is_a_series_elastic_actuator():
+    """A flexibility (spherical joint, stiffness k, damping nu, inertia 1e-5) in front of the pendulum joint, a rotor inertia
+    J on its motor, a PD law on the motor, no gravity: flexibility angle, pendulum angle and their rates follow the linear SEA
+    system of the reference's test (its A matrix; here with the command held over every step, i.e. the exact discretisation of
+    plant + zero-order hold) to the reference's own tolerance of 1e-4 -- the two are not equal, the flexible element's inertia
+    is small, not zero -- and nothing moves about the other axes."""
+    k, nu, J, I = 20.0, 0.1, 0.1, 5.0
+    k_control, nu_control = 100.0, 1.0
+    m = robots.pendulum_flexible(k, nu, J)
+    assert m.joint_names == ["universe", "pivotFlexibility", "pivot"] and m.flexibility_joint_indices == [1]
+    assert m.nq == 5 and m.nv == 4 and np.allclose(m.rotor_inertia, [1e-5, 1e-5, 1e-5, J])
+    e = OracleEngine(m, gravity=(0, 0, 0, 0, 0, 0))
+    dt, n = 1e-4, 20000
+    e.start(np.array([0.0, 0.0, 0.0, 1.0, 0.0]), np.array([0.0, 0.1, 0.0, 0.0]), command=np.array([0.0]))
+    Ap = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [-k * (1 / I + 1 / J), 0, -nu * (1 / I + 1 / J), 0], [k / J, 0, nu / J, 0]])
+    Bp = np.array([0, 0, -1 / J, 1 / J])
+    aug = np.zeros((5, 5))
+    aug[:4, :4], aug[:4, 4] = Ap, Bp
+    Ed = expm(aug * dt)
+    x = np.array([0.0, 0.0, 0.1, 0.0])
+    err = off = 0.0
+    for _ in range(n):
+        q, v = e.get("q"), e.get("v")
+        u = -k_control * q[4] - nu_control * v[3]
+        e.set_command(np.array([u]))
+        e.step(dt, command_changed=True)
+        x = Ed[:4, :4] @ x + Ed[:4, 4] * u
+        q, v = e.get("q"), e.get("v")
+        err = max(err, abs(2 * np.arctan2(q[1], q[3]) - x[0]), abs(q[4] - x[1]), abs(v[1] - x[2]), abs(v[3] - x[3]))
+        off = max(off, abs(q[0]), abs(q[2]), abs(v[0]), abs(v[2]))
+    assert err < 1e-4 and off == 0.0, (err, off)
+    assert np.abs(x).max() > 1e-3     # (the motion has not died out over the window)
+
+
+def test_flexibility_joints_are_inserted_like_the_reference_does():
+    """`flexibilityConfig` at a fixed frame and in front of a mechanical joint (model.cc:1087-1165, pinocchio.cc:460-503,
+    578-700): names, parents, placements, the weightless body, the rotor inertia, the refusal of vanishing inertias."""
+    base = robots.tree_arm(False)
+    m = robots.tree_arm_flexible(False)
+    assert m.njoints == base.njoints + 2 and m.nq == base.nq + 8 and m.nv == base.nv + 6
+    jf, jm = m.joint_index("c_skewFlexibility"), m.joint_index("c_skew")
+    assert int(m.parents[jm]) == jf and int(m.jtypes[jf]) == 14
+    b = base.joint_index("c_skew")
+    assert int(m.parents[jf]) == m.joint_index(base.joint_names[int(base.parents[b])])
+    assert np.allclose(m.placement_R[jf], base.placement_R[b]) and np.allclose(m.placement_p[jf], base.placement_p[b])
+    assert np.allclose(m.placement_R[jm], np.eye(3)) and np.allclose(m.placement_p[jm], 0.0)
+    assert m.mass[jf] == 0.0 and np.allclose(m.rotor_inertia[m.idx_v[jf]:m.idx_v[jf] + 3], [1e-3, 2e-3, 1e-3])
+    jp = m.joint_index("z_fixed_plate")                      # the fixed joint became the flexibility itself
+    assert int(m.jtypes[jp]) == 14 and m.mass[jp] == pytest.approx(0.7)
+    assert m.mass[m.joint_index("b_yaw")] == base.mass[base.joint_index("b_yaw")]
+    assert base.mass.sum() == pytest.approx(m.mass.sum())
+    assert m.frames["plate"].parent_joint == jp
+    assert np.allclose(m.flex_stiffness[jp], [60.0, 80.0, 50.0]) and np.allclose(m.flex_damping[jf], [0.8, 0.6, 0.7])
+    assert np.allclose(m.neutral()[m.idx_q[jf]:m.idx_q[jf] + 4], [0, 0, 0, 1])
+    with pytest.raises(LookupError):
+        robots.build_model_from_urdf(os.path.join(robots.DATA, "tree_arm.urdf"), flexibility=[
+            {"frameName": "nope", "stiffness": np.ones(3), "damping": np.ones(3), "inertia": np.ones(3)}])
+    with pytest.raises(ValueError):
+        robots.build_model_from_urdf(os.path.join(robots.DATA, "tree_arm.urdf"), flexibility=[
+            {"frameName": "c_skew", "stiffness": np.ones(3), "damping": np.ones(3), "inertia": 1e-7 * np.ones(3)}])
