@@ -392,6 +392,9 @@ SECONDARY = (
     dict(model_name="anymal", B=65536, solver="euler_explicit", contact_model="constraint", dt=1e-3, steps=20, warmup=3),
     dict(model_name="atlas", B=32768, solver="runge_kutta_4", contact_model="spring_damper", dt=2.5e-4, steps=20, warmup=3),
     dict(model_name="atlas", B=32768, solver="euler_explicit", contact_model="constraint", dt=5e-4, steps=8, warmup=2),
+    # a seven-joint fixed-base arm (tests/data/arm7.urdf compiled into jiminy_amd/data/models/arm7.json): the class of robot
+    # the one-robot-per-lane kernels serve
+    dict(model_name="arm7", B=65536, solver="runge_kutta_4", contact_model="spring_damper", dt=1e-3, steps=20, warmup=3),
 )
 
 

@@ -65,6 +65,7 @@ JT_NAME = {JT_NONE: "universe", JT_RX: "RX", JT_RY: "RY", JT_RZ: "RZ",
            JT_RU: "RU", JT_PX: "PX", JT_PY: "PY", JT_PZ: "PZ", JT_PU: "PU",
            JT_RUBX: "RUBX", JT_RUBY: "RUBY", JT_RUBZ: "RUBZ",
            JT_RUBU: "RUBU", JT_FREEFLYER: "FF", JT_SPHERICAL: "S"}
+BACKLASH_JOINT_SUFFIX = "Backlash"      # `<name>Backlash`: the backlash joint behind the motorised joint `<name>`
 FLEXIBLE_JOINT_SUFFIX = "Flexibility"   # core/include/jiminy/core/robot/model.h (name of a flexibility joint inserted
                                         # in front of the mechanical joint `<name>`: `<name>Flexibility`)
 
@@ -506,7 +507,8 @@ def build_model_from_urdf(urdf_path: str,
                           has_freeflyer: bool = False,
                           name: Optional[str] = None,
                           gravity: Sequence[float] = (0.0, 0.0, -9.81, 0.0, 0.0, 0.0),
-                          flexibility: Optional[Sequence[Dict[str, Any]]] = None
+                          flexibility: Optional[Sequence[Dict[str, Any]]] = None,
+                          backlash: Optional[Dict[str, float]] = None
                           ) -> CompiledModel:
     """URDF -> CompiledModel without hardware (≙ `jiminy.Robot.initialize(urdf, has_freeflyer)`).
 
@@ -516,9 +518,19 @@ def build_model_from_urdf(urdf_path: str,
     (`<name>Flexibility`, at the joint's placement, the mechanical joint then sits at its origin; weightless body --
     addFlexibilityJointBeforeMechanicalJoint, utilities/pinocchio.cc:460-503) or IN PLACE of a fixed joint of that name (the
     links behind it hang on the new joint -- addFlexibilityJointAtFixedFrame :578-700); `inertia` is the joint's rotor
-    inertia.  Joints stay numbered depth-first (the reference re-sorts its joints after the insertion)."""
+    inertia.  Joints stay numbered depth-first (the reference re-sorts its joints after the insertion).
+
+    `backlash`: `{joint name: backlash}` -- the reference's motor options `enableBacklash` / `backlash`
+    (Robot::initializeExtendedModel, core/src/robot/robot.cc:580-629): a second joint of the same kind `<name>Backlash` BEHIND
+    the joint, at its origin, that takes over the joint's body (the motorised joint is left weightless, its rotor inertia is
+    the motor's armature) and is bounded to +- backlash / 2 (addBacklashJointAfterMechanicalJoint, utilities/pinocchio.cc:505-576).
+    Its bound is a `JointConstraint` like any position limit: use `contacts.model = "constraint"`."""
     robot_name, links, joints = _parse_urdf(urdf_path)
     flex = {str(f["frameName"]): f for f in (flexibility or [])}
+    backlash = {str(k): float(v) for k, v in (backlash or {}).items() if float(v) >= 2.220446049250313e-16}
+    for jn in backlash:
+        if jn not in joints or joints[jn].jtype == "fixed":
+            raise LookupError(f"joint '{jn}' not found in model: no backlash joint can be inserted behind it")
     for fname in flex:
         if fname not in joints:
             raise LookupError(f"Frame '{fname}' does not exists. Impossible to insert flexibility joint on it.")
@@ -625,6 +637,22 @@ def build_model_from_urdf(urdf_path: str,
                 eff.append(uj.effort)
                 vel.append(uj.velocity)
                 add_frame(uj.name, new, SE3(), "joint")
+                if uj.name in backlash:
+                    if t not in (JT_RX, JT_RY, JT_RZ, JT_RU, JT_PX, JT_PY, JT_PZ, JT_PU):
+                        raise NotImplementedError("Backlash can only be associated with a bounded 1-dof linear or rotary joint "
+                                                  "here (the reference also takes unbounded rotary ones).")
+                    joint_names.append(uj.name + BACKLASH_JOINT_SUFFIX)
+                    parents.append(new)
+                    jtypes.append(t)
+                    axes.append(ax)
+                    placements.append(SE3())
+                    inertias.append(Inertia())
+                    lower.append(-0.5 * backlash[uj.name])
+                    upper.append(0.5 * backlash[uj.name])
+                    eff.append(math.inf)
+                    vel.append(math.inf)
+                    new = len(joint_names) - 1
+                    add_frame(uj.name + BACKLASH_JOINT_SUFFIX, new, SE3(), "joint")
                 visit(uj.child, new, SE3())
 
     visit(root_link, root_joint_idx, SE3())
@@ -924,13 +952,14 @@ def load_hardware_description_file(model: CompiledModel, hardware_path: str,
 
 def build_robot(urdf_path: str, hardware_path: Optional[str] = None,
                 has_freeflyer: bool = False, name: Optional[str] = None,
-                flexibility: Optional[Sequence[Dict[str, Any]]] = None) -> CompiledModel:
+                flexibility: Optional[Sequence[Dict[str, Any]]] = None,
+                backlash: Optional[Dict[str, float]] = None) -> CompiledModel:
     """≙ `BaseJiminyRobot.initialize(urdf_path, hardware_path, has_freeflyer=...)`.
 
     As in the reference, a `<urdf>_hardware.toml` next to the URDF is picked up
     automatically when `hardware_path` is None.
     """
-    model = build_model_from_urdf(urdf_path, has_freeflyer, name, flexibility=flexibility)
+    model = build_model_from_urdf(urdf_path, has_freeflyer, name, flexibility=flexibility, backlash=backlash)
     if hardware_path is None:
         cand = os.path.splitext(urdf_path)[0] + "_hardware.toml"
         if os.path.exists(cand):

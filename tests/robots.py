@@ -91,7 +91,7 @@ def foot_pendulum() -> CompiledModel:
 def all_test_models() -> List[CompiledModel]:
     return [pendulum(), double_pendulum(), point_mass(), two_masses(), tree_arm(False),
             tree_arm(True), crane_walker(), biped(False), biped(True), arm7(),
-            pendulum_flexible(), tree_arm_flexible(False), tree_arm_flexible(True)]
+            pendulum_flexible(), tree_arm_flexible(False), tree_arm_flexible(True), pendulum_backlash()]
 
 
 # ---- robots of the reference's user-FrameConstraint tests, restated (the constraint frames are part of the topology)
@@ -222,3 +222,14 @@ def tree_arm_flexible(has_freeflyer: bool = False) -> CompiledModel:
     return build_robot(os.path.join(DATA, "tree_arm.urdf"), os.path.join(DATA, "tree_arm_hardware.toml"),
                        has_freeflyer=has_freeflyer, name="tree_arm_flex_ff" if has_freeflyer else "tree_arm_flex",
                        flexibility=flex)
+
+
+def pendulum_backlash(backlash: float = 2.2, armature: float = 1.0) -> CompiledModel:
+    """unit_py/test_simple_pendulum.py:269-285: the pendulum with a rotor inertia on its motor and a backlash between the
+    motor and the mass (`pivotBacklash`, bounded to +- backlash / 2)."""
+    m = build_model_from_urdf(os.path.join(DATA, "pendulum.urdf"), name="pendulum_backlash", backlash={"pivot": backlash})
+    add_motor(m, "pivot", "pivot", enableVelocityLimit=False, enableEffortLimit=False,
+              enableArmature=armature > 0, armature=armature)
+    add_sensor(m, "EncoderSensor", "pivot", joint_name="pivot")
+    add_sensor(m, "ImuSensor", "tip", frame_name="tip")
+    return m

@@ -189,6 +189,7 @@ def _models():
         "point_mass": robots.point_mass,
         "tree_arm": lambda: robots.tree_arm(False),
         "tree_arm_ff": lambda: robots.tree_arm(True),
+        "pendulum_backlash": robots.pendulum_backlash,
         "tree_arm_flex": lambda: robots.tree_arm_flexible(False),
         "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True),
         "crane_walker": robots.crane_walker,
@@ -504,7 +505,8 @@ def test_spring_damper_path_is_untouched_by_the_constraint_state():
 
 # ------------------------------------------------------------------ device build (C ABI) vs oracle
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "point_mass", "biped", "biped_torso"])
+@pytest.mark.parametrize("name", ["anymal", "atlas", "crane_walker", "tree_arm", "point_mass", "biped", "biped_torso",
+                                  "tree_arm_flex", "tree_arm_flex_ff", "pendulum_backlash"])
 def test_gpu_constraint_model_matches_oracle(name, gpu_device):
     import torch
 

@@ -573,3 +573,39 @@ def test_flexibility_joints_are_inserted_like_the_reference_does():
     with pytest.raises(ValueError):
         robots.build_model_from_urdf(os.path.join(robots.DATA, "tree_arm.urdf"), flexibility=[
             {"frameName": "c_skew", "stiffness": np.ones(3), "damping": np.ones(3), "inertia": 1e-7 * np.ones(3)}])
+
+
+# ---- reference unit_py/test_simple_pendulum.py:269-332: backlash between the motor and the pendulum
+def test_backlash_two_phases():
+    """A rotor inertia J on the motor, a backlash of 2 x 1.1 rad behind it, a constant motor torque: inside the backlash the
+    rotor and the pendulum move independently (the rotor under the torque alone, the mass under gravity), once the limit is
+    reached -- 0.4 s after the impact, rebounds gone -- they move as one body of inertia m l^2 + J.  Both phases against an
+    independent integration, to the reference's tolerance (1e-7); `constraints.regularization = 0` like there.  (The impact
+    time is taken from the first phase's own law: this pendulum stands upright at q = 0, the reference's hangs.)"""
+    J, BACK, TAU = 1.0, 1.1, 5.0
+    m = robots.pendulum_backlash(2 * BACK, J)
+    assert m.joint_names == ["universe", "pivot", "pivotBacklash"] and m.mass.tolist() == [0.0, 0.0, 5.0]
+    assert m.position_lower[1] == -BACK and m.position_upper[1] == BACK and m.rotor_inertia.tolist() == [J, 0.0]
+    assert m.frames["tip"].parent_joint == 2 and m.frames["pivot"].parent_joint == 1
+    e = OracleEngine(m)
+    e.set_constraint_options(regularization=0.0)
+    dt, x0 = 1e-4, [0.0, 0.1, 0.0, 0.0]
+    e.start(np.array(x0[:2]), np.array(x0[2:]), command=np.array([-TAU]))
+    free = lambda t, x: [x[2], x[3], -TAU / J, G * np.sin(x[0] + x[1]) + TAU / J]   # noqa: E731
+    hit = lambda t, x: x[1] - BACK                                                   # noqa: E731
+    hit.terminal = True
+    t_impact = solve_ivp(free, (0, 5), x0, events=hit, method="DOP853", rtol=1e-12, atol=1e-12).t_events[0][0]
+    n = int(round((t_impact + 1.0) / dt))
+    X = np.zeros((n, 4))
+    for i in range(n):
+        e.step(dt, command_changed=False)
+        X[i] = np.concatenate([e.get("q"), e.get("v")])
+    T = dt * np.arange(1, n + 1)
+    t1, t2 = np.searchsorted(T, [t_impact - 0.02, t_impact + 0.4])
+    sol = solve_ivp(free, (0, T[t1 - 1]), x0, t_eval=T[:t1], method="DOP853", rtol=1e-12, atol=1e-12)
+    assert np.abs(sol.y.T - X[:t1]).max() < 1e-7
+    I_total = 5.0 + J
+    joined = lambda t, x: [x[2], x[3], 5.0 * G / I_total * np.sin(x[0] + x[1]) - TAU / I_total, 0.0]   # noqa: E731
+    sol = solve_ivp(joined, (0, T[-1] - T[t2]), X[t2], t_eval=T[t2:] - T[t2], method="DOP853", rtol=1e-12, atol=1e-12)
+    assert np.abs(sol.y.T - X[t2:]).max() < 1e-7
+    assert abs(X[-1, 1] - BACK) < 1e-9 and e.status == 0

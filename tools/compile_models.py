@@ -27,6 +27,13 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     data = os.path.join(REF, "data")
 
+    # the authored seven-joint fixed-base arm of the test-suite (tests/data/arm7.urdf: no reference file involved): the
+    # secondary workload of bench.py on the one-robot-per-lane kernels
+    tdata = os.path.join(ROOT, "tests", "data")
+    m = build_robot(os.path.join(tdata, "arm7.urdf"), os.path.join(tdata, "arm7_hardware.toml"), has_freeflyer=False, name="arm7")
+    m.save(os.path.join(OUT, "arm7.json"))
+    print("arm7", m.joint_names, m.nq, m.nv)
+
     # double pendulum: motors on both joints like the reference example
     # (python/jiminy_py/examples/double_pendulum.py uses "PendulumJoint" / "SecondPendulumJoint")
     m = build_model_from_urdf(os.path.join(data, "toys_models/double_pendulum/double_pendulum.urdf"),

@@ -22,6 +22,9 @@ def main():
     name, tag, want = argv[0], argv[1], argv[2:]
     os.environ["JIMINY_AMD_LIB_TAG"] = tag
     from jiminy_amd import codegen, load_builtin
+    tree_csrc = codegen.CSRC
+    if os.environ.get("JIMINY_AMD_CSRC_DEV"):      # sources of an experiment kept outside the tree
+        codegen.CSRC = os.environ["JIMINY_AMD_CSRC_DEV"]
     try:
         model = load_builtin(name)
     except LookupError:
@@ -53,6 +56,7 @@ def main():
         raise SystemExit(f"failed: {bad}")
     subprocess.check_call([codegen.HIPCC, f"--offload-arch={codegen.OFFLOAD_ARCH}", "-fPIC", "-shared",
                            *[os.path.join(objdir, f"{k}.o") for k in units], "-o", lib])
+    codegen.CSRC = tree_csrc     # (the record says "built from the tree's sources": an experiment is loaded, not rebuilt)
     with open(lib + ".src", "w") as f:
         f.write(codegen.source_digest(model, v, None) + "\n")
     print(lib, [k for k, _ in procs], f"{time.time() - t:.0f} s")
