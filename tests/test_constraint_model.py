@@ -1068,3 +1068,47 @@ def test_gpu_solver_region_stays_inside_its_workspace(gpu_device):
     nb = _abi.constraint_rows(model)["n_bounds"]
     assert int((eng.field("con_flags")[nb:, 0] & 1).sum()) == 16
     assert int((eng.status & ~16).abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_masked_reset_through_the_split_start_path(gpu_device, monkeypatch):
+    """A reset of a FEW lanes of a robot whose `start` / `reset` launches go through the split pipeline (Atlas, 96 lanes: four
+    pre passes, the exact solves, the sweep kernels, the post pass over the whole batch, every robot that does not restart
+    leaving through its header): the untouched lanes keep q / v / a / multipliers / flags bit for bit, and the restarted lanes
+    end where the single kernel (`JIMINY_AMD_QCON_SPLIT_START=0`) puts them."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = load_builtin("atlas")
+    B, dt = 96, 5e-4
+    ref, _ = _pair(model, B, seed=41)
+    other = sample_standing_states(model, B, seed=43)
+    lanes = np.zeros(B, dtype=bool)
+    lanes[[3, 17, 18, 64, 95]] = True
+    results = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("JIMINY_AMD_QCON_SPLIT_START", split)
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces",))
+        eng.set_options({"stepper": {"odeSolver": "euler_explicit", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt,
+                                     "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]}, "contacts": {"model": "constraint"}})
+        eng.set_command(torch.from_numpy(ref["command"]))
+        eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+        for _ in range(3):
+            eng.step(dt)
+        torch.cuda.synchronize()
+        keys = ("q", "v", "a", "con_data", "con_flags", "contact_forces")
+        before = {k: eng.field(k).clone() for k in keys}
+        eng.reset_lanes(torch.from_numpy(lanes.astype(np.uint8)).to(gpu_device), torch.from_numpy(other["q"]), torch.from_numpy(other["v"]))
+        torch.cuda.synchronize()
+        after = {k: eng.field(k).clone() for k in keys}
+        keep = torch.from_numpy(~lanes).to(gpu_device)
+        for k in keys:
+            assert torch.equal(after[k][..., keep], before[k][..., keep]), (split, k)
+        assert torch.equal(after["q"][:, ~keep], torch.from_numpy(other["q"][:, lanes]).to(gpu_device))
+        assert not torch.equal(after["a"][:, ~keep], before["a"][:, ~keep])
+        eng.step(dt)
+        torch.cuda.synchronize()
+        results[split] = {k: eng.field(k).cpu().numpy().astype(np.float64) for k in ("q", "v", "a", "con_data")}
+        eng.stop()
+    for k, x in results["1"].items():
+        assert rel_err(x, results["0"][k]) < 1e-7, (k, rel_err(x, results["0"][k]))
