@@ -47,15 +47,22 @@ class _PointEnv:
 
 
 def test_ppo_improves_on_a_toy_problem():
-    env = _PointEnv(256, 0)
-    learner = ppo.PPO(2, 2, torch.device("cpu"), lr=3e-3, epochs=4, minibatches=2, gamma=0.0, lam=0.0)
-    obs = env.x.clone()
-    rewards = []
-    for it in range(30):
-        buf, obs = learner.rollout(obs, env.step, 8)
-        learner.update(buf)
-        rewards.append(float(buf["rew"].mean()))
-    assert np.mean(rewards[-5:]) > np.mean(rewards[:5]) + 0.5
+    # (one thread: in the full suite the worker threads of the host-emulation libraries loaded before this test spin next to
+    # torch's, and these tiny tensor operations took two minutes instead of seven seconds)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        env = _PointEnv(256, 0)
+        learner = ppo.PPO(2, 2, torch.device("cpu"), lr=3e-3, epochs=4, minibatches=2, gamma=0.0, lam=0.0)
+        obs = env.x.clone()
+        rewards = []
+        for it in range(30):
+            buf, obs = learner.rollout(obs, env.step, 8)
+            learner.update(buf)
+            rewards.append(float(buf["rew"].mean()))
+        assert np.mean(rewards[-5:]) > np.mean(rewards[:5]) + 0.5
+    finally:
+        torch.set_num_threads(threads)
 
 
 def _ddp_worker(rank, world, port, q):
