@@ -27,8 +27,12 @@ CON_OPTIONS = dict(tol_abs=1e-11, tol_rel=1e-10)  # PGS run to stagnation: fixtu
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]     # optional: regenerate the fixtures of these models only
     for name, B, kw in (("cartpole", 16, {}), ("anymal", 16, {"grounded_fraction": 0.5}),
-                        ("atlas", 8, {"base_height": (0.9, 1.0), "grounded_fraction": 0.5})):
+                        ("atlas", 8, {"base_height": (0.9, 1.0), "grounded_fraction": 0.5}),
+                        ("arm7", 16, {})):          # (the authored 7-joint arm: the one-robot-per-lane kernels' robot)
+        if only and name not in only:
+            continue
         model = load_builtin(name)
         st = sample_states(model, B, seed=123, **kw)
         arr = alloc_soa(model, B)
@@ -46,6 +50,8 @@ def main() -> None:
         print(name, "ok", {k: v.shape for k, v in list(out.items())[:3]})
     # contacts.model = "constraint": standing robots, some joints beyond their limits
     for name, B in (("anymal", 16), ("atlas", 4)):
+        if only and name not in only:
+            continue
         model = load_builtin(name)
         st = sample_standing_states(model, B, seed=321)
         arr = alloc_soa(model, B)
