@@ -178,3 +178,39 @@ def test_first_interval_with_euler_equals_the_hand_computed_two_step_result():
     launches, _, _ = E.plan_step(dt, 0.0, dt, o)
     assert [(n) for _, n, _, _ in launches] == [1]
     assert oracle_engine_step(model, ref, loop, dt, "euler_explicit", command_changed=True) == 1
+
+
+def test_cross_variant_agreement_of_the_float64_rows_is_a_strict_second_opinion():
+    """`_verified_library`'s last resort when float32 cannot vouch for the float64 emitted rows (a flexibility inertia of 1e-5
+    next to 5 kg m^2): the rows of the separately compiled build variants must agree with each other.  Round-off passes, a
+    wrong row in ONE variant does not, lanes that are NaN in any variant are left out, nothing left to compare is a failure."""
+    import torch
+
+    from tests import robots
+    model = robots.pendulum()
+    key = model.topology_hash()
+    rng = np.random.default_rng(0)
+    base = [{"a": torch.from_numpy(rng.standard_normal((1, 8))), "imu": torch.from_numpy(rng.standard_normal((6, 8)))}
+            for _ in range(2)]
+    ok = torch.ones(8, dtype=torch.bool)
+
+    def put(variant, rows, lanes=ok):
+        E._OUTPUT_ROWS_F64[(key, variant)] = (rows, lanes)
+
+    try:
+        for v in (0, 1, 2):
+            put(v, [{k: x * (1.0 + 1e-13 * v) for k, x in r.items()} for r in base])
+        assert E._float64_rows_agree_across_variants(model, [0, 1, 2]) < 1e-11
+        bad = [{k: x.clone() for k, x in r.items()} for r in base]
+        bad[1]["imu"][3, 5] += 0.5
+        put(2, bad)
+        assert E._float64_rows_agree_across_variants(model, [0, 1, 2]) > 1e-2
+        lanes = ok.clone()
+        lanes[5] = False                         # ... unless that lane is NaN there: it is not compared
+        put(2, bad, lanes)
+        assert E._float64_rows_agree_across_variants(model, [0, 1, 2]) < 1e-11
+        put(2, bad, torch.zeros(8, dtype=torch.bool))
+        assert E._float64_rows_agree_across_variants(model, [0, 1, 2]) == float("inf")
+    finally:
+        for v in (0, 1, 2):
+            E._OUTPUT_ROWS_F64.pop((key, v), None)
