@@ -609,3 +609,54 @@ def test_backlash_two_phases():
     sol = solve_ivp(joined, (0, T[-1] - T[t2]), X[t2], t_eval=T[t2:] - T[t2], method="DOP853", rtol=1e-12, atol=1e-12)
     assert np.abs(sol.y.T - X[t2:]).max() < 1e-7
     assert abs(X[-1, 1] - BACK) < 1e-9 and e.status == 0
+
+
+def test_body_on_a_flexibility_follows_the_rigid_body_equations_in_three_dimensions():
+    """A flexibility IN PLACE of a fixed joint (the second insertion kind, pinocchio.cc:578-700): one body -- full inertia
+    tensor, off-centre mass, rotated mount -- on a spherical joint with an anisotropic spring-damper and a rotor inertia, under
+    gravity.  Against an independent integration of (I_0 + J) w' = -Jlog3(q) (K log3 q) - D w + c x m R^T g - w x I_0 w,
+    q' = q (0, w) / 2: the gyroscopic term, `log3` / `Jlog3` away from a principal axis, the quaternion integration and the
+    joint placement all enter."""
+    from jiminy_amd.model import build_model_from_urdf
+    K, D, J = np.array([3.0, 5.0, 2.0]), np.array([0.05, 0.02, 0.04]), np.array([2e-3, 1e-3, 3e-3])
+    m = build_model_from_urdf(os.path.join(robots.DATA, "flex_body.urdf"), name="flex_body",
+                              flexibility=[{"frameName": "mount", "stiffness": K, "damping": D, "inertia": J}])
+    assert m.joint_names == ["universe", "mount"] and int(m.jtypes[1]) == 14 and m.mass[1] == 2.0
+    g = np.array([0.0, 0.0, -G])
+    Rp, mass, c = m.placement_R[1], m.mass[1], m.com[1]
+    I0 = m.inertia[1] + mass * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+
+    def qmul(a, b):
+        return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2],
+                         a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+
+    def qrot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def rhs(t, x):
+        q, w = x[:4] / np.linalg.norm(x[:4]), x[4:]
+        n = np.linalg.norm(q[:3])
+        th = 2.0 * np.arctan2(n, q[3])
+        aa = (th / n) * q[:3]
+        st_1mct = np.sin(th) / (1.0 - np.cos(th))
+        S = np.array([[0, -aa[2], aa[1]], [aa[2], 0, -aa[0]], [-aa[1], aa[0], 0]])
+        Jl = (1.0 / th ** 2 - st_1mct / (2.0 * th)) * np.outer(aa, aa) + 0.5 * th * st_1mct * np.eye(3) + 0.5 * S
+        tau = -Jl @ (K * aa) - D * w + np.cross(c, mass * ((Rp @ qrot(q)).T @ g))
+        return np.concatenate([0.5 * qmul(q, np.array([w[0], w[1], w[2], 0.0])), np.linalg.solve(I0 + np.diag(J), tau - np.cross(w, I0 @ w))])
+
+    q0 = np.array([0.1, -0.05, 0.08, 0.0])
+    q0[3] = np.sqrt(1.0 - np.dot(q0[:3], q0[:3]))
+    w0 = np.array([0.4, -0.3, 0.5])
+    e = OracleEngine(m)
+    e.start(q0, w0)
+    dt, n = 2e-4, 5000
+    for _ in range(n):
+        e.step(dt, command_changed=False)
+    sol = solve_ivp(rhs, (0, n * dt), np.concatenate([q0, w0]), method="DOP853", rtol=1e-12, atol=1e-13)
+    xf = sol.y[:, -1]
+    xf[:4] /= np.linalg.norm(xf[:4])
+    assert np.abs(e.get("q") - xf[:4]).max() < 1e-7 and np.abs(e.get("v") - xf[4:]).max() < 1e-6
+    assert np.abs(e.get("v") - w0).max() > 0.5     # (it has moved)
