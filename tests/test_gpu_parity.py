@@ -853,3 +853,50 @@ def test_flexibility_with_armature_is_a_series_elastic_actuator_on_the_device(gp
             assert np.abs(qh[[0, 2]]).max() == 0.0 and np.abs(vh[[0, 2]]).max() == 0.0
     assert err < 1e-4, err
     assert int(eng.status.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_backlash_two_phases_on_the_device(gpu_device):
+    """unit_py/test_simple_pendulum.py:269-332 through the engine (constraint contact model, whose bound rows are the backlash):
+    inside the backlash the rotor and the pendulum move independently, 0.4 s after the impact they move as one body of inertia
+    m l^2 + J -- both phases against an independent integration to the reference's tolerance, on lanes with different motor
+    torques (so that they reach the limit at different times)."""
+    from scipy.integrate import solve_ivp
+    from tests import robots
+    G, J, BACK = 9.81, 1.0, 1.1
+    model = robots.pendulum_backlash(2 * BACK, J)
+    B, dt = 6, 1e-4
+    taus = np.linspace(3.0, 8.0, B)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device)
+    eng.set_options({"stepper": {"odeSolver": "runge_kutta_4", "dtMax": dt, "controllerUpdatePeriod": dt, "sensorsUpdatePeriod": dt},
+                     "contacts": {"model": "constraint"}, "constraints": {"regularization": 0.0}})
+    x0 = [0.0, 0.1, 0.0, 0.0]
+    q0 = torch.tensor(x0[:2], dtype=torch.float64)[:, None].repeat(1, B)
+    eng.set_command(torch.from_numpy(-taus)[None, :])
+    eng.start(q0, torch.zeros((2, B), dtype=torch.float64))
+    t_imp = []
+    for tau in taus:
+        free = lambda t, x, tau=tau: [x[2], x[3], -tau / J, G * np.sin(x[0] + x[1]) + tau / J]   # noqa: E731
+        hit = lambda t, x: x[1] - BACK                                                            # noqa: E731
+        hit.terminal = True
+        t_imp.append(solve_ivp(free, (0, 5), x0, events=hit, method="DOP853", rtol=1e-12, atol=1e-12).t_events[0][0])
+    n = int(round((max(t_imp) + 0.9) / dt))
+    every = 20
+    X, T = [], []
+    q, v = eng.field("q"), eng.field("v")
+    for i in range(n):
+        eng.step(dt)
+        if (i + 1) % every == 0:
+            X.append(torch.cat([q, v]).cpu().numpy().copy())
+            T.append((i + 1) * dt)
+    X, T = np.array(X), np.array(T)          # [time][4][lane]
+    for lane, tau in enumerate(taus):
+        t1, t2 = np.searchsorted(T, [t_imp[lane] - 0.02, t_imp[lane] + 0.4])
+        free = lambda t, x: [x[2], x[3], -tau / J, G * np.sin(x[0] + x[1]) + tau / J]            # noqa: E731
+        sol = solve_ivp(free, (0, T[t1 - 1]), x0, t_eval=T[:t1], method="DOP853", rtol=1e-12, atol=1e-12)
+        assert np.abs(sol.y.T - X[:t1, :, lane]).max() < 1e-7, lane
+        I_total = 5.0 + J
+        joined = lambda t, x: [x[2], x[3], 5.0 * G / I_total * np.sin(x[0] + x[1]) - tau / I_total, 0.0]   # noqa: E731
+        sol = solve_ivp(joined, (0, T[-1] - T[t2]), X[t2, :, lane], t_eval=T[t2:] - T[t2], method="DOP853", rtol=1e-12, atol=1e-12)
+        assert np.abs(sol.y.T - X[t2:, :, lane]).max() < 1e-7, lane
+    assert int(eng.status.abs().sum()) == 0
