@@ -660,3 +660,49 @@ def test_body_on_a_flexibility_follows_the_rigid_body_equations_in_three_dimensi
     xf[:4] /= np.linalg.norm(xf[:4])
     assert np.abs(e.get("q") - xf[:4]).max() < 1e-7 and np.abs(e.get("v") - xf[4:]).max() < 1e-6
     assert np.abs(e.get("v") - w0).max() > 0.5     # (it has moved)
+
+
+# ---- reference unit_py/test_simulator.py:26-109 with its own robot options: backlash + rotor inertia on both joints
+def test_double_pendulum_with_backlash_velocity_increments_and_imu_at_rest():
+    """The reference's simulator consistency test on a double pendulum whose motors carry a backlash of 0.05 rad and a rotor
+    inertia of 3 kg m^2, constraint contact model, explicit Euler at 1 ms: (i) the velocity increment over a step is the
+    logged acceleration times dt (1e-12) while the backlash bounds switch on and off; (ii) under its PD law
+    (`-5000 ((q - target) + 0.07 v)` on the motor-side joints) the robot comes to rest against the backlash limits and every
+    IMU then reads an acceleration of norm 9.81 (1e-6)."""
+    from jiminy_amd.model import add_motor, add_sensor, build_model_from_urdf
+    m = build_model_from_urdf(os.path.join(robots.DATA, "double_pendulum.urdf"), name="double_pendulum_backlash",
+                              backlash={"shoulder": 0.05, "elbow": 0.05})
+    assert m.joint_names == ["universe", "shoulder", "shoulderBacklash", "elbow", "elbowBacklash"]
+    for j in ("shoulder", "elbow"):
+        add_motor(m, j, j, enableVelocityLimit=False, enableEffortLimit=False, enableArmature=True, armature=3.0)
+    for f in ("upper", "lower"):
+        add_sensor(m, "ImuSensor", f, frame_name=f)
+    assert m.frames["upper"].parent_joint == 2 and m.frames["lower"].parent_joint == 4      # the bodies hang on the backlash joints
+    e = OracleEngine(m)
+    e.set_constraint_options()
+    dt = 1e-3
+    # (i) held command, from a swinging state: the bounds engage and release along the way
+    e.start(np.array([1.2, 0.01, -0.4, -0.02]), np.array([0.5, -1.0, 0.3, 2.0]), command=np.array([20.0, -5.0]))
+    flags = set()
+    for _ in range(1500):
+        v0, a0 = e.get("v").copy(), e.get("a").copy()
+        e.step(dt, solver="euler_explicit", command_changed=False)
+        assert np.abs((e.get("v") - v0) / dt - a0).max() < 1e-12
+        flags.add(tuple(np.round(e.get("q")[1::2] / 0.025).astype(int)))
+    assert len(flags) >= 3           # inside the backlash and at limits along the way
+    # (ii) PD law towards (1.5, 0): at rest against the limits, the IMUs read gravity
+    target = np.array([1.5, 0.0])
+    e.start(np.array([1.45, 0.0, 0.0, 0.0]), np.zeros(4), command=np.zeros(2))
+    n_rest, err = 0, 0.0
+    for i in range(5000):
+        q, v = e.get("q"), e.get("v")
+        e.set_command(-5000.0 * ((q[::2] - target) + 0.07 * v[::2]))
+        e.step(dt, solver="euler_explicit", command_changed=True)
+        if (i + 1) * dt > 1.0:
+            imu = e.get("imu").reshape(2, 6)
+            for s in range(2):
+                if np.linalg.norm(imu[s, :3]) < 1e-10:
+                    n_rest += 1
+                    err = max(err, abs(np.linalg.norm(imu[s, 3:]) - 9.81))
+    assert n_rest > 1000 and err < 1e-6, (n_rest, err)
+    assert np.abs(np.abs(e.get("q")[1::2]) - 0.025).max() < 1e-4       # both bodies rest against their backlash limits
