@@ -266,15 +266,19 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
     T cs[2];
     joint_calc<T, Tp, J>(P, q, v, Mj, vj, cs);
 }
-// liMi of a joint for the sweeps: rebuilt from the cached joint coordinate and the constant placement (a
-// free-flyer's is kept)
-#ifndef JM_LANE_REBUILD
-#define JM_LANE_REBUILD 1
+// liMi of a joint for the sweeps.  Trees of JM_LANE_REBUILD_MIN_JOINTS joints and more rebuild it from the cached joint
+// coordinate and the constant placement (two scalars alive per joint instead of twelve); smaller trees keep it: with the
+// sweeps' hand-over in LDS their registers suffice, and the rebuild costs constant loads and multiply-adds on a kernel that
+// is bound by latency (measured at the end of round 5, 65 536 robots, RK4: the 7-joint arm 0.120 -> 0.099 ms per launch,
+// 0.147 -> 0.117 with the full extra terms, `tree_arm` 0.083 -> 0.073).  A free-flyer's and a spherical joint's are kept.
+#ifndef JM_LANE_REBUILD_MIN_JOINTS
+#define JM_LANE_REBUILD_MIN_JOINTS 10
 #endif
+template<class Tp> constexpr bool lane_rebuild() { return Tp::NJ - 1 >= JM_LANE_REBUILD_MIN_JOINTS; }
 template<class T, class Tp, int J, class W> JM_DEV SE3<T> limi_of(CPtr<T> P, const W & w)
 {
     constexpr int t = Tp::jtype[J];
-    if constexpr (t == JM_JT_FREEFLYER || jt_is_sph(t) || !JM_LANE_REBUILD) return w.liMi[J];
+    if constexpr (t == JM_JT_FREEFLYER || jt_is_sph(t) || !lane_rebuild<Tp>()) return w.liMi[J];
     else
     {
         using L = Layout<Tp>;
