@@ -689,39 +689,44 @@ Force contact_at_frame(const Engine & e, const FrameP & fr)
     return fl;
 }
 
-// SimpleMotor::computeEffort (basic_motors.cc:83-143)
+// SimpleMotor::computeEffort (basic_motors.cc:83-143), one motor
+void motor_law(const MotorP & mp, double vj, double command, double & uMotorOut, double & uTransmissionOut)
+{
+    const double vMotor = mp.red * vj;
+    double effortMin = -INF, effortMax = INF;
+    if (mp.flags & JM_MOTOR_EFFORT_LIMIT)
+    {
+        effortMin = -mp.effort_limit;
+        effortMax = mp.effort_limit;
+        if (mp.flags & JM_MOTOR_VELOCITY_LIMIT)
+        {
+            const double velocityDelta = mp.effort_limit * mp.inv_slope;
+            if (velocityDelta > 0.0)
+            {
+                const double velocityThr = std::max(mp.velocity_limit - velocityDelta, 0.0);
+                effortMin *= std::clamp((mp.velocity_limit + vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
+                effortMax *= std::clamp((mp.velocity_limit - vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
+            }
+        }
+    }
+    const double uMotor = std::clamp(command, effortMin, effortMax);
+    double uT = mp.red * uMotor;
+    if (mp.flags & JM_MOTOR_FRICTION)
+    {
+        if (vj > 0.0) uT += mp.fvp * vj + mp.fdp * std::tanh(mp.fds * vj);
+        else uT += mp.fvn * vj + mp.fdn * std::tanh(mp.fds * vj);
+    }
+    uMotorOut = uMotor;
+    uTransmissionOut = uT;
+}
+
+// Robot::computeMotorEfforts -> AbstractMotorBase::computeEffortAll (abstract_motor.cc:461-493)
 void motor_efforts(Engine & e, const double * v)
 {
     for (size_t i = 0; i < e.mdl.motors.size(); ++i)
     {
         const MotorP & mp = e.mdl.motors[i];
-        const double vj = v[mp.idx_v];
-        const double vMotor = mp.red * vj;
-        double effortMin = -INF, effortMax = INF;
-        if (mp.flags & JM_MOTOR_EFFORT_LIMIT)
-        {
-            effortMin = -mp.effort_limit;
-            effortMax = mp.effort_limit;
-            if (mp.flags & JM_MOTOR_VELOCITY_LIMIT)
-            {
-                const double velocityDelta = mp.effort_limit * mp.inv_slope;
-                if (velocityDelta > 0.0)
-                {
-                    const double velocityThr = std::max(mp.velocity_limit - velocityDelta, 0.0);
-                    effortMin *= std::clamp((mp.velocity_limit + vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
-                    effortMax *= std::clamp((mp.velocity_limit - vMotor) / (mp.velocity_limit - velocityThr), 0.0, 1.0);
-                }
-            }
-        }
-        const double uMotor = std::clamp(e.command[i], effortMin, effortMax);
-        double uT = mp.red * uMotor;
-        if (mp.flags & JM_MOTOR_FRICTION)
-        {
-            if (vj > 0.0) uT += mp.fvp * vj + mp.fdp * std::tanh(mp.fds * vj);
-            else uT += mp.fvn * vj + mp.fdn * std::tanh(mp.fds * vj);
-        }
-        e.uMotor[i] = uMotor;
-        e.uTransmission[i] = uT;
+        motor_law(mp, v[mp.idx_v], e.command[i], e.uMotor[i], e.uTransmission[i]);
     }
 }
 
@@ -1114,18 +1119,99 @@ struct PgsRowSet
     struct C { int start, dim, nblocks; };
     std::vector<C> cons;
 };
-bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const std::vector<double> & b,
-               std::vector<double> & x, int & iters)
+struct PgsOptions
+{
+    double friction, torsion, tolAbs, tolRel;
+    unsigned iterMax;
+};
+// PGSSolver::ProjectedGaussSeidelIter (constraint_solvers.cc:107-222): one sweep at relaxation factor w
+void pgs_sweep(const PgsOptions & po, const PgsRowSet & rs, const Dense & A, const std::vector<double> & b, double w,
+               std::vector<double> & x, std::vector<double> & y)
 {
     const int n = (int)b.size();
-    const double friction = e.opt.contact_friction, torsion = e.copt.torsion;
-    const unsigned iterMax = (unsigned)e.copt.pgs_iter_max;
-    std::vector<double> y(n, 0.0), yPrev(n, 0.0);
+    const double friction = po.friction, torsion = po.torsion;
     auto col_dot = [&](int i) {
         double s = 0.0;
         for (int k = 0; k < n; ++k) s += A(k, i) * x[k];
         return s;
     };
+    // first, the unbounded constraints, coefficient by coefficient (constraint_solvers.cc:112-128)
+    for (const auto & c : rs.cons)
+    {
+        if (c.nblocks != 0) continue;
+        for (int i = c.start; i < c.start + c.dim; ++i)
+        {
+            y[i] = b[i] - col_dot(i);
+            x[i] += y[i] / A(i, i);
+        }
+    }
+    for (int blk = 0; blk < 3; ++blk)
+        for (const auto & c : rs.cons)
+        {
+            if (c.nblocks <= blk) continue;
+            const int o = c.start;
+            // blocks (constraint_solvers.cc:48-87): 0: {2} lo 0 hi inf (joint bound: {0});
+            // 1: {3, 2} hi = torsion; 2: {0, 1, 2} hi = friction
+            int fIndex[3] = {0, 0, 0}, fSize = 1;
+            double lo = 0.0, hi = INF;
+            bool isZero = false;
+            if (c.nblocks == 3)
+            {
+                if (blk == 0) { fIndex[0] = 2; fSize = 1; }
+                else if (blk == 1) { fIndex[0] = 3; fIndex[1] = 2; fSize = 2; hi = torsion; isZero = torsion < EPS; }
+                else { fIndex[0] = 0; fIndex[1] = 1; fIndex[2] = 2; fSize = 3; hi = friction; isZero = friction < EPS; }
+            }
+            const int i0 = o + fIndex[0];
+            double & el = x[i0];
+            if (isZero)
+            {
+                el *= 0;
+                for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= 0;
+                continue;
+            }
+            double A_max = A(i0, i0);
+            y[i0] = b[i0] - col_dot(i0);
+            for (int j = 1; j < fSize - 1; ++j)
+            {
+                const int k = o + fIndex[j];
+                y[k] = b[k] - col_dot(k);
+                if (A(k, k) > A_max) A_max = A(k, k);
+            }
+            el += w * y[i0] / A_max;
+            for (int j = 1; j < fSize - 1; ++j)
+            {
+                const int k = o + fIndex[j];
+                x[k] += w * y[k] / A_max;
+            }
+            if (fSize == 1) el = std::clamp(el, lo, hi);
+            else
+            {
+                const double thr = hi * x[o + fIndex[fSize - 1]];
+                if (fSize == 2) el = std::clamp(el, -thr, thr);
+                else
+                {
+                    double squaredNorm = el * el;
+                    for (int j = 1; j < fSize - 1; ++j) squaredNorm += x[o + fIndex[j]] * x[o + fIndex[j]];
+                    if (squaredNorm > thr * thr)
+                    {
+                        const double scale = thr / std::sqrt(squaredNorm);
+                        el *= scale;
+                        for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= scale;
+                    }
+                }
+            }
+        }
+}
+
+// PGSSolver::ProjectedGaussSeidelSolver (constraint_solvers.cc:224-326)
+bool pgs_solve(const PgsOptions & po, const PgsRowSet & rs, const Dense & A, const std::vector<double> & b,
+               std::vector<double> & x, int & iters, std::vector<double> * yOut = nullptr)
+{
+    const int n = (int)b.size();
+    const unsigned iterMax = po.iterMax;
+    std::vector<double> y(n, 0.0), yPrev(n, 0.0);
+    bool converged = false;
+    iters = (int)iterMax;
     for (unsigned iter = 0; iter < iterMax; ++iter)
     {
         yPrev = y;
@@ -1136,85 +1222,27 @@ bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const st
             w = 0.01;
             if (ratio > 0.0) w += (1.0 - 0.01) * std::pow(ratio, 2.0);
         }
-        // first, the unbounded constraints, coefficient by coefficient (constraint_solvers.cc:112-128)
-        for (const auto & c : rs.cons)
-        {
-            if (c.nblocks != 0) continue;
-            for (int i = c.start; i < c.start + c.dim; ++i)
-            {
-                y[i] = b[i] - col_dot(i);
-                x[i] += y[i] / A(i, i);
-            }
-        }
-        for (int blk = 0; blk < 3; ++blk)
-            for (const auto & c : rs.cons)
-            {
-                if (c.nblocks <= blk) continue;
-                const int o = c.start;
-                // blocks (constraint_solvers.cc:48-87): 0: {2} lo 0 hi inf (joint bound: {0});
-                // 1: {3, 2} hi = torsion; 2: {0, 1, 2} hi = friction
-                int fIndex[3] = {0, 0, 0}, fSize = 1;
-                double lo = 0.0, hi = INF;
-                bool isZero = false;
-                if (c.nblocks == 3)
-                {
-                    if (blk == 0) { fIndex[0] = 2; fSize = 1; }
-                    else if (blk == 1) { fIndex[0] = 3; fIndex[1] = 2; fSize = 2; hi = torsion; isZero = torsion < EPS; }
-                    else { fIndex[0] = 0; fIndex[1] = 1; fIndex[2] = 2; fSize = 3; hi = friction; isZero = friction < EPS; }
-                }
-                const int i0 = o + fIndex[0];
-                double & el = x[i0];
-                if (isZero)
-                {
-                    el *= 0;
-                    for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= 0;
-                    continue;
-                }
-                double A_max = A(i0, i0);
-                y[i0] = b[i0] - col_dot(i0);
-                for (int j = 1; j < fSize - 1; ++j)
-                {
-                    const int k = o + fIndex[j];
-                    y[k] = b[k] - col_dot(k);
-                    if (A(k, k) > A_max) A_max = A(k, k);
-                }
-                el += w * y[i0] / A_max;
-                for (int j = 1; j < fSize - 1; ++j)
-                {
-                    const int k = o + fIndex[j];
-                    x[k] += w * y[k] / A_max;
-                }
-                if (fSize == 1) el = std::clamp(el, lo, hi);
-                else
-                {
-                    const double thr = hi * x[o + fIndex[fSize - 1]];
-                    if (fSize == 2) el = std::clamp(el, -thr, thr);
-                    else
-                    {
-                        double squaredNorm = el * el;
-                        for (int j = 1; j < fSize - 1; ++j) squaredNorm += x[o + fIndex[j]] * x[o + fIndex[j]];
-                        if (squaredNorm > thr * thr)
-                        {
-                            const double scale = thr / std::sqrt(squaredNorm);
-                            el *= scale;
-                            for (int j = 1; j < fSize - 1; ++j) x[o + fIndex[j]] *= scale;
-                        }
-                    }
-                }
-            }
+        pgs_sweep(po, rs, A, b, w, x, y);
         double ymax = 0.0;
         for (int i = 0; i < n; ++i) ymax = std::max(ymax, std::fabs(y[i]));
-        const double tol = e.copt.tol_abs + e.copt.tol_rel * ymax + EPS;
+        const double tol = po.tolAbs + po.tolRel * ymax + EPS;
         bool ok = true;
         for (int i = 0; i < n; ++i) ok &= std::fabs(y[i] - yPrev[i]) < tol;
         if (ok)
         {
             iters = (int)iter + 1;
-            return true;
+            converged = true;
+            break;
         }
     }
-    iters = (int)iterMax;
-    return false;
+    if (yOut) *yOut = y;
+    return converged;
+}
+bool pgs_solve(const Engine & e, const PgsRowSet & rs, const Dense & A, const std::vector<double> & b,
+               std::vector<double> & x, int & iters)
+{
+    const PgsOptions po{e.opt.contact_friction, e.copt.torsion, e.copt.tol_abs, e.copt.tol_rel, (unsigned)e.copt.pgs_iter_max};
+    return pgs_solve(po, rs, A, b, x, iters);
 }
 
 V3 log3(const M3 & R);
@@ -1980,6 +2008,12 @@ void start(Engine & e)
 }
 
 // One fixed step (AbstractStepper::tryStep + success bookkeeping engine.cc:2132-2187)
+namespace rk4   // runge_kutta4_stepper.h:12-23
+{
+const double A[4][4] = {{0, 0, 0, 0}, {0.5, 0, 0, 0}, {0, 0.5, 0, 0}, {0, 0, 1.0, 0}};
+const double c[4] = {0.0, 0.5, 0.5, 1.0};
+const double b[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+}
 void try_step(Engine & e, int solver, double dt)
 {
     const Model & m = e.mdl;
@@ -2002,8 +2036,8 @@ void try_step(Engine & e, int solver, double dt)
     }
     else
     {
-        static const double A[4][4] = {{0, 0, 0, 0}, {0.5, 0, 0, 0}, {0, 0.5, 0, 0}, {0, 0, 1.0, 0}};
-        static const double b[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+        using rk4::A;
+        using rk4::b;
         std::vector<double> * kv = e.st_kv, * ka = e.st_ka;
         std::copy(e.v.begin(), e.v.end(), kv[0].begin());
         std::copy(e.a.begin(), e.a.end(), ka[0].begin());
@@ -2064,6 +2098,7 @@ const double A[7][7] = {
     {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0, 0},
     {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0}};
 const double b[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
+const double c[7] = {0.0, 2.0 / 10.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0, 1.0, 1.0};
 const double e[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0, 187.0 / 2100.0, 1.0 / 40.0};
 constexpr double STEPPER_ORDER = 5.0, SAFETY = 0.8, ERROR_THRESHOLD = 0.5, MIN_FACTOR = 0.2, MAX_FACTOR = 5.0;
 }
@@ -2176,6 +2211,22 @@ struct AdaptiveOptions
     int successiveIterFailedMax = 1000;
 };
 
+// RungeKuttaDOPRIStepper::adjustStep after the error estimate (runge_kutta_dopri_stepper.cc:24-56): true = accepted
+bool dopri_adjust(double error, double & dt)
+{
+    if (error < 1.0)
+    {
+        if (error < std::min(dopri::ERROR_THRESHOLD, std::pow(dopri::SAFETY, dopri::STEPPER_ORDER)))
+        {
+            const double clipped = std::max(error, std::pow(dopri::MAX_FACTOR / dopri::SAFETY, -dopri::STEPPER_ORDER));
+            dt *= dopri::SAFETY * std::pow(clipped, -1.0 / dopri::STEPPER_ORDER);
+        }
+        return true;
+    }
+    dt *= std::max(dopri::SAFETY * std::pow(error, -1.0 / (dopri::STEPPER_ORDER - 2.0)), dopri::MIN_FACTOR);
+    return false;
+}
+
 // RungeKuttaDOPRIStepper::tryStep: returns 0 = success, 1 = failure (error too large), 2 = error (NaN)
 int dopri_try_step(Engine & e, const AdaptiveOptions & ao, double & t, double & dt)
 {
@@ -2238,14 +2289,9 @@ int dopri_try_step(Engine & e, const AdaptiveOptions & ao, double & t, double & 
     }
     if (nan) return 2;   // "The estimated integration error contains 'nan'."
     // adjustStep (boost odeint controlled stepper rule)
-    if (error < 1.0)
+    const double dt_done = dt;
+    if (dopri_adjust(error, dt))
     {
-        const double dt_done = dt;
-        if (error < std::min(dopri::ERROR_THRESHOLD, std::pow(dopri::SAFETY, dopri::STEPPER_ORDER)))
-        {
-            const double clipped = std::max(error, std::pow(dopri::MAX_FACTOR / dopri::SAFETY, -dopri::STEPPER_ORDER));
-            dt *= dopri::SAFETY * std::pow(clipped, -1.0 / dopri::STEPPER_ORDER);
-        }
         // abstract_stepper.cc:41-48: NaN in the new derivative -> IS_ERROR, state not committed
         for (double x : ka[6]) if (x != x) return 2;
         // success: state <- solution, derivative <- k_last (FSAL)
@@ -2253,7 +2299,6 @@ int dopri_try_step(Engine & e, const AdaptiveOptions & ao, double & t, double & 
         t += dt_done;
         return 0;
     }
-    dt *= std::max(dopri::SAFETY * std::pow(error, -1.0 / (dopri::STEPPER_ORDER - 2.0)), dopri::MIN_FACTOR);
     return 1;
 }
 
@@ -2709,5 +2754,93 @@ void orc_batch_run_dopri(void * h, const orc_batch_io * io, const orc_adaptive_i
         ad->succ_too_large[l] = S.successiveIterTooLarge; ad->succ_failed[l] = S.successiveIterFailed;
         store_lane(e, *io, l);
     }
+}
+
+// ---- leaf entry points: the very functions the engine above calls, one application per case.  They exist so that
+// tests/test_reference_cpp_leaves.py can hold them against the outputs of the REFERENCE'S OWN TEXT compiled by
+// tools/make_ref_cpp_fixtures.py (tests/golden/ref_cpp_leaves.npz); the layouts are that tool's.
+// params[n][12] = stiffness damping friction transitionEps transitionVelocity | n(3) depth v(3)
+void orc_leaf_contact_law(int64_t n, const double * params, double * out /* [n][3] */)
+{
+    for (int64_t i = 0; i < n; ++i)
+    {
+        const double * c = params + i * 12;
+        jm_options o{};
+        o.contact_stiffness = c[0]; o.contact_damping = c[1]; o.contact_friction = c[2];
+        o.contact_transition_eps = c[3]; o.contact_transition_velocity = c[4];
+        const V3 f = contact_law(o, V3{c[5], c[6], c[7]}, c[8], V3{c[9], c[10], c[11]});
+        out[i * 3 + 0] = f.x; out[i * 3 + 1] = f.y; out[i * 3 + 2] = f.z;
+    }
+}
+// params[n][14] = red effLimOn velLimOn invSlope effortLimit velocityLimit fricOn fvp fvn fdp fdn fds | v command
+void orc_leaf_motor_law(int64_t n, const double * params, double * u_motor, double * u_transmission)
+{
+    for (int64_t i = 0; i < n; ++i)
+    {
+        const double * c = params + i * 14;
+        MotorP mp{};
+        mp.red = c[0];
+        mp.flags = (c[1] != 0.0 ? JM_MOTOR_EFFORT_LIMIT : 0) | (c[2] != 0.0 ? JM_MOTOR_VELOCITY_LIMIT : 0) |
+                   (c[6] != 0.0 ? JM_MOTOR_FRICTION : 0);
+        mp.inv_slope = c[3]; mp.effort_limit = c[4]; mp.velocity_limit = c[5];
+        mp.fvp = c[7]; mp.fvn = c[8]; mp.fdp = c[9]; mp.fdn = c[10]; mp.fds = c[11];
+        motor_law(mp, c[12], c[13], u_motor[i], u_transmission[i]);
+    }
+}
+// code: 1 accepted, 0 rejected, 2 NaN error (the reference throws)
+void orc_leaf_dopri_adjust(int64_t n, const double * error, const double * dt, int32_t * code, double * dt_out)
+{
+    for (int64_t i = 0; i < n; ++i)
+    {
+        double d = dt[i];
+        if (error[i] != error[i]) code[i] = 2;
+        else code[i] = dopri_adjust(error[i], d) ? 1 : 0;
+        dt_out[i] = d;
+    }
+}
+void orc_leaf_dopri_constants(double * out5)
+{
+    out5[0] = dopri::STEPPER_ORDER; out5[1] = dopri::SAFETY; out5[2] = dopri::ERROR_THRESHOLD;
+    out5[3] = dopri::MIN_FACTOR; out5[4] = dopri::MAX_FACTOR;
+}
+// row major: rk4 A(16) c(4) b(4), dopri A(49) c(7) b(7) e(7)
+void orc_leaf_tableaux(double * out94)
+{
+    double * o = out94;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) *o++ = rk4::A[i][j];
+    for (int i = 0; i < 4; ++i) *o++ = rk4::c[i];
+    for (int i = 0; i < 4; ++i) *o++ = rk4::b[i];
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) *o++ = dopri::A[i][j];
+    for (int i = 0; i < 7; ++i) *o++ = dopri::c[i];
+    for (int i = 0; i < 7; ++i) *o++ = dopri::b[i];
+    for (int i = 0; i < 7; ++i) *o++ = dopri::e[i];
+}
+// types[nc]: ConstraintRegistryType (0 contact frame, 2 joint bound, 3 user); A row major (symmetric); prm = friction,
+// torsion, tolAbs, tolRel.  sweep_w >= 0: ONE sweep at that relaxation factor; sweep_w < 0: the solver loop.
+// Returns the convergence flag of the loop (1 for a sweep); x is updated in place, y receives the residuals.
+int orc_leaf_pgs(int nc, const int32_t * types, const int32_t * dims, int n, const double * A, const double * b,
+                 const double * prm, int iter_max, double sweep_w, double * x, double * y, int32_t * iters)
+{
+    PgsRowSet rs;
+    int row = 0;
+    for (int c = 0; c < nc; ++c)
+    {
+        // the block table of the PGSSolver constructor (constraint_solvers.cc:46-90)
+        const int nblocks = types[c] == 2 ? 1 : (types[c] == 0 || types[c] == 1 ? 3 : 0);
+        rs.cons.push_back({row, dims[c], nblocks});
+        row += dims[c];
+    }
+    Dense Ad(n, n);
+    std::copy(A, A + (size_t)n * n, Ad.d.begin());
+    const std::vector<double> bv(b, b + n);
+    std::vector<double> xv(x, x + n), yv(n, 0.0);
+    const PgsOptions po{prm[0], prm[1], prm[2], prm[3], (unsigned)iter_max};
+    int ok = 1, it = 1;
+    if (sweep_w >= 0.0) pgs_sweep(po, rs, Ad, bv, sweep_w, xv, yv);
+    else ok = pgs_solve(po, rs, Ad, bv, xv, it, &yv) ? 1 : 0;
+    std::copy(xv.begin(), xv.end(), x);
+    std::copy(yv.begin(), yv.end(), y);
+    if (iters) *iters = it;
+    return ok;
 }
 }

@@ -1,8 +1,9 @@
 """Scalar restatement of the reference's random tile terrain. TEST INFRASTRUCTURE ONLY (same rules as oracle.cpp).
 
 Follows core/src/utilities/random.cc line by line: `xxHash` (:200-256), `uniformSparseFromStateImpl` (:488-501),
-`tile2dInterp1d` (:511-550), `tiles` (:552-656).  Pinned in tests/test_terrain.py: the hash against the independent
-`xxhash` package (XXH32 reference implementation), the generator on its structural laws (constant tile interiors,
+`tile2dInterp1d` (:511-550), `tiles` (:552-656).  Pinned: the hash against the reference's own compiled text
+(tests/test_reference_cpp_leaves.py) and, for keys shorter than 16 bytes -- where the reference IS XXH32 --, against the independent
+`xxhash` package (tests/test_terrain.py); the generator on its structural laws (constant tile interiors,
 continuity across the blend bands, sparsity)."""
 import math
 import struct
@@ -27,9 +28,14 @@ def xx_hash(data: bytes, seed: int) -> int:
             v1, v2, v3, v4 = rnd(v1, w[0]), rnd(v2, w[1]), rnd(v3, w[2]), rnd(v4, w[3])
             i += 16
         h = (rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18)) & M
+        # random.cc:228 `len &= 15;` BEFORE `hash += len` (:236): for keys of 16 bytes or more the reference adds the
+        # length of the TAIL, where XXH32 adds the whole length -- found by the reference-compiled fixtures
+        # (tests/golden/ref_cpp_leaves.npz, round 6).  The reference only hashes 4- and 8-byte keys on the hot path.
+        n_added = n & 15
     else:
         h = (seed + P5) & M
-    h = (h + n) & M
+        n_added = n
+    h = (h + n_added) & M
     while n - i >= 4:
         h = (h + struct.unpack_from("<I", data, i)[0] * P3) & M
         h = (rotl32(h, 17) * P4) & M

@@ -10,13 +10,18 @@ from oracle import terrain_numpy as ref
 
 
 def test_scalar_hash_is_xxh32():
-    """The oracle's restatement of `xxHash` against the XXH32 reference implementation (python-xxhash)."""
+    """The oracle's restatement of `xxHash` against the XXH32 reference implementation (python-xxhash).
+    Keys of 16 bytes or more: the reference adds `len & 15` instead of `len` (random.cc:228, 236), so it is XXH32 of the
+    same bytes only when the length is a multiple of 16 ... minus the length term; the reference-compiled fixtures
+    (tests/test_reference_cpp_leaves.py) pin those, this test pins the short keys the hot path hashes."""
     xxhash = pytest.importorskip("xxhash")
     rg = np.random.default_rng(0)
-    for n in (0, 1, 3, 4, 7, 8, 15, 16, 17, 31, 32, 100):
+    for n in (0, 1, 3, 4, 7, 8, 12, 15):
         data = rg.bytes(n)
         for seed in (0, 1, 0xDEADBEEF):
             assert ref.xx_hash(data, seed) == xxhash.xxh32(data, seed=seed).intdigest()
+    data = rg.bytes(37)
+    assert ref.xx_hash(data, 5) != xxhash.xxh32(data, seed=5).intdigest()
 
 
 def test_tensor_hash_matches_the_scalar_one():
