@@ -704,6 +704,15 @@ def _constraint_rows_self_test(model: CompiledModel, variant: int, device: torch
 
 
 def _verified_library(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
+    try:
+        return _verified_library_impl(model, dtype, device)
+    finally:
+        # the float64 probe rows (device tensors) only serve the cross-variant comparison inside the call above
+        for k in [k for k in _OUTPUT_ROWS_F64 if k[0] == model.topology_hash()]:
+            del _OUTPUT_ROWS_F64[k]
+
+
+def _verified_library_impl(model: CompiledModel, dtype: torch.dtype, device: torch.device) -> HipLibrary:
     """The HIP library of `model`, checked once per process, topology and dtype by
     `_library_self_test`.  A build that fails the check is a toolchain mis-compile (DESIGN.md
     section 4.7): the next build variant (codegen.BUILD_VARIANTS) is compiled and checked instead;
@@ -774,6 +783,7 @@ class BatchedEngine:
             raise RuntimeError("no HIP device available: the batched engine runs on the GPU only "
                                "(there is no CPU fallback)")
         self.model = model
+        self._topology_at_creation = model.topology_hash()    # kernels and the constraint-state rows are sized for THIS model
         self.batch_size = int(batch_size)
         self.dtype = dtype
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -1019,6 +1029,10 @@ class BatchedEngine:
                                       "can be registered")
         if name in self._user_constraints:
             raise ValueError(f"a constraint named '{name}' is already registered")                  # model.cc:884-890
+        if self.model.topology_hash() != self._topology_at_creation:
+            raise BadControlFlow("the model was modified after this engine was created (constraints, contact points or sensors "
+                                 "declared on it later): the kernels and the con_flags / con_data rows of the batch were sized "
+                                 "for the model as it was -- declare everything on the model first, then create the engine")
         freq = constraint.baumgarte_freq
         if freq is not None and freq < 0.0:
             raise ValueError("Natural frequency must be positive.")                                 # abstract_constraint.cc:91-94
@@ -1026,7 +1040,9 @@ class BatchedEngine:
         others = {f for _, _, _, f in self._user_constraints.values()}
         if others and others != {freq}:
             raise NotImplementedError("the user constraints of a batch share one Baumgarte frequency "
-                                      f"({next(iter(others))}): give this one the same `baumgarte_freq`")
+                                      f"({next(iter(others))}): give this one the same `baumgarte_freq` (mind the defaults: "
+                                      "JointConstraint None = the gains of contacts.stabilizationFreq, the frame-type "
+                                      "constraints 0.0 = the reference's freshly created constraint)")
         if self._options["contacts"]["model"] != "constraint" or self.dtype != torch.float64:
             raise NotImplementedError("user constraints need the constraint contact model on a float64 batch")
         if "con_flags" not in self._fields:

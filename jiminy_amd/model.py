@@ -739,7 +739,7 @@ def add_frame_constraint(model: CompiledModel, name: str, frame_name: str,
     model.frame(frame_name)
     if len(mask_dofs) != 6 or not any(mask_dofs):
         raise ValueError("mask_dofs must hold six booleans, at least one of them set")
-    if any(x["name"] == name for x in model.constraint_frames):
+    if any(x["name"] == name for x in model.constraint_frames + model.constraint_joints):
         raise ValueError(f"constraint '{name}' already declared")     # model.cc: "A constraint with name ... already exists"
     model.constraint_frames.append({"name": name, "frame": frame_name,
                                     "mask": int(sum(1 << d for d in range(6) if mask_dofs[d]))})

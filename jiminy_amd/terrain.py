@@ -206,7 +206,7 @@ def _perlin_process(wavelength: float, num_octaves: int, n: int, seed: int, peri
             shift = [g.uniform() for _ in range(n)]
             octaves.append((wl, scale, shift, g()))
         else:
-            wl_p = float(period) / max(round(float(period) / wl), 1.0)
+            wl_p = float(period) / max(math.floor(float(period) / wl + 0.5), 1.0)     # std::round: half away from zero
             size = int(float(period) / wl_p)
             shift = [g.uniform() for _ in range(n)]
             table = []

@@ -241,7 +241,7 @@ class PeriodicPerlinOctave(RandomPerlinOctave):
         import numpy as np
         if period < wavelength:
             raise ValueError("'period' must be larger than 'wavelength'.")
-        self.wavelength = period / max(round(period / wavelength), 1.0)
+        self.wavelength = period / max(math.floor(period / wavelength + 0.5), 1.0)    # std::round (random.hxx:499): half away from zero
         self.n, self.period, self._np = n, period, np
         self.size = int(period / self.wavelength)
         self.shift = [g.uniform() for _ in range(n)]

@@ -271,3 +271,14 @@ def test_branch_parallel_decomposition_of_the_shipped_and_the_authored_robots():
     for m in (load_builtin("cartpole"), load_builtin("double_pendulum"), robots.tree_arm(False), robots.tree_arm(True),
               robots.point_mass()):
         assert codegen.quad_structure(m) is None
+
+
+def test_constraint_names_are_unique_across_frame_and_joint_constraints():
+    """`Model::addConstraint` refuses any duplicate name (model.cc:884-890), whatever the constraint types."""
+    from jiminy_amd.model import add_frame_constraint, add_joint_constraint
+    from tests import robots
+    m = robots.tree_arm(False)
+    joint = m.joint_names[1]
+    add_joint_constraint(m, "hold", joint)
+    with pytest.raises(ValueError, match="already declared"):
+        add_frame_constraint(m, "hold", next(iter(m.frames)) if isinstance(m.frames, dict) else m.frames[0].name)

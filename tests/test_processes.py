@@ -148,5 +148,10 @@ def test_perlin_time_processes_match_the_scalar_restatement_lane_by_lane():
     assert 0.05 < float(dense.abs().max()) < 1.5
     with pytest.raises(ValueError):
         PeriodicPerlinProcess(0.4, 0.3, 2, B)
+    # period / wavelength = 2.5 exactly: std::round goes AWAY from zero (3 knots, random.hxx:499-500), Python's round to even (2)
+    half = PeriodicPerlinProcess(2.0, 5.0, 1, 2)
+    half.reset(torch.tensor([5, 9]))
+    assert half._size == [3] and half._octaves[0][0] == 5.0 / 3.0
+    assert float(half(0.7)[0]) == terrain_numpy.PeriodicPerlinProcess(2.0, 5.0, 1, 1, 5)([0.7])
     with pytest.raises(ValueError):
         RandomPerlinProcess(0.4, 0, B)

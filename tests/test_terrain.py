@@ -161,7 +161,7 @@ def test_periodic_perlin_grounds_match_the_scalar_restatement_and_are_periodic()
     from oracle import terrain_numpy as orc
     rg = np.random.default_rng(16)
     x, y = rg.uniform(-7, 7, 400), rg.uniform(-7, 7, 400)
-    for wl, period, n_oct, seed in ((1.0, 4.0, 1, 3), (1.5, 6.0, 3, 77)):
+    for wl, period, n_oct, seed in ((1.0, 4.0, 1, 3), (1.5, 6.0, 3, 77), (2.0, 5.0, 1, 8)):      # last: a half-way ratio (std::round)
         t2, s2 = terrain.periodic_perlin_ground(wl, period, n_oct, seed), orc.periodic_perlin_ground(wl, period, n_oct, seed)
         got = t2(torch.from_numpy(x), torch.from_numpy(y)).numpy()
         assert np.abs(got - np.array([s2(a, b) for a, b in zip(x, y)])).max() < 1e-12
