@@ -331,6 +331,28 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                                     "only avg_launch_ms is measured in this run"}
         except Exception:
             traffic = None
+    # fp64 vector roof (MI355X: 78.6 TFLOP/s = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz; no MFMA on this path).  Two counts:
+    # `executed` = measured VALU instructions per wave-launch (committed PMC profile) x flops per VALU instruction of the
+    # evaluation loop (static ISA mix, tools/isa_mix.py) x 64 lanes x waves -- what the pipes did, replicated trunk work and
+    # padding included; `algorithmic` = SURVEY.md 8d's estimate per env-step (47 kflop ANYmal, 114 kflop Atlas) x robots.
+    flops = None
+    mix_path = os.path.join(ROOT, "profiles", f"isa_mix_{model_name}_latest.json")
+    alg_kflop = {"anymal": 47.0, "atlas": 114.0}.get(model_name)
+    if valu is not None and os.path.exists(mix_path) and not constrained and solver == "runge_kutta_4":
+        try:
+            with open(mix_path) as f:
+                mix = json.load(f)
+            executed = valu["insts_per_wave_per_launch"] * mix["flops_per_valu_instruction_per_lane"] * 64.0 * valu["waves"]
+            flops = {"bound": "fp64-valu", "peak": 78.6, "unit": "TFLOP/s",
+                     "achieved_TFLOPs": executed / avg_launch_s / 1e12, "frac": executed / avg_launch_s / 1e12 / 78.6,
+                     "flops_per_launch_executed": executed,
+                     "achieved_TFLOPs_algorithmic": (alg_kflop * 1e3 * B / avg_launch_s / 1e12) if alg_kflop else None,
+                     "frac_algorithmic": (alg_kflop * 1e3 * B / avg_launch_s / 1e12 / 78.6) if alg_kflop else None,
+                     "isa_mix": {k: mix[k] for k in ("loop_valu", "loop_fma64", "loop_mul64", "loop_add64", "loop_dpp",
+                                                     "fused_share_of_fp64_arith", "fp64_arith_share_of_valu")},
+                     "from": [os.path.relpath(mix_path, ROOT), valu.get("from")]}
+        except Exception:
+            flops = None
     what_ran = ("4 dynamics evaluations (FK + contacts + motors + ABA)" if solver == "runge_kutta_4" else
                 "1 dynamics evaluation (FK + contacts + motors + " + ("CRBA-free constrained ABA + PGS" if constrained else "ABA") + ")")
     extras_txt = ("full computeExtraTerms (energies, subtree masses / centroidal momentum and its derivative, RNEA joint "
@@ -365,7 +387,7 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                      "kernel": kernel_name, "launches_timed": n_launch,
                      "avg_launch_ms": 1e3 * avg_launch_s,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "secondary": valu},
+                     "secondary": valu, "flops": flops},
     }
     if gather is not None:
         out["gather"] = {"dtype": ctx.gather_dtype, "every": ctx.gather_every, "collectives": gather.launched,
@@ -380,7 +402,8 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
                "steps": steps, "warmup": warmup, "ms_per_step": out["ms_per_step"],
                "ms_per_launch": 1e3 * avg_launch_s, "launches_timed": n_launch, "kernel": kernel_name,
                "algorithmic_bytes_per_launch": alg_bytes_per_launch, "achieved_GBps": achieved,
-               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue": valu,
+               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "valu_issue": valu, "flops": flops,
+               "lanes_nan_max": nan_frac,
                "lanes_ok_min": ok_frac, "extra_terms_written": extras_written,
                **({"mean_active_constraints": active, "lanes_pgs_iteration_cap_last_eval": pgs_fail} if constrained else {})}
     return out, states, model
@@ -389,6 +412,10 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
 # secondary workloads of the driver-run line (N = 1): the reference's SHIPPED configuration (anymal_options.toml:5,24 /
 # atlas_options.toml: euler_explicit + contacts.model = "constraint") and BASELINE.json configs[3]'s robot
 SECONDARY = (
+    # the headline robot and solver at HALF the step: the headline's dt = 1e-3 with contacts.stiffness = 1e6 sits at the edge
+    # of RK4's stability region (0.2 % of the lanes go non-finite within a 20-step episode, `lanes_nan_max` of the headline);
+    # at 5e-4 every lane stays finite -- the same launch, a workload the reference would not abort on
+    dict(model_name="anymal", B=65536, solver="runge_kutta_4", contact_model="spring_damper", dt=5e-4, steps=20, warmup=3),
     dict(model_name="anymal", B=65536, solver="euler_explicit", contact_model="constraint", dt=1e-3, steps=20, warmup=3),
     dict(model_name="atlas", B=32768, solver="runge_kutta_4", contact_model="spring_damper", dt=2.5e-4, steps=20, warmup=3),
     dict(model_name="atlas", B=32768, solver="euler_explicit", contact_model="constraint", dt=5e-4, steps=8, warmup=2),
