@@ -39,15 +39,19 @@ namespace jm
 {
 extern template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
 #if JM_TOPO_QUAD
-extern template __global__ void k_quad_con<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con<double, Topo, 0>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_quad_gen<double, Topo>(const BatchArgs<double>);
-extern template __global__ void k_quad_con_gen<double, Topo>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_gen<double, Topo, 0>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_gen<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_quad_dopri<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 extern template __global__ void k_quad_dopri_gen<double, Topo>(const BatchArgs<double>, const AdaptiveArgs<double>, int);
 #endif
 #if JM_TOPO_QCON_SPLIT
-extern template __global__ void k_quad_con_split<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
-extern template __global__ void k_quad_con_split<double, Topo, 2>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_split<double, Topo, 1, 0>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_split<double, Topo, 2, 0>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_split<double, Topo, 1, 1>(const BatchArgs<double>, const QConArgs<double>);
+extern template __global__ void k_quad_con_split<double, Topo, 2, 1>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
@@ -280,18 +284,18 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                         hipLaunchKernelGGL((jm::k_qtip_pgs<double, Tp>), dim3(g64), dim3(256), 0, s, C, A.P, (unsigned)A.B);
                 };
                 C.split_pass = 0;
-                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
+                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1, 1>), dim3(g64), dim3(256), 0, s, A, C);
                 hipLaunchKernelGGL((jm::k_qcon_exact<double, Tp>), dim3(g64), dim3(256), 0, s, C);
                 if constexpr (jm::QTip<Tp>::ON)
                     hipLaunchKernelGGL((jm::k_qtip_exact<double, Tp>), dim3((unsigned)((A.B + 255) / 256)), dim3(256), 0, s, C);
                 for (int pass = 1; pass <= 3; ++pass)
                 {
                     C.split_pass = pass;
-                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, s, A, C);
+                    hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1, 1>), dim3(g64), dim3(256), 0, s, A, C);
                     solve();
                 }
                 C.split_pass = 4;
-                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, s, A, C);
+                hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2, 1>), dim3(g64), dim3(256), 0, s, A, C);
                 return;
             }
             // robots whose solves live in the workspace: step launches go through pre | solve | post per evaluation (jm_qcon.h)
@@ -327,7 +331,7 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                     for (int e = 0; e < n_evals; ++e)
                     {
                         C.split_e = e;
-                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1>), dim3(g64), dim3(256), 0, sc, A, C);
+                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1, 0>), dim3(g64), dim3(256), 0, sc, A, C);
                         // (solves of up to 64 rows, then the waves that hold a larger one)
                         hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
                         if constexpr (jm::QConRows<Tp>::MAXM > 64)
@@ -335,7 +339,7 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                         // (the waves whose robots all have few active joint rows: operational-space form, jm_qtip.h)
                         if constexpr (jm::QTip<Tp>::ON)
                             hipLaunchKernelGGL((jm::k_qtip_pgs<double, Tp>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
-                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2>), dim3(g64), dim3(256), 0, sc, A, C);
+                        hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 2, 0>), dim3(g64), dim3(256), 0, sc, A, C);
                     }
                 }
                 if (n_chunks > 1)
@@ -348,9 +352,15 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
             }
         }
         // (user-registered JointConstraints: kernels built with them -- the variation kernel, or any kernel of a split topology)
+        // (`start` / `reset` -- Engine::start's four passes with the exact solve -- are instantiations of their own)
+        const bool init = A.mode == jm::MODE_START || A.mode == jm::MODE_RESET;
         if (A.model_lane || A.applied || A.ground_h || (b->joint_locks && !jm::qcon_split<Tp>()))
-            hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
-        else hipLaunchKernelGGL((jm::k_quad_con<double, Tp>), dim3(grid), dim3(nth), 0, s, A, C);
+        {
+            if (init) hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp, 1>), dim3(grid), dim3(nth), 0, s, A, C);
+            else hipLaunchKernelGGL((jm::k_quad_con_gen<double, Tp, 0>), dim3(grid), dim3(nth), 0, s, A, C);
+        }
+        else if (init) hipLaunchKernelGGL((jm::k_quad_con<double, Tp, 1>), dim3(grid), dim3(nth), 0, s, A, C);
+        else hipLaunchKernelGGL((jm::k_quad_con<double, Tp, 0>), dim3(grid), dim3(nth), 0, s, A, C);
     }
     else { (void)b; (void)A; (void)C0; (void)s; }
 }

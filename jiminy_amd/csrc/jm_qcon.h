@@ -56,6 +56,12 @@
                          // full evaluation (cheaper arithmetic, but it keeps the free evaluation's data live across the PGS
                          // sweeps: measured slower on ANYmal because the sweeps then spill)
 #endif
+#ifndef JM_QCON_INIT_ON_CHIP
+#define JM_QCON_INIT_ON_CHIP 1  // Engine::start / reset passes whose solve fits the on-chip part of the region take the branch-free
+                                // on-chip store and the register-resident sweeps like every other evaluation (0: round-5 behaviour,
+                                // the general store with its per-access LDS / HBM branch and the quad-cooperative sweeps: ANYmal,
+                                // 65 536 robots, reset of every lane 11.6 ms -- twelve times a step)
+#endif
 #ifndef JM_QCON_REGS_NIT
 #define JM_QCON_REGS_NIT 4  // on-chip solves of up to 4 * JM_QCON_REGS_NIT rows run out of registers (qcon_pgs_regs / _fixed), larger
                             // ones out of LDS (qcon_pgs with the on-chip store): a quarter of a 40-row matrix is 400 registers
@@ -1532,7 +1538,7 @@ namespace jm
 // PH = 1 / 2 (split stepping, regular evaluations only): the part before the solve (free acceleration, switching, delassus
 // matrix, right-hand side and warm start into the workspace; constraint context into the stage buffer) / after it (multipliers
 // back to the lane state, evaluation that applies them).
-template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH>
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH, int INIT>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1562,8 +1568,8 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         apply();
         return;
     }
-    const bool refresh = start_passes < 0;
-    const bool init = start_passes > 0;
+    const bool refresh = INIT == 1 ? false : start_passes < 0;
+    const bool init = INIT < 0 ? start_passes > 0 : INIT == 1;
     const int n_pass = init ? start_passes : 1;
     // (compact batches of the per-stage adaptive stepper: the per-lane friction stays in batch order, BatchArgs::lane_map)
     const T friction = C.friction ? C.friction[A.lane_map ? (unsigned)A.lane_map[r32] : r32] : P[L::OPT + 8];
@@ -1770,7 +1776,7 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
         if constexpr (MFIT >= 4)
         {
             // the whole solve of this robot fits the on-chip part of its region (quad-uniform decision)
-            if (!init && cx.m <= MFIT) phases(QStoreChip<T, (MFIT + 3) / 4>{V.lds});
+            if ((JM_QCON_INIT_ON_CHIP || !init) && cx.m <= MFIT) phases(QStoreChip<T, (MFIT + 3) / 4>{V.lds});
             else phases(V);
         }
         else phases(V);
@@ -2101,7 +2107,8 @@ template<class T, class Tp> JM_DEV QStore<T> qcon_store(T * lds, T * ws, long lo
     return {lds, ws + r, B, CAP};
 }
 
-template<class T, class Tp>
+// INIT = 0: every mode but `start` / `reset`; INIT = 1: those two (jm_lib.cpp picks the kernel by mode)
+template<class T, class Tp, int INIT>
 __global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
 k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
 {
@@ -2120,7 +2127,7 @@ k_quad_con(const BatchArgs<T> A, const QConArgs<T> C)
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
-    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP>(A, r, k, table, S, &C, &V);
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP, false, 0, INIT>(A, r, k, table, S, &C, &V);
 }
 // ---------------------------------------------------------------- split stepping: pre | solve | post
 // Robots whose solves do not fit the chip (Atlas: 27-52 rows standing, up to JM_QCON_MAXM) step through THREE launches per
@@ -2143,7 +2150,8 @@ template<class T, class Tp> JM_DEV QStore<T> qcon_split_store(T * ws, long long 
     return {nullptr, ws + (size_t)r * (size_t)qcon_split_region_rows<T, Tp>(), 1u, 0};
 }
 
-template<class T, class Tp, int PH>
+// INIT = 0: the parts of a step launch; INIT = 1: the passes of `start` / `reset` (jm_lib.cpp picks by mode)
+template<class T, class Tp, int PH, int INIT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PH == 1 ? JM_QCON_PRE_WAVES : JM_QCON_POST_WAVES)))
 k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
 {
@@ -2158,7 +2166,7 @@ k_quad_con_split(const BatchArgs<T> A, const QConArgs<T> C)
     T * tile = C.stage + (size_t)(r >> 4) * (size_t)SR::TILE;
     const StageBuf<T, 64, 16> S{tile + (threadIdx.x & 63), tile + SR::NL * 64 + ((threadIdx.x >> 2) & 15), k == 0};
     const QStore<T> V = qcon_split_store<T, Tp>(C.ws, r);
-    quad_lane_run<T, Tp, DppQuad, 64, 16, true, 0, false, PH>(A, r, k, table, S, &C, &V);
+    quad_lane_run<T, Tp, DppQuad, 64, 16, true, 0, false, PH, INIT>(A, r, k, table, S, &C, &V);
 }
 
 template<class T, class Tp, int NJ, int LO, int D>
@@ -2236,7 +2244,7 @@ k_qtip_pgs(const QConArgs<T> C, const T * P, unsigned)
                                                 xs + (threadIdx.x >> 2) * XS, zs + (threadIdx.x >> 2) * ZS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
 }
 
-template<class T, class Tp>
+template<class T, class Tp, int INIT>
 __global__ void __launch_bounds__((64 * qcon_block_waves<T, Tp>())) __attribute__((amdgpu_waves_per_eu(1)))
 k_quad_con_gen(const BatchArgs<T> A, const QConArgs<T> C)
 {
@@ -2255,7 +2263,7 @@ k_quad_con_gen(const BatchArgs<T> A, const QConArgs<T> C)
     if (r >= A.B) return;
     const StageBuf<T, NTH, NTH / 4> S{stage_l + threadIdx.x, stage_b + (threadIdx.x >> 2), k == 0};
     const QStore<T> V = qcon_store<T, Tp>(con + (threadIdx.x >> 2) * RSTRIDE, C.ws, r, (unsigned)A.B);
-    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP, true>(A, r, k, table, S, &C, &V);
+    quad_lane_run<T, Tp, DppQuad, NTH, NTH / 4, true, CAP, true, 0, INIT>(A, r, k, table, S, &C, &V);
 }
 #endif
 }  // namespace jm

@@ -1739,7 +1739,7 @@ template<class Tp> constexpr int qcon_first_lambda_row() { return qcon_first_con
 template<class T> struct QConArgs;
 template<class T> struct QStore;
 template<class Tp> struct QSplitRegion;   // (jm_qcon.h)
-template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH = 0>
+template<class T, class Tp, class X, class SB, int CAPC, bool GEN, int PH = 0, int INIT = -1>
 JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T> & A, const QConArgs<T> & C, const QStore<T> & V,
                           unsigned r, int k, const QIdx<Tp> & ix, const SB & S_, const T * qb, const T * vb, const T * ql,
                           const T * vl, const T * cmdb, const T * cmdl, bool emit, bool sensors, T * ddqb, T * ddq, int & status,
@@ -1749,7 +1749,10 @@ JM_DEV void quad_eval_con(CPtr<T> P, const LimbTable<T> & LT, const BatchArgs<T>
 // constrained one (`C` / `V`: constraint state and the robot's solver region).
 // PH (QCON only): 0 = every evaluation of the launch in this kernel; 1 / 2 = split stepping, the part of evaluation
 // `C->split_e` before / after the multipliers are solved (k_quad_con_pre / k_quad_con_post, jm_qcon.h).
-template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0, bool GEN = false, int PH = 0>
+// INIT (constraint kernels): -1 = `start` / `reset` and the other modes in one kernel, decided at run time (the split kernels);
+// 1 = a kernel that only serves MODE_START / MODE_RESET, 0 = one that never does -- the four-pass initialisation with its exact
+// solve is a large piece of code whose register pressure otherwise leaks into the step path (round 6)
+template<class T, class Tp, class X, int SL, int SB, bool QCON = false, int CAPC = 0, bool GEN = false, int PH = 0, int INIT = -1>
 JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * limb_table, const StageBuf<T, SL, SB> & S,
                           const QConArgs<T> * C = nullptr, const QStore<T> * V = nullptr)
 {
@@ -1780,7 +1783,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     // every mode runs through the same evaluation loop (two inlined copies of the dynamics: with
     // and without the output code): `start`, `reset` and `dynamics` are one evaluation at a given
     // state, `step` is the RK4 / Euler state machine. The step state lives in the stage buffer.
-    const bool stepping = A.mode == MODE_STEP;
+    const bool stepping = INIT == 1 ? false : (A.mode == MODE_STEP);
     const T * qsrc = A.q;
     const T * vsrc = A.v;
     if (A.mode == MODE_DYNAMICS) { qsrc = A.q_in; vsrc = A.v_in; }
@@ -1969,7 +1972,8 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
     if constexpr (QCON)
     {
         // constraint contact model: ONE call site of the (large) constrained evaluation, emitting or not at run time
-        const int start_passes = (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0);
+        const int start_passes = INIT == 1 ? 4 : (INIT == 0 ? (A.mode == MODE_REFRESH ? -1 : 0) :
+                                 ((A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : (A.mode == MODE_REFRESH ? -1 : 0)));
         if constexpr (PH != 0)
         {
             // one part of one evaluation of a step launch (MODE_STEP only)
@@ -1987,9 +1991,9 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
                 });
             }
             // (start / reset in the split form: the four passes of Engine::start are launches of their own, C->split_pass)
-            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN, PH>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last,
+            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN, PH, INIT>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last,
                                     !stepping || A.update_sensors != 0, ddqb, ddq, status,
-                                    (A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : 0);
+                                    INIT == 1 ? 4 : (INIT == 0 ? 0 : ((A.mode == MODE_START || A.mode == MODE_RESET) ? 4 : 0)));
             if (PH == 1 || !last)
             {
                 S.putl(SR::STATUSL, (T)status);
@@ -2012,7 +2016,7 @@ JM_DEV void quad_lane_run(const BatchArgs<T> & A, long long r, int k, const T * 
             rr = r32;
             JM_OPAQUE(rr);
             advance(st, last, rr);
-            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
+            quad_eval_con<T, Tp, X, StageBuf<T, SL, SB>, CAPC, GEN, 0, INIT>(P, LT, A, *C, *V, rr, k, ix, S, qb, vb, ql, vl, cmdb, cmdl, last && A.mode != MODE_DYNAMICS,
                                     (!stepping && A.mode != MODE_REFRESH) || A.update_sensors != 0, ddqb, ddq, status,
                                     start_passes);
         }

@@ -79,7 +79,7 @@ def main():
         loops = loop_blocks(body)
         tot = stats(body.splitlines())
         print("  whole kernel:", sum(tot.values()), dict(tot))
-        for h, lines in sorted(loops.items(), key=lambda kv: -len(kv[1]))[:3]:
+        for h, lines in sorted(loops.items(), key=lambda kv: -len(kv[1]))[:int(__import__("os").environ.get("LOOPS", "3"))]:
             c = stats(lines)
             valu = sum(v for k, v in c.items() if k in ("fma64", "mul64", "add64", "valu_other", "dpp", "accvgpr"))
             print(f"  loop {h}: {sum(c.values())} instr, VALU {valu}: {dict(c)}")
