@@ -175,7 +175,7 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
         # attitude noise), 5 % of the lanes with joints beyond a position limit
         states = sample_standing_states(model, B, seed=rank, joint_noise=0.01, base_angle_max=0.004,
                                         depth_range=(-6e-3, -5e-3), twist_std=0.02, joint_vel_std=0.05,
-                                        command_fraction=0.1, out_of_bounds_fraction=0.05)
+                                        command_fraction=0.1, out_of_bounds_fraction=float(os.environ.get("JM_BENCH_OOB_FRACTION", "0.05")))
     else:
         states = sample_states(model, B, seed=rank)
     # extra_terms = "full": every optional output of the step is bound, so that the launch runs the whole of

@@ -295,7 +295,9 @@ def qcon_split(model: CompiledModel) -> bool:
     if quad_structure(model) is None:
         return False
     nb = sum(1 for t in model.jtypes[1:] if 1 <= int(t) <= 8)
-    return min(nb + 4 * model.ncontacts, 96) > qcon_split_min()
+    # ... or whose whole solve fits the fixed 16-row layout of the one-lane-per-robot solve (`jm::qcon_split_lane`, round 6)
+    lane = 1 <= model.ncontacts and 3 * model.ncontacts <= 16
+    return min(nb + 4 * model.ncontacts, 96) > qcon_split_min() or lane
 
 
 def qcon_split_min() -> int:

@@ -55,6 +55,7 @@ extern template __global__ void k_quad_con_split<double, Topo, 2, 1>(const Batch
 extern template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
 extern template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
+extern template __global__ void k_qcon_pgs_lane<double, Topo>(const QConArgs<double>, const double *, int32_t *);
 extern template __global__ void k_qcon_exact<double, Topo>(const QConArgs<double>);
 extern template __global__ void k_qtip_exact<double, Topo>(const QConArgs<double>);
 #endif
@@ -101,6 +102,14 @@ struct jm_batch
     bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
     bool qcon_split_start = true;   // ... and split start / reset launches (JIMINY_AMD_QCON_SPLIT_START=0: single kernel)
     bool joint_locks = false; // the batch carries user-registered JointConstraints (jm_batch_set_joint_locks)
+    // split stepping of robots whose solve runs one lane per robot (jm_qcon.h, qcon_pgs_lane): robots that do not fit that
+    // form are counted on the device (`lane_miss`), the count of the last finished step is read without waiting
+    // (`lane_miss_host`, pinned; `lane_miss_ev`), and while it is non-zero the batch steps with the single kernel
+    int32_t * lane_miss = nullptr;
+    int32_t * lane_miss_host = nullptr;
+    hipEvent_t lane_miss_ev = nullptr;
+    bool lane_miss_pending = false;
+    int split_cooldown = 0;
     int split_chunks = 1;     // ... as this many independent chunks on streams of their own (JIMINY_AMD_QCON_SPLIT_CHUNKS; measured: no gain)
     hipStream_t split_stream[8] = {};
     hipEvent_t split_fork = nullptr, split_join[8] = {};
@@ -299,8 +308,46 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                 return;
             }
             // robots whose solves live in the workspace: step launches go through pre | solve | post per evaluation (jm_qcon.h)
-            if (b->qcon_split && A.mode == jm::MODE_STEP && !(A.model_lane || A.applied || A.ground_h) && (A.B & 15) == 0 && !b->ov_flags)
+            // robots with small solves (one lane per robot): only while every solve of the batch fits that form -- a robot
+            // that does not (more active bounds than the layout holds, torsion rows, a joint lock) falls to the streamed form,
+            // an order of magnitude slower per robot.  The miss count of the last finished step decides, without a wait;
+            // a batch that had misses steps with the single kernel for the next 64 steps, then tries again.
+            bool lane_ok = true;
+            hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
+            if constexpr (!jm::qcon_split_large<Tp>())
             {
+                if (A.mode == jm::MODE_STEP && !capturing)
+                {
+                    if (b->lane_miss_pending && hipEventQuery(b->lane_miss_ev) == hipSuccess)
+                    {
+                        b->lane_miss_pending = false;
+                        if (*b->lane_miss_host > 0) b->split_cooldown = 64;
+                    }
+                    if (b->split_cooldown > 0) { --b->split_cooldown; lane_ok = false; }
+                }
+                if (C0.torsion >= 2.220446049250313e-16) lane_ok = false;   // (four-row contact blocks: never the fixed layout)
+            }
+            if (lane_ok && b->qcon_split && A.mode == jm::MODE_STEP && !(A.model_lane || A.applied || A.ground_h) && (A.B & 15) == 0 && !b->ov_flags)
+            {
+                int32_t * miss = nullptr;
+                if constexpr (!jm::qcon_split_large<Tp>())
+                    if (!capturing)
+                    {
+                        if (!b->lane_miss)
+                        {
+                            if (hipMalloc((void **)&b->lane_miss, sizeof(int32_t)) != hipSuccess ||
+                                hipHostMalloc((void **)&b->lane_miss_host, sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+                                hipEventCreateWithFlags(&b->lane_miss_ev, hipEventDisableTiming) != hipSuccess)
+                            { b->lane_miss = nullptr; }
+                            else *b->lane_miss_host = 0;
+                        }
+                        if (b->lane_miss && !b->lane_miss_pending)
+                        {
+                            miss = b->lane_miss;
+                            (void)hipMemsetAsync(miss, 0, sizeof(int32_t), s);
+                        }
+                    }
                 C.stage = C.ws + (size_t)jm::qcon_split_region_rows<double, Tp>() * (size_t)A.B;
                 const int pre = A.command_changed ? 1 : 0;
                 const int n_evals = pre + A.n_sub * (A.solver == JM_SOLVER_RUNGE_KUTTA_4 ? 4 : 1);
@@ -332,6 +379,10 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                     {
                         C.split_e = e;
                         hipLaunchKernelGGL((jm::k_quad_con_split<double, Tp, 1, 0>), dim3(g64), dim3(256), 0, sc, A, C);
+                        // (robots whose system fits the fixed 16-row layout: one lane per robot, out of registers -- jm_qcon.h,
+                        // qcon_pgs_lane; they are marked done for the streamed form that follows)
+                        if constexpr (jm::QLanePgs<Tp>::FITS && JM_QCON_PGS_LANE)
+                            hipLaunchKernelGGL((jm::k_qcon_pgs_lane<double, Tp>), dim3((unsigned)((C.split_r1 - C.split_r0 + 63) / 64)), dim3(64), 0, sc, C, A.P, miss);
                         // (solves of up to 64 rows, then the waves that hold a larger one)
                         hipLaunchKernelGGL((jm::k_qcon_pgs<double, Tp, 8, 0, JM_QCON_PGS_DEPTH>), dim3(g64), dim3(256), 0, sc, C, A.P, (unsigned)A.B);
                         if constexpr (jm::QConRows<Tp>::MAXM > 64)
@@ -348,6 +399,12 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                         hipEventRecord(b->split_join[c], b->split_stream[c]);
                         hipStreamWaitEvent(s, b->split_join[c], 0);
                     }
+                if (miss)
+                {
+                    (void)hipMemcpyAsync(b->lane_miss_host, miss, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                    (void)hipEventRecord(b->lane_miss_ev, s);
+                    b->lane_miss_pending = true;
+                }
                 return;
             }
         }
@@ -620,6 +677,8 @@ int32_t jm_batch_create(const jm_model * model, int64_t batch_size, int32_t dtyp
     // kernel variant: limb-parallel when the topology allows it; JM_KERNEL_VARIANT=lane forces the
     // generic one-robot-per-lane kernel (A/B measurements)
     b->variant = (Topo::QUAD && model->root_at_origin) ? VARIANT_QUAD : VARIANT_LANE;
+    // (`start` / `reset` of robots with small solves: the single kernel -- its passes run on chip; jm_qcon.h, k_quad_con<1>)
+    if constexpr (Topo::QUAD) b->qcon_split_start = jm::qcon_split_large<Topo>();
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT")) b->qcon_split = e[0] != '0';
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT_START")) b->qcon_split_start = e[0] != '0';
     if (const char * e = std::getenv("JIMINY_AMD_QCON_SPLIT_CHUNKS"))
@@ -655,6 +714,9 @@ int32_t jm_batch_destroy(jm_batch * b)
     (void)hipSetDevice(b->device);
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->ad_count) (void)hipFree(b->ad_count);
+    if (b->lane_miss) (void)hipFree(b->lane_miss);
+    if (b->lane_miss_host) (void)hipHostFree(b->lane_miss_host);
+    if (b->lane_miss_ev) (void)hipEventDestroy(b->lane_miss_ev);
     if (b->ad_flags) (void)hipFree(b->ad_flags);
     if (b->ad_count_host) (void)hipHostFree(b->ad_count_host);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);

@@ -48,6 +48,7 @@ template __global__ void k_quad_con_split<double, Topo, 2, 0>(const BatchArgs<do
 #elif JM_CON_PART == 9 && JM_TOPO_QCON_SPLIT
 template __global__ void k_qcon_pgs<double, Topo, 8, 0, JM_QCON_PGS_DEPTH>(const QConArgs<double>, const double *, unsigned);
 template __global__ void k_qcon_pgs<double, Topo, 12, 64, JM_QCON_PGS_DEPTH - 1>(const QConArgs<double>, const double *, unsigned);
+template __global__ void k_qcon_pgs_lane<double, Topo>(const QConArgs<double>, const double *, int32_t *);
 #elif JM_CON_PART == 11 && JM_TOPO_QUAD
 template __global__ void k_quad_con<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
 #elif JM_CON_PART == 12 && JM_TOPO_QUAD

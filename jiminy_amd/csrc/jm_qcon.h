@@ -222,7 +222,15 @@ template<class Tp> struct QSplitRegion
 #ifndef JM_QCON_SPLIT_MIN
 #define JM_QCON_SPLIT_MIN 32
 #endif
-template<class Tp> constexpr bool qcon_split() { return Tp::QUAD && QConRows<Tp>::MAXM > JM_QCON_SPLIT_MIN; }
+#ifndef JM_QCON_PGS_LANE
+#define JM_QCON_PGS_LANE 1   // round 6: robots with few contact points step in the split form too, their solve one lane per robot (qcon_pgs_lane)
+#endif
+// robots whose solves are LARGE (the streamed / operational-space forms; `start` / `reset` through the split kernels as well)
+template<class Tp> constexpr bool qcon_split_large() { return Tp::QUAD && QConRows<Tp>::MAXM > JM_QCON_SPLIT_MIN; }
+// robots whose whole solve fits the fixed 16-row layout of qcon_pgs_lane (up to five contact points): pre | solve | post as
+// well -- the solve kernel holds a robot per lane, which the single kernel cannot (ANYmal: 0.87 -> 0.72-0.84 ms per launch)
+template<class Tp> constexpr bool qcon_split_lane() { return JM_QCON_PGS_LANE != 0 && Tp::QUAD && ConRows<Tp>::NC >= 1 && 3 * ConRows<Tp>::NC <= 16; }
+template<class Tp> constexpr bool qcon_split() { return qcon_split_large<Tp>() || qcon_split_lane<Tp>(); }
 // which kernels know user-registered JointConstraints (bit 2 of a joint row's flag): the variation kernels, and every
 // constraint kernel of the topologies that step in the split form (their solves run out of the workspace anyway); the plain
 // kernels of robots with register-resident solves (ANYmal) stay free of it -- the host launches the variation kernel for a
@@ -1898,7 +1906,8 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
     auto G = [&](int e) -> T & { return *(T *)(ws + (g0 + (unsigned)e * (unsigned)sizeof(T))); };
     const int hdr = (int)G(RG::HDR);
     if (X::wave_any(((hdr >> 24) & 1) != 0)) return false;   // (the wave solves in the operational-space form, jm_qtip.h)
-    const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff, A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
+    // (bit 25: solved by the one-lane-per-robot form, qcon_pgs_lane -- nothing left to do for this robot)
+    const int m = ((hdr >> 25) & 1) ? 0 : (hdr & 0xff), nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff, A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
     {
         const bool big = X::wave_any(m > 8 * NJ), mine = X::wave_any(m > LO);
         if (big || !mine) return false;   // (uniform over the wave)
@@ -2048,6 +2057,248 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
     return true;
 }
 
+// ---------------------------------------------------------------- the solve of small systems, ONE LANE per robot (round 6)
+// The register-resident Gauss-Seidel of the single kernel (qcon_pgs_fixed) spreads a 16-row solve over the four lanes of the
+// robot's quad: the projection logic of a row runs replicated in the four lanes, only the four multiply-adds of the residual
+// update are shared -- ~26 wave instructions per robot and sweep, issue-bound at one wave per SIMD (the sweeps were 0.31 of
+// the 0.44 ms of an ANYmal evaluation).  In the split form (pre | solve | post) the solve is a kernel of its own, and a
+// kernel of its own can choose its own layout: here a lane owns a whole robot -- the packed lower triangle of the matrix
+// (136 scalars), x, 1 / diag, the maintained residuals and the residuals of the previous sweep in its registers, a
+// residual update of 16 independent multiply-adds -- ~7 wave instructions per robot and sweep, 64 robots per wave, no
+// cross-lane traffic at all.  Same fixed row layout as qcon_pgs_fixed (contact block c at positions 3 c .. 3 c + 2, the
+// active joint bounds behind), same sweep order, relaxation schedule, projections and stopping rule
+// (PGSSolver::ProjectedGaussSeidelSolver, constraint_solvers.cc:107-326).  Taken by the robots whose solve fits the layout
+// (<= 16 rows, 3-row contact blocks i.e. contacts.torsion = 0, at most 16 - 3 NC active bounds, positive friction, no
+// user-registered joint lock); it marks the region header (bit 25) so that the streamed form leaves the robot alone.
+#ifndef JM_QCON_LANE_SIDE
+#define JM_QCON_LANE_SIDE 0
+#endif
+template<class Tp> struct QLanePgs
+{
+    static constexpr int MR = 16, NC = ConRows<Tp>::NC, NBF = MR - 3 * NC;
+    static constexpr bool FITS = qcon_split_lane<Tp>();
+    static constexpr int DONE_BIT = 25;
+    static constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+};
+// `reg`: the robot's region of the workspace (QSplitRegion / QStoreSq layout, written by k_quad_con_split<1>).  WANY(pred):
+// true when any robot of the wave satisfies pred (uniform skips; the identity on the host).
+// NBS = joint-bound positions of this instantiation (0 .. 16 - 3 NC).  A lane holds the whole triangle of a 3 NC + NBS row
+// system; the VALU addresses 256 registers per lane, which hold the 3 NC x 3 NC contact block (78 scalars for four feet) next
+// to the vectors of the solve; what does not fit sits in accumulation registers behind a v_accvgpr_read per operand half
+// (843 VALU instructions per sweep at NBS = 4 against 405 at NBS = 0).  The kernel picks the smallest instantiation that
+// serves every robot of the wave (most waves of standing robots have no active bound).
+// JM_QCON_LANE_SIDE = 1 (measured, off): the entries of the bound rows and the residuals of the previous sweep in LDS
+// instead, entry-major over the lanes (`side`, stride SS) -- 843 -> 562 VALU instructions per sweep, but a wave that is alone
+// on its SIMD waits out every one of those reads: 187 -> 278 us per solve of 65 536 ANYmal systems.
+template<class Tp, int NBS> struct QLaneSide
+{
+    static constexpr bool SIDE_ON = JM_QCON_LANE_SIDE != 0 && NBS > 0;
+    static constexpr int NC = ConRows<Tp>::NC, MR = 3 * NC + NBS;
+    // entries (r, c), r >= c, with r >= 3 NC, in row order; then MR residuals of the previous sweep
+    static constexpr int NA = MR * (MR + 1) / 2 - (3 * NC) * (3 * NC + 1) / 2;
+    static constexpr int YT = NA, TOTAL = SIDE_ON ? NA + MR : 0;
+    static constexpr bool in_side(int r, int c) { return SIDE_ON && (r >= 3 * NC || c >= 3 * NC); }
+    static constexpr int slot(int r, int c)   // (r >= c)
+    {
+        return r * (r + 1) / 2 + c - (3 * NC) * (3 * NC + 1) / 2;
+    }
+};
+// `side`: this lane's column of the wave's side store (entry e at side[e * SS]); SS = 64 on the device, 1 on the host.
+template<class T, class Tp, int NBS, int SS, class WANY>
+JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, WANY && wany)
+{
+    using RG = QSplitRegion<Tp>;
+    using LP = QLanePgs<Tp>;
+    using SD = QLaneSide<Tp, NBS>;
+    constexpr bool SIDE_ON = SD::SIDE_ON;
+    constexpr int NC = LP::NC, NBF = NBS, MR = 3 * NC + NBS, NCORE = (3 * NC) * (3 * NC + 1) / 2;
+    static_assert(MR <= LP::MR, "fixed layout of at most 16 rows");
+    const T eps = Eps<T>::eps;
+    const int hdr = (int)reg[RG::HDR];
+    const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff;
+    const int nca = cb == 3 ? (m - nb) / 3 : 0;
+    const bool mine = m > 0 && m <= MR && ((hdr >> 24) & 1) == 0 && cb == 3 && nb <= NBF && nca <= NC && nb + 3 * nca == m &&
+                      reg[RG::LOCK] == T(0) && !(friction < eps);
+    if (!wany(mine)) return;
+    const int A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
+    const unsigned iter_max = (unsigned)C.iter_max;
+    // position -> packed row of this robot (-1: unused)
+    int pk[MR];
+    unsigned used = 0u;
+    static_for<0, NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const bool on = mine && c < nca;
+        const int base = nb + 3 * c;
+        pk[3 * c] = on ? base : -1; pk[3 * c + 1] = on ? base + 1 : -1; pk[3 * c + 2] = on ? base + 2 : -1;
+        used |= on ? (7u << (3 * c)) : 0u;
+    });
+    static_for<0, NBF>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const bool on = mine && q < nb;
+        pk[3 * NC + q] = on ? q : -1;
+        used |= on ? (1u << (3 * NC + q)) : 0u;
+    });
+    unsigned used_any = 0u;
+    static_for<0, MR>([&](auto ic) { used_any |= wany(((used >> decltype(ic)::value) & 1u) != 0u) ? (1u << decltype(ic)::value) : 0u; });
+    T At[SIDE_ON ? NCORE : MR * (MR + 1) / 2], x[MR], invd[MR], y[MR], yt0[SIDE_ON ? 1 : MR];
+    // matrix entry (r, c) / residual of the previous sweep: register or side store, decided at compile time
+    auto A_ = [&](auto rc, auto cc) __attribute__((always_inline)) -> T {
+        constexpr int r = decltype(rc)::value >= decltype(cc)::value ? decltype(rc)::value : decltype(cc)::value;
+        constexpr int c = decltype(rc)::value >= decltype(cc)::value ? decltype(cc)::value : decltype(rc)::value;
+        if constexpr (SD::in_side(r, c)) return side[SD::slot(r, c) * SS];
+        else return At[LP::tri(r, c)];
+    };
+    auto yturn_get = [&](auto ic) __attribute__((always_inline)) -> T {
+        if constexpr (SIDE_ON) return side[(SD::YT + decltype(ic)::value) * SS];
+        else return yt0[decltype(ic)::value];
+    };
+    auto yturn_put = [&](auto ic, T v) __attribute__((always_inline)) {
+        if constexpr (SIDE_ON) side[(SD::YT + decltype(ic)::value) * SS] = v;
+        else yt0[decltype(ic)::value] = v;
+    };
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int pi = pk[i];
+        const bool vi = pi >= 0;
+        const T xi = reg[vi ? pi : 0], bi = reg[vi ? m + pi : 0], aii = reg[vi ? A0 + pi * ms + pi : 0];
+        x[i] = vi ? xi : T(0);
+        y[i] = vi ? bi : T(0);
+        invd[i] = vi ? rcp_(vi ? aii : T(1)) : T(0);
+        yturn_put(ic, T(0));
+        static_for<0, i + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const int pc = pk[c];
+            const bool v = vi && pc >= 0;
+            const T a = reg[v ? A0 + pi * ms + pc : 0];
+            if constexpr (SD::in_side(i, c)) side[SD::slot(i, c) * SS] = v ? a : T(0);
+            else At[LP::tri(i, c)] = v ? a : T(0);
+        });
+    });
+    // y = b - A x
+    static_for<0, MR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if ((used_any >> i) & 1u)
+        {
+            T s0 = T(0), s1 = T(0);
+            static_for<0, MR>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c & 1) s1 += A_(ic, cc) * x[c];
+                else s0 += A_(ic, cc) * x[c];
+            });
+            y[i] -= s0 + s1;
+        }
+    });
+    bool converged = !mine;
+    const T ratio_den = T(1) / T(iter_max - 20u - 30u);
+#pragma nounroll
+    for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
+    {
+        T dmax = T(0), ymax = T(0);
+        const T ratio = (T(iter_max - 20u) - T(iter)) * ratio_den;
+        T w = T(1);
+        if (ratio < T(1))
+        {
+            w = T(0.01);
+            if (ratio > T(0)) w += (T(1) - T(0.01)) * (ratio * ratio);
+        }
+        auto residual = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T yy = y[i];
+            dmax = fmax_(dmax, cabs_(yy - yturn_get(ic)));
+            ymax = fmax_(ymax, cabs_(yy));
+            yturn_put(ic, yy);
+            return yy;
+        };
+        auto set_x = [&](auto ic, T val) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const T dx = val - x[i];
+            x[i] = val;
+            static_for<0, MR>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                // (a bound position no robot of the wave uses: its residual is never read)
+                if (r < 3 * NC || ((used_any >> r) & 1u)) y[r] -= A_(rc, ic) * dx;
+            });
+        };
+        // (the side-store entries are loop invariants: without a fence per row the compiler reads all of them once, ahead of
+        // the sweeps, into registers it does not have; with it the reads of a row's column are issued at the head of the
+        // row, under its projection chain)
+        // block 0: joint bounds, then the normal forces (unilateral)
+        static_for<0, NBF>([&](auto qc) {
+            constexpr int i = 3 * NC + decltype(qc)::value;
+            if ((used_any >> i) & 1u)
+            {
+                if constexpr (SIDE_ON) JM_REFRESH();
+                const T yy = residual(std::integral_constant<int, i>{});
+                set_x(std::integral_constant<int, i>{}, fmax_(x[i] + (w * yy) * invd[i], T(0)));
+            }
+        });
+        static_for<0, NC>([&](auto cc) {
+            constexpr int i = 3 * decltype(cc)::value + 2;
+            if ((used_any >> i) & 1u)
+            {
+                if constexpr (SIDE_ON) JM_REFRESH();
+                const T yy = residual(std::integral_constant<int, i>{});
+                set_x(std::integral_constant<int, i>{}, fmax_(x[i] + (w * yy) * invd[i], T(0)));
+            }
+        });
+        // block 2: friction cones (rows i, i + 1; normal force = row i + 2)
+        static_for<0, NC>([&](auto cc) {
+            constexpr int i = 3 * decltype(cc)::value;
+            if ((used_any >> i) & 1u)
+            {
+                if constexpr (SIDE_ON) JM_REFRESH();
+                const T y0 = residual(std::integral_constant<int, i>{});
+                const T y1 = residual(std::integral_constant<int, i + 1>{});
+                const T ia = fmin_(invd[i], invd[i + 1]);   // 1 / max(a00, a11)
+                const T e0 = x[i] + (w * y0) * ia;
+                const T e1 = x[i + 1] + (w * y1) * ia;
+                const T thr = friction * x[i + 2];
+                const T n2 = e0 * e0 + e1 * e1;
+                const bool out = n2 > thr * thr;
+                const T scale = out ? thr * rsqrt_(out ? n2 : T(1)) : T(1);
+                set_x(std::integral_constant<int, i>{}, e0 * scale);
+                set_x(std::integral_constant<int, i + 1>{}, e1 * scale);
+            }
+        });
+        const T tol = C.tol_abs + C.tol_rel * ymax + eps;
+        converged = dmax < tol;
+    }
+    if (mine)
+    {
+        static_for<0, MR>([&](auto ic) { if (pk[decltype(ic)::value] >= 0) reg[pk[decltype(ic)::value]] = x[decltype(ic)::value]; });
+        reg[RG::OK] = converged ? T(1) : T(0);
+        reg[RG::HDR] = (T)(hdr | (1 << LP::DONE_BIT));
+    }
+}
+
+// the smallest instantiation that serves every robot of the wave; `miss` (device counter or null): robots with a solve that
+// this form cannot take -- they fall to the streamed form, which is an order of magnitude slower per robot: the host
+// watches the counter and steps such batches with the single kernel instead (jm_lib.cpp)
+template<class T, class Tp, int SS, class WANY>
+JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * miss, WANY && wany)
+{
+    using RG = QSplitRegion<Tp>;
+    constexpr int NBF = QLanePgs<Tp>::NBF;
+    const int hdr = (int)reg[RG::HDR];
+    const int m = hdr & 0xff, nb = (hdr >> 8) & 0xff, cb = (hdr >> 16) & 0xff;
+    const bool tip = ((hdr >> 24) & 1) != 0;
+    const bool fits = m > 0 && m <= 16 && cb == 3 && nb <= NBF && !tip && nb + 3 * ((m - nb) / 3) == m && (m - nb) / 3 <= QLanePgs<Tp>::NC &&
+                      reg[RG::LOCK] == T(0) && !(friction < Eps<T>::eps);
+    if (miss && m > 0 && !tip && !fits)
+    {
+#ifndef JM_HOST_EMU
+        atomicAdd(miss, 1);
+#else
+        *miss += 1;
+#endif
+    }
+    const int nbq = fits ? nb : 0;
+    if (!wany(nbq > 0)) qcon_pgs_lane<T, Tp, 0, SS>(C, friction, reg, side, wany);
+    else if (NBF >= 1 && !wany(nbq > 1)) qcon_pgs_lane<T, Tp, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side, wany);
+    else if (NBF >= 2 && !wany(nbq > 2)) qcon_pgs_lane<T, Tp, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side, wany);
+    else qcon_pgs_lane<T, Tp, NBF, SS>(C, friction, reg, side, wany);
+}
+
 #ifndef JM_HOST_EMU
 // ---------------------------------------------------------------- kernel configuration (host-visible)
 // waves per block and on-chip scalars per LANE of the per-robot solver region (a robot owns 4 lanes' worth):
@@ -2186,6 +2437,24 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
     const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
     qcon_pgs_lean<T, Tp, DppQuad, NJ, LO, D>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
                                              (T *)xs2 + (threadIdx.x >> 2) * XS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
+}
+
+// the solve of the robots whose system fits the fixed 16-row layout, one lane per robot (qcon_pgs_lane): launched BEFORE
+// k_qcon_pgs, which then finds those robots marked done.  One wave per block: 64 robots, the whole register file.
+template<class T, class Tp>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
+k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * miss)
+{
+    using L = Layout<Tp>;
+    using RG = QSplitRegion<Tp>;
+    constexpr int NBF = QLanePgs<Tp>::FITS ? QLanePgs<Tp>::NBF : 0;
+    constexpr int SIDE = QLanePgs<Tp>::FITS ? QLaneSide<Tp, NBF>::TOTAL : 0;
+    __shared__ T side_[(SIDE > 0 ? SIDE : 1) * 64];
+    const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + threadIdx.x;
+    if (r >= (unsigned)C.split_r1) return;
+    if constexpr (QLanePgs<Tp>::FITS)
+        qcon_pgs_lane_any<T, Tp, 64>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
+                                     side_ + threadIdx.x, miss, [](bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; });
 }
 
 // Engine::start / reset in the split form: the exact solve of the first pass (`ignoreBounds`), one quad per robot --

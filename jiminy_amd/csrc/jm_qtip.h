@@ -58,7 +58,7 @@ template<class Tp> struct QTip
                                                   // (Atlas standing in its neutral pose already has five joints at a limit)
     static constexpr int NE = 6 * NCT + NBX;      // extended operational space
     static constexpr int ZL = (NE + 3) / 4;       // entries of z / rows of E per lane (entry e: lane e & 3, slot e >> 2)
-    static constexpr bool ON = JM_QTIP != 0 && qcon_split<Tp>() && NCT >= 1 && NCT <= 2;
+    static constexpr bool ON = JM_QTIP != 0 && qcon_split_large<Tp>() && NCT >= 1 && NCT <= 2;
     // the robot's region of the workspace in this form: x | b | y | 1 / diag (4 m, as in every form: what qcon_rhs / qcon_scatter
     // read and write) | E (NE x NE, row-major) | one record of REC scalars per row, everything a row visit reads in one
     // 96-byte block: X[6] | b | 1 / diag | R | y of the previous sweep | z offset (as an integer in the scalar's low word) | -

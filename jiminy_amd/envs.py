@@ -383,7 +383,9 @@ class VecJiminyEnv:
 
 class WalkerVecEnv(VecJiminyEnv):
     """≙ `WalkerJiminyEnv` (envs/locomotion.py): legged robot with a free-flyer, fall detection
-    at half the neutral height and the 'survival' / 'energy' reward mixture."""
+    at half the neutral height and the 'survival' / 'energy' / 'failure' / 'direction' reward mixture.
+    Not built: the flexibility randomisation of `std_ratio['model']` (locomotion.py:288-296) -- flexibility stiffness /
+    damping are constants of the batch here (the lane-family kernels have no per-lane model rows)."""
 
     def __init__(self, *args: Any, reward_mixture: Optional[Dict[str, float]] = None, **kw: Any) -> None:
         super().__init__(*args, **kw)
@@ -395,6 +397,35 @@ class WalkerVecEnv(VecJiminyEnv):
         enc_of = {e.get("motor_index", -1): i for i, e in enumerate(m.sensors.get("EncoderSensor", []))}
         self._motor_enc_idx = (torch.tensor([enc_of[i] for i in range(m.nmotors)], device=self.device)
                                if all(i in enc_of for i in range(m.nmotors)) and m.nmotors else None)
+
+        # 'direction' (locomotion.py:419-424): mean of the logged free-flyer Y position over the episode, per environment.
+        # The reference's log holds one row per integrator step; here the position is sampled once per environment step
+        # (what a launch makes visible) plus the initial state, accumulated on the device.
+        self._dir_sum = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+        self._dir_n = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+
+    def _direction_restart(self, lane_mask: Optional[torch.Tensor]) -> None:
+        y0 = self.engine.robot_state.q[1].to(torch.float64)
+        if lane_mask is None:
+            self._dir_sum.copy_(y0)
+            self._dir_n.fill_(1.0)
+        else:
+            self._dir_sum.copy_(torch.where(lane_mask, y0, self._dir_sum))
+            self._dir_n.copy_(torch.where(lane_mask, torch.ones_like(self._dir_n), self._dir_n))
+
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        out = super().reset(seed, options)
+        self._direction_restart(None)
+        return out
+
+    def reset_lanes(self, lane_mask: torch.Tensor) -> None:
+        super().reset_lanes(lane_mask)
+        self._direction_restart(lane_mask)
+
+    def _after_step(self):
+        self._dir_sum += self.engine.robot_state.q[1].to(torch.float64)
+        self._dir_n += 1.0
+        return super()._after_step()
 
     def has_terminated(self) -> Tuple[torch.Tensor, torch.Tensor]:
         terminated, truncated = super().has_terminated()
@@ -413,6 +444,10 @@ class WalkerVecEnv(VecJiminyEnv):
             total -= self.reward_mixture["energy"] * power / self._power_consumption_max
         if "failure" in self.reward_mixture:
             total -= self.reward_mixture["failure"] * terminated.to(self.dtype)
+        if "direction" in self.reward_mixture:
+            # at termination only: minus the absolute mean lateral position of the episode (locomotion.py:419-424)
+            drift = (self._dir_sum / torch.clamp_min(self._dir_n, 1.0)).abs().to(self.dtype)
+            total -= self.reward_mixture["direction"] * drift * terminated.to(self.dtype)
         return total
 
 

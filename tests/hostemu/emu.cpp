@@ -187,6 +187,8 @@ template<class T, class Tp, bool GEN = false> static void run_quad_con(const jm:
 // the same launch in the split form of robots with large solves (jm_qcon.h: k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>
 // per evaluation, stage buffer and solver region persistent between the parts): one robot at a time, its four lanes as threads
 static int g_split = 0;
+static long long g_lane_solves = 0;
+extern "C" long long emu_lane_solves() { return g_lane_solves; }
 static long long g_tip_solves = 0;   // solves that took the operational-space form (jm_qtip.h)
 extern "C" long long emu_tip_solves() { return g_tip_solves; }
 extern "C" void emu_set_split(int on) { g_split = on; }
@@ -227,6 +229,19 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                     char * ws = (char *)region.data();
                     const unsigned g0 = (unsigned)((size_t)r * RG::ROWS * sizeof(T));
                     auto solve = [&]() {
+                        // (robots whose solve fits the fixed 16-row layout: one lane per robot, jm_lib.cpp launches k_qcon_pgs_lane
+                        // ahead of the streamed form, which then finds them marked done)
+                        if constexpr (jm::QLanePgs<Tp>::FITS)
+                        {
+                            if (k == 0 && A.mode == jm::MODE_STEP)
+                            {
+                                T side[jm::QLaneSide<Tp, jm::QLanePgs<Tp>::NBF>::TOTAL + 1];
+                                jm::qcon_pgs_lane_any<T, Tp, 1>(C, friction, region.data() + (size_t)r * RG::ROWS, side, (int32_t *)nullptr,
+                                                                [](bool p) { return p; });
+                                ++g_lane_solves;
+                            }
+                            HostQuad::sync();
+                        }
                         bool tip = false;
                         if constexpr (jm::QTip<Tp>::ON)
                             tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), vis.data(), ws, g0);

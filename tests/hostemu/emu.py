@@ -50,6 +50,7 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_split.restype = None
     L.emu_has_split.restype = C.c_int
     L.emu_tip_solves.restype = C.c_longlong
+    L.emu_lane_solves.restype = C.c_longlong
     L.emu_set_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.emu_set_gen.restype = None
@@ -151,6 +152,11 @@ def run_dopri(model: CompiledModel, arrays: Dict[str, np.ndarray], adaptive: Dic
     for i, n in enumerate(_AD_I[:4]):
         adaptive[n][:] = isv[i]
     return int(counters[0]), int(counters[1])
+
+
+def lane_solves(model: CompiledModel) -> int:
+    """Calls of the one-lane-per-robot solve of the split form (jm_qcon.h, qcon_pgs_lane) since the library was loaded."""
+    return int(_lib(model).emu_lane_solves())
 
 
 def tip_solves(model: CompiledModel) -> int:

@@ -570,3 +570,27 @@ def test_env_with_every_randomisation_switched_on(gpu_device, contact_model):
     n1, a = run()
     n2, b = run()
     assert n1 == n2 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_direction_reward_is_the_mean_lateral_position_of_the_episode(gpu_device):
+    """`WalkerJiminyEnv.compute_reward`, 'direction' (envs/locomotion.py:419-424): at termination, minus the absolute mean
+    of the free-flyer Y positions of the episode (initial state included); nothing before."""
+    B = 32
+    env = make_anymal_env(B, pd_pipeline=False, auto_reset=False, reward_mixture={"direction": 2.0})
+    obs, _ = env.reset(seed=1)
+    ys = [obs["states"]["agent"]["q"][:, 1].double().cpu().numpy().copy()]
+    action = torch.zeros((B, 12), dtype=torch.float64, device=gpu_device)
+    action[:, 0::3] = torch.linspace(-30.0, 30.0, B, device=gpu_device, dtype=torch.float64)[:, None]   # hip abduction: tips sideways
+    done_at = np.full(B, -1)
+    for step in range(40):
+        obs, reward, terminated, truncated, _ = env.step(action)
+        ys.append(obs["states"]["agent"]["q"][:, 1].double().cpu().numpy().copy())
+        r, t = reward.cpu().numpy(), terminated.cpu().numpy()
+        live = done_at < 0
+        assert np.all(r[live & ~t] == 0.0)                       # no contribution before the episode ends
+        for lane in np.nonzero(live & t)[0]:
+            want = -2.0 * abs(np.mean([y[lane] for y in ys]))
+            assert abs(r[lane] - want) <= 1e-12 * max(1.0, abs(want)), (lane, r[lane], want)
+            done_at[lane] = step
+    assert (done_at >= 0).sum() >= B // 4                        # the limp robots did fall
