@@ -300,6 +300,10 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
         if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
             # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
             kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
+            nbj = sum(1 for t in model.jtypes[1:] if 1 <= int(t) <= 8)
+            if min(nbj + 4 * model.ncontacts, 96) <= 32:
+                # robots with few contact points (round 6): the solve runs one lane per robot
+                kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs_lane + jm::k_quad_con_split<2>"
         pmc_path = os.path.join(ROOT, "profiles", "pmc_con_latest.json" if model_name == "anymal" else f"pmc_{model_name}_con_latest.json")
     achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
     if os.path.exists(pmc_path):

@@ -2080,8 +2080,6 @@ template<class Tp> struct QLanePgs
     static constexpr int DONE_BIT = 25;
     static constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 };
-// `reg`: the robot's region of the workspace (QSplitRegion / QStoreSq layout, written by k_quad_con_split<1>).  WANY(pred):
-// true when any robot of the wave satisfies pred (uniform skips; the identity on the host).
 // NBS = joint-bound positions of this instantiation (0 .. 16 - 3 NC).  A lane holds the whole triangle of a 3 NC + NBS row
 // system; the VALU addresses 256 registers per lane, which hold the 3 NC x 3 NC contact block (78 scalars for four feet) next
 // to the vectors of the solve; what does not fit sits in accumulation registers behind a v_accvgpr_read per operand half
@@ -2104,8 +2102,8 @@ template<class Tp, int NBS> struct QLaneSide
     }
 };
 // `side`: this lane's column of the wave's side store (entry e at side[e * SS]); SS = 64 on the device, 1 on the host.
-template<class T, class Tp, int NBS, int SS, class WANY>
-JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, WANY && wany)
+template<class T, class Tp, class X, int NBS, int SS>
+JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
 {
     using RG = QSplitRegion<Tp>;
     using LP = QLanePgs<Tp>;
@@ -2119,7 +2117,7 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
     const int nca = cb == 3 ? (m - nb) / 3 : 0;
     const bool mine = m > 0 && m <= MR && ((hdr >> 24) & 1) == 0 && cb == 3 && nb <= NBF && nca <= NC && nb + 3 * nca == m &&
                       reg[RG::LOCK] == T(0) && !(friction < eps);
-    if (!wany(mine)) return;
+    if (!X::wave_any(mine)) return;
     const int A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
     const unsigned iter_max = (unsigned)C.iter_max;
     // position -> packed row of this robot (-1: unused)
@@ -2139,7 +2137,7 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
         used |= on ? (1u << (3 * NC + q)) : 0u;
     });
     unsigned used_any = 0u;
-    static_for<0, MR>([&](auto ic) { used_any |= wany(((used >> decltype(ic)::value) & 1u) != 0u) ? (1u << decltype(ic)::value) : 0u; });
+    static_for<0, MR>([&](auto ic) { used_any |= X::wave_any(((used >> decltype(ic)::value) & 1u) != 0u) ? (1u << decltype(ic)::value) : 0u; });
     T At[SIDE_ON ? NCORE : MR * (MR + 1) / 2], x[MR], invd[MR], y[MR], yt0[SIDE_ON ? 1 : MR];
     // matrix entry (r, c) / residual of the previous sweep: register or side store, decided at compile time
     auto A_ = [&](auto rc, auto cc) __attribute__((always_inline)) -> T {
@@ -2204,8 +2202,8 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
         auto residual = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             const T yy = y[i];
-            dmax = fmax_(dmax, cabs_(yy - yturn_get(ic)));
-            ymax = fmax_(ymax, cabs_(yy));
+            dmax = X::max_abs(dmax, yy - yturn_get(ic));
+            ymax = X::max_abs(ymax, yy);
             yturn_put(ic, yy);
             return yy;
         };
@@ -2229,7 +2227,7 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
             {
                 if constexpr (SIDE_ON) JM_REFRESH();
                 const T yy = residual(std::integral_constant<int, i>{});
-                set_x(std::integral_constant<int, i>{}, fmax_(x[i] + (w * yy) * invd[i], T(0)));
+                set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
             }
         });
         static_for<0, NC>([&](auto cc) {
@@ -2238,7 +2236,7 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
             {
                 if constexpr (SIDE_ON) JM_REFRESH();
                 const T yy = residual(std::integral_constant<int, i>{});
-                set_x(std::integral_constant<int, i>{}, fmax_(x[i] + (w * yy) * invd[i], T(0)));
+                set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
             }
         });
         // block 2: friction cones (rows i, i + 1; normal force = row i + 2)
@@ -2274,8 +2272,8 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side, 
 // the smallest instantiation that serves every robot of the wave; `miss` (device counter or null): robots with a solve that
 // this form cannot take -- they fall to the streamed form, which is an order of magnitude slower per robot: the host
 // watches the counter and steps such batches with the single kernel instead (jm_lib.cpp)
-template<class T, class Tp, int SS, class WANY>
-JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * miss, WANY && wany)
+template<class T, class Tp, class X, int SS>
+JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * miss)
 {
     using RG = QSplitRegion<Tp>;
     constexpr int NBF = QLanePgs<Tp>::NBF;
@@ -2293,10 +2291,11 @@ JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * si
 #endif
     }
     const int nbq = fits ? nb : 0;
-    if (!wany(nbq > 0)) qcon_pgs_lane<T, Tp, 0, SS>(C, friction, reg, side, wany);
-    else if (NBF >= 1 && !wany(nbq > 1)) qcon_pgs_lane<T, Tp, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side, wany);
-    else if (NBF >= 2 && !wany(nbq > 2)) qcon_pgs_lane<T, Tp, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side, wany);
-    else qcon_pgs_lane<T, Tp, NBF, SS>(C, friction, reg, side, wany);
+    if (!X::wave_any(nbq > 0)) qcon_pgs_lane<T, Tp, X, 0, SS>(C, friction, reg, side);
+    else if (NBF >= 1 && !X::wave_any(nbq > 1)) qcon_pgs_lane<T, Tp, X, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side);
+    else if (NBF >= 2 && !X::wave_any(nbq > 2)) qcon_pgs_lane<T, Tp, X, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side);
+    else if (NBF >= 3 && !X::wave_any(nbq > 3)) qcon_pgs_lane<T, Tp, X, (NBF >= 3 ? 3 : NBF), SS>(C, friction, reg, side);
+    else qcon_pgs_lane<T, Tp, X, NBF, SS>(C, friction, reg, side);
 }
 
 #ifndef JM_HOST_EMU
@@ -2453,8 +2452,8 @@ k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * miss)
     const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + threadIdx.x;
     if (r >= (unsigned)C.split_r1) return;
     if constexpr (QLanePgs<Tp>::FITS)
-        qcon_pgs_lane_any<T, Tp, 64>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
-                                     side_ + threadIdx.x, miss, [](bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; });
+        qcon_pgs_lane_any<T, Tp, DppQuad, 64>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
+                                              side_ + threadIdx.x, miss);
 }
 
 // Engine::start / reset in the split form: the exact solve of the first pass (`ignoreBounds`), one quad per robot --
