@@ -805,10 +805,10 @@ def test_bench_line_runs_the_full_extra_terms(gpu_device):
     sys.path.insert(0, root)
     import bench
     assert [(c["model_name"], c["contact_model"], c["solver"]) for c in bench.SECONDARY] == [
-        ("anymal", "spring_damper", "runge_kutta_4"),     # (round 6: the headline robot at dt = 5e-4, every lane finite)
+        ("anymal", "spring_damper", "runge_kutta_4"),     # (round 6: the headline robot at dt = 2.5e-4, every lane finite)
         ("anymal", "constraint", "euler_explicit"), ("atlas", "spring_damper", "runge_kutta_4"), ("atlas", "constraint", "euler_explicit"),
         ("arm7", "spring_damper", "runge_kutta_4")]       # (round 5: the one-robot-per-lane kernels' robot)
-    assert bench.SECONDARY[0]["dt"] == 5e-4
+    assert bench.SECONDARY[0]["dt"] == 2.5e-4
     assert set(bench.FULL_EXTRA_OUTPUTS) >= {"energy", "joint_forces", "centroidal"}
 
 
