@@ -2502,6 +2502,7 @@ k_qtip_pgs(const QConArgs<T> C, const T * P, unsigned)
     constexpr int VS_ = QConRows<Tp>::MAXM + 4;
     __shared__ T xs[XS * 64];
     __shared__ T zs[ZS * 64];
+    __shared__ T yps[XS * 64];                   // residuals of the previous sweep (same stride as the multipliers)
     __shared__ unsigned short vis[VS_ * 64];
     const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + (threadIdx.x >> 2);
     if (r >= (unsigned)C.split_r1) return;
@@ -2509,7 +2510,8 @@ k_qtip_pgs(const QConArgs<T> C, const T * P, unsigned)
     const unsigned g0 = (threadIdx.x >> 2) * (unsigned)(RG::ROWS * sizeof(T));
     if constexpr (TP::ON)
         qtip_pgs<T, Tp, DppQuad, JM_QTIP_DEPTH>(C, C.friction ? C.friction[r] : P[L::OPT + 8], (int)(threadIdx.x & 3),
-                                                xs + (threadIdx.x >> 2) * XS, zs + (threadIdx.x >> 2) * ZS, vis + (threadIdx.x >> 2) * VS_, ws, g0);
+                                                xs + (threadIdx.x >> 2) * XS, zs + (threadIdx.x >> 2) * ZS, yps + (threadIdx.x >> 2) * XS,
+                                                vis + (threadIdx.x >> 2) * VS_, ws, g0);
 }
 
 template<class T, class Tp, int INIT>

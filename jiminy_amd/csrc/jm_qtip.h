@@ -378,7 +378,7 @@ JM_DEV int qtip_visit_table(int k, int m, int nb, int cb, unsigned long long loc
 // A visit is straight-line code: the projections of the row kinds are computed side by side and selected (the robots of a
 // wave are at different places of their sweeps); only the friction cone (two rows) is a branch of its own.
 template<class T, class Tp, class X, int D>
-JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, unsigned short * vt, char * ws, unsigned g0)
+JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, T * ypl, unsigned short * vt, char * ws, unsigned g0)
 {
     using RG = QSplitRegion<Tp>;
     using TP = QTip<Tp>;
@@ -394,8 +394,10 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
     const bool friction_zero = friction < eps, torsion_zero = C.torsion < eps;
     const unsigned iter_max = (unsigned)C.iter_max;
     auto zoff_of = [&](int row) { return (int)(unsigned)as_bits(G(REC0 + REC * row + TP::RMETA)); };
-    for (int i = k; i < m; i += 4) { x[i] = G(i); G(REC0 + REC * i + TP::RB) = G(m + i); G(REC0 + REC * i + TP::RYP) = T(0); }
-    if (lead) { x[m] = T(0); x[m + 1] = T(0); }
+    // (`ypl`: the residuals of the previous sweep, on chip since round 6 -- as a field of the row records they were a global
+    // store per visit, and every wait for a prefetched record also waited for the stores issued before it)
+    for (int i = k; i < m; i += 4) { x[i] = G(i); G(REC0 + REC * i + TP::RB) = G(m + i); ypl[i] = T(0); }
+    if (lead) { x[m] = T(0); x[m + 1] = T(0); ypl[m] = T(0); ypl[m + 1] = T(0); }
     for (int i = k; i < TP::ZPAD; i += 4) z[i] = T(0);
     // this lane's rows of E: the columns of the tips in registers (what every contact row needs), the columns of the joint
     // slots stay in the region (read by the few joint rows of a sweep: 32 registers less)
@@ -449,19 +451,19 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
     }
     X::sync();
     // what a visit reads of the workspace: the record of its row (and of the next one: a cone's second row)
-    struct Rec { T xr[6], b, invd, reg, yp; T xr2[6], b2, invd2, reg2, yp2; int i, kind, zoff; };
+    struct Rec { T xr[6], b, invd, reg; T xr2[6], b2, invd2, reg2; int i, kind, zoff; };
     auto fetch = [&](int t, Rec & R_) __attribute__((always_inline)) {
         const int v = vt[t];
         R_.i = v & 0xff; R_.kind = v >> 8;
         const T * rp = &G(REC0 + REC * R_.i);
 #pragma unroll
         for (int a = 0; a < 6; ++a) R_.xr[a] = rp[a];
-        R_.b = rp[TP::RB]; R_.invd = rp[TP::RINVD]; R_.reg = rp[TP::RREG]; R_.yp = rp[TP::RYP];
+        R_.b = rp[TP::RB]; R_.invd = rp[TP::RINVD]; R_.reg = rp[TP::RREG];
         R_.zoff = (int)(unsigned)as_bits(rp[TP::RMETA]);
         // (the row after it: read whatever the kind -- one more 96-byte block at an immediate offset, no branch around loads)
 #pragma unroll
         for (int a = 0; a < 6; ++a) R_.xr2[a] = rp[REC + a];
-        R_.b2 = rp[REC + TP::RB]; R_.invd2 = rp[REC + TP::RINVD]; R_.reg2 = rp[REC + TP::RREG]; R_.yp2 = rp[REC + TP::RYP];
+        R_.b2 = rp[REC + TP::RB]; R_.invd2 = rp[REC + TP::RINVD]; R_.reg2 = rp[REC + TP::RREG];
     };
     auto relaxation = [&](unsigned iter) {
         const T ratio = (T(iter_max - 20u) - T(iter)) / T(iter_max - 20u - 30u);
@@ -491,6 +493,7 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
             const int i = cur.i, kind = cur.kind;
             // multipliers of the row, its neighbours in the contact block (x is zero beyond m), z at the row's slot
             const T xi = x[i], xm1 = x[i > 0 ? i - 1 : 0], xp1 = x[i + 1], xp2 = x[i + 2];
+            const T yp_i = ypl[i], yp_i1 = ypl[i + 1];
             T zt[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) zt[a] = z[cur.zoff + a];
@@ -500,7 +503,6 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
             for (int a = 0; a < 6; ++a) { yz += cur.xr[a] * zt[a]; yz2 += cur.xr2[a] * zt[a]; }
             const T y = cur.b - yz - cur.reg * xi;
             T gt[NCT][6], gb;   // X^T dx on each tip (zero on the tips the row does not touch) / on the row's joint slot
-            T ynew2 = T(0);
             if (kind == 5)
             {
                 // friction cone: rows i, i + 1 (multipliers xi, xp1), normal force xp2
@@ -508,7 +510,7 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                 T e0 = xi * T(0), e1 = xp1 * T(0);
                 if (!friction_zero)
                 {
-                    dmax = X::max_abs(X::max_abs(dmax, y - cur.yp), y1 - cur.yp2);
+                    dmax = X::max_abs(X::max_abs(dmax, y - yp_i), y1 - yp_i1);
                     ymax = X::max_abs(X::max_abs(ymax, y), y1);
                     const T ia = fmin_(cur.invd, cur.invd2);   // 1 / max(a00, a11)
                     e0 = xi + (w * y) * ia;
@@ -520,7 +522,6 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                     const T scale = out ? thr * rsqrt_(out ? n2 : T(1)) : T(1);
                     e0 *= scale;
                     e1 *= scale;
-                    ynew2 = y1;
                 }
                 const T d0 = e0 - xi, d1 = e1 - xp1;
                 static_for<0, NCT>([&](auto tc) {
@@ -533,7 +534,7 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                 gb = T(0);
                 // (written by the four lanes alike: same value, same address -- no exec-mask detour for a lead lane)
                 x[i] = e0; x[i + 1] = e1;
-                if (!friction_zero) { G(REC0 + REC * i + TP::RYP) = y; G(REC0 + REC * (i + 1) + TP::RYP) = y1; }
+                if (!friction_zero) { ypl[i] = y; ypl[i + 1] = y1; }
             }
             else
             {
@@ -547,7 +548,7 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                 xn = zeroed ? xi * T(0) : xn;
                 if (!zeroed)
                 {
-                    dmax = X::max_abs(dmax, y - cur.yp);
+                    dmax = X::max_abs(dmax, y - yp_i);
                     ymax = X::max_abs(ymax, y);
                 }
                 const T dx = xn - xi;
@@ -559,13 +560,8 @@ JM_DEV bool qtip_pgs(const QConArgs<T> & C, T friction, int k, T * x, T * z, uns
                 });
                 gb = cur.xr[0] * dx;
                 x[i] = xn;
-                if (!zeroed) G(REC0 + REC * i + TP::RYP) = y;
+                if (!zeroed) ypl[i] = y;
             }
-            // (solves of fewer visits than the ring: the row is already in flight again, with its residual of the sweep before)
-            static_for<0, D>([&](auto ec) {
-                constexpr int e = decltype(ec)::value;
-                if (e != d && ring[e].i == i) { ring[e].yp = y; if (kind == 5) ring[e].yp2 = ynew2; }
-            });
             // z += E[:, slot of the row] X^T dx for this lane's entries
             static_for<0, NCT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;

@@ -211,6 +211,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
         // on-chip arrays of the solve, shared by the four lanes of the robot
         std::vector<jm::QPair<T>> xs(8 * 12 / 2 + 2);
         std::vector<T> zs(jm::QTip<Tp>::ZPAD + 4, (T)std::nan(""));
+        std::vector<T> yps(jm::QConRows<Tp>::MAXM + 4, (T)std::nan(""));   // residuals of the previous sweep (on chip on the device)
         std::vector<unsigned short> vis(8 * 12 + 8);
         std::vector<std::thread> th;
         for (int k = 0; k < 4; ++k)
@@ -243,7 +244,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                         }
                         bool tip = false;
                         if constexpr (jm::QTip<Tp>::ON)
-                            tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), vis.data(), ws, g0);
+                            tip = jm::qtip_pgs<T, Tp, HostQuad, JM_QTIP_DEPTH>(C, friction, k, (T *)xs.data(), zs.data(), yps.data(), vis.data(), ws, g0);
                         if (tip) { if (k == 0) ++g_tip_solves; }
                         else if (!jm::qcon_pgs_lean<T, Tp, HostQuad, 8, 0, JM_QCON_PGS_DEPTH>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0))
                             jm::qcon_pgs_lean<T, Tp, HostQuad, 12, 64, JM_QCON_PGS_DEPTH - 1>(C, friction, k, (T *)xs.data(), vis.data(), ws, g0);
