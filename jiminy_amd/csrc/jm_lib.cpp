@@ -102,13 +102,18 @@ struct jm_batch
     bool qcon_split = true;   // constraint model, large solves: split step launches (JIMINY_AMD_QCON_SPLIT=0 at creation: single kernel)
     bool qcon_split_start = true;   // ... and split start / reset launches (JIMINY_AMD_QCON_SPLIT_START=0: single kernel)
     bool joint_locks = false; // the batch carries user-registered JointConstraints (jm_batch_set_joint_locks)
-    // split stepping of robots whose solve runs one lane per robot (jm_qcon.h, qcon_pgs_lane): robots that do not fit that
-    // form are counted on the device (`lane_miss`), the count of the last finished step is read without waiting
-    // (`lane_miss_host`, pinned; `lane_miss_ev`), and while it is non-zero the batch steps with the single kernel
-    int32_t * lane_miss = nullptr;
-    int32_t * lane_miss_host = nullptr;
-    hipEvent_t lane_miss_ev = nullptr;
-    bool lane_miss_pending = false;
+    // split stepping of robots whose solve runs one lane per robot (jm_qcon.h, qcon_pgs_lane): the solve kernel counts the
+    // robots it cannot take, its sweeps, its waves and its longest solve on the device (four counters per slot).  A batch
+    // with misses, or whose solves are short (robots standing under control), steps with the single kernel for a while, then one
+    // step in the split form probes again.  The decision for step n only reads the counters of steps <= n - 2 and WAITS for
+    // them (they have long arrived: no stall), and `start` resets the state: the sequence of forms is a function of the
+    // simulated data, not of host timing -- two runs from the same state are bit-identical (reference pin 11)
+    static constexpr int LANE_SLOTS = 4;
+    int32_t * lane_stat = nullptr;        // device, [LANE_SLOTS][4]
+    int32_t * lane_stat_host = nullptr;   // pinned, [LANE_SLOTS][4]
+    hipEvent_t lane_ev[LANE_SLOTS] = {};
+    long long lane_step_of[LANE_SLOTS] = {-1, -1, -1, -1};   // step whose counters the slot is waiting for (-1: free)
+    long long lane_step = 0;              // split-capable step launches since `start`
     int split_cooldown = 0;
     int split_chunks = 1;     // ... as this many independent chunks on streams of their own (JIMINY_AMD_QCON_SPLIT_CHUNKS; measured: no gain)
     hipStream_t split_stream[8] = {};
@@ -310,42 +315,68 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
             // robots whose solves live in the workspace: step launches go through pre | solve | post per evaluation (jm_qcon.h)
             // robots with small solves (one lane per robot): only while every solve of the batch fits that form -- a robot
             // that does not (more active bounds than the layout holds, torsion rows, a joint lock) falls to the streamed form,
-            // an order of magnitude slower per robot.  The miss count of the last finished step decides, without a wait;
-            // a batch that had misses steps with the single kernel for the next 64 steps, then tries again.
+            // an order of magnitude slower per robot, and the split form only pays off for long solves: the counters of the solve
+            // kernel decide (see jm_batch::lane_stat).
             bool lane_ok = true;
             hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
             if constexpr (!jm::qcon_split_large<Tp>())
             {
+                if (A.mode == jm::MODE_START)
+                {
+                    // a simulation starts in the split form with a clean history: the forms of its steps depend on its data only
+                    b->lane_step = 0;
+                    b->split_cooldown = 0;
+                    for (int i = 0; i < jm_batch::LANE_SLOTS; ++i) b->lane_step_of[i] = -1;
+                }
                 if (A.mode == jm::MODE_STEP && !capturing)
                 {
-                    if (b->lane_miss_pending && hipEventQuery(b->lane_miss_ev) == hipSuccess)
+                    for (int pass = 0; pass < jm_batch::LANE_SLOTS; ++pass)
                     {
-                        b->lane_miss_pending = false;
-                        if (*b->lane_miss_host > 0) b->split_cooldown = 64;
+                        // oldest outstanding slot of a step <= n - 2
+                        int k = -1;
+                        for (int i = 0; i < jm_batch::LANE_SLOTS; ++i)
+                            if (b->lane_step_of[i] >= 0 && b->lane_step_of[i] <= b->lane_step - 2 && (k < 0 || b->lane_step_of[i] < b->lane_step_of[k])) k = i;
+                        if (k < 0) break;
+                        (void)hipEventSynchronize(b->lane_ev[k]);
+                        b->lane_step_of[k] = -1;
+                        const int32_t * st = b->lane_stat_host + 4 * k;   // [0] misfits, [1] sweeps, [2] waves, [3] longest solve
+                        if (std::getenv("JM_DEBUG_SPLIT")) std::fprintf(stderr, "[split] miss %d sweeps %d waves %d longest %d\n", st[0], st[1], st[2], st[3]);
+                        int cool = 0;
+                        if (st[0] > 0) cool = 64;
+                        // measured on ANYmal, 65 536 robots, per evaluation: single kernel ~147 us + 5.3 us per average sweep (its
+                        // waves queue four deep on a SIMD); split form ~247 us + 1.55 us per sweep of the LONGEST solve of the launch
+                        // (every wave of the solve kernel is resident at once)
+                        else if (st[2] > 0 && 5.3 * (double)st[1] / (double)st[2] - 1.55 * (double)st[3] < 100.0) cool = 256;
+                        if (cool > b->split_cooldown) b->split_cooldown = cool;
                     }
                     if (b->split_cooldown > 0) { --b->split_cooldown; lane_ok = false; }
+                    ++b->lane_step;
                 }
+                // (a captured step keeps one form for all its replays: the single kernel, which is never far off)
+                if (capturing && !std::getenv("JIMINY_AMD_QCON_SPLIT_CAPTURE")) lane_ok = false;
                 if (C0.torsion >= 2.220446049250313e-16) lane_ok = false;   // (four-row contact blocks: never the fixed layout)
             }
             if (lane_ok && b->qcon_split && A.mode == jm::MODE_STEP && !(A.model_lane || A.applied || A.ground_h) && (A.B & 15) == 0 && !b->ov_flags)
             {
                 int32_t * miss = nullptr;
+                int lane_slot = -1;
                 if constexpr (!jm::qcon_split_large<Tp>())
                     if (!capturing)
                     {
-                        if (!b->lane_miss)
+                        if (!b->lane_stat)
                         {
-                            if (hipMalloc((void **)&b->lane_miss, sizeof(int32_t)) != hipSuccess ||
-                                hipHostMalloc((void **)&b->lane_miss_host, sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
-                                hipEventCreateWithFlags(&b->lane_miss_ev, hipEventDisableTiming) != hipSuccess)
-                            { b->lane_miss = nullptr; }
-                            else *b->lane_miss_host = 0;
+                            bool ok = hipMalloc((void **)&b->lane_stat, 4 * jm_batch::LANE_SLOTS * sizeof(int32_t)) == hipSuccess &&
+                                      hipHostMalloc((void **)&b->lane_stat_host, 4 * jm_batch::LANE_SLOTS * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+                            for (int i = 0; ok && i < jm_batch::LANE_SLOTS; ++i) ok = hipEventCreateWithFlags(&b->lane_ev[i], hipEventDisableTiming) == hipSuccess;
+                            if (!ok) b->lane_stat = nullptr;
+                            else std::memset(b->lane_stat_host, 0, 4 * jm_batch::LANE_SLOTS * sizeof(int32_t));
                         }
-                        if (b->lane_miss && !b->lane_miss_pending)
+                        if (b->lane_stat)
                         {
-                            miss = b->lane_miss;
-                            (void)hipMemsetAsync(miss, 0, sizeof(int32_t), s);
+                            lane_slot = (int)((b->lane_step - 1) % jm_batch::LANE_SLOTS);   // (drained above: its step is <= n - 4)
+                            miss = b->lane_stat + 4 * lane_slot;
+                            (void)hipMemsetAsync(miss, 0, 4 * sizeof(int32_t), s);
                         }
                     }
                 C.stage = C.ws + (size_t)jm::qcon_split_region_rows<double, Tp>() * (size_t)A.B;
@@ -401,9 +432,9 @@ template<class Tp> void launch_quad_con(jm_batch * b, jm::BatchArgs<double> & A,
                     }
                 if (miss)
                 {
-                    (void)hipMemcpyAsync(b->lane_miss_host, miss, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-                    (void)hipEventRecord(b->lane_miss_ev, s);
-                    b->lane_miss_pending = true;
+                    (void)hipMemcpyAsync(b->lane_stat_host + 4 * lane_slot, miss, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                    (void)hipEventRecord(b->lane_ev[lane_slot], s);
+                    b->lane_step_of[lane_slot] = b->lane_step - 1;
                 }
                 return;
             }
@@ -714,9 +745,9 @@ int32_t jm_batch_destroy(jm_batch * b)
     (void)hipSetDevice(b->device);
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->ad_count) (void)hipFree(b->ad_count);
-    if (b->lane_miss) (void)hipFree(b->lane_miss);
-    if (b->lane_miss_host) (void)hipHostFree(b->lane_miss_host);
-    if (b->lane_miss_ev) (void)hipEventDestroy(b->lane_miss_ev);
+    if (b->lane_stat) (void)hipFree(b->lane_stat);
+    if (b->lane_stat_host) (void)hipHostFree(b->lane_stat_host);
+    for (int i = 0; i < jm_batch::LANE_SLOTS; ++i) if (b->lane_ev[i]) (void)hipEventDestroy(b->lane_ev[i]);
     if (b->ad_flags) (void)hipFree(b->ad_flags);
     if (b->ad_count_host) (void)hipHostFree(b->ad_count_host);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);

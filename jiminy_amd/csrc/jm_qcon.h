@@ -2103,7 +2103,7 @@ template<class Tp, int NBS> struct QLaneSide
 };
 // `side`: this lane's column of the wave's side store (entry e at side[e * SS]); SS = 64 on the device, 1 on the host.
 template<class T, class Tp, class X, int NBS, int SS>
-JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
+JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
 {
     using RG = QSplitRegion<Tp>;
     using LP = QLanePgs<Tp>;
@@ -2117,7 +2117,7 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
     const int nca = cb == 3 ? (m - nb) / 3 : 0;
     const bool mine = m > 0 && m <= MR && ((hdr >> 24) & 1) == 0 && cb == 3 && nb <= NBF && nca <= NC && nb + 3 * nca == m &&
                       reg[RG::LOCK] == T(0) && !(friction < eps);
-    if (!X::wave_any(mine)) return;
+    if (!X::wave_any(mine)) return 0;
     const int A0 = 4 * m, ms = QStoreSq<T>::row_stride(m);
     const unsigned iter_max = (unsigned)C.iter_max;
     // position -> packed row of this robot (-1: unused)
@@ -2187,10 +2187,12 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
         }
     });
     bool converged = !mine;
+    int sweeps = 0;
     const T ratio_den = T(1) / T(iter_max - 20u - 30u);
 #pragma nounroll
     for (unsigned iter = 0; iter < iter_max && !converged; ++iter)
     {
+        ++sweeps;
         T dmax = T(0), ymax = T(0);
         const T ratio = (T(iter_max - 20u) - T(iter)) * ratio_den;
         T w = T(1);
@@ -2267,13 +2269,18 @@ JM_DEV void qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
         reg[RG::OK] = converged ? T(1) : T(0);
         reg[RG::HDR] = (T)(hdr | (1 << LP::DONE_BIT));
     }
+    return sweeps;
 }
 
-// the smallest instantiation that serves every robot of the wave; `miss` (device counter or null): robots with a solve that
-// this form cannot take -- they fall to the streamed form, which is an order of magnitude slower per robot: the host
-// watches the counter and steps such batches with the single kernel instead (jm_lib.cpp)
+// the smallest instantiation that serves every robot of the wave.  `stat` (device counters or null) -- what the host decides
+// the form of the next steps on (jm_lib.cpp): [0] robots with a solve that this form cannot take (they fall to the streamed
+// form, an order of magnitude slower per robot), [1] sweeps of the waves (the longest solve of each), [2] waves, [3] the longest
+// solve of the launch.  The split form pays ~100 us per evaluation for its kernel boundaries and lasts as long as its longest
+// solve (~1.5 us per sweep); the single kernel pays ~5 us per AVERAGE sweep: robots dropped on the ground (redundant contacts
+// that only the relaxation schedule ends: ~54 sweeps on average, 100 at most) are the split form's, robots standing under
+// control (~10 on average) the single kernel's
 template<class T, class Tp, class X, int SS>
-JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * miss)
+JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * stat, bool lead)
 {
     using RG = QSplitRegion<Tp>;
     constexpr int NBF = QLanePgs<Tp>::NBF;
@@ -2282,20 +2289,39 @@ JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * si
     const bool tip = ((hdr >> 24) & 1) != 0;
     const bool fits = m > 0 && m <= 16 && cb == 3 && nb <= NBF && !tip && nb + 3 * ((m - nb) / 3) == m && (m - nb) / 3 <= QLanePgs<Tp>::NC &&
                       reg[RG::LOCK] == T(0) && !(friction < Eps<T>::eps);
-    if (miss && m > 0 && !tip && !fits)
+    if (stat && m > 0 && !tip && !fits)
     {
 #ifndef JM_HOST_EMU
-        atomicAdd(miss, 1);
+        atomicAdd(stat, 1);
 #else
-        *miss += 1;
+        stat[0] += 1;
 #endif
     }
     const int nbq = fits ? nb : 0;
-    if (!X::wave_any(nbq > 0)) qcon_pgs_lane<T, Tp, X, 0, SS>(C, friction, reg, side);
-    else if (NBF >= 1 && !X::wave_any(nbq > 1)) qcon_pgs_lane<T, Tp, X, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side);
-    else if (NBF >= 2 && !X::wave_any(nbq > 2)) qcon_pgs_lane<T, Tp, X, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side);
-    else if (NBF >= 3 && !X::wave_any(nbq > 3)) qcon_pgs_lane<T, Tp, X, (NBF >= 3 ? 3 : NBF), SS>(C, friction, reg, side);
-    else qcon_pgs_lane<T, Tp, X, NBF, SS>(C, friction, reg, side);
+    int sweeps;
+    if (!X::wave_any(nbq > 0)) sweeps = qcon_pgs_lane<T, Tp, X, 0, SS>(C, friction, reg, side);
+    else if (NBF >= 1 && !X::wave_any(nbq > 1)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side);
+    else if (NBF >= 2 && !X::wave_any(nbq > 2)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side);
+    else if (NBF >= 3 && !X::wave_any(nbq > 3)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 3 ? 3 : NBF), SS>(C, friction, reg, side);
+    else sweeps = qcon_pgs_lane<T, Tp, X, NBF, SS>(C, friction, reg, side);
+    if (stat)
+    {
+        // longest solve of the wave (<= 127 sweeps: seven uniform tests), reported by its lead lane
+        int mx = 0;
+#pragma unroll
+        for (int bit = 6; bit >= 0; --bit)
+            if (X::wave_any(sweeps >= (mx | (1 << bit)))) mx |= 1 << bit;
+        if (lead && X::wave_any(fits))
+        {
+#ifndef JM_HOST_EMU
+            atomicAdd(stat + 1, mx);
+            atomicAdd(stat + 2, 1);
+            atomicMax(stat + 3, mx);
+#else
+            stat[1] += mx; stat[2] += 1; stat[3] = stat[3] > mx ? stat[3] : mx;
+#endif
+        }
+    }
 }
 
 #ifndef JM_HOST_EMU
@@ -2442,7 +2468,7 @@ k_qcon_pgs(const QConArgs<T> C, const T * P, unsigned)
 // k_qcon_pgs, which then finds those robots marked done.  One wave per block: 64 robots, the whole register file.
 template<class T, class Tp>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
-k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * miss)
+k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * stat)
 {
     using L = Layout<Tp>;
     using RG = QSplitRegion<Tp>;
@@ -2453,7 +2479,7 @@ k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * miss)
     if (r >= (unsigned)C.split_r1) return;
     if constexpr (QLanePgs<Tp>::FITS)
         qcon_pgs_lane_any<T, Tp, DppQuad, 64>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
-                                              side_ + threadIdx.x, miss);
+                                              side_ + threadIdx.x, stat, threadIdx.x == 0);
 }
 
 // Engine::start / reset in the split form: the exact solve of the first pass (`ignoreBounds`), one quad per robot --

@@ -574,6 +574,57 @@ def test_gpu_constraint_model_matches_oracle(name, gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,solver,n_sub,B", [("anymal", "euler_explicit", 2, 96), ("anymal", "runge_kutta_4", 1, 96),
+                                                 ("biped", "euler_explicit", 1, 64), ("anymal", "euler_explicit", 1, 4096)])
+def test_gpu_split_stepping_with_the_one_lane_per_robot_solve(gpu_device, monkeypatch, name, solver, n_sub, B):
+    """Robots with few contact points (ANYmal, bipeds) step through k_quad_con_split<1> | k_qcon_pgs_lane | k_quad_con_split<2>
+    when the batch is a multiple of 16 (round 6, jm_qcon.h: the solve holds a robot per lane): same flags and status, states /
+    multipliers / outputs at round-off of the single kernel (JIMINY_AMD_QCON_SPLIT=0) and, for the small batches, of the oracle.
+    Twelve steps: long enough for the library to read its sweep counters and switch the form of the following steps (robots
+    resting on the ground converge in a few sweeps: the single kernel takes over after the first steps; jm_lib.cpp)."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine
+    model = _models()[name]()
+    with_oracle = B <= 128
+    ref, _ = _pair(model, B, seed=29)
+    dt = 5e-4
+    engines = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("JIMINY_AMD_QCON_SPLIT", split)
+        eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                            extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+        eng.set_options({"stepper": {"odeSolver": solver, "dtMax": dt, "controllerUpdatePeriod": n_sub * dt,
+                                     "sensorsUpdatePeriod": n_sub * dt, "tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]},
+                         "contacts": {"model": "constraint"}})
+        eng.set_command(torch.from_numpy(ref["command"]))
+        eng.start(torch.from_numpy(ref["q"]), torch.from_numpy(ref["v"]))
+        engines.append(eng)
+    if with_oracle:
+        oracle_batch(model, ref, "start", constraint_options=TIGHT)
+        loop = ReferenceFixedStepLoop(dt)
+    split, single = engines
+    for i in range(12):
+        for eng in engines:
+            eng.step(n_sub * dt)
+        torch.cuda.synchronize()     # (the counters of this step are in: the next one may change form)
+        if with_oracle:
+            oracle_engine_step(model, ref, loop, n_sub * dt, solver, command_changed=True, constraint_options=TIGHT)
+        if i in (0, 2, 11):
+            assert np.array_equal(split.field("con_flags").cpu().numpy(), single.field("con_flags").cpu().numpy()), i
+            assert np.array_equal(split.status.cpu().numpy(), single.status.cpu().numpy()), i
+            for k in OUTS:
+                if k in split._fields and split._rows.get(k, 1) > 0:
+                    a, b = split.field(k).cpu().numpy(), single.field(k).cpu().numpy()
+                    # (two summation orders of the same Gauss-Seidel iterates run to stagnation; worst lane of the batch)
+                    assert rel_err(a, b) < (1e-8 if B <= 128 else 1e-7), (i, k, rel_err(a, b))
+                    if with_oracle and k in ref and ref[k].size:
+                        assert rel_err(a, ref[k]) < 1e-6, (i, k, rel_err(a, ref[k]))
+    if with_oracle:
+        assert np.array_equal(split.field("con_flags").cpu().numpy(), ref["con_flags"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver,n_sub,B", [("runge_kutta_4", 1, 48), ("runge_kutta_4", 3, 48), ("euler_explicit", 2, 48),
                                             ("runge_kutta_4", 2, 2048 + 80)])
 def test_gpu_split_stepping_of_large_solves(gpu_device, monkeypatch, solver, n_sub, B):
