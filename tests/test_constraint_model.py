@@ -239,7 +239,7 @@ QUAD_MODELS = ("anymal", "atlas", "crane_walker", "biped", "biped_torso")
 
 
 @pytest.mark.parametrize("name,variant", [(n, "lane") for n in _models()] + [(n, "quad") for n in QUAD_MODELS] +
-                         [("atlas", "split"), ("anymal", "split"), ("biped", "split"), ("biped_torso", "split")])
+                         [("atlas", "split"), ("anymal", "split"), ("biped", "split")])
 def test_constraint_kernel_matches_oracle_on_the_host(name, variant):
     """Both device formulations compiled for the host against the oracle (the reference's dense one):
     `lane` = one robot per lane, sequential bias-free solves (jm_constraint.h); `quad` = four lanes per
