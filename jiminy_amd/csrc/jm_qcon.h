@@ -2070,9 +2070,6 @@ JM_DEV bool qcon_pgs_lean(const QConArgs<T> & C, T friction, int k, T * x, unsig
 // (PGSSolver::ProjectedGaussSeidelSolver, constraint_solvers.cc:107-326).  Taken by the robots whose solve fits the layout
 // (<= 16 rows, 3-row contact blocks i.e. contacts.torsion = 0, at most 16 - 3 NC active bounds, positive friction, no
 // user-registered joint lock); it marks the region header (bit 25) so that the streamed form leaves the robot alone.
-#ifndef JM_QCON_LANE_SIDE
-#define JM_QCON_LANE_SIDE 0
-#endif
 template<class Tp> struct QLanePgs
 {
     static constexpr int MR = 16, NC = ConRows<Tp>::NC, NBF = MR - 3 * NC;
@@ -2085,31 +2082,15 @@ template<class Tp> struct QLanePgs
 // to the vectors of the solve; what does not fit sits in accumulation registers behind a v_accvgpr_read per operand half
 // (843 VALU instructions per sweep at NBS = 4 against 405 at NBS = 0).  The kernel picks the smallest instantiation that
 // serves every robot of the wave (most waves of standing robots have no active bound).
-// JM_QCON_LANE_SIDE = 1 (measured, off): the entries of the bound rows and the residuals of the previous sweep in LDS
-// instead, entry-major over the lanes (`side`, stride SS) -- 843 -> 562 VALU instructions per sweep, but a wave that is alone
-// on its SIMD waits out every one of those reads: 187 -> 278 us per solve of 65 536 ANYmal systems.
-template<class Tp, int NBS> struct QLaneSide
-{
-    static constexpr bool SIDE_ON = JM_QCON_LANE_SIDE != 0 && NBS > 0;
-    static constexpr int NC = ConRows<Tp>::NC, MR = 3 * NC + NBS;
-    // entries (r, c), r >= c, with r >= 3 NC, in row order; then MR residuals of the previous sweep
-    static constexpr int NA = MR * (MR + 1) / 2 - (3 * NC) * (3 * NC + 1) / 2;
-    static constexpr int YT = NA, TOTAL = SIDE_ON ? NA + MR : 0;
-    static constexpr bool in_side(int r, int c) { return SIDE_ON && (r >= 3 * NC || c >= 3 * NC); }
-    static constexpr int slot(int r, int c)   // (r >= c)
-    {
-        return r * (r + 1) / 2 + c - (3 * NC) * (3 * NC + 1) / 2;
-    }
-};
-// `side`: this lane's column of the wave's side store (entry e at side[e * SS]); SS = 64 on the device, 1 on the host.
-template<class T, class Tp, class X, int NBS, int SS>
-JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
+// (Measured and dropped in round 6: the entries of the bound rows and the residuals of the previous sweep in LDS instead,
+// entry-major over the lanes -- 843 -> 562 VALU instructions per sweep, but a wave that is alone on its SIMD waits out every
+// one of those reads: 187 -> 278 us per solve of 65 536 ANYmal systems.)
+template<class T, class Tp, class X, int NBS>
+JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg)
 {
     using RG = QSplitRegion<Tp>;
     using LP = QLanePgs<Tp>;
-    using SD = QLaneSide<Tp, NBS>;
-    constexpr bool SIDE_ON = SD::SIDE_ON;
-    constexpr int NC = LP::NC, NBF = NBS, MR = 3 * NC + NBS, NCORE = (3 * NC) * (3 * NC + 1) / 2;
+    constexpr int NC = LP::NC, NBF = NBS, MR = 3 * NC + NBS, NTRI = MR * (MR + 1) / 2;
     static_assert(MR <= LP::MR, "fixed layout of at most 16 rows");
     const T eps = Eps<T>::eps;
     const int hdr = (int)reg[RG::HDR];
@@ -2138,22 +2119,9 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
     });
     unsigned used_any = 0u;
     static_for<0, MR>([&](auto ic) { used_any |= X::wave_any(((used >> decltype(ic)::value) & 1u) != 0u) ? (1u << decltype(ic)::value) : 0u; });
-    T At[SIDE_ON ? NCORE : MR * (MR + 1) / 2], x[MR], invd[MR], y[MR], yt0[SIDE_ON ? 1 : MR];
-    // matrix entry (r, c) / residual of the previous sweep: register or side store, decided at compile time
-    auto A_ = [&](auto rc, auto cc) __attribute__((always_inline)) -> T {
-        constexpr int r = decltype(rc)::value >= decltype(cc)::value ? decltype(rc)::value : decltype(cc)::value;
-        constexpr int c = decltype(rc)::value >= decltype(cc)::value ? decltype(cc)::value : decltype(rc)::value;
-        if constexpr (SD::in_side(r, c)) return side[SD::slot(r, c) * SS];
-        else return At[LP::tri(r, c)];
-    };
-    auto yturn_get = [&](auto ic) __attribute__((always_inline)) -> T {
-        if constexpr (SIDE_ON) return side[(SD::YT + decltype(ic)::value) * SS];
-        else return yt0[decltype(ic)::value];
-    };
-    auto yturn_put = [&](auto ic, T v) __attribute__((always_inline)) {
-        if constexpr (SIDE_ON) side[(SD::YT + decltype(ic)::value) * SS] = v;
-        else yt0[decltype(ic)::value] = v;
-    };
+    T At[NTRI], x[MR], invd[MR], y[MR], yturn[MR];
+    // matrix entry (r, c) of the packed triangle
+    auto A_ = [&](auto rc, auto cc) __attribute__((always_inline)) -> T { return At[LP::tri(decltype(rc)::value, decltype(cc)::value)]; };
     static_for<0, MR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int pi = pk[i];
@@ -2162,14 +2130,13 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
         x[i] = vi ? xi : T(0);
         y[i] = vi ? bi : T(0);
         invd[i] = vi ? rcp_(vi ? aii : T(1)) : T(0);
-        yturn_put(ic, T(0));
+        yturn[i] = T(0);
         static_for<0, i + 1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             const int pc = pk[c];
             const bool v = vi && pc >= 0;
             const T a = reg[v ? A0 + pi * ms + pc : 0];
-            if constexpr (SD::in_side(i, c)) side[SD::slot(i, c) * SS] = v ? a : T(0);
-            else At[LP::tri(i, c)] = v ? a : T(0);
+            At[LP::tri(i, c)] = v ? a : T(0);
         });
     });
     // y = b - A x
@@ -2204,9 +2171,9 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
         auto residual = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             const T yy = y[i];
-            dmax = X::max_abs(dmax, yy - yturn_get(ic));
+            dmax = X::max_abs(dmax, yy - yturn[i]);
             ymax = X::max_abs(ymax, yy);
-            yturn_put(ic, yy);
+            yturn[i] = yy;
             return yy;
         };
         auto set_x = [&](auto ic, T val) __attribute__((always_inline)) {
@@ -2219,15 +2186,11 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
                 if (r < 3 * NC || ((used_any >> r) & 1u)) y[r] -= A_(rc, ic) * dx;
             });
         };
-        // (the side-store entries are loop invariants: without a fence per row the compiler reads all of them once, ahead of
-        // the sweeps, into registers it does not have; with it the reads of a row's column are issued at the head of the
-        // row, under its projection chain)
         // block 0: joint bounds, then the normal forces (unilateral)
         static_for<0, NBF>([&](auto qc) {
             constexpr int i = 3 * NC + decltype(qc)::value;
             if ((used_any >> i) & 1u)
             {
-                if constexpr (SIDE_ON) JM_REFRESH();
                 const T yy = residual(std::integral_constant<int, i>{});
                 set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
             }
@@ -2236,7 +2199,6 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
             constexpr int i = 3 * decltype(cc)::value + 2;
             if ((used_any >> i) & 1u)
             {
-                if constexpr (SIDE_ON) JM_REFRESH();
                 const T yy = residual(std::integral_constant<int, i>{});
                 set_x(std::integral_constant<int, i>{}, X::max_(x[i] + (w * yy) * invd[i], T(0)));
             }
@@ -2246,7 +2208,6 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
             constexpr int i = 3 * decltype(cc)::value;
             if ((used_any >> i) & 1u)
             {
-                if constexpr (SIDE_ON) JM_REFRESH();
                 const T y0 = residual(std::integral_constant<int, i>{});
                 const T y1 = residual(std::integral_constant<int, i + 1>{});
                 const T ia = fmin_(invd[i], invd[i + 1]);   // 1 / max(a00, a11)
@@ -2279,8 +2240,8 @@ JM_DEV int qcon_pgs_lane(const QConArgs<T> & C, T friction, T * reg, T * side)
 // solve (~1.5 us per sweep); the single kernel pays ~5 us per AVERAGE sweep: robots dropped on the ground (redundant contacts
 // that only the relaxation schedule ends: ~54 sweeps on average, 100 at most) are the split form's, robots standing under
 // control (~10 on average) the single kernel's
-template<class T, class Tp, class X, int SS>
-JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * side, int32_t * stat, bool lead)
+template<class T, class Tp, class X>
+JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, int32_t * stat, bool lead)
 {
     using RG = QSplitRegion<Tp>;
     constexpr int NBF = QLanePgs<Tp>::NBF;
@@ -2299,11 +2260,11 @@ JM_DEV void qcon_pgs_lane_any(const QConArgs<T> & C, T friction, T * reg, T * si
     }
     const int nbq = fits ? nb : 0;
     int sweeps;
-    if (!X::wave_any(nbq > 0)) sweeps = qcon_pgs_lane<T, Tp, X, 0, SS>(C, friction, reg, side);
-    else if (NBF >= 1 && !X::wave_any(nbq > 1)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 1 ? 1 : NBF), SS>(C, friction, reg, side);
-    else if (NBF >= 2 && !X::wave_any(nbq > 2)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 2 ? 2 : NBF), SS>(C, friction, reg, side);
-    else if (NBF >= 3 && !X::wave_any(nbq > 3)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 3 ? 3 : NBF), SS>(C, friction, reg, side);
-    else sweeps = qcon_pgs_lane<T, Tp, X, NBF, SS>(C, friction, reg, side);
+    if (!X::wave_any(nbq > 0)) sweeps = qcon_pgs_lane<T, Tp, X, 0>(C, friction, reg);
+    else if (NBF >= 1 && !X::wave_any(nbq > 1)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 1 ? 1 : NBF)>(C, friction, reg);
+    else if (NBF >= 2 && !X::wave_any(nbq > 2)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 2 ? 2 : NBF)>(C, friction, reg);
+    else if (NBF >= 3 && !X::wave_any(nbq > 3)) sweeps = qcon_pgs_lane<T, Tp, X, (NBF >= 3 ? 3 : NBF)>(C, friction, reg);
+    else sweeps = qcon_pgs_lane<T, Tp, X, NBF>(C, friction, reg);
     if (stat)
     {
         // longest solve of the wave (<= 127 sweeps: seven uniform tests), reported by its lead lane
@@ -2472,14 +2433,11 @@ k_qcon_pgs_lane(const QConArgs<T> C, const T * P, int32_t * stat)
 {
     using L = Layout<Tp>;
     using RG = QSplitRegion<Tp>;
-    constexpr int NBF = QLanePgs<Tp>::FITS ? QLanePgs<Tp>::NBF : 0;
-    constexpr int SIDE = QLanePgs<Tp>::FITS ? QLaneSide<Tp, NBF>::TOTAL : 0;
-    __shared__ T side_[(SIDE > 0 ? SIDE : 1) * 64];
     const unsigned r = (unsigned)C.split_r0 + blockIdx.x * 64u + threadIdx.x;
     if (r >= (unsigned)C.split_r1) return;
     if constexpr (QLanePgs<Tp>::FITS)
-        qcon_pgs_lane_any<T, Tp, DppQuad, 64>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
-                                              side_ + threadIdx.x, stat, threadIdx.x == 0);
+        qcon_pgs_lane_any<T, Tp, DppQuad>(C, C.friction ? C.friction[r] : P[L::OPT + 8], C.ws + (size_t)r * (size_t)RG::ROWS,
+                                          stat, threadIdx.x == 0);
 }
 
 // Engine::start / reset in the split form: the exact solve of the first pass (`ignoreBounds`), one quad per robot --

@@ -2302,6 +2302,24 @@ int dopri_try_step(Engine & e, const AdaptiveOptions & ao, double & t, double & 
     return 1;
 }
 
+// Size of the next try of Engine::step's inner loop (engine.cc:2063-2089): stretched onto the breakpoint when the rest
+// after it would be below clamp(0.1 dt, 1e-10, 1e-6) (not after a try that failed for being too long), then cut to whole
+// microseconds.  Pinned to the reference's compiled lines by tests/golden/ref_cpp_leaves.npz (substep_*).
+void substep_rule(double & dt, double t, double tNext, uint32_t successiveIterTooLarge)
+{
+    double dtResidualThr = STEPPER_MIN_TIMESTEP;
+    if (successiveIterTooLarge == 0)
+        dtResidualThr = std::min(std::max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP);
+    if (tNext - t < dt || (successiveIterTooLarge <= 1 && tNext - t < dt + dtResidualThr)) dt = tNext - t;
+    if (dt > SIMULATION_MIN_TIMESTEP)
+    {
+        const double dtResidual = std::fmod(dt, SIMULATION_MIN_TIMESTEP);
+        if (dtResidual > STEPPER_MIN_TIMESTEP && dtResidual < SIMULATION_MIN_TIMESTEP - STEPPER_MIN_TIMESTEP &&
+            dt - dtResidual > STEPPER_MIN_TIMESTEP)
+            dt -= dtResidual;
+    }
+}
+
 // One breakpoint interval [t, tNext] of Engine::step with the adaptive stepper (engine.cc:2021-2222).
 void step_dopri(Engine & e, AdaptiveState & S, const AdaptiveOptions & ao, double tNext, int command_changed,
                 int update_sensors)
@@ -2318,17 +2336,7 @@ void step_dopri(Engine & e, AdaptiveState & S, const AdaptiveOptions & ao, doubl
             hasDynamicsChanged = false;
         }
         if (dt < STEPPER_MIN_TIMESTEP) { e.status |= JM_LANE_STEPPER_FAILURE; break; }
-        double dtResidualThr = STEPPER_MIN_TIMESTEP;
-        if (S.successiveIterTooLarge == 0)
-            dtResidualThr = std::min(std::max(0.1 * dt, STEPPER_MIN_TIMESTEP), SIMULATION_MIN_TIMESTEP);
-        if (tNext - t < dt || (S.successiveIterTooLarge <= 1 && tNext - t < dt + dtResidualThr)) dt = tNext - t;
-        if (dt > SIMULATION_MIN_TIMESTEP)
-        {
-            const double dtResidual = std::fmod(dt, SIMULATION_MIN_TIMESTEP);
-            if (dtResidual > STEPPER_MIN_TIMESTEP && dtResidual < SIMULATION_MIN_TIMESTEP - STEPPER_MIN_TIMESTEP &&
-                dt - dtResidual > STEPPER_MIN_TIMESTEP)
-                dt -= dtResidual;
-        }
+        substep_rule(dt, t, tNext, static_cast<uint32_t>(S.successiveIterTooLarge));
         if (S.successiveIterFailed > ao.successiveIterFailedMax) { e.status |= JM_LANE_STEPPER_FAILURE; break; }
         isBreakpointReached = (dtLargest > dt);
         dtLargest = dt;
@@ -2785,6 +2793,16 @@ void orc_leaf_motor_law(int64_t n, const double * params, double * u_motor, doub
         mp.inv_slope = c[3]; mp.effort_limit = c[4]; mp.velocity_limit = c[5];
         mp.fvp = c[7]; mp.fvn = c[8]; mp.fdp = c[9]; mp.fdn = c[10]; mp.fds = c[11];
         motor_law(mp, c[12], c[13], u_motor[i], u_transmission[i]);
+    }
+}
+void orc_leaf_substep(int64_t n, const double * dt, const double * t, const double * tNext, const int32_t * tooLarge,
+                      double * dt_out)
+{
+    for (int64_t i = 0; i < n; ++i)
+    {
+        double d = dt[i];
+        substep_rule(d, t[i], tNext[i], static_cast<uint32_t>(tooLarge[i]));
+        dt_out[i] = d;
     }
 }
 // code: 1 accepted, 0 rejected, 2 NaN error (the reference throws)

@@ -236,8 +236,7 @@ template<class T, class Tp> static void run_quad_con_split(const jm::BatchArgs<T
                         {
                             if (k == 0 && A.mode == jm::MODE_STEP)
                             {
-                                T side[jm::QLaneSide<Tp, jm::QLanePgs<Tp>::NBF>::TOTAL + 1];
-                                jm::qcon_pgs_lane_any<T, Tp, HostQuad, 1>(C, friction, region.data() + (size_t)r * RG::ROWS, side, (int32_t *)nullptr, true);
+                                jm::qcon_pgs_lane_any<T, Tp, HostQuad>(C, friction, region.data() + (size_t)r * RG::ROWS, (int32_t *)nullptr, true);
                                 ++g_lane_solves;
                             }
                             HostQuad::sync();

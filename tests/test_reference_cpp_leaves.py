@@ -163,6 +163,39 @@ def test_dopri_step_size_controller():
     assert np.array_equal(k, FIX["dopri_constants"])
 
 
+def test_substep_selection_rule():
+    """`Engine::step`'s choice of the next try (engine.cc:2063-2089) on the reference's compiled lines: the oracle's
+    `substep_rule` (which `step_dopri` calls), the fixed-step planner of the product and the loop of tests/helpers.py."""
+    from jiminy_amd.engine import substep_sizes
+    from tests.helpers import ReferenceFixedStepLoop
+    L = _lib()
+    L.orc_leaf_substep.argtypes = [C.c_int64, pd, pd, pd, C.POINTER(C.c_int32), pd]
+    dt, t, tn, tl = (np.ascontiguousarray(FIX[k]) for k in ("substep_dt", "substep_t", "substep_tnext", "substep_too_large"))
+    out = np.zeros(len(dt))
+    L.orc_leaf_substep(len(dt), _p(dt), _p(t), _p(tn), _p(tl, C.c_int32), _p(out))
+    want = FIX["substep_dt_out"]
+    assert np.array_equal(out, want)                             # comparisons, one subtraction, one libm fmod: bit for bit
+    # every branch is in the fixture: stretched onto the breakpoint, refused after a too-long try, snapped, untouched
+    gap = tn - t
+    thr = np.where(tl == 0, np.clip(0.1 * dt, 1e-10, 1e-6), 1e-10)
+    stretched = (gap < dt) | ((tl <= 1) & (gap < dt + thr))
+    assert stretched.sum() > 50 and (~stretched).sum() > 50
+    assert ((gap >= dt) & stretched).sum() > 10                  # the residual merge proper
+    assert ((tl == 2) & (gap >= dt) & (gap < dt + 1e-6)).sum() > 0
+    base = np.where(stretched, gap, dt)
+    assert (want != base).sum() > 50 and (want == base).sum() > 10     # snapped to whole microseconds / left alone
+    for i, (iv, dmax, dfirst, n) in enumerate(zip(FIX["interval"], FIX["interval_dt_max"], FIX["interval_dt_first"],
+                                                  FIX["interval_count"])):
+        ref = FIX["interval_sizes"][i, :n]
+        assert n < 64
+        got = substep_sizes(float(iv), float(dmax), float(dfirst))
+        assert len(got) == n and np.array_equal(np.array(got), ref), (i, got, ref)
+        loop = ReferenceFixedStepLoop(float(dmax))
+        loop.dt = float(dfirst)
+        mine = np.array(list(loop.sizes(float(iv))))             # counts the time left down instead of t up: last bits only
+        assert len(mine) == n and np.abs(mine - ref).max() <= 1e-18 + 4e-16 * iv, i
+
+
 def test_simple_motor_law():
     L = _lib()
     L.orc_leaf_motor_law.argtypes = [C.c_int64, pd, pd, pd]

@@ -10,9 +10,9 @@ set -u
 exec < /dev/null
 TAG=${1:-r05}
 bash tools/gpu_profile.sh ${TAG}_quad_full pmc_latest.json --no-secondary 2>&1 | tail -n 8 | cut -c1-200
-JM_PROFILE_DOMINANT='%k_qcon_pgs_lane%' JM_PROFILE_KERNELS='%k_quad_con_split<%1, 0>%,%k_quad_con_split<%2, 0>%,%k_quad_con<%' \
+JM_PROFILE_DOMINANT='%k_qcon_pgs_lane%' JM_PROFILE_KERNELS='%k_quad_con_split<%1_ 0>%,%k_quad_con_split<%2_ 0>%,%k_quad_con<%' \
   bash tools/gpu_profile.sh ${TAG}_con pmc_con_latest.json --no-secondary --contact-model constraint --steps 40 --warmup 5 2>&1 | tail -n 4 | cut -c1-200
 bash tools/gpu_profile.sh ${TAG}_atlas pmc_atlas_latest.json --no-secondary --model atlas --batch 32768 --dt 2.5e-4 --steps 40 --warmup 5 2>&1 | tail -n 4 | cut -c1-200
-JM_PROFILE_DOMINANT='%k_qtip_pgs%' JM_PROFILE_KERNELS='%k_quad_con_split<%1, 0>%,%k_quad_con_split<%2, 0>%,%k_qcon_pgs<%8,%,%k_qtip_exact%' \
+JM_PROFILE_DOMINANT='%k_qtip_pgs%' JM_PROFILE_KERNELS='%k_quad_con_split<%1_ 0>%,%k_quad_con_split<%2_ 0>%,%k_qcon_pgs<%8,%,%k_qtip_exact%' \
   bash tools/gpu_profile.sh ${TAG}_atlas_con pmc_atlas_con_latest.json --no-secondary --model atlas --batch 32768 --contact-model constraint --dt 5e-4 --steps 20 --warmup 3 2>&1 | tail -n 4 | cut -c1-200
 ls gpurun_out/${TAG}_*/summary

@@ -12,6 +12,7 @@ Two tiers, labelled per array group in the .npz (`tier__<group>`), in DESIGN.md 
   tier A  "reference-compiled": the TU contains reference text + standard headers only.
           PCG32 (+ its seed_seq constructor), uniform, the ziggurat normal and its tables, xxHash, MurmurHash3
           (core/src/utilities/random.cc:8-318, utilities/random.h, random.hxx, fwd.h `function_ref`),
+          the sub-step selection of Engine::step (engine.cc:2063-2089: stretch onto the breakpoint, snap to microseconds),
           the step-size controller of RungeKuttaDOPRIStepper::adjustStep (runge_kutta_dopri_stepper.cc:24-56 with
           the constants of runge_kutta_dopri_stepper.h:34-47) and the body of SimpleMotor::computeEffort
           (basic_motors.cc:89-142; the option struct around it is a plain data holder with the reference's member
@@ -108,6 +109,11 @@ def tu_tier_a() -> str:
     parts.append(grab(f"{CORE}/utilities/random.hxx", 16, 57, "namespace internal", "}"))
     # PCG32, uniform, ziggurat normal, xxHash, MurmurHash3: the whole first part of random.cc
     parts.append(grab("core/src/utilities/random.cc", 8, 318, "// ***************************** Uniform random bit generators", "}"))
+    # sub-step selection of Engine::step (engine.cc:2063-2089): stretch onto the breakpoint, snap to whole microseconds
+    parts.append(grab(f"{CORE}/constants.h", 18, 20, "inline constexpr double STEPPER_MIN_TIMESTEP", "inline constexpr double SIMULATION_MAX_TIMESTEP"))
+    parts.append("void substep_body(double & dt, const double t, const double tNext, const uint32_t successiveIterTooLarge)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 2063, 2089, "double dtResidualThr = STEPPER_MIN_TIMESTEP;", "}"))
+    parts.append("}\n")
     # step-size controller
     parts.append("namespace DOPRI\n{\n")
     parts.append(grab(f"{CORE}/stepper/runge_kutta_dopri_stepper.h", 34, 47, "/// \\brief Stepper order", "inline constexpr double MAX_FACTOR"))
@@ -224,6 +230,34 @@ int main(int argc, char ** argv)
         }
         io::put(code); io::put(dtOut);
         io::put(std::vector<double>{DOPRI::STEPPER_ORDER, DOPRI::SAFETY, DOPRI::ERROR_THRESHOLD, DOPRI::MIN_FACTOR, DOPRI::MAX_FACTOR});
+    }
+    // ---- sub-step rule: one application per case, then whole intervals of a fixed-step solver (the loop around the rule --
+    //      t += dt, dt = min(dtLargest = INF, dtMax) after every try, engine.cc:2136-2222 -- is this driver's)
+    {
+        const int64_t n = io::geti();
+        const auto dt = io::get<double>(n), t = io::get<double>(n), tn = io::get<double>(n);
+        const auto tl = io::get<int32_t>(n);
+        std::vector<double> out(n);
+        for (int64_t i = 0; i < n; ++i) { double d = dt[i]; substep_body(d, t[i], tn[i], static_cast<uint32_t>(tl[i])); out[i] = d; }
+        io::put(out);
+        const int64_t ni = io::geti();
+        const auto iv = io::get<double>(ni), dmax = io::get<double>(ni), dfirst = io::get<double>(ni);
+        std::vector<double> seq(ni * 64, 0.0);
+        std::vector<int32_t> cnt(ni);
+        for (int64_t i = 0; i < ni; ++i)
+        {
+            double tt = 0.0, d = dfirst[i];
+            int32_t k = 0;
+            while (iv[i] - tt > STEPPER_MIN_TIMESTEP && k < 64)
+            {
+                substep_body(d, tt, iv[i], 0U);
+                seq[i * 64 + k++] = d;
+                tt += d;
+                d = dmax[i];
+            }
+            cnt[i] = k;
+        }
+        io::put(cnt); io::put(seq);
     }
     // ---- SimpleMotor::computeEffort
     {
@@ -498,6 +532,25 @@ def main(out_path: str = OUT) -> None:
     blob.i(len(err))
     blob.a(err, np.float64)
     blob.a(dts, np.float64)
+    # sub-step rule: (dt, t, tNext, successiveIterTooLarge) across every branch, then whole intervals (interval, dtMax, first dt)
+    nsr = 400
+    sr_dt = 10.0 ** rg.uniform(-7.5, -1.7, nsr)
+    sr_t = rg.uniform(0.0, 2.0, nsr)
+    gap = np.where(rg.random(nsr) < 0.5, sr_dt * rg.uniform(0.3, 1.3, nsr), sr_dt * rg.uniform(1.0, 40.0, nsr))
+    gap[:40] = sr_dt[:40] + 10.0 ** rg.uniform(-11, -6.2, 40)          # just beyond the step: the residual-merge band
+    sr_dt[40:60] = np.round(sr_dt[40:60], 6) + rg.uniform(0, 1e-6, 20)  # around whole microseconds
+    sr_tn = sr_t + gap
+    sr_tl = rg.integers(0, 3, nsr).astype(np.int32)
+    blob.i(nsr)
+    for arr in (sr_dt, sr_t, sr_tn):
+        blob.a(arr, np.float64)
+    blob.a(sr_tl, np.int32)
+    iv = np.array([1e-3, 1e-3, 1e-3, 5e-3, 5e-3, 1e-3, 1.05e-6, 1.2e-6, 4e-2, 1e-3, 2.5e-4, 1e-3, 7.77e-4, 1e-2], dtype=np.float64)
+    ivmax = np.array([1e-3, 1e-3, 1 / 3e3, 1e-3, 7e-4, 2e-2, 1e-3, 1e-3, 5e-3, 1e-4 + 3e-8, 1e-3, 9.999e-4, 1e-4, 2e-2])
+    ivfirst = np.array([1e-6, 1e-3, 1 / 3e3, 1e-6, 7e-4, 1e-6, 1e-6, 1e-6, 5e-3, 1e-6, 1e-6, 9.999e-4, 1e-4, 1e-6])
+    blob.i(len(iv))
+    for arr in (iv, ivmax, ivfirst):
+        blob.a(arr, np.float64)
     # motors: [red, effLimOn, velLimOn, invSlope, effortLimit, velocityLimit, fricOn, fvp, fvn, fdp, fdn, fds, v, command]
     # MOTOR_GROUP rows share one parameter set (a motor's options are model constants: the device test builds one
     # model per group); group 0 = ANYmal's shipped motor (anymal_hardware.toml:7-11, URDF effort 80 / velocity 7.5)
@@ -541,9 +594,12 @@ def main(out_path: str = OUT) -> None:
     out.update(hash_len=lens, hash_seed=hseeds, hash_key=keys, xxhash=rd.take(np.uint32, nk), murmur3=rd.take(np.uint32, nk))
     out.update(dopri_err=err, dopri_dt=dts, dopri_code=rd.take(np.int32, len(err)), dopri_dt_out=rd.take(np.float64, len(err)),
                dopri_constants=rd.take(np.float64, 5))
+    out.update(substep_dt=sr_dt, substep_t=sr_t, substep_tnext=sr_tn, substep_too_large=sr_tl, substep_dt_out=rd.take(np.float64, nsr))
+    out.update(interval=iv, interval_dt_max=ivmax, interval_dt_first=ivfirst, interval_count=rd.take(np.int32, len(iv)),
+               interval_sizes=rd.take(np.float64, len(iv), 64))
     out.update(motor_group=np.array(MOTOR_GROUP), motor_params=mp, motor_u=rd.take(np.float64, nm), motor_u_transmission=rd.take(np.float64, nm))
     rd.done()
-    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor"):
+    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval"):
         out[f"tier__{group}"] = np.array("A")
 
     # ============================================================ tier B
