@@ -298,8 +298,10 @@ def measure(ctx, *, model_name: str, B: int, dtype, solver: str, contact_model: 
         kernel_name = "jm::k_quad_con" if kernel_name == "jm::k_quad" else "jm::k_constrained"
         from jiminy_amd.codegen import qcon_split
         if kernel_name == "jm::k_quad_con" and qcon_split(model) and B % 16 == 0 and os.environ.get("JIMINY_AMD_QCON_SPLIT", "1") != "0":
-            # large solves: one launch of the step = (k_quad_con_split<1> | k_qcon_pgs | k_quad_con_split<2>) per evaluation
-            kernel_name = "jm::k_quad_con_split<1> + jm::k_qcon_pgs + jm::k_quad_con_split<2>"
+            # large solves: one launch of the step = (k_quad_con_split<1> | solve | k_quad_con_split<2>) per evaluation; the solve
+            # of robots with many contact points per foot runs in the operational space of the feet (k_qtip_pgs, jm_qtip.h),
+            # k_qcon_pgs (the streamed form) only finds the robots that form could not take
+            kernel_name = "jm::k_quad_con_split<1> + jm::k_qtip_pgs + jm::k_quad_con_split<2>"
             nbj = sum(1 for t in model.jtypes[1:] if 1 <= int(t) <= 8)
             if min(nbj + 4 * model.ncontacts, 96) <= 32:
                 # robots with few contact points (round 6): the solve runs one lane per robot

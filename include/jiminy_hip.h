@@ -217,8 +217,9 @@ enum {
                               add one multiplier row each behind the frames' and one reference-configuration row each
                               behind the frames' reference transforms */
     JM_F_FRICTION = 20,    /* [1] in, optional: contacts.friction of every lane (domain randomisation of the ground
-                              friction, gym_jiminy envs/locomotion.py:257-262); both contact models (spring-damper:
-                              branch-parallel topologies), unbound = the batch-wide contacts.friction option */
+                              friction, gym_jiminy envs/locomotion.py:257-262); both contact models, every topology
+                              (spring-damper on the one-robot-per-lane kernels: ABI 9), unbound = the batch-wide
+                              contacts.friction option */
     JM_F_MODEL_LANE = 21,  /* [13 * njoints] in, optional: body parameters of every lane, rows per joint
                               mass | com 3 | inertia xx xy xz yy yz zz | joint placement translation 3 -- the
                               output of Model::addBiasedToExtendedModel (core/src/robot/model.cc:1166-1236: mass,
@@ -232,7 +233,12 @@ enum {
                               of jm_batch_set_ground -- every environment its own patch of one large terrain, the batched
                               form of one `world.groundProfile` per environment instance (gym_jiminy: a new random
                               ground per episode); unbound = (0, 0) */
-    JM_F_COUNT = 24
+    JM_F_FLEXIBILITY = 24, /* [6 * nspherical] in, optional (ABI 9): stiffness 3, damping 3 of every spherical (flexibility) joint, in
+                              joint order, per lane -- `flexibilityConfig` randomised per environment the way
+                              WalkerJiminyEnv._setup does per episode (gym_jiminy envs/locomotion.py:288-296); read by
+                              Engine::computeInternalDynamics' flexibility efforts (core/src/engine/engine.cc:3365-3391);
+                              unbound = jm_model_desc::flex_stiffness / flex_damping */
+    JM_F_COUNT = 25
 };
 
 /* ---- `contacts.model = "constraint"` (the reference's default contact model, engine.h:273) and the

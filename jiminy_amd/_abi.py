@@ -8,7 +8,7 @@ import numpy as np
 
 from .model import CompiledModel
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # error codes
 JM_OK, JM_EINVAL, JM_ERUNTIME, JM_ECONTROLFLOW = 0, -1, -2, -3
@@ -26,7 +26,8 @@ CONTACT_MODELS = {"spring_damper": JM_CONTACT_SPRING_DAMPER, "constraint": JM_CO
 (JM_F_Q, JM_F_V, JM_F_A, JM_F_COMMAND, JM_F_U_MOTOR, JM_F_U, JM_F_F_EXTERNAL,
  JM_F_CONTACT_FORCES, JM_F_IMU, JM_F_FORCE, JM_F_CONTACT, JM_F_ENCODER, JM_F_EFFORT,
  JM_F_ENERGY, JM_F_JOINT_FORCES, JM_F_CENTROIDAL, JM_F_STATUS, JM_F_WORKSPACE,
- JM_F_CON_FLAGS, JM_F_CON_DATA, JM_F_FRICTION, JM_F_MODEL_LANE, JM_F_APPLIED, JM_F_GROUND_OFFSET, JM_F_COUNT) = range(25)
+ JM_F_CON_FLAGS, JM_F_CON_DATA, JM_F_FRICTION, JM_F_MODEL_LANE, JM_F_APPLIED, JM_F_GROUND_OFFSET, JM_F_FLEXIBILITY,
+ JM_F_COUNT) = range(26)
 
 FIELD_NAMES = {
     "q": JM_F_Q, "v": JM_F_V, "a": JM_F_A, "command": JM_F_COMMAND, "u_motor": JM_F_U_MOTOR,
@@ -36,6 +37,7 @@ FIELD_NAMES = {
     "centroidal": JM_F_CENTROIDAL, "status": JM_F_STATUS, "workspace": JM_F_WORKSPACE,
     "con_flags": JM_F_CON_FLAGS, "con_data": JM_F_CON_DATA, "friction": JM_F_FRICTION,
     "model_lane": JM_F_MODEL_LANE, "applied": JM_F_APPLIED, "ground_offset": JM_F_GROUND_OFFSET,
+    "flexibility": JM_F_FLEXIBILITY,
 }
 
 _pi = C.POINTER(C.c_int32)

@@ -151,6 +151,9 @@ template<class T> struct BatchArgs
     // batch of B_full lanes -- the per-lane OPTIONAL inputs (model_lane, friction, applied, ground_off) stay in batch order
     const int32_t * lane_map;
     long long B_full;
+    // `[6 per spherical joint][B]` stiffness 3, damping 3 of the flexibility joints of every lane (JM_F_FLEXIBILITY), or null:
+    // `flexibilityConfig` randomised per environment (envs/locomotion.py:288-296); one-robot-per-lane kernels
+    const T * flex_lane;
 };
 // MODE_REFRESH: evaluate at the bound state and emit the outputs (sensors if `update_sensors`), OR-ing
 // the lane status into the existing one: the closing launch of an adaptive-step interval
@@ -189,6 +192,11 @@ template<class T, class Tp> struct Work
     // the lane's column of the sweeps' stash (LDS on the device, see eval_aba): element r at stash[r * LANE_STRIDE]
     T * stash;
     int status;
+    // per-environment variation: the lane's ground friction coefficient (BatchArgs::friction; < 0: the option) and the lane's
+    // column of BatchArgs::flex_lane (row r at flex[r * flex_stride]; null: the parameter block)
+    T mu;
+    const T * flex;
+    long long flex_stride;
     static constexpr bool CONSTRAINED = false;
 };
 // working set of the constraint contact model (jm_constraint.h): keeps the factorised root block
@@ -328,11 +336,12 @@ template<class T, class Tp, int J> JM_DEV T joint_St_dot(CPtr<T> P, Sp<T> f)
 }
 
 // Engine::computeContactDynamics (engine.cc:3197-3238), flat ground n = z
-template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> vW)
+// `mu_lane` >= 0: the lane's own friction coefficient (BatchArgs::friction) instead of the option
+template<class T, class Tp> JM_DEV V3<T> contact_law(CPtr<T> P, T depth, V3<T> vW, T mu_lane = T(-1))
 {
     using L = Layout<Tp>;
-    const T k = P[L::OPT + 6], c = P[L::OPT + 7], mu = P[L::OPT + 8], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
-    // (per-lane friction goes through contact_law_n, the form of the per-environment variation kernels)
+    const T k = P[L::OPT + 6], c = P[L::OPT + 7], eps = P[L::OPT + 9], vt = P[L::OPT + 10];
+    const T mu = mu_lane >= T(0) ? mu_lane : P[L::OPT + 8];
     const T vDepth = vW.z;
     const T fN = -fmin_(k * depth + c * vDepth, T(0));
     const V3<T> vT = {vW.x, vW.y, vW.z - vDepth};
@@ -540,7 +549,7 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
             // world velocity of the contact point: oMi.R (v_lin + w x p_frame)
             const V3<T> vj = w.vel[j].l + cross(w.vel[j].a, fr.p);
             const V3<T> vW = w.oMi[j].R * vj;
-            const V3<T> fW = contact_law<T, Tp>(P, depth, vW);
+            const V3<T> fW = contact_law<T, Tp>(P, depth, vW, w.mu);
             fl.l = tmul(w.oMi[j].R, fW);
             fl.a = cross(fr.p, fl.l);
         }
@@ -595,14 +604,21 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
             constexpr int o = L::FLEX + 6 * spherical_rank<Tp>(j);
             T angle;
             const V3<T> aa = quat_log3(q[iq], q[iq + 1], q[iq + 2], q[iq + 3], angle);
-            V3<T> t3 = jlog3_mul(angle, aa, V3<T>{P[o] * aa.x, P[o + 1] * aa.y, P[o + 2] * aa.z});
+            // stiffness 3, damping 3: the lane's own (JM_F_FLEXIBILITY) or the model's
+            constexpr int of = 6 * spherical_rank<Tp>(j);
+            T kd[6];
+            static_for<0, 6>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                kd[i] = w.flex ? w.flex[(long long)(of + i) * w.flex_stride] : P[o + i];
+            });
+            V3<T> t3 = jlog3_mul(angle, aa, V3<T>{kd[0] * aa.x, kd[1] * aa.y, kd[2] * aa.z});
             // "Flexible joint angle must be smaller than 0.95 * pi": the reference throws (engine.cc:3379-3383) -- a rejected
             // trial of the adaptive stepper, the end of a fixed-step simulation.  The efforts become NaN and so does the
             // acceleration, which takes those very paths (JM_LANE_NAN / a rejected attempt).
             if (angle > T(0.95 * 3.14159265358979323846)) t3.x = T(__builtin_nan(""));
-            w.ueff[iv] -= t3.x + P[o + 3] * v[iv];
-            w.ueff[iv + 1] -= t3.y + P[o + 4] * v[iv + 1];
-            w.ueff[iv + 2] -= t3.z + P[o + 5] * v[iv + 2];
+            w.ueff[iv] -= t3.x + kd[3] * v[iv];
+            w.ueff[iv + 1] -= t3.y + kd[4] * v[iv + 1];
+            w.ueff[iv + 2] -= t3.z + kd[5] * v[iv + 2];
         }
     });
     static_for<0, Tp::NV>([&](auto ic) { w.u[decltype(ic)::value] = w.ueff[decltype(ic)::value]; });
@@ -1182,6 +1198,13 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
 #endif
     w.status = 0;
     w.stash = sb + (long long)stage_rows<Tp>() * SBS;
+    {
+        // (compact batches of the per-stage adaptive stepper: the optional per-lane inputs stay in batch order)
+        const long long lg = A.lane_map ? (long long)A.lane_map[lane] : (long long)lane;
+        w.mu = A.friction ? A.friction[lg] : T(-1);
+        w.flex_stride = A.lane_map ? A.B_full : B;
+        w.flex = A.flex_lane ? A.flex_lane + lg : nullptr;
+    }
     static_for<0, NM>([&](auto mc) { cmd[decltype(mc)::value] = A.command[decltype(mc)::value * B + lane]; });
 
     if (A.mode == MODE_RESET)

@@ -31,7 +31,7 @@
 #include "jm_qdopri.h"
 #include "jm_random.h"
 
-#define JM_ABI_VERSION 8
+#define JM_ABI_VERSION 9
 
 #ifdef JM_SPLIT_CONSTRAINT
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
@@ -215,6 +215,7 @@ template<class T> jm::BatchArgs<T> make_args(const jm_batch * b)
     for (int i = 0; i < 4; ++i) A.applied_joint[i] = b->applied_joint[i];
     // spring-damper model: the lane's own friction coefficient when the field is bound (variation kernels)
     A.friction = b->copt.contact_model == JM_CONTACT_CONSTRAINT ? nullptr : (const T *)b->field[JM_F_FRICTION];
+    A.flex_lane = (const T *)b->field[JM_F_FLEXIBILITY];
     return A;
 }
 

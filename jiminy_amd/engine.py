@@ -961,7 +961,9 @@ class BatchedEngine:
         if getattr(self, "_gen_checked", False) or self.dtype != torch.float64 or \
                 os.environ.get("JIMINY_AMD_SELF_TEST", "1") == "0":
             return
-        lane_mu = "friction" in self._fields and self._options["contacts"]["model"] != "constraint"
+        # (the one-robot-per-lane kernels read the lane's friction in their only contact law: no variation form to check)
+        lane_mu = "friction" in self._fields and self._options["contacts"]["model"] != "constraint" and \
+            codegen.quad_structure(self.model) is not None and os.environ.get("JM_KERNEL_VARIANT") != "lane"
         # (user constraints: only the branch-parallel family moves to its variation kernels for them; the lane kernel has none)
         locks = bool(self._user_constraints) and codegen.quad_structure(self.model) is not None and \
             os.environ.get("JM_KERNEL_VARIANT") != "lane"
@@ -1178,16 +1180,16 @@ class BatchedEngine:
     def set_lane_friction(self, friction: Optional[Any]) -> None:
         """Ground friction coefficient of every lane (`contacts.friction` randomised per environment as
         `WalkerJiminyEnv._setup` does per episode, gym_jiminy envs/locomotion.py:257-262).  `(B,)` values, or
-        None to go back to the batch-wide option.  Both contact models (the spring-damper law reads it in the
-        per-environment variation kernels: float64 batches of branch-parallel topologies); fixed-step solvers."""
+        None to go back to the batch-wide option.  Both contact models, both kernel families (the spring-damper law of the
+        branch-parallel family reads it in the per-environment variation kernels: float64 batches there)."""
         if friction is None:
             self._fields.pop("friction", None)
             self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["friction"], None))
             return
-        if self._options["contacts"]["model"] != "constraint" and \
-                (codegen.quad_structure(self.model) is None or self.dtype != torch.float64):
-            raise NotImplementedError("per-lane friction with the spring-damper model needs a float64 batch of a "
-                                      "branch-parallel topology (floating base with four limbs)")
+        quad = codegen.quad_structure(self.model) is not None and os.environ.get("JM_KERNEL_VARIANT") != "lane"
+        if self._options["contacts"]["model"] != "constraint" and quad and self.dtype != torch.float64:
+            raise NotImplementedError("per-lane friction with the spring-damper model on a branch-parallel topology (floating base "
+                                      "with limb chains) needs a float64 batch")
         f = torch.as_tensor(friction, dtype=self.dtype, device=self.device).reshape(1, -1)
         if f.shape[1] != self.batch_size or bool((f < 0).any()):
             raise ValueError("friction must hold one non-negative value per lane")
@@ -1195,6 +1197,37 @@ class BatchedEngine:
             self._fields["friction"] = torch.empty((1, self.batch_size), dtype=self.dtype, device=self.device)
             self._bind("friction")
         self._fields["friction"].copy_(f)
+
+    def set_lane_flexibility(self, stiffness: Optional[Any], damping: Optional[Any] = None) -> None:
+        """Stiffness and damping of the flexibility (spherical) joints of every lane: `flexibilityConfig` randomised per
+        environment, the way `WalkerJiminyEnv._setup` draws it per episode (gym_jiminy envs/locomotion.py:288-296).
+        `stiffness`, `damping`: `(nflex, 3, B)` or `(nflex, 3)` (the same for every lane), the joints in the order of
+        `model.flexibility_joint_indices`; None to go back to the model's values.  Read by the flexibility efforts of
+        `Engine::computeInternalDynamics` (engine.cc:3365-3391), one-robot-per-lane kernels (the family of every model
+        with a spherical joint), both contact models, fixed-step and adaptive solvers."""
+        nflex = len(self.model.flexibility_joint_indices)
+        if stiffness is None:
+            self._fields.pop("flexibility", None)
+            self._lib.check(self._L.jm_batch_bind(self._batch_h, _abi.FIELD_NAMES["flexibility"], None))
+            return
+        if nflex == 0:
+            raise LookupError(f"{self.model.name} has no flexibility joint")
+        if damping is None:
+            raise ValueError("give stiffness and damping together")
+        rows = torch.empty((6 * nflex, self.batch_size), dtype=self.dtype, device=self.device)
+        for o, val in ((0, stiffness), (3, damping)):
+            t = torch.as_tensor(val, dtype=self.dtype, device=self.device)
+            if t.dim() == 2:
+                t = t.unsqueeze(-1).expand(-1, -1, self.batch_size)
+            if tuple(t.shape) != (nflex, 3, self.batch_size) or bool((t < 0).any()):
+                raise ValueError(f"expected non-negative values of shape ({nflex}, 3) or ({nflex}, 3, {self.batch_size})")
+            for k in range(nflex):
+                rows[6 * k + o:6 * k + o + 3] = t[k]
+        if "flexibility" not in self._fields:
+            self._fields["flexibility"] = rows
+            self._bind("flexibility")
+        else:
+            self._fields["flexibility"].copy_(rows)
 
     # ------------------------------------------------------------------ state access
     @property

@@ -166,6 +166,7 @@ class VecJiminyEnv:
         if self._ground_profile is not None:
             self.engine.set_ground_profile(*self._ground_profile)
         self._randomise_ground(None)
+        self._randomise_flexibility(None)
         if self._spawn_dz is not None:
             q = q.clone()
             q[2] += self._spawn_dz.to(q.dtype).to(q.device)
@@ -240,6 +241,7 @@ class VecJiminyEnv:
         q, v = self._state_cache if self._state_cache is not None else self._sample_state(self.num_envs)
         self._on_reset(lane_mask)
         self._randomise_ground(lane_mask)
+        self._randomise_flexibility(lane_mask)
         if self._spawn_dz is not None:
             q = q.clone()
             q[2] += self._spawn_dz.to(q.dtype).to(q.device)
@@ -291,6 +293,30 @@ class VecJiminyEnv:
         if lane_mask is not None and "friction" in self.engine._fields:
             mu = torch.where(lane_mask, mu, self.engine.field("friction")[0])
         self.engine.set_lane_friction(mu)
+
+    FLEX_STIFFNESS_SCALE, FLEX_DAMPING_SCALE = 1000.0, 10.0    # envs/locomotion.py:37-38
+
+    def _randomise_flexibility(self, lane_mask: Optional[torch.Tensor]) -> None:
+        """Flexibility parameters of the environments being reset, ≙ `flexibility['stiffness'] += FLEX_STIFFNESS_SCALE *
+        sample(scale=std_ratio['model'])`, `flexibility['damping'] += FLEX_DAMPING_SCALE * sample(...)` for every entry of
+        `flexibilityConfig` (envs/locomotion.py:288-296; utils/misc.py:178-212: `sample(scale=s)` = U(-s, s)): one draw per
+        flexibility joint and environment, added to the three axes alike, around the model's own values (the reference
+        starts every episode from the robot options it was built with).  Values are kept non-negative."""
+        scale = float(self.std_ratio.get("model", 0.0))
+        flex = self.model.flexibility_joint_indices
+        if scale <= 0.0 or not flex or self.model.flex_stiffness is None:
+            return
+        n, B = len(flex), self.num_envs
+        k0 = torch.tensor(np.asarray(self.model.flex_stiffness)[flex], dtype=torch.float64)[:, :, None]
+        d0 = torch.tensor(np.asarray(self.model.flex_damping)[flex], dtype=torch.float64)[:, :, None]
+        u = torch.rand((2, n, 1, B), generator=self._generator, dtype=torch.float64) * 2.0 - 1.0
+        k = (k0 + self.FLEX_STIFFNESS_SCALE * scale * u[0]).clamp_min(0.0).to(self.dtype).to(self.device)
+        d = (d0 + self.FLEX_DAMPING_SCALE * scale * u[1]).clamp_min(0.0).to(self.dtype).to(self.device)
+        if lane_mask is not None and "flexibility" in self.engine._fields:
+            old = self.engine.field("flexibility").reshape(n, 2, 3, B)
+            k = torch.where(lane_mask[None, None, :], k, old[:, 0])
+            d = torch.where(lane_mask[None, None, :], d, old[:, 1])
+        self.engine.set_lane_flexibility(k, d)
 
     # envs/locomotion.py:30-36
     F_IMPULSE_DT, F_IMPULSE_PERIOD, F_IMPULSE_DELTA, F_IMPULSE_SCALE = 10.0e-3, 2.0, 0.25, 1000.0
@@ -384,8 +410,8 @@ class VecJiminyEnv:
 class WalkerVecEnv(VecJiminyEnv):
     """≙ `WalkerJiminyEnv` (envs/locomotion.py): legged robot with a free-flyer, fall detection
     at half the neutral height and the 'survival' / 'energy' / 'failure' / 'direction' reward mixture.
-    Not built: the flexibility randomisation of `std_ratio['model']` (locomotion.py:288-296) -- flexibility stiffness /
-    damping are constants of the batch here (the lane-family kernels have no per-lane model rows)."""
+    `std_ratio['model']` randomises the flexibility stiffness / damping of every environment per episode
+    (locomotion.py:288-296, `VecJiminyEnv._randomise_flexibility`)."""
 
     def __init__(self, *args: Any, reward_mixture: Optional[Dict[str, float]] = None, **kw: Any) -> None:
         super().__init__(*args, **kw)

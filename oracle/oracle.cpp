@@ -504,6 +504,8 @@ struct Engine
     int32_t * con_flags = nullptr;
     double * con_data = nullptr;
     const double * lane_friction = nullptr;  // [B] contacts.friction of every lane, or null
+    // [6 per spherical joint][B] stiffness 3, damping 3 of the flexibility joints of every lane (JM_F_FLEXIBILITY), or null
+    const double * lane_flex = nullptr;
     // per-lane (x, y) offset of the ground-profile queries ([2][B], batch drivers; JM_F_GROUND_OFFSET): every environment its
     // own patch of the terrain
     const double * lane_ground_offset = nullptr;
@@ -2475,6 +2477,7 @@ void orc_engine_bind_constraints(void * h, int32_t * flags, double * data)
     e.con_data = data;
 }
 void orc_engine_bind_friction(void * h, const double * friction) { static_cast<Engine *>(h)->lane_friction = friction; }
+void orc_engine_bind_flexibility(void * h, const double * flex) { static_cast<Engine *>(h)->lane_flex = flex; }
 void orc_engine_bind_ground_offset(void * h, const double * offsets) { static_cast<Engine *>(h)->lane_ground_offset = offsets; }
 void orc_engine_bind_model_lane(void * h, const double * model_lane) { static_cast<Engine *>(h)->model_lane = model_lane; }
 void orc_engine_bind_ground(void * h, const double * heights, int nx, int ny, double x0, double y0, double dx, double dy)
@@ -2582,6 +2585,23 @@ static void load_lane(Engine & e, const orc_batch_io & io, int64_t l)
 {
     const int64_t B = io.B;
     if (e.lane_friction) e.opt.contact_friction = e.lane_friction[l];
+    if (e.lane_flex)
+    {
+        // one `flexibilityConfig` per environment (gym_jiminy envs/locomotion.py:288-296)
+        Model & m = e.mdl;
+        m.flex_k.resize(3 * (size_t)m.njoints, 0.0); m.flex_d.resize(3 * (size_t)m.njoints, 0.0);
+        int64_t k = 0;
+        for (int j = 1; j < m.njoints; ++j)
+        {
+            if (m.jtype[j] != JM_JT_SPHERICAL) continue;
+            for (int i = 0; i < 3; ++i)
+            {
+                m.flex_k[3 * j + i] = e.lane_flex[(6 * k + i) * B + l];
+                m.flex_d[3 * j + i] = e.lane_flex[(6 * k + 3 + i) * B + l];
+            }
+            ++k;
+        }
+    }
     if (e.lane_ground_offset) { e.ground_ox = e.lane_ground_offset[l]; e.ground_oy = e.lane_ground_offset[B + l]; }
     else { e.ground_ox = 0; e.ground_oy = 0; }
     if (e.con_flags && e.con_data)

@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
         L.orc_engine_bind_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_bind_friction.restype = None
+        L.orc_engine_bind_flexibility.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_bind_flexibility.restype = None
         L.orc_engine_bind_ground_offset.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_bind_ground_offset.restype = None
         L.orc_engine_bind_model_lane.argtypes = [C.c_void_p, C.c_void_p]
@@ -157,6 +159,12 @@ class OracleEngine:
         """Per-lane `contacts.friction` of the batch drivers (`[B]` float64), None = the engine option."""
         self._friction = None if friction is None else np.ascontiguousarray(friction, dtype=np.float64)
         self._L.orc_engine_bind_friction(self._h, None if friction is None else self._friction.ctypes.data)
+
+    def bind_flexibility(self, flex: Optional[np.ndarray]) -> None:
+        """Per-lane flexibility parameters of the batch drivers (`[6 * nspherical][B]` float64: stiffness 3, damping 3 per
+        spherical joint in joint order), None = the model's `flexibilityConfig`."""
+        self._flex = None if flex is None else np.ascontiguousarray(flex, dtype=np.float64)
+        self._L.orc_engine_bind_flexibility(self._h, None if flex is None else self._flex.ctypes.data)
 
     def bind_model_lane(self, model_lane: Optional[np.ndarray]) -> None:
         """Per-lane body parameters `[13 * njoints][B]` (mass | com | inertia xx xy xz yy yz zz | placement

@@ -35,6 +35,8 @@ def oracle_batch(model: CompiledModel, arr: Dict[str, np.ndarray], mode: str, op
         e.bind_constraints(arr["con_flags"], arr["con_data"])
     if arr.get("friction") is not None:     # per-lane contacts.friction, either contact model
         e.bind_friction(arr["friction"])
+    if arr.get("flexibility") is not None:  # per-lane flexibilityConfig (stiffness 3, damping 3 per spherical joint)
+        e.bind_flexibility(arr["flexibility"])
     e.batch_run(mode, oracle_io(arr), **kw)
 
 

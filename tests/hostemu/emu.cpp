@@ -314,6 +314,8 @@ static void * g_con_flags = nullptr;
 static void * g_con_data = nullptr;
 static void * g_friction = nullptr;
 extern "C" void emu_set_friction(void * friction) { g_friction = friction; }
+static const void * g_flex_lane = nullptr;
+extern "C" void emu_set_flexibility(const void * flex) { g_flex_lane = flex; }
 extern "C" void emu_set_constraints(const jm_constraint_options * o, void * flags, void * data)
 {
     g_copt = *o;
@@ -371,7 +373,9 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.B = io->B; A.mode = mode; A.solver = solver; A.n_sub = n_sub; A.command_changed = command_changed;
     A.update_sensors = update_sensors; A.dt = (T)dt;
     A.friction = g_copt.contact_model == JM_CONTACT_CONSTRAINT ? nullptr : (const T *)g_friction;
-    const bool gen = g_model_lane || g_ground || g_applied || A.friction;
+    A.flex_lane = (const T *)g_flex_lane;
+    // (per-lane friction alone: the variation form of the branch-parallel code; the one-robot-per-lane code reads it as it is)
+    const bool gen = g_model_lane || g_ground || g_applied || (A.friction && g_variant == 1 && Topo::QUAD);
     A.model_lane = (const T *)g_model_lane;
     A.ground_h = (const T *)g_ground; A.ground_nx = g_gnx; A.ground_ny = g_gny;
     A.ground_off = g_ground ? (const T *)g_ground_off : nullptr;

@@ -46,6 +46,8 @@ def _lib(model: CompiledModel) -> C.CDLL:
     L.emu_set_friction.restype = None
     L.emu_set_ground_offset.argtypes = [C.c_void_p]
     L.emu_set_ground_offset.restype = None
+    L.emu_set_flexibility.argtypes = [C.c_void_p]
+    L.emu_set_flexibility.restype = None
     L.emu_set_split.argtypes = [C.c_int]
     L.emu_set_split.restype = None
     L.emu_has_split.restype = C.c_int
@@ -93,6 +95,8 @@ def run(model: CompiledModel, arrays: Dict[str, np.ndarray], mode: str, options=
     L.emu_set_ground_offset(go.ctypes.data if (go is not None and gh is not None) else None)
     fr = arrays.get("friction")
     L.emu_set_friction(fr.ctypes.data if fr is not None else None)
+    fx = arrays.get("flexibility")
+    L.emu_set_flexibility(fx.ctypes.data if fx is not None else None)
     if variant == "quad" and not L.emu_has_quad():
         raise RuntimeError("this topology has no limb-parallel variant")
     L.emu_set_variant(1 if variant == "quad" else 0)

@@ -594,3 +594,44 @@ def test_direction_reward_is_the_mean_lateral_position_of_the_episode(gpu_device
             assert abs(r[lane] - want) <= 1e-12 * max(1.0, abs(want)), (lane, r[lane], want)
             done_at[lane] = step
     assert (done_at >= 0).sum() >= B // 4                        # the limp robots did fall
+
+
+@pytest.mark.gpu
+def test_flexibility_parameters_are_drawn_per_environment_and_episode(gpu_device):
+    """`WalkerJiminyEnv._setup`, `std_ratio['model']` (envs/locomotion.py:288-296): every entry of `flexibilityConfig` gets
+    `stiffness += 1000 sample(scale)`, `damping += 10 sample(scale)` (one draw each, the three axes alike) at every reset of
+    an environment; the engine steps every environment with its own values."""
+    from jiminy_amd.envs import WalkerVecEnv
+    from tests import robots
+    model = robots.tree_arm_flexible(True)
+    B, scale = 64, 0.02      # (+- 20 N m/rad, +- 0.2 N m s/rad: below the smallest nominal values, nothing clamped at zero)
+    env = WalkerVecEnv(model, B, 2e-3, engine_options={"stepper": {"odeSolver": "runge_kutta_4", "dtMax": 5e-4},
+                                                      "contacts": {"model": "spring_damper"}},
+                       device=gpu_device, auto_reset=False, std_ratio={"model": scale})
+    env.reset(seed=3)
+    flex = model.flexibility_joint_indices
+    rows = env.engine.field("flexibility").cpu().numpy().reshape(len(flex), 2, 3, B)
+    for i, j in enumerate(flex):
+        dk = rows[i, 0] - model.flex_stiffness[j][:, None]
+        dd = rows[i, 1] - model.flex_damping[j][:, None]
+        assert np.abs(dk - dk[0]).max() < 1e-12 and np.abs(dd - dd[0]).max() < 1e-12     # one draw for the three axes
+        assert np.abs(dk).max() <= 1000.0 * scale and np.abs(dd).max() <= 10.0 * scale
+        assert dk[0].std() > 0.3 * 1000.0 * scale and dd[0].std() > 0.3 * 10.0 * scale    # ... per environment (uniform: 0.58)
+    assert abs(np.corrcoef(rows[0, 0, 0], rows[1, 0, 0])[0, 1]) < 0.5                     # ... and per flexibility joint
+    # the environments evolve differently from a batch that keeps the model's values
+    plain = WalkerVecEnv(model, B, 2e-3, engine_options={"stepper": {"odeSolver": "runge_kutta_4", "dtMax": 5e-4},
+                                                        "contacts": {"model": "spring_damper"}},
+                         device=gpu_device, auto_reset=False)
+    plain.reset(seed=3)
+    assert torch.equal(env.engine.field("q"), plain.engine.field("q"))
+    action = torch.zeros((B, model.nmotors), dtype=torch.float64, device=gpu_device)
+    for _ in range(5):
+        env.step(action)
+        plain.step(action)
+    assert (env.engine.field("q") - plain.engine.field("q")).abs().max() > 1e-6
+    # a lane reset draws again for those lanes only
+    mask = torch.zeros(B, dtype=torch.bool, device=gpu_device)
+    mask[::2] = True
+    env.reset_lanes(mask)
+    rows2 = env.engine.field("flexibility").cpu().numpy().reshape(len(flex), 2, 3, B)
+    assert np.array_equal(rows2[..., 1::2], rows[..., 1::2]) and not np.array_equal(rows2[..., ::2], rows[..., ::2])

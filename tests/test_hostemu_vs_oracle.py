@@ -78,6 +78,46 @@ def test_lane_kernel_matches_oracle(name, solver):
     assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
 
 
+@pytest.mark.parametrize("name", ["tree_arm_flex_ff", "pendulum_flexible", "tree_arm_ff", "anymal"])
+def test_lane_kernel_per_environment_friction_and_flexibility(name):
+    """The per-environment rows of the one-robot-per-lane kernels: ground friction of every lane under the spring-damper law
+    (JM_F_FRICTION, envs/locomotion.py:257-262) and stiffness / damping of the flexibility joints of every lane
+    (JM_F_FLEXIBILITY, envs/locomotion.py:288-296) -- different values per lane, against the oracle's one-robot engine."""
+    model = _models()[name]()
+    B = 16
+    rng = np.random.default_rng(5)
+    ref, got = _pair(model, B, seed=3)
+    nflex = len(model.flexibility_joint_indices)
+    extra = {}
+    if model.ncontacts:
+        extra["friction"] = np.ascontiguousarray(10.0 ** rng.uniform(-0.7, 0.3, (1, B)))
+    if nflex:
+        fx = np.zeros((6 * nflex, B))
+        for k, j in enumerate(model.flexibility_joint_indices):
+            fx[6 * k:6 * k + 3] = model.flex_stiffness[j][:, None] * rng.uniform(0.5, 1.5, (1, B))
+            fx[6 * k + 3:6 * k + 6] = model.flex_damping[j][:, None] * rng.uniform(0.5, 1.5, (1, B))
+        extra["flexibility"] = fx
+    assert extra
+    for arr in (ref, got):
+        arr.update(extra)
+    plain = {k: v.copy() for k, v in got.items() if k not in extra}
+    oracle_batch(model, ref, "start")
+    emu.run(model, got, "start")
+    emu.run(model, plain, "start")
+    _check(got, ref, 1e-10, what="start")
+    dt = 5e-5 if name == "pendulum_flexible" else 5e-4
+    for i in range(6):
+        kw = dict(solver="runge_kutta_4", dt=dt, n_substeps=2 if i % 2 else 1, command_changed=(i % 3 == 0))
+        oracle_batch(model, ref, "step", **kw)
+        emu.run(model, got, "step", **kw)
+        emu.run(model, plain, "step", **kw)
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.any()
+    _check(got, ref, 1e-8, ok, what="steps")
+    # ... and the rows are read: the batch-wide parameters give another trajectory
+    assert rel_err(plain["v"], ref["v"], ok) > 1e-6
+
+
 QUAD_CASES = {
     # name: (states kwargs, dt)
     "anymal": (dict(base_height=(0.3, 0.6), grounded_fraction=0.6), 5e-4),

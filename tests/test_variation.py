@@ -526,11 +526,88 @@ def test_gpu_per_lane_friction_with_the_spring_damper_law(gpu_device):
         plain[k][:] = st[k]
     oracle_batch(model, plain, "start")
     assert rel_err(eng.field("a").cpu().numpy(), plain["a"]) < 1e-10
-    # small trees have no variation kernel
-    with pytest.raises(NotImplementedError):
-        small = BatchedEngine(load_builtin("cartpole"), 4, dtype=torch.float64, device=gpu_device)
-        small.set_options({"contacts": {"model": "spring_damper"}})
-        small.set_lane_friction(np.ones(4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["runge_kutta_4", "runge_kutta_dopri"])
+def test_gpu_per_lane_friction_and_flexibility_on_the_one_robot_per_lane_kernels(gpu_device, solver):
+    """The per-environment rows of the lane family (ABI 9): ground friction of every lane under the spring-damper law and the
+    stiffness / damping of the flexibility joints of every lane (`WalkerJiminyEnv._setup`, envs/locomotion.py:257-262,
+    288-296), fixed-step and adaptive (whose compact launches find the rows through `BatchArgs::lane_map`), against the
+    oracle's one-robot engine with the lane's own values."""
+    from jiminy_amd.engine import BatchedEngine
+    from tests import robots
+    model = robots.tree_arm_flexible(True)
+    B, dt = 48, 5e-4
+    rng = np.random.default_rng(8)
+    st = sample_states(model, B, seed=21, base_height=(0.3, 0.6), grounded_fraction=0.7)
+    flex = model.flexibility_joint_indices
+    k = np.stack([model.flex_stiffness[j][:, None] * rng.uniform(0.5, 1.5, (1, B)) for j in flex])
+    d = np.stack([model.flex_damping[j][:, None] * rng.uniform(0.5, 1.5, (1, B)) for j in flex])
+    mu = 10.0 ** rng.uniform(-0.7, 0.3, B)
+    ref = alloc_soa(model, B)
+    for key in ("q", "v", "command"):
+        ref[key][:] = st[key]
+    ref["friction"] = mu.copy()
+    ref["flexibility"] = np.ascontiguousarray(np.concatenate([np.concatenate([k[i], d[i]]) for i in range(len(flex))]))
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device, extra_outputs=("contact_forces", "f_external"))
+    eng.set_options({"stepper": {"odeSolver": solver, "dtMax": 0.02 if solver == "runge_kutta_dopri" else dt,
+                                 "controllerUpdatePeriod": 2e-3 if solver == "runge_kutta_dopri" else dt,
+                                 "sensorsUpdatePeriod": 2e-3 if solver == "runge_kutta_dopri" else dt},
+                     "contacts": {"model": "spring_damper"}})
+    eng.set_lane_friction(mu)
+    eng.set_lane_flexibility(k, d)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    oracle_batch(model, ref, "start")
+    assert rel_err(eng.field("a").cpu().numpy(), ref["a"]) < 1e-9
+    plain = alloc_soa(model, B)
+    for key in ("q", "v", "command"):
+        plain[key][:] = st[key]
+    oracle_batch(model, plain, "start")
+    assert rel_err(plain["a"], ref["a"]) > 1e-3          # the rows matter on this batch
+    if solver == "runge_kutta_4":
+        loop = ReferenceFixedStepLoop(dt)
+        for _ in range(6):
+            eng.step(dt)
+            oracle_engine_step(model, ref, loop, dt, "runge_kutta_4", command_changed=False)
+        tol = 1e-8
+    else:
+        from jiminy_amd.engine import plan_breakpoints
+        from oracle.oracle_py import OracleEngine, adaptive_state
+        from tests.helpers import oracle_io
+        orc = OracleEngine(model)
+        orc.bind_friction(ref["friction"])
+        orc.bind_flexibility(ref["flexibility"])
+        io = oracle_io(ref)
+        ad = adaptive_state(B)
+        o = eng.get_options()["stepper"]
+        t, t_err = 0.0, 0.0
+        for _ in range(3):
+            intervals, t_end, t_err = plan_breakpoints(t, t_err, 2e-3, eng.get_options())
+            for i, (t_next, cmd, sens) in enumerate(intervals):
+                orc.batch_run_dopri(io, ad, t_next, tol_rel=o["tolRel"], tol_abs=o["tolAbs"], dt_max=o["dtMax"],
+                                    new_step=(i == 0), command_changed=False, update_sensors=sens)
+            t = t_end
+            eng.step(2e-3)
+        # (accept / reject decisions are discontinuous in the error estimate: lanes that follow the oracle's step sequence)
+        ss = eng.stepper_state
+        same = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+        assert same.mean() > 0.8
+        ref["status"][0][~same] |= 1
+        tol = 1e-7
+    ok = (ref["status"][0] & 1) == 0
+    assert ok.sum() > B // 2
+    for key in ("q", "v", "a", "contact_forces", "f_external"):
+        assert rel_err(eng.field(key).cpu().numpy(), ref[key], ok) < tol, key
+    # back to the model's own values
+    eng.stop()
+    eng.set_lane_friction(None)
+    eng.set_lane_flexibility(None)
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    assert rel_err(eng.field("a").cpu().numpy(), plain["a"]) < 1e-9
+    with pytest.raises(LookupError):
+        BatchedEngine(load_builtin("cartpole"), 4, dtype=torch.float64, device=gpu_device).set_lane_flexibility(np.ones((1, 3)), np.ones((1, 3)))
 
 
 @pytest.mark.gpu
