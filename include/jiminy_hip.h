@@ -228,7 +228,8 @@ enum {
     JM_F_APPLIED = 22,     /* [6 * K] in, optional: world-aligned (force, moment) applied at K <= 4 frames of any
                               joint (jm_batch_set_applied_frames), i.e. the current value of the impulse /
                               profile forces of core/src/engine/engine.cc:1838-2016 (the caller owns their time
-                              schedule and cuts the launches at their breakpoints); branch-parallel topologies */
+                              schedule and cuts the launches at their breakpoints); every topology (the
+                              one-robot-per-lane kernels: ABI 9) */
     JM_F_GROUND_OFFSET = 23, /* [2] in, optional: (x, y) added to the world position at which every lane samples the height map
                               of jm_batch_set_ground -- every environment its own patch of one large terrain, the batched
                               form of one `world.groundProfile` per environment instance (gym_jiminy: a new random

@@ -421,7 +421,8 @@ def build_library(model: CompiledModel, force: bool = False, verbose: bool = Fal
     common += extra_flags or []
     if qcon_split_min() != 32:
         common.append(f"-DJM_QCON_SPLIT_MIN={qcon_split_min()}")
-    parts = [1, 2, 3, 4, 5, 6, 11, 12] if quad_structure(model) is not None else [1]
+    # (15, 16: the one-robot-per-lane kernels in the form that reads applied wrenches -- topologies without branch-parallel kernels)
+    parts = [1, 2, 3, 4, 5, 6, 11, 12] if quad_structure(model) is not None else [1, 15, 16]
     if qcon_split(model):
         parts += [7, 8, 9, 10, 13, 14]
     objs = [lib + ".main.o"] + [lib + f".part{p}.o" for p in parts]

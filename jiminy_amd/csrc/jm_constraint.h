@@ -76,6 +76,10 @@ struct WithCon
     template<class T, class Tp> using WorkT = WorkC<T, Tp>;
     template<class T> using ArgsT = ConArgs<T>;
 };
+struct WithConA : WithCon
+{
+    template<class T, class Tp> using WorkT = WorkCA<T, Tp>;   // ... with applied wrenches
+};
 
 template<class Tp> struct ConRows
 {
@@ -727,8 +731,9 @@ template<class T, class Tp, int X, class W> JM_DEV void xframe_points(CPtr<T> P,
     p2 = w.oMi[j2].p + w.oMi[j2].R * ld_v3<T>(P, L::XPAR + 8 * X + 1);
 }
 
-template<class T, class Tp, class CA>
-JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
+// (WC: WorkC, or WorkCA in the instantiation that reads the applied wrenches)
+template<class T, class Tp, class CA, class WC>
+JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WC & w, const CA & C,
                              long long lane, long long B, int start_passes)
 {
     using L = Layout<Tp>;
@@ -1445,7 +1450,7 @@ JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WorkC<T, Tp> & w, cons
 #ifndef JM_HOST_EMU
 // One wave per SIMD (512 registers): capping the registers for 2-3 resident waves was measured 1.5x
 // slower (more spill traffic), see DESIGN.md section 4.8.
-template<class T, class Tp>
+template<class T, class Tp, bool VAR = false>
 __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const ConArgs<T> C)
 {
     T * const lds = lane_lds<T, Tp>();
@@ -1487,7 +1492,7 @@ __global__ void __launch_bounds__(64) k_constrained(const BatchArgs<T> A, const 
         Cl.xstride = (int)A.B;
     }
 #endif
-    lane_run<T, Tp, 64, WithCon>(A, lane, lds + threadIdx.x, Cl);
+    lane_run<T, Tp, 64, typename std::conditional<VAR, WithConA, WithCon>::type>(A, lane, lds + threadIdx.x, Cl);
 }
 #endif
 }  // namespace jm

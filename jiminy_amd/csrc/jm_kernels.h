@@ -192,13 +192,19 @@ template<class T, class Tp> struct Work
     // the lane's column of the sweeps' stash (LDS on the device, see eval_aba): element r at stash[r * LANE_STRIDE]
     T * stash;
     int status;
-    // per-environment variation: the lane's ground friction coefficient (BatchArgs::friction; < 0: the option) and the lane's
-    // column of BatchArgs::flex_lane (row r at flex[r * flex_stride]; null: the parameter block)
-    T mu;
-    const T * flex;
-    long long flex_stride;
+    // per-environment variation (ground friction, flexibility parameters, applied wrenches of the lane: BatchArgs::friction /
+    // flex_lane / applied): read where they are used, through the launch arguments (uniform: scalar registers) and the lane
+    // index (alive anyway) -- a pointer per lane kept across the evaluations costs the sweeps their registers (7-joint arm:
+    // 0.099 -> 0.119 ms per launch with five such members here)
+    const BatchArgs<T> * args;
+    long long lane;
     static constexpr bool CONSTRAINED = false;
+    // applied wrenches (BatchArgs::applied) are read by an instantiation of their own (WorkA / WorkCA): with them the external
+    // force of EVERY joint is a run-time quantity, without them the joints that carry no contact point have none and the sweeps
+    // lose those terms at compile time (7-joint arm: 0.099 against 0.121 ms per launch with the test in the only instantiation)
+    static constexpr bool APPLIED = false;
 };
+template<class T, class Tp> struct WorkA : Work<T, Tp> { static constexpr bool APPLIED = true; };
 // working set of the constraint contact model (jm_constraint.h): keeps the factorised root block
 template<class T, class Tp> struct WorkC : Work<T, Tp>
 {
@@ -206,6 +212,7 @@ template<class T, class Tp> struct WorkC : Work<T, Tp>
     T rootdinv[6];
     static constexpr bool CONSTRAINED = true;
 };
+template<class T, class Tp> struct WorkCA : WorkC<T, Tp> { static constexpr bool APPLIED = true; };
 // evaluation policy of lane_run: plain (spring-damper contacts) or constraint contact model
 template<class T> struct NoConArgs {};
 struct NoCon
@@ -213,6 +220,10 @@ struct NoCon
     static constexpr bool ON = false;
     template<class T, class Tp> using WorkT = Work<T, Tp>;
     template<class T> using ArgsT = NoConArgs<T>;
+};
+struct NoConA : NoCon
+{
+    template<class T, class Tp> using WorkT = WorkA<T, Tp>;   // ... with applied wrenches
 };
 
 template<class T, class Tp, int J> JM_DEV V3<T> joint_axis(CPtr<T> P)
@@ -538,6 +549,12 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
         }
     });
     // ---- spring-damper contact forces (engine.cc:3394-3425)
+    // (the optional per-lane inputs stay in batch order under the compact launches of the per-stage adaptive stepper)
+    const BatchArgs<T> & A_ = *w.args;
+    auto lane_g = [&]() -> long long { return A_.lane_map ? (long long)A_.lane_map[w.lane] : w.lane; };
+    T mu_lane = T(-1);
+    if constexpr (Tp::NC > 0 && !W::CONSTRAINED)
+        if (A_.friction) mu_lane = A_.friction[lane_g()];
     static_for<0, Tp::NC>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int j = Tp::contact_joint[c];
@@ -549,13 +566,36 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
             // world velocity of the contact point: oMi.R (v_lin + w x p_frame)
             const V3<T> vj = w.vel[j].l + cross(w.vel[j].a, fr.p);
             const V3<T> vW = w.oMi[j].R * vj;
-            const V3<T> fW = contact_law<T, Tp>(P, depth, vW, w.mu);
+            const V3<T> fW = contact_law<T, Tp>(P, depth, vW, mu_lane);
             fl.l = tmul(w.oMi[j].R, fW);
             fl.a = cross(fr.p, fl.l);
         }
         w.fext[j] = w.fext[j] + fl;
         w.cf[c] = actinv_force(fr, fl);
     });
+    // ---- impulse / profile forces (Engine::computeExternalForces, engine.cc:3481-3560): the world-aligned wrench applied at
+    // a frame goes to the frame's parent joint, in the joint frame (convertForceGlobalFrameToJoint, utilities/pinocchio.cc:794-809)
+    if constexpr (W::APPLIED)
+    if (A_.applied && A_.applied_k > 0)
+    {
+        const BatchArgs<T> & A = A_;
+        const long long st = A.lane_map ? A.B_full : A.B;
+        const T * const a0 = A.applied + lane_g();
+        static_for<1, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            for (int i = 0; i < A.applied_k; ++i)
+            {
+                if (A.applied_joint[i] != j) continue;
+                const T * a = a0 + (long long)(6 * i) * st;
+                const V3<T> F = {a[0], a[st], a[2 * st]}, M = {a[3 * st], a[4 * st], a[5 * st]};
+                const V3<T> p = {A.applied_p[3 * i], A.applied_p[3 * i + 1], A.applied_p[3 * i + 2]};
+                Sp<T> f;
+                f.l = tmul(w.oMi[j].R, F);
+                f.a = tmul(w.oMi[j].R, M) + cross(p, f.l);
+                w.fext[j] = w.fext[j] + f;
+            }
+        });
+    }
     // ---- motors (basic_motors.cc:83-143) and total effort
     static_for<0, Tp::NV>([&](auto ic) { w.ueff[decltype(ic)::value] = T(0); });
     static_for<0, Tp::NM>([&](auto mc) {
@@ -607,10 +647,13 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
             // stiffness 3, damping 3: the lane's own (JM_F_FLEXIBILITY) or the model's
             constexpr int of = 6 * spherical_rank<Tp>(j);
             T kd[6];
-            static_for<0, 6>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                kd[i] = w.flex ? w.flex[(long long)(of + i) * w.flex_stride] : P[o + i];
-            });
+            static_for<0, 6>([&](auto ic) { kd[decltype(ic)::value] = P[o + decltype(ic)::value]; });
+            if (A_.flex_lane)
+            {
+                const long long st = A_.lane_map ? A_.B_full : A_.B;
+                const T * const f0 = A_.flex_lane + lane_g();
+                static_for<0, 6>([&](auto ic) { kd[decltype(ic)::value] = f0[(long long)(of + decltype(ic)::value) * st]; });
+            }
             V3<T> t3 = jlog3_mul(angle, aa, V3<T>{kd[0] * aa.x, kd[1] * aa.y, kd[2] * aa.z});
             // "Flexible joint angle must be smaller than 0.95 * pi": the reference throws (engine.cc:3379-3383) -- a rejected
             // trial of the adaptive stepper, the end of a fixed-step simulation.  The efforts become NaN and so does the
@@ -1157,8 +1200,8 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
 // constraint contact model (jm_constraint.h): the free evaluation above + constraint switching +
 // the boxed forward dynamics; `start_passes` > 0 runs the Engine::start sequence, < 0 only re-applies the
 // stored multipliers (MODE_REFRESH)
-template<class T, class Tp, class CA>
-JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WorkC<T, Tp> & w, const CA & C,
+template<class T, class Tp, class CA, class WC>
+JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd, WC & w, const CA & C,
                              long long lane, long long B, int start_passes);
 
 // efforts and wrenches of the stored multipliers on top of eval_kinematics' (the output pass of the constraint model)
@@ -1198,13 +1241,8 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
 #endif
     w.status = 0;
     w.stash = sb + (long long)stage_rows<Tp>() * SBS;
-    {
-        // (compact batches of the per-stage adaptive stepper: the optional per-lane inputs stay in batch order)
-        const long long lg = A.lane_map ? (long long)A.lane_map[lane] : (long long)lane;
-        w.mu = A.friction ? A.friction[lg] : T(-1);
-        w.flex_stride = A.lane_map ? A.B_full : B;
-        w.flex = A.flex_lane ? A.flex_lane + lg : nullptr;
-    }
+    w.args = &A;
+    w.lane = lane;
     static_for<0, NM>([&](auto mc) { cmd[decltype(mc)::value] = A.command[decltype(mc)::value * B + lane]; });
 
     if (A.mode == MODE_RESET)
@@ -1362,12 +1400,13 @@ JM_DEV void lane_run(const BatchArgs<T> & A, long long lane, T * sb,
 }
 
 #ifndef JM_HOST_EMU
-template<class T, class Tp>
+// VAR: the instantiation that reads the applied wrenches (BatchArgs::applied)
+template<class T, class Tp, bool VAR = false>
 __global__ void __launch_bounds__(64) k_batch(const BatchArgs<T> A)
 {
     const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
     if (lane >= A.B) return;
-    lane_run<T, Tp, 64>(A, lane, lane_lds<T, Tp>() + threadIdx.x);
+    lane_run<T, Tp, 64, typename std::conditional<VAR, NoConA, NoCon>::type>(A, lane, lane_lds<T, Tp>() + threadIdx.x);
 }
 #endif
 }  // namespace jm

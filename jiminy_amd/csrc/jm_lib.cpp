@@ -37,7 +37,11 @@
 // the constraint-model kernel is instantiated by jm_lib_constraint.cpp (compiled in parallel)
 namespace jm
 {
-extern template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
+extern template __global__ void k_constrained<double, Topo, false>(const BatchArgs<double>, const ConArgs<double>);
+#if !JM_TOPO_QUAD
+extern template __global__ void k_batch<double, Topo, true>(const BatchArgs<double>);
+extern template __global__ void k_constrained<double, Topo, true>(const BatchArgs<double>, const ConArgs<double>);
+#endif
 #if JM_TOPO_QUAD
 extern template __global__ void k_quad_con<double, Topo, 0>(const BatchArgs<double>, const QConArgs<double>);
 extern template __global__ void k_quad_con<double, Topo, 1>(const BatchArgs<double>, const QConArgs<double>);
@@ -461,11 +465,19 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     const unsigned grid = (unsigned)((A.B + 63) / 64);
     // only the step launches are timed: the roofline leg prices one pass of the hot path, not the
     // (cheaper, single-evaluation) start / reset / dynamics launches
-    if (A.model_lane || A.ground_h || A.applied || A.friction)
     {
-        if (!(Topo::QUAD && b->variant == VARIANT_QUAD) || !std::is_same<T, double>::value)
-            return fail(JM_ENOTIMPL, "per-lane body parameters / friction, height-map ground and applied wrenches need a float64 "
-                                     "batch of a branch-parallel topology (floating base with four limbs)");
+        // body parameters per lane and height maps: the variation form of the branch-parallel kernels only; friction per lane and
+        // applied wrenches: that form (float64) or the one-robot-per-lane kernels, which read them as they are (ABI 9)
+        const bool quad = Topo::QUAD && b->variant == VARIANT_QUAD;
+        if ((A.model_lane || A.ground_h) && !(quad && std::is_same<T, double>::value))
+            return fail(JM_ENOTIMPL, "per-lane body parameters and a height-map ground need a float64 batch of a branch-parallel "
+                                     "topology (floating base with limb chains)");
+        if (A.friction && quad && !std::is_same<T, double>::value)
+            return fail(JM_ENOTIMPL, "per-lane friction on a branch-parallel topology needs a float64 batch");
+        // (applied wrenches: an instantiation of their own in either family; the one-robot-per-lane one exists for the
+        // topologies that have no branch-parallel kernels)
+        if (A.applied && !(std::is_same<T, double>::value && (quad || !Topo::QUAD)))
+            return fail(JM_ENOTIMPL, "applied wrenches need a float64 batch (and, on a branch-parallel topology, its own kernels)");
     }
     const bool timed = b->timing && A.mode == jm::MODE_STEP && b->n_timed < JM_TIMING_RING;
     if (timed) HIP_TRY(hipEventRecord(b->ev[2 * b->n_timed], s));
@@ -498,12 +510,24 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
             C.yl = nullptr; C.ystride = 0; C.yrows = 0;
             C.park = nullptr; C.park_rows = 0;
             if (Topo::QUAD && b->variant == VARIANT_QUAD && R::NR > 0) launch_quad_con<Topo>(b, A, C, s);
-            else hipLaunchKernelGGL((jm::k_constrained<T, Topo>), dim3(grid), dim3(64), 0, s, A, C);
+            else
+            {
+                bool done = false;
+                if constexpr (!Topo::QUAD)
+                    if (A.applied) { hipLaunchKernelGGL((jm::k_constrained<T, Topo, true>), dim3(grid), dim3(64), 0, s, A, C); done = true; }
+                if (!done) hipLaunchKernelGGL((jm::k_constrained<T, Topo, false>), dim3(grid), dim3(64), 0, s, A, C);
+            }
         }
         else return fail(JM_ENOTIMPL, "contacts.model = 'constraint' needs a float64 batch");
     }
     else if (b->variant == VARIANT_QUAD) launch_quad<T, Topo>(b, A, s);
-    else hipLaunchKernelGGL((jm::k_batch<T, Topo>), dim3(grid), dim3(64), 0, s, A);
+    else
+    {
+        bool done = false;
+        if constexpr (!Topo::QUAD && std::is_same<T, double>::value)
+            if (A.applied) { hipLaunchKernelGGL((jm::k_batch<T, Topo, true>), dim3(grid), dim3(64), 0, s, A); done = true; }
+        if (!done) hipLaunchKernelGGL((jm::k_batch<T, Topo, false>), dim3(grid), dim3(64), 0, s, A);
+    }
     HIP_TRY(hipGetLastError());
     if (timed)
     {

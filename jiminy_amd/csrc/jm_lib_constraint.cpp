@@ -30,7 +30,7 @@
 namespace jm
 {
 #if JM_CON_PART == 1
-template __global__ void k_constrained<double, Topo>(const BatchArgs<double>, const ConArgs<double>);
+template __global__ void k_constrained<double, Topo, false>(const BatchArgs<double>, const ConArgs<double>);
 #elif JM_CON_PART == 2 && JM_TOPO_QUAD
 template __global__ void k_quad_con<double, Topo, 0>(const BatchArgs<double>, const QConArgs<double>);
 #elif JM_CON_PART == 3 && JM_TOPO_QUAD
@@ -57,6 +57,12 @@ template __global__ void k_quad_con_gen<double, Topo, 1>(const BatchArgs<double>
 template __global__ void k_quad_con_split<double, Topo, 1, 1>(const BatchArgs<double>, const QConArgs<double>);
 #elif JM_CON_PART == 14 && JM_TOPO_QCON_SPLIT
 template __global__ void k_quad_con_split<double, Topo, 2, 1>(const BatchArgs<double>, const QConArgs<double>);
+#elif JM_CON_PART == 15 && !JM_TOPO_QUAD
+// the one-robot-per-lane kernels in the form that reads the applied wrenches (impulse / profile forces on frames, ABI 9):
+// topologies without the branch-parallel structure (those have their variation kernels, parts 3 and 4)
+template __global__ void k_batch<double, Topo, true>(const BatchArgs<double>);
+#elif JM_CON_PART == 16 && !JM_TOPO_QUAD
+template __global__ void k_constrained<double, Topo, true>(const BatchArgs<double>, const ConArgs<double>);
 #elif JM_CON_PART == 10 && JM_TOPO_QCON_SPLIT
 template __global__ void k_qtip_pgs<double, Topo>(const QConArgs<double>, const double *, unsigned);
 template __global__ void k_qcon_exact<double, Topo>(const QConArgs<double>);

@@ -967,7 +967,8 @@ class BatchedEngine:
         # (user constraints: only the branch-parallel family moves to its variation kernels for them; the lane kernel has none)
         locks = bool(self._user_constraints) and codegen.quad_structure(self.model) is not None and \
             os.environ.get("JM_KERNEL_VARIANT") != "lane"
-        if not ("model_lane" in self._fields or self._ground is not None or "applied" in self._fields or lane_mu or locks):
+        quad = codegen.quad_structure(self.model) is not None and os.environ.get("JM_KERNEL_VARIANT") != "lane"
+        if not ("model_lane" in self._fields or self._ground is not None or ("applied" in self._fields and quad) or lane_mu or locks):
             return
         self._gen_checked = True
         variant = self._lib_variant_index
@@ -1725,9 +1726,10 @@ class BatchedEngine:
         """Slot of the frame among the (at most four) frames that carry applied wrenches.  Any frame of the model: the
         wrench goes to the frame's parent joint, like `Engine::computeExternalForces` (engine.cc:3481-3560)."""
         fr = self.model.frame(frame_name)
-        if codegen.quad_structure(self.model) is None or self.dtype != torch.float64:
-            raise NotImplementedError("external forces need a float64 batch of a branch-parallel topology "
-                                      "(floating base with four limbs)")
+        if self.dtype != torch.float64 or (codegen.quad_structure(self.model) is not None and
+                                           os.environ.get("JM_KERNEL_VARIANT") == "lane"):
+            raise NotImplementedError("external forces need a float64 batch (the kernels that read them are float64 "
+                                      "instantiations of their own in either kernel family)")
         if frame_name not in self._force_frames:
             if len(self._force_frames) == 4:
                 raise NotImplementedError("at most 4 frames can carry external forces")

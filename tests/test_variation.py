@@ -99,16 +99,24 @@ def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, co
     assert rel_err(plain["a"], a_start) > 1e-3
 
 
-@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False)])
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False),
+                                              ("tree_arm_ff", False), ("tree_arm_ff", True), ("tree_arm_flex_ff", False), ("arm7", False)])
 def test_applied_forces_on_frames_of_any_joint_on_the_host(name, constrained):
     """`Engine::registerImpulseForce / registerProfileForce` accept any frame (engine.cc:1838-1935); the wrench goes to the
     frame's parent joint (computeExternalForces, engine.cc:3481-3560).  Two frames: one on the first joint after the root
     (ANYmal: a hip, Atlas: the first back joint of the trunk tree), one on the last joint (a limb tip)."""
-    model = load_builtin(name)
+    from tests import robots
+    lane_family = name not in ("anymal", "atlas")      # (round 6, ABI 9: the one-robot-per-lane kernels take the wrenches too)
+    model = {"tree_arm_ff": lambda: robots.tree_arm(True), "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True),
+             "arm7": robots.arm7}[name]() if lane_family else load_builtin(name)
+    variant = "lane" if lane_family else "quad"
     B = 8 if name == "anymal" else 4
     rg = np.random.default_rng(21)
-    st = sample_standing_states(model, B, seed=21) if constrained else sample_states(model, B, seed=21, grounded_fraction=0.5)
-    joints = np.array([2, model.njoints - 1], dtype=np.int32)
+    if lane_family:
+        st = sample_states(model, B, seed=21, base_height=(0.3, 0.6), grounded_fraction=0.6)
+    else:
+        st = sample_standing_states(model, B, seed=21) if constrained else sample_states(model, B, seed=21, grounded_fraction=0.5)
+    joints = np.array([2 if model.njoints > 2 else 1, model.njoints - 1], dtype=np.int32)
     applied = (rg.normal(0, 40.0, (12, B)), np.array([[0.05, -0.02, 0.03], [0.0, 0.01, -0.04]]), joints)
     copt = TIGHT if constrained else None
     ref, got = alloc_soa(model, B), alloc_soa(model, B)
@@ -123,14 +131,14 @@ def test_applied_forces_on_frames_of_any_joint_on_the_host(name, constrained):
         e.bind_constraints(ref["con_flags"], ref["con_data"])
     e.bind_applied(*applied)
     io = oracle_io(ref)
-    kw = dict(variant="quad", constraint_options=copt, applied=applied)
+    kw = dict(variant=variant, constraint_options=copt, applied=applied)
     e.batch_run("start", io)
     emu.run(model, got, "start", **kw)
     for k in OUTS:
         assert rel_err(got[k], ref[k]) < 1e-10, ("start", k)
     # RobotState::fExternal of the two parent joints carries the wrenches (joint frame)
     fe = ref["f_external"].reshape(model.njoints, 6, B)
-    assert np.abs(fe[2]).max() > 1.0 and np.abs(fe[model.njoints - 1]).max() > 1.0
+    assert np.abs(fe[joints[0]]).max() > 1.0 and np.abs(fe[model.njoints - 1]).max() > 1.0
     for solver in ("runge_kutta_4", "euler_explicit"):
         e.batch_run("step", io, solver=solver, dt=5e-4, n_substeps=2, command_changed=True)
         emu.run(model, got, "step", solver=solver, dt=5e-4, n_substeps=2, command_changed=True, **kw)
@@ -143,7 +151,7 @@ def test_applied_forces_on_frames_of_any_joint_on_the_host(name, constrained):
         alloc_constraint_state(model, plain, B)
     for k in ("q", "v", "command"):
         plain[k][:] = st[k]
-    emu.run(model, plain, "start", variant="quad", constraint_options=copt, applied=applied[:2])
+    emu.run(model, plain, "start", variant=variant, constraint_options=copt, applied=applied[:2])
     assert rel_err(plain["a"], ref["a"]) > 1e-3
 
 
@@ -379,17 +387,24 @@ def test_gpu_variation_matches_oracle(gpu_device, name, constrained):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False)])
+@pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False),
+                                              ("tree_arm_ff", False), ("tree_arm_ff", True), ("tree_arm_flex_ff", False)])
 def test_gpu_applied_forces_on_frames_of_any_joint(gpu_device, name, constrained):
     """`register_profile_force` on a frame of a limb and on a frame of the first joint after the root (engine.cc:1895-1935 accepts
     any frame): device against the oracle, through the engine's API."""
     import torch
 
     from jiminy_amd.engine import BatchedEngine
-    model = load_builtin(name)
+    from tests import robots
+    lane_family = name not in ("anymal", "atlas")      # (round 6, ABI 9: the one-robot-per-lane kernels take the wrenches too)
+    model = {"tree_arm_ff": lambda: robots.tree_arm(True),
+             "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True)}[name]() if lane_family else load_builtin(name)
     B, dt = (64, 5e-4) if name == "anymal" else (24, 2.5e-4)
     rg = np.random.default_rng(22)
-    st = sample_standing_states(model, B, seed=22) if constrained else sample_states(model, B, seed=22, grounded_fraction=0.5)
+    if lane_family:
+        st = sample_states(model, B, seed=22, base_height=(0.3, 0.6), grounded_fraction=0.6)
+    else:
+        st = sample_standing_states(model, B, seed=22) if constrained else sample_states(model, B, seed=22, grounded_fraction=0.5)
     frames = [next(n for n, f in model.frames.items() if f.parent_joint == j) for j in (2, model.njoints - 1)]
     joints = np.array([model.frame(n).parent_joint for n in frames], dtype=np.int32)
     offsets = np.array([model.frame(n).p for n in frames])
@@ -535,6 +550,8 @@ def test_gpu_per_lane_friction_and_flexibility_on_the_one_robot_per_lane_kernels
     stiffness / damping of the flexibility joints of every lane (`WalkerJiminyEnv._setup`, envs/locomotion.py:257-262,
     288-296), fixed-step and adaptive (whose compact launches find the rows through `BatchArgs::lane_map`), against the
     oracle's one-robot engine with the lane's own values."""
+    import torch
+
     from jiminy_amd.engine import BatchedEngine
     from tests import robots
     model = robots.tree_arm_flexible(True)
