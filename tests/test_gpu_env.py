@@ -635,3 +635,38 @@ def test_flexibility_parameters_are_drawn_per_environment_and_episode(gpu_device
     env.reset_lanes(mask)
     rows2 = env.engine.field("flexibility").cpu().numpy().reshape(len(flex), 2, 3, B)
     assert np.array_equal(rows2[..., 1::2], rows[..., 1::2]) and not np.array_equal(rows2[..., ::2], rows[..., ::2])
+
+
+@pytest.mark.gpu
+def test_disturbance_forces_on_a_robot_of_the_one_robot_per_lane_family(gpu_device):
+    """`std_ratio['disturbance']` (envs/locomotion.py:298-359: the Gaussian-process force profile and the impulses on the root
+    body) on a robot that the one-robot-per-lane kernels step (a free-flyer with flexibility joints): the applied wrench of every
+    environment reaches `f_external` of the root joint -- rotated into the joint frame (convertForceGlobalFrameToJoint) --, and
+    the robots drift apart from an undisturbed batch."""
+    from jiminy_amd.envs import WalkerVecEnv
+    from tests import robots
+    model = robots.tree_arm_flexible(True)
+    B = 32
+    opts = {"stepper": {"odeSolver": "runge_kutta_4", "dtMax": 5e-4}, "contacts": {"model": "spring_damper"}}
+    env = WalkerVecEnv(model, B, 2e-3, engine_options=opts, device=gpu_device, auto_reset=False, std_ratio={"disturbance": 0.5})
+    plain = WalkerVecEnv(model, B, 2e-3, engine_options=opts, device=gpu_device, auto_reset=False)
+    env.engine.enable_output("f_external")
+    plain.engine.enable_output("f_external")
+    env.reset(seed=5)
+    plain.reset(seed=5)
+    assert torch.equal(env.engine.field("q"), plain.engine.field("q"))
+    w = env.engine.field("applied")[:6].clone()                  # world-aligned (force, moment) on the root body
+    assert float(w[:2].abs().max()) > 1.0 and float(w[2:].abs().max()) == 0.0
+    q = env.engine.field("q")
+    x, y, z, s = q[3], q[4], q[5], q[6]                          # free-flyer quaternion (x, y, z, w): world -> joint = R^T
+    R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - s * z), 2 * (x * z + s * y)]),
+                     torch.stack([2 * (x * y + s * z), 1 - 2 * (x * x + z * z), 2 * (y * z - s * x)]),
+                     torch.stack([2 * (x * z - s * y), 2 * (y * z + s * x), 1 - 2 * (x * x + y * y)])])
+    want = torch.einsum("ijb,ib->jb", R, w[:3])
+    got = (env.engine.field("f_external") - plain.engine.field("f_external"))[6:9]      # root joint, linear part
+    assert float((got - want).abs().max()) < 1e-9 * float(want.abs().max())
+    action = torch.zeros((B, model.nmotors), dtype=torch.float64, device=gpu_device)
+    for _ in range(10):
+        env.step(action)
+        plain.step(action)
+    assert float((env.engine.field("q")[:2] - plain.engine.field("q")[:2]).abs().max()) > 1e-6
