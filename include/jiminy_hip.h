@@ -224,7 +224,8 @@ enum {
                               mass | com 3 | inertia xx xy xz yy yz zz | joint placement translation 3 -- the
                               output of Model::addBiasedToExtendedModel (core/src/robot/model.cc:1166-1236: mass,
                               centre of mass, inertia and relative body position biases), one model per
-                              environment; branch-parallel topologies, float64; unbound = the model's own */
+                              environment; float64, every topology (the one-robot-per-lane kernels: ABI 9);
+                              unbound = the model's own */
     JM_F_APPLIED = 22,     /* [6 * K] in, optional: world-aligned (force, moment) applied at K <= 4 frames of any
                               joint (jm_batch_set_applied_frames), i.e. the current value of the impulse /
                               profile forces of core/src/engine/engine.cc:1838-2016 (the caller owns their time

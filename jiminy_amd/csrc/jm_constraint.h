@@ -252,13 +252,13 @@ template<class Tp, class F> JM_DEV void for_contacts(F && f)
 
 // liMi of a 1-dof joint rebuilt from the cached joint coordinate (WorkC::jcs) and the constant placement
 // (scalar loads): the column solves are bound by the traffic of the spilled working set, not by flops
-template<class T, class Tp, int J> JM_DEV SE3<T> limi_rebuilt(CPtr<T> P, const WorkC<T, Tp> & w)
+template<class T, class Tp, int J, class WC> JM_DEV SE3<T> limi_rebuilt(CPtr<T> P, const WC & w)
 {
 #if JM_CON_REBUILD
     using L = Layout<Tp>;
     constexpr int t = Tp::jtype[J];
     if constexpr (jt_is_sph(t)) return w.liMi[J];
-    const SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
+    const SE3<T> plc = joint_placement<T, Tp, J>(P, w);
     SE3<T> Mj;
     if constexpr (jt_is_rev(t))
     {
@@ -303,8 +303,8 @@ template<class Tp> constexpr int max_depth()
 // instead of 2 x njoints x 6 -- the temporaries of these solves were what the kernel spilled most.
 // `bmask`: joints that carry a non-zero bias force / effort in the leaves-to-root sweep (bit j), `fmask`:
 // joints whose acceleration is wanted; the others are skipped.
-template<class T, class Tp, class FT, class FB, class VIS>
-JM_DEV void delta_sweeps(CPtr<T> P, const WorkC<T, Tp> & w, FT && tau, FB && fb, VIS && visit,
+template<class T, class Tp, class WC, class FT, class FB, class VIS>
+JM_DEV void delta_sweeps(CPtr<T> P, const WC & w, FT && tau, FB && fb, VIS && visit,
                          unsigned long long bmask = ~0ull, unsigned long long fmask = ~0ull)
 {
     constexpr int NJ = Tp::NJ;
@@ -1417,8 +1417,8 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
 // What an evaluation's last pass adds to the efforts / external wrenches / contact forces of the kinematic half, from
 // the flags and multipliers it stored (engine.cc:3770-3857: bounds into u, contacts into fExternal; user constraints act
 // through the accelerations only)
-template<class T, class Tp, class CA>
-JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WorkC<T, Tp> & w, const CA & C, long long lane, long long B)
+template<class T, class Tp, class CA, class WC>
+JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WC & w, const CA & C, long long lane, long long B)
 {
     using L = Layout<Tp>;
     using R = ConRows<Tp>;

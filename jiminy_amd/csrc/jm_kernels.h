@@ -199,7 +199,8 @@ template<class T, class Tp> struct Work
     const BatchArgs<T> * args;
     long long lane;
     static constexpr bool CONSTRAINED = false;
-    // applied wrenches (BatchArgs::applied) are read by an instantiation of their own (WorkA / WorkCA): with them the external
+    // applied wrenches (BatchArgs::applied) and the lane's own body parameters (BatchArgs::model_lane) are read by the VARIATION
+    // instantiations (WorkA / WorkCA, `k_batch<..., true>`, `k_constrained<..., true>`): with applied wrenches the external
     // force of EVERY joint is a run-time quantity, without them the joints that carry no contact point have none and the sweeps
     // lose those terms at compile time (7-joint arm: 0.099 against 0.121 ms per launch with the test in the only instantiation)
     static constexpr bool APPLIED = false;
@@ -293,6 +294,42 @@ JM_DEV void joint_calc(CPtr<T> P, const T * q, const T * v, SE3<T> & Mj, Sp<T> &
 #ifndef JM_LANE_REBUILD_MIN_JOINTS
 #define JM_LANE_REBUILD_MIN_JOINTS 10
 #endif
+// Body of joint J (mass, centre of mass, inertia) and placement of joint J in its parent: the model's (parameter block, scalar
+// loads) or, in the variation instantiations (W::APPLIED) with BatchArgs::model_lane bound, the lane's own -- one biased model
+// per environment (Model::addBiasedToExtendedModel, model.cc:1166-1236); rows `[13 J + k][B]`: mass | com 3 | inertia xx xy xz
+// yy yz zz | placement translation 3.
+template<class T, class Tp, int J, class W> JM_DEV RBI<T> body_rbi(CPtr<T> P, const W & w)
+{
+    using L = Layout<Tp>;
+    RBI<T> Y = ld_rbi<T>(P, L::JOINT + J * L::JSTRIDE + 12);
+    if constexpr (W::APPLIED)
+    {
+        const BatchArgs<T> & A = *w.args;
+        if (A.model_lane)
+        {
+            const long long st = A.lane_map ? A.B_full : A.B;
+            const T * const r = A.model_lane + (long long)(13 * J) * st + (A.lane_map ? (long long)A.lane_map[w.lane] : w.lane);
+            Y = {r[0], {r[st], r[2 * st], r[3 * st]}, S3<T>{r[4 * st], r[5 * st], r[6 * st], r[7 * st], r[8 * st], r[9 * st]}};
+        }
+    }
+    return Y;
+}
+template<class T, class Tp, int J, class W> JM_DEV SE3<T> joint_placement(CPtr<T> P, const W & w)
+{
+    using L = Layout<Tp>;
+    SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
+    if constexpr (W::APPLIED)
+    {
+        const BatchArgs<T> & A = *w.args;
+        if (A.model_lane)
+        {
+            const long long st = A.lane_map ? A.B_full : A.B;
+            const T * const r = A.model_lane + (long long)(13 * J + 10) * st + (A.lane_map ? (long long)A.lane_map[w.lane] : w.lane);
+            plc.p = {r[0], r[st], r[2 * st]};
+        }
+    }
+    return plc;
+}
 template<class Tp> constexpr bool lane_rebuild() { return Tp::NJ - 1 >= JM_LANE_REBUILD_MIN_JOINTS; }
 template<class T, class Tp, int J, class W> JM_DEV SE3<T> limi_of(CPtr<T> P, const W & w)
 {
@@ -301,7 +338,7 @@ template<class T, class Tp, int J, class W> JM_DEV SE3<T> limi_of(CPtr<T> P, con
     else
     {
         using L = Layout<Tp>;
-        const SE3<T> plc = ld_se3<T>(P, L::JOINT + J * L::JSTRIDE);
+        const SE3<T> plc = joint_placement<T, Tp, J>(P, w);
         SE3<T> Mj;
         // (opaque copies: common-subexpression elimination would otherwise merge the rebuilt placement with the
         // one the forward kinematics formed and keep all twelve scalars alive in between)
@@ -529,7 +566,7 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
         SE3<T> Mj;
         Sp<T> vj;
         joint_calc<T, Tp, j>(P, q, v, Mj, vj, w.jcs[j]);
-        const SE3<T> plc = ld_se3<T>(P, L::JOINT + j * L::JSTRIDE);
+        const SE3<T> plc = joint_placement<T, Tp, j>(P, w);
         w.liMi[j] = plc * Mj;
         if constexpr (p > 0)
         {
@@ -749,7 +786,7 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
         constexpr int p = Tp::parent[j];
         constexpr int t = Tp::jtype[j];
         constexpr int iv = Tp::idx_v[j];
-        const RBI<T> Yj = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+        const RBI<T> Yj = body_rbi<T, Tp, j>(P, w);
         AI<T> Ia;
         if constexpr (Tp::nchildren[j] > 0) Ia = Yacc[j];
         else Ia = ai_from_rbi(Yj);
@@ -817,7 +854,7 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
                 const AI<T> Tr = ai_transform(M, Y);
                 if constexpr (Tp::first_child[p] == j)
                 {
-                    Yacc[p] = ai_from_rbi(ld_rbi<T>(P, L::JOINT + p * L::JSTRIDE + 12)) + Tr;
+                    Yacc[p] = ai_from_rbi(body_rbi<T, Tp, p>(P, w)) + Tr;
                     facc[p] = act_force(M, pa);
                 }
                 else
@@ -858,7 +895,7 @@ JM_DEV void eval_aba(CPtr<T> P, const T * v, W & w)
                 const AI<T> Tr = ai_transform(M, Ia);
                 if constexpr (Tp::first_child[p] == j)
                 {
-                    Yacc[p] = ai_from_rbi(ld_rbi<T>(P, L::JOINT + p * L::JSTRIDE + 12)) + Tr;
+                    Yacc[p] = ai_from_rbi(body_rbi<T, Tp, p>(P, w)) + Tr;
                     facc[p] = act_force(M, pa);
                 }
                 else
@@ -994,7 +1031,7 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
         T kin = T(0), pot = T(0), rot = T(0);
         static_for<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+            const RBI<T> Y = body_rbi<T, Tp, j>(P, w);
             kin += rbi_vtiv(Y, w.vel[j]);
             const V3<T> cg = w.oMi[j].p + w.oMi[j].R * Y.c;
             pot -= Y.m * dot(cg, g);
@@ -1036,7 +1073,7 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
         static_rfor<1, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int p = Tp::parent[j];
-            const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+            const RBI<T> Y = body_rbi<T, Tp, j>(P, w);
             Sp<T> hj = rbi_mul(Y, w.vel[j]);
             const Sp<T> vxh = cross_mf(w.vel[j], hj);
             Sp<T> fBj = rbi_mul(Y, da[j]) + vxh;
@@ -1082,7 +1119,7 @@ JM_DEV void extra_terms_and_outputs(CPtr<T> P, const BatchArgs<T> & A, long long
             V3<T> mc[NJ];  // mass * com of each subtree, in the joint frame
             static_for<1, NJ>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const RBI<T> Y = ld_rbi<T>(P, L::JOINT + j * L::JSTRIDE + 12);
+                const RBI<T> Y = body_rbi<T, Tp, j>(P, w);
                 ms[j] = Y.m;
                 mc[j] = Y.m * Y.c;
             });
@@ -1205,8 +1242,8 @@ JM_DEV void eval_constrained(CPtr<T> P, const T * q, const T * v, const T * cmd,
                              long long lane, long long B, int start_passes);
 
 // efforts and wrenches of the stored multipliers on top of eval_kinematics' (the output pass of the constraint model)
-template<class T, class Tp, class CA>
-JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WorkC<T, Tp> & w, const CA & C, long long lane, long long B);
+template<class T, class Tp, class CA, class WC>
+JM_DEV void constraint_forces_from_multipliers(CPtr<T> P, WC & w, const CA & C, long long lane, long long B);
 
 template<class T, class Tp, class CON, class W>
 JM_DEV void eval_any(CPtr<T> P, const T * q, const T * v, const T * cmd, W & w,

@@ -383,9 +383,9 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     A.applied = (const T *)g_applied; A.applied_k = g_applied_k;
     for (int i = 0; i < 12; ++i) A.applied_p[i] = (T)g_applied_p[i];
     for (int i = 0; i < 4; ++i) A.applied_joint[i] = g_applied_joint[i];
-    // (the one-robot-per-lane code reads the lane's friction, flexibility and applied wrenches as they are; body parameters per
-    // lane and height maps exist in the variation form of the branch-parallel code only)
-    if ((g_model_lane || g_ground) && !(g_variant == 1 && Topo::QUAD)) return JM_ENOTIMPL;
+    // (the one-robot-per-lane code reads the lane's friction and flexibility as they are, applied wrenches and body parameters in
+    // its variation instantiation; height maps exist in the variation form of the branch-parallel code only)
+    if (g_ground && !(g_variant == 1 && Topo::QUAD)) return JM_ENOTIMPL;
     if (g_variant == 1 && Topo::QUAD)
     {
         if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
@@ -449,14 +449,14 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
         // (applied wrenches: the instantiation that reads them, like the library's launch)
         for (long long lane = 0; lane < io->B; ++lane)
         {
-            if (A.applied) jm::lane_run<T, Topo, 1, jm::WithConA>(A, lane, sb.data(), C);
+            if (A.applied || A.model_lane) jm::lane_run<T, Topo, 1, jm::WithConA>(A, lane, sb.data(), C);
             else jm::lane_run<T, Topo, 1, jm::WithCon>(A, lane, sb.data(), C);
         }
         return 0;
     }
     for (long long lane = 0; lane < io->B; ++lane)
     {
-        if (A.applied) jm::lane_run<T, Topo, 1, jm::NoConA>(A, lane, sb.data());
+        if (A.applied || A.model_lane) jm::lane_run<T, Topo, 1, jm::NoConA>(A, lane, sb.data());
         else jm::lane_run<T, Topo, 1>(A, lane, sb.data());
     }
     return 0;

@@ -78,7 +78,7 @@ def test_lane_kernel_matches_oracle(name, solver):
     assert np.array_equal(got["status"][0][ok], ref["status"][0][ok])
 
 
-@pytest.mark.parametrize("name", ["tree_arm_flex_ff", "pendulum_flexible", "tree_arm_ff", "anymal"])
+@pytest.mark.parametrize("name", ["tree_arm_flex_ff", "pendulum_flexible", "anymal"])
 def test_lane_kernel_per_environment_friction_and_flexibility(name):
     """The per-environment rows of the one-robot-per-lane kernels: ground friction of every lane under the spring-damper law
     (JM_F_FRICTION, envs/locomotion.py:257-262) and stiffness / damping of the flexibility joints of every lane

@@ -99,8 +99,63 @@ def test_branch_parallel_code_with_variation_matches_oracle_on_the_host(name, co
     assert rel_err(plain["a"], a_start) > 1e-3
 
 
+def _lane_family_model(name):
+    from tests import robots
+    return {"tree_arm_ff": lambda: robots.tree_arm(True), "tree_arm": lambda: robots.tree_arm(False),
+            "tree_arm_flex_ff": lambda: robots.tree_arm_flexible(True), "arm7": robots.arm7}[name]()
+
+
+@pytest.mark.parametrize("name,constrained", [("tree_arm_ff", False), ("tree_arm_ff", True), ("tree_arm_flex_ff", False),
+                                              ("arm7", False), ("arm7", True)])
+def test_one_robot_per_lane_code_with_variation_matches_oracle_on_the_host(name, constrained):
+    """The variation instantiation of the one-robot-per-lane kernels (round 6, ABI 9): a biased model per lane
+    (`Model::addBiasedToExtendedModel`: mass, centre of mass, inertia, relative body position) and wrenches on frames of two
+    joints, both contact models, against the oracle's one-robot engine."""
+    import torch
+    model = _lane_family_model(name)
+    B = 8
+    rg = np.random.default_rng(31)
+    st = sample_states(model, B, seed=31, base_height=(0.3, 0.6), grounded_fraction=0.6)
+    ml = sample_model_lane(model, B, {"massBodiesBiasStd": 0.1, "inertiaBodiesBiasStd": 0.1,
+                                      "centerOfMassPositionBodiesBiasStd": 0.05, "relativePositionBodiesBiasStd": 0.02},
+                           torch.Generator().manual_seed(31)).numpy()
+    joints = np.array([2, model.njoints - 1], dtype=np.int32)
+    applied = (rg.normal(0, 20.0, (12, B)), np.array([[0.05, -0.02, 0.03], [0.0, 0.01, -0.04]]), joints)
+    copt = TIGHT if constrained else None
+    for with_wrenches in (False, True):
+        ref, got = alloc_soa(model, B), alloc_soa(model, B)
+        for arr in (ref, got):
+            if constrained:
+                alloc_constraint_state(model, arr, B)
+            for k in ("q", "v", "command"):
+                arr[k][:] = st[k]
+        e = _oracle(model, ref, ml, None, applied if with_wrenches else None, copt)
+        io = oracle_io(ref)
+        kw = dict(variant="lane", constraint_options=copt, model_lane=ml, applied=applied if with_wrenches else None)
+        e.batch_run("start", io)
+        emu.run(model, got, "start", **kw)
+        for k in OUTS:
+            assert rel_err(got[k], ref[k]) < 1e-10, ("start", with_wrenches, k)
+        a_start = got["a"].copy()
+        for solver in ("runge_kutta_4", "euler_explicit"):
+            e.batch_run("step", io, solver=solver, dt=5e-4, n_substeps=2, command_changed=True)
+            emu.run(model, got, "step", solver=solver, dt=5e-4, n_substeps=2, command_changed=True, **kw)
+            ok = (ref["status"][0] & 1) == 0
+            assert ok.sum() >= B // 2
+            for k in OUTS:
+                assert rel_err(got[k], ref[k], ok) < 1e-8, (solver, with_wrenches, k)
+    # the biased models are not a no-op
+    plain = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, plain, B)
+    for k in ("q", "v", "command"):
+        plain[k][:] = st[k]
+    emu.run(model, plain, "start", variant="lane", constraint_options=copt, applied=applied)
+    assert rel_err(plain["a"], a_start) > 1e-3
+
+
 @pytest.mark.parametrize("name,constrained", [("anymal", False), ("anymal", True), ("atlas", False),
-                                              ("tree_arm_ff", False), ("tree_arm_ff", True), ("tree_arm_flex_ff", False), ("arm7", False)])
+                                              ("tree_arm_ff", False), ("tree_arm_flex_ff", False)])
 def test_applied_forces_on_frames_of_any_joint_on_the_host(name, constrained):
     """`Engine::registerImpulseForce / registerProfileForce` accept any frame (engine.cc:1838-1935); the wrench goes to the
     frame's parent joint (computeExternalForces, engine.cc:3481-3560).  Two frames: one on the first joint after the root
@@ -925,3 +980,77 @@ def test_gpu_adaptive_stepper_with_a_periodic_profile_force_matches_the_oracle(g
     for k in ("q", "v"):
         assert rel_err(eng.field(k).cpu().numpy(), ref[k], same) < 1e-7, k
         assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,constrained,solver", [("tree_arm_ff", False, "runge_kutta_4"), ("tree_arm_ff", True, "euler_explicit"),
+                                                     ("tree_arm_flex_ff", False, "runge_kutta_4"), ("arm7", False, "runge_kutta_4"),
+                                                     ("tree_arm_ff", False, "runge_kutta_dopri")])
+def test_gpu_one_robot_per_lane_kernels_with_variation(gpu_device, name, constrained, solver):
+    """A biased model per lane (`set_lane_model`, ≙ `Model::addBiasedToExtendedModel` per environment) and a profile force on a
+    frame, on robots of the one-robot-per-lane family (`k_batch<..., true>` / `k_constrained<..., true>`): device against the
+    oracle through the engine's API; the adaptive solver reads the rows through the compact launches' lane map."""
+    import torch
+
+    from jiminy_amd.engine import BatchedEngine, plan_breakpoints
+    from oracle.oracle_py import adaptive_state
+    model = _lane_family_model(name)
+    B, dt = 48, 5e-4
+    rg = np.random.default_rng(41)
+    st = sample_states(model, B, seed=41, base_height=(0.3, 0.6), grounded_fraction=0.6)
+    ml = sample_model_lane(model, B, {"massBodiesBiasStd": 0.1, "inertiaBodiesBiasStd": 0.1,
+                                      "centerOfMassPositionBodiesBiasStd": 0.05, "relativePositionBodiesBiasStd": 0.02},
+                           torch.Generator().manual_seed(41)).numpy()
+    frame = next(n for n, f in model.frames.items() if f.parent_joint == model.njoints - 1)
+    wrench = rg.normal(0, 10.0, (6, B))
+    copt = TIGHT if constrained else None
+    ref = alloc_soa(model, B)
+    if constrained:
+        alloc_constraint_state(model, ref, B)
+    for k in ("q", "v", "command"):
+        ref[k][:] = st[k]
+    e = _oracle(model, ref, ml, None, (wrench, np.array([model.frame(frame).p]), np.array([model.njoints - 1], dtype=np.int32)), copt)
+    io = oracle_io(ref)
+    eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
+                        extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
+    adaptive = solver == "runge_kutta_dopri"
+    stepper = {"odeSolver": solver, "dtMax": 0.02 if adaptive else dt, "controllerUpdatePeriod": 2e-3 if adaptive else dt,
+               "sensorsUpdatePeriod": 2e-3 if adaptive else dt}
+    if constrained:
+        stepper.update({"tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]})
+    eng.set_options({"stepper": stepper, "contacts": {"model": "constraint" if constrained else "spring_damper"}})
+    eng.set_lane_model(torch.from_numpy(ml))
+    w = torch.from_numpy(wrench.copy()).to(gpu_device)
+    eng.register_profile_force(frame, lambda t, q, v, w=w: w, update_period=1.0)
+    eng.set_command(torch.from_numpy(st["command"]))
+    eng.start(torch.from_numpy(st["q"]), torch.from_numpy(st["v"]))
+    e.batch_run("start", io)
+    for k in OUTS:
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k]) < (1e-7 if constrained else 1e-10), ("start", k)
+    if adaptive:
+        ad = adaptive_state(B)
+        o = eng.get_options()["stepper"]
+        t, t_err = 0.0, 0.0
+        for _ in range(3):
+            intervals, t_end, t_err = plan_breakpoints(t, t_err, 2e-3, eng.get_options())
+            for i, (t_next, cmd, sens) in enumerate(intervals):
+                e.batch_run_dopri(io, ad, t_next, tol_rel=o["tolRel"], tol_abs=o["tolAbs"], dt_max=o["dtMax"],
+                                  new_step=(i == 0), command_changed=False, update_sensors=sens)
+            t = t_end
+            eng.step(2e-3)
+        ss = eng.stepper_state
+        ok = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
+        assert ok.mean() > 0.8
+        ok &= (ref["status"][0] & 1) == 0
+        tol = 1e-7
+    else:
+        loop = ReferenceFixedStepLoop(dt)
+        ok = np.ones(B, dtype=bool)
+        for _ in range(3):
+            eng.step(dt)
+            loop.advance(lambda h, first: e.batch_run("step", io, solver=solver, dt=h, n_substeps=1, command_changed=first), dt, constrained)
+            ok &= ((ref["status"][0] & 1) == 0) & (np.abs(ref["v"]).max(axis=0) < 1e2)
+        tol = 1e-7 if constrained else 1e-8
+    assert ok.sum() > 0.5 * B
+    for k in ("q", "v", "a", "contact_forces", "f_external"):
+        assert rel_err(eng.field(k).cpu().numpy(), ref[k], ok) < tol, k
