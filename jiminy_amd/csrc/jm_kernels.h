@@ -596,14 +596,33 @@ JM_DEV void eval_kinematics(CPtr<T> P, const T * q, const T * v, const T * cmd, 
         constexpr int c = decltype(cc)::value;
         constexpr int j = Tp::contact_joint[c];
         const SE3<T> fr = ld_se3<T>(P, L::CONTACT + 12 * c);
-        const T depth = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, fr.p);
+        T depth = w.oMi[j].p.z + dot(V3<T>{w.oMi[j].R.m20, w.oMi[j].R.m21, w.oMi[j].R.m22}, fr.p);
+        V3<T> nG = {T(0), T(0), T(1)};
+        bool on_map = false;
+        if constexpr (W::APPLIED && !W::CONSTRAINED)
+            if (A_.ground_h)
+            {
+                // world.groundProfile at the contact point (height map of the variation instantiation, the lane's own patch of
+                // it with BatchArgs::ground_off); first-order projection (engine.cc:3138-3145)
+                const V3<T> pW = w.oMi[j].p + w.oMi[j].R * fr.p;
+                T ox = T(0), oy = T(0);
+                if (A_.ground_off)
+                {
+                    const long long st = A_.lane_map ? A_.B_full : A_.B;
+                    ox = A_.ground_off[lane_g()]; oy = A_.ground_off[st + lane_g()];
+                }
+                T hG;
+                ground_profile(A_, pW.x + ox, pW.y + oy, hG, nG);
+                depth = (pW.z - hG) * nG.z;
+                on_map = true;
+            }
         Sp<T> fl = zero6<T>();
         if (!W::CONSTRAINED && depth < T(0))
         {
             // world velocity of the contact point: oMi.R (v_lin + w x p_frame)
             const V3<T> vj = w.vel[j].l + cross(w.vel[j].a, fr.p);
             const V3<T> vW = w.oMi[j].R * vj;
-            const V3<T> fW = contact_law<T, Tp>(P, depth, vW, mu_lane);
+            const V3<T> fW = on_map ? contact_law_n<T, Tp>(P, nG, depth, vW, mu_lane) : contact_law<T, Tp>(P, depth, vW, mu_lane);
             fl.l = tmul(w.oMi[j].R, fW);
             fl.a = cross(fr.p, fl.l);
         }

@@ -469,9 +469,11 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
         // body parameters per lane and height maps: the variation form of the branch-parallel kernels only; friction per lane and
         // applied wrenches: that form (float64) or the one-robot-per-lane kernels, which read them as they are (ABI 9)
         const bool quad = Topo::QUAD && b->variant == VARIANT_QUAD;
-        if (A.ground_h && !(quad && std::is_same<T, double>::value))
-            return fail(JM_ENOTIMPL, "a height-map ground needs a float64 batch of a branch-parallel topology (floating base with "
-                                     "limb chains)");
+        // (height-map ground on the one-robot-per-lane kernels: the spring-damper law of their variation instantiation)
+        if (A.ground_h && !(std::is_same<T, double>::value &&
+                            (quad || (!Topo::QUAD && b->copt.contact_model != JM_CONTACT_CONSTRAINT))))
+            return fail(JM_ENOTIMPL, "a height-map ground needs a float64 batch; with contacts.model = 'constraint' also a "
+                                     "branch-parallel topology (floating base with limb chains)");
         if (A.model_lane && !(std::is_same<T, double>::value && (quad || !Topo::QUAD)))
             return fail(JM_ENOTIMPL, "per-lane body parameters need a float64 batch (and, on a branch-parallel topology, its own kernels)");
         if (A.friction && quad && !std::is_same<T, double>::value)
@@ -527,7 +529,7 @@ template<class T> int32_t launch(jm_batch * b, jm::BatchArgs<T> & A, void * stre
     {
         bool done = false;
         if constexpr (!Topo::QUAD && std::is_same<T, double>::value)
-            if (A.applied || A.model_lane) { hipLaunchKernelGGL((jm::k_batch<T, Topo, true>), dim3(grid), dim3(64), 0, s, A); done = true; }
+            if (A.applied || A.model_lane || A.ground_h) { hipLaunchKernelGGL((jm::k_batch<T, Topo, true>), dim3(grid), dim3(64), 0, s, A); done = true; }
         if (!done) hipLaunchKernelGGL((jm::k_batch<T, Topo, false>), dim3(grid), dim3(64), 0, s, A);
     }
     HIP_TRY(hipGetLastError());

@@ -968,7 +968,8 @@ class BatchedEngine:
         locks = bool(self._user_constraints) and codegen.quad_structure(self.model) is not None and \
             os.environ.get("JM_KERNEL_VARIANT") != "lane"
         quad = codegen.quad_structure(self.model) is not None and os.environ.get("JM_KERNEL_VARIANT") != "lane"
-        if not ((("model_lane" in self._fields or "applied" in self._fields) and quad) or self._ground is not None or lane_mu or locks):
+        # (either family: the variation kernels -- `k_quad_gen` ..., or the variation instantiations of the one-robot-per-lane kernels)
+        if not ("model_lane" in self._fields or "applied" in self._fields or self._ground is not None or lane_mu or locks):
             return
         self._gen_checked = True
         variant = self._lib_variant_index

@@ -385,7 +385,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     for (int i = 0; i < 4; ++i) A.applied_joint[i] = g_applied_joint[i];
     // (the one-robot-per-lane code reads the lane's friction and flexibility as they are, applied wrenches and body parameters in
     // its variation instantiation; height maps exist in the variation form of the branch-parallel code only)
-    if (g_ground && !(g_variant == 1 && Topo::QUAD)) return JM_ENOTIMPL;
+    if (g_ground && !(g_variant == 1 && Topo::QUAD) && g_copt.contact_model == JM_CONTACT_CONSTRAINT) return JM_ENOTIMPL;
     if (g_variant == 1 && Topo::QUAD)
     {
         if (g_copt.contact_model == JM_CONTACT_CONSTRAINT)
@@ -456,7 +456,7 @@ static int run(const jm_model_desc * d, const jm_options * o, const emu_io * io,
     }
     for (long long lane = 0; lane < io->B; ++lane)
     {
-        if (A.applied || A.model_lane) jm::lane_run<T, Topo, 1, jm::NoConA>(A, lane, sb.data());
+        if (A.applied || A.model_lane || A.ground_h) jm::lane_run<T, Topo, 1, jm::NoConA>(A, lane, sb.data());
         else jm::lane_run<T, Topo, 1>(A, lane, sb.data());
     }
     return 0;

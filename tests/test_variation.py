@@ -122,6 +122,9 @@ def test_one_robot_per_lane_code_with_variation_matches_oracle_on_the_host(name,
     joints = np.array([2, model.njoints - 1], dtype=np.int32)
     applied = (rg.normal(0, 20.0, (12, B)), np.array([[0.05, -0.02, 0.03], [0.0, 0.01, -0.04]]), joints)
     copt = TIGHT if constrained else None
+    # (spring-damper law: a bumpy height map too, every lane on its own patch of it)
+    ground = None if constrained else (0.03 * rg.standard_normal((7, 9)), -1.0, -0.8, 0.25, 0.3)
+    offsets = None if constrained else np.ascontiguousarray(rg.uniform(-0.3, 0.3, (2, B)))
     for with_wrenches in (False, True):
         ref, got = alloc_soa(model, B), alloc_soa(model, B)
         for arr in (ref, got):
@@ -129,9 +132,12 @@ def test_one_robot_per_lane_code_with_variation_matches_oracle_on_the_host(name,
                 alloc_constraint_state(model, arr, B)
             for k in ("q", "v", "command"):
                 arr[k][:] = st[k]
-        e = _oracle(model, ref, ml, None, applied if with_wrenches else None, copt)
+        e = _oracle(model, ref, ml, ground, applied if with_wrenches else None, copt)
+        if offsets is not None:
+            e.bind_ground_offset(offsets)
+            got["ground_offset"] = offsets
         io = oracle_io(ref)
-        kw = dict(variant="lane", constraint_options=copt, model_lane=ml, applied=applied if with_wrenches else None)
+        kw = dict(variant="lane", constraint_options=copt, model_lane=ml, ground=ground, applied=applied if with_wrenches else None)
         e.batch_run("start", io)
         emu.run(model, got, "start", **kw)
         for k in OUTS:
@@ -140,7 +146,8 @@ def test_one_robot_per_lane_code_with_variation_matches_oracle_on_the_host(name,
         for solver in ("runge_kutta_4", "euler_explicit"):
             e.batch_run("step", io, solver=solver, dt=5e-4, n_substeps=2, command_changed=True)
             emu.run(model, got, "step", solver=solver, dt=5e-4, n_substeps=2, command_changed=True, **kw)
-            ok = (ref["status"][0] & 1) == 0
+            # (a robot dropped deep into a bump of the map leaves at 1e12 m/s on both sides: not a comparison)
+            ok = ((ref["status"][0] & 1) == 0) & (np.abs(ref["v"]).max(axis=0) < 1e2) & (np.abs(ref["a"]).max(axis=0) < 1e6)
             assert ok.sum() >= B // 2
             for k in OUTS:
                 assert rel_err(got[k], ref[k], ok) < 1e-8, (solver, with_wrenches, k)
@@ -1009,7 +1016,12 @@ def test_gpu_one_robot_per_lane_kernels_with_variation(gpu_device, name, constra
         alloc_constraint_state(model, ref, B)
     for k in ("q", "v", "command"):
         ref[k][:] = st[k]
-    e = _oracle(model, ref, ml, None, (wrench, np.array([model.frame(frame).p]), np.array([model.njoints - 1], dtype=np.int32)), copt)
+    # (spring-damper law: a bumpy height map, every lane on its own patch of it)
+    ground = None if constrained else (0.02 * rg.standard_normal((7, 9)), -1.0, -0.8, 0.25, 0.3)
+    offsets = np.ascontiguousarray(rg.uniform(-0.3, 0.3, (2, B)))
+    e = _oracle(model, ref, ml, ground, (wrench, np.array([model.frame(frame).p]), np.array([model.njoints - 1], dtype=np.int32)), copt)
+    if ground is not None:
+        e.bind_ground_offset(offsets)
     io = oracle_io(ref)
     eng = BatchedEngine(model, B, dtype=torch.float64, device=gpu_device,
                         extra_outputs=("contact_forces", "f_external", "joint_forces", "energy", "centroidal"))
@@ -1020,6 +1032,9 @@ def test_gpu_one_robot_per_lane_kernels_with_variation(gpu_device, name, constra
         stepper.update({"tolAbs": TIGHT["tol_abs"], "tolRel": TIGHT["tol_rel"]})
     eng.set_options({"stepper": stepper, "contacts": {"model": "constraint" if constrained else "spring_damper"}})
     eng.set_lane_model(torch.from_numpy(ml))
+    if ground is not None:
+        eng.set_ground_heightmap(*ground)
+        eng.set_ground_offsets(torch.from_numpy(offsets.T.copy()))   # (B, 2)
     w = torch.from_numpy(wrench.copy()).to(gpu_device)
     eng.register_profile_force(frame, lambda t, q, v, w=w: w, update_period=1.0)
     eng.set_command(torch.from_numpy(st["command"]))
@@ -1041,7 +1056,7 @@ def test_gpu_one_robot_per_lane_kernels_with_variation(gpu_device, name, constra
         ss = eng.stepper_state
         ok = (ss.iter_lanes.cpu().numpy() == ad["iter"]) & (ss.iter_failed_lanes.cpu().numpy() == ad["iter_failed"])
         assert ok.mean() > 0.8
-        ok &= (ref["status"][0] & 1) == 0
+        ok &= ((ref["status"][0] & 1) == 0) & (np.abs(ref["v"]).max(axis=0) < 1e2)
         tol = 1e-7
     else:
         loop = ReferenceFixedStepLoop(dt)
