@@ -967,7 +967,6 @@ class BatchedEngine:
         # (user constraints: only the branch-parallel family moves to its variation kernels for them; the lane kernel has none)
         locks = bool(self._user_constraints) and codegen.quad_structure(self.model) is not None and \
             os.environ.get("JM_KERNEL_VARIANT") != "lane"
-        quad = codegen.quad_structure(self.model) is not None and os.environ.get("JM_KERNEL_VARIANT") != "lane"
         # (either family: the variation kernels -- `k_quad_gen` ..., or the variation instantiations of the one-robot-per-lane kernels)
         if not ("model_lane" in self._fields or "applied" in self._fields or self._ground is not None or lane_mu or locks):
             return
