@@ -670,3 +670,30 @@ def test_disturbance_forces_on_a_robot_of_the_one_robot_per_lane_family(gpu_devi
         env.step(action)
         plain.step(action)
     assert float((env.engine.field("q")[:2] - plain.engine.field("q")[:2]).abs().max()) > 1e-6
+
+
+@pytest.mark.gpu
+def test_model_biases_per_environment_on_a_robot_of_the_one_robot_per_lane_family(gpu_device):
+    """`model_options` (`massBodiesBiasStd` ...: `Model::addBiasedToExtendedModel` per environment and episode) through the env
+    on a robot the one-robot-per-lane kernels step: the biased models are drawn on the device, bound, and used -- heavier robots
+    fall alike but load their joints differently."""
+    from jiminy_amd.envs import WalkerVecEnv
+    from tests import robots
+    model = robots.tree_arm_flexible(True)
+    B = 32
+    opts = {"stepper": {"odeSolver": "runge_kutta_4", "dtMax": 5e-4}, "contacts": {"model": "spring_damper"}}
+    env = WalkerVecEnv(model, B, 2e-3, engine_options=opts, device=gpu_device, auto_reset=False,
+                       model_options={"dynamics": {"massBodiesBiasStd": 0.1, "inertiaBodiesBiasStd": 0.1}})
+    plain = WalkerVecEnv(model, B, 2e-3, engine_options=opts, device=gpu_device, auto_reset=False)
+    env.reset(seed=9)
+    plain.reset(seed=9)
+    ml = env.engine.field("model_lane").view(model.njoints, 13, B)
+    mass = ml[2, 0]
+    assert float(mass.std()) > 0.0 and abs(float(mass.mean()) / model.mass[2] - 1.0) < 0.1
+    assert float(ml[1, 0].std()) == 0.0                          # the free-flyer's body is never biased (model.cc:337-341)
+    action = torch.zeros((B, model.nmotors), dtype=torch.float64, device=gpu_device)
+    for _ in range(5):
+        env.step(action)
+        plain.step(action)
+    assert float((env.engine.field("v") - plain.engine.field("v")).abs().max()) > 1e-6
+    assert int((env.engine.status & 1).sum()) == int((plain.engine.status & 1).sum())
