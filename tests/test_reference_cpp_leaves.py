@@ -196,6 +196,22 @@ def test_substep_selection_rule():
         assert len(mine) == n and np.abs(mine - ref).max() <= 1e-18 + 4e-16 * iv, i
 
 
+def test_update_period_arithmetic():
+    """`isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod)` (utilities/helpers.hxx:59-116; engine.cc:749-750 the stepper
+    update period, engine.cc:2699-2733 the refusal of periods that are not multiples of each other) on the reference's compiled
+    text: the host side's `is_gcd_included`, including the pairs the reference refuses although they are multiples on paper."""
+    from jiminy_amd.engine import is_gcd_included
+    a, b = FIX["period_a"], FIX["period_b"]
+    got = [is_gcd_included(float(x), float(y)) for x, y in zip(a, b)]
+    assert np.array_equal(np.array([g[0] for g in got], dtype=np.int32), FIX["period_included"])
+    assert np.array_equal(np.array([g[1] for g in got]), FIX["period_min"])
+    inc = FIX["period_included"].astype(bool)
+    ratio = np.maximum(a, b) / np.where(np.minimum(a, b) > 0, np.minimum(a, b), 1.0)
+    on_paper = (np.minimum(a, b) > 1e-15) & (np.abs(ratio - np.round(ratio)) < 1e-9)
+    assert (on_paper & ~inc).sum() > 10 and (on_paper & inc).sum() > 50         # (0.03, 0.01) is refused, (0.005, 0.001) is not
+    assert np.isinf(FIX["period_min"]).sum() == 1 and (~on_paper & ~inc).sum() >= 2
+
+
 def test_simple_motor_law():
     L = _lib()
     L.orc_leaf_motor_law.argtypes = [C.c_int64, pd, pd, pd]

@@ -13,6 +13,7 @@ Two tiers, labelled per array group in the .npz (`tier__<group>`), in DESIGN.md 
           PCG32 (+ its seed_seq constructor), uniform, the ziggurat normal and its tables, xxHash, MurmurHash3
           (core/src/utilities/random.cc:8-318, utilities/random.h, random.hxx, fwd.h `function_ref`),
           the sub-step selection of Engine::step (engine.cc:2063-2089: stretch onto the breakpoint, snap to microseconds),
+          the update-period arithmetic minClipped / isGcdIncluded (utilities/helpers.hxx:59-116),
           the step-size controller of RungeKuttaDOPRIStepper::adjustStep (runge_kutta_dopri_stepper.cc:24-56 with
           the constants of runge_kutta_dopri_stepper.h:34-47) and the body of SimpleMotor::computeEffort
           (basic_motors.cc:89-142; the option struct around it is a plain data holder with the reference's member
@@ -114,6 +115,8 @@ def tu_tier_a() -> str:
     parts.append("void substep_body(double & dt, const double t, const double tNext, const uint32_t successiveIterTooLarge)\n{\n")
     parts.append(grab("core/src/engine/engine.cc", 2063, 2089, "double dtResidualThr = STEPPER_MIN_TIMESTEP;", "}"))
     parts.append("}\n")
+    # update-period arithmetic of Engine::setOptions / reset (helpers.hxx:59-116: minClipped, isGcdIncluded over doubles)
+    parts.append(grab(f"{CORE}/utilities/helpers.hxx", 59, 116, "inline const double & minClipped()", "}"))
     # step-size controller
     parts.append("namespace DOPRI\n{\n")
     parts.append(grab(f"{CORE}/stepper/runge_kutta_dopri_stepper.h", 34, 47, "/// \\brief Stepper order", "inline constexpr double MAX_FACTOR"))
@@ -258,6 +261,20 @@ int main(int argc, char ** argv)
             cnt[i] = k;
         }
         io::put(cnt); io::put(seq);
+    }
+    // ---- isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod) (engine.cc:749-750, 2699-2700)
+    {
+        const int64_t n = io::geti();
+        const auto a = io::get<double>(n), b = io::get<double>(n);
+        std::vector<int32_t> inc(n);
+        std::vector<double> vmin(n);
+        for (int64_t i = 0; i < n; ++i)
+        {
+            auto [isIncluded, valueMin] = isGcdIncluded(a[i], b[i]);
+            inc[i] = isIncluded ? 1 : 0;
+            vmin[i] = valueMin;
+        }
+        io::put(inc); io::put(vmin);
     }
     // ---- SimpleMotor::computeEffort
     {
@@ -551,6 +568,16 @@ def main(out_path: str = OUT) -> None:
     blob.i(len(iv))
     for arr in (iv, ivmax, ivfirst):
         blob.a(arr, np.float64)
+    # update periods: multiples that are exact in binary, multiples that are not (0.009 / 0.003: fmod leaves 0.003 - 1 ulp and
+    # the reference refuses the pair), non-multiples, zeros (continuous mode), values around EPS
+    base = np.array([1e-3, 5e-4, 2.5e-3, 3e-3, 4e-3, 1e-2, 7e-4, 1.1e-3, 1e-6, 2e-2])
+    mult = np.arange(1, 13, dtype=np.float64)
+    gp_a = np.concatenate([np.repeat(base, len(mult)) * np.tile(mult, len(base)), [0.0, 0.0, 1e-3, 5e-3, 1e-17, 1e-3, 2.5e-3, 1.5e-3]])
+    gp_b = np.concatenate([np.repeat(base, len(mult)), [0.0, 1e-3, 0.0, 2e-3, 1e-3, 1e-3 + 1e-11, 1e-3, 1e-3]])
+    swap = rg.random(len(gp_a)) < 0.5
+    gp_a, gp_b = np.where(swap, gp_b, gp_a), np.where(swap, gp_a, gp_b)
+    blob.i(len(gp_a))
+    blob.a(gp_a, np.float64); blob.a(gp_b, np.float64)
     # motors: [red, effLimOn, velLimOn, invSlope, effortLimit, velocityLimit, fricOn, fvp, fvn, fdp, fdn, fds, v, command]
     # MOTOR_GROUP rows share one parameter set (a motor's options are model constants: the device test builds one
     # model per group); group 0 = ANYmal's shipped motor (anymal_hardware.toml:7-11, URDF effort 80 / velocity 7.5)
@@ -597,9 +624,10 @@ def main(out_path: str = OUT) -> None:
     out.update(substep_dt=sr_dt, substep_t=sr_t, substep_tnext=sr_tn, substep_too_large=sr_tl, substep_dt_out=rd.take(np.float64, nsr))
     out.update(interval=iv, interval_dt_max=ivmax, interval_dt_first=ivfirst, interval_count=rd.take(np.int32, len(iv)),
                interval_sizes=rd.take(np.float64, len(iv), 64))
+    out.update(period_a=gp_a, period_b=gp_b, period_included=rd.take(np.int32, len(gp_a)), period_min=rd.take(np.float64, len(gp_a)))
     out.update(motor_group=np.array(MOTOR_GROUP), motor_params=mp, motor_u=rd.take(np.float64, nm), motor_u_transmission=rd.take(np.float64, nm))
     rd.done()
-    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval"):
+    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period"):
         out[f"tier__{group}"] = np.array("A")
 
     # ============================================================ tier B
