@@ -196,6 +196,32 @@ def test_substep_selection_rule():
         assert len(mine) == n and np.abs(mine - ref).max() <= 1e-18 + 4e-16 * iv, i
 
 
+def test_breakpoints_of_consecutive_steps():
+    """The end time of `Engine::step` with its Kahan compensation (engine.cc:1793-1795) and the time to the next breakpoint of
+    the discrete branch (engine.cc:1991-2018: update period, impulse breakpoints, end of the step; a remainder below a
+    microsecond skips one update) on the reference's compiled lines, driven over up to 64 consecutive steps: the host planner
+    `engine._breakpoint_intervals` gives the same end times, compensation terms and breakpoints, bit for bit."""
+    from jiminy_amd.engine import _breakpoint_intervals
+    n_bp = 0
+    for i in range(len(FIX["bp_period"])):
+        per, step, ns = float(FIX["bp_period"][i]), float(FIX["bp_step"][i]), int(FIX["bp_nsteps"][i])
+        imp = tuple(float(x) for x in FIX["bp_impulse"][i] if np.isfinite(x))
+        opts = {"stepper": {"dtMax": 1e-3, "controllerUpdatePeriod": per, "sensorsUpdatePeriod": per}}
+        t, t_err = 0.0, 0.0
+        times, t_ends, t_errs = [], [], []
+        for _ in range(ns):
+            intervals, t_end, t_err = _breakpoint_intervals(t, t_err, step, opts, imp)
+            times += [iv[0] for iv in intervals]
+            t_ends.append(t_end)
+            t_errs.append(t_err)
+            t = intervals[-1][0] if intervals else t_end
+        n = int(FIX["bp_count"][i])
+        assert n < 512 and len(times) == n and np.array_equal(np.array(times), FIX["bp_times"][i, :n]), i
+        assert np.array_equal(np.array(t_ends), FIX["bp_t_end"][i, :ns]) and np.array_equal(np.array(t_errs), FIX["bp_t_error"][i, :ns]), i
+        n_bp += n
+    assert n_bp > 1500 and np.abs(FIX["bp_t_error"]).max() > 0.0      # (the compensation term is exercised)
+
+
 def test_update_period_arithmetic():
     """`isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod)` (utilities/helpers.hxx:59-116; engine.cc:749-750 the stepper
     update period, engine.cc:2699-2733 the refusal of periods that are not multiples of each other) on the reference's compiled

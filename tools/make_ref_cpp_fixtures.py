@@ -14,6 +14,8 @@ Two tiers, labelled per array group in the .npz (`tier__<group>`), in DESIGN.md 
           (core/src/utilities/random.cc:8-318, utilities/random.h, random.hxx, fwd.h `function_ref`),
           the sub-step selection of Engine::step (engine.cc:2063-2089: stretch onto the breakpoint, snap to microseconds),
           the update-period arithmetic minClipped / isGcdIncluded (utilities/helpers.hxx:59-116),
+          the end time of Engine::step with its Kahan compensation and the time to the next breakpoint (engine.cc:1793-1795,
+          1991-2018),
           the step-size controller of RungeKuttaDOPRIStepper::adjustStep (runge_kutta_dopri_stepper.cc:24-56 with
           the constants of runge_kutta_dopri_stepper.h:34-47) and the body of SimpleMotor::computeEffort
           (basic_motors.cc:89-142; the option struct around it is a plain data holder with the reference's member
@@ -114,6 +116,17 @@ def tu_tier_a() -> str:
     parts.append(grab(f"{CORE}/constants.h", 18, 20, "inline constexpr double STEPPER_MIN_TIMESTEP", "inline constexpr double SIMULATION_MAX_TIMESTEP"))
     parts.append("void substep_body(double & dt, const double t, const double tNext, const uint32_t successiveIterTooLarge)\n{\n")
     parts.append(grab("core/src/engine/engine.cc", 2063, 2089, "double dtResidualThr = STEPPER_MIN_TIMESTEP;", "}"))
+    parts.append("}\n")
+    # breakpoints of Engine::step: the end time with its Kahan compensation (engine.cc:1793-1795) and the time to the next
+    # breakpoint of the discrete branch (engine.cc:1991-2018)
+    parts.append("struct StepperStateTimes { double t; double tError; };\n"
+                 "double end_time_body(StepperStateTimes & stepperState_, const double stepSize)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 1793, 1795, "const double stepSizeCorrected = stepSize - stepperState_.tError;",
+                      "stepperState_.tError = (tEnd - stepperState_.t) - stepSizeCorrected;"))
+    parts.append("return tEnd;\n}\n"
+                 "void next_breakpoint_body(const double stepperUpdatePeriod_, const double t, const double tImpulseForceNext, "
+                 "const double tEnd, double & tNext)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 1991, 2018, "double dtNextGlobal;  // dt to apply for the next stepper step", "tNext += dtNextGlobal;"))
     parts.append("}\n")
     # update-period arithmetic of Engine::setOptions / reset (helpers.hxx:59-116: minClipped, isGcdIncluded over doubles)
     parts.append(grab(f"{CORE}/utilities/helpers.hxx", 59, 116, "inline const double & minClipped()", "}"))
@@ -261,6 +274,39 @@ int main(int argc, char ** argv)
             cnt[i] = k;
         }
         io::put(cnt); io::put(seq);
+    }
+    // ---- breakpoints of consecutive Engine::step calls.  The loop around the two reference bodies is this driver's: the next
+    //      impulse breakpoint is the first one at least STEPPER_MIN_TIMESTEP ahead (engine.cc:1872-1889), the integration is
+    //      taken to land on tNext exactly (t = tNext), the outer loop runs while tEnd - t >= STEPPER_MIN_TIMESTEP (:1838)
+    {
+        const int64_t n = io::geti();
+        const auto period = io::get<double>(n), step = io::get<double>(n);
+        const auto nsteps = io::get<int32_t>(n);
+        const auto imp = io::get<double>(n * 4);     // up to four impulse breakpoints per case (INF: none)
+        std::vector<double> tend(n * 64, 0.0), terr(n * 64, 0.0), bps(n * 512, 0.0);
+        std::vector<int32_t> nbp(n, 0);
+        for (int64_t i = 0; i < n; ++i)
+        {
+            StepperStateTimes st{0.0, 0.0};
+            double tNext = 0.0;
+            int32_t k = 0;
+            for (int32_t s = 0; s < nsteps[i] && s < 64; ++s)
+            {
+                const double tEnd = end_time_body(st, step[i]);
+                tend[i * 64 + s] = tEnd; terr[i * 64 + s] = st.tError;
+                while (tEnd - st.t >= STEPPER_MIN_TIMESTEP && k < 512)
+                {
+                    double tImpulseForceNext = INF;
+                    for (int j = 0; j < 4; ++j)
+                        if (!(imp[i * 4 + j] - st.t < STEPPER_MIN_TIMESTEP)) tImpulseForceNext = std::min(tImpulseForceNext, imp[i * 4 + j]);
+                    next_breakpoint_body(period[i], st.t, tImpulseForceNext, tEnd, tNext);
+                    st.t = tNext;
+                    bps[i * 512 + k++] = tNext;
+                }
+            }
+            nbp[i] = k;
+        }
+        io::put(tend); io::put(terr); io::put(nbp); io::put(bps);
     }
     // ---- isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod) (engine.cc:749-750, 2699-2700)
     {
@@ -568,6 +614,17 @@ def main(out_path: str = OUT) -> None:
     blob.i(len(iv))
     for arr in (iv, ivmax, ivfirst):
         blob.a(arr, np.float64)
+    # breakpoints: (update period, step size, number of consecutive steps, impulse breakpoints)
+    bk = [(1e-3, 1e-3, 60, ()), (1e-3, 5e-3, 40, ()), (5e-3, 1e-3, 60, ()), (1e-3, 1e-3, 40, (2.5e-3, 7.2e-3)), (2e-3, 0.04, 10, (0.013, 0.0131)),
+          (1e-3, 2.5e-3, 40, ()), (1 / 3e3, 1e-3, 60, ()), (1e-3, 1 / 3e2, 30, ()), (7e-4, 2e-3, 50, (3e-3 + 5e-11,)), (1e-2, 1e-2, 64, ()),
+          (1e-3, 1.0000005e-3, 64, ()), (5e-3, 0.04, 12, (0.02, 0.06, 0.1, 0.1000000001)), (4e-3, 0.02, 25, ()), (1e-3, 3.7e-3, 40, (1.85e-3,))]
+    blob.i(len(bk))
+    blob.a(np.array([b[0] for b in bk]), np.float64); blob.a(np.array([b[1] for b in bk]), np.float64)
+    blob.a(np.array([b[2] for b in bk]), np.int32)
+    bk_imp = np.full((len(bk), 4), np.inf)
+    for i, b in enumerate(bk):
+        bk_imp[i, :len(b[3])] = b[3]
+    blob.a(bk_imp, np.float64)
     # update periods: multiples that are exact in binary, multiples that are not (0.009 / 0.003: fmod leaves 0.003 - 1 ulp and
     # the reference refuses the pair), non-multiples, zeros (continuous mode), values around EPS
     base = np.array([1e-3, 5e-4, 2.5e-3, 3e-3, 4e-3, 1e-2, 7e-4, 1.1e-3, 1e-6, 2e-2])
@@ -624,10 +681,13 @@ def main(out_path: str = OUT) -> None:
     out.update(substep_dt=sr_dt, substep_t=sr_t, substep_tnext=sr_tn, substep_too_large=sr_tl, substep_dt_out=rd.take(np.float64, nsr))
     out.update(interval=iv, interval_dt_max=ivmax, interval_dt_first=ivfirst, interval_count=rd.take(np.int32, len(iv)),
                interval_sizes=rd.take(np.float64, len(iv), 64))
+    out.update(bp_period=np.array([b[0] for b in bk]), bp_step=np.array([b[1] for b in bk]), bp_nsteps=np.array([b[2] for b in bk], dtype=np.int32),
+               bp_impulse=bk_imp, bp_t_end=rd.take(np.float64, len(bk), 64), bp_t_error=rd.take(np.float64, len(bk), 64),
+               bp_count=rd.take(np.int32, len(bk)), bp_times=rd.take(np.float64, len(bk), 512))
     out.update(period_a=gp_a, period_b=gp_b, period_included=rd.take(np.int32, len(gp_a)), period_min=rd.take(np.float64, len(gp_a)))
     out.update(motor_group=np.array(MOTOR_GROUP), motor_params=mp, motor_u=rd.take(np.float64, nm), motor_u_transmission=rd.take(np.float64, nm))
     rd.done()
-    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period"):
+    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period", "bp"):
         out[f"tier__{group}"] = np.array("A")
 
     # ============================================================ tier B
