@@ -83,10 +83,7 @@ def _breakpoint_intervals(t: float, t_error: float, step_size: float, options: D
     update_period = min(periods) if periods else math.inf
 
     def hit(period: float, time: float) -> bool:
-        if period < EPS:
-            return True
-        nxt = period - math.fmod(time, period)
-        return nxt < SIMULATION_MIN_TIMESTEP or period - nxt < STEPPER_MIN_TIMESTEP
+        return period < EPS or update_due(period, time)
 
     intervals: List[Tuple[float, float, bool, bool]] = []
     while t_end - t >= STEPPER_MIN_TIMESTEP:
@@ -115,6 +112,26 @@ def plan_breakpoints(t: float, t_error: float, step_size: float, options: Dict[s
     step sizes inside an interval are chosen per lane on the device (engine.cc:2021-2222)."""
     intervals, t_end, t_err = _breakpoint_intervals(t, t_error, step_size, options, extra_breakpoints)
     return [(tn, c, s) for tn, _, c, s in intervals], t_end, t_err
+
+
+def update_due(period: float, t: float) -> bool:
+    """Is a periodic update (controller command engine.cc:1923-1927, profile force :1903-1907, sensors :2386-2410) due at time
+    `t`: the time to the next multiple of the period is below a microsecond (the update is taken early and the multiple
+    skipped) or the last multiple is less than STEPPER_MIN_TIMESTEP behind.  Pinned to the reference's compiled lines
+    (`tests/golden/ref_cpp_leaves.npz`, `update_*`)."""
+    dt_next = period - math.fmod(t, period)
+    return dt_next < SIMULATION_MIN_TIMESTEP or period - dt_next < STEPPER_MIN_TIMESTEP
+
+
+def impulse_active(t_impulse: float, dt_impulse: float, t: float, was_active: bool = False) -> bool:
+    """≙ the active-set update of an impulse force (engine.cc:1857-1869): switched on once `t > t_impulse - 1e-10`, off once
+    `t >= t_impulse + dt_impulse - 1e-10` (both tests run, in that order, at every breakpoint)."""
+    active = was_active
+    if t > t_impulse - STEPPER_MIN_TIMESTEP:
+        active = True
+    if t >= t_impulse + dt_impulse - STEPPER_MIN_TIMESTEP:
+        active = False
+    return active
 
 
 def min_clipped(*values: float) -> float:
@@ -1844,14 +1861,14 @@ class BatchedEngine:
         active = []
         changed = False
         for i, f in enumerate(self._impulse_forces):
-            if f["t"] - STEPPER_MIN_TIMESTEP <= t < f["t"] + f["dt"] - STEPPER_MIN_TIMESTEP:
+            if impulse_active(f["t"], f["dt"], t, i in self._impulse_active):
                 a[6 * f["frame"]:6 * f["frame"] + 6] += f["force"]
                 active.append(i)
         if active != self._impulse_active:
             self._impulse_active = active
             changed = True
         for p in self._profile_forces:
-            if p["value"] is None or p["period"] <= EPS or t - p["t_last"] >= p["period"] - STEPPER_MIN_TIMESTEP:
+            if p["value"] is None or p["period"] <= EPS or update_due(p["period"], t):
                 w = torch.as_tensor(p["func"](t, self._fields["q"], self._fields["v"]), dtype=self.dtype, device=self.device)
                 p["value"] = w[:, None].expand(6, self.batch_size) if w.dim() == 1 else w
                 p["t_last"] = t if p["period"] <= EPS else math.floor(t / p["period"] + 1e-9) * p["period"]

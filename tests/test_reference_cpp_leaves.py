@@ -222,6 +222,28 @@ def test_breakpoints_of_consecutive_steps():
     assert n_bp > 1500 and np.abs(FIX["bp_t_error"]).max() > 0.0      # (the compensation term is exercised)
 
 
+def test_periodic_update_and_impulse_activity_rules():
+    """When the controller command / a profile force is refreshed (engine.cc:1923-1927, 1903-1907: the same expression) and when
+    an impulse force is active (engine.cc:1857-1869) on the reference's compiled lines: `engine.update_due` and
+    `engine.impulse_active`, the two predicates the host side plans its launches with."""
+    from jiminy_amd.engine import impulse_active, update_due
+    per, t = FIX["update_period"], FIX["update_t"]
+    got = np.array([update_due(float(p), float(x)) for p, x in zip(per, t)], dtype=np.int32)
+    assert np.array_equal(got, FIX["update_force"]) and np.array_equal(got, FIX["update_controller"])
+    assert 0.2 < got.mean() < 0.9
+    ts = FIX["impulse_times"]
+    for i, (ti, dti) in enumerate(zip(FIX["impulse_t"], FIX["impulse_dt"])):
+        active = False
+        for k, x in enumerate(ts):
+            before = active
+            active = impulse_active(float(ti), float(dti), float(x), active)
+            assert int(active) == FIX["impulse_active"][i, k], (i, k)
+            # (`hasDynamicsChanged` is raised whenever one of the two tests fires, also when the flag keeps its value)
+            fired = (x > ti - 1e-10) or (x >= ti + dti - 1e-10)
+            assert int(fired) == FIX["impulse_changed"][i, k], (i, k, before)
+    assert FIX["impulse_active"].sum() > 10 and (FIX["impulse_active"].sum(axis=1) == 0).any()   # (a 1e-10 s impulse never acts)
+
+
 def test_update_period_arithmetic():
     """`isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod)` (utilities/helpers.hxx:59-116; engine.cc:749-750 the stepper
     update period, engine.cc:2699-2733 the refusal of periods that are not multiples of each other) on the reference's compiled

@@ -15,7 +15,8 @@ Two tiers, labelled per array group in the .npz (`tier__<group>`), in DESIGN.md 
           the sub-step selection of Engine::step (engine.cc:2063-2089: stretch onto the breakpoint, snap to microseconds),
           the update-period arithmetic minClipped / isGcdIncluded (utilities/helpers.hxx:59-116),
           the end time of Engine::step with its Kahan compensation and the time to the next breakpoint (engine.cc:1793-1795,
-          1991-2018),
+          1991-2018), the refresh rule of profile forces / the controller and the activity of impulse forces (engine.cc:1857-1869,
+          1903-1907, 1923-1927),
           the step-size controller of RungeKuttaDOPRIStepper::adjustStep (runge_kutta_dopri_stepper.cc:24-56 with
           the constants of runge_kutta_dopri_stepper.h:34-47) and the body of SimpleMotor::computeEffort
           (basic_motors.cc:89-142; the option struct around it is a plain data holder with the reference's member
@@ -127,6 +128,22 @@ def tu_tier_a() -> str:
                  "void next_breakpoint_body(const double stepperUpdatePeriod_, const double t, const double tImpulseForceNext, "
                  "const double tEnd, double & tNext)\n{\n")
     parts.append(grab("core/src/engine/engine.cc", 1991, 2018, "double dtNextGlobal;  // dt to apply for the next stepper step", "tNext += dtNextGlobal;"))
+    parts.append("}\n")
+    # when a profile force / the controller is refreshed (engine.cc:1903-1907, 1923-1927) and when an impulse force is active
+    # (engine.cc:1857-1869); the structs are data holders with the member names those lines read
+    parts.append("struct ProfileForceHolder { double updatePeriod; };\n"
+                 "bool force_update_body(const ProfileForceHolder & profileForce, const double t)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 1903, 1907, "double forceUpdatePeriod = profileForce.updatePeriod;",
+                      "forceUpdatePeriod - dtNextForceUpdatePeriod < STEPPER_MIN_TIMESTEP)"))
+    parts.append("{ return true; }\nreturn false;\n}\n"
+                 "struct StepperOptionsHolder { double controllerUpdatePeriod; };\nstruct EngineOptionsHolder { StepperOptionsHolder stepper; };\n"
+                 "bool controller_update_body(const EngineOptionsHolder * engineOptions_, const double t)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 1923, 1927, "double controllerUpdatePeriod = engineOptions_->stepper.controllerUpdatePeriod;",
+                      "controllerUpdatePeriod - dtNextControllerUpdatePeriod < STEPPER_MIN_TIMESTEP)"))
+    parts.append("{ return true; }\nreturn false;\n}\n"
+                 "struct ImpulseForceHolder { double t; double dt; };\n"
+                 "void impulse_active_body(const ImpulseForceHolder * impulseForceIt, bool * isImpulseForceActiveIt, bool & hasDynamicsChanged, const double t)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 1857, 1869, "double tImpulseForce = impulseForceIt->t;", "}"))
     parts.append("}\n")
     # update-period arithmetic of Engine::setOptions / reset (helpers.hxx:59-116: minClipped, isGcdIncluded over doubles)
     parts.append(grab(f"{CORE}/utilities/helpers.hxx", 59, 116, "inline const double & minClipped()", "}"))
@@ -307,6 +324,35 @@ int main(int argc, char ** argv)
             nbp[i] = k;
         }
         io::put(tend); io::put(terr); io::put(nbp); io::put(bps);
+    }
+    // ---- refresh of profile forces / the controller at time t, activity of an impulse force carried over a time sequence
+    {
+        const int64_t n = io::geti();
+        const auto period = io::get<double>(n), t = io::get<double>(n);
+        std::vector<int32_t> fu(n), cu(n);
+        for (int64_t i = 0; i < n; ++i)
+        {
+            fu[i] = force_update_body(ProfileForceHolder{period[i]}, t[i]) ? 1 : 0;
+            const EngineOptionsHolder eo{{period[i]}};
+            cu[i] = controller_update_body(&eo, t[i]) ? 1 : 0;
+        }
+        io::put(fu); io::put(cu);
+        const int64_t m = io::geti(), nt = io::geti();
+        const auto it = io::get<double>(m), idt = io::get<double>(m);
+        const auto ts = io::get<double>(nt);
+        std::vector<int32_t> act(m * nt), chg(m * nt);
+        for (int64_t i = 0; i < m; ++i)
+        {
+            bool active = false;
+            const ImpulseForceHolder f{it[i], idt[i]};
+            for (int64_t k = 0; k < nt; ++k)
+            {
+                bool changed = false;
+                impulse_active_body(&f, &active, changed, ts[k]);
+                act[i * nt + k] = active ? 1 : 0; chg[i * nt + k] = changed ? 1 : 0;
+            }
+        }
+        io::put(act); io::put(chg);
     }
     // ---- isGcdIncluded(sensorsUpdatePeriod, controllerUpdatePeriod) (engine.cc:749-750, 2699-2700)
     {
@@ -625,6 +671,21 @@ def main(out_path: str = OUT) -> None:
     for i, b in enumerate(bk):
         bk_imp[i, :len(b[3])] = b[3]
     blob.a(bk_imp, np.float64)
+    # refresh rule: times on, just before, just after and between multiples of the period
+    up_p = np.repeat(np.array([1e-3, 5e-3, 1e-2, 1 / 3e2, 7e-4, 2.5e-3]), 60)
+    kk = np.tile(np.repeat(np.arange(1, 13), 5), 6).astype(np.float64)
+    off = np.tile(np.array([0.0, -5e-7, -2e-6, 5e-11, 3e-4]), 72)
+    up_t = kk * up_p + np.minimum(off, 0.4 * up_p)
+    up_t[::7] = (kk * up_p)[::7]
+    blob.i(len(up_p))
+    blob.a(up_p, np.float64); blob.a(up_t, np.float64)
+    imp_t = np.array([0.0, 2.0, 2.0, 1.9, 1e-3, 0.5])
+    imp_dt = np.array([1e-2, 1e-2, 1e-10, 0.2, 1e-3, 5e-11])
+    imp_ts = np.concatenate([np.arange(0, 40) * 1e-3, 2.0 + np.array([-1e-3, -1e-10, -5e-11, 0.0, 5e-11, 5e-3, 1e-2 - 1e-10, 1e-2 - 5e-11, 1e-2, 2e-2]),
+                             [0.5 - 5e-11, 0.5, 0.5 + 1e-10, 1.9, 2.1 - 1e-10, 2.1, 3.0]])
+    imp_ts = np.sort(imp_ts)
+    blob.i(len(imp_t)); blob.i(len(imp_ts))
+    blob.a(imp_t, np.float64); blob.a(imp_dt, np.float64); blob.a(imp_ts, np.float64)
     # update periods: multiples that are exact in binary, multiples that are not (0.009 / 0.003: fmod leaves 0.003 - 1 ulp and
     # the reference refuses the pair), non-multiples, zeros (continuous mode), values around EPS
     base = np.array([1e-3, 5e-4, 2.5e-3, 3e-3, 4e-3, 1e-2, 7e-4, 1.1e-3, 1e-6, 2e-2])
@@ -684,10 +745,13 @@ def main(out_path: str = OUT) -> None:
     out.update(bp_period=np.array([b[0] for b in bk]), bp_step=np.array([b[1] for b in bk]), bp_nsteps=np.array([b[2] for b in bk], dtype=np.int32),
                bp_impulse=bk_imp, bp_t_end=rd.take(np.float64, len(bk), 64), bp_t_error=rd.take(np.float64, len(bk), 64),
                bp_count=rd.take(np.int32, len(bk)), bp_times=rd.take(np.float64, len(bk), 512))
+    out.update(update_period=up_p, update_t=up_t, update_force=rd.take(np.int32, len(up_p)), update_controller=rd.take(np.int32, len(up_p)))
+    out.update(impulse_t=imp_t, impulse_dt=imp_dt, impulse_times=imp_ts, impulse_active=rd.take(np.int32, len(imp_t), len(imp_ts)),
+               impulse_changed=rd.take(np.int32, len(imp_t), len(imp_ts)))
     out.update(period_a=gp_a, period_b=gp_b, period_included=rd.take(np.int32, len(gp_a)), period_min=rd.take(np.float64, len(gp_a)))
     out.update(motor_group=np.array(MOTOR_GROUP), motor_params=mp, motor_u=rd.take(np.float64, nm), motor_u_transmission=rd.take(np.float64, nm))
     rd.done()
-    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period", "bp"):
+    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period", "bp", "update", "impulse"):
         out[f"tier__{group}"] = np.array("A")
 
     # ============================================================ tier B
