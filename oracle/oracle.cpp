@@ -2322,6 +2322,34 @@ void substep_rule(double & dt, double t, double tNext, uint32_t successiveIterTo
     }
 }
 
+// Bookkeeping of Engine::step's inner loop after a try (engine.cc:2138-2221): counters, the restoration of the step size after a
+// breakpoint cut it (only if the new estimate is above the size just taken and well below the estimate before the
+// breakpoint), the recovery from an evaluation error, the size of the next try.  `rc`: 0 success, 1 rejected, 2 error.
+// Pinned to the reference's compiled lines by tests/golden/ref_cpp_leaves.npz (after_try_*).
+void after_try(int rc, bool isBreakpointReached, double & dt, double & dtLargest, AdaptiveState & S, const AdaptiveOptions & ao)
+{
+    if (rc == 0)
+    {
+        S.successiveIterTooLarge = 0;
+        S.successiveIterFailed = 0;
+        ++S.iter;
+        if (isBreakpointReached)
+        {
+            const double thr = S.dtLargestPrev * ao.dtRestoreThresholdRel;
+            if (dt < dtLargest && dtLargest < thr) dtLargest = S.dtLargestPrev;
+        }
+        S.dtLargestPrev = dtLargest;
+    }
+    else
+    {
+        if (rc == 2) dtLargest *= 0.1;
+        if (rc == 1) ++S.successiveIterTooLarge;
+        ++S.successiveIterFailed;
+        ++S.iterFailed;
+    }
+    dt = std::min(dtLargest, ao.dtMax);
+}
+
 // One breakpoint interval [t, tNext] of Engine::step with the adaptive stepper (engine.cc:2021-2222).
 void step_dopri(Engine & e, AdaptiveState & S, const AdaptiveOptions & ao, double tNext, int command_changed,
                 int update_sensors)
@@ -2345,25 +2373,10 @@ void step_dopri(Engine & e, AdaptiveState & S, const AdaptiveOptions & ao, doubl
         const int rc = dopri_try_step(e, ao, t, dtLargest);
         if (rc == 0)
         {
-            S.successiveIterTooLarge = 0;
-            S.successiveIterFailed = 0;
             extra_terms(e);
-            ++S.iter; ++e.iter;
-            if (isBreakpointReached)
-            {
-                const double thr = S.dtLargestPrev * ao.dtRestoreThresholdRel;
-                if (dt < dtLargest && dtLargest < thr) dtLargest = S.dtLargestPrev;
-            }
-            S.dtLargestPrev = dtLargest;
+            ++e.iter;
         }
-        else
-        {
-            if (rc == 2) dtLargest *= 0.1;
-            if (rc == 1) ++S.successiveIterTooLarge;
-            ++S.successiveIterFailed;
-            ++S.iterFailed;
-        }
-        dt = std::min(dtLargest, ao.dtMax);
+        after_try(rc, isBreakpointReached, dt, dtLargest, S, ao);
     }
     if (update_sensors) sensors(e);
 }
@@ -2813,6 +2826,24 @@ void orc_leaf_motor_law(int64_t n, const double * params, double * u_motor, doub
         mp.inv_slope = c[3]; mp.effort_limit = c[4]; mp.velocity_limit = c[5];
         mp.fvp = c[7]; mp.fvn = c[8]; mp.fdp = c[9]; mp.fdn = c[10]; mp.fds = c[11];
         motor_law(mp, c[12], c[13], u_motor[i], u_transmission[i]);
+    }
+}
+// in/out per case: dt, dtLargest, dtLargestPrev; counters [tooLarge, failed, iter, iterFailed]
+void orc_leaf_after_try(int64_t n, const int32_t * rc, const int32_t * bp, double dtRestoreThresholdRel, double dtMax,
+                        double * dt, double * dtLargest, double * dtLargestPrev, int64_t * counters)
+{
+    AdaptiveOptions ao{};
+    ao.dtRestoreThresholdRel = dtRestoreThresholdRel; ao.dtMax = dtMax;
+    for (int64_t i = 0; i < n; ++i)
+    {
+        AdaptiveState S{};
+        S.dtLargestPrev = dtLargestPrev[i];
+        S.successiveIterTooLarge = (int)counters[4 * i]; S.successiveIterFailed = (int)counters[4 * i + 1];
+        S.iter = counters[4 * i + 2]; S.iterFailed = counters[4 * i + 3];
+        after_try(rc[i], bp[i] != 0, dt[i], dtLargest[i], S, ao);
+        dtLargestPrev[i] = S.dtLargestPrev;
+        counters[4 * i] = S.successiveIterTooLarge; counters[4 * i + 1] = S.successiveIterFailed;
+        counters[4 * i + 2] = S.iter; counters[4 * i + 3] = S.iterFailed;
     }
 }
 void orc_leaf_substep(int64_t n, const double * dt, const double * t, const double * tNext, const int32_t * tooLarge,

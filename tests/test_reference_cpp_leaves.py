@@ -222,6 +222,27 @@ def test_breakpoints_of_consecutive_steps():
     assert n_bp > 1500 and np.abs(FIX["bp_t_error"]).max() > 0.0      # (the compensation term is exercised)
 
 
+def test_adaptive_loop_bookkeeping_after_a_try():
+    """What `Engine::step`'s inner loop does with the outcome of a try (engine.cc:2138-2221): counters, the restoration of the
+    step size after a breakpoint cut it (`dtRestoreThresholdRel`, :2166-2172), the recovery from an evaluation error
+    (`dtLargest *= 0.1`, :2197-2200), the next try `min(dtLargest, dtMax)` (:2221) -- on the reference's compiled lines against
+    the oracle's `after_try`, which `step_dopri` calls after every try."""
+    L = _lib()
+    pi64 = C.POINTER(C.c_int64)
+    L.orc_leaf_after_try.argtypes = [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_double, C.c_double, pd, pd, pd, pi64]
+    rc, bp = np.ascontiguousarray(FIX["after_try_rc"]), np.ascontiguousarray(FIX["after_try_bp"])
+    dt, dtl, dtlp = (FIX[k].copy() for k in ("after_try_dt", "after_try_dt_largest", "after_try_dt_largest_prev"))
+    cnt = np.ascontiguousarray(FIX["after_try_counters"].copy())
+    L.orc_leaf_after_try(len(rc), _p(rc, C.c_int32), _p(bp, C.c_int32), 0.2, 0.02, _p(dt), _p(dtl), _p(dtlp), _p(cnt, C.c_int64))
+    assert np.array_equal(dt, FIX["after_try_dt_out"]) and np.array_equal(dtl, FIX["after_try_dt_largest_out"])
+    assert np.array_equal(dtlp, FIX["after_try_dt_largest_prev_out"]) and np.array_equal(cnt, FIX["after_try_counters_out"])
+    # every branch: restored step sizes, untouched ones, errors, rejections, the dtMax clip, the INF of fixed-step steppers
+    ok = rc == 0
+    restored = ok & (FIX["after_try_dt_largest_out"] != FIX["after_try_dt_largest"])
+    assert restored.sum() > 5 and (ok & (bp == 1) & ~restored).sum() > 5 and (rc == 1).sum() > 20 and (rc == 2).sum() > 20
+    assert (FIX["after_try_dt_out"] == 0.02).sum() > 10 and np.isinf(FIX["after_try_dt_largest"]).sum() > 10
+
+
 def test_periodic_update_and_impulse_activity_rules():
     """When the controller command / a profile force is refreshed (engine.cc:1923-1927, 1903-1907: the same expression) and when
     an impulse force is active (engine.cc:1857-1869) on the reference's compiled lines: `engine.update_due` and

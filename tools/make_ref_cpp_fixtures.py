@@ -15,7 +15,7 @@ Two tiers, labelled per array group in the .npz (`tier__<group>`), in DESIGN.md 
           the sub-step selection of Engine::step (engine.cc:2063-2089: stretch onto the breakpoint, snap to microseconds),
           the update-period arithmetic minClipped / isGcdIncluded (utilities/helpers.hxx:59-116),
           the end time of Engine::step with its Kahan compensation and the time to the next breakpoint (engine.cc:1793-1795,
-          1991-2018), the refresh rule of profile forces / the controller and the activity of impulse forces (engine.cc:1857-1869,
+          1991-2018), the bookkeeping of the adaptive loop after a try (engine.cc:2166-2172, 2197-2208, 2221), the refresh rule of profile forces / the controller and the activity of impulse forces (engine.cc:1857-1869,
           1903-1907, 1923-1927),
           the step-size controller of RungeKuttaDOPRIStepper::adjustStep (runge_kutta_dopri_stepper.cc:24-56 with
           the constants of runge_kutta_dopri_stepper.h:34-47) and the body of SimpleMotor::computeEffort
@@ -128,6 +128,21 @@ def tu_tier_a() -> str:
                  "void next_breakpoint_body(const double stepperUpdatePeriod_, const double t, const double tImpulseForceNext, "
                  "const double tEnd, double & tNext)\n{\n")
     parts.append(grab("core/src/engine/engine.cc", 1991, 2018, "double dtNextGlobal;  // dt to apply for the next stepper step", "tNext += dtNextGlobal;"))
+    parts.append("}\n")
+    # bookkeeping of the adaptive loop after a try (engine.cc:2166-2172 restore of the step size after a breakpoint, 2197-2208
+    # failure counters and error recovery, 2221 size of the next try); data holders with the member names those lines read
+    parts.append("namespace stepper\n{\n")
+    parts.append(grab(f"{CORE}/stepper/abstract_stepper.h", 15, 20, "enum class ReturnCode : uint8_t", "};"))
+    parts.append("struct StatusInfoHolder { ReturnCode returnCode; };\n}\n"
+                 "struct StepperStateHolder { double dtLargestPrev; int64_t iterFailed; };\n"
+                 "struct StepperOptsHolder { double dtRestoreThresholdRel; double dtMax; };\nstruct EngineOptsHolder { StepperOptsHolder stepper; };\n"
+                 "void restore_body(const StepperStateHolder & stepperState_, const EngineOptsHolder * engineOptions_, const double dt, double & dtLargest)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 2166, 2172, "double dtRestoreThresholdAbs =", "}"))
+    parts.append("}\nvoid failure_body(const stepper::StatusInfoHolder & status, StepperStateHolder & stepperState_, double & dtLargest, "
+                 "uint32_t & successiveIterTooLarge, uint32_t & successiveIterFailed)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 2197, 2208, "if (status.returnCode == stepper::ReturnCode::IS_ERROR)", "++stepperState_.iterFailed;"))
+    parts.append("}\nvoid next_dt_body(const EngineOptsHolder * engineOptions_, const double dtLargest, double & dt)\n{\n")
+    parts.append(grab("core/src/engine/engine.cc", 2221, 2221, "dt = std::min(dtLargest, engineOptions_->stepper.dtMax);", "dt = std::min(dtLargest, engineOptions_->stepper.dtMax);"))
     parts.append("}\n")
     # when a profile force / the controller is refreshed (engine.cc:1903-1907, 1923-1927) and when an impulse force is active
     # (engine.cc:1857-1869); the structs are data holders with the member names those lines read
@@ -324,6 +339,38 @@ int main(int argc, char ** argv)
             nbp[i] = k;
         }
         io::put(tend); io::put(terr); io::put(nbp); io::put(bps);
+    }
+    // ---- after a try of the adaptive loop.  Around the three reference bodies the driver restates the success branch's plain
+    //      assignments (engine.cc:2141-2142 counters to zero, 2157 ++iter, 2160 `if (isBreakpointReached)`, 2184 dtLargestPrev)
+    {
+        const int64_t n = io::geti();
+        const auto relmax = io::get<double>(2);
+        const double rel = relmax[0], dtMax = relmax[1];
+        const auto rc = io::get<int32_t>(n), bp = io::get<int32_t>(n);
+        auto dt = io::get<double>(n), dtl = io::get<double>(n), dtlp = io::get<double>(n);
+        auto cnt = io::get<int64_t>(n * 4);
+        const EngineOptsHolder eo{{rel, dtMax}};
+        for (int64_t i = 0; i < n; ++i)
+        {
+            StepperStateHolder st{dtlp[i], cnt[4 * i + 3]};
+            uint32_t tooLarge = static_cast<uint32_t>(cnt[4 * i]), failed = static_cast<uint32_t>(cnt[4 * i + 1]);
+            if (rc[i] == 0)
+            {
+                tooLarge = 0; failed = 0;
+                ++cnt[4 * i + 2];
+                if (bp[i]) restore_body(st, &eo, dt[i], dtl[i]);
+                st.dtLargestPrev = dtl[i];
+            }
+            else
+            {
+                const stepper::StatusInfoHolder status{static_cast<stepper::ReturnCode>(rc[i])};
+                failure_body(status, st, dtl[i], tooLarge, failed);
+            }
+            next_dt_body(&eo, dtl[i], dt[i]);
+            dtlp[i] = st.dtLargestPrev;
+            cnt[4 * i] = tooLarge; cnt[4 * i + 1] = failed; cnt[4 * i + 3] = st.iterFailed;
+        }
+        io::put(dt); io::put(dtl); io::put(dtlp); io::put(cnt);
     }
     // ---- refresh of profile forces / the controller at time t, activity of an impulse force carried over a time sequence
     {
@@ -671,6 +718,22 @@ def main(out_path: str = OUT) -> None:
     for i, b in enumerate(bk):
         bk_imp[i, :len(b[3])] = b[3]
     blob.a(bk_imp, np.float64)
+    # after a try: (return code, breakpoint reached, dt tried, dtLargest the stepper returned, dtLargestPrev, counters)
+    nat = 300
+    at_rc = rg.choice([0, 0, 0, 1, 2], nat).astype(np.int32)
+    at_bp = (rg.random(nat) < 0.5).astype(np.int32)
+    at_dt = 10.0 ** rg.uniform(-6, -2, nat)
+    at_dtl = at_dt * 10.0 ** rg.uniform(-0.5, 1.5, nat)
+    at_dtl[::9] = np.inf                                               # (fixed-step steppers return INF)
+    at_dtlp = at_dtl * 10.0 ** rg.uniform(-0.3, 1.7, nat)
+    at_dtlp[::9] = 10.0 ** rg.uniform(-4, -1, len(at_dtlp[::9]))
+    at_cnt = np.stack([rg.integers(0, 3, nat), rg.integers(0, 5, nat), rg.integers(0, 1000, nat), rg.integers(0, 50, nat)], axis=1).astype(np.int64)
+    blob.i(nat)
+    blob.a(np.array([0.2, 0.02]), np.float64)     # dtRestoreThresholdRel, dtMax (engine.h defaults)
+    blob.a(at_rc, np.int32); blob.a(at_bp, np.int32)
+    for arr in (at_dt, at_dtl, at_dtlp):
+        blob.a(arr, np.float64)
+    blob.a(at_cnt, np.int64)
     # refresh rule: times on, just before, just after and between multiples of the period
     up_p = np.repeat(np.array([1e-3, 5e-3, 1e-2, 1 / 3e2, 7e-4, 2.5e-3]), 60)
     kk = np.tile(np.repeat(np.arange(1, 13), 5), 6).astype(np.float64)
@@ -745,13 +808,16 @@ def main(out_path: str = OUT) -> None:
     out.update(bp_period=np.array([b[0] for b in bk]), bp_step=np.array([b[1] for b in bk]), bp_nsteps=np.array([b[2] for b in bk], dtype=np.int32),
                bp_impulse=bk_imp, bp_t_end=rd.take(np.float64, len(bk), 64), bp_t_error=rd.take(np.float64, len(bk), 64),
                bp_count=rd.take(np.int32, len(bk)), bp_times=rd.take(np.float64, len(bk), 512))
+    out.update(after_try_rc=at_rc, after_try_bp=at_bp, after_try_dt=at_dt, after_try_dt_largest=at_dtl, after_try_dt_largest_prev=at_dtlp,
+               after_try_counters=at_cnt, after_try_dt_out=rd.take(np.float64, nat), after_try_dt_largest_out=rd.take(np.float64, nat),
+               after_try_dt_largest_prev_out=rd.take(np.float64, nat), after_try_counters_out=rd.take(np.int64, nat, 4))
     out.update(update_period=up_p, update_t=up_t, update_force=rd.take(np.int32, len(up_p)), update_controller=rd.take(np.int32, len(up_p)))
     out.update(impulse_t=imp_t, impulse_dt=imp_dt, impulse_times=imp_ts, impulse_active=rd.take(np.int32, len(imp_t), len(imp_ts)),
                impulse_changed=rd.take(np.int32, len(imp_t), len(imp_ts)))
     out.update(period_a=gp_a, period_b=gp_b, period_included=rd.take(np.int32, len(gp_a)), period_min=rd.take(np.float64, len(gp_a)))
     out.update(motor_group=np.array(MOTOR_GROUP), motor_params=mp, motor_u=rd.take(np.float64, nm), motor_u_transmission=rd.take(np.float64, nm))
     rd.done()
-    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period", "bp", "update", "impulse"):
+    for group in ("pcg", "uniform", "normal", "seedseq", "zig", "hash", "xxhash", "murmur3", "dopri", "motor", "substep", "interval", "period", "bp", "update", "impulse", "after"):
         out[f"tier__{group}"] = np.array("A")
 
     # ============================================================ tier B
